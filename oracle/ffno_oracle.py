@@ -1,0 +1,205 @@
+"""CPU oracle for the F-FNO hot path (TEST INFRASTRUCTURE -- not a product path).
+
+This file is a *restatement*, in plain CPU torch ops, of the algorithm the
+reference implements in
+
+  fourierflow/modules/factorized_fno/grid_2d.py:51-99   (SpectralConv2d.forward_fourier)
+  fourierflow/modules/factorized_fno/grid_2d.py:42-49   (SpectralConv2d.forward)
+  fourierflow/modules/factorized_fno/grid_2d.py:154-177 (FNOFactorized2DBlock.forward)
+  fourierflow/modules/feedforward.py:6-24               (FeedForward)
+  fourierflow/modules/linear.py:41-52                   (WNLinear = nn.Linear + weight_norm dim=0)
+  fourierflow/modules/loss.py:33-46                     (LpLoss.rel)
+
+It is written functionally over a reference-compatible ``state_dict`` (same key
+names / shapes as the reference module) so the golden
+vectors under tests/golden/ -- produced by importing the real reference in the
+build container with tools/make_golden.py -- pin it (tests/test_oracle_golden.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  The shipped package (fourierflow_amd/) never does.
+
+Parity status: PINNED against golden vectors generated from the imported
+reference (tests/golden/*.npz, generator tools/make_golden.py).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------
+# WNLinear  (linear.py:41-52; torch.nn.utils.weight_norm, dim=0)
+# --------------------------------------------------------------------------
+def wn_weight(g: Tensor, v: Tensor) -> Tensor:
+    """W = g * v / ||v||_2 taken over every dim but 0 (one norm per output row)."""
+    return v * (g / v.norm(2, dim=1, keepdim=True))
+
+
+def linear_from_sd(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
+    """Apply the (possibly weight-normed) linear stored under ``prefix``."""
+    if prefix + "weight_g" in sd:
+        w = wn_weight(sd[prefix + "weight_g"], sd[prefix + "weight_v"])
+    else:
+        w = sd[prefix + "weight"]
+    return F.linear(x, w, sd.get(prefix + "bias"))
+
+
+# --------------------------------------------------------------------------
+# FeedForward  (feedforward.py:6-24)
+# --------------------------------------------------------------------------
+def feedforward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int = 2,
+                layer_norm: bool = False) -> Tensor:
+    """n_layers x [linear -> (dropout p=0) -> ReLU except last -> LayerNorm iff last & layer_norm]."""
+    for i in range(n_layers):
+        x = linear_from_sd(sd, f"{prefix}layers.{i}.0.", x)
+        if i < n_layers - 1:
+            x = torch.relu(x)
+        elif layer_norm:
+            x = F.layer_norm(x, x.shape[-1:], sd[f"{prefix}layers.{i}.3.weight"],
+                             sd[f"{prefix}layers.{i}.3.bias"])
+    return x
+
+
+# --------------------------------------------------------------------------
+# SpectralConv2d.forward_fourier  (grid_2d.py:51-99)
+# --------------------------------------------------------------------------
+def spectral_branch(x_cf: Tensor, w: Optional[Tensor], modes: int, dim: int, mode: str) -> Tensor:
+    """One axis of the factorized spectral conv on a channels-first tensor [B, I, M, N].
+
+    rfft(norm='ortho') along ``dim`` -> keep ``modes`` lowest bins -> per-mode
+    complex channel mix with w[I, O, modes, 2] -> zero-padded irfft(norm='ortho').
+    """
+    L = x_cf.shape[dim]
+    spec = torch.fft.rfft(x_cf, dim=dim, norm="ortho")
+    kept = spec.narrow(dim, 0, modes)
+    if mode == "full":
+        wc = torch.view_as_complex(w.contiguous())
+        eq = "bixy,ioy->boxy" if dim in (-1, 3) else "bixy,iox->boxy"
+        kept = torch.einsum(eq, kept, wc)
+    elif mode != "low-pass":
+        raise ValueError(mode)
+    shape = list(kept.shape)
+    shape[dim] = L // 2 + 1
+    padded = kept.new_zeros(shape)
+    padded.narrow(dim, 0, modes).copy_(kept)
+    return torch.fft.irfft(padded, n=L, dim=dim, norm="ortho")
+
+
+def forward_fourier(x: Tensor, w_y: Optional[Tensor], w_x: Optional[Tensor], modes: int,
+                    mode: str = "full") -> Tensor:
+    """x [B, M, N, I] channels-last -> [B, M, N, O].
+
+    ``w_y`` is fourier_weight[0] (mixes along the LAST spatial axis, grid_2d.py:65-68),
+    ``w_x`` is fourier_weight[1] (first spatial axis, grid_2d.py:83-86).
+    """
+    x_cf = x.permute(0, 3, 1, 2)
+    xy = spectral_branch(x_cf, w_y, modes, -1, mode)
+    xx = spectral_branch(x_cf, w_x, modes, -2, mode)
+    return (xx + xy).permute(0, 2, 3, 1)
+
+
+# --------------------------------------------------------------------------
+# FNOFactorized2DBlock.forward  (grid_2d.py:154-177)
+# --------------------------------------------------------------------------
+def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
+                 use_fork: bool = False, mode: str = "full", n_ff_layers: int = 2,
+                 layer_norm: bool = False, return_intermediates: bool = False):
+    """Forward of the whole block over a reference-layout state_dict.
+
+    Returns {'forecast', 'forecast_list'} like the reference; with
+    ``return_intermediates`` also the per-layer inputs for test diagnostics.
+    """
+    def head(t: Tensor) -> Tensor:
+        return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", t))
+
+    x = linear_from_sd(sd, "in_proj.", x)
+    forecast = 0
+    forecast_list: List[Tensor] = []
+    inter = [x]
+    b = None
+    for i in range(n_layers):
+        pre = f"spectral_layers.{i}."
+        s = x
+        if mode != "no-fourier":
+            s = forward_fourier(x, sd.get(pre + "fourier_weight.0"), sd.get(pre + "fourier_weight.1"),
+                                modes, mode)
+        b = feedforward(sd, pre + "backcast_ff.", s, n_ff_layers, layer_norm)
+        if use_fork:
+            f_out = head(feedforward(sd, pre + "forecast_ff.", s, n_ff_layers, layer_norm))
+            forecast = forecast + f_out
+            forecast_list.append(f_out)
+        x = x + b
+        inter.append(x)
+    if not use_fork:
+        forecast = head(b)
+    out = {"forecast": forecast, "forecast_list": forecast_list}
+    if return_intermediates:
+        out["layer_inputs"] = inter
+    return out
+
+
+# --------------------------------------------------------------------------
+# LpLoss.rel  (loss.py:33-46): mean_b ||x_b - y_b||_2 / ||y_b||_2
+# --------------------------------------------------------------------------
+def lp_rel_loss(pred: Tensor, target: Tensor) -> Tensor:
+    n = pred.shape[0]
+    d = (pred.reshape(n, -1) - target.reshape(n, -1)).norm(2, dim=1)
+    return (d / target.reshape(n, -1).norm(2, dim=1)).mean()
+
+
+# --------------------------------------------------------------------------
+# Cosine-with-warmup multiplier  (schedulers/cosine_with_warmup.py:6-17)
+# --------------------------------------------------------------------------
+def cosine_warmup_factor(step: int, num_warmup_steps: int, num_training_steps: int,
+                         num_cycles: float = 0.5) -> float:
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+# --------------------------------------------------------------------------
+# Reference-compatible random init (for benches / tests that do not load golden weights).
+# Shapes & init rules: grid_2d.py:103-152, linear.py:41-52, SURVEY.md a3/a5.
+# --------------------------------------------------------------------------
+def init_block_state_dict(*, modes: int, width: int, input_dim: int, n_layers: int,
+                          share_weight: bool, factor: int, ff_weight_norm: bool, gain: float = 1.0,
+                          seed: int = 0, dtype=torch.float32) -> Dict[str, Tensor]:
+    gen = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+
+    def add_linear(prefix: str, fan_in: int, fan_out: int):
+        bound = 1.0 / math.sqrt(fan_in)  # kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(fan_in), +)
+        w = (torch.rand(fan_out, fan_in, generator=gen, dtype=torch.float64) * 2 - 1) * bound
+        bias = (torch.rand(fan_out, generator=gen, dtype=torch.float64) * 2 - 1) * bound
+        if ff_weight_norm:
+            sd[prefix + "weight_g"] = w.norm(2, dim=1, keepdim=True).to(dtype)
+            sd[prefix + "weight_v"] = w.to(dtype)
+        else:
+            sd[prefix + "weight"] = w.to(dtype)
+        sd[prefix + "bias"] = bias.to(dtype)
+
+    def fourier_pair():
+        # xavier_normal_ on [I, O, K, 2]: fan_in = O*K*2, fan_out = I*K*2
+        std = gain * math.sqrt(2.0 / (2 * width * modes * 2))
+        return [(torch.randn(width, width, modes, 2, generator=gen, dtype=torch.float64) * std).to(dtype)
+                for _ in range(2)]
+
+    add_linear("in_proj.", input_dim, width)
+    shared = fourier_pair() if share_weight else None
+    if shared is not None:
+        sd["fourier_weight.0"], sd["fourier_weight.1"] = shared
+    for i in range(n_layers):
+        pre = f"spectral_layers.{i}."
+        fw = shared if shared is not None else fourier_pair()
+        sd[pre + "fourier_weight.0"], sd[pre + "fourier_weight.1"] = fw
+        add_linear(pre + "backcast_ff.layers.0.0.", width, width * factor)
+        add_linear(pre + "backcast_ff.layers.1.0.", width * factor, width)
+    add_linear("out.0.", width, 128)
+    add_linear("out.1.", 128, 1)
+    return sd

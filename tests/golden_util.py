@@ -1,0 +1,172 @@
+"""Deterministic inputs shared by tools/make_golden.py (which feeds them to the imported
+reference) and the tests (which feed them to the oracle / the HIP path).
+
+Weights and inputs are a pure function of (kwargs, seed) through numpy's
+RandomState (MT19937, stable across numpy versions), so the committed fixtures
+only need to hold the reference's OUTPUTS (forecast, loss, gradients) -- small files.
+State-dict key layout = the reference's: shared tensors
+appear under every duplicate key the reference registers.
+"""
+from __future__ import annotations
+
+import ast
+import math
+import os
+from typing import Dict
+
+import numpy as np
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+BLOCK_DEFAULTS = dict(input_dim=12, dropout=0.0, in_dropout=0.0, n_layers=4, share_weight=False,
+                      share_fork=False, factor=2, ff_weight_norm=False, n_ff_layers=2, gain=1,
+                      layer_norm=False, use_fork=False, mode="full")
+
+
+def full_kwargs(kw: dict) -> dict:
+    out = dict(BLOCK_DEFAULTS)
+    out.update(kw)
+    return out
+
+
+def _linear(rs, sd, prefix, fan_in, fan_out, wnorm):
+    bound = 1.0 / math.sqrt(fan_in)
+    w = rs.uniform(-bound, bound, size=(fan_out, fan_in)).astype(np.float32)
+    b = rs.uniform(-bound, bound, size=(fan_out,)).astype(np.float32)
+    if wnorm:
+        # g deliberately != ||v|| so the weight-norm arithmetic is actually exercised
+        g = (np.linalg.norm(w, axis=1, keepdims=True) * rs.uniform(0.7, 1.3, size=(fan_out, 1))).astype(np.float32)
+        sd[prefix + "weight_g"] = g
+        sd[prefix + "weight_v"] = w
+    else:
+        sd[prefix + "weight"] = w
+    sd[prefix + "bias"] = b
+
+
+def _ff(rs, width, factor, wnorm, n_ff_layers, layer_norm):
+    sd: Dict[str, np.ndarray] = {}
+    for i in range(n_ff_layers):
+        fin = width if i == 0 else width * factor
+        fout = width if i == n_ff_layers - 1 else width * factor
+        _linear(rs, sd, f"layers.{i}.0.", fin, fout, wnorm)
+        if layer_norm and i == n_ff_layers - 1:
+            sd[f"layers.{i}.3.weight"] = rs.uniform(0.5, 1.5, size=(fout,)).astype(np.float32)
+            sd[f"layers.{i}.3.bias"] = rs.uniform(-0.2, 0.2, size=(fout,)).astype(np.float32)
+    return sd
+
+
+def make_block_state_dict(kw: dict, seed: int) -> Dict[str, np.ndarray]:
+    """Reference-layout state_dict (incl. duplicated shared keys) for FNOFactorized2DBlock(**kw)."""
+    kw = full_kwargs(kw)
+    rs = np.random.RandomState(seed)
+    C, K = kw["width"], kw["modes"]
+    wn, f, nff, ln = kw["ff_weight_norm"], kw["factor"], kw["n_ff_layers"], kw["layer_norm"]
+    sd: Dict[str, np.ndarray] = {}
+    _linear(rs, sd, "in_proj.", kw["input_dim"], C, wn)
+
+    def fourier_pair():
+        std = kw["gain"] * math.sqrt(2.0 / (2 * C * K * 2))
+        return [(rs.standard_normal((C, C, K, 2)) * std).astype(np.float32) for _ in range(2)]
+
+    shared_fc = shared_bc = None
+    if kw["share_fork"]:
+        if kw["use_fork"]:
+            shared_fc = _ff(rs, C, f, wn, nff, ln)
+            for k, v in shared_fc.items():
+                sd["forecast_ff." + k] = v
+        shared_bc = _ff(rs, C, f, wn, nff, ln)
+        for k, v in shared_bc.items():
+            sd["backcast_ff." + k] = v
+    shared_fw = None
+    if kw["share_weight"]:
+        shared_fw = fourier_pair()
+        sd["fourier_weight.0"], sd["fourier_weight.1"] = shared_fw
+    for i in range(kw["n_layers"]):
+        pre = f"spectral_layers.{i}."
+        fw = shared_fw if shared_fw is not None else fourier_pair()
+        sd[pre + "fourier_weight.0"], sd[pre + "fourier_weight.1"] = fw
+        if kw["use_fork"]:
+            fc = shared_fc if shared_fc is not None else _ff(rs, C, f, wn, nff, ln)
+            for k, v in fc.items():
+                sd[pre + "forecast_ff." + k] = v
+        bc = shared_bc if shared_bc is not None else _ff(rs, C, f, wn, nff, ln)
+        for k, v in bc.items():
+            sd[pre + "backcast_ff." + k] = v
+    _linear(rs, sd, "out.0.", C, 128, wn)
+    _linear(rs, sd, "out.1.", 128, 1, wn)
+    return sd
+
+
+def make_block_io(kw: dict, seed: int, B: int, M: int, N: int):
+    rs = np.random.RandomState(seed + 100003)
+    x = rs.standard_normal((B, M, N, full_kwargs(kw)["input_dim"])).astype(np.float32)
+    target = rs.standard_normal((B, M, N, 1)).astype(np.float32)
+    return x, target
+
+
+def make_spectral_io(seed: int, B: int, M: int, N: int, C: int, K: int):
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    std = math.sqrt(2.0 / (2 * C * K * 2))
+    w0 = (rs.standard_normal((C, C, K, 2)) * std).astype(np.float32)
+    w1 = (rs.standard_normal((C, C, K, 2)) * std).astype(np.float32)
+    gy = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    return x, w0, w1, gy
+
+
+# ---- compact storage of big gradient tensors -------------------------------------------
+FULL_LIMIT = 8192
+N_SAMPLES = 512
+
+
+def sample_index(n: int) -> np.ndarray:
+    return np.random.RandomState(12345).randint(0, n, size=N_SAMPLES)
+
+
+def pack_array(name: str, a: np.ndarray, out: dict):
+    a = np.asarray(a)
+    if a.size <= FULL_LIMIT:
+        out[name] = a
+    else:
+        flat = a.reshape(-1).astype(np.float64)
+        out[name + "#shape"] = np.array(a.shape)
+        out[name + "#l2"] = np.array(np.sqrt((flat ** 2).sum()))
+        out[name + "#sum"] = np.array(flat.sum())
+        out[name + "#samples"] = a.reshape(-1)[sample_index(a.size)]
+
+
+def packed_names(npz) -> list:
+    names = set()
+    for k in npz.files:
+        names.add(k.split("#")[0])
+    return sorted(names)
+
+
+def compare_packed(npz, name: str, got: np.ndarray, rtol: float):
+    """Relative-L2 style comparison of ``got`` against a (possibly compacted) fixture entry.
+    Returns the worst relative error found."""
+    got = np.asarray(got, dtype=np.float64)
+    if name in npz.files:
+        ref = npz[name].astype(np.float64)
+        assert ref.shape == got.shape, (name, ref.shape, got.shape)
+        den = max(np.linalg.norm(ref), 1e-30)
+        return float(np.linalg.norm(got - ref) / den)
+    shape = tuple(npz[name + "#shape"])
+    assert shape == got.shape, (name, shape, got.shape)
+    l2 = float(npz[name + "#l2"])
+    flat = got.reshape(-1)
+    idx = sample_index(flat.size)
+    ref_s = npz[name + "#samples"].astype(np.float64)
+    scale = l2 / math.sqrt(flat.size)  # rms of the reference tensor
+    e_samples = float(np.abs(flat[idx] - ref_s).max() / max(scale, 1e-30)) / 8.0  # max-vs-rms slack
+    e_l2 = abs(float(np.linalg.norm(flat)) - l2) / max(l2, 1e-30)
+    e_sum = abs(float(flat.sum()) - float(npz[name + "#sum"])) / max(l2 * math.sqrt(flat.size), 1e-30)
+    return max(e_samples, e_l2, e_sum)
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+
+
+def golden_kwargs(npz) -> dict:
+    return ast.literal_eval(str(npz["kwargs"]))
