@@ -1,0 +1,74 @@
+"""ctypes signatures of include/ffno.h (single source of truth for the Python host AND the tests).
+
+``bind(cdll)`` attaches argtypes/restype for every exported entry point and returns the list of
+symbol names; a missing symbol raises AttributeError (the "exports every symbol" check).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+SZ = C.c_size_t
+
+
+class WnDesc(C.Structure):
+    """Mirror of ``ffno_wn_desc`` (include/ffno.h)."""
+    _fields_ = [("g", P), ("v", P), ("w", P), ("dw", P), ("dg", P), ("dv", P),
+                ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
+SIGNATURES = {
+    "ffno_build_target": (C.c_char_p, []),
+    "ffno_abi_version": (I, []),
+    "ffno_twiddle_fill_host": (I, [P, I]),
+    "ffno_dft_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "ffno_fw_pack": (I, [P, P, P, I, I, P]),
+    "ffno_mode_mix": (I, [P, P, P, I, I, I, I, P]),
+    "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, P]),
+    "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
+    "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),
+    "ffno_spectral2d_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "ffno_spectral2d_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "ffno_ff_mask_words": (SZ, [I, I]),
+    "ffno_ff_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ff_bwd_data": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ff_wgrad_partial_floats": (SZ, [I, I, I]),
+    "ffno_ff_bwd_weights_partial": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ffno_ff_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ffno_weightnorm_fwd": (I, [P, I, I, P]),
+    "ffno_weightnorm_bwd": (I, [P, I, I, P]),
+    "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P]),
+    "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "ffno_head_fold": (I, [P, P, P, P, P, I, I, P]),
+    "ffno_head_fwd": (I, [P, P, P, I, I, I, P]),
+    "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_lploss_fwd_bwd": (I, [P, P, P, P, P, I, I, F, P]),
+    "ffno_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, I, F, P]),
+    "ffno_axpy": (I, [P, P, F, SZ, P]),
+}
+
+
+def bind(lib: C.CDLL):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return list(SIGNATURES)
+
+
+ERRORS = {-1: "FFNO_EINVAL (null pointer / bad size)", -2: "FFNO_EUNSUPPORTED (shape outside the compiled set)",
+          -3: "FFNO_EMODES (modes > L/2+1)"}
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc == -3:
+        raise ValueError(f"{what}: {ERRORS[rc]}")
+    if rc in (-1, -2):
+        raise ValueError(f"{what}: {ERRORS[rc]}")
+    raise RuntimeError(f"{what}: HIP launch failed with hipError_t {rc}")

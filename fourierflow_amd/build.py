@@ -1,0 +1,67 @@
+"""Build the gfx950 C-ABI library (hipcc) in-tree: fourierflow_amd/lib/libffno_hip.so.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the resulting
+.so is git-ignored but travels to the GPU box with the working tree.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libffno_hip.so")
+SOURCES = ["spectral.hip", "ff.hip", "pointwise.hip", "block.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build the gfx950 F-FNO kernels)")
+
+
+def source_files():
+    return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _stamp() -> str:
+    h = hashlib.sha256()
+    for p in sorted(source_files() + [os.path.join(CSRC, "ffno_device.h"), os.path.join(ROOT, "include", "ffno.h")]):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp_file = LIB + ".stamp"
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    objs = []
+    for src in source_files():
+        obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src,
+               "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", obj, "-Wno-unused-result", *extra_flags]
+        if verbose:
+            print("[ffno build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+    if verbose:
+        print("[ffno build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,477 @@
+// Pointwise feed-forward of the F-FNO layer for gfx950 (fp32, v_mfma_f32_32x32x2_f32).
+//
+// Replaces FeedForward.forward (reference fourierflow/modules/feedforward.py:13-19, n_layers = 2,
+// dropout 0, no LayerNorm) + the residual add of FNOFactorized2DBlock.forward (grid_2d.py:169),
+// and their autograd:
+//     h = relu(s W1^T + b1)        out = resid + h W2^T + b2
+//
+// Formulation: pixels are the MFMA *column* index (lane & 31), so both GEMMs are evaluated
+// transposed -- h^T[hid][px] = W1[hid][:] . s^T[:][px] and out^T[c][px] = W2[c][:] . h^T[:][px].
+// The D-fragment of the first GEMM (lane = pixel, registers = hidden rows) is then exactly a valid
+// B-fragment of the second one (k index = hidden row), so the [P][H] hidden activations never touch
+// LDS or HBM between the two GEMMs; the k-ordering of the second GEMM simply follows the D layout:
+// accumulator register r of half h holds hidden row (r&3) + 8(r>>2) + 4h, and the W2 A-operand is
+// fetched with the same permutation (4 consecutive hidden rows = one 16-B LDS read).
+// The weights (W1 [H][C], W2 [C][H]; 128 KiB at C=64,H=256) live in LDS for the lifetime of a
+// persistent workgroup; rows are padded by 4 floats so the 16-B A-operand reads are conflict-free.
+#include "ffno_device.h"
+#include "ffno.h"
+
+namespace ffno {
+
+template <int C, int H>
+struct FFSmem {
+    static constexpr int LD1 = C + 4;  // W1s row stride (floats)
+    static constexpr int LD2 = H + 4;  // W2s row stride
+    static constexpr int W1_OFF = 0;
+    static constexpr int W2_OFF = H * LD1;
+    static constexpr int B1_OFF = W2_OFF + C * LD2;
+    static constexpr int B2_OFF = B1_OFF + H;
+    static constexpr int FLOATS = B2_OFF + C;
+};
+
+template <int C, int H>
+__device__ __forceinline__ void ff_load_weights(float* sm, const float* __restrict__ W1,
+                                                const float* __restrict__ W2, const float* b1, const float* b2) {
+    using S = FFSmem<C, H>;
+    for (int e = threadIdx.x * 4; e < H * C; e += blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(W1 + e);
+        *reinterpret_cast<float4*>(sm + S::W1_OFF + (e / C) * S::LD1 + (e % C)) = v;
+    }
+    for (int e = threadIdx.x * 4; e < H * C; e += blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(W2 + e);
+        *reinterpret_cast<float4*>(sm + S::W2_OFF + (e / H) * S::LD2 + (e % H)) = v;
+    }
+    if (b1)
+        for (int e = threadIdx.x; e < H; e += blockDim.x) sm[S::B1_OFF + e] = b1[e];
+    if (b2)
+        for (int e = threadIdx.x; e < C; e += blockDim.x) sm[S::B2_OFF + e] = b2[e];
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+template <int C, int H, int NW>
+__global__ __launch_bounds__(NW * 64) void ff_fwd_kernel(const float* __restrict__ s, const float* resid,
+                                                         const float* __restrict__ W1,
+                                                         const float* __restrict__ b1,
+                                                         const float* __restrict__ W2,
+                                                         const float* __restrict__ b2, float* out, float* h,
+                                                         uint32_t* mask, int P) {
+    using S = FFSmem<C, H>;
+    constexpr int KS = C / 2;    // k-steps of GEMM1 (two channels per MFMA)
+    constexpr int CTO = C / 32;  // output row tiles of GEMM2
+    constexpr int NQ = H / 64;   // hidden chunks of 64 (two 32-row tiles each)
+    __shared__ __attribute__((aligned(16))) float sm[S::FLOATS];
+    ff_load_weights<C, H>(sm, W1, W2, b1, b2);
+    __syncthreads();
+    const float* W1s = sm + S::W1_OFF;
+    const float* W2s = sm + S::W2_OFF;
+    const float* b1s = sm + S::B1_OFF;
+    const float* b2s = sm + S::B2_OFF;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
+        const long px = (long)tile * 32 + j;
+        const bool valid = px < P;
+        // B operand of GEMM1: this lane's pixel, channels [KS*half, KS*half + KS)
+        float sB[KS];
+        FFNO_UNROLL
+        for (int u = 0; u < KS / 4; ++u) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) v = *reinterpret_cast<const float4*>(s + px * C + KS * half + 4 * u);
+            sB[4 * u + 0] = v.x;
+            sB[4 * u + 1] = v.y;
+            sB[4 * u + 2] = v.z;
+            sB[4 * u + 3] = v.w;
+        }
+        f32x16 o[CTO];
+        FFNO_UNROLL
+        for (int to = 0; to < CTO; ++to) o[to] = zero16();
+        uint32_t mbits[NQ];
+
+        FFNO_UNROLL
+        for (int q = 0; q < NQ; ++q) {
+            f32x16 hT[2];
+            FFNO_UNROLL
+            for (int T = 0; T < 2; ++T) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) hT[T][r] = b1s[64 * q + 32 * T + drow(r, half)];
+            }
+            FFNO_UNROLL
+            for (int u = 0; u < KS / 4; ++u) {
+                FFNO_UNROLL
+                for (int T = 0; T < 2; ++T) {
+                    const float4 a =
+                        *reinterpret_cast<const float4*>(W1s + (64 * q + 32 * T + j) * S::LD1 + KS * half + 4 * u);
+                    hT[T] = mfma32(a.x, sB[4 * u + 0], hT[T]);
+                    hT[T] = mfma32(a.y, sB[4 * u + 1], hT[T]);
+                    hT[T] = mfma32(a.z, sB[4 * u + 2], hT[T]);
+                    hT[T] = mfma32(a.w, sB[4 * u + 3], hT[T]);
+                }
+            }
+            uint32_t bits = 0;
+            FFNO_UNROLL
+            for (int T = 0; T < 2; ++T) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const bool pos = hT[T][r] > 0.f;
+                    hT[T][r] = pos ? hT[T][r] : 0.f;
+                    bits |= (pos ? 1u : 0u) << (16 * T + r);
+                }
+            }
+            mbits[q] = bits;
+            if (h && valid) {
+                FFNO_UNROLL
+                for (int T = 0; T < 2; ++T) {
+                    FFNO_UNROLL
+                    for (int g = 0; g < 4; ++g) {
+                        *reinterpret_cast<float4*>(h + px * H + 64 * q + 32 * T + 8 * g + 4 * half) =
+                            make_float4(hT[T][4 * g], hT[T][4 * g + 1], hT[T][4 * g + 2], hT[T][4 * g + 3]);
+                    }
+                }
+            }
+            // GEMM2 partial over this hidden chunk, k order = D-fragment order of hT
+            FFNO_UNROLL
+            for (int T = 0; T < 2; ++T) {
+                FFNO_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    FFNO_UNROLL
+                    for (int to = 0; to < CTO; ++to) {
+                        const float4 a = *reinterpret_cast<const float4*>(W2s + (32 * to + j) * S::LD2 + 64 * q +
+                                                                           32 * T + 8 * g + 4 * half);
+                        o[to] = mfma32(a.x, hT[T][4 * g + 0], o[to]);
+                        o[to] = mfma32(a.y, hT[T][4 * g + 1], o[to]);
+                        o[to] = mfma32(a.z, hT[T][4 * g + 2], o[to]);
+                        o[to] = mfma32(a.w, hT[T][4 * g + 3], o[to]);
+                    }
+                }
+            }
+        }
+        if (mask) {
+            uint32_t* mp = mask + ((long)tile * 64 + lane) * NQ;
+            FFNO_UNROLL
+            for (int q = 0; q < NQ; ++q) mp[q] = mbits[q];
+        }
+        if (valid) {
+            FFNO_UNROLL
+            for (int to = 0; to < CTO; ++to) {
+                FFNO_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * to + 8 * g + 4 * half;
+                    float4 v = make_float4(o[to][4 * g] + b2s[c0], o[to][4 * g + 1] + b2s[c0 + 1],
+                                           o[to][4 * g + 2] + b2s[c0 + 2], o[to][4 * g + 3] + b2s[c0 + 3]);
+                    if (resid) {
+                        const float4 rv = *reinterpret_cast<const float4*>(resid + px * C + c0);
+                        v.x += rv.x;
+                        v.y += rv.y;
+                        v.z += rv.z;
+                        v.w += rv.w;
+                    }
+                    *reinterpret_cast<float4*>(out + px * C + c0) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- backward, data path ----------------------------------------------------------------------------
+//   dh^T[hid][px] = relu'(.) * sum_c W2[c][hid] db[px][c]     (A = W2 read column-wise, B = db fragment)
+//   ds^T[c][px]   = sum_hid W1[hid][c] dh^T[hid][px]           (chained from the dh D-fragment)
+template <int C, int H, int NW>
+__global__ __launch_bounds__(NW * 64) void ff_bwd_data_kernel(const float* __restrict__ db,
+                                                              const uint32_t* __restrict__ mask,
+                                                              const float* __restrict__ W1,
+                                                              const float* __restrict__ W2, float* dh, float* ds,
+                                                              int P) {
+    using S = FFSmem<C, H>;
+    constexpr int KS = C / 2;
+    constexpr int CTO = C / 32;
+    constexpr int NQ = H / 64;
+    __shared__ __attribute__((aligned(16))) float sm[S::FLOATS];
+    ff_load_weights<C, H>(sm, W1, W2, nullptr, nullptr);
+    __syncthreads();
+    const float* W1s = sm + S::W1_OFF;
+    const float* W2s = sm + S::W2_OFF;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+
+    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
+        const long px = (long)tile * 32 + j;
+        const bool valid = px < P;
+        float dB[KS];
+        FFNO_UNROLL
+        for (int u = 0; u < KS / 4; ++u) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) v = *reinterpret_cast<const float4*>(db + px * C + KS * half + 4 * u);
+            dB[4 * u + 0] = v.x;
+            dB[4 * u + 1] = v.y;
+            dB[4 * u + 2] = v.z;
+            dB[4 * u + 3] = v.w;
+        }
+        uint32_t mbits[NQ];
+        {
+            const uint32_t* mp = mask + ((long)tile * 64 + lane) * NQ;
+            FFNO_UNROLL
+            for (int q = 0; q < NQ; ++q) mbits[q] = mp[q];
+        }
+        f32x16 dS[CTO];
+        FFNO_UNROLL
+        for (int to = 0; to < CTO; ++to) dS[to] = zero16();
+
+        FFNO_UNROLL
+        for (int q = 0; q < NQ; ++q) {
+            FFNO_UNROLL
+            for (int T = 0; T < 2; ++T) {
+                f32x16 d = zero16();
+#ifndef FFNO_EMU
+#pragma unroll 8
+#endif
+                for (int t = 0; t < KS; ++t) {
+                    const float a = W2s[(KS * half + t) * S::LD2 + 64 * q + 32 * T + j];
+                    d = mfma32(a, dB[t], d);
+                }
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) d[r] = ((mbits[q] >> (16 * T + r)) & 1u) ? d[r] : 0.f;
+                if (dh && valid) {
+                    FFNO_UNROLL
+                    for (int g = 0; g < 4; ++g) {
+                        *reinterpret_cast<float4*>(dh + px * H + 64 * q + 32 * T + 8 * g + 4 * half) =
+                            make_float4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]);
+                    }
+                }
+                FFNO_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    FFNO_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        const int hid = 64 * q + 32 * T + 8 * g + 4 * half + e;
+                        FFNO_UNROLL
+                        for (int to = 0; to < CTO; ++to) {
+                            const float a = W1s[hid * S::LD1 + 32 * to + j];
+                            dS[to] = mfma32(a, d[4 * g + e], dS[to]);
+                        }
+                    }
+                }
+            }
+        }
+        if (valid) {
+            FFNO_UNROLL
+            for (int to = 0; to < CTO; ++to) {
+                FFNO_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = 32 * to + 8 * g + 4 * half;
+                    *reinterpret_cast<float4*>(ds + px * C + c0) =
+                        make_float4(dS[to][4 * g], dS[to][4 * g + 1], dS[to][4 * g + 2], dS[to][4 * g + 3]);
+                }
+            }
+        }
+    }
+}
+
+// ---- backward, weight path ------------------------------------------------------------------------
+// Pixel-sliced "TN" GEMMs (contraction over pixels), partial sums per slice:
+//   dW1[hid][c] = sum_p dh[p][hid] s[p][c]     dW2[c][hid] = sum_p db[p][c] h[p][hid]
+//   db1[hid]    = sum_p dh[p][hid]             db2[c]      = sum_p db[p][c]
+// Both operands are read straight from global memory: for a fixed pixel the lanes read consecutive
+// channels (128-B segments), and the big operands (h, dh) are exclusive to one wave.
+template <int C, int H>
+struct FFWgCfg {
+    static constexpr int HT = H / 32;
+    static constexpr int NW = HT < 4 ? HT : 4;
+    static constexpr int TPW = HT / NW;
+    static constexpr int CT = C / 32;
+    static constexpr int PART = 2 * H * C + H + C;  // floats per slice
+};
+
+template <int C, int H>
+__global__ __launch_bounds__((FFWgCfg<C, H>::NW * 64)) void ff_bwd_weights_partial_kernel(
+    const float* __restrict__ s, const float* __restrict__ db, const float* __restrict__ h,
+    const float* __restrict__ dh, float* __restrict__ partial, int P, int chunk) {
+    using G = FFWgCfg<C, H>;
+    constexpr int TPW = G::TPW, CT = G::CT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const long pbeg = (long)blockIdx.x * chunk;
+    const long pend = min((long)P, pbeg + chunk);
+
+    f32x16 acc1[TPW][CT], acc2[CT][TPW];
+    float bs1[TPW], bs2[CT];
+    FFNO_UNROLL
+    for (int a = 0; a < TPW; ++a) {
+        bs1[a] = 0.f;
+        FFNO_UNROLL
+        for (int b = 0; b < CT; ++b) {
+            acc1[a][b] = zero16();
+            acc2[b][a] = zero16();
+        }
+    }
+    FFNO_UNROLL
+    for (int b = 0; b < CT; ++b) bs2[b] = 0.f;
+
+    const int nsteps = (int)((max(pend - pbeg, 0L) + 1) >> 1);
+    for (int t0 = 0; t0 < nsteps; t0 += 2) {
+        // two k-steps per trip, all loads issued before the MFMAs (tail steps are predicated to zero)
+        float dhA[2][TPW], hB[2][TPW], sB[2][CT], dbA[2][CT];
+        FFNO_UNROLL
+        for (int u = 0; u < 2; ++u) {
+            const long p = pbeg + 2 * (t0 + u) + half;
+            const bool valid = p < pend;
+            FFNO_UNROLL
+            for (int a = 0; a < TPW; ++a) {
+                dhA[u][a] = valid ? dh[p * H + 32 * (TPW * wave + a) + j] : 0.f;
+                hB[u][a] = valid ? h[p * H + 32 * (TPW * wave + a) + j] : 0.f;
+            }
+            FFNO_UNROLL
+            for (int b = 0; b < CT; ++b) {
+                sB[u][b] = valid ? s[p * C + 32 * b + j] : 0.f;
+                dbA[u][b] = valid ? db[p * C + 32 * b + j] : 0.f;
+            }
+        }
+        FFNO_UNROLL
+        for (int u = 0; u < 2; ++u) {
+            FFNO_UNROLL
+            for (int a = 0; a < TPW; ++a) {
+                bs1[a] += dhA[u][a];
+                FFNO_UNROLL
+                for (int b = 0; b < CT; ++b) {
+                    acc1[a][b] = mfma32(dhA[u][a], sB[u][b], acc1[a][b]);
+                    acc2[b][a] = mfma32(dbA[u][b], hB[u][a], acc2[b][a]);
+                }
+            }
+            FFNO_UNROLL
+            for (int b = 0; b < CT; ++b) bs2[b] += dbA[u][b];
+        }
+    }
+    float* part = partial + (long)blockIdx.x * G::PART;
+    float* pW1 = part;
+    float* pW2 = part + H * C;
+    float* pb1 = part + 2 * H * C;
+    float* pb2 = pb1 + H;
+    FFNO_UNROLL
+    for (int a = 0; a < TPW; ++a) {
+        FFNO_UNROLL
+        for (int b = 0; b < CT; ++b) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                pW1[(32 * (TPW * wave + a) + drow(r, half)) * C + 32 * b + j] = acc1[a][b][r];
+                pW2[(32 * b + drow(r, half)) * H + 32 * (TPW * wave + a) + j] = acc2[b][a][r];
+            }
+        }
+        const float v = bs1[a] + __shfl_xor(bs1[a], 32);
+        if (half == 0) pb1[32 * (TPW * wave + a) + j] = v;
+    }
+    FFNO_UNROLL
+    for (int b = 0; b < CT; ++b) {
+        const float v = bs2[b] + __shfl_xor(bs2[b], 32);
+        if (wave == 0 && half == 0) pb2[32 * b + j] = v;
+    }
+}
+
+__global__ void ff_bwd_weights_reduce_kernel(const float* __restrict__ partial, float* dW1, float* dW2, float* db1,
+                                             float* db2, int C, int H, int nsplit, int accumulate) {
+    const int part = 2 * H * C + H + C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < part; e += gridDim.x * blockDim.x) {
+        float sum = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) sum += partial[(long)sp * part + e];
+        float* dst;
+        if (e < H * C)
+            dst = dW1 + e;
+        else if (e < 2 * H * C)
+            dst = dW2 + (e - H * C);
+        else if (e < 2 * H * C + H)
+            dst = db1 + (e - 2 * H * C);
+        else
+            dst = db2 + (e - 2 * H * C - H);
+        *dst = accumulate ? (*dst + sum) : sum;
+    }
+}
+
+static inline int ff_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+// number of persistent workgroups: one per CU (the 128-KiB weight image allows one resident block)
+static const int kFFBlocks = 256;
+
+}  // namespace ffno
+
+using namespace ffno;
+
+extern "C" size_t ffno_ff_mask_words(int P, int H) { return (size_t)((P + 31) / 32) * 64 * (size_t)(H / 64); }
+
+#define FFNO_FF_DISPATCH(MACRO) \
+    MACRO(64, 256)              \
+    MACRO(64, 128)              \
+    MACRO(32, 128)              \
+    MACRO(32, 64)
+
+extern "C" int ffno_ff_fwd(const float* s, const float* resid, const float* W1, const float* b1, const float* W2,
+                           const float* b2, float* out, float* h, uint32_t* mask, int P, int C, int H,
+                           void* stream) {
+    if (!s || !W1 || !b1 || !W2 || !b2 || !out || P <= 0) return FFNO_EINVAL;
+    constexpr int NW = 8;
+    const int ntiles = (P + 31) / 32;
+    const dim3 grid(max(1, min(kFFBlocks, (ntiles + NW - 1) / NW))), block(NW * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CC, HH)                                                                                         \
+    if (C == CC && H == HH) {                                                                                \
+        hipLaunchKernelGGL((ff_fwd_kernel<CC, HH, NW>), grid, block, 0,                                      \
+                           st, s, resid, W1, b1, W2, b2, out, h, mask, P);                                   \
+        return ff_launch_status();                                                                           \
+    }
+    FFNO_FF_DISPATCH(CASE)
+#undef CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const float* W1, const float* W2, float* dh,
+                                float* ds, int P, int C, int H, void* stream) {
+    if (!db || !mask || !W1 || !W2 || !ds || P <= 0) return FFNO_EINVAL;
+    constexpr int NW = 8;
+    const int ntiles = (P + 31) / 32;
+    const dim3 grid(max(1, min(kFFBlocks, (ntiles + NW - 1) / NW))), block(NW * 64);
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CC, HH)                                                                                              \
+    if (C == CC && H == HH) {                                                                                     \
+        hipLaunchKernelGGL((ff_bwd_data_kernel<CC, HH, NW>), grid, block, 0,                                      \
+                           st, db, mask, W1, W2, dh, ds, P);                                                      \
+        return ff_launch_status();                                                                                \
+    }
+    FFNO_FF_DISPATCH(CASE)
+#undef CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" size_t ffno_ff_wgrad_partial_floats(int C, int H, int nsplit) {
+    return (size_t)nsplit * (size_t)(2 * H * C + H + C);
+}
+
+extern "C" int ffno_ff_bwd_weights_partial(const float* s, const float* db, const float* h, const float* dh,
+                                           float* partial, int P, int C, int H, int nsplit, void* stream) {
+    if (!s || !db || !h || !dh || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    int chunk = (P + nsplit - 1) / nsplit;
+    chunk += chunk & 1;
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CC, HH)                                                                                               \
+    if (C == CC && H == HH) {                                                                                      \
+        hipLaunchKernelGGL((ff_bwd_weights_partial_kernel<CC, HH>), dim3(nsplit), dim3(FFWgCfg<CC, HH>::NW * 64), 0, \
+                           st, s, db, h, dh, partial, P, chunk);                                                   \
+        return ff_launch_status();                                                                                 \
+    }
+    FFNO_FF_DISPATCH(CASE)
+#undef CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" int ffno_ff_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2,
+                                          int C, int H, int nsplit, int accumulate, void* stream) {
+    if (!partial || !dW1 || !dW2 || !db1 || !db2 || nsplit <= 0) return FFNO_EINVAL;
+    const int part = 2 * H * C + H + C;
+    hipLaunchKernelGGL(ff_bwd_weights_reduce_kernel, dim3((part + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       partial, dW1, dW2, db1, db2, C, H, nsplit, accumulate);
+    return ff_launch_status();
+}

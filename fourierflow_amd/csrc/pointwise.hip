@@ -1,0 +1,455 @@
+// Small bandwidth-bound kernels around the spectral/FF hot loop (fp32, VALU): weight-norm,
+// lift (in_proj), output head, relative-L2 loss, fused flat AdamW.  Reference citations per entry
+// point are in include/ffno.h.
+#include "ffno_device.h"
+#include "ffno.h"
+
+#include <math.h>
+
+namespace ffno {
+
+static inline int pw_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+// ---- weight norm ------------------------------------------------------------------------------------
+// one wave per weight row; descriptor table selects the matrix (blockIdx.y)
+__global__ __launch_bounds__(256) void wn_fwd_kernel(const ffno_wn_desc* __restrict__ descs) {
+    const ffno_wn_desc d = descs[blockIdx.y];
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.rows) return;
+    const float* v = d.v + (long)row * d.cols;
+    float ss = 0.f;
+    for (int c = lane; c < d.cols; c += 64) ss += v[c] * v[c];
+    ss = wave_sum(ss);
+    const float scale = d.g[row] / sqrtf(ss);
+    float* w = d.w + (long)row * d.cols;
+    for (int c = lane; c < d.cols; c += 64) w[c] = v[c] * scale;
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const ffno_wn_desc* __restrict__ descs) {
+    const ffno_wn_desc d = descs[blockIdx.y];
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= d.rows) return;
+    const float* v = d.v + (long)row * d.cols;
+    const float* dw = d.dw + (long)row * d.cols;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < d.cols; c += 64) {
+        ss += v[c] * v[c];
+        dot += dw[c] * v[c];
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    const float inv = 1.f / sqrtf(ss);
+    const float dg = dot * inv;
+    const float g = d.g[row];
+    if (lane == 0) d.dg[row] = dg;
+    float* dv = d.dv + (long)row * d.cols;
+    for (int c = lane; c < d.cols; c += 64) dv[c] = g * inv * (dw[c] - dg * inv * v[c]);
+}
+
+// ---- lift (in_proj) -----------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                       const float* __restrict__ b, float* __restrict__ out, int P,
+                                                       int Cin) {
+    FFNO_DYN_SMEM(smem);
+    float* Wt = reinterpret_cast<float*>(smem);  // [Cin + 1][C], last row = bias
+    for (int e = threadIdx.x; e < Cin * C; e += blockDim.x) Wt[(e % Cin) * C + (e / Cin)] = W[e];
+    for (int e = threadIdx.x; e < C; e += blockDim.x) Wt[Cin * C + e] = b[e];
+    __syncthreads();
+    constexpr int LPP = C / 4;        // lanes per pixel (one float4 of outputs each)
+    constexpr int PPB = 256 / LPP;    // pixels per block pass
+    const int c4 = (threadIdx.x % LPP) * 4, pl = threadIdx.x / LPP;
+    for (long p = (long)blockIdx.x * PPB + pl; p < P; p += (long)gridDim.x * PPB) {
+        float4 acc = *reinterpret_cast<const float4*>(Wt + Cin * C + c4);
+        const float* xp = x + p * Cin;
+        for (int i = 0; i < Cin; ++i) {
+            const float xv = xp[i];
+            const float4 w = *reinterpret_cast<const float4*>(Wt + i * C + c4);
+            acc.x = fmaf(xv, w.x, acc.x);
+            acc.y = fmaf(xv, w.y, acc.y);
+            acc.z = fmaf(xv, w.z, acc.z);
+            acc.w = fmaf(xv, w.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(out + p * C + c4) = acc;
+    }
+}
+
+// partial[split][i][c] = sum_{p in slice} gout[p][c] * (i < Cin ? x[p][i] : 1)
+template <int C>
+__global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ gout,
+                                                               float* __restrict__ partial, int P, int Cin,
+                                                               int chunk) {
+    constexpr int TP = 32;                     // pixels staged per pass
+    constexpr int MAXU = (C * 64) / 256;       // pairs per thread for Cin + 1 <= 64
+    __shared__ float gs[TP * C];
+    __shared__ float xs[TP * 64];
+    const int npairs = C * (Cin + 1);
+    float acc[MAXU];
+    FFNO_UNROLL
+    for (int u = 0; u < MAXU; ++u) acc[u] = 0.f;
+    const long pbeg = (long)blockIdx.x * chunk, pend = min((long)P, pbeg + chunk);
+    for (long p0 = pbeg; p0 < pend; p0 += TP) {
+        const int np = (int)min((long)TP, pend - p0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < TP * C; e += 256) gs[e] = (e / C) < np ? gout[p0 * C + e] : 0.f;
+        for (int e = threadIdx.x; e < TP * (Cin + 1); e += 256) {
+            const int pp = e / (Cin + 1), i = e % (Cin + 1);
+            xs[pp * 64 + i] = (pp < np) ? (i < Cin ? x[(p0 + pp) * Cin + i] : 1.f) : 0.f;
+        }
+        __syncthreads();
+        FFNO_UNROLL
+        for (int u = 0; u < MAXU; ++u) {
+            const int e = u * 256 + threadIdx.x;
+            if (e < npairs) {
+                const int c = e % C, i = e / C;
+                float a = acc[u];
+                for (int pp = 0; pp < TP; ++pp) a = fmaf(gs[pp * C + c], xs[pp * 64 + i], a);
+                acc[u] = a;
+            }
+        }
+    }
+    FFNO_UNROLL
+    for (int u = 0; u < MAXU; ++u) {
+        const int e = u * 256 + threadIdx.x;
+        if (e < npairs) partial[(long)blockIdx.x * npairs + e] = acc[u];
+    }
+}
+
+__global__ void lift_bwd_reduce_kernel(const float* __restrict__ partial, float* dW, float* db, int Cin, int C,
+                                       int nsplit, int accumulate) {
+    const int npairs = C * (Cin + 1);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < npairs; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * npairs + e];
+        const int c = e % C, i = e / C;
+        float* dst = (i < Cin) ? (dW + c * Cin + i) : (db + c);
+        *dst = accumulate ? (*dst + s) : s;
+    }
+}
+
+// ---- output head ----------------------------------------------------------------------------------------
+__global__ void head_fold_kernel(const float* __restrict__ Wa, const float* __restrict__ ca,
+                                 const float* __restrict__ Wb, const float* __restrict__ cb, float* fold, int C,
+                                 int D) {
+    const int c = threadIdx.x;
+    if (c < C) {
+        float s = 0.f;
+        for (int jd = 0; jd < D; ++jd) s = fmaf(Wb[jd], Wa[jd * C + c], s);
+        fold[c] = s;
+    } else if (c == C) {
+        float s = cb[0];
+        for (int jd = 0; jd < D; ++jd) s = fmaf(Wb[jd], ca[jd], s);
+        fold[C] = s;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ b, const float* __restrict__ fold,
+                                                       float* y, int P, int accumulate) {
+    constexpr int LPP = C / 4, PPB = 256 / LPP;
+    const int c4 = (threadIdx.x % LPP) * 4, pl = threadIdx.x / LPP;
+    const float4 w = *reinterpret_cast<const float4*>(fold + c4);
+    const float beff = fold[C];
+    const long npass = ((long)P + PPB - 1) / PPB;
+    for (long pass = blockIdx.x; pass < npass; pass += gridDim.x) {  // uniform trip count per wave (shuffles)
+        const long p = pass * PPB + pl;
+        float d = 0.f;
+        if (p < P) {
+            const float4 v = *reinterpret_cast<const float4*>(b + p * C + c4);
+            d = v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+        }
+        FFNO_UNROLL
+        for (int m = LPP / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m);
+        if (p < P && c4 == 0) y[p] = (accumulate ? y[p] : 0.f) + d + beff;
+    }
+}
+
+// gb[p][:] = gy[p] * weff ;  partial[block][0..C) = sum_p gy[p] b[p][:],  partial[block][C] = sum_p gy[p]
+template <int C>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ b, const float* __restrict__ gy,
+                                                       const float* __restrict__ fold, float* __restrict__ gb,
+                                                       float* __restrict__ partial, int P) {
+    constexpr int LPP = C / 4, PPB = 256 / LPP;
+    __shared__ float red[PPB * (C + 4)];
+    const int l = threadIdx.x % LPP, c4 = l * 4, pl = threadIdx.x / LPP;
+    const float4 w = *reinterpret_cast<const float4*>(fold + c4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sg = 0.f;
+    for (long p = (long)blockIdx.x * PPB + pl; p < P; p += (long)gridDim.x * PPB) {
+        const float g = gy[p];
+        const float4 v = *reinterpret_cast<const float4*>(b + p * C + c4);
+        acc.x = fmaf(g, v.x, acc.x);
+        acc.y = fmaf(g, v.y, acc.y);
+        acc.z = fmaf(g, v.z, acc.z);
+        acc.w = fmaf(g, v.w, acc.w);
+        if (l == 0) sg += g;
+        if (gb) *reinterpret_cast<float4*>(gb + p * C + c4) = make_float4(g * w.x, g * w.y, g * w.z, g * w.w);
+    }
+    float* r = red + pl * (C + 4);
+    r[c4] = acc.x;
+    r[c4 + 1] = acc.y;
+    r[c4 + 2] = acc.z;
+    r[c4 + 3] = acc.w;
+    if (l == 0) r[C] = sg;
+    __syncthreads();
+    for (int e = threadIdx.x; e <= C; e += 256) {
+        float s = 0.f;
+        for (int q = 0; q < PPB; ++q) s += red[q * (C + 4) + e];
+        partial[(long)blockIdx.x * (C + 1) + e] = s;
+    }
+}
+
+__global__ void head_bwd_reduce_kernel(const float* __restrict__ partial, float* red, int C, int nsplit) {
+    for (int e = threadIdx.x; e <= C; e += blockDim.x) {
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * (C + 1) + e];
+        red[e] = s;
+    }
+}
+
+// y = Wb (Wa b + ca) + cb :   dWb[j] = (Wa G)[j] + ca[j] S ; dWa[j][c] = Wb[j] G[c] ; dca[j] = Wb[j] S ; dcb = S
+__global__ void head_param_grads_kernel(const float* __restrict__ red, const float* __restrict__ Wa,
+                                        const float* __restrict__ ca, const float* __restrict__ Wb, float* dWa,
+                                        float* dca, float* dWb, float* dcb, int C, int D, int accumulate) {
+    const float S = red[C];
+    for (int jd = threadIdx.x; jd < D; jd += blockDim.x) {
+        float s = ca[jd] * S;
+        for (int c = 0; c < C; ++c) s = fmaf(Wa[jd * C + c], red[c], s);
+        dWb[jd] = accumulate ? dWb[jd] + s : s;
+        const float t = Wb[jd] * S;
+        dca[jd] = accumulate ? dca[jd] + t : t;
+    }
+    for (int e = threadIdx.x; e < D * C; e += blockDim.x) {
+        const float t = Wb[e / C] * red[e % C];
+        dWa[e] = accumulate ? dWa[e] + t : t;
+    }
+    if (threadIdx.x == 0) dcb[0] = accumulate ? dcb[0] + S : S;
+}
+
+// ---- relative L2 loss -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lploss_reduce_kernel(const float* __restrict__ pred,
+                                                            const float* __restrict__ target, float* tmp, int n) {
+    __shared__ float sd[4], sy[4];
+    const int bidx = blockIdx.x;
+    const float* p = pred + (long)bidx * n;
+    const float* t = target + (long)bidx * n;
+    float d2 = 0.f, y2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = p[i] - t[i];
+        d2 = fmaf(d, d, d2);
+        y2 = fmaf(t[i], t[i], y2);
+    }
+    d2 = wave_sum(d2);
+    y2 = wave_sum(y2);
+    if ((threadIdx.x & 63) == 0) {
+        sd[threadIdx.x >> 6] = d2;
+        sy[threadIdx.x >> 6] = y2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tmp[2 * bidx] = sd[0] + sd[1] + sd[2] + sd[3];
+        tmp[2 * bidx + 1] = sy[0] + sy[1] + sy[2] + sy[3];
+    }
+}
+
+__global__ __launch_bounds__(256) void lploss_grad_kernel(const float* __restrict__ pred,
+                                                          const float* __restrict__ target,
+                                                          const float* __restrict__ tmp, float* loss_out,
+                                                          float* gpred, int B, int n, float gscale) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && loss_out) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += sqrtf(tmp[2 * b]) / sqrtf(tmp[2 * b + 1]);
+        loss_out[0] = s / (float)B;
+    }
+    if (!gpred) return;
+    const int bidx = blockIdx.y;
+    const float dn = sqrtf(tmp[2 * bidx]), yn = sqrtf(tmp[2 * bidx + 1]);
+    const float coef = dn > 0.f ? gscale / ((float)B * dn * yn) : 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const long e = (long)bidx * n + i;
+        gpred[e] = coef * (pred[e] - target[e]);
+    }
+}
+
+// ---- fused flat AdamW ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                                                    float beta1, float beta2, float eps, float wd, float bc1,
+                                                    float bc2_sqrt, float gscale) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha,
+                                                   size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = fmaf(alpha, x[i], y[i]);
+}
+
+}  // namespace ffno
+
+using namespace ffno;
+
+extern "C" const char* ffno_build_target(void) {
+#ifdef FFNO_EMU
+    return "emu";
+#else
+    return "gfx950";
+#endif
+}
+extern "C" int ffno_abi_version(void) { return 1; }
+
+extern "C" int ffno_twiddle_fill_host(float* tw_host, int L) {
+    if (!tw_host || L <= 0) return FFNO_EINVAL;
+    const double inv = 1.0 / sqrt((double)L);
+    for (int jx = 0; jx < L; ++jx) {
+        const double th = 2.0 * M_PI * (double)jx / (double)L;
+        double c = cos(th), s = sin(th);
+        // exact zeros / +-1 at the quarter points so DC / Nyquist imaginary parts vanish identically
+        if (4 * jx == L || 4 * jx == 3 * L) c = 0.0;
+        if (jx == 0 || 2 * jx == L) s = 0.0;
+        tw_host[jx] = (float)(c * inv);
+        tw_host[L + jx] = (float)(s * inv);
+    }
+    return FFNO_OK;
+}
+
+extern "C" int ffno_weightnorm_fwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream) {
+    if (!descs_dev || n <= 0 || max_rows <= 0) return FFNO_EINVAL;
+    hipLaunchKernelGGL(wn_fwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    return pw_status();
+}
+extern "C" int ffno_weightnorm_bwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream) {
+    if (!descs_dev || n <= 0 || max_rows <= 0) return FFNO_EINVAL;
+    hipLaunchKernelGGL(wn_bwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    return pw_status();
+}
+
+extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
+                             void* stream) {
+    if (!x || !W || !b || !out || P <= 0 || Cin <= 0) return FFNO_EINVAL;
+    if (Cin > 63) return FFNO_EUNSUPPORTED;
+    const size_t smem = sizeof(float) * (size_t)(Cin + 1) * C;
+    const int ppb = 256 / (C / 4);
+    const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin);
+    else if (C == 32)
+        hipLaunchKernelGGL((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin);
+    else
+        return FFNO_EUNSUPPORTED;
+    return pw_status();
+}
+
+extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
+                             int Cin, int C, int nsplit, int accumulate, void* stream) {
+    if (!x || !gout || !partial || !dW || !db || P <= 0 || Cin <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    if (Cin > 63) return FFNO_EUNSUPPORTED;
+    const int chunk = (P + nsplit - 1) / nsplit;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL((lift_bwd_partial_kernel<64>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
+    else if (C == 32)
+        hipLaunchKernelGGL((lift_bwd_partial_kernel<32>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
+    else
+        return FFNO_EUNSUPPORTED;
+    int rc = pw_status();
+    if (rc) return rc;
+    const int npairs = C * (Cin + 1);
+    hipLaunchKernelGGL(lift_bwd_reduce_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, partial, dW, db, Cin, C,
+                       nsplit, accumulate);
+    return pw_status();
+}
+
+extern "C" int ffno_head_fold(const float* Wa, const float* ca, const float* Wb, const float* cb, float* fold,
+                              int C, int D, void* stream) {
+    if (!Wa || !ca || !Wb || !cb || !fold || C <= 0 || D <= 0 || C > 255) return FFNO_EINVAL;
+    hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Wa, ca, Wb, cb, fold, C, D);
+    return pw_status();
+}
+
+extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int accumulate,
+                             void* stream) {
+    if (!b || !fold || !y || P <= 0) return FFNO_EINVAL;
+    const int ppb = 256 / (C / 4);
+    const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL((head_fwd_kernel<64>), grid, block, 0, s, b, fold, y, P, accumulate);
+    else if (C == 32)
+        hipLaunchKernelGGL((head_fwd_kernel<32>), grid, block, 0, s, b, fold, y, P, accumulate);
+    else
+        return FFNO_EUNSUPPORTED;
+    return pw_status();
+}
+
+extern "C" int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
+                             float* red, int P, int C, int nsplit, void* stream) {
+    if (!b || !gy || !fold || !partial || !red || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
+    else if (C == 32)
+        hipLaunchKernelGGL((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
+    else
+        return FFNO_EUNSUPPORTED;
+    int rc = pw_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(1), dim3(128), 0, s, partial, red, C, nsplit);
+    return pw_status();
+}
+
+extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,
+                                     float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int accumulate,
+                                     void* stream) {
+    if (!red || !Wa || !ca || !Wb || !dWa || !dca || !dWb || !dcb) return FFNO_EINVAL;
+    hipLaunchKernelGGL(head_param_grads_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, red, Wa, ca, Wb, dWa, dca,
+                       dWb, dcb, C, D, accumulate);
+    return pw_status();
+}
+
+extern "C" int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out, float* gpred,
+                                   float* tmp, int B, int n_per_sample, float gscale, void* stream) {
+    if (!pred || !target || !tmp || B <= 0 || n_per_sample <= 0) return FFNO_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(lploss_reduce_kernel, dim3(B), dim3(256), 0, s, pred, target, tmp, n_per_sample);
+    int rc = pw_status();
+    if (rc) return rc;
+    const int gx = max(1, min((n_per_sample + 255) / 256, 64));
+    hipLaunchKernelGGL(lploss_grad_kernel, dim3(gx, B), dim3(256), 0, s, pred, target, tmp, loss_out, gpred, B,
+                       n_per_sample, gscale);
+    return pw_status();
+}
+
+extern "C" int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale,
+                               void* stream) {
+    if (!p || !g || !m || !v || n == 0 || step <= 0) return FFNO_EINVAL;
+    const float bc1 = 1.f - (float)pow((double)beta1, (double)step);
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    const unsigned blocks = (unsigned)min((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+                       eps, weight_decay, bc1, bc2s, grad_scale);
+    return pw_status();
+}
+
+extern "C" int ffno_axpy(float* y, const float* x, float alpha, size_t n, void* stream) {
+    if (!y || !x || n == 0) return FFNO_EINVAL;
+    const unsigned blocks = (unsigned)min((n + 255) / 256, (size_t)2048);
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
+    return pw_status();
+}

@@ -1,0 +1,623 @@
+// Spectral stages of the factorized Fourier layer for gfx950 (fp32, v_mfma_f32_32x32x2_f32).
+//
+// Replaces the torch op sequence of SpectralConv2d.forward_fourier
+// (reference fourierflow/modules/factorized_fno/grid_2d.py:51-99) and its autograd:
+//   stage A  dft_fwd   : truncated real DFT along one axis    (rfft + [:K] slice,       :58,67,76,85)
+//   stage B  mode_mix  : per-mode complex channel mix         (einsum bixy,ioy->boxy,   :65-68,83-86)
+//   stage C  dft_inv   : zero-padded inverse real DFT + sum   (new_zeros+irfft+xx+xy,   :61,72,79,90,94)
+//   fw_grad            : dW = sum_lines conj(X) dY            (autograd of the einsum)
+//
+// Only K << L/2 modes are kept, so both transforms are evaluated as truncated DFT matrix products on
+// the matrix cores (any L, incl. non powers of two); the DFT matrix is never stored: each lane
+// walks a 2L-entry cos/sin table in LDS (k*n mod L advanced incrementally).  Activations stay
+// channels-last [B][M][N][C]; spectra are mode-major spec[k][line][re/im][c] so stage B reads one
+// contiguous [lines][2C] panel per mode.
+#include "ffno_device.h"
+#include "ffno.h"
+
+namespace ffno {
+
+// ---- line addressing ---------------------------------------------------------------------------
+// axis 0: lines (b,m), element n at stride C.      axis 1: lines (b,n), element m at stride N*C.
+struct LineMap {
+    int lines_per_group;   // axis0: R (one group)   axis1: N
+    long group_stride;     // axis0: 0               axis1: M*N*C
+    long line_stride;      // axis0: N*C             axis1: C
+    long elem_stride;      // axis0: C               axis1: N*C
+    __host__ __device__ long base(int r) const {
+        return (long)(r / lines_per_group) * group_stride + (long)(r % lines_per_group) * line_stride;
+    }
+};
+
+static inline LineMap make_linemap(int axis, int B, int M, int N, int C) {
+    LineMap m;
+    if (axis == 0) {
+        m.lines_per_group = B * M;
+        m.group_stride = 0;
+        m.line_stride = (long)N * C;
+        m.elem_stride = C;
+    } else {
+        m.lines_per_group = N;
+        m.group_stride = (long)M * N * C;
+        m.line_stride = C;
+        m.elem_stride = (long)N * C;
+    }
+    return m;
+}
+
+template <int CT>
+struct ColVec;
+template <>
+struct ColVec<1> {
+    float v[1];
+    __device__ __forceinline__ void load(const float* p) { v[0] = p[0]; }
+    __device__ __forceinline__ void store(float* p) const { p[0] = v[0]; }
+};
+template <>
+struct ColVec<2> {
+    float v[2];
+    __device__ __forceinline__ void load(const float* p) {
+        float2 t = *reinterpret_cast<const float2*>(p);
+        v[0] = t.x;
+        v[1] = t.y;
+    }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+
+// ---- stage A ------------------------------------------------------------------------------------
+// One wave per line.  D[kk][c] = sum_n F[kk][n] x[n][c], kk = 2k+ri (interleaved re/im rows).
+// A operand (F) comes from the LDS twiddle table, B operand (x) straight from global memory:
+// lane (j, half) loads channels CT*j..CT*j+CT-1 of element n = 2t+half, i.e. each load instruction
+// covers two full C-float rows (contiguous 512 B for C=64 on axis 0).
+template <int C, int RT>
+__global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ x, float* __restrict__ spec,
+                                                      const float* __restrict__ tw, int R, int L, int K,
+                                                      LineMap lm, int scale_ck) {
+    constexpr int CT = C / 32;
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = tw[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+
+    float amul[RT];
+    int tbase[RT], step[RT], idx0[RT];
+    FFNO_UNROLL
+    for (int rt = 0; rt < RT; ++rt) {
+        const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
+        const bool valid = kk < 2 * K;
+        const float ck = (scale_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        amul[rt] = valid ? (ri ? -ck : ck) : 0.f;
+        tbase[rt] = ri ? L : 0;
+        const int km = valid ? k : 0;
+        step[rt] = (2 * km) % L;
+        idx0[rt] = (km * half) % L;
+    }
+    const int nsteps = (L + 1) >> 1;
+
+    for (int line = blockIdx.x * 4 + wave; line < R; line += gridDim.x * 4) {
+        const float* xl = x + lm.base(line) + CT * j;
+        f32x16 acc[RT][CT];
+        int idx[RT];
+        FFNO_UNROLL
+        for (int rt = 0; rt < RT; ++rt) {
+            idx[rt] = idx0[rt];
+            FFNO_UNROLL
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = zero16();
+        }
+        for (int t0 = 0; t0 < nsteps; t0 += 4) {
+            // four k-steps per trip: issue all loads first (tail steps read zeros), then the MFMAs
+            ColVec<CT> b[4];
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const int n = 2 * (t0 + u) + half;
+                if (n < L) {
+                    b[u].load(xl + (long)n * lm.elem_stride);
+                } else {
+                    FFNO_UNROLL
+                    for (int ct = 0; ct < CT; ++ct) b[u].v[ct] = 0.f;
+                }
+            }
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                FFNO_UNROLL
+                for (int rt = 0; rt < RT; ++rt) {
+                    const float a = amul[rt] * tws[tbase[rt] + idx[rt]];
+                    idx[rt] += step[rt];
+                    if (idx[rt] >= L) idx[rt] -= L;
+                    FFNO_UNROLL
+                    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma32(a, b[u].v[ct], acc[rt][ct]);
+                }
+            }
+        }
+        FFNO_UNROLL
+        for (int rt = 0; rt < RT; ++rt) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int kk = 32 * rt + drow(r, half);
+                if (kk < 2 * K) {
+                    const int k = kk >> 1, ri = kk & 1;
+                    ColVec<CT> o;
+                    FFNO_UNROLL
+                    for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[rt][ct][r];
+                    o.store(spec + (((long)k * R + line) * 2 + ri) * C + CT * j);
+                }
+            }
+        }
+    }
+}
+
+// ---- stage C ------------------------------------------------------------------------------------
+// One wave per line.  out[n][c] = sum_kk G[n][kk] Y[kk][c]; two 32-row tiles of n per pass.
+template <int C>
+__global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ spec, float* out,
+                                                      const float* resid, const float* __restrict__ tw,
+                                                      int R, int L, int K, LineMap lm, int apply_ck,
+                                                      int accumulate) {
+    constexpr int CT = C / 32;
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = tw[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const float sgn = half ? -1.f : 1.f;
+    const int tbase = half ? L : 0;
+    const int RTtot = (L + 31) >> 5;
+
+    for (int line = blockIdx.x * 4 + wave; line < R; line += gridDim.x * 4) {
+        const long lbase = lm.base(line) + CT * j;
+        for (int rt0 = 0; rt0 < RTtot; rt0 += 2) {
+            const int n0 = 32 * rt0 + j, n1 = n0 + 32;  // A-operand rows of the two tiles
+            const int st0 = n0 % L, st1 = n1 % L;
+            int i0 = 0, i1 = 0;
+            f32x16 acc[2][CT];
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                FFNO_UNROLL
+                for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
+            }
+            for (int t0 = 0; t0 < K; t0 += 4) {
+                ColVec<CT> b[4];
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u;
+                    if (t < K) {
+                        b[u].load(spec + (((long)t * R + line) * 2 + half) * C + CT * j);
+                    } else {
+                        FFNO_UNROLL
+                        for (int ct = 0; ct < CT; ++ct) b[u].v[ct] = 0.f;
+                    }
+                }
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const int t = t0 + u;
+                    const float ck = (apply_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                    const float a0 = sgn * ck * tws[tbase + i0];
+                    const float a1 = sgn * ck * tws[tbase + i1];
+                    i0 += st0;
+                    if (i0 >= L) i0 -= L;
+                    i1 += st1;
+                    if (i1 >= L) i1 -= L;
+                    FFNO_UNROLL
+                    for (int ct = 0; ct < CT; ++ct) {
+                        acc[0][ct] = mfma32(a0, b[u].v[ct], acc[0][ct]);
+                        acc[1][ct] = mfma32(a1, b[u].v[ct], acc[1][ct]);
+                    }
+                }
+            }
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * (rt0 + q) + drow(r, half);
+                    if (n < L) {
+                        const long a = lbase + (long)n * lm.elem_stride;
+                        ColVec<CT> o;
+                        FFNO_UNROLL
+                        for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[q][ct][r];
+                        if (accumulate) {
+                            ColVec<CT> p;
+                            p.load(out + a);
+                            FFNO_UNROLL
+                            for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
+                        }
+                        if (resid) {
+                            ColVec<CT> p;
+                            p.load(resid + a);
+                            FFNO_UNROLL
+                            for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
+                        }
+                        o.store(out + a);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- Fourier weight repack ------------------------------------------------------------------------
+__global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wpt,
+                               int C, int K) {
+    const long total = (long)C * C * K * 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        // e indexes wp[k][ri][i][o]
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const int k = e / ((long)C * C * 2);
+        const float v = w[(((long)i * C + o) * K + k) * 2 + ri];
+        wp[e] = v;
+        wpt[(((long)k * 2 + ri) * C + o) * C + i] = v;
+    }
+}
+
+// ---- stage B ------------------------------------------------------------------------------------
+// Block = (mode k, chunk of row tiles); 4 waves, each owns one 32-line tile at a time.
+// D[line][(q,o)] = sum_{(p,i)} X[line][(p,i)] * Wb[(p,i)][(q,o)]  with the 2x2 real block form of the
+// complex product.  A operand = staged X tile (LDS, row stride 2C+1 -> conflict-free column reads),
+// B operand = the mode's weight planes (LDS, lanes read consecutive floats).
+template <int C>
+__global__ __launch_bounds__(256) void mode_mix_kernel(const float* __restrict__ spec_in,
+                                                       const float* __restrict__ planes,
+                                                       float* __restrict__ spec_out, int R, int K,
+                                                       int conj_t) {
+    constexpr int CT = C / 32;
+    constexpr int LDA = 2 * C + 1;
+    __shared__ __attribute__((aligned(16))) float smem_mix[2 * C * C + 4 * 32 * LDA];
+    float* Wr = smem_mix;
+    float* Wi = Wr + C * C;
+    float* stage = Wi + C * C;
+
+    const int k = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    {
+        const float* pk = planes + (long)k * 2 * C * C;
+        for (int i = threadIdx.x; i < 2 * C * C; i += blockDim.x) Wr[i] = pk[i];
+    }
+    float* st = stage + wave * 32 * LDA;
+    const float* xin = spec_in + (long)k * R * 2 * C;
+    float* yout = spec_out + (long)k * R * 2 * C;
+
+    // per-lane plane selection / sign of the real block form (see header comment of ffno_mode_mix)
+    const float* plane[2];
+    float sign[2];
+    FFNO_UNROLL
+    for (int q = 0; q < 2; ++q) {
+        plane[q] = (half == q) ? Wr : Wi;
+        if (conj_t == 0)
+            sign[q] = (half == 1 && q == 0) ? -1.f : 1.f;
+        else
+            sign[q] = (half == 0 && q == 1) ? -1.f : 1.f;
+    }
+
+    const int ntiles = (R + 31) >> 5;
+    const int tiles_per_iter = gridDim.x * 4;
+    const int niter = (ntiles + tiles_per_iter - 1) / tiles_per_iter;
+    for (int it = 0; it < niter; ++it) {
+        const int tile = it * tiles_per_iter + blockIdx.x * 4 + wave;
+        const int row0 = tile * 32;
+        __syncthreads();  // previous iteration's reads of `st` are done (also covers the weight load)
+        // stage the [32][2C] panel (contiguous in global memory) with coalesced 16-B loads
+        FFNO_UNROLL
+        for (int u = 0; u < (32 * 2 * C) / (64 * 4); ++u) {
+            const int e = 4 * (lane + 64 * u);
+            const int row = e / (2 * C), col = e % (2 * C);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row0 + row < R) v = *reinterpret_cast<const float4*>(xin + (long)(row0 + row) * 2 * C + col);
+            float* d = st + row * LDA + col;
+            d[0] = v.x;
+            d[1] = v.y;
+            d[2] = v.z;
+            d[3] = v.w;
+        }
+        __syncthreads();
+        f32x16 acc[2][CT];
+        FFNO_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            FFNO_UNROLL
+            for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
+        }
+#ifndef FFNO_EMU
+#pragma unroll 4
+#endif
+        for (int t = 0; t < C; ++t) {
+            const float a = st[j * LDA + C * half + t];
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                FFNO_UNROLL
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float b = sign[q] * plane[q][t * C + 32 * ct + j];
+                    acc[q][ct] = mfma32(a, b, acc[q][ct]);
+                }
+            }
+        }
+        FFNO_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            FFNO_UNROLL
+            for (int ct = 0; ct < CT; ++ct) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + drow(r, half);
+                    if (row < R) yout[((long)row * 2 + q) * C + 32 * ct + j] = acc[q][ct][r];
+                }
+            }
+        }
+    }
+}
+
+// ---- Fourier weight gradient ----------------------------------------------------------------------
+// Block = (mode k, line slice); wave w -> (part = real/imag of dW, a = 32-row tile of the input channel i).
+//   dWr[i][o] = sum_r Xr[r][i] dYr[r][o] + Xi[r][i] dYi[r][o]
+//   dWi[i][o] = sum_r Xr[r][i] dYi[r][o] - Xi[r][i] dYr[r][o]
+template <int C>
+__global__ __launch_bounds__(C * 4) void fw_grad_partial_kernel(const float* __restrict__ xs,
+                                                                 const float* __restrict__ dys,
+                                                                 float* __restrict__ partial, int R, int K,
+                                                                 int chunk, int beta) {
+    constexpr int CT = C / 32;
+    const int k = blockIdx.y, split = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int part = wave / CT, a = wave % CT;
+    const int rbeg = split * chunk;
+    const int rend = min(R, rbeg + chunk);
+    const float* xk = xs + (long)k * R * 2 * C;
+    const float* dk = dys + (long)k * R * 2 * C;
+
+    f32x16 acc[CT];
+    FFNO_UNROLL
+    for (int b = 0; b < CT; ++b) acc[b] = zero16();
+    const int nsteps = (max(rend - rbeg, 0) + 1) >> 1;
+    for (int t0 = 0; t0 < nsteps; t0 += 2) {
+        float xr[2], xi[2], dyr[2][CT], dyi[2][CT];
+        FFNO_UNROLL
+        for (int u = 0; u < 2; ++u) {
+            const int row = rbeg + 2 * (t0 + u) + half;
+            const bool valid = row < rend;
+            xr[u] = xi[u] = 0.f;
+            FFNO_UNROLL
+            for (int b = 0; b < CT; ++b) dyr[u][b] = dyi[u][b] = 0.f;
+            if (valid) {
+                const float* xrow = xk + (long)row * 2 * C;
+                const float* drow_ = dk + (long)row * 2 * C;
+                xr[u] = xrow[32 * a + j];
+                xi[u] = xrow[C + 32 * a + j];
+                FFNO_UNROLL
+                for (int b = 0; b < CT; ++b) {
+                    dyr[u][b] = drow_[32 * b + j];
+                    dyi[u][b] = drow_[C + 32 * b + j];
+                }
+            }
+        }
+        FFNO_UNROLL
+        for (int u = 0; u < 2; ++u) {
+            FFNO_UNROLL
+            for (int b = 0; b < CT; ++b) {
+                if (part == 0) {
+                    acc[b] = mfma32(xr[u], dyr[u][b], acc[b]);
+                    acc[b] = mfma32(xi[u], dyi[u][b], acc[b]);
+                } else {
+                    acc[b] = mfma32(xr[u], dyi[u][b], acc[b]);
+                    acc[b] = mfma32(-xi[u], dyr[u][b], acc[b]);
+                }
+            }
+        }
+    }
+    float* pout = partial + (((long)split * K + k) * 2 + part) * C * C;
+    FFNO_UNROLL
+    for (int b = 0; b < CT; ++b) {
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * a + drow(r, half);
+            float* p = pout + (long)i * C + 32 * b + j;
+            *p = beta ? (*p + acc[b][r]) : acc[b][r];
+        }
+    }
+}
+
+__global__ void fw_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int C, int K,
+                                      int nsplit, int accumulate) {
+    const long total = (long)C * C * K * 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        // e indexes the plane layout [k][ri][i][o] (coalesced reads)
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const int k = e / ((long)C * C * 2);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * total + e];
+        float* g = gw + (((long)i * C + o) * K + k) * 2 + ri;
+        *g = accumulate ? (*g + s) : s;
+    }
+}
+
+static inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+}  // namespace ffno
+
+using namespace ffno;
+
+extern "C" int ffno_dft_fwd(const float* x, float* spec, const float* tw, int B, int M, int N, int C, int K,
+                            int axis, int scale_ck, void* stream) {
+    if (!x || !spec || !tw || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1)) return FFNO_EINVAL;
+    const int L = axis == 0 ? N : M;
+    const int R = axis == 0 ? B * M : B * N;
+    if (K > L / 2 + 1) return FFNO_EMODES;
+    const int RT = (2 * K + 31) / 32;
+    const LineMap lm = make_linemap(axis, B, M, N, C);
+    const dim3 grid(min((R + 3) / 4, 4096)), block(256);
+    const size_t smem = sizeof(float) * 2 * L;
+    hipStream_t s = (hipStream_t)stream;
+#define FFNO_DFT_FWD_CASE(CC, RR)                                                                        \
+    if (C == CC && RT == RR) {                                                                           \
+        hipLaunchKernelGGL((dft_fwd_kernel<CC, RR>), grid, block, smem, s, x, spec, tw, R, L, K, lm, scale_ck); \
+        return launch_status();                                                                          \
+    }
+    FFNO_DFT_FWD_CASE(64, 1)
+    FFNO_DFT_FWD_CASE(64, 2)
+    FFNO_DFT_FWD_CASE(64, 3)
+    FFNO_DFT_FWD_CASE(64, 4)
+    FFNO_DFT_FWD_CASE(32, 1)
+    FFNO_DFT_FWD_CASE(32, 2)
+    FFNO_DFT_FWD_CASE(32, 3)
+    FFNO_DFT_FWD_CASE(32, 4)
+#undef FFNO_DFT_FWD_CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" int ffno_dft_inv(const float* spec, float* out, const float* resid, const float* tw, int B, int M,
+                            int N, int C, int K, int axis, int apply_ck, int accumulate, void* stream) {
+    if (!spec || !out || !tw || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1)) return FFNO_EINVAL;
+    const int L = axis == 0 ? N : M;
+    const int R = axis == 0 ? B * M : B * N;
+    if (K > L / 2 + 1) return FFNO_EMODES;
+    const LineMap lm = make_linemap(axis, B, M, N, C);
+    const dim3 grid(min((R + 3) / 4, 4096)), block(256);
+    const size_t smem = sizeof(float) * 2 * L;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64) {
+        hipLaunchKernelGGL((dft_inv_kernel<64>), grid, block, smem, s, spec, out, resid, tw, R, L, K, lm, apply_ck,
+                           accumulate);
+    } else if (C == 32) {
+        hipLaunchKernelGGL((dft_inv_kernel<32>), grid, block, smem, s, spec, out, resid, tw, R, L, K, lm, apply_ck,
+                           accumulate);
+    } else {
+        return FFNO_EUNSUPPORTED;
+    }
+    return launch_status();
+}
+
+extern "C" int ffno_fw_pack(const float* w, float* wp, float* wpt, int C, int K, void* stream) {
+    if (!w || !wp || !wpt || C <= 0 || K <= 0) return FFNO_EINVAL;
+    const long total = (long)C * C * K * 2;
+    hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)min((total + 255) / 256, 1024L)), dim3(256), 0,
+                       (hipStream_t)stream, w, wp, wpt, C, K);
+    return launch_status();
+}
+
+extern "C" int ffno_mode_mix(const float* spec_in, const float* planes, float* spec_out, int R, int C, int K,
+                             int conj_transpose, void* stream) {
+    if (!spec_in || !planes || !spec_out || R <= 0 || K <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    const int ntiles = (R + 31) / 32;
+    // enough row-chunks that K * chunks covers the chip (256 CUs), at most one tile per wave per pass
+    int chunks = max(1, min((ntiles + 3) / 4, max(1, 512 / K)));
+    const dim3 grid(chunks, K), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL((mode_mix_kernel<64>), grid, block, 0, s, spec_in, planes, spec_out, R, K, conj_transpose);
+    else
+        hipLaunchKernelGGL((mode_mix_kernel<32>), grid, block, 0, s, spec_in, planes, spec_out, R, K, conj_transpose);
+    return launch_status();
+}
+
+extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* partial, int R, int C,
+                                    int K, int nsplit, int beta, void* stream) {
+    if (!spec_x || !spec_dy || !partial || R <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    int chunk = (R + nsplit - 1) / nsplit;
+    chunk += chunk & 1;  // even, so the (2t + half) row pairing never straddles slices
+    const dim3 grid(nsplit, K), block(C * 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        hipLaunchKernelGGL((fw_grad_partial_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
+    else
+        hipLaunchKernelGGL((fw_grad_partial_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
+    return launch_status();
+}
+
+extern "C" int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
+                                   void* stream) {
+    if (!partial || !gw || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    const long total = (long)C * C * K * 2;
+    hipLaunchKernelGGL(fw_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 2048L)), dim3(256), 0,
+                       (hipStream_t)stream, partial, gw, C, K, nsplit, accumulate);
+    return launch_status();
+}
+
+// ---- operator level -----------------------------------------------------------------------------
+// workspace layout (floats): [spec_a: K*Rmax*2C][spec_b: K*Rmax*2C][wp: 2KCC][wpt: 2KCC][partial: NSPLIT*2KCC]
+static const int kFwSplit = 8;
+
+extern "C" size_t ffno_spectral2d_ws_floats(int B, int M, int N, int C, int K) {
+    const size_t rmax = (size_t)B * (size_t)max(M, N);
+    const size_t spec = (size_t)K * rmax * 2 * C;
+    const size_t planes = (size_t)2 * K * C * C;
+    return 2 * spec + 2 * planes + (size_t)kFwSplit * planes;
+}
+
+extern "C" int ffno_spectral2d_fwd(const float* x, const float* w_y, const float* w_x, float* out, float* ws,
+                                   const float* tw_n, const float* tw_m, int B, int M, int N, int C, int K,
+                                   int mode, void* stream) {
+    if (!x || !out || !ws || !tw_n || !tw_m) return FFNO_EINVAL;
+    if (mode != FFNO_MODE_FULL && mode != FFNO_MODE_LOWPASS) return FFNO_EINVAL;
+    if (mode == FFNO_MODE_FULL && (!w_y || !w_x)) return FFNO_EINVAL;
+    const size_t rmax = (size_t)B * (size_t)max(M, N);
+    const size_t spec = (size_t)K * rmax * 2 * C, planes = (size_t)2 * K * C * C;
+    float* sa = ws;
+    float* sb = ws + spec;
+    float* wp = ws + 2 * spec;
+    float* wpt = wp + planes;
+    int rc;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int R = axis == 0 ? B * M : B * N;
+        const float* tw = axis == 0 ? tw_n : tw_m;
+        const float* w = axis == 0 ? w_y : w_x;
+        if ((rc = ffno_dft_fwd(x, sa, tw, B, M, N, C, K, axis, 0, stream))) return rc;
+        const float* y = sa;
+        if (mode == FFNO_MODE_FULL) {
+            if ((rc = ffno_fw_pack(w, wp, wpt, C, K, stream))) return rc;
+            if ((rc = ffno_mode_mix(sa, wp, sb, R, C, K, 0, stream))) return rc;
+            y = sb;
+        }
+        if ((rc = ffno_dft_inv(y, out, nullptr, tw, B, M, N, C, K, axis, 1, axis == 1, stream))) return rc;
+    }
+    return FFNO_OK;
+}
+
+extern "C" int ffno_spectral2d_bwd(const float* x, const float* w_y, const float* w_x, const float* gy, float* gx,
+                                   float* gw_y, float* gw_x, float* ws, const float* tw_n, const float* tw_m,
+                                   int B, int M, int N, int C, int K, int mode, int accumulate_gx,
+                                   int accumulate_gw, void* stream) {
+    if (!gy || !gx || !ws || !tw_n || !tw_m) return FFNO_EINVAL;
+    if (mode != FFNO_MODE_FULL && mode != FFNO_MODE_LOWPASS) return FFNO_EINVAL;
+    if (mode == FFNO_MODE_FULL && (!w_y || !w_x || !x)) return FFNO_EINVAL;
+    const size_t rmax = (size_t)B * (size_t)max(M, N);
+    const size_t spec = (size_t)K * rmax * 2 * C, planes = (size_t)2 * K * C * C;
+    float* sa = ws;
+    float* sb = ws + spec;
+    float* wp = ws + 2 * spec;
+    float* wpt = wp + planes;
+    float* partial = wpt + planes;
+    int rc;
+    for (int axis = 0; axis < 2; ++axis) {
+        const int R = axis == 0 ? B * M : B * N;
+        const float* tw = axis == 0 ? tw_n : tw_m;
+        const float* w = axis == 0 ? w_y : w_x;
+        float* gw = axis == 0 ? gw_y : gw_x;
+        // dY = adjoint of the zero-padded irfft applied to gy
+        if ((rc = ffno_dft_fwd(gy, sa, tw, B, M, N, C, K, axis, 1, stream))) return rc;
+        const float* dxs = sa;
+        if (mode == FFNO_MODE_FULL) {
+            if (gw) {
+                if ((rc = ffno_dft_fwd(x, sb, tw, B, M, N, C, K, axis, 0, stream))) return rc;  // recompute X
+                if ((rc = ffno_fw_grad_partial(sb, sa, partial, R, C, K, kFwSplit, 0, stream))) return rc;
+                if ((rc = ffno_fw_grad_reduce(partial, gw, C, K, kFwSplit, accumulate_gw, stream))) return rc;
+            }
+            if ((rc = ffno_fw_pack(w, wp, wpt, C, K, stream))) return rc;
+            if ((rc = ffno_mode_mix(sa, wpt, sb, R, C, K, 1, stream))) return rc;
+            dxs = sb;
+        }
+        if ((rc = ffno_dft_inv(dxs, gx, nullptr, tw, B, M, N, C, K, axis, 0, (axis == 1) || accumulate_gx, stream)))
+            return rc;
+    }
+    return FFNO_OK;
+}

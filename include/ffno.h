@@ -1,0 +1,210 @@
+/*
+ * ffno.h -- C ABI of the MI355X (gfx950) F-FNO hot-path library  (libffno_hip.so)
+ *
+ * Drop-in boundary for the spectral-layer stack of alasdairtran/fourierflow.  The reference has no
+ * FFI of its own (it is pure PyTorch); each entry point below replaces the *sequence of stock torch
+ * ops* cited next to it, and the Python host in fourierflow_amd/ re-exposes them behind the
+ * reference's `fourierflow.modules` classes (same ctor kwargs, parameter names and forward contract).
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless named *_host.
+ *   - the library borrows pointers for the duration of the enqueue, never allocates user-visible
+ *     memory, and only enqueues work on `stream` (a hipStream_t passed as void*); no hidden syncs.
+ *   - every function returns 0 on success, a negative FFNO_E* code on bad arguments / unsupported
+ *     shapes, or a positive hipError_t if a launch failed.  Nothing throws across the ABI.
+ *   - activations are channels-last fp32: x[B][M][N][C]; "pixels" P = B*M*N.
+ *   - supported widths: C in {32, 64}; hidden H = factor*C in {64, 128, 256} (H % 64 == 0).
+ *
+ * Spectrum layout (internal but part of the ABI because callers own the workspaces):
+ *   spec[k][r][ri][c]   k = mode (0..K-1), r = line index, ri = 0 real / 1 imag, c = channel
+ *   lines: axis 0 (transform along N, fourier_weight[0]): r = b*M + m  (R = B*M lines of length N)
+ *          axis 1 (transform along M, fourier_weight[1]): r = b*N + n  (R = B*N lines of length M)
+ */
+#ifndef FFNO_H_
+#define FFNO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFNO_OK 0
+#define FFNO_EINVAL (-1)       /* null pointer / non-positive size */
+#define FFNO_EUNSUPPORTED (-2) /* shape outside the compiled template set */
+#define FFNO_EMODES (-3)       /* modes > L/2+1 (the reference fails with an einsum size error here) */
+
+#define FFNO_MODE_FULL 0       /* grid_2d.py:64-68  */
+#define FFNO_MODE_LOWPASS 1    /* grid_2d.py:69-70  */
+#define FFNO_MODE_NOFOURIER 2  /* grid_2d.py:44-45  */
+
+/* library / build identification ("gfx950", or "emu" for the CPU test build) */
+const char* ffno_build_target(void);
+int ffno_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Twiddle table for a transform of length L (host helper, double precision -> fp32):
+ *   tw_host[j] = cos(2*pi*j/L)/sqrt(L), tw_host[L + j] = sin(2*pi*j/L)/sqrt(L),  j in [0, L)
+ * norm='ortho' of torch.fft.rfft / irfft (grid_2d.py:58,72,76,90) is folded into the table.
+ * The caller uploads it once per L and passes the device copy as `tw`.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_twiddle_fill_host(float* tw_host, int L);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage A -- truncated forward real DFT along one axis.
+ * Replaces: rearrange 'b m n i -> b i m n' + torch.fft.rfft(x, dim, norm='ortho')[..., :K]
+ *           (grid_2d.py:52,58,67 / :76,85).  Never materialises the L/2+1-bin spectrum.
+ * scale_ck = 1 multiplies row k by c_k (1 for DC/Nyquist, 2 otherwise): the adjoint of the
+ *           zero-padded irfft, used by the backward pass.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_dft_fwd(const float* x, float* spec, const float* tw, int B, int M, int N, int C, int K,
+                 int axis, int scale_ck, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fourier-weight repack: w[I][O][K][2] (the reference parameter layout, grid_2d.py:26) ->
+ * mode-major planes wp[K][2][I][O] and the transposed copy wpt[K][2][O][I] (for the backward mix).
+ * --------------------------------------------------------------------------------------------- */
+int ffno_fw_pack(const float* w, float* wp, float* wpt, int C, int K, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage B -- per-mode complex channel mix on R lines.
+ * Replaces: torch.einsum("bixy,ioy->boxy" | "bixy,iox->boxy", X[..:K], view_as_complex(W))
+ *           (grid_2d.py:65-68, 83-86).
+ *   conj_transpose = 0:  Y[k][r][o] = sum_i X[k][r][i] * W[i][o][k]          (pass planes = wp)
+ *   conj_transpose = 1:  dX[k][r][i] = sum_o dY[k][r][o] * conj(W[i][o][k])  (pass planes = wpt)
+ * --------------------------------------------------------------------------------------------- */
+int ffno_mode_mix(const float* spec_in, const float* planes, float* spec_out, int R, int C, int K,
+                  int conj_transpose, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage C -- zero-padded inverse real DFT along one axis, with fused accumulate / residual.
+ * Replaces: new_zeros + slice-assign + torch.fft.irfft(out_ft, n=L, dim, norm='ortho') and the
+ *           branch sum `xx + xy` (grid_2d.py:61,65,72,79,83,90,94).  imag(DC) is ignored exactly as
+ *           the C2R transform does.
+ *   out = (accumulate ? out : 0) + (resid ? resid : 0) + iDFT(spec)
+ *   apply_ck = 1: forward semantics (bins k>=1 counted twice); 0: adjoint of the truncated rfft.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_dft_inv(const float* spec, float* out, const float* resid, const float* tw, int B, int M,
+                 int N, int C, int K, int axis, int apply_ck, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fourier-weight gradient:  dW[i][o][k] = sum_r conj(X[k][r][i]) * dY[k][r][o]
+ * (autograd of the einsum above).  Two steps so the result is deterministic:
+ *   partial[s][k][2][I][O]  (+)=  sum over the s-th slice of the R lines     (beta: 0 overwrite, 1 add)
+ *   gw[I][O][K][2]          (+)=  sum_s partial[s]                            (accumulate)
+ * --------------------------------------------------------------------------------------------- */
+int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* partial, int R, int C,
+                         int K, int nsplit, int beta, void* stream);
+int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Operator level: SpectralConv2d.forward_fourier (grid_2d.py:51-99) and its backward, composed of
+ * the stages above over a caller-provided workspace.
+ *   w_y = fourier_weight[0] (last spatial axis), w_x = fourier_weight[1] (first spatial axis)
+ *   mode FULL / LOWPASS.   ws needs ffno_spectral2d_ws_floats() floats.
+ * Backward: gx (+)= d/dx, gw_y/gw_x (+)= d/dW (pass NULL to skip), given gy = dL/dout.
+ * --------------------------------------------------------------------------------------------- */
+size_t ffno_spectral2d_ws_floats(int B, int M, int N, int C, int K);
+int ffno_spectral2d_fwd(const float* x, const float* w_y, const float* w_x, float* out, float* ws,
+                        const float* tw_n, const float* tw_m, int B, int M, int N, int C, int K,
+                        int mode, void* stream);
+int ffno_spectral2d_bwd(const float* x, const float* w_y, const float* w_x, const float* gy,
+                        float* gx, float* gw_y, float* gw_x, float* ws, const float* tw_n,
+                        const float* tw_m, int B, int M, int N, int C, int K, int mode,
+                        int accumulate_gx, int accumulate_gw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Feed-forward  (feedforward.py:13-19 with n_layers=2, dropout=0, no LayerNorm) + residual
+ * (grid_2d.py:169):   out = (resid ? resid : 0) + relu(s W1^T + b1) W2^T + b2
+ *   W1[H][C], b1[H], W2[C][H], b2[C] are the EFFECTIVE weights (after weight-norm).
+ *   h    (optional, [P][H])  : post-ReLU hidden activations, kept for the weight gradient
+ *   mask (optional)          : ReLU sign bits, ffno_ff_mask_words(P,H) uint32 words
+ * out may alias resid.
+ * --------------------------------------------------------------------------------------------- */
+size_t ffno_ff_mask_words(int P, int H);
+int ffno_ff_fwd(const float* s, const float* resid, const float* W1, const float* b1,
+                const float* W2, const float* b2, float* out, float* h, uint32_t* mask, int P,
+                int C, int H, void* stream);
+/* data gradient: dh = (db W2) * relu'(.)  [P][H],  ds = dh W1  [P][C] */
+int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const float* W1, const float* W2,
+                     float* dh, float* ds, int P, int C, int H, void* stream);
+/* weight gradients (two steps, deterministic):
+ *   partial[s] = { dW1[H][C], dW2[C][H], db1[H], db2[C] } over the s-th pixel slice
+ *   then reduce over s into dW1, dW2, db1, db2 (accumulate: 0 overwrite / 1 add)          */
+size_t ffno_ff_wgrad_partial_floats(int C, int H, int nsplit);
+int ffno_ff_bwd_weights_partial(const float* s, const float* db, const float* h, const float* dh,
+                                float* partial, int P, int C, int H, int nsplit, void* stream);
+int ffno_ff_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2,
+                               int C, int H, int nsplit, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight normalisation (linear.py:48-49, torch.nn.utils.weight_norm dim=0), batched over a
+ * device-resident descriptor table so one launch covers every linear of the block.
+ *   fwd: w = g * v / ||v||_row          bwd: dg = sum_in dw*v/||v|| ; dv = g/||v|| (dw - dg v/||v||)
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ffno_wn_desc {
+    const float* g;  /* [rows]            (weight_g, stored [rows,1]) */
+    const float* v;  /* [rows][cols]      (weight_v) */
+    float* w;        /* [rows][cols]      effective weight (fwd out) */
+    const float* dw; /* [rows][cols]      gradient w.r.t. the effective weight (bwd in) */
+    float* dg;       /* [rows]            (bwd out) */
+    float* dv;       /* [rows][cols]      (bwd out) */
+    int32_t rows;
+    int32_t cols;
+} ffno_wn_desc;
+int ffno_weightnorm_fwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream);
+int ffno_weightnorm_bwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * in_proj (grid_2d.py:112,157): out[P][C] = x[P][Cin] W^T + b, and its parameter gradients
+ * (deterministic two-step reduction; partial needs nsplit*C*(Cin+1) floats).
+ * --------------------------------------------------------------------------------------------- */
+int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
+                  void* stream);
+int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
+                  int Cin, int C, int nsplit, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Output head (grid_2d.py:150-152,171-172): y[P] = (b W_a^T + c_a) W_b^T + c_b with W_a[D][C],
+ * W_b[1][D] and NO activation in between, evaluated as one affine map  y = b . weff + beff.
+ *   ffno_head_fold : weff[C] = W_b W_a, beff = W_b c_a + c_b           (fold[C+1])
+ *   ffno_head_fwd  : y[p] (+)= b[p] . weff + beff
+ *   ffno_head_bwd  : gb[p][c] = gy[p]*weff[c];  red[C+1] = { sum_p gy[p] b[p][:],  sum_p gy[p] }
+ *   ffno_head_param_grads : dW_a, dc_a, dW_b, dc_b from red (exact chain rule of the two linears)
+ * --------------------------------------------------------------------------------------------- */
+int ffno_head_fold(const float* Wa, const float* ca, const float* Wb, const float* cb, float* fold,
+                   int C, int D, void* stream);
+int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int accumulate,
+                  void* stream);
+int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
+                  float* red, int P, int C, int nsplit, void* stream);
+int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,
+                          float* dWa, float* dca, float* dWb, float* dcb, int C, int D,
+                          int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Relative-L2 loss (loss.py:33-46) and its gradient:
+ *   loss = mean_b ||pred_b - y_b||_2 / ||y_b||_2 ;  gpred = dloss/dpred * gscale
+ * per-sample work buffer `tmp` needs 2*B floats.  loss is written to loss_out[0].
+ * --------------------------------------------------------------------------------------------- */
+int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out, float* gpred,
+                        float* tmp, int B, int n_per_sample, float gscale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused AdamW over one flat parameter buffer (torch.optim.AdamW semantics, config.yaml:36-40):
+ *   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)        with g := grad * grad_scale
+ * --------------------------------------------------------------------------------------------- */
+int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    void* stream);
+
+/* small utilities used by the host driver */
+int ffno_axpy(float* y, const float* x, float alpha, size_t n, void* stream); /* y += alpha*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFNO_H_ */

@@ -1,0 +1,52 @@
+"""Build the CPU wave-emulator flavour of the kernels (TEST INFRASTRUCTURE).
+
+Compiles the *same* sources as the gfx950 library with -DFFNO_EMU against tests/emu/hip_emu.h and
+writes tests/emu/_build/libffno_emu.so.  Only tests load it; the package never does.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "fourierflow_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+LIB = os.path.join(OUT, "libffno_emu.so")
+SOURCES = ["spectral.hip", "ff.hip", "pointwise.hip", "block.hip"]
+
+
+def _cxx():
+    for cand in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("clang++")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("clang++ (ext_vector_type support) not found for the emulator build")
+
+
+def build(verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    h = hashlib.sha256()
+    for p in sorted(srcs + [os.path.join(CSRC, "ffno_device.h"), os.path.join(HERE, "hip_emu.h"),
+                            os.path.join(ROOT, "include", "ffno.h")]):
+        h.update(open(p, "rb").read())
+    stamp = h.hexdigest()
+    sf = LIB + ".stamp"
+    if os.path.exists(LIB) and os.path.exists(sf) and open(sf).read() == stamp:
+        return LIB
+    objs = []
+    for src in srcs:
+        obj = os.path.join(OUT, os.path.basename(src) + ".o")
+        cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-DFFNO_EMU", "-I", HERE, "-I", CSRC,
+               "-I", os.path.join(ROOT, "include"), "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-psabi", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([_cxx(), "-shared", "-fPIC", "-o", LIB, *objs])
+    open(sf, "w").write(stamp)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

@@ -1,0 +1,274 @@
+// Minimal HIP-on-CPU shim -- TEST INFRASTRUCTURE ONLY (never built into the shipped library).
+//
+// Lets the *actual* kernel sources under fourierflow_amd/csrc/ be compiled with a host
+// compiler (-DFFNO_EMU) and executed lane-by-lane on the CPU so that index math, MFMA fragment
+// layouts, LDS addressing and barrier placement can be checked against the oracle without a GPU.
+//
+// Execution model: workgroups run one after another; every thread of a workgroup is a ucontext
+// fiber; __syncthreads() and the wave-level exchange ops (MFMA, shuffles) are rendezvous points
+// at which a fiber yields to a round-robin scheduler.  Fibers are resumed in a rotating order so
+// missing barriers have a chance to show up as wrong results.
+//
+// MFMA lane maps follow /opt/skills/guides/cdna_hip_programming.md section 3:
+//   v_mfma_f32_32x32x2_f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31],
+//                            D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+//   v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15, row=4*(l>>4)+r
+// A GPU self-test (tests/test_gpu_mfma_layout.py) checks the hardware against the same maps.
+#pragma once
+#include <ucontext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float a, float b) { return float2{a, b}; }
+static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
+static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+static const hipError_t hipSuccess = 0;
+static inline hipError_t hipGetLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+static const int hipMemcpyDeviceToDevice = 3;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace emu {
+
+struct Fiber {
+    ucontext_t ctx;
+    dim3 tid;
+    unsigned linear;
+    bool done;
+};
+
+struct WaveX {  // per-wave exchange state (double-buffered by parity)
+    float a[2][64], b[2][64];
+    int arrived;
+    unsigned gen;
+    int parity;
+};
+
+struct State {
+    dim3 blockIdx_, blockDim_, gridDim_;
+    Fiber* cur = nullptr;
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    std::vector<char> stacks;
+    std::vector<WaveX> waves;
+    std::vector<char> dyn_smem;
+    std::function<void()> body;
+    int wg_arrived = 0;
+    unsigned wg_gen = 0;
+    unsigned nthreads = 0;
+    unsigned long long n_switch = 0;
+};
+
+inline State& S() {
+    static State s;
+    return s;
+}
+
+static const size_t kStack = 128 * 1024;
+
+inline void yield() {
+    State& s = S();
+    s.n_switch++;
+    swapcontext(&s.cur->ctx, &s.sched);
+}
+
+inline void trampoline() {
+    State& s = S();
+    s.body();
+    s.cur->done = true;
+    swapcontext(&s.cur->ctx, &s.sched);
+}
+
+inline void wg_barrier() {
+    State& s = S();
+    unsigned gen = s.wg_gen;
+    if (++s.wg_arrived == (int)s.nthreads) {
+        s.wg_arrived = 0;
+        s.wg_gen++;
+        return;
+    }
+    while (s.wg_gen == gen) yield();
+}
+
+inline WaveX& my_wave() { return S().waves[S().cur->linear >> 6]; }
+
+inline void wave_barrier(WaveX& w) {
+    unsigned gen = w.gen;
+    if (++w.arrived == 64) {
+        w.arrived = 0;
+        w.gen++;
+        return;
+    }
+    while (w.gen == gen) yield();
+}
+
+// exchange one (a, b) pair across the wave; returns the parity slot that holds this round's data
+inline int wave_exchange(float a, float b) {
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int p = w.parity;
+    w.a[p][lane] = a;
+    w.b[p][lane] = b;
+    wave_barrier(w);
+    // the last arriver flipped nothing yet: flip lazily, exactly once per round
+    // (every lane sees the same p because parity is only advanced after all have read `p`)
+    return p;
+}
+
+inline void wave_exchange_done(int p) {
+    // every lane calls this after consuming slot p; the first one to do so flips parity.
+    WaveX& w = my_wave();
+    if (w.parity == p) w.parity = p ^ 1;
+}
+
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    int p = wave_exchange(a, b);
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int j = lane & 31, half = lane >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float acc = c[r];
+        acc = fmaf(w.a[p][i], w.b[p][j], acc);            // k = 0
+        acc = fmaf(w.a[p][i + 32], w.b[p][j + 32], acc);  // k = 1
+        d[r] = acc;
+    }
+    wave_exchange_done(p);
+    return d;
+}
+
+inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
+    int p = wave_exchange(a, b);
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int j = lane & 15, q = lane >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * q + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.a[p][i + 16 * k], w.b[p][j + 16 * k], acc);
+        d[r] = acc;
+    }
+    wave_exchange_done(p);
+    return d;
+}
+
+inline float shfl(float v, int src_lane) {
+    int p = wave_exchange(v, 0.f);
+    float r = my_wave().a[p][src_lane & 63];
+    wave_exchange_done(p);
+    return r;
+}
+
+template <class F>
+inline void run_grid(dim3 grid, dim3 block, size_t smem, F&& body) {
+    State& s = S();
+    s.nthreads = block.x * block.y * block.z;
+    if (s.nthreads % 64 != 0 || s.nthreads > 1024) {
+        fprintf(stderr, "emu: block size %u unsupported\n", s.nthreads);
+        abort();
+    }
+    s.blockDim_ = block;
+    s.gridDim_ = grid;
+    s.fibers.resize(s.nthreads);
+    if (s.stacks.size() < kStack * s.nthreads) s.stacks.resize(kStack * s.nthreads);
+    s.waves.assign(s.nthreads / 64, WaveX());
+    s.dyn_smem.assign(smem + 64, 0);
+    s.body = body;
+    unsigned rot = 0;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                s.blockIdx_ = dim3(bx, by, bz);
+                s.wg_arrived = 0;
+                for (auto& w : s.waves) { w.arrived = 0; w.parity = 0; }
+                for (unsigned t = 0; t < s.nthreads; ++t) {
+                    Fiber& f = s.fibers[t];
+                    f.linear = t;
+                    f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                    f.done = false;
+                    getcontext(&f.ctx);
+                    f.ctx.uc_stack.ss_sp = s.stacks.data() + kStack * t;
+                    f.ctx.uc_stack.ss_size = kStack;
+                    f.ctx.uc_link = nullptr;
+                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                }
+                unsigned remaining = s.nthreads;
+                while (remaining) {
+                    unsigned progressed = 0;
+                    // rotate the start wave each sweep so wave ordering assumptions are exposed
+                    unsigned nw = s.nthreads / 64;
+                    rot = (rot + 1) % nw;
+                    for (unsigned wi = 0; wi < nw; ++wi) {
+                        unsigned wv = (wi + rot) % nw;
+                        for (unsigned l = 0; l < 64; ++l) {
+                            Fiber& f = s.fibers[wv * 64 + l];
+                            if (f.done) continue;
+                            s.cur = &f;
+                            swapcontext(&s.sched, &f.ctx);
+                            progressed++;
+                            if (f.done) remaining--;
+                        }
+                    }
+                    if (!progressed) break;
+                }
+            }
+    s.cur = nullptr;
+}
+
+}  // namespace emu
+
+#define threadIdx (emu::S().cur->tid)
+#define blockIdx (emu::S().blockIdx_)
+#define blockDim (emu::S().blockDim_)
+#define gridDim (emu::S().gridDim_)
+
+static inline void __syncthreads() { emu::wg_barrier(); }
+static inline float __shfl_xor(float v, int mask) { return emu::shfl(v, (emu::S().cur->linear & 63) ^ mask); }
+static inline float __shfl_down(float v, int d) {
+    int l = emu::S().cur->linear & 63;
+    return emu::shfl(v, l + d > 63 ? l : l + d);
+}
+static inline float __shfl(float v, int src) { return emu::shfl(v, src); }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+using std::max;
+using std::min;
+
+// kernel launch: hipLaunchKernelGGL(kernel, grid, block, smem, stream, args...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define hipLaunchKernelGGL(kernel, grid, block, smem, stream, ...) \
+    emu::run_grid((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
