@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Benchmark of the F-FNO hot path on MI355X: training steps/s of torus_li/markov/24_layers.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One *step* = forward + relative-L2 loss + backward + (gradient all-reduce over RCCL when N > 1) +
+fused AdamW/cosine update on one batch of synthetic N(0,1) inputs already resident in HBM -- the
+reference's `Grid2DMarkovExperiment._training_step` + `optimize_manually`
+(routines/grid_2d_markov.py:172-193, routines/base.py:27-52) for the model of
+experiments/torus_li/markov/24_layers/config.yaml (modes 16, width 64, 24 layers, shared Fourier
+weights, factor 4, weight-norm), fp32, per-GPU batch 32 (weak scaling: global batch = 32 * N).
+
+Prints ONE JSON line (rank 0).  `value` = whole-node training steps/s = N * K / T, where every rank
+runs K steps of per-GPU batch 32 and T is the max over ranks of the barrier-bracketed wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MARKOV24 = dict(modes=16, width=64, n_layers=24, input_dim=3, share_weight=True, factor=4, ff_weight_norm=True,
+                gain=0.1, dropout=0.0, in_dropout=0.0)
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+class KernelTimer:
+    """HIP-event timing of selected launches on the stream they are enqueued on (torch's current stream)."""
+
+    def __init__(self, names, every=1):
+        self.names = set(names)
+        self.pairs = {n: [] for n in names}
+        self._open = {}
+        self.enabled = False
+        self.count = {n: 0 for n in names}
+        self.every = every
+
+    def want(self, name):
+        if not self.enabled or name not in self.names:
+            return False
+        self.count[name] += 1
+        return self.count[name] % self.every == 0
+
+    def start(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self._open[name] = ev
+
+    def stop(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        self.pairs[name].append((self._open.pop(name), ev))
+
+    def summary(self):
+        out = {}
+        for n, prs in self.pairs.items():
+            if prs:
+                ms = [a.elapsed_time(b) for a, b in prs]
+                out[n] = dict(avg_us=1e3 * sum(ms) / len(ms), samples=len(ms), launches_per_sample=self.every)
+        return out
+
+
+def algorithmic_work(P, C, H, K, B, M, N):
+    """Algorithmic FLOPs / bytes per launch of the timed kernels."""
+    R0, R1 = B * M, B * N
+    return {
+        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=4.0 * (2 * P * C + P * H + P * C)),
+        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=4.0 * (2 * P * C + P * H)),
+        "ff_bwd_weights_partial": dict(flops=4.0 * P * C * H, bytes=4.0 * (2 * P * C + 2 * P * H)),
+        "mode_mix": dict(flops=8.0 * R0 * K * C * C, bytes=4.0 * (2 * K * R0 * 2 * C)),
+        "dft_fwd": dict(flops=2.0 * R0 * (2 * K) * N * C, bytes=4.0 * (P * C + K * R0 * 2 * C)),
+        "dft_inv": dict(flops=2.0 * R0 * (2 * K) * N * C, bytes=4.0 * (2 * P * C + K * R0 * 2 * C)),
+    }
+
+
+def cpu_baseline(batch, grid, steps, kw):
+    """The oracle (op-for-op CPU torch restatement of the reference, certified against its golden
+    vectors) timed on this box's host cores: same model, batch and synthetic data distribution."""
+    from oracle import ffno_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = orc.init_block_state_dict(modes=kw["modes"], width=kw["width"], input_dim=kw["input_dim"],
+                                   n_layers=kw["n_layers"], share_weight=kw["share_weight"], factor=kw["factor"],
+                                   ff_weight_norm=kw["ff_weight_norm"], gain=kw["gain"], seed=0)
+    uniq, seen = [], {}
+    for k, v in sd.items():
+        if id(v) not in seen:
+            seen[id(v)] = v.requires_grad_(True)
+            uniq.append(v)
+    opt = torch.optim.AdamW(uniq, lr=2.5e-3, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: orc.cosine_warmup_factor(s, 500, 100000, 0.5))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(batch, grid, grid, kw["input_dim"], generator=g)
+    y = torch.randn(batch, grid, grid, 1, generator=g)
+
+    def step():
+        opt.zero_grad()
+        out = orc.ffno2d_block(sd, x, modes=kw["modes"], n_layers=kw["n_layers"])["forecast"]
+        loss = orc.lp_rel_loss(out, y)
+        loss.backward()
+        opt.step()
+        sch.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dt = (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.ffno2d_block(sd, x, modes=kw["modes"], n_layers=kw["n_layers"])
+        fwd = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit="steps/s", cores=torch.get_num_threads(), kind="port",
+                ms_per_forward=1e3 * fwd,
+                sample=f"oracle (CPU torch restatement of the reference op sequence) train step, same model, "
+                       f"batch {batch}, {grid}x{grid}, fp32: 1 warm-up + {steps} timed steps")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--modes", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 disables)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.trainer import FFNOTrainer
+
+    kw = dict(MARKOV24, n_layers=args.layers, modes=args.modes)
+    torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
+    block = FNOFactorized2DBlock(**kw).to(dev)
+    trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
+    B, G = args.batch, args.grid
+    gen = torch.Generator().manual_seed(1000 + rank)  # rank r draws its own shard of the global batch
+    x = torch.randn(B, G, G, kw["input_dim"], generator=gen).to(dev)
+    y = torch.randn(B, G, G, 1, generator=gen).to(dev)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(x, y)
+    names = ["ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial", "mode_mix", "dft_fwd", "dft_inv"]
+    timer = KernelTimer(names, every=8) if rank == 0 else None   # sample 1 launch in 8: negligible overhead
+    trainer.engine.timer = timer
+    if timer:
+        timer.enabled = True
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(x, y)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if timer:
+        timer.enabled = False
+    trainer.engine.timer = None
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    loss_val = float(loss.item())
+
+    # forward-only latency (the reference's `infer` path), same batch
+    for _ in range(2):
+        trainer.predict(x)
+    sync()
+    t1 = time.perf_counter()
+    nf = max(5, args.steps)
+    for _ in range(nf):
+        trainer.predict(x)
+    sync()
+    ms_fwd = 1e3 * (time.perf_counter() - t1) / nf
+
+    if rank == 0:
+        P = B * G * G
+        C, H, K = kw["width"], kw["width"] * kw["factor"], kw["modes"]
+        work = algorithmic_work(P, C, H, K, B, G, G)
+        ksum = timer.summary()
+        kernels = {}
+        for n, srow in ksum.items():
+            w = work[n]
+            us = srow["avg_us"]
+            kernels[n] = dict(avg_us=round(us, 2), tflops=round(w["flops"] / us * 1e-6, 2),
+                              gbs=round(w["bytes"] / us * 1e-3, 1), samples=srow["samples"])
+        # dominant kernel = largest share of the step (launch counts per step: FF kernels 24, spectral 48 fwd+48 bwd...)
+        per_step = {"ff_fwd": 24, "ff_bwd_data": 24, "ff_bwd_weights_partial": 24, "mode_mix": 96, "dft_fwd": 96,
+                    "dft_inv": 96}
+        scale = args.layers / 24.0
+        dom = max(kernels, key=lambda n: kernels[n]["avg_us"] * per_step[n] * scale) if kernels else None
+        roofline = None
+        if dom:
+            ach = kernels[dom]["tflops"]
+            roofline = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            avg_launch_us=kernels[dom]["avg_us"],
+                            note="algorithmic fp32 FLOPs per launch / HIP-event launch time; PMC traffic in profiles/")
+        cpu = None
+        if world == 1 and args.cpu_steps > 0:
+            cpu = cpu_baseline(B, G, args.cpu_steps, kw)
+        steps_per_s = world * args.steps / elapsed
+        out = {
+            "metric": "training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)",
+            "value": round(steps_per_s, 3), "unit": "steps/s (per-GPU batch %d, summed over ranks)" % B,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic N(0,1) inputs/targets, reference-init weights",
+            "config": {"workload": "torus_li/markov/24_layers train step: FNOFactorized2DBlock(modes=%d,width=64,"
+                                   "n_layers=%d,input_dim=3,share_weight,factor=4,weight_norm) %dx%d, fp32"
+                                   % (K, args.layers, G, G),
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "optimizer": "AdamW(lr 2.5e-3, wd 1e-4) + cosine warm-up, fused flat kernel",
+                       "collective": "1 x all_reduce(flat fp32 grads, %d floats) / step" % trainer.pflat.numel()},
+            "samples_per_s": round(steps_per_s * B, 1), "ms_per_forward": round(ms_fwd, 3),
+            "final_loss": round(loss_val, 5),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

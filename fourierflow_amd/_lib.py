@@ -1,0 +1,84 @@
+"""Loader of the gfx950 C-ABI library (fourierflow_amd/lib/libffno_hip.so).
+
+There is NO CPU fallback: if the HIP library cannot be loaded every operator raises.  (The tests can
+install the CPU wave-emulator build of the *same kernel sources* through ``_install_test_backend`` --
+that hook is only ever called from tests/ and is never consulted otherwise.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+from . import _capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libffno_hip.so")
+
+_lock = threading.Lock()
+_lib = None
+_test_backend = None
+
+
+class FFNOLibraryError(RuntimeError):
+    pass
+
+
+def get_lib() -> ctypes.CDLL:
+    """The bound C-ABI library; builds it with hipcc on first use if the .so is absent."""
+    global _lib
+    if _test_backend is not None:
+        return _test_backend
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                try:
+                    from . import build as _build
+                    _build.build(verbose=False)
+                except Exception as e:  # noqa: BLE001
+                    raise FFNOLibraryError(
+                        f"libffno_hip.so is missing and could not be built ({e}). Run "
+                        f"`python -m fourierflow_amd.build` (needs hipcc, ROCm >= 7.0). "
+                        f"There is no CPU fallback for the F-FNO operators.") from e
+            try:
+                lib = ctypes.CDLL(LIB_PATH)
+            except OSError as e:
+                raise FFNOLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+            _capi.bind(lib)
+            if lib.ffno_build_target() != b"gfx950":
+                raise FFNOLibraryError(f"{LIB_PATH} is not a gfx950 build")
+            _lib = lib
+    return _lib
+
+
+def is_test_backend() -> bool:
+    return _test_backend is not None
+
+
+def _install_test_backend(lib):
+    """tests/ only: route the host code to the CPU wave-emulator build of the kernel sources."""
+    global _test_backend
+    _test_backend = lib
+
+
+def current_stream(device) -> int:
+    """hipStream_t of torch's current stream on ``device`` (0 for the emulator backend)."""
+    if _test_backend is not None:
+        return 0
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_device_tensor(t, what: str):
+    import torch
+    if _test_backend is not None:
+        if t.is_cuda:
+            raise FFNOLibraryError("emulator backend takes CPU tensors")
+    elif not t.is_cuda:
+        raise FFNOLibraryError(
+            f"{what}: expected a tensor on an MI355X (cuda) device, got {t.device}. "
+            f"The fourierflow_amd operators are HIP-only; there is no CPU path.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{what}: expected float32, got {t.dtype}")

@@ -1,0 +1,46 @@
+"""WNLinear -- parameter container mirroring the reference's ``fourierflow.modules.WNLinear``
+(fourierflow/modules/linear.py:41-52: nn.Linear + torch.nn.utils.weight_norm, dim=0).
+
+Same constructor, same parameter names (``weight_g`` [out,1], ``weight_v`` [out,in], ``bias`` -- or
+``weight``/``bias`` without weight-norm) and the same initialisation (nn.Linear's kaiming-uniform,
+g = ||v|| per row), so reference checkpoints load with strict=True.  The arithmetic
+(W = g v/||v||, y = x W^T + b and its gradients) runs inside the HIP kernels of the owning block;
+a WNLinear is never evaluated on its own.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+
+class WNLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None, dtype=None,
+                 wnorm: bool = False):
+        super().__init__()
+        self.in_features, self.out_features, self.wnorm = in_features, out_features, wnorm
+        w = torch.empty(out_features, in_features, device=device, dtype=dtype or torch.float32)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        if bias:
+            bound = 1.0 / math.sqrt(in_features) if in_features > 0 else 0.0
+            self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=w.dtype).uniform_(-bound, bound))
+        else:
+            raise NotImplementedError("bias=False is not part of the F-FNO hot path")
+        if wnorm:
+            self.weight_g = nn.Parameter(w.norm(2, dim=1, keepdim=True))
+            self.weight_v = nn.Parameter(w)
+        else:
+            self.weight = nn.Parameter(w)
+
+    def effective_weight(self) -> torch.Tensor:
+        """W = g * v / ||v||_row (plain torch; diagnostics only -- the hot path uses ffno_weightnorm_fwd)."""
+        if not self.wnorm:
+            return self.weight
+        return self.weight_v * (self.weight_g / self.weight_v.norm(2, dim=1, keepdim=True))
+
+    def forward(self, x):  # pragma: no cover - deliberate
+        raise NotImplementedError(
+            "WNLinear is evaluated inside the fused HIP kernels of its parent block (lift / feed-forward / head); "
+            "it has no standalone forward in fourierflow_amd.")
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, wnorm={self.wnorm}"

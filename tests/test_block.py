@@ -1,0 +1,107 @@
+"""Whole-block host logic (engine + module mirror + autograd glue) against the golden vectors produced
+by the imported reference -- on the CPU wave-emulator build of the kernels (-m "not gpu") and on the
+MI355X through the shipped gfx950 library (-m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from backend_util import host_device, rel_l2  # noqa: F401
+from oracle import ffno_oracle as orc
+
+
+
+def build_block(kw, seed, device):
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    blk = FNOFactorized2DBlock(**kw)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in gu.make_block_state_dict(kw, seed).items()}
+    if gu.full_kwargs(kw)["mode"] != "full" and not gu.full_kwargs(kw)["share_weight"]:
+        pass
+    blk.load_state_dict(sd, strict=True)
+    return blk.to(device)
+
+
+TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64_nofourier", "c32_nown",
+        "c64_4l_markov", "c64_24l_markov"]
+GPU_ONLY = {"c64_4l_markov", "c64_24l_markov"}  # too slow for the CPU emulator
+
+
+@pytest.mark.parametrize("tag", TAGS)
+def test_block_forward_backward_vs_reference_golden(tag, host_device):
+    if host_device == "cpu" and tag in GPU_ONLY:
+        pytest.skip("emulator too slow for this size; runs with -m gpu")
+    g = gu.load_golden("block_" + tag)
+    kw = gu.golden_kwargs(g)
+    B, M, N, seed = [int(v) for v in g["meta"]]
+    blk = build_block(kw, seed, host_device)
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
+    out = blk(torch.from_numpy(x_np).to(host_device))
+    pred = out["forecast"]
+    assert out["forecast_list"] == []
+    assert gu.compare_packed(g, "forecast", pred.detach().cpu().numpy(), 1e-5) < 1e-5
+    loss = orc.lp_rel_loss(pred, torch.from_numpy(t_np).to(host_device))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    loss.backward()
+    named = dict(blk.named_parameters())
+    for n in [k for k in gu.packed_names(g) if k.startswith("grad.")]:
+        p = named[n[5:]]
+        assert p.grad is not None, n
+        err = gu.compare_packed(g, n, p.grad.cpu().numpy(), 1e-5)
+        assert err < 5e-5, (n, err)
+
+
+def test_state_dict_keys_match_reference_layout():
+    kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    for extra in (dict(), dict(share_fork=True), dict(share_weight=False, ff_weight_norm=False)):
+        k = {**kw, **extra}
+        blk = FNOFactorized2DBlock(**k)
+        ref = gu.make_block_state_dict(k, 0)
+        assert set(blk.state_dict().keys()) == set(ref.keys())
+        for name, v in blk.state_dict().items():
+            assert tuple(v.shape) == ref[name].shape, name
+        # init statistics follow the reference's rules
+        if k["ff_weight_norm"]:
+            lin = blk.in_proj
+            assert torch.allclose(lin.weight_g[:, 0], lin.weight_v.norm(dim=1), rtol=1e-5)
+
+
+def test_unsupported_options_fail_loudly():
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    base = dict(modes=4, width=64, input_dim=3, n_layers=2, factor=4)
+    for bad in (dict(use_fork=True), dict(layer_norm=True), dict(n_ff_layers=3), dict(dropout=0.1), dict(in_dropout=0.1)):
+        with pytest.raises(NotImplementedError):
+            FNOFactorized2DBlock(**{**base, **bad})
+    with pytest.raises(ValueError):
+        FNOFactorized2DBlock(**{**base, "width": 48}).engine()
+
+
+def test_cpu_tensor_without_hip_library_path_raises():
+    """Product path: CPU tensors are refused (no CPU fallback)."""
+    from fourierflow_amd import _lib
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    assert not _lib.is_test_backend()
+    blk = FNOFactorized2DBlock(modes=4, width=64, input_dim=3, n_layers=1, factor=4)
+    with pytest.raises(_lib.FFNOLibraryError):
+        blk(torch.zeros(1, 8, 8, 3))
+
+
+def test_standalone_ops_spectral_and_ff(host_device):
+    from fourierflow_amd.modules.factorized_fno.grid_2d import SpectralConv2d
+    torch.manual_seed(0)
+    conv = SpectralConv2d(64, 64, 3, None, None, None, factor=2, ff_weight_norm=True, n_ff_layers=2,
+                          layer_norm=False, use_fork=False, dropout=0.0, mode="full").to(host_device)
+    x = torch.randn(1, 8, 10, 64, device=host_device, requires_grad=True)
+    b, f = conv(x)
+    assert f is None
+    b.sum().backward()
+    # oracle on the same weights
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in conv.state_dict().items()}
+    xo = x.detach().cpu().clone().requires_grad_(True)
+    s = orc.forward_fourier(xo, sd["fourier_weight.0"], sd["fourier_weight.1"], 3)
+    bo = orc.feedforward(sd, "backcast_ff.", s)
+    bo.sum().backward()
+    assert rel_l2(b.detach().cpu().numpy(), bo.detach().numpy()) < 1e-5
+    assert rel_l2(x.grad.cpu().numpy(), xo.grad.numpy()) < 1e-5
+    for n, p in conv.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), sd[n].grad.numpy()) < 2e-5, n
