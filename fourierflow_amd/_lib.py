@@ -42,6 +42,10 @@ def get_lib() -> ctypes.CDLL:
                         f"libffno_hip.so is missing and could not be built ({e}). Run "
                         f"`python -m fourierflow_amd.build` (needs hipcc, ROCm >= 7.0). "
                         f"There is no CPU fallback for the F-FNO operators.") from e
+            # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the
+            # system one).  It MUST be loaded first so this library binds to the runtime that owns
+            # torch's streams and allocations; two runtimes in one process = hipErrorNoDevice.
+            import torch  # noqa: F401
             try:
                 lib = ctypes.CDLL(LIB_PATH)
             except OSError as e:

@@ -419,7 +419,7 @@ extern "C" int ffno_ff_fwd(const float* s, const float* resid, const float* W1, 
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                         \
     if (C == CC && H == HH) {                                                                                \
-        hipLaunchKernelGGL((ff_fwd_kernel<CC, HH, NW>), grid, block, 0,                                      \
+        FFNO_LAUNCH((ff_fwd_kernel<CC, HH, NW>), grid, block, 0,                                      \
                            st, s, resid, W1, b1, W2, b2, out, h, mask, P);                                   \
         return ff_launch_status();                                                                           \
     }
@@ -437,7 +437,7 @@ extern "C" int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const flo
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                              \
     if (C == CC && H == HH) {                                                                                     \
-        hipLaunchKernelGGL((ff_bwd_data_kernel<CC, HH, NW>), grid, block, 0,                                      \
+        FFNO_LAUNCH((ff_bwd_data_kernel<CC, HH, NW>), grid, block, 0,                                      \
                            st, db, mask, W1, W2, dh, ds, P);                                                      \
         return ff_launch_status();                                                                                \
     }
@@ -458,7 +458,7 @@ extern "C" int ffno_ff_bwd_weights_partial(const float* s, const float* db, cons
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \
-        hipLaunchKernelGGL((ff_bwd_weights_partial_kernel<CC, HH>), dim3(nsplit), dim3(FFWgCfg<CC, HH>::NW * 64), 0, \
+        FFNO_LAUNCH((ff_bwd_weights_partial_kernel<CC, HH>), dim3(nsplit), dim3(FFWgCfg<CC, HH>::NW * 64), 0, \
                            st, s, db, h, dh, partial, P, chunk);                                                   \
         return ff_launch_status();                                                                                 \
     }
@@ -471,7 +471,7 @@ extern "C" int ffno_ff_bwd_weights_reduce(const float* partial, float* dW1, floa
                                           int C, int H, int nsplit, int accumulate, void* stream) {
     if (!partial || !dW1 || !dW2 || !db1 || !db2 || nsplit <= 0) return FFNO_EINVAL;
     const int part = 2 * H * C + H + C;
-    hipLaunchKernelGGL(ff_bwd_weights_reduce_kernel, dim3((part + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    FFNO_LAUNCH(ff_bwd_weights_reduce_kernel, dim3((part + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        partial, dW1, dW2, db1, db2, C, H, nsplit, accumulate);
     return ff_launch_status();
 }

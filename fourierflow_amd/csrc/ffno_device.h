@@ -24,6 +24,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #include <stdint.h>
 
+// Every launch first clears any stale (non-sticky) error another HIP user of the process left behind
+// (e.g. PyTorch probing a capability), so the status a C-ABI entry point returns belongs to OUR launch.
+#define FFNO_LAUNCH(...)              \
+    do {                              \
+        (void)hipGetLastError();      \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 namespace ffno {
 
 static constexpr int kWave = 64;

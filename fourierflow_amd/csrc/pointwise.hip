@@ -329,12 +329,12 @@ extern "C" int ffno_twiddle_fill_host(float* tw_host, int L) {
 
 extern "C" int ffno_weightnorm_fwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream) {
     if (!descs_dev || n <= 0 || max_rows <= 0) return FFNO_EINVAL;
-    hipLaunchKernelGGL(wn_fwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    FFNO_LAUNCH(wn_fwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
     return pw_status();
 }
 extern "C" int ffno_weightnorm_bwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream) {
     if (!descs_dev || n <= 0 || max_rows <= 0) return FFNO_EINVAL;
-    hipLaunchKernelGGL(wn_bwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    FFNO_LAUNCH(wn_bwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
     return pw_status();
 }
 
@@ -347,9 +347,9 @@ extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, flo
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        hipLaunchKernelGGL((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin);
+        FFNO_LAUNCH((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin);
     else if (C == 32)
-        hipLaunchKernelGGL((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin);
+        FFNO_LAUNCH((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
@@ -362,15 +362,15 @@ extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, 
     const int chunk = (P + nsplit - 1) / nsplit;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        hipLaunchKernelGGL((lift_bwd_partial_kernel<64>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<64>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
     else if (C == 32)
-        hipLaunchKernelGGL((lift_bwd_partial_kernel<32>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<32>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
     if (rc) return rc;
     const int npairs = C * (Cin + 1);
-    hipLaunchKernelGGL(lift_bwd_reduce_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, partial, dW, db, Cin, C,
+    FFNO_LAUNCH(lift_bwd_reduce_kernel, dim3((npairs + 255) / 256), dim3(256), 0, s, partial, dW, db, Cin, C,
                        nsplit, accumulate);
     return pw_status();
 }
@@ -378,7 +378,7 @@ extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, 
 extern "C" int ffno_head_fold(const float* Wa, const float* ca, const float* Wb, const float* cb, float* fold,
                               int C, int D, void* stream) {
     if (!Wa || !ca || !Wb || !cb || !fold || C <= 0 || D <= 0 || C > 255) return FFNO_EINVAL;
-    hipLaunchKernelGGL(head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Wa, ca, Wb, cb, fold, C, D);
+    FFNO_LAUNCH(head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Wa, ca, Wb, cb, fold, C, D);
     return pw_status();
 }
 
@@ -389,9 +389,9 @@ extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P,
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        hipLaunchKernelGGL((head_fwd_kernel<64>), grid, block, 0, s, b, fold, y, P, accumulate);
+        FFNO_LAUNCH((head_fwd_kernel<64>), grid, block, 0, s, b, fold, y, P, accumulate);
     else if (C == 32)
-        hipLaunchKernelGGL((head_fwd_kernel<32>), grid, block, 0, s, b, fold, y, P, accumulate);
+        FFNO_LAUNCH((head_fwd_kernel<32>), grid, block, 0, s, b, fold, y, P, accumulate);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
@@ -402,14 +402,14 @@ extern "C" int ffno_head_bwd(const float* b, const float* gy, const float* fold,
     if (!b || !gy || !fold || !partial || !red || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        hipLaunchKernelGGL((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
+        FFNO_LAUNCH((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
     else if (C == 32)
-        hipLaunchKernelGGL((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
+        FFNO_LAUNCH((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
     if (rc) return rc;
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(1), dim3(128), 0, s, partial, red, C, nsplit);
+    FFNO_LAUNCH(head_bwd_reduce_kernel, dim3(1), dim3(128), 0, s, partial, red, C, nsplit);
     return pw_status();
 }
 
@@ -417,7 +417,7 @@ extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const fl
                                      float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int accumulate,
                                      void* stream) {
     if (!red || !Wa || !ca || !Wb || !dWa || !dca || !dWb || !dcb) return FFNO_EINVAL;
-    hipLaunchKernelGGL(head_param_grads_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, red, Wa, ca, Wb, dWa, dca,
+    FFNO_LAUNCH(head_param_grads_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, red, Wa, ca, Wb, dWa, dca,
                        dWb, dcb, C, D, accumulate);
     return pw_status();
 }
@@ -426,11 +426,11 @@ extern "C" int ffno_lploss_fwd_bwd(const float* pred, const float* target, float
                                    float* tmp, int B, int n_per_sample, float gscale, void* stream) {
     if (!pred || !target || !tmp || B <= 0 || n_per_sample <= 0) return FFNO_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lploss_reduce_kernel, dim3(B), dim3(256), 0, s, pred, target, tmp, n_per_sample);
+    FFNO_LAUNCH(lploss_reduce_kernel, dim3(B), dim3(256), 0, s, pred, target, tmp, n_per_sample);
     int rc = pw_status();
     if (rc) return rc;
     const int gx = max(1, min((n_per_sample + 255) / 256, 64));
-    hipLaunchKernelGGL(lploss_grad_kernel, dim3(gx, B), dim3(256), 0, s, pred, target, tmp, loss_out, gpred, B,
+    FFNO_LAUNCH(lploss_grad_kernel, dim3(gx, B), dim3(256), 0, s, pred, target, tmp, loss_out, gpred, B,
                        n_per_sample, gscale);
     return pw_status();
 }
@@ -442,7 +442,7 @@ extern "C" int ffno_adamw_flat(float* p, const float* g, float* m, float* v, siz
     const float bc1 = 1.f - (float)pow((double)beta1, (double)step);
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     const unsigned blocks = (unsigned)min((n + 255) / 256, (size_t)2048);
-    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
+    FFNO_LAUNCH(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
                        eps, weight_decay, bc1, bc2s, grad_scale);
     return pw_status();
 }
@@ -450,6 +450,6 @@ extern "C" int ffno_adamw_flat(float* p, const float* g, float* m, float* v, siz
 extern "C" int ffno_axpy(float* y, const float* x, float alpha, size_t n, void* stream) {
     if (!y || !x || n == 0) return FFNO_EINVAL;
     const unsigned blocks = (unsigned)min((n + 255) / 256, (size_t)2048);
-    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
+    FFNO_LAUNCH(axpy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, x, alpha, n);
     return pw_status();
 }

@@ -458,7 +458,7 @@ extern "C" int ffno_dft_fwd(const float* x, float* spec, const float* tw, int B,
     hipStream_t s = (hipStream_t)stream;
 #define FFNO_DFT_FWD_CASE(CC, RR)                                                                        \
     if (C == CC && RT == RR) {                                                                           \
-        hipLaunchKernelGGL((dft_fwd_kernel<CC, RR>), grid, block, smem, s, x, spec, tw, R, L, K, lm, scale_ck); \
+        FFNO_LAUNCH((dft_fwd_kernel<CC, RR>), grid, block, smem, s, x, spec, tw, R, L, K, lm, scale_ck); \
         return launch_status();                                                                          \
     }
     FFNO_DFT_FWD_CASE(64, 1)
@@ -484,10 +484,10 @@ extern "C" int ffno_dft_inv(const float* spec, float* out, const float* resid, c
     const size_t smem = sizeof(float) * 2 * L;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64) {
-        hipLaunchKernelGGL((dft_inv_kernel<64>), grid, block, smem, s, spec, out, resid, tw, R, L, K, lm, apply_ck,
+        FFNO_LAUNCH((dft_inv_kernel<64>), grid, block, smem, s, spec, out, resid, tw, R, L, K, lm, apply_ck,
                            accumulate);
     } else if (C == 32) {
-        hipLaunchKernelGGL((dft_inv_kernel<32>), grid, block, smem, s, spec, out, resid, tw, R, L, K, lm, apply_ck,
+        FFNO_LAUNCH((dft_inv_kernel<32>), grid, block, smem, s, spec, out, resid, tw, R, L, K, lm, apply_ck,
                            accumulate);
     } else {
         return FFNO_EUNSUPPORTED;
@@ -498,7 +498,7 @@ extern "C" int ffno_dft_inv(const float* spec, float* out, const float* resid, c
 extern "C" int ffno_fw_pack(const float* w, float* wp, float* wpt, int C, int K, void* stream) {
     if (!w || !wp || !wpt || C <= 0 || K <= 0) return FFNO_EINVAL;
     const long total = (long)C * C * K * 2;
-    hipLaunchKernelGGL(fw_pack_kernel, dim3((unsigned)min((total + 255) / 256, 1024L)), dim3(256), 0,
+    FFNO_LAUNCH(fw_pack_kernel, dim3((unsigned)min((total + 255) / 256, 1024L)), dim3(256), 0,
                        (hipStream_t)stream, w, wp, wpt, C, K);
     return launch_status();
 }
@@ -513,9 +513,9 @@ extern "C" int ffno_mode_mix(const float* spec_in, const float* planes, float* s
     const dim3 grid(chunks, K), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        hipLaunchKernelGGL((mode_mix_kernel<64>), grid, block, 0, s, spec_in, planes, spec_out, R, K, conj_transpose);
+        FFNO_LAUNCH((mode_mix_kernel<64>), grid, block, 0, s, spec_in, planes, spec_out, R, K, conj_transpose);
     else
-        hipLaunchKernelGGL((mode_mix_kernel<32>), grid, block, 0, s, spec_in, planes, spec_out, R, K, conj_transpose);
+        FFNO_LAUNCH((mode_mix_kernel<32>), grid, block, 0, s, spec_in, planes, spec_out, R, K, conj_transpose);
     return launch_status();
 }
 
@@ -528,9 +528,9 @@ extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, f
     const dim3 grid(nsplit, K), block(C * 4);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        hipLaunchKernelGGL((fw_grad_partial_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
+        FFNO_LAUNCH((fw_grad_partial_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
     else
-        hipLaunchKernelGGL((fw_grad_partial_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
+        FFNO_LAUNCH((fw_grad_partial_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
     return launch_status();
 }
 
@@ -538,7 +538,7 @@ extern "C" int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K
                                    void* stream) {
     if (!partial || !gw || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
     const long total = (long)C * C * K * 2;
-    hipLaunchKernelGGL(fw_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 2048L)), dim3(256), 0,
+    FFNO_LAUNCH(fw_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 2048L)), dim3(256), 0,
                        (hipStream_t)stream, partial, gw, C, K, nsplit, accumulate);
     return launch_status();
 }

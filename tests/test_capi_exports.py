@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  (its bundled HIP runtime must be the one our library binds to)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

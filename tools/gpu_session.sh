@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprof.  Logs go to gpurun_out/ (merged back).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+STAGES="${1:-test smoke bench prof}"
+rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu_info.log
+nproc >> gpurun_out/gpu_info.log
+for st in $STAGES; do
+  case $st in
+    test)
+      timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      echo "[session] pytest -m gpu rc=$?"; tail -n 25 gpurun_out/pytest_gpu.log ;;
+    smoke)
+      timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
+      echo "[session] smoke rc=$?"; tail -n 5 gpurun_out/smoke.log ;;
+    bench)
+      timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2>&1
+      echo "[session] bench rc=$?"; tail -n 3 gpurun_out/bench.log ;;
+    benchfast)
+      timeout 600 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/bench_fast.log 2>&1
+      echo "[session] benchfast rc=$?"; tail -n 3 gpurun_out/bench_fast.log ;;
+    prof)
+      rm -rf gpurun_out/prof
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o ffno -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-steps 0 > "$OLDPWD/gpurun_out/prof.log" 2>&1)
+      echo "[session] rocprof rc=$?"; tail -n 2 gpurun_out/prof.log
+      find gpurun_out/prof -name "*kernel_stats*" | head -3
+      f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
+      [ -n "$f" ] && head -n 25 "$f" | cut -c1-200
+      # keep the merge-back small: drop the per-dispatch trace, keep stats
+      find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
+  esac
+done
