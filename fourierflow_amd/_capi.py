@@ -19,6 +19,11 @@ class WnDesc(C.Structure):
                 ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class TrDesc(C.Structure):
+    """Mirror of ``ffno_tr_desc`` (include/ffno.h)."""
+    _fields_ = [("src", P), ("dst", P), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 SIGNATURES = {
     "ffno_build_target": (C.c_char_p, []),
     "ffno_abi_version": (I, []),
@@ -40,6 +45,7 @@ SIGNATURES = {
     "ffno_ff_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),
+    "ffno_transpose_batched": (I, [P, I, I, I, P]),
     "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P]),
     "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "ffno_head_fold": (I, [P, P, P, P, P, I, I, P]),

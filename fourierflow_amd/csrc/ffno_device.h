@@ -14,12 +14,17 @@
 #include "hip_emu.h"
 #define FFNO_DYN_SMEM(name) char* name = (char*)(((uintptr_t)emu::S().dyn_smem.data() + 63) & ~(uintptr_t)63)
 #define FFNO_UNROLL
+#define FFNO_NOUNROLL
+#define FFNO_SCHED_FENCE() ((void)0)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FFNO_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define FFNO_UNROLL _Pragma("unroll")
+#define FFNO_NOUNROLL _Pragma("unroll 1")
+// bounds live ranges: stops the scheduler from hoisting a whole unrolled loop's operand loads
+#define FFNO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 #include <stdint.h>

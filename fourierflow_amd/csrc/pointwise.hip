@@ -49,6 +49,20 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const ffno_wn_desc* __restr
     for (int c = lane; c < d.cols; c += 64) dv[c] = g * inv * (dw[c] - dg * inv * v[c]);
 }
 
+// ---- batched transpose (effective weights -> transposed copies for the backward chain kernel) --------
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const ffno_tr_desc* __restrict__ descs) {
+    __shared__ float tile[32][33];
+    const ffno_tr_desc d = descs[blockIdx.z];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (c0 >= d.cols || r0 >= d.rows) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int yy = ty; yy < 32; yy += 8)
+        if (r0 + yy < d.rows && c0 + tx < d.cols) tile[yy][tx] = d.src[(long)(r0 + yy) * d.cols + c0 + tx];
+    __syncthreads();
+    for (int yy = ty; yy < 32; yy += 8)
+        if (c0 + yy < d.cols && r0 + tx < d.rows) d.dst[(long)(c0 + yy) * d.rows + r0 + tx] = tile[tx][yy];
+}
+
 // ---- lift (in_proj) -----------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
@@ -335,6 +349,13 @@ extern "C" int ffno_weightnorm_fwd(const ffno_wn_desc* descs_dev, int n, int max
 extern "C" int ffno_weightnorm_bwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream) {
     if (!descs_dev || n <= 0 || max_rows <= 0) return FFNO_EINVAL;
     FFNO_LAUNCH(wn_bwd_kernel, dim3((max_rows + 3) / 4, n), dim3(256), 0, (hipStream_t)stream, descs_dev);
+    return pw_status();
+}
+
+extern "C" int ffno_transpose_batched(const ffno_tr_desc* descs_dev, int n, int max_rows, int max_cols, void* stream) {
+    if (!descs_dev || n <= 0 || max_rows <= 0 || max_cols <= 0) return FFNO_EINVAL;
+    FFNO_LAUNCH(transpose_batched_kernel, dim3((max_cols + 31) / 32, (max_rows + 31) / 32, n), dim3(256), 0,
+                (hipStream_t)stream, descs_dev);
     return pw_status();
 }
 

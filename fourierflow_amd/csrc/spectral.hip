@@ -258,32 +258,50 @@ __global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // ---- stage B ------------------------------------------------------------------------------------
 // Block = (mode k, chunk of row tiles); 4 waves, each owns one 32-line tile at a time.
 // D[line][(q,o)] = sum_{(p,i)} X[line][(p,i)] * Wb[(p,i)][(q,o)]  with the 2x2 real block form of the
-// complex product.  A operand = staged X tile (LDS, row stride 2C+1 -> conflict-free column reads),
-// B operand = the mode's weight planes (LDS, lanes read consecutive floats).
+// complex product.  A operand: each lane keeps its line's C floats of part `half` (re or im) in
+// registers, loaded straight from global memory with 16-B loads (the [lines][2C] panel of a mode is
+// contiguous, every byte of every fetched line is used).  B operand: the mode's two weight planes in
+// LDS (32 KiB at C=64), lanes read consecutive floats (conflict-free).
 template <int C>
-__global__ __launch_bounds__(256) void mode_mix_kernel(const float* __restrict__ spec_in,
+__global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restrict__ spec_in,
                                                        const float* __restrict__ planes,
                                                        float* __restrict__ spec_out, int R, int K,
                                                        int conj_t) {
     constexpr int CT = C / 32;
-    constexpr int LDA = 2 * C + 1;
-    __shared__ __attribute__((aligned(16))) float smem_mix[2 * C * C + 4 * 32 * LDA];
+    __shared__ __attribute__((aligned(16))) float smem_mix[2 * C * C];
     float* Wr = smem_mix;
     float* Wi = Wr + C * C;
-    float* stage = Wi + C * C;
 
     const int k = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
-    {
-        const float* pk = planes + (long)k * 2 * C * C;
-        for (int i = threadIdx.x; i < 2 * C * C; i += blockDim.x) Wr[i] = pk[i];
-    }
-    float* st = stage + wave * 32 * LDA;
     const float* xin = spec_in + (long)k * R * 2 * C;
     float* yout = spec_out + (long)k * R * 2 * C;
+    const int ntiles = (R + 31) >> 5;
+    int tile = blockIdx.x * 4 + wave;
 
-    // per-lane plane selection / sign of the real block form (see header comment of ffno_mode_mix)
+    // first tile's A fragment is requested before the weight planes are staged (latencies overlap)
+    float a[C];
+    {
+        const int row = tile * 32 + j;
+        FFNO_UNROLL
+        for (int u = 0; u < C / 4; ++u) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tile < ntiles && row < R) v = *reinterpret_cast<const float4*>(xin + ((long)row * 2 + half) * C + 4 * u);
+            a[4 * u + 0] = v.x;
+            a[4 * u + 1] = v.y;
+            a[4 * u + 2] = v.z;
+            a[4 * u + 3] = v.w;
+        }
+    }
+    {
+        const float* pk = planes + (long)k * 2 * C * C;
+        for (int i = threadIdx.x * 4; i < 2 * C * C; i += blockDim.x * 4)
+            *reinterpret_cast<float4*>(Wr + i) = *reinterpret_cast<const float4*>(pk + i);
+    }
+    __syncthreads();
+
+    // per-lane plane selection / sign of the real block form (see ffno_mode_mix in include/ffno.h)
     const float* plane[2];
     float sign[2];
     FFNO_UNROLL
@@ -295,45 +313,39 @@ __global__ __launch_bounds__(256) void mode_mix_kernel(const float* __restrict__
             sign[q] = (half == 0 && q == 1) ? -1.f : 1.f;
     }
 
-    const int ntiles = (R + 31) >> 5;
-    const int tiles_per_iter = gridDim.x * 4;
-    const int niter = (ntiles + tiles_per_iter - 1) / tiles_per_iter;
-    for (int it = 0; it < niter; ++it) {
-        const int tile = it * tiles_per_iter + blockIdx.x * 4 + wave;
+    for (; tile < ntiles; tile += gridDim.x * 4) {
         const int row0 = tile * 32;
-        __syncthreads();  // previous iteration's reads of `st` are done (also covers the weight load)
-        // stage the [32][2C] panel (contiguous in global memory) with coalesced 16-B loads
-        FFNO_UNROLL
-        for (int u = 0; u < (32 * 2 * C) / (64 * 4); ++u) {
-            const int e = 4 * (lane + 64 * u);
-            const int row = e / (2 * C), col = e % (2 * C);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row0 + row < R) v = *reinterpret_cast<const float4*>(xin + (long)(row0 + row) * 2 * C + col);
-            float* d = st + row * LDA + col;
-            d[0] = v.x;
-            d[1] = v.y;
-            d[2] = v.z;
-            d[3] = v.w;
-        }
-        __syncthreads();
         f32x16 acc[2][CT];
         FFNO_UNROLL
         for (int q = 0; q < 2; ++q) {
             FFNO_UNROLL
             for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
         }
-#ifndef FFNO_EMU
-#pragma unroll 4
-#endif
+        FFNO_UNROLL
         for (int t = 0; t < C; ++t) {
-            const float a = st[j * LDA + C * half + t];
+            if ((t & 7) == 0) FFNO_SCHED_FENCE();
             FFNO_UNROLL
             for (int q = 0; q < 2; ++q) {
                 FFNO_UNROLL
                 for (int ct = 0; ct < CT; ++ct) {
                     const float b = sign[q] * plane[q][t * C + 32 * ct + j];
-                    acc[q][ct] = mfma32(a, b, acc[q][ct]);
+                    acc[q][ct] = mfma32(a[t], b, acc[q][ct]);
                 }
+            }
+        }
+        FFNO_SCHED_FENCE();
+        // next tile's fragment (if any) is in flight while this tile's results are stored
+        {
+            const int nrow = (tile + gridDim.x * 4) * 32 + j;
+            const bool more = (tile + gridDim.x * 4) < ntiles;
+            FFNO_UNROLL
+            for (int u = 0; u < C / 4; ++u) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (more && nrow < R) v = *reinterpret_cast<const float4*>(xin + ((long)nrow * 2 + half) * C + 4 * u);
+                a[4 * u + 0] = v.x;
+                a[4 * u + 1] = v.y;
+                a[4 * u + 2] = v.z;
+                a[4 * u + 3] = v.w;
             }
         }
         FFNO_UNROLL
@@ -373,10 +385,10 @@ __global__ __launch_bounds__(C * 4) void fw_grad_partial_kernel(const float* __r
     FFNO_UNROLL
     for (int b = 0; b < CT; ++b) acc[b] = zero16();
     const int nsteps = (max(rend - rbeg, 0) + 1) >> 1;
-    for (int t0 = 0; t0 < nsteps; t0 += 2) {
-        float xr[2], xi[2], dyr[2][CT], dyi[2][CT];
+    for (int t0 = 0; t0 < nsteps; t0 += 4) {
+        float xr[4], xi[4], dyr[4][CT], dyi[4][CT];
         FFNO_UNROLL
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const int row = rbeg + 2 * (t0 + u) + half;
             const bool valid = row < rend;
             xr[u] = xi[u] = 0.f;
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(C * 4) void fw_grad_partial_kernel(const float* __r
             }
         }
         FFNO_UNROLL
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
             FFNO_UNROLL
             for (int b = 0; b < CT; ++b) {
                 if (part == 0) {

@@ -32,12 +32,13 @@ def _p(t: Optional[torch.Tensor]):
 
 
 class _Linear:
-    __slots__ = ("prefix", "rows", "cols", "wnorm", "weff", "gweff")
+    __slots__ = ("prefix", "rows", "cols", "wnorm", "weff", "gweff", "wt")
 
     def __init__(self, prefix, rows, cols, wnorm):
         self.prefix, self.rows, self.cols, self.wnorm = prefix, rows, cols, wnorm
-        self.weff = None
-        self.gweff = None
+        self.weff = None   # effective weight [rows, cols] (after weight-norm)
+        self.gweff = None  # gradient w.r.t. the effective weight
+        self.wt = None     # transposed effective weight [cols, rows] (feed-forward linears only; backward)
 
 
 class FFNO2DEngine:
@@ -145,6 +146,8 @@ class FFNO2DEngine:
         self.weff_flat = torch.empty(max(n_eff, 1), dtype=torch.float32, device=dev)
         self.gweff_flat = torch.zeros(max(n_eff, 1), dtype=torch.float32, device=dev)
         self.fold = torch.zeros(self.C + 1, dtype=torch.float32, device=dev)
+        n_ff = sum(l.rows * l.cols for p, l in self.linears.items() if "_ff." in p)
+        self.wt_flat = torch.empty(max(n_ff, 1), dtype=torch.float32, device=dev)
         n_sets = len({n for n in self.fw_names})
         self._fw_sets = []  # unique (name_y, name_x) in first-use order
         for names in self.fw_names:
@@ -181,6 +184,17 @@ class FFNO2DEngine:
                 lin.weff = self.params[lin.prefix + "weight"]
                 lin.gweff = self.grad_view(lin.prefix + "weight")
         self._n_desc = len(descs)
+        toff, tdescs = 0, []
+        for pfx, lin in self.linears.items():
+            if "_ff." not in pfx:
+                continue
+            n = lin.rows * lin.cols
+            lin.wt = self.wt_flat[toff:toff + n].view(lin.cols, lin.rows)
+            toff += n
+            tdescs.append(_capi.TrDesc(lin.weff.data_ptr(), lin.wt.data_ptr(), lin.rows, lin.cols))
+        self._n_tr = len(tdescs)
+        arr = (_capi.TrDesc * len(tdescs))(*tdescs)
+        self._tr_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
         self._max_rows = max([l.rows for l in self.linears.values()])
         if descs:
             arr = (_capi.WnDesc * len(descs))(*descs)
@@ -323,12 +337,13 @@ class FFNO2DEngine:
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                                               _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")),
                                               C, HEAD_DIM, 0, st)
+        self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen, fw_seen = set(), set()
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
-            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.G), _p(ws.MASK[l]), _p(l0.weff), _p(l1.weff), _p(ws.DH), _p(ws.DS),
+            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.G), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(ws.DH), _p(ws.DS),
                                              P, C, H, st)
             self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(ws.G), _p(ws.Hbuf[l]), _p(ws.DH), _p(ws.ffpart),
                                                         P, C, H, ws.nsplit_ff, st)

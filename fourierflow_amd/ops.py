@@ -133,7 +133,8 @@ class _FeedForwardFn(torch.autograd.Function):
         gout = gout.contiguous()
         dh = torch.empty(P, H, dtype=torch.float32, device=s.device)
         ds = torch.empty_like(s)
-        _capi.check(lib.ffno_ff_bwd_data(_p(gout), _p(mask), _p(W1), _p(W2), _p(dh), _p(ds), P, C, H, st), "ff_bwd_data")
+        W1t, W2t = W1.t().contiguous(), W2.t().contiguous()
+        _capi.check(lib.ffno_ff_bwd_data(_p(gout), _p(mask), _p(W1t), _p(W2t), _p(dh), _p(ds), P, C, H, st), "ff_bwd_data")
         nsplit = max(1, min(256, (P + 127) // 128))
         part = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit)), dtype=torch.float32, device=s.device)
         _capi.check(lib.ffno_ff_bwd_weights_partial(_p(s), _p(gout), _p(h), _p(dh), _p(part), P, C, H, nsplit, st),

@@ -127,8 +127,10 @@ size_t ffno_ff_mask_words(int P, int H);
 int ffno_ff_fwd(const float* s, const float* resid, const float* W1, const float* b1,
                 const float* W2, const float* b2, float* out, float* h, uint32_t* mask, int P,
                 int C, int H, void* stream);
-/* data gradient: dh = (db W2) * relu'(.)  [P][H],  ds = dh W1  [P][C] */
-int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const float* W1, const float* W2,
+/* data gradient: dh = (db W2) * relu'(.)  [P][H],  ds = dh W1  [P][C].
+ * Takes the TRANSPOSED effective weights W1t[C][H] = W1^T and W2t[H][C] = W2^T (see
+ * ffno_transpose_batched) so both GEMM operands are row-contiguous in LDS, like the forward. */
+int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const float* W1t, const float* W2t,
                      float* dh, float* ds, int P, int C, int H, void* stream);
 /* weight gradients (two steps, deterministic):
  *   partial[s] = { dW1[H][C], dW2[C][H], db1[H], db2[C] } over the s-th pixel slice
@@ -156,6 +158,16 @@ typedef struct ffno_wn_desc {
 } ffno_wn_desc;
 int ffno_weightnorm_fwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream);
 int ffno_weightnorm_bwd(const ffno_wn_desc* descs_dev, int n, int max_rows, void* stream);
+
+/* Batched 2-D transpose dst[cols][rows] = src[rows][cols]^T over a device-resident descriptor table
+ * (one launch produces every W^T the backward pass needs). */
+typedef struct ffno_tr_desc {
+    const float* src;
+    float* dst;
+    int32_t rows;
+    int32_t cols;
+} ffno_tr_desc;
+int ffno_transpose_batched(const ffno_tr_desc* descs_dev, int n, int max_rows, int max_cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * in_proj (grid_2d.py:112,157): out[P][C] = x[P][Cin] W^T + b, and its parameter gradients

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from backend_util import be, rel_l2  # noqa: F401
-from fourierflow_amd._capi import WnDesc
+from fourierflow_amd._capi import TrDesc, WnDesc
 
 TOL = 1e-5
 
@@ -50,7 +50,8 @@ def test_ff_fwd_bwd(be, P, C, H):
     # backward (data)
     db = rs.standard_normal((P, C)).astype(np.float32)
     ddb, dh, ds = be.put(db), be.empty((P, H)), be.empty((P, C))
-    assert lib.ffno_ff_bwd_data(p(ddb), p(mask), p(dW1_), p(dW2_), p(dh), p(ds), P, C, H, None) == 0
+    dW1t, dW2t = be.put(W1.T.copy()), be.put(W2.T.copy())   # the backward chain takes the transposed weights
+    assert lib.ffno_ff_bwd_data(p(ddb), p(mask), p(dW1t), p(dW2t), p(dh), p(ds), P, C, H, None) == 0
     ref_dh = (db.astype(np.float64) @ W2.astype(np.float64)) * (ref_h > 0)
     ref_ds = ref_dh @ W1.astype(np.float64)
     assert rel_l2(be.get(dh), ref_dh) < TOL
@@ -101,6 +102,20 @@ def test_weightnorm_batched(be):
         rdg = (dw64 * v64 / nrm).sum(1)
         assert rel_l2(be.get(d[4]), rdg) < TOL
         assert rel_l2(be.get(d[5]), g[:, None] / nrm * (dw64 - rdg[:, None] * v64 / nrm)) < TOL
+
+
+def test_transpose_batched(be):
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(4)
+    shapes = [(256, 64), (64, 256), (33, 70), (1, 5)]
+    src = [rs.standard_normal(sh).astype(np.float32) for sh in shapes]
+    dsrc = [be.put(a) for a in src]
+    ddst = [be.empty((sh[1], sh[0])) for sh in shapes]
+    descs = (TrDesc * len(shapes))(*[TrDesc(p(a), p(b), sh[0], sh[1]) for a, b, sh in zip(dsrc, ddst, shapes)])
+    table = be.put(np.frombuffer(bytes(descs), dtype=np.uint8))
+    assert lib.ffno_transpose_batched(p(table), len(shapes), 256, 256, None) == 0
+    for a, b in zip(src, ddst):
+        np.testing.assert_array_equal(be.get(b), a.T)
 
 
 @pytest.mark.parametrize("P,Cin,C", [(100, 3, 64), (77, 5, 32), (50, 37, 64)])
