@@ -34,6 +34,8 @@ SIGNATURES = {
     "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
+    "ffno_spectral_fused_supported": (I, [I, I, I]),
+    "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),
     "ffno_spectral2d_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_spectral2d_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),

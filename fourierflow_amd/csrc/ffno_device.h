@@ -49,6 +49,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 #endif
 }
 
+// v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D reg r = D[4*(l>>4) + r][l & 15]
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+#ifdef FFNO_EMU
+    return emu::mfma_16x16x4(a, b, c);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
     FFNO_UNROLL

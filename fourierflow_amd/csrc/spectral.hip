@@ -362,6 +362,237 @@ __global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restric
     }
 }
 
+// ---- fused branch: stage A -> B -> C with the spectrum tile resident in LDS ---------------------------
+// One workgroup (8 waves) owns 8 lines of one axis:
+//   phase 1  wave w: truncated DFT of line w (as dft_fwd)        -> XS[line][kk = 2k+ri][c]  (LDS)
+//                                                                 (+ optional copy of the spectrum to HBM
+//                                                                    for the weight gradient)
+//   phase 2  wave w: modes k = w, w+8, ..: per-mode channel mix IN PLACE on XS.  Rows of the MFMA tile
+//            are (line, re/im) pairs, so 8 lines fill a 16-row v_mfma_f32_16x16x4_f32 tile and the weight
+//            planes are used as plain real matrices:  P1 = Xrows.Wr, P2 = Xrows.Wi,
+//            Yr = P1[re] - P2[im],  Yi = P2[re] + P1[im]   (adjoint: dXr = P1[re] + P2[im], dXi = P1[im] - P2[re])
+//            B operand (weights) streams from L2 as 16-B loads of full 256-B plane rows.
+//   phase 3  wave w: zero-padded inverse DFT of line w (as dft_inv) from XS, fused accumulate / residual.
+// HBM traffic per branch: read x once, write out once (+ read out when accumulating) -- the spectra of
+// stages A/B never travel.  Supported when 8 * 2K * C floats fit the LDS budget (K <= 16 at C = 64).
+template <int C>
+struct FusedCfg {
+    static constexpr int LINES = 8;
+    static constexpr int KMAX = 1024 / C;            // 2K*C <= 2048 floats per line
+    static constexpr int LSMAX = 2 * KMAX * C + 4;   // line stride (floats), 16-B aligned, breaks bank period
+};
+
+template <int C>
+__global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __restrict__ in, float* out,
+                                                             const float* resid, float* __restrict__ spec_save,
+                                                             const float* __restrict__ planes,
+                                                             const float* __restrict__ tw, int R, int L, int K,
+                                                             LineMap lm, int fwd_ck, int inv_ck, int conj_t,
+                                                             int accumulate) {
+    using F = FusedCfg<C>;
+    constexpr int CT = C / 32;
+    __shared__ __attribute__((aligned(16))) float XS[F::LINES * F::LSMAX];
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = tw[i];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int LS = 2 * K * C + 4;
+    const int line = blockIdx.x * F::LINES + wave;
+    const bool live = line < R;
+    float* xs = XS + wave * LS;
+    __syncthreads();
+
+    // ---------------- phase 1: forward truncated DFT of this wave's line ----------------
+    {
+        const int kk = j, k = kk >> 1, ri = kk & 1;   // A-operand row of this lane (one 32-row tile: 2K <= 32)
+        const bool rowok = kk < 2 * K;
+        const float ck = (fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
+        const int km = rowok ? k : 0;
+        const int step = (2 * km) % L;
+        int idx = (km * half) % L;
+        f32x16 acc[CT];
+        FFNO_UNROLL
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = zero16();
+        if (live) {
+            const float* xl = in + lm.base(line) + CT * j;
+            const int nsteps = (L + 1) >> 1;
+            for (int t0 = 0; t0 < nsteps; t0 += 4) {
+                ColVec<CT> b[4];
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const int n = 2 * (t0 + u) + half;
+                    if (n < L) {
+                        b[u].load(xl + (long)n * lm.elem_stride);
+                    } else {
+                        FFNO_UNROLL
+                        for (int ct = 0; ct < CT; ++ct) b[u].v[ct] = 0.f;
+                    }
+                }
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const float a = amul * tws[tbase + idx];
+                    idx += step;
+                    if (idx >= L) idx -= L;
+                    FFNO_UNROLL
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma32(a, b[u].v[ct], acc[ct]);
+                }
+            }
+        }
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = drow(r, half);
+            if (row < 2 * K) {
+                ColVec<CT> o;
+                FFNO_UNROLL
+                for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[ct][r];
+                o.store(xs + row * C + CT * j);
+                if (spec_save && live) o.store(spec_save + (((long)(row >> 1) * R + line) * 2 + (row & 1)) * C + CT * j);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: per-mode channel mix, in place on XS ----------------
+    if (planes) {
+        // D columns: lane column jo of tile e <-> output channel o = 64*og + 4*jo + e, so one 16-B load per lane
+        // fetches the B values of four column tiles and a wave reads full 256-B plane rows.
+        constexpr int NOG = C / 64;
+        const int io = lane & 15, kq = lane >> 4;       // A row (line, re/im) = io ; B column group = io
+        const float* arow = XS + (io >> 1) * LS + (io & 1) * C + kq;
+        for (int k = wave; k < K; k += F::LINES) {
+            const float* pr = planes + ((long)k * 2 + 0) * C * C;
+            const float* pi = planes + ((long)k * 2 + 1) * C * C;
+            f32x4 p1[NOG][4], p2[NOG][4];
+            FFNO_UNROLL
+            for (int og = 0; og < NOG; ++og) {
+                FFNO_UNROLL
+                for (int e = 0; e < 4; ++e) {
+                    FFNO_UNROLL
+                    for (int r = 0; r < 4; ++r) p1[og][e][r] = p2[og][e][r] = 0.f;
+                }
+            }
+            FFNO_UNROLL
+            for (int t0 = 0; t0 < C / 4; t0 += 4) {
+                float a[4];
+                float4 br[4][NOG], bi[4][NOG];
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const int ic = 4 * (t0 + u) + kq;   // input channel of this lane's B row / A column
+                    a[u] = arow[2 * k * C + 4 * (t0 + u)];
+                    FFNO_UNROLL
+                    for (int og = 0; og < NOG; ++og) {
+                        br[u][og] = *reinterpret_cast<const float4*>(pr + (long)ic * C + 64 * og + 4 * io);
+                        bi[u][og] = *reinterpret_cast<const float4*>(pi + (long)ic * C + 64 * og + 4 * io);
+                    }
+                }
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    FFNO_UNROLL
+                    for (int og = 0; og < NOG; ++og) {
+                        p1[og][0] = mfma16(a[u], br[u][og].x, p1[og][0]);
+                        p1[og][1] = mfma16(a[u], br[u][og].y, p1[og][1]);
+                        p1[og][2] = mfma16(a[u], br[u][og].z, p1[og][2]);
+                        p1[og][3] = mfma16(a[u], br[u][og].w, p1[og][3]);
+                        p2[og][0] = mfma16(a[u], bi[u][og].x, p2[og][0]);
+                        p2[og][1] = mfma16(a[u], bi[u][og].y, p2[og][1]);
+                        p2[og][2] = mfma16(a[u], bi[u][og].z, p2[og][2]);
+                        p2[og][3] = mfma16(a[u], bi[u][og].w, p2[og][3]);
+                    }
+                }
+            }
+            // rows of the D tile: 4*(lane>>4) + r = 2*line + ri  ->  this lane holds lines 2*kq (r = 0,1) and 2*kq+1 (r = 2,3)
+            FFNO_UNROLL
+            for (int ll = 0; ll < 2; ++ll) {
+                float* dst = XS + (2 * kq + ll) * LS + 2 * k * C;
+                FFNO_UNROLL
+                for (int og = 0; og < NOG; ++og) {
+                    float yr[4], yi[4];
+                    FFNO_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        const float p1r = p1[og][e][2 * ll], p1i = p1[og][e][2 * ll + 1];
+                        const float p2r = p2[og][e][2 * ll], p2i = p2[og][e][2 * ll + 1];
+                        if (conj_t == 0) {
+                            yr[e] = p1r - p2i;
+                            yi[e] = p2r + p1i;
+                        } else {
+                            yr[e] = p1r + p2i;
+                            yi[e] = p1i - p2r;
+                        }
+                    }
+                    *reinterpret_cast<float4*>(dst + 64 * og + 4 * io) = make_float4(yr[0], yr[1], yr[2], yr[3]);
+                    *reinterpret_cast<float4*>(dst + C + 64 * og + 4 * io) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 3: zero-padded inverse DFT of this wave's line ----------------
+    if (live) {
+        const float sgn = half ? -1.f : 1.f;
+        const int tbase = half ? L : 0;
+        const int RTtot = (L + 31) >> 5;
+        const long lbase = lm.base(line) + CT * j;
+        for (int rt0 = 0; rt0 < RTtot; rt0 += 2) {
+            const int n0 = 32 * rt0 + j, n1 = n0 + 32;
+            const int st0 = n0 % L, st1 = n1 % L;
+            int i0 = 0, i1 = 0;
+            f32x16 acc[2][CT];
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                FFNO_UNROLL
+                for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
+            }
+            for (int t = 0; t < K; ++t) {
+                const float ck = (inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                ColVec<CT> b;
+                b.load(xs + (2 * t + half) * C + CT * j);
+                const float a0 = sgn * ck * tws[tbase + i0];
+                const float a1 = sgn * ck * tws[tbase + i1];
+                i0 += st0;
+                if (i0 >= L) i0 -= L;
+                i1 += st1;
+                if (i1 >= L) i1 -= L;
+                FFNO_UNROLL
+                for (int ct = 0; ct < CT; ++ct) {
+                    acc[0][ct] = mfma32(a0, b.v[ct], acc[0][ct]);
+                    acc[1][ct] = mfma32(a1, b.v[ct], acc[1][ct]);
+                }
+            }
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int n = 32 * (rt0 + q) + drow(r, half);
+                    if (n < L) {
+                        const long a = lbase + (long)n * lm.elem_stride;
+                        ColVec<CT> o;
+                        FFNO_UNROLL
+                        for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[q][ct][r];
+                        if (accumulate) {
+                            ColVec<CT> p;
+                            p.load(out + a);
+                            FFNO_UNROLL
+                            for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
+                        }
+                        if (resid) {
+                            ColVec<CT> p;
+                            p.load(resid + a);
+                            FFNO_UNROLL
+                            for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
+                        }
+                        o.store(out + a);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- Fourier weight gradient ----------------------------------------------------------------------
 // Block = (mode k, line slice); wave w -> (part = real/imag of dW, a = 32-row tile of the input channel i).
 //   dWr[i][o] = sum_r Xr[r][i] dYr[r][o] + Xi[r][i] dYi[r][o]
@@ -552,6 +783,29 @@ extern "C" int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K
     const long total = (long)C * C * K * 2;
     FFNO_LAUNCH(fw_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 2048L)), dim3(256), 0,
                        (hipStream_t)stream, partial, gw, C, K, nsplit, accumulate);
+    return launch_status();
+}
+
+
+extern "C" int ffno_spectral_fused_supported(int C, int K, int L) {
+    if (C == 64) return K <= FusedCfg<64>::KMAX && L <= 4096 ? 1 : 0;
+    return 0;
+}
+
+extern "C" int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
+                                   const float* planes, const float* tw, int B, int M, int N, int C, int K, int axis,
+                                   int scale_ck_fwd, int apply_ck_inv, int conj_transpose, int accumulate,
+                                   void* stream) {
+    if (!in || !out || !tw || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1)) return FFNO_EINVAL;
+    const int L = axis == 0 ? N : M;
+    const int R = axis == 0 ? B * M : B * N;
+    if (K > L / 2 + 1) return FFNO_EMODES;
+    if (!ffno_spectral_fused_supported(C, K, L)) return FFNO_EUNSUPPORTED;
+    const LineMap lm = make_linemap(axis, B, M, N, C);
+    const dim3 grid((R + 7) / 8), block(512);
+    const size_t smem = sizeof(float) * 2 * L;
+    FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
+                tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
     return launch_status();
 }
 

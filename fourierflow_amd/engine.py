@@ -102,6 +102,7 @@ class FFNO2DEngine:
         self._ws_key = None
         self._tw: Dict[int, torch.Tensor] = {}
         self._saved = None
+        self.use_fused = True   # fused A->B->C branch kernel when (C, K, L) fits its LDS tile; else 3 stage kernels
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
 
     def _k(self, name, fn, *args):
@@ -288,6 +289,8 @@ class FFNO2DEngine:
         P = ws.P
         self._prepare_weights(st)
         tw = (self._twiddle(N), self._twiddle(M))
+        fused = (self.use_fused and self.mode != "no-fourier" and
+                 all(lib.ffno_spectral_fused_supported(C, K, Lx) for Lx in (N, M)))
         lin_in = self.linears["in_proj."]
         self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), P, self.Cin, C, st)
         for l in range(L):
@@ -299,10 +302,16 @@ class FFNO2DEngine:
             else:
                 for a in (0, 1):
                     sx = ws.SX[sv][a]
+                    si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
+                    if fused:
+                        self._k("spectral_fused", lib.ffno_spectral_fused, _p(ws.X), _p(s_l), None,
+                                _p(sx) if (save_for_backward and self.mode == "full") else None,
+                                _p(self.planes[si, a, 0]) if self.mode == "full" else None, _p(tw[a]),
+                                B, M, N, C, K, a, 0, 1, 0, int(a == 1), st)
+                        continue
                     self._k("dft_fwd", lib.ffno_dft_fwd, _p(ws.X), _p(sx), _p(tw[a]), B, M, N, C, K, a, 0, st)
                     y = sx
                     if self.mode == "full":
-                        si = self._fw_sets.index(self.fw_names[l])
                         self._k("mode_mix", lib.ffno_mode_mix, _p(sx), _p(self.planes[si, a, 0]), _p(ws.SY), ws.R[a], C, K, 0, st)
                         y = ws.SY
                     self._k("dft_inv", lib.ffno_dft_inv, _p(y), _p(s_l), None, _p(tw[a]), B, M, N, C, K, a, 1, int(a == 1), st)
@@ -330,6 +339,8 @@ class FFNO2DEngine:
         st = _lib.current_stream(self.device)
         P = ws.P
         tw = (self._twiddle(N), self._twiddle(M))
+        fused = (self.use_fused and self.mode != "no-fourier" and
+                 all(lib.ffno_spectral_fused_supported(C, K, Lx) for Lx in (N, M)))
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         gv = self.grad_view
         self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G), _p(ws.headpart), _p(ws.red), P, C,
@@ -358,15 +369,24 @@ class FFNO2DEngine:
                     self._k("axpy", lib.ffno_axpy, _p(ws.G), _p(ws.DS), 1.0, P * C, st)
                 continue
             for a in (0, 1):
+                acc = 0 if (last and a == 0) else 1
+                si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
+                if fused:
+                    self._k("spectral_fused(adj)", lib.ffno_spectral_fused, _p(ws.DS), _p(ws.G), None,
+                            _p(ws.SD) if self.mode == "full" else None,
+                            _p(self.planes[si, a, 1]) if self.mode == "full" else None, _p(tw[a]),
+                            B, M, N, C, K, a, 1, 0, 1, acc, st)
+                    if self.mode == "full":
+                        self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SX[l][a]), _p(ws.SD), _p(ws.fwpart[si][a]),
+                                ws.R[a], C, K, ws.nsplit_fw[a], int(si in fw_seen), st)
+                    continue
                 self._k("dft_fwd(adj)", lib.ffno_dft_fwd, _p(ws.DS), _p(ws.SD), _p(tw[a]), B, M, N, C, K, a, 1, st)
                 dxs = ws.SD
                 if self.mode == "full":
-                    si = self._fw_sets.index(self.fw_names[l])
                     self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SX[l][a]), _p(ws.SD), _p(ws.fwpart[si][a]), ws.R[a], C, K,
-                                                         ws.nsplit_fw[a], int(si in fw_seen), st)
+                            ws.nsplit_fw[a], int(si in fw_seen), st)
                     self._k("mode_mix(adj)", lib.ffno_mode_mix, _p(ws.SD), _p(self.planes[si, a, 1]), _p(ws.SY), ws.R[a], C, K, 1, st)
                     dxs = ws.SY
-                acc = 0 if (last and a == 0) else 1
                 self._k("dft_inv(adj)", lib.ffno_dft_inv, _p(dxs), _p(ws.G), None, _p(tw[a]), B, M, N, C, K, a, 0, acc, st)
             if self.mode == "full":
                 fw_seen.add(self._fw_sets.index(self.fw_names[l]))

@@ -100,6 +100,22 @@ int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nspli
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused branch (stage A -> B -> C in ONE launch, the spectrum tile stays in LDS; fast path):
+ *   out = (accumulate ? out : 0) + (resid ? resid : 0) + iDFT_axis( mix( DFT_axis(in) ) )
+ *   planes == NULL skips the mix (mode 'low-pass');  spec_save (optional, spec[k][r][ri][c]) receives
+ *   the stage-A spectrum, which the Fourier-weight gradient needs.
+ *   forward : scale_ck_fwd = 0, apply_ck_inv = 1, conj_transpose = 0, planes = wp
+ *   backward: scale_ck_fwd = 1, apply_ck_inv = 0, conj_transpose = 1, planes = wpt
+ * ffno_spectral_fused_supported() says whether (C, K, L) fits (8 lines x 2K x C floats of LDS);
+ * otherwise use the three stage kernels above.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_spectral_fused_supported(int C, int K, int L);
+int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
+                        const float* planes, const float* tw, int B, int M, int N, int C, int K,
+                        int axis, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
+                        int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Operator level: SpectralConv2d.forward_fourier (grid_2d.py:51-99) and its backward, composed of
  * the stages above over a caller-provided workspace.
  *   w_y = fourier_weight[0] (last spatial axis), w_x = fourier_weight[1] (first spatial axis)

@@ -167,3 +167,76 @@ def test_spectral2d_full_size_golden_and_properties():
     assert lib.ffno_spectral2d_fwd(p(dx), None, None, p(y), p(ws), p(twn), p(twm), B, M, N, C, K, 1, None) == 0
     lp = be.get(y).astype(np.float64)
     assert float((lp * x).sum()) > 0 and np.linalg.norm(lp) <= 2 * np.linalg.norm(x) * (1 + 1e-6)
+
+
+@pytest.mark.parametrize("B,M,N,K", [(1, 8, 12, 3), (2, 6, 10, 5), (1, 20, 64, 16), (1, 13, 9, 4), (3, 5, 7, 2), (2, 16, 32, 8)])
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
+def test_spectral_fused_branch_equals_three_stage_path(be, B, M, N, K, axis, direction):
+    """The fused branch kernel (DFT -> mix -> iDFT in LDS) against fp64 torch.fft, incl. the saved spectrum,
+    ragged line counts (R % 8 != 0), accumulate + residual epilogue, and the adjoint configuration."""
+    C = 64
+    L = N if axis == 0 else M
+    if K > L // 2 + 1:
+        pytest.skip("modes exceed axis")
+    lib, p = be.lib, be.ptr
+    assert lib.ffno_spectral_fused_supported(C, K, L) == 1
+    rs = np.random.RandomState(B + 10 * M + 100 * N + K + axis)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+    R = B * M if axis == 0 else B * N
+    dx, dw, tw = be.put(x), be.put(w), be.twiddle(L)
+    wp, wpt = be.zeros((K, 2, C, C)), be.zeros((K, 2, C, C))
+    assert lib.ffno_fw_pack(p(dw), p(wp), p(wpt), C, K, None) == 0
+    out, spec = be.empty(x.shape), be.empty((K, R, 2, C))
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    planes = None if direction == "lowpass" else (wpt if direction == "adj" else wp)
+    assert lib.ffno_spectral_fused(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, C, K, axis,
+                                   fwd_ck, inv_ck, conj, 0, None) == 0
+    # fp64 reference
+    xt = torch.tensor(x, dtype=torch.float64)
+    dim = 2 if axis == 0 else 1
+    f = torch.fft.rfft(xt, dim=dim, norm="ortho").narrow(dim, 0, K)
+    ck = torch.tensor([1.0 if (k == 0 or 2 * k == L) else 2.0 for k in range(K)], dtype=torch.float64)
+    shape = [1, 1, 1, 1]
+    shape[dim] = K
+    wc = torch.tensor(w[..., 0].astype(np.float64) + 1j * w[..., 1])
+    if direction == "adj":
+        f = f * ck.view(shape)                                    # adjoint of the zero-padded irfft
+        y = torch.einsum("bmko,iok->bmki" if axis == 0 else "bkno,iok->bkni", f, wc.conj())
+    elif direction == "fwd":
+        y = torch.einsum("bmki,iok->bmko" if axis == 0 else "bkni,iok->bkno", f, wc)
+    else:
+        y = f
+    if direction == "adj":                                        # adjoint of the truncated rfft: no c_k, plain sum
+        n = torch.arange(L, dtype=torch.float64)
+        kk = torch.arange(K, dtype=torch.float64)
+        ang = 2 * np.pi * torch.outer(n, kk) / L
+        Gr, Gi = torch.cos(ang) / np.sqrt(L), -torch.sin(ang) / np.sqrt(L)
+        ref = (torch.einsum("nk,bmkc->bmnc", Gr, y.real) + torch.einsum("nk,bmkc->bmnc", Gi, y.imag)) if axis == 0 \
+            else (torch.einsum("nk,bknc->bnkc", Gr, y.real).permute(0, 1, 2, 3) if False else
+                  torch.einsum("mk,bknc->bmnc", Gr, y.real) + torch.einsum("mk,bknc->bmnc", Gi, y.imag))
+    else:
+        full_shape = list(y.shape)
+        full_shape[dim] = L // 2 + 1
+        full = torch.zeros(full_shape, dtype=torch.complex128)
+        full.narrow(dim, 0, K).copy_(y)
+        ref = torch.fft.irfft(full, n=L, dim=dim, norm="ortho")
+    assert rel_l2(be.get(out), ref.numpy()) < TOL
+    # saved spectrum == stage-A output (with the same c_k convention)
+    fs = f.permute(2, 0, 1, 3).reshape(K, R, C) if axis == 0 else f.permute(1, 0, 2, 3).reshape(K, R, C)
+    assert rel_l2(be.get(spec), torch.stack([fs.real, fs.imag], dim=2).numpy()) < TOL
+    # accumulate + residual epilogue, no spectrum save
+    resid = rs.standard_normal(x.shape).astype(np.float32)
+    dres = be.put(resid)
+    assert lib.ffno_spectral_fused(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, C, K, axis,
+                                   fwd_ck, inv_ck, conj, 1, None) == 0
+    assert rel_l2(be.get(out), 2 * ref.numpy() + resid) < TOL
+
+
+def test_spectral_fused_support_matrix(be):
+    assert be.lib.ffno_spectral_fused_supported(64, 16, 64) == 1
+    assert be.lib.ffno_spectral_fused_supported(64, 17, 64) == 0
+    assert be.lib.ffno_spectral_fused_supported(32, 8, 64) == 0
+    x, tw = be.zeros((1, 4, 64, 64)), be.twiddle(64)
+    assert be.lib.ffno_spectral_fused(be.ptr(x), be.ptr(x), None, None, None, be.ptr(tw), 1, 4, 64, 64, 17, 0, 0, 1, 0, 0, None) == -2
