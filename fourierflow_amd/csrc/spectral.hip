@@ -420,10 +420,11 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
         if (live) {
             const float* xl = in + lm.base(line) + CT * j;
             const int nsteps = (L + 1) >> 1;
-            for (int t0 = 0; t0 < nsteps; t0 += 4) {
-                ColVec<CT> b[4];
+            constexpr int UN = 16;   // k-steps whose loads are all in flight together (whole line at L <= 32... 64: two trips)
+            for (int t0 = 0; t0 < nsteps; t0 += UN) {
+                ColVec<CT> b[UN];
                 FFNO_UNROLL
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     const int n = 2 * (t0 + u) + half;
                     if (n < L) {
                         b[u].load(xl + (long)n * lm.elem_stride);
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                     }
                 }
                 FFNO_UNROLL
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     const float a = amul * tws[tbase + idx];
                     idx += step;
                     if (idx >= L) idx -= L;
@@ -463,70 +464,88 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
         constexpr int NOG = C / 64;
         const int io = lane & 15, kq = lane >> 4;       // A row (line, re/im) = io ; B column group = io
         const float* arow = XS + (io >> 1) * LS + (io & 1) * C + kq;
-        for (int k = wave; k < K; k += F::LINES) {
+        // Work list of this wave: modes k = wave, wave+8, ...; each mode = 2 chunks of C/8 k-steps.  The weight
+        // fragments of chunk i+1 are requested (16-B loads of full 256-B plane rows, L2-resident) before chunk i's
+        // MFMAs start: two register buffers in ping-pong, statically indexed.
+        constexpr int HK = C / 8;                      // k-steps per chunk (each k-step = 4 input channels)
+        const int nmodes = (K - wave + F::LINES - 1) / F::LINES;   // modes owned by this wave (K > wave else <= 0)
+        const int nch = nmodes > 0 ? 2 * nmodes : 0;
+        float4 wr0[HK][NOG], wi0[HK][NOG], wr1[HK][NOG], wi1[HK][NOG];
+        f32x4 p1[NOG][4], p2[NOG][4];
+
+        auto load_chunk = [&](float4 (&wr)[HK][NOG], float4 (&wi)[HK][NOG], int ch) {
+            const int k = wave + F::LINES * (ch >> 1), tb = (ch & 1) * HK;
             const float* pr = planes + ((long)k * 2 + 0) * C * C;
             const float* pi = planes + ((long)k * 2 + 1) * C * C;
-            f32x4 p1[NOG][4], p2[NOG][4];
             FFNO_UNROLL
-            for (int og = 0; og < NOG; ++og) {
-                FFNO_UNROLL
-                for (int e = 0; e < 4; ++e) {
-                    FFNO_UNROLL
-                    for (int r = 0; r < 4; ++r) p1[og][e][r] = p2[og][e][r] = 0.f;
-                }
-            }
-            FFNO_UNROLL
-            for (int t0 = 0; t0 < C / 4; t0 += 4) {
-                float a[4];
-                float4 br[4][NOG], bi[4][NOG];
-                FFNO_UNROLL
-                for (int u = 0; u < 4; ++u) {
-                    const int ic = 4 * (t0 + u) + kq;   // input channel of this lane's B row / A column
-                    a[u] = arow[2 * k * C + 4 * (t0 + u)];
-                    FFNO_UNROLL
-                    for (int og = 0; og < NOG; ++og) {
-                        br[u][og] = *reinterpret_cast<const float4*>(pr + (long)ic * C + 64 * og + 4 * io);
-                        bi[u][og] = *reinterpret_cast<const float4*>(pi + (long)ic * C + 64 * og + 4 * io);
-                    }
-                }
-                FFNO_UNROLL
-                for (int u = 0; u < 4; ++u) {
-                    FFNO_UNROLL
-                    for (int og = 0; og < NOG; ++og) {
-                        p1[og][0] = mfma16(a[u], br[u][og].x, p1[og][0]);
-                        p1[og][1] = mfma16(a[u], br[u][og].y, p1[og][1]);
-                        p1[og][2] = mfma16(a[u], br[u][og].z, p1[og][2]);
-                        p1[og][3] = mfma16(a[u], br[u][og].w, p1[og][3]);
-                        p2[og][0] = mfma16(a[u], bi[u][og].x, p2[og][0]);
-                        p2[og][1] = mfma16(a[u], bi[u][og].y, p2[og][1]);
-                        p2[og][2] = mfma16(a[u], bi[u][og].z, p2[og][2]);
-                        p2[og][3] = mfma16(a[u], bi[u][og].w, p2[og][3]);
-                    }
-                }
-            }
-            // rows of the D tile: 4*(lane>>4) + r = 2*line + ri  ->  this lane holds lines 2*kq (r = 0,1) and 2*kq+1 (r = 2,3)
-            FFNO_UNROLL
-            for (int ll = 0; ll < 2; ++ll) {
-                float* dst = XS + (2 * kq + ll) * LS + 2 * k * C;
+            for (int u = 0; u < HK; ++u) {
+                const int ic = 4 * (tb + u) + kq;
                 FFNO_UNROLL
                 for (int og = 0; og < NOG; ++og) {
-                    float yr[4], yi[4];
-                    FFNO_UNROLL
-                    for (int e = 0; e < 4; ++e) {
-                        const float p1r = p1[og][e][2 * ll], p1i = p1[og][e][2 * ll + 1];
-                        const float p2r = p2[og][e][2 * ll], p2i = p2[og][e][2 * ll + 1];
-                        if (conj_t == 0) {
-                            yr[e] = p1r - p2i;
-                            yi[e] = p2r + p1i;
-                        } else {
-                            yr[e] = p1r + p2i;
-                            yi[e] = p1i - p2r;
-                        }
-                    }
-                    *reinterpret_cast<float4*>(dst + 64 * og + 4 * io) = make_float4(yr[0], yr[1], yr[2], yr[3]);
-                    *reinterpret_cast<float4*>(dst + C + 64 * og + 4 * io) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                    wr[u][og] = *reinterpret_cast<const float4*>(pr + (long)ic * C + 64 * og + 4 * io);
+                    wi[u][og] = *reinterpret_cast<const float4*>(pi + (long)ic * C + 64 * og + 4 * io);
                 }
             }
+        };
+        auto compute_chunk = [&](const float4 (&wr)[HK][NOG], const float4 (&wi)[HK][NOG], int ch) {
+            const int k = wave + F::LINES * (ch >> 1), tb = (ch & 1) * HK;
+            if ((ch & 1) == 0) {
+                FFNO_UNROLL
+                for (int og = 0; og < NOG; ++og) {
+                    FFNO_UNROLL
+                    for (int e = 0; e < 4; ++e) {
+                        FFNO_UNROLL
+                        for (int r = 0; r < 4; ++r) p1[og][e][r] = p2[og][e][r] = 0.f;
+                    }
+                }
+            }
+            FFNO_UNROLL
+            for (int u = 0; u < HK; ++u) {
+                const float a = arow[2 * k * C + 4 * (tb + u)];
+                FFNO_UNROLL
+                for (int og = 0; og < NOG; ++og) {
+                    p1[og][0] = mfma16(a, wr[u][og].x, p1[og][0]);
+                    p1[og][1] = mfma16(a, wr[u][og].y, p1[og][1]);
+                    p1[og][2] = mfma16(a, wr[u][og].z, p1[og][2]);
+                    p1[og][3] = mfma16(a, wr[u][og].w, p1[og][3]);
+                    p2[og][0] = mfma16(a, wi[u][og].x, p2[og][0]);
+                    p2[og][1] = mfma16(a, wi[u][og].y, p2[og][1]);
+                    p2[og][2] = mfma16(a, wi[u][og].z, p2[og][2]);
+                    p2[og][3] = mfma16(a, wi[u][og].w, p2[og][3]);
+                }
+            }
+            if (ch & 1) {
+                // rows of the D tile: 4*(lane>>4) + r = 2*line + ri -> this lane holds lines 2*kq (r = 0,1), 2*kq+1 (r = 2,3)
+                FFNO_UNROLL
+                for (int ll = 0; ll < 2; ++ll) {
+                    float* dst = XS + (2 * kq + ll) * LS + 2 * k * C;
+                    FFNO_UNROLL
+                    for (int og = 0; og < NOG; ++og) {
+                        float yr[4], yi[4];
+                        FFNO_UNROLL
+                        for (int e = 0; e < 4; ++e) {
+                            const float p1r = p1[og][e][2 * ll], p1i = p1[og][e][2 * ll + 1];
+                            const float p2r = p2[og][e][2 * ll], p2i = p2[og][e][2 * ll + 1];
+                            if (conj_t == 0) {
+                                yr[e] = p1r - p2i;
+                                yi[e] = p2r + p1i;
+                            } else {
+                                yr[e] = p1r + p2i;
+                                yi[e] = p1i - p2r;
+                            }
+                        }
+                        *reinterpret_cast<float4*>(dst + 64 * og + 4 * io) = make_float4(yr[0], yr[1], yr[2], yr[3]);
+                        *reinterpret_cast<float4*>(dst + C + 64 * og + 4 * io) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                    }
+                }
+            }
+        };
+        if (nch > 0) load_chunk(wr0, wi0, 0);
+        for (int ch = 0; ch < nch; ch += 2) {
+            load_chunk(wr1, wi1, ch + 1);                 // nch is even: chunk ch+1 always exists
+            compute_chunk(wr0, wi0, ch);
+            if (ch + 2 < nch) load_chunk(wr0, wi0, ch + 2);
+            compute_chunk(wr1, wi1, ch + 1);
         }
         __syncthreads();
     }

@@ -240,7 +240,7 @@ class FFNO2DEngine:
             ws.SD = torch.empty(max(spec), **f32)
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
-            ws.nsplit_fw = [max(1, min(max(1, 256 // K), (r + 63) // 64)) for r in ws.R]
+            ws.nsplit_fw = [max(1, min(max(1, 512 // K), (r + 63) // 64)) for r in ws.R]
             plane = 2 * K * C * C
             ws.fwpart = [[torch.empty(ws.nsplit_fw[a] * plane, **f32) for a in (0, 1)]
                          for _ in range(max(len(self._fw_sets), 1))]
