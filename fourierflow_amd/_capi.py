@@ -32,7 +32,7 @@ SIGNATURES = {
     "ffno_fw_pack": (I, [P, P, P, I, I, P]),
     "ffno_mode_mix": (I, [P, P, P, I, I, I, I, P]),
     "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
-    "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, P]),
+    "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),

@@ -616,59 +616,80 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
 // Block = (mode k, line slice); wave w -> (part = real/imag of dW, a = 32-row tile of the input channel i).
 //   dWr[i][o] = sum_r Xr[r][i] dYr[r][o] + Xi[r][i] dYi[r][o]
 //   dWi[i][o] = sum_r Xr[r][i] dYi[r][o] - Xi[r][i] dYr[r][o]
+// The contraction index r runs over the R lines of `nlayers` layers (virtual row v = layer*R + line), so a
+// weight tensor shared by all layers gets its whole gradient from ONE launch at the end of the backward
+// pass instead of a read-modify-write of the partials per layer.  Operand rows for trip i+1 are requested
+// before trip i's MFMAs (two statically indexed register buffers).
 template <int C>
 __global__ __launch_bounds__(C * 4) void fw_grad_partial_kernel(const float* __restrict__ xs,
                                                                  const float* __restrict__ dys,
                                                                  float* __restrict__ partial, int R, int K,
-                                                                 int chunk, int beta) {
+                                                                 int chunk, int beta, int nlayers, long stride_x,
+                                                                 long stride_dy) {
     constexpr int CT = C / 32;
+    constexpr int UN = 4;
     const int k = blockIdx.y, split = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int part = wave / CT, a = wave % CT;
-    const int rbeg = split * chunk;
-    const int rend = min(R, rbeg + chunk);
+    const long vtot = (long)nlayers * R;
+    const long vbeg = (long)split * chunk;
+    const long vend = min(vtot, vbeg + chunk);
     const float* xk = xs + (long)k * R * 2 * C;
     const float* dk = dys + (long)k * R * 2 * C;
 
     f32x16 acc[CT];
     FFNO_UNROLL
     for (int b = 0; b < CT; ++b) acc[b] = zero16();
-    const int nsteps = (max(rend - rbeg, 0) + 1) >> 1;
-    for (int t0 = 0; t0 < nsteps; t0 += 4) {
-        float xr[4], xi[4], dyr[4][CT], dyi[4][CT];
+    const int nsteps = (int)((max(vend - vbeg, 0L) + 1) >> 1);
+    const int ntrips = (nsteps + UN - 1) / UN;
+
+    struct Frag {
+        float xr[UN], xi[UN], dyr[UN][CT], dyi[UN][CT];
+    };
+    Frag f0, f1;
+    auto load = [&](Frag& f, int trip) {
         FFNO_UNROLL
-        for (int u = 0; u < 4; ++u) {
-            const int row = rbeg + 2 * (t0 + u) + half;
-            const bool valid = row < rend;
-            xr[u] = xi[u] = 0.f;
+        for (int u = 0; u < UN; ++u) {
+            const long v = vbeg + 2 * ((long)trip * UN + u) + half;
+            f.xr[u] = f.xi[u] = 0.f;
             FFNO_UNROLL
-            for (int b = 0; b < CT; ++b) dyr[u][b] = dyi[u][b] = 0.f;
-            if (valid) {
-                const float* xrow = xk + (long)row * 2 * C;
-                const float* drow_ = dk + (long)row * 2 * C;
-                xr[u] = xrow[32 * a + j];
-                xi[u] = xrow[C + 32 * a + j];
+            for (int b = 0; b < CT; ++b) f.dyr[u][b] = f.dyi[u][b] = 0.f;
+            if (v < vend) {
+                const long l = v / R, row = v - l * R;
+                const float* xrow = xk + l * stride_x + row * 2 * C;
+                const float* drow_ = dk + l * stride_dy + row * 2 * C;
+                f.xr[u] = xrow[32 * a + j];
+                f.xi[u] = xrow[C + 32 * a + j];
                 FFNO_UNROLL
                 for (int b = 0; b < CT; ++b) {
-                    dyr[u][b] = drow_[32 * b + j];
-                    dyi[u][b] = drow_[C + 32 * b + j];
+                    f.dyr[u][b] = drow_[32 * b + j];
+                    f.dyi[u][b] = drow_[C + 32 * b + j];
                 }
             }
         }
+    };
+    auto compute = [&](const Frag& f) {
         FFNO_UNROLL
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < UN; ++u) {
             FFNO_UNROLL
             for (int b = 0; b < CT; ++b) {
                 if (part == 0) {
-                    acc[b] = mfma32(xr[u], dyr[u][b], acc[b]);
-                    acc[b] = mfma32(xi[u], dyi[u][b], acc[b]);
+                    acc[b] = mfma32(f.xr[u], f.dyr[u][b], acc[b]);
+                    acc[b] = mfma32(f.xi[u], f.dyi[u][b], acc[b]);
                 } else {
-                    acc[b] = mfma32(xr[u], dyi[u][b], acc[b]);
-                    acc[b] = mfma32(-xi[u], dyr[u][b], acc[b]);
+                    acc[b] = mfma32(f.xr[u], f.dyi[u][b], acc[b]);
+                    acc[b] = mfma32(-f.xi[u], f.dyr[u][b], acc[b]);
                 }
             }
         }
+    };
+    if (ntrips > 0) load(f0, 0);
+    for (int trip = 0; trip < ntrips; trip += 2) {
+        load(f1, trip + 1);       // past-the-end trips load zeros (predicated)
+        compute(f0);
+        load(f0, trip + 2);
+        compute(f1);
     }
     float* pout = partial + (((long)split * K + k) * 2 + part) * C * C;
     FFNO_UNROLL
@@ -782,17 +803,22 @@ extern "C" int ffno_mode_mix(const float* spec_in, const float* planes, float* s
 }
 
 extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* partial, int R, int C,
-                                    int K, int nsplit, int beta, void* stream) {
-    if (!spec_x || !spec_dy || !partial || R <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
+                                    int K, int nsplit, int beta, int nlayers, size_t layer_stride_x,
+                                    size_t layer_stride_dy, void* stream) {
+    if (!spec_x || !spec_dy || !partial || R <= 0 || K <= 0 || nsplit <= 0 || nlayers <= 0) return FFNO_EINVAL;
     if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
-    int chunk = (R + nsplit - 1) / nsplit;
+    const long vtot = (long)nlayers * R;
+    long chunk = (vtot + nsplit - 1) / nsplit;
     chunk += chunk & 1;  // even, so the (2t + half) row pairing never straddles slices
+    if (chunk > 0x7fffffffL) return FFNO_EINVAL;
     const dim3 grid(nsplit, K), block(C * 4);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((fw_grad_partial_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
+        FFNO_LAUNCH((fw_grad_partial_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
+                    nlayers, (long)layer_stride_x, (long)layer_stride_dy);
     else
-        FFNO_LAUNCH((fw_grad_partial_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, chunk, beta);
+        FFNO_LAUNCH((fw_grad_partial_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
+                    nlayers, (long)layer_stride_x, (long)layer_stride_dy);
     return launch_status();
 }
 
@@ -894,7 +920,7 @@ extern "C" int ffno_spectral2d_bwd(const float* x, const float* w_y, const float
         if (mode == FFNO_MODE_FULL) {
             if (gw) {
                 if ((rc = ffno_dft_fwd(x, sb, tw, B, M, N, C, K, axis, 0, stream))) return rc;  // recompute X
-                if ((rc = ffno_fw_grad_partial(sb, sa, partial, R, C, K, kFwSplit, 0, stream))) return rc;
+                if ((rc = ffno_fw_grad_partial(sb, sa, partial, R, C, K, kFwSplit, 0, 1, 0, 0, stream))) return rc;
                 if ((rc = ffno_fw_grad_reduce(partial, gw, C, K, kFwSplit, accumulate_gw, stream))) return rc;
             }
             if ((rc = ffno_fw_pack(w, wp, wpt, C, K, stream))) return rc;

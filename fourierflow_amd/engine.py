@@ -228,7 +228,9 @@ class FFNO2DEngine:
         ws.Y = torch.empty(P, **f32)
         ws.S = torch.empty(ns, P, C, **f32)
         spec = [K * ws.R[0] * 2 * C, K * ws.R[1] * 2 * C]
-        ws.SX = [[torch.empty(spec[a], **f32) for a in (0, 1)] for _ in range(ns)]
+        ws.spec = spec
+        ws.SXall = [torch.empty(ns, spec[a], **f32) for a in (0, 1)]      # forward spectra, per axis, layer-major
+        ws.SX = [[ws.SXall[a][i] for a in (0, 1)] for i in range(ns)]
         ws.SY = torch.empty(max(spec), **f32)
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
         if save:
@@ -238,9 +240,10 @@ class FFNO2DEngine:
             ws.DS = torch.empty(P, C, **f32)
             ws.G = torch.empty(P, C, **f32)
             ws.SD = torch.empty(max(spec), **f32)
+            ws.SDall = [torch.empty(L, spec[a], **f32) for a in (0, 1)] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
-            ws.nsplit_fw = [max(1, min(max(1, 512 // K), (r + 63) // 64)) for r in ws.R]
+            ws.nsplit_fw = [max(1, min(max(1, 512 // K), (L * r + 63) // 64)) for r in ws.R]
             plane = 2 * K * C * C
             ws.fwpart = [[torch.empty(ws.nsplit_fw[a] * plane, **f32) for a in (0, 1)]
                          for _ in range(max(len(self._fw_sets), 1))]
@@ -349,7 +352,7 @@ class FFNO2DEngine:
                                               _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")),
                                               C, HEAD_DIM, 0, st)
         self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
-        ff_seen, fw_seen = set(), set()
+        ff_seen = set()
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
@@ -371,30 +374,30 @@ class FFNO2DEngine:
             for a in (0, 1):
                 acc = 0 if (last and a == 0) else 1
                 si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
+                sd = ws.SDall[a][l] if self.mode == "full" else ws.SD   # dY of every layer is kept for the dW launch
                 if fused:
                     self._k("spectral_fused(adj)", lib.ffno_spectral_fused, _p(ws.DS), _p(ws.G), None,
-                            _p(ws.SD) if self.mode == "full" else None,
+                            _p(sd) if self.mode == "full" else None,
                             _p(self.planes[si, a, 1]) if self.mode == "full" else None, _p(tw[a]),
                             B, M, N, C, K, a, 1, 0, 1, acc, st)
-                    if self.mode == "full":
-                        self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SX[l][a]), _p(ws.SD), _p(ws.fwpart[si][a]),
-                                ws.R[a], C, K, ws.nsplit_fw[a], int(si in fw_seen), st)
                     continue
-                self._k("dft_fwd(adj)", lib.ffno_dft_fwd, _p(ws.DS), _p(ws.SD), _p(tw[a]), B, M, N, C, K, a, 1, st)
-                dxs = ws.SD
+                self._k("dft_fwd(adj)", lib.ffno_dft_fwd, _p(ws.DS), _p(sd), _p(tw[a]), B, M, N, C, K, a, 1, st)
+                dxs = sd
                 if self.mode == "full":
-                    self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SX[l][a]), _p(ws.SD), _p(ws.fwpart[si][a]), ws.R[a], C, K,
-                            ws.nsplit_fw[a], int(si in fw_seen), st)
-                    self._k("mode_mix(adj)", lib.ffno_mode_mix, _p(ws.SD), _p(self.planes[si, a, 1]), _p(ws.SY), ws.R[a], C, K, 1, st)
+                    self._k("mode_mix(adj)", lib.ffno_mode_mix, _p(sd), _p(self.planes[si, a, 1]), _p(ws.SY), ws.R[a], C, K, 1, st)
                     dxs = ws.SY
                 self._k("dft_inv(adj)", lib.ffno_dft_inv, _p(dxs), _p(ws.G), None, _p(tw[a]), B, M, N, C, K, a, 0, acc, st)
-            if self.mode == "full":
-                fw_seen.add(self._fw_sets.index(self.fw_names[l]))
         lin_in = self.linears["in_proj."]
         self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(ws.G), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")), P,
                                       self.Cin, C, ws.nsplit_lift, 0, st)
         for si, names in enumerate(self._fw_sets):
+            layers = [l for l in range(L) if self.fw_names[l] == names]
+            l0_, nl = layers[0], len(layers)
+            assert layers == list(range(l0_, l0_ + nl))
             for a, n in enumerate(names):
+                # dW = sum over the lines of every layer that uses this weight: ONE launch per axis
+                self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SXall[a][l0_]), _p(ws.SDall[a][l0_]),
+                        _p(ws.fwpart[si][a]), ws.R[a], C, K, ws.nsplit_fw[a], 0, nl, ws.spec[a], ws.spec[a], st)
                 self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce, _p(ws.fwpart[si][a]), _p(gv(n)), C, K, ws.nsplit_fw[a], 0, st)
         if self._desc_dev is not None:
             self._k("weightnorm_bwd", lib.ffno_weightnorm_bwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)

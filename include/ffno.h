@@ -91,11 +91,14 @@ int ffno_dft_inv(const float* spec, float* out, const float* resid, const float*
 /* ---------------------------------------------------------------------------------------------
  * Fourier-weight gradient:  dW[i][o][k] = sum_r conj(X[k][r][i]) * dY[k][r][o]
  * (autograd of the einsum above).  Two steps so the result is deterministic:
- *   partial[s][k][2][I][O]  (+)=  sum over the s-th slice of the R lines     (beta: 0 overwrite, 1 add)
+ *   partial[s][k][2][I][O]  (+)=  sum over the s-th slice of the lines        (beta: 0 overwrite, 1 add)
  *   gw[I][O][K][2]          (+)=  sum_s partial[s]                            (accumulate)
+ * The contraction can run over `nlayers` layers at once (weights shared by all layers: grid_2d.py:125-141):
+ * layer l's spectra start at spec_x + l*layer_stride_x / spec_dy + l*layer_stride_dy (floats).
  * --------------------------------------------------------------------------------------------- */
 int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* partial, int R, int C,
-                         int K, int nsplit, int beta, void* stream);
+                         int K, int nsplit, int beta, int nlayers, size_t layer_stride_x,
+                         size_t layer_stride_dy, void* stream);
 int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
                         void* stream);
 

@@ -103,16 +103,35 @@ def test_fw_grad(be, R, C, K, nsplit):
     dys = rs.standard_normal((K, R, 2, C)).astype(np.float32)
     dxs, ddys = be.put(xs), be.put(dys)
     partial, gw = be.zeros((nsplit, K, 2, C, C)), be.zeros((C, C, K, 2))
-    assert be.lib.ffno_fw_grad_partial(be.ptr(dxs), be.ptr(ddys), be.ptr(partial), R, C, K, nsplit, 0, None) == 0
+    assert be.lib.ffno_fw_grad_partial(be.ptr(dxs), be.ptr(ddys), be.ptr(partial), R, C, K, nsplit, 0, 1, 0, 0, None) == 0
     assert be.lib.ffno_fw_grad_reduce(be.ptr(partial), be.ptr(gw), C, K, nsplit, 0, None) == 0
     xc = xs[:, :, 0].astype(np.float64) + 1j * xs[:, :, 1]
     dc = dys[:, :, 0].astype(np.float64) + 1j * dys[:, :, 1]
     ref = np.einsum("kri,kro->iok", np.conj(xc), dc)
     ref = np.stack([ref.real, ref.imag], axis=-1)
     assert rel_l2(be.get(gw), ref) < TOL
-    assert be.lib.ffno_fw_grad_partial(be.ptr(dxs), be.ptr(ddys), be.ptr(partial), R, C, K, nsplit, 1, None) == 0
+    assert be.lib.ffno_fw_grad_partial(be.ptr(dxs), be.ptr(ddys), be.ptr(partial), R, C, K, nsplit, 1, 1, 0, 0, None) == 0
     assert be.lib.ffno_fw_grad_reduce(be.ptr(partial), be.ptr(gw), C, K, nsplit, 1, None) == 0
     assert rel_l2(be.get(gw), 3 * ref) < TOL
+
+
+@pytest.mark.parametrize("R,C,K,nl,nsplit", [(37, 64, 2, 3, 4), (16, 32, 2, 5, 3)])
+def test_fw_grad_over_layers(be, R, C, K, nl, nsplit):
+    """One launch contracts over the lines of several layers (shared Fourier weights)."""
+    rs = np.random.RandomState(R + nl)
+    pad = 7 * 2 * C                       # layer stride larger than one layer's spectra
+    stride = K * R * 2 * C + pad
+    xs = rs.standard_normal((nl, stride)).astype(np.float32)
+    dys = rs.standard_normal((nl, stride)).astype(np.float32)
+    dxs, ddys = be.put(xs), be.put(dys)
+    partial, gw = be.zeros((nsplit, K, 2, C, C)), be.zeros((C, C, K, 2))
+    assert be.lib.ffno_fw_grad_partial(be.ptr(dxs), be.ptr(ddys), be.ptr(partial), R, C, K, nsplit, 0, nl, stride, stride, None) == 0
+    assert be.lib.ffno_fw_grad_reduce(be.ptr(partial), be.ptr(gw), C, K, nsplit, 0, None) == 0
+    x4 = xs[:, :K * R * 2 * C].reshape(nl, K, R, 2, C).astype(np.float64)
+    d4 = dys[:, :K * R * 2 * C].reshape(nl, K, R, 2, C).astype(np.float64)
+    xc, dc = x4[:, :, :, 0] + 1j * x4[:, :, :, 1], d4[:, :, :, 0] + 1j * d4[:, :, :, 1]
+    ref = np.einsum("lkri,lkro->iok", np.conj(xc), dc)
+    assert rel_l2(be.get(gw), np.stack([ref.real, ref.imag], axis=-1)) < TOL
 
 
 @pytest.mark.parametrize("tag", ["c64_rect", "c32_odd", "tiny_lowpass_as_c32"])
