@@ -35,16 +35,15 @@ SIGNATURES = {
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
-    "ffno_spectral_fused_dual": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),
     "ffno_spectral2d_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_spectral2d_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_ff_mask_words": (SZ, [I, I]),
-    "ffno_ff_fwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
-    "ffno_ff_bwd_data": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ff_fwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ff_bwd_data": (I, [P, P, P, P, P, P, I, I, I, P]),
     "ffno_ff_wgrad_partial_floats": (SZ, [I, I, I]),
-    "ffno_ff_bwd_weights_partial": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ffno_ff_bwd_weights_partial": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ff_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),

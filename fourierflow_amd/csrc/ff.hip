@@ -54,8 +54,7 @@ __device__ __forceinline__ void ff_load_weights(float* sm, const float* __restri
 //   backward: in = db, A1 = W2^T [H][C], A2 = W1^T [C][H]   dh^T = mask * (A1 in^T)  ; ds^T  = A2 dh^T
 // (the backward takes the TRANSPOSED effective weights so both A operands are row-contiguous 16-B LDS reads).
 template <int C, int H, int NW, bool BWD>
-__global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restrict__ in,
-                                                           const float* __restrict__ in2, const float* resid,
+__global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restrict__ in, const float* resid,
                                                            const float* __restrict__ A1g,
                                                            const float* __restrict__ bias1,
                                                            const float* __restrict__ A2g,
@@ -85,16 +84,7 @@ __global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restri
         FFNO_UNROLL
         for (int u = 0; u < KS / 4; ++u) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (px0 < P) {
-                v = *reinterpret_cast<const float4*>(in + px0 * C + KS * half + 4 * u);
-                if (in2) {   // operand = in + in2 (the two spectral branches write separate buffers)
-                    const float4 w = *reinterpret_cast<const float4*>(in2 + px0 * C + KS * half + 4 * u);
-                    v.x += w.x;
-                    v.y += w.y;
-                    v.z += w.z;
-                    v.w += w.w;
-                }
-            }
+            if (px0 < P) v = *reinterpret_cast<const float4*>(in + px0 * C + KS * half + 4 * u);
             nB[4 * u + 0] = v.x;
             nB[4 * u + 1] = v.y;
             nB[4 * u + 2] = v.z;
@@ -112,16 +102,7 @@ __global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restri
             FFNO_UNROLL
             for (int u = 0; u < KS / 4; ++u) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pxn < P) {
-                    v = *reinterpret_cast<const float4*>(in + pxn * C + KS * half + 4 * u);
-                    if (in2) {
-                        const float4 w = *reinterpret_cast<const float4*>(in2 + pxn * C + KS * half + 4 * u);
-                        v.x += w.x;
-                        v.y += w.y;
-                        v.z += w.z;
-                        v.w += w.w;
-                    }
-                }
+                if (pxn < P) v = *reinterpret_cast<const float4*>(in + pxn * C + KS * half + 4 * u);
                 nB[4 * u + 0] = v.x;
                 nB[4 * u + 1] = v.y;
                 nB[4 * u + 2] = v.z;
@@ -250,9 +231,8 @@ struct FFWgCfg {
 // whose load latencies overlap; the groups' accumulators are combined through LDS at the end.
 template <int C, int H>
 __global__ __launch_bounds__((FFWgCfg<C, H>::NW * 128)) void ff_bwd_weights_partial_kernel(
-    const float* __restrict__ s, const float* __restrict__ s2, const float* __restrict__ db,
-    const float* __restrict__ db2, const float* __restrict__ h, const float* __restrict__ dh,
-    float* __restrict__ partial, int P, int chunk) {
+    const float* __restrict__ s, const float* __restrict__ db, const float* __restrict__ h,
+    const float* __restrict__ dh, float* __restrict__ partial, int P, int chunk) {
     using G = FFWgCfg<C, H>;
     constexpr int TPW = G::TPW, CT = G::CT, NW = G::NW, UNR = G::UNR;
     __shared__ float comb[NW * 64 * (G::ACC + 2)];
@@ -292,8 +272,6 @@ __global__ __launch_bounds__((FFWgCfg<C, H>::NW * 128)) void ff_bwd_weights_part
             for (int b = 0; b < CT; ++b) {
                 sB[u][b] = valid ? s[p * C + 32 * b + j] : 0.f;
                 dbA[u][b] = valid ? db[p * C + 32 * b + j] : 0.f;
-                if (s2 && valid) sB[u][b] += s2[p * C + 32 * b + j];
-                if (db2 && valid) dbA[u][b] += db2[p * C + 32 * b + j];
             }
         }
         FFNO_UNROLL
@@ -443,9 +421,9 @@ extern "C" size_t ffno_ff_mask_words(int P, int H) { return (size_t)((P + 31) / 
     MACRO(32, 128)              \
     MACRO(32, 64)
 
-extern "C" int ffno_ff_fwd(const float* s, const float* s2, const float* resid, const float* W1, const float* b1,
-                           const float* W2, const float* b2, float* out, float* h, uint32_t* mask, int P, int C,
-                           int H, void* stream) {
+extern "C" int ffno_ff_fwd(const float* s, const float* resid, const float* W1, const float* b1, const float* W2,
+                           const float* b2, float* out, float* h, uint32_t* mask, int P, int C, int H,
+                           void* stream) {
     if (!s || !W1 || !b1 || !W2 || !b2 || !out || P <= 0) return FFNO_EINVAL;
     constexpr int NW = 8;
     const int ntiles = (P + 31) / 32;
@@ -454,7 +432,7 @@ extern "C" int ffno_ff_fwd(const float* s, const float* s2, const float* resid, 
 #define CASE(CC, HH)                                                                                         \
     if (C == CC && H == HH) {                                                                                \
         FFNO_LAUNCH((ff_chain_kernel<CC, HH, NW, false>), grid, block, 0,                                      \
-                           st, s, s2, resid, W1, b1, W2, b2, out, h, mask, P);                                   \
+                           st, s, resid, W1, b1, W2, b2, out, h, mask, P);                                   \
         return ff_launch_status();                                                                           \
     }
     FFNO_FF_DISPATCH(CASE)
@@ -462,8 +440,8 @@ extern "C" int ffno_ff_fwd(const float* s, const float* s2, const float* resid, 
     return FFNO_EUNSUPPORTED;
 }
 
-extern "C" int ffno_ff_bwd_data(const float* db, const float* db2, const uint32_t* mask, const float* W1t,
-                                const float* W2t, float* dh, float* ds, int P, int C, int H, void* stream) {
+extern "C" int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const float* W1t, const float* W2t, float* dh,
+                                float* ds, int P, int C, int H, void* stream) {
     if (!db || !mask || !W1t || !W2t || !ds || P <= 0) return FFNO_EINVAL;
     constexpr int NW = 8;
     const int ntiles = (P + 31) / 32;
@@ -472,7 +450,7 @@ extern "C" int ffno_ff_bwd_data(const float* db, const float* db2, const uint32_
 #define CASE(CC, HH)                                                                                              \
     if (C == CC && H == HH) {                                                                                     \
         FFNO_LAUNCH((ff_chain_kernel<CC, HH, NW, true>), grid, block, 0,                                      \
-                           st, db, db2, nullptr, W2t, nullptr, W1t, nullptr, ds, dh, const_cast<uint32_t*>(mask), P);                                                      \
+                           st, db, nullptr, W2t, nullptr, W1t, nullptr, ds, dh, const_cast<uint32_t*>(mask), P);                                                      \
         return ff_launch_status();                                                                                \
     }
     FFNO_FF_DISPATCH(CASE)
@@ -484,9 +462,8 @@ extern "C" size_t ffno_ff_wgrad_partial_floats(int C, int H, int nsplit) {
     return (size_t)nsplit * (size_t)(2 * H * C + H + C);
 }
 
-extern "C" int ffno_ff_bwd_weights_partial(const float* s, const float* s2, const float* db, const float* db2,
-                                           const float* h, const float* dh, float* partial, int P, int C, int H,
-                                           int nsplit, void* stream) {
+extern "C" int ffno_ff_bwd_weights_partial(const float* s, const float* db, const float* h, const float* dh,
+                                           float* partial, int P, int C, int H, int nsplit, void* stream) {
     if (!s || !db || !h || !dh || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     int chunk = (P + nsplit - 1) / nsplit;
     chunk += chunk & 1;
@@ -494,7 +471,7 @@ extern "C" int ffno_ff_bwd_weights_partial(const float* s, const float* s2, cons
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \
         FFNO_LAUNCH((ff_bwd_weights_partial_kernel<CC, HH>), dim3(nsplit), dim3(FFWgCfg<CC, HH>::NW * 128), 0, \
-                           st, s, s2, db, db2, h, dh, partial, P, chunk);                                                   \
+                           st, s, db, h, dh, partial, P, chunk);                                                   \
         return ff_launch_status();                                                                                 \
     }
     FFNO_FF_DISPATCH(CASE)

@@ -382,32 +382,15 @@ struct FusedCfg {
     static constexpr int LSMAX = 2 * KMAX * C + 4;   // line stride (floats), 16-B aligned, breaks bank period
 };
 
-struct FusedAxis {      // everything that differs between the two branches of one dual launch
-    const float* in;
-    float* out;
-    const float* resid;
-    float* spec_save;
-    const float* planes;
-    const float* tw;
-    int R, L, accumulate;
-    LineMap lm;
-};
-
 template <int C>
-__global__ __launch_bounds__(512) void spectral_fused_kernel(FusedAxis ax0, FusedAxis ax1, int K, int fwd_ck,
-                                                             int inv_ck, int conj_t) {
+__global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __restrict__ in, float* out,
+                                                             const float* resid, float* __restrict__ spec_save,
+                                                             const float* __restrict__ planes,
+                                                             const float* __restrict__ tw, int R, int L, int K,
+                                                             LineMap lm, int fwd_ck, int inv_ck, int conj_t,
+                                                             int accumulate) {
     using F = FusedCfg<C>;
     constexpr int CT = C / 32;
-    const FusedAxis& ax = blockIdx.y ? ax1 : ax0;   // blockIdx.y selects the branch (two branches per launch)
-    const int R = ax.R, L = ax.L, accumulate = ax.accumulate;
-    if ((int)blockIdx.x * F::LINES >= R) return;     // whole workgroup: the other branch may have more lines
-    const float* __restrict__ in = ax.in;
-    float* out = ax.out;
-    const float* resid = ax.resid;
-    float* __restrict__ spec_save = ax.spec_save;
-    const float* __restrict__ planes = ax.planes;
-    const float* __restrict__ tw = ax.tw;
-    const LineMap lm = ax.lm;
     __shared__ __attribute__((aligned(16))) float XS[F::LINES * F::LSMAX];
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
@@ -854,51 +837,20 @@ extern "C" int ffno_spectral_fused_supported(int C, int K, int L) {
     return 0;
 }
 
-static FusedAxis make_fused_axis(int axis, const float* in, float* out, const float* resid, float* spec_save,
-                                 const float* planes, const float* tw, int B, int M, int N, int C, int accumulate) {
-    FusedAxis a;
-    a.in = in;
-    a.out = out;
-    a.resid = resid;
-    a.spec_save = spec_save;
-    a.planes = planes;
-    a.tw = tw;
-    a.R = axis == 0 ? B * M : B * N;
-    a.L = axis == 0 ? N : M;
-    a.accumulate = accumulate;
-    a.lm = make_linemap(axis, B, M, N, C);
-    return a;
-}
-
 extern "C" int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
                                    const float* planes, const float* tw, int B, int M, int N, int C, int K, int axis,
                                    int scale_ck_fwd, int apply_ck_inv, int conj_transpose, int accumulate,
                                    void* stream) {
     if (!in || !out || !tw || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1)) return FFNO_EINVAL;
-    const FusedAxis a = make_fused_axis(axis, in, out, resid, spec_save, planes, tw, B, M, N, C, accumulate);
-    if (K > a.L / 2 + 1) return FFNO_EMODES;
-    if (!ffno_spectral_fused_supported(C, K, a.L)) return FFNO_EUNSUPPORTED;
-    const dim3 grid((a.R + 7) / 8, 1), block(512);
-    FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, sizeof(float) * 2 * a.L, (hipStream_t)stream, a, a, K,
-                scale_ck_fwd, apply_ck_inv, conj_transpose);
-    return launch_status();
-}
-
-extern "C" int ffno_spectral_fused_dual(const float* in, float* out_y, float* out_x, const float* resid_y,
-                                        float* spec_save_y, float* spec_save_x, const float* planes_y,
-                                        const float* planes_x, const float* tw_n, const float* tw_m, int B, int M,
-                                        int N, int C, int K, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
-                                        int accumulate_y, void* stream) {
-    if (!in || !out_y || !out_x || out_y == out_x || !tw_n || !tw_m || B <= 0 || M <= 0 || N <= 0 || K <= 0)
-        return FFNO_EINVAL;
-    if ((planes_y == nullptr) != (planes_x == nullptr)) return FFNO_EINVAL;
-    const FusedAxis ay = make_fused_axis(0, in, out_y, resid_y, spec_save_y, planes_y, tw_n, B, M, N, C, accumulate_y);
-    const FusedAxis axx = make_fused_axis(1, in, out_x, nullptr, spec_save_x, planes_x, tw_m, B, M, N, C, 0);
-    if (K > ay.L / 2 + 1 || K > axx.L / 2 + 1) return FFNO_EMODES;
-    if (!ffno_spectral_fused_supported(C, K, ay.L) || !ffno_spectral_fused_supported(C, K, axx.L)) return FFNO_EUNSUPPORTED;
-    const dim3 grid((max(ay.R, axx.R) + 7) / 8, 2), block(512);
-    FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, sizeof(float) * 2 * max(ay.L, axx.L), (hipStream_t)stream, ay,
-                axx, K, scale_ck_fwd, apply_ck_inv, conj_transpose);
+    const int L = axis == 0 ? N : M;
+    const int R = axis == 0 ? B * M : B * N;
+    if (K > L / 2 + 1) return FFNO_EMODES;
+    if (!ffno_spectral_fused_supported(C, K, L)) return FFNO_EUNSUPPORTED;
+    const LineMap lm = make_linemap(axis, B, M, N, C);
+    const dim3 grid((R + 7) / 8), block(512);
+    const size_t smem = sizeof(float) * 2 * L;
+    FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
+                tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
     return launch_status();
 }
 

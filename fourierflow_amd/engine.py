@@ -226,8 +226,7 @@ class FFNO2DEngine:
         ws.X = torch.empty(P, C, **f32)
         ws.Blast = torch.empty(P, C, **f32)
         ws.Y = torch.empty(P, **f32)
-        ws.S = torch.empty(ns, P, C, **f32)    # FF input (y-branch output, or the branch sum on the staged path)
-        ws.S2 = torch.empty(ns, P, C, **f32)   # x-branch output of the dual fused launch (consumers add S + S2)
+        ws.S = torch.empty(ns, P, C, **f32)
         spec = [K * ws.R[0] * 2 * C, K * ws.R[1] * 2 * C]
         ws.spec = spec
         ws.SXall = [torch.empty(ns, spec[a], **f32) for a in (0, 1)]      # forward spectra, per axis, layer-major
@@ -240,7 +239,6 @@ class FFNO2DEngine:
             ws.DH = torch.empty(P, H, **f32)
             ws.DS = torch.empty(P, C, **f32)
             ws.G = torch.empty(P, C, **f32)
-            ws.Gb = [torch.empty(P, C, **f32) for _ in range(2)]   # x-branch part of the running gradient (ping-pong)
             ws.SD = torch.empty(max(spec), **f32)
             ws.SDall = [torch.empty(L, spec[a], **f32) for a in (0, 1)] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
@@ -301,35 +299,32 @@ class FFNO2DEngine:
         for l in range(L):
             sv = l if save_for_backward else 0
             last = l == L - 1
-            s_l, s2_l = ws.S[sv], None
+            s_l = ws.S[sv]
             if self.mode == "no-fourier":
                 s_l.copy_(ws.X)
             else:
-                si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
-                full = self.mode == "full"
-                if fused:
-                    # both branches in ONE launch; they write separate buffers and the FF kernel adds them
-                    keep = save_for_backward and full
-                    self._k("spectral_fused_dual", lib.ffno_spectral_fused_dual, _p(ws.X), _p(s_l), _p(ws.S2[sv]), None,
-                            _p(ws.SX[sv][0]) if keep else None, _p(ws.SX[sv][1]) if keep else None,
-                            _p(self.planes[si, 0, 0]) if full else None, _p(self.planes[si, 1, 0]) if full else None,
-                            _p(tw[0]), _p(tw[1]), B, M, N, C, K, 0, 1, 0, 0, st)
-                    s2_l = ws.S2[sv]
-                for a in (() if fused else (0, 1)):
+                for a in (0, 1):
                     sx = ws.SX[sv][a]
+                    si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
+                    if fused:
+                        self._k("spectral_fused", lib.ffno_spectral_fused, _p(ws.X), _p(s_l), None,
+                                _p(sx) if (save_for_backward and self.mode == "full") else None,
+                                _p(self.planes[si, a, 0]) if self.mode == "full" else None, _p(tw[a]),
+                                B, M, N, C, K, a, 0, 1, 0, int(a == 1), st)
+                        continue
                     self._k("dft_fwd", lib.ffno_dft_fwd, _p(ws.X), _p(sx), _p(tw[a]), B, M, N, C, K, a, 0, st)
                     y = sx
-                    if full:
+                    if self.mode == "full":
                         self._k("mode_mix", lib.ffno_mode_mix, _p(sx), _p(self.planes[si, a, 0]), _p(ws.SY), ws.R[a], C, K, 0, st)
                         y = ws.SY
                     self._k("dft_inv", lib.ffno_dft_inv, _p(y), _p(s_l), None, _p(tw[a]), B, M, N, C, K, a, 1, int(a == 1), st)
             l0, l1, b0, b1 = self._ff_weights(l)
-            self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), _p(s2_l), None if last else _p(ws.X), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1),
+            self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None if last else _p(ws.X), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1),
                                         _p(ws.Blast if last else ws.X),
                                         _p(ws.Hbuf[sv]) if save_for_backward else None,
                                         _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
         self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), P, C, 0, st)
-        self._saved = (x, B, M, N, fused) if save_for_backward else None
+        self._saved = (x, B, M, N) if save_for_backward else None
         return ws.Y.view(B, M, N, 1).clone()
 
     # ------------------------------------------------------------------------------------------------
@@ -338,7 +333,7 @@ class FFNO2DEngine:
         (layout: ``param_names`` order; use ``grad_view(name)``)."""
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
-        x, B, M, N, fused = self._saved
+        x, B, M, N = self._saved
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
@@ -347,6 +342,8 @@ class FFNO2DEngine:
         st = _lib.current_stream(self.device)
         P = ws.P
         tw = (self._twiddle(N), self._twiddle(M))
+        fused = (self.use_fused and self.mode != "no-fourier" and
+                 all(lib.ffno_spectral_fused_supported(C, K, Lx) for Lx in (N, M)))
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         gv = self.grad_view
         self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G), _p(ws.headpart), _p(ws.red), P, C,
@@ -356,19 +353,17 @@ class FFNO2DEngine:
                                               C, HEAD_DIM, 0, st)
         self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
-        gb = None
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
-            # running gradient = G (+ gb when the previous dual launch left its x-branch part in a separate buffer)
-            s2_l = ws.S2[l] if fused else None
-            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.G), _p(gb), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(ws.DH), _p(ws.DS),
-                    P, C, H, st)
-            self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(s2_l), _p(ws.G), _p(gb),
-                    _p(ws.Hbuf[l]), _p(ws.DH), _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
+            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.G), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(ws.DH), _p(ws.DS),
+                                             P, C, H, st)
+            self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(ws.G), _p(ws.Hbuf[l]), _p(ws.DH), _p(ws.ffpart),
+                                                        P, C, H, ws.nsplit_ff, st)
             self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
-                    _p(gv(fp + "layers.0.0.bias")), _p(gv(fp + "layers.1.0.bias")), C, H, ws.nsplit_ff, int(fp in ff_seen), st)
+                                                       _p(gv(fp + "layers.0.0.bias")), _p(gv(fp + "layers.1.0.bias")),
+                                                       C, H, ws.nsplit_ff, int(fp in ff_seen), st)
             ff_seen.add(fp)
             if self.mode == "no-fourier":
                 if last:
@@ -376,29 +371,22 @@ class FFNO2DEngine:
                 else:
                     self._k("axpy", lib.ffno_axpy, _p(ws.G), _p(ws.DS), 1.0, P * C, st)
                 continue
-            si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
-            full = self.mode == "full"
-            if fused:
-                # G <- (last ? 0 : G + gb) + adj_y(DS) ;  gb' <- adj_x(DS)   (one launch, separate output buffers)
-                gb_next = ws.Gb[(L - 1 - l) & 1]
-                self._k("spectral_fused_dual(adj)", lib.ffno_spectral_fused_dual, _p(ws.DS), _p(ws.G), _p(gb_next),
-                        None if last else _p(gb),
-                        _p(ws.SDall[0][l]) if full else None, _p(ws.SDall[1][l]) if full else None,
-                        _p(self.planes[si, 0, 1]) if full else None, _p(self.planes[si, 1, 1]) if full else None,
-                        _p(tw[0]), _p(tw[1]), B, M, N, C, K, 1, 0, 1, 0 if last else 1, st)
-                gb = gb_next
-                continue
             for a in (0, 1):
                 acc = 0 if (last and a == 0) else 1
-                sd = ws.SDall[a][l] if full else ws.SD   # dY of every layer is kept for the dW launch
+                si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
+                sd = ws.SDall[a][l] if self.mode == "full" else ws.SD   # dY of every layer is kept for the dW launch
+                if fused:
+                    self._k("spectral_fused(adj)", lib.ffno_spectral_fused, _p(ws.DS), _p(ws.G), None,
+                            _p(sd) if self.mode == "full" else None,
+                            _p(self.planes[si, a, 1]) if self.mode == "full" else None, _p(tw[a]),
+                            B, M, N, C, K, a, 1, 0, 1, acc, st)
+                    continue
                 self._k("dft_fwd(adj)", lib.ffno_dft_fwd, _p(ws.DS), _p(sd), _p(tw[a]), B, M, N, C, K, a, 1, st)
                 dxs = sd
-                if full:
+                if self.mode == "full":
                     self._k("mode_mix(adj)", lib.ffno_mode_mix, _p(sd), _p(self.planes[si, a, 1]), _p(ws.SY), ws.R[a], C, K, 1, st)
                     dxs = ws.SY
                 self._k("dft_inv(adj)", lib.ffno_dft_inv, _p(dxs), _p(ws.G), None, _p(tw[a]), B, M, N, C, K, a, 0, acc, st)
-        if gb is not None:
-            self._k("axpy", lib.ffno_axpy, _p(ws.G), _p(gb), 1.0, P * C, st)
         lin_in = self.linears["in_proj."]
         self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(ws.G), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")), P,
                                       self.Cin, C, ws.nsplit_lift, 0, st)

@@ -118,7 +118,7 @@ class _FeedForwardFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         h = torch.empty(P, H, dtype=torch.float32, device=s.device) if need else None
         mask = torch.zeros(int(lib.ffno_ff_mask_words(P, H)), dtype=torch.int32, device=s.device) if need else None
-        _capi.check(lib.ffno_ff_fwd(_p(s), None, _p(resid), _p(W1), _p(b1), _p(W2), _p(b2), _p(out), _p(h), _p(mask), P, C, H, st),
+        _capi.check(lib.ffno_ff_fwd(_p(s), _p(resid), _p(W1), _p(b1), _p(W2), _p(b2), _p(out), _p(h), _p(mask), P, C, H, st),
                     "ff_fwd")
         ctx.save_for_backward(s, W1, W2, h, mask)
         ctx.has_resid = resid is not None
@@ -134,10 +134,10 @@ class _FeedForwardFn(torch.autograd.Function):
         dh = torch.empty(P, H, dtype=torch.float32, device=s.device)
         ds = torch.empty_like(s)
         W1t, W2t = W1.t().contiguous(), W2.t().contiguous()
-        _capi.check(lib.ffno_ff_bwd_data(_p(gout), None, _p(mask), _p(W1t), _p(W2t), _p(dh), _p(ds), P, C, H, st), "ff_bwd_data")
+        _capi.check(lib.ffno_ff_bwd_data(_p(gout), _p(mask), _p(W1t), _p(W2t), _p(dh), _p(ds), P, C, H, st), "ff_bwd_data")
         nsplit = max(1, min(256, (P + 127) // 128))
         part = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit)), dtype=torch.float32, device=s.device)
-        _capi.check(lib.ffno_ff_bwd_weights_partial(_p(s), None, _p(gout), None, _p(h), _p(dh), _p(part), P, C, H, nsplit, st),
+        _capi.check(lib.ffno_ff_bwd_weights_partial(_p(s), _p(gout), _p(h), _p(dh), _p(part), P, C, H, nsplit, st),
                     "ff_bwd_weights_partial")
         dW1, dW2 = torch.empty_like(W1), torch.empty_like(W2)
         db1 = torch.empty(H, dtype=torch.float32, device=s.device)

@@ -111,18 +111,8 @@ int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nspli
  *   backward: scale_ck_fwd = 1, apply_ck_inv = 0, conj_transpose = 1, planes = wpt
  * ffno_spectral_fused_supported() says whether (C, K, L) fits (8 lines x 2K x C floats of LDS);
  * otherwise use the three stage kernels above.
- * ffno_spectral_fused_dual runs BOTH branches in one launch (twice the workgroups, so load, MFMA and
- * store phases of different workgroups overlap on every CU).  The branches must not write the same
- * buffer, so the x branch (first spatial axis) writes out_x = branch_x(in) and the consumer adds the two:
- *   out_y = (accumulate_y ? out_y : 0) + (resid_y ? resid_y : 0) + branch_y(in) ;  out_x = branch_x(in)
- * (ffno_ff_fwd / ffno_ff_bwd_data / ffno_ff_bwd_weights_partial take the second addend as `*2`).
- */
+ * --------------------------------------------------------------------------------------------- */
 int ffno_spectral_fused_supported(int C, int K, int L);
-int ffno_spectral_fused_dual(const float* in, float* out_y, float* out_x, const float* resid_y,
-                             float* spec_save_y, float* spec_save_x, const float* planes_y,
-                             const float* planes_x, const float* tw_n, const float* tw_m, int B, int M,
-                             int N, int C, int K, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
-                             int accumulate_y, void* stream);
 int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
                         const float* planes, const float* tw, int B, int M, int N, int C, int K,
                         int axis, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
@@ -153,23 +143,20 @@ int ffno_spectral2d_bwd(const float* x, const float* w_y, const float* w_x, cons
  * out may alias resid.
  * --------------------------------------------------------------------------------------------- */
 size_t ffno_ff_mask_words(int P, int H);
-/* s2 / db2 (optional, may be NULL): second addend of the operand, i.e. the kernel consumes s + s2
- * (the two spectral branches of ffno_spectral_fused_dual write separate buffers). */
-int ffno_ff_fwd(const float* s, const float* s2, const float* resid, const float* W1,
-                const float* b1, const float* W2, const float* b2, float* out, float* h,
-                uint32_t* mask, int P, int C, int H, void* stream);
+int ffno_ff_fwd(const float* s, const float* resid, const float* W1, const float* b1,
+                const float* W2, const float* b2, float* out, float* h, uint32_t* mask, int P,
+                int C, int H, void* stream);
 /* data gradient: dh = (db W2) * relu'(.)  [P][H],  ds = dh W1  [P][C].
  * Takes the TRANSPOSED effective weights W1t[C][H] = W1^T and W2t[H][C] = W2^T (see
  * ffno_transpose_batched) so both GEMM operands are row-contiguous in LDS, like the forward. */
-int ffno_ff_bwd_data(const float* db, const float* db2, const uint32_t* mask, const float* W1t,
-                     const float* W2t, float* dh, float* ds, int P, int C, int H, void* stream);
+int ffno_ff_bwd_data(const float* db, const uint32_t* mask, const float* W1t, const float* W2t,
+                     float* dh, float* ds, int P, int C, int H, void* stream);
 /* weight gradients (two steps, deterministic):
  *   partial[s] = { dW1[H][C], dW2[C][H], db1[H], db2[C] } over the s-th pixel slice
  *   then reduce over s into dW1, dW2, db1, db2 (accumulate: 0 overwrite / 1 add)          */
 size_t ffno_ff_wgrad_partial_floats(int C, int H, int nsplit);
-int ffno_ff_bwd_weights_partial(const float* s, const float* s2, const float* db, const float* db2,
-                                const float* h, const float* dh, float* partial, int P, int C, int H,
-                                int nsplit, void* stream);
+int ffno_ff_bwd_weights_partial(const float* s, const float* db, const float* h, const float* dh,
+                                float* partial, int P, int C, int H, int nsplit, void* stream);
 int ffno_ff_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2,
                                int C, int H, int nsplit, int accumulate, void* stream);
 

@@ -259,40 +259,3 @@ def test_spectral_fused_support_matrix(be):
     assert be.lib.ffno_spectral_fused_supported(32, 8, 64) == 0
     x, tw = be.zeros((1, 4, 64, 64)), be.twiddle(64)
     assert be.lib.ffno_spectral_fused(be.ptr(x), be.ptr(x), None, None, None, be.ptr(tw), 1, 4, 64, 64, 17, 0, 0, 1, 0, 0, None) == -2
-
-
-@pytest.mark.parametrize("B,M,N,K", [(2, 6, 10, 3), (1, 16, 32, 8), (3, 12, 5, 2)])
-def test_spectral_fused_dual_launch_equals_two_single_launches(be, B, M, N, K):
-    """Both branches in one launch (separate output buffers) == two single-branch launches."""
-    C = 64
-    if K > min(M, N) // 2 + 1:
-        pytest.skip("modes exceed axis")
-    lib, p = be.lib, be.ptr
-    rs = np.random.RandomState(B + M + N + K)
-    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
-    resid = rs.standard_normal((B, M, N, C)).astype(np.float32)
-    acc0 = rs.standard_normal((B, M, N, C)).astype(np.float32)
-    ws_ = [(rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32) for _ in range(2)]
-    dx, dres = be.put(x), be.put(resid)
-    tw = [be.twiddle(N), be.twiddle(M)]
-    wp = []
-    for w in ws_:
-        a, b = be.zeros((K, 2, C, C)), be.zeros((K, 2, C, C))
-        assert lib.ffno_fw_pack(p(be.put(w)), p(a), p(b), C, K, None) == 0
-        wp.append(a)
-    R = (B * M, B * N)
-    # reference: single launches
-    ref_y, ref_x = be.put(acc0), be.empty(x.shape)
-    sy, sx = be.empty((K, R[0], 2, C)), be.empty((K, R[1], 2, C))
-    assert lib.ffno_spectral_fused(p(dx), p(ref_y), p(dres), p(sy), p(wp[0]), p(tw[0]), B, M, N, C, K, 0, 0, 1, 0, 1, None) == 0
-    assert lib.ffno_spectral_fused(p(dx), p(ref_x), None, p(sx), p(wp[1]), p(tw[1]), B, M, N, C, K, 1, 0, 1, 0, 0, None) == 0
-    out_y, out_x = be.put(acc0), be.empty(x.shape)
-    sy2, sx2 = be.empty((K, R[0], 2, C)), be.empty((K, R[1], 2, C))
-    assert lib.ffno_spectral_fused_dual(p(dx), p(out_y), p(out_x), p(dres), p(sy2), p(sx2), p(wp[0]), p(wp[1]),
-                                        p(tw[0]), p(tw[1]), B, M, N, C, K, 0, 1, 0, 1, None) == 0
-    np.testing.assert_array_equal(be.get(out_y), be.get(ref_y))
-    np.testing.assert_array_equal(be.get(out_x), be.get(ref_x))
-    np.testing.assert_array_equal(be.get(sy2), be.get(sy))
-    np.testing.assert_array_equal(be.get(sx2), be.get(sx))
-    assert lib.ffno_spectral_fused_dual(p(dx), p(out_y), p(out_y), None, None, None, None, None, p(tw[0]), p(tw[1]),
-                                        B, M, N, C, K, 0, 1, 0, 0, None) == -1      # outputs must differ
