@@ -50,14 +50,14 @@ class KernelTimer:
         self.count[name] += 1
         return self.count[name] % self.every == 0
 
-    def start(self, name):
+    def start(self, name, stream=None):
         ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
+        ev.record(stream) if stream is not None else ev.record()
         self._open[name] = ev
 
-    def stop(self, name):
+    def stop(self, name, stream=None):
         ev = torch.cuda.Event(enable_timing=True)
-        ev.record()
+        ev.record(stream) if stream is not None else ev.record()
         self.pairs[name].append((self._open.pop(name), ev))
 
     def summary(self):

@@ -103,15 +103,17 @@ class FFNO2DEngine:
         self._tw: Dict[int, torch.Tensor] = {}
         self._saved = None
         self.use_fused = True   # fused A->B->C branch kernel when (C, K, L) fits its LDS tile; else 3 stage kernels
+        self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
+        self.overlap = True     # backward: FF weight-gradient kernels on a side stream, overlapped with the spectral adjoint
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
 
     def _k(self, name, fn, *args):
         """Enqueue one C-ABI call; with a timer attached, bracket it with HIP events on the launch stream."""
         t = self.timer
         if t is not None and t.want(name):
-            t.start(name)
+            t.start(name, self._issue_stream)
             rc = fn(*args)
-            t.stop(name)
+            t.stop(name, self._issue_stream)
         else:
             rc = fn(*args)
         if rc != 0:
@@ -236,9 +238,9 @@ class FFNO2DEngine:
         if save:
             ws.Hbuf = torch.empty(ns, P, H, **f32)
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
-            ws.DH = torch.empty(P, H, **f32)
+            ws.DH = [torch.empty(P, H, **f32) for _ in range(2)]   # ping-pong: the side stream reads one while the next layer writes the other
             ws.DS = torch.empty(P, C, **f32)
-            ws.G = torch.empty(P, C, **f32)
+            ws.G = [torch.empty(P, C, **f32) for _ in range(2)]    # running gradient, ping-pong per layer
             ws.SD = torch.empty(max(spec), **f32)
             ws.SDall = [torch.empty(L, spec[a], **f32) for a in (0, 1)] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
@@ -346,7 +348,24 @@ class FFNO2DEngine:
                  all(lib.ffno_spectral_fused_supported(C, K, Lx) for Lx in (N, M)))
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         gv = self.grad_view
-        self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G), _p(ws.headpart), _p(ws.red), P, C,
+        # Two streams: the main stream carries the dependency chain  ff_bwd_data(l) -> spectral adjoint(l) ->
+        # ff_bwd_data(l-1) ...; the FF weight-gradient GEMMs of layer l only need (G_l, dh_l, s_l, h_l), so they run
+        # on a side stream concurrently with the adjoint of layer l and the data gradient of layer l-1 (the kernels
+        # co-reside on a CU: 67 KiB + 66 KiB of LDS).  G and dh are ping-pong buffers; events order the reuse.
+        use_side = self.overlap and self.device.type == "cuda" and self.mode != "no-fourier"
+        side = ev_a = ev_b = None
+        main_obj = None
+        if use_side:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(self.device)
+                self._ev = [torch.cuda.Event() for _ in range(3)]
+            side, main_obj = self._side, torch.cuda.current_stream(self.device)
+            ev_a, ev_b = self._ev[0], self._ev[1:]
+            st_side = ctypes.c_void_p(side.cuda_stream)
+        else:
+            st_side = st
+        cur = 0
+        self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red), P, C,
                                       ws.nsplit_head, st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                                               _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")),
@@ -357,38 +376,54 @@ class FFNO2DEngine:
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
-            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.G), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(ws.DH), _p(ws.DS),
-                                             P, C, H, st)
-            self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(ws.G), _p(ws.Hbuf[l]), _p(ws.DH), _p(ws.ffpart),
-                                                        P, C, H, ws.nsplit_ff, st)
+            g_in, g_out, dh = ws.G[cur], ws.G[1 - cur], ws.DH[l & 1]
+            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(g_in), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(dh), _p(ws.DS),
+                    P, C, H, st)
+            if use_side:
+                ev_a.record(main_obj)
+                side.wait_event(ev_a)
+                self._issue_stream = side
+            self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(g_in), _p(ws.Hbuf[l]), _p(dh),
+                    _p(ws.ffpart), P, C, H, ws.nsplit_ff, st_side)
             self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
-                                                       _p(gv(fp + "layers.0.0.bias")), _p(gv(fp + "layers.1.0.bias")),
-                                                       C, H, ws.nsplit_ff, int(fp in ff_seen), st)
+                    _p(gv(fp + "layers.0.0.bias")), _p(gv(fp + "layers.1.0.bias")), C, H, ws.nsplit_ff, int(fp in ff_seen), st_side)
             ff_seen.add(fp)
+            if use_side:
+                self._issue_stream = None
+                ev_b[l & 1].record(side)
+                if not last:
+                    # layer l+1's weight-gradient kernels read g_out's buffer (their G) and DH[(l+1)&1]: wait for them
+                    main_obj.wait_event(ev_b[(l + 1) & 1])
             if self.mode == "no-fourier":
                 if last:
-                    ws.G.copy_(ws.DS)
+                    g_out.copy_(ws.DS)
                 else:
-                    self._k("axpy", lib.ffno_axpy, _p(ws.G), _p(ws.DS), 1.0, P * C, st)
+                    torch.add(g_in, ws.DS, out=g_out)
+                cur = 1 - cur
                 continue
+            si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
+            full = self.mode == "full"
+            resid = None if last else _p(g_in)      # G_{l-1} = G_l (residual path) + adjoint terms; last layer: no residual
             for a in (0, 1):
-                acc = 0 if (last and a == 0) else 1
-                si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
-                sd = ws.SDall[a][l] if self.mode == "full" else ws.SD   # dY of every layer is kept for the dW launch
+                sd = ws.SDall[a][l] if full else ws.SD   # dY of every layer is kept for the dW launch
                 if fused:
-                    self._k("spectral_fused(adj)", lib.ffno_spectral_fused, _p(ws.DS), _p(ws.G), None,
-                            _p(sd) if self.mode == "full" else None,
-                            _p(self.planes[si, a, 1]) if self.mode == "full" else None, _p(tw[a]),
-                            B, M, N, C, K, a, 1, 0, 1, acc, st)
+                    self._k("spectral_fused(adj)", lib.ffno_spectral_fused, _p(ws.DS), _p(g_out), resid if a == 0 else None,
+                            _p(sd) if full else None, _p(self.planes[si, a, 1]) if full else None, _p(tw[a]),
+                            B, M, N, C, K, a, 1, 0, 1, int(a == 1), st)
                     continue
                 self._k("dft_fwd(adj)", lib.ffno_dft_fwd, _p(ws.DS), _p(sd), _p(tw[a]), B, M, N, C, K, a, 1, st)
                 dxs = sd
-                if self.mode == "full":
+                if full:
                     self._k("mode_mix(adj)", lib.ffno_mode_mix, _p(sd), _p(self.planes[si, a, 1]), _p(ws.SY), ws.R[a], C, K, 1, st)
                     dxs = ws.SY
-                self._k("dft_inv(adj)", lib.ffno_dft_inv, _p(dxs), _p(ws.G), None, _p(tw[a]), B, M, N, C, K, a, 0, acc, st)
+                self._k("dft_inv(adj)", lib.ffno_dft_inv, _p(dxs), _p(g_out), resid if a == 0 else None, _p(tw[a]), B, M, N, C, K, a,
+                        0, int(a == 1), st)
+            cur = 1 - cur
+        if use_side:
+            main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
+        g_fin = ws.G[cur]
         lin_in = self.linears["in_proj."]
-        self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(ws.G), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")), P,
+        self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")), P,
                                       self.Cin, C, ws.nsplit_lift, 0, st)
         for si, names in enumerate(self._fw_sets):
             layers = [l for l in range(L) if self.fw_names[l] == names]
