@@ -104,7 +104,9 @@ class FFNO2DEngine:
         self._saved = None
         self.use_fused = True   # fused A->B->C branch kernel when (C, K, L) fits its LDS tile; else 3 stage kernels
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
-        self.overlap = True     # backward: FF weight-gradient kernels on a side stream, overlapped with the spectral adjoint
+        # backward: FF weight-gradient kernels on a side stream next to the spectral adjoint.  Measured on MI355X
+        # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
+        self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
 
     def _k(self, name, fn, *args):

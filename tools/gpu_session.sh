@@ -29,5 +29,13 @@ for st in $STAGES; do
       [ -n "$f" ] && head -n 25 "$f" | cut -c1-200
       # keep the merge-back small: drop the per-dispatch trace, keep stats
       find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
+    pmc)
+      # HBM traffic counters, one PMC pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel-trace only
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf gpurun_out/pmc_$c
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/gpurun_out/pmc_$c" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 > "$OLDPWD/gpurun_out/pmc_$c.log" 2>&1)
+        echo "[session] pmc $c rc=$?"
+      done
+      ls -la gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE ;;
   esac
 done
