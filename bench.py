@@ -69,16 +69,22 @@ class KernelTimer:
         return out
 
 
-def algorithmic_work(P, C, H, K, B, M, N):
-    """Algorithmic FLOPs / bytes per launch of the timed kernels."""
-    R0, R1 = B * M, B * N
+def algorithmic_work(P, C, H, K, B, M, N, L):
+    """Algorithmic FLOPs / HBM bytes per launch of the timed kernels and launches per train step.
+    fp32: 4 B per element.  R = lines per axis; spectra are K*R*2C floats."""
+    R = B * M
+    spec = 4.0 * K * R * 2 * C
+    act = 4.0 * P * C
+    dft = 2.0 * R * (2 * K) * N * C            # truncated DFT (or its inverse) of R lines as a [2K x N].[N x C] product
+    mix = 8.0 * R * K * C * C                   # complex per-mode channel mix
     return {
-        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=4.0 * (2 * P * C + P * H + P * C)),
-        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=4.0 * (2 * P * C + P * H)),
-        "ff_bwd_weights_partial": dict(flops=4.0 * P * C * H, bytes=4.0 * (2 * P * C + 2 * P * H)),
-        "mode_mix": dict(flops=8.0 * R0 * K * C * C, bytes=4.0 * (2 * K * R0 * 2 * C)),
-        "dft_fwd": dict(flops=2.0 * R0 * (2 * K) * N * C, bytes=4.0 * (P * C + K * R0 * 2 * C)),
-        "dft_inv": dict(flops=2.0 * R0 * (2 * K) * N * C, bytes=4.0 * (2 * P * C + K * R0 * 2 * C)),
+        # one spectral branch: read x, write s (+ read s when accumulating the 2nd branch), + save the spectrum (training)
+        "spectral_fused": dict(flops=2 * dft + mix, bytes=(act + act + spec) + 0.5 * act, per_step=2 * L, bound="hbm"),
+        "spectral_fused(adj)": dict(flops=2 * dft + mix, bytes=(act + act + act + spec), per_step=2 * L, bound="hbm"),
+        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=3 * act + 4.0 * P * H + P * H / 8, per_step=L, bound="mfma"),
+        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=2 * act + 4.0 * P * H + P * H / 8, per_step=L, bound="mfma"),
+        "ff_bwd_weights_partial": dict(flops=4.0 * P * C * H, bytes=2 * act + 8.0 * P * H, per_step=L, bound="mfma"),
+        "fw_grad_partial": dict(flops=L * mix, bytes=2 * L * spec, per_step=2, bound="hbm"),
     }
 
 
@@ -197,8 +203,8 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         log("warm-up done; timing")
-    names = ["ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial", "mode_mix", "dft_fwd", "dft_inv"]
-    timer = KernelTimer(names, every=8) if rank == 0 else None   # sample 1 launch in 8: negligible overhead
+    names = ["spectral_fused", "spectral_fused(adj)", "ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial", "fw_grad_partial"]
+    timer = KernelTimer(names, every=7) if rank == 0 else None   # sample 1 launch in 7 (odd: both branches get sampled)
     trainer.engine.timer = timer
     if timer:
         timer.enabled = True
@@ -234,26 +240,47 @@ def main():
         log(f"forward-only: {ms_fwd:.3f} ms")
         P = B * G * G
         C, H, K = kw["width"], kw["width"] * kw["factor"], kw["modes"]
-        work = algorithmic_work(P, C, H, K, B, G, G)
+        work = algorithmic_work(P, C, H, K, B, G, G, args.layers)
         ksum = timer.summary()
+        pmc = {}
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if B == 32 and G == 64 and args.layers == 24 and K == 16:
+                pmc = pj["kernels"]
+        except Exception:  # noqa: BLE001 - the PMC summary is optional evidence
+            pass
         kernels = {}
         for n, srow in ksum.items():
             w = work[n]
             us = srow["avg_us"]
-            kernels[n] = dict(avg_us=round(us, 2), tflops=round(w["flops"] / us * 1e-6, 2),
-                              gbs=round(w["bytes"] / us * 1e-3, 1), samples=srow["samples"])
-        # dominant kernel = largest share of the step (launch counts per step: FF kernels 24, spectral 48 fwd+48 bwd...)
-        per_step = {"ff_fwd": 24, "ff_bwd_data": 24, "ff_bwd_weights_partial": 24, "mode_mix": 96, "dft_fwd": 96,
-                    "dft_inv": 96}
-        scale = args.layers / 24.0
-        dom = max(kernels, key=lambda n: kernels[n]["avg_us"] * per_step[n] * scale) if kernels else None
+            kernels[n] = dict(avg_us=round(us, 2), per_step=w["per_step"], ms_per_step=round(us * w["per_step"] * 1e-3, 3),
+                              tflops=round(w["flops"] / us * 1e-6, 2), gbs=round(w["bytes"] / us * 1e-3, 1),
+                              frac_mfma=round(w["flops"] / us * 1e-6 / FP32_MFMA_PEAK_TFLOPS, 3),
+                              frac_hbm=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3), samples=srow["samples"])
+        # dominant kernel = the kernel symbol with the largest share of the step (spectral_fused fwd+adj are one symbol)
+        share = {}
+        for n, kr in kernels.items():
+            share[n.split("(")[0]] = share.get(n.split("(")[0], 0.0) + kr["ms_per_step"]
+        dom_sym = max(share, key=share.get) if share else None
         roofline = None
-        if dom:
-            ach = kernels[dom]["tflops"]
-            roofline = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                            avg_launch_us=kernels[dom]["avg_us"],
-                            note="algorithmic fp32 FLOPs per launch / HIP-event launch time; PMC traffic in profiles/")
+        if dom_sym:
+            members = [n for n in kernels if n.split("(")[0] == dom_sym]
+            us = sum(kernels[n]["avg_us"] * kernels[n]["per_step"] for n in members) / sum(kernels[n]["per_step"] for n in members)
+            fl = sum(work[n]["flops"] * work[n]["per_step"] for n in members) / sum(work[n]["per_step"] for n in members)
+            by = sum(work[n]["bytes"] * work[n]["per_step"] for n in members) / sum(work[n]["per_step"] for n in members)
+            bound = work[members[0]]["bound"]
+            if bound == "hbm":
+                ach, peak, unit = by / us * 1e-3, HBM_PEAK_GBS, "GB/s"
+            else:
+                ach, peak, unit = fl / us * 1e-6, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+            traffic = pmc.get(dom_sym, {}).get("hbm_bytes_per_launch")
+            roofline = dict(kernel=dom_sym, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
+                            frac=round(ach / peak, 4), traffic=traffic, avg_launch_us=round(us, 2),
+                            share_of_step=round(share[dom_sym] / (1e3 * elapsed / args.steps), 3),
+                            algorithmic_bytes_per_launch=int(by), algorithmic_flops_per_launch=int(fl),
+                            note="achieved = algorithmic bytes (or FLOPs) per launch / mean HIP-event launch time in the timed "
+                                 "region; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/pmc_traffic.json "
+                                 "(separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE)")
         cpu = None
         if world == 1 and args.cpu_steps > 0:
             cpu = cpu_baseline(B, G, args.cpu_steps, kw)
