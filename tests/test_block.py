@@ -117,3 +117,24 @@ def test_standalone_ops_spectral_and_ff(host_device):
     assert rel_l2(x.grad.cpu().numpy(), xo.grad.numpy()) < 1e-5
     for n, p in conv.named_parameters():
         assert rel_l2(p.grad.cpu().numpy(), sd[n].grad.numpy()) < 2e-5, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid,modes,layers", [(256, 32, 2), (256, 64, 1), (128, 16, 2)])
+def test_large_grid_block_matches_oracle_on_gpu(grid, modes, layers):
+    """BASELINE config 4 regime (torus_kochkov 256x256, modes 32 / 64: staged spectral kernels, multi-tile DFT)
+    and a 128x128 case on the fused path: forward vs the CPU oracle at the north-star tolerance, gradients
+    at rounding level."""
+    import oracle_util as ou
+    kw = dict(modes=modes, width=64, input_dim=5, n_layers=layers, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    B, seed = 1, 77
+    blk = build_block(kw, seed, "cuda:0")
+    x_np, t_np = gu.make_block_io(kw, seed, B, grid, grid)
+    pred = blk(torch.from_numpy(x_np).cuda())["forecast"]
+    loss = orc.lp_rel_loss(pred, torch.from_numpy(t_np).cuda())
+    loss.backward()
+    ref_out, ref_loss, ref_grads = ou.oracle_block_run(kw, seed, B, grid, grid)
+    assert rel_l2(pred.detach().cpu().numpy(), ref_out["forecast"].detach().numpy()) < 1e-5
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    errs = {n: rel_l2(p.grad.cpu().numpy(), ref_grads[n]) for n, p in blk.named_parameters()}
+    assert max(errs.values()) < 3e-3 and float(np.median(list(errs.values()))) < 3e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:4]

@@ -29,6 +29,9 @@ for st in $STAGES; do
       [ -n "$f" ] && head -n 25 "$f" | cut -c1-200
       # keep the merge-back small: drop the per-dispatch trace, keep stats
       find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
+    bench256)
+      timeout 900 python bench.py --steps 10 --warmup 3 --grid 256 --layers 12 --modes 32 --batch 2 --cpu-steps 1 > gpurun_out/bench_256.log 2>&1
+      echo "[session] bench256 rc=$?"; tail -n 1 gpurun_out/bench_256.log | cut -c1-1200 ;;
     pmc)
       # HBM traffic counters, one PMC pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel-trace only
       for c in FETCH_SIZE WRITE_SIZE; do
