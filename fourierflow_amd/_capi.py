@@ -19,6 +19,11 @@ class WnDesc(C.Structure):
                 ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class PadMap(C.Structure):
+    """Mirror of ``ffno_padmap`` (include/ffno.h)."""
+    _fields_ = [("size", C.c_int32 * 3), ("padded", C.c_int32 * 3)]
+
+
 class TrDesc(C.Structure):
     """Mirror of ``ffno_tr_desc`` (include/ffno.h)."""
     _fields_ = [("src", P), ("dst", P), ("rows", C.c_int32), ("cols", C.c_int32)]
@@ -48,12 +53,12 @@ SIGNATURES = {
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),
     "ffno_transpose_batched": (I, [P, I, I, I, P]),
-    "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P]),
-    "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
-    "ffno_head_fold": (I, [P, P, P, P, P, I, I, P]),
-    "ffno_head_fwd": (I, [P, P, P, I, I, I, P]),
-    "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
-    "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P, P]),
+    "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "ffno_head_fold": (I, [P, P, P, P, P, I, I, I, P]),
+    "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
+    "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
+    "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_lploss_fwd_bwd": (I, [P, P, P, P, P, I, I, F, P]),
     "ffno_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, I, F, P]),
     "ffno_axpy": (I, [P, P, F, SZ, P]),

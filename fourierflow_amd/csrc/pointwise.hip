@@ -63,11 +63,45 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const ffno_tr_de
         if (c0 + yy < d.cols && r0 + tx < d.rows) d.dst[(long)(c0 + yy) * d.rows + r0 + tx] = tile[tx][yy];
 }
 
+// ---- pad / crop index map -------------------------------------------------------------------------------
+// The 3-D mesh operator zero-pads the lifted features by 8 cells at the END of every spatial axis and crops
+// the last layer's output again (reference mesh_3d.py:165,173).  Instead of materialising pad / crop copies,
+// the lift and head kernels address the padded activation buffer directly: unpadded pixel p -> padded pixel q.
+struct PadMapDev {
+    int s1, s2;          // unpadded sizes of the two inner spatial axes (row-major [b][s0][s1][s2])
+    int p0, p1, p2;      // padded sizes of the three spatial axes
+    int s0;
+    int enabled;
+    __device__ __forceinline__ long map(long p) const {
+        if (!enabled) return p;
+        const long z = p % s2, t = p / s2;
+        const long y = t % s1, t2 = t / s1;
+        const long x = t2 % s0, b = t2 / s0;
+        return ((b * p0 + x) * p1 + y) * p2 + z;
+    }
+};
+
+static inline PadMapDev make_padmap(const ffno_padmap* pm) {
+    PadMapDev d;
+    d.enabled = 0;
+    d.s0 = d.s1 = d.s2 = d.p0 = d.p1 = d.p2 = 1;
+    if (pm) {
+        d.s0 = pm->size[0];
+        d.s1 = pm->size[1];
+        d.s2 = pm->size[2];
+        d.p0 = pm->padded[0];
+        d.p1 = pm->padded[1];
+        d.p2 = pm->padded[2];
+        d.enabled = (d.s0 != d.p0 || d.s1 != d.p1 || d.s2 != d.p2) ? 1 : 0;
+    }
+    return d;
+}
+
 // ---- lift (in_proj) -----------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ b, float* __restrict__ out, int P,
-                                                       int Cin) {
+                                                       int Cin, PadMapDev pm) {
     FFNO_DYN_SMEM(smem);
     float* Wt = reinterpret_cast<float*>(smem);  // [Cin + 1][C], last row = bias
     for (int e = threadIdx.x; e < Cin * C; e += blockDim.x) Wt[(e % Cin) * C + (e / Cin)] = W[e];
@@ -87,16 +121,16 @@ __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__
             acc.z = fmaf(xv, w.z, acc.z);
             acc.w = fmaf(xv, w.w, acc.w);
         }
-        *reinterpret_cast<float4*>(out + p * C + c4) = acc;
+        *reinterpret_cast<float4*>(out + pm.map(p) * C + c4) = acc;
     }
 }
 
-// partial[split][i][c] = sum_{p in slice} gout[p][c] * (i < Cin ? x[p][i] : 1)
+// partial[split][i][c] = sum_{p in slice} gout[q(p)][c] * (i < Cin ? x[p][i] : 1)
 template <int C>
 __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ gout,
                                                                float* __restrict__ partial, int P, int Cin,
-                                                               int chunk) {
+                                                               int chunk, PadMapDev pm) {
     constexpr int TP = 32;                     // pixels staged per pass
     constexpr int MAXU = (C * 64) / 256;       // pairs per thread for Cin + 1 <= 64
     __shared__ float gs[TP * C];
@@ -109,7 +143,7 @@ __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __re
     for (long p0 = pbeg; p0 < pend; p0 += TP) {
         const int np = (int)min((long)TP, pend - p0);
         __syncthreads();
-        for (int e = threadIdx.x; e < TP * C; e += 256) gs[e] = (e / C) < np ? gout[p0 * C + e] : 0.f;
+        for (int e = threadIdx.x; e < TP * C; e += 256) gs[e] = (e / C) < np ? gout[pm.map(p0 + e / C) * C + (e % C)] : 0.f;
         for (int e = threadIdx.x; e < TP * (Cin + 1); e += 256) {
             const int pp = e / (Cin + 1), i = e % (Cin + 1);
             xs[pp * 64 + i] = (pp < np) ? (i < Cin ? x[(p0 + pp) * Cin + i] : 1.f) : 0.f;
@@ -146,102 +180,132 @@ __global__ void lift_bwd_reduce_kernel(const float* __restrict__ partial, float*
 }
 
 // ---- output head ----------------------------------------------------------------------------------------
+// y[p][o] = (b[p] Wa^T + ca) Wb[o]^T + cb[o]  folded to  y[p][o] = b[p] . weff[o] + beff[o];  fold[o][C+1].
+static constexpr int kHeadMaxOut = 8;
+
 __global__ void head_fold_kernel(const float* __restrict__ Wa, const float* __restrict__ ca,
                                  const float* __restrict__ Wb, const float* __restrict__ cb, float* fold, int C,
-                                 int D) {
-    const int c = threadIdx.x;
-    if (c < C) {
-        float s = 0.f;
-        for (int jd = 0; jd < D; ++jd) s = fmaf(Wb[jd], Wa[jd * C + c], s);
-        fold[c] = s;
-    } else if (c == C) {
-        float s = cb[0];
-        for (int jd = 0; jd < D; ++jd) s = fmaf(Wb[jd], ca[jd], s);
-        fold[C] = s;
+                                 int D, int O) {
+    for (int e = threadIdx.x; e < O * (C + 1); e += blockDim.x) {
+        const int o = e / (C + 1), c = e % (C + 1);
+        float s = (c == C) ? cb[o] : 0.f;
+        for (int jd = 0; jd < D; ++jd) s = fmaf(Wb[o * D + jd], (c == C) ? ca[jd] : Wa[jd * C + c], s);
+        fold[e] = s;
     }
 }
 
 template <int C>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ b, const float* __restrict__ fold,
-                                                       float* y, int P, int accumulate) {
+                                                       float* y, int P, int O, int accumulate, PadMapDev pm) {
     constexpr int LPP = C / 4, PPB = 256 / LPP;
     const int c4 = (threadIdx.x % LPP) * 4, pl = threadIdx.x / LPP;
-    const float4 w = *reinterpret_cast<const float4*>(fold + c4);
-    const float beff = fold[C];
     const long npass = ((long)P + PPB - 1) / PPB;
     for (long pass = blockIdx.x; pass < npass; pass += gridDim.x) {  // uniform trip count per wave (shuffles)
         const long p = pass * PPB + pl;
-        float d = 0.f;
-        if (p < P) {
-            const float4 v = *reinterpret_cast<const float4*>(b + p * C + c4);
-            d = v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < P) v = *reinterpret_cast<const float4*>(b + pm.map(p) * C + c4);
+        for (int o = 0; o < O; ++o) {
+            const float4 w = *reinterpret_cast<const float4*>(fold + o * (C + 1) + c4);
+            float d = v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
+            FFNO_UNROLL
+            for (int m = LPP / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m);
+            if (p < P && c4 == 0) y[p * O + o] = (accumulate ? y[p * O + o] : 0.f) + d + fold[o * (C + 1) + C];
         }
-        FFNO_UNROLL
-        for (int m = LPP / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m);
-        if (p < P && c4 == 0) y[p] = (accumulate ? y[p] : 0.f) + d + beff;
     }
 }
 
-// gb[p][:] = gy[p] * weff ;  partial[block][0..C) = sum_p gy[p] b[p][:],  partial[block][C] = sum_p gy[p]
+// gb[q(p)][:] = sum_o gy[p][o] * weff[o] ;  partial[block][o][0..C) = sum_p gy[p][o] b[q(p)][:],  [o][C] = sum_p gy[p][o]
 template <int C>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ b, const float* __restrict__ gy,
                                                        const float* __restrict__ fold, float* __restrict__ gb,
-                                                       float* __restrict__ partial, int P) {
+                                                       float* __restrict__ partial, int P, int O, PadMapDev pm) {
     constexpr int LPP = C / 4, PPB = 256 / LPP;
     __shared__ float red[PPB * (C + 4)];
     const int l = threadIdx.x % LPP, c4 = l * 4, pl = threadIdx.x / LPP;
-    const float4 w = *reinterpret_cast<const float4*>(fold + c4);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    float sg = 0.f;
-    for (long p = (long)blockIdx.x * PPB + pl; p < P; p += (long)gridDim.x * PPB) {
-        const float g = gy[p];
-        const float4 v = *reinterpret_cast<const float4*>(b + p * C + c4);
-        acc.x = fmaf(g, v.x, acc.x);
-        acc.y = fmaf(g, v.y, acc.y);
-        acc.z = fmaf(g, v.z, acc.z);
-        acc.w = fmaf(g, v.w, acc.w);
-        if (l == 0) sg += g;
-        if (gb) *reinterpret_cast<float4*>(gb + p * C + c4) = make_float4(g * w.x, g * w.y, g * w.z, g * w.w);
+    float4 acc[kHeadMaxOut];
+    float sg[kHeadMaxOut];
+    FFNO_UNROLL
+    for (int o = 0; o < kHeadMaxOut; ++o) {
+        acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sg[o] = 0.f;
     }
-    float* r = red + pl * (C + 4);
-    r[c4] = acc.x;
-    r[c4 + 1] = acc.y;
-    r[c4 + 2] = acc.z;
-    r[c4 + 3] = acc.w;
-    if (l == 0) r[C] = sg;
-    __syncthreads();
-    for (int e = threadIdx.x; e <= C; e += 256) {
-        float s = 0.f;
-        for (int q = 0; q < PPB; ++q) s += red[q * (C + 4) + e];
-        partial[(long)blockIdx.x * (C + 1) + e] = s;
+    for (long p = (long)blockIdx.x * PPB + pl; p < P; p += (long)gridDim.x * PPB) {
+        const long q = pm.map(p);
+        const float4 v = *reinterpret_cast<const float4*>(b + q * C + c4);
+        float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
+        FFNO_UNROLL
+        for (int o = 0; o < kHeadMaxOut; ++o) {
+            if (o < O) {
+                const float g = gy[p * O + o];
+                const float4 w = *reinterpret_cast<const float4*>(fold + o * (C + 1) + c4);
+                acc[o].x = fmaf(g, v.x, acc[o].x);
+                acc[o].y = fmaf(g, v.y, acc[o].y);
+                acc[o].z = fmaf(g, v.z, acc[o].z);
+                acc[o].w = fmaf(g, v.w, acc[o].w);
+                sg[o] += g;
+                gsum.x = fmaf(g, w.x, gsum.x);
+                gsum.y = fmaf(g, w.y, gsum.y);
+                gsum.z = fmaf(g, w.z, gsum.z);
+                gsum.w = fmaf(g, w.w, gsum.w);
+            }
+        }
+        if (gb) *reinterpret_cast<float4*>(gb + q * C + c4) = gsum;
+    }
+    for (int o = 0; o < O; ++o) {
+        __syncthreads();
+        float* r = red + pl * (C + 4);
+        FFNO_UNROLL
+        for (int oo = 0; oo < kHeadMaxOut; ++oo) {
+            if (oo == o) {
+                r[c4] = acc[oo].x;
+                r[c4 + 1] = acc[oo].y;
+                r[c4 + 2] = acc[oo].z;
+                r[c4 + 3] = acc[oo].w;
+                if (l == 0) r[C] = sg[oo];
+            }
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e <= C; e += 256) {
+            float s = 0.f;
+            for (int qq = 0; qq < PPB; ++qq) s += red[qq * (C + 4) + e];
+            partial[((long)blockIdx.x * O + o) * (C + 1) + e] = s;
+        }
     }
 }
 
-__global__ void head_bwd_reduce_kernel(const float* __restrict__ partial, float* red, int C, int nsplit) {
-    for (int e = threadIdx.x; e <= C; e += blockDim.x) {
+__global__ void head_bwd_reduce_kernel(const float* __restrict__ partial, float* red, int C, int O, int nsplit) {
+    for (int e = threadIdx.x; e < O * (C + 1); e += blockDim.x) {
         float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * (C + 1) + e];
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * O * (C + 1) + e];
         red[e] = s;
     }
 }
 
-// y = Wb (Wa b + ca) + cb :   dWb[j] = (Wa G)[j] + ca[j] S ; dWa[j][c] = Wb[j] G[c] ; dca[j] = Wb[j] S ; dcb = S
+// y = Wb (Wa b + ca) + cb, red[o] = { G_o = sum_p gy[p][o] b[p][:], S_o = sum_p gy[p][o] }:
+//   dWb[o][j] = (Wa G_o)[j] + ca[j] S_o ; dWa[j][c] = sum_o Wb[o][j] G_o[c] ; dca[j] = sum_o Wb[o][j] S_o ; dcb[o] = S_o
 __global__ void head_param_grads_kernel(const float* __restrict__ red, const float* __restrict__ Wa,
                                         const float* __restrict__ ca, const float* __restrict__ Wb, float* dWa,
-                                        float* dca, float* dWb, float* dcb, int C, int D, int accumulate) {
-    const float S = red[C];
+                                        float* dca, float* dWb, float* dcb, int C, int D, int O, int accumulate) {
+    for (int e = threadIdx.x; e < O * D; e += blockDim.x) {
+        const int o = e / D, jd = e % D;
+        float s = ca[jd] * red[o * (C + 1) + C];
+        for (int c = 0; c < C; ++c) s = fmaf(Wa[jd * C + c], red[o * (C + 1) + c], s);
+        dWb[e] = accumulate ? dWb[e] + s : s;
+    }
     for (int jd = threadIdx.x; jd < D; jd += blockDim.x) {
-        float s = ca[jd] * S;
-        for (int c = 0; c < C; ++c) s = fmaf(Wa[jd * C + c], red[c], s);
-        dWb[jd] = accumulate ? dWb[jd] + s : s;
-        const float t = Wb[jd] * S;
+        float t = 0.f;
+        for (int o = 0; o < O; ++o) t = fmaf(Wb[o * D + jd], red[o * (C + 1) + C], t);
         dca[jd] = accumulate ? dca[jd] + t : t;
     }
     for (int e = threadIdx.x; e < D * C; e += blockDim.x) {
-        const float t = Wb[e / C] * red[e % C];
+        float t = 0.f;
+        for (int o = 0; o < O; ++o) t = fmaf(Wb[o * D + e / C], red[o * (C + 1) + e % C], t);
         dWa[e] = accumulate ? dWa[e] + t : t;
     }
-    if (threadIdx.x == 0) dcb[0] = accumulate ? dcb[0] + S : S;
+    for (int o = threadIdx.x; o < O; o += blockDim.x) {
+        const float S = red[o * (C + 1) + C];
+        dcb[o] = accumulate ? dcb[o] + S : S;
+    }
 }
 
 // ---- relative L2 loss -----------------------------------------------------------------------------------
@@ -360,32 +424,34 @@ extern "C" int ffno_transpose_batched(const ffno_tr_desc* descs_dev, int n, int 
 }
 
 extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
-                             void* stream) {
+                             const ffno_padmap* pad, void* stream) {
     if (!x || !W || !b || !out || P <= 0 || Cin <= 0) return FFNO_EINVAL;
     if (Cin > 63) return FFNO_EUNSUPPORTED;
+    const PadMapDev pm = make_padmap(pad);
     const size_t smem = sizeof(float) * (size_t)(Cin + 1) * C;
     const int ppb = 256 / (C / 4);
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin);
+        FFNO_LAUNCH((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin, pm);
     else if (C == 32)
-        FFNO_LAUNCH((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin);
+        FFNO_LAUNCH((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin, pm);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
 }
 
 extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
-                             int Cin, int C, int nsplit, int accumulate, void* stream) {
+                             int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
     if (!x || !gout || !partial || !dW || !db || P <= 0 || Cin <= 0 || nsplit <= 0) return FFNO_EINVAL;
     if (Cin > 63) return FFNO_EUNSUPPORTED;
+    const PadMapDev pm = make_padmap(pad);
     const int chunk = (P + nsplit - 1) / nsplit;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<64>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<64>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
     else if (C == 32)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<32>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<32>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
@@ -397,49 +463,54 @@ extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, 
 }
 
 extern "C" int ffno_head_fold(const float* Wa, const float* ca, const float* Wb, const float* cb, float* fold,
-                              int C, int D, void* stream) {
-    if (!Wa || !ca || !Wb || !cb || !fold || C <= 0 || D <= 0 || C > 255) return FFNO_EINVAL;
-    FFNO_LAUNCH(head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Wa, ca, Wb, cb, fold, C, D);
+                              int C, int D, int O, void* stream) {
+    if (!Wa || !ca || !Wb || !cb || !fold || C <= 0 || D <= 0 || O <= 0) return FFNO_EINVAL;
+    if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
+    FFNO_LAUNCH(head_fold_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, Wa, ca, Wb, cb, fold, C, D, O);
     return pw_status();
 }
 
-extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int accumulate,
-                             void* stream) {
-    if (!b || !fold || !y || P <= 0) return FFNO_EINVAL;
+extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int O, int accumulate,
+                             const ffno_padmap* pad, void* stream) {
+    if (!b || !fold || !y || P <= 0 || O <= 0) return FFNO_EINVAL;
+    if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
+    const PadMapDev pm = make_padmap(pad);
     const int ppb = 256 / (C / 4);
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((head_fwd_kernel<64>), grid, block, 0, s, b, fold, y, P, accumulate);
+        FFNO_LAUNCH((head_fwd_kernel<64>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
     else if (C == 32)
-        FFNO_LAUNCH((head_fwd_kernel<32>), grid, block, 0, s, b, fold, y, P, accumulate);
+        FFNO_LAUNCH((head_fwd_kernel<32>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
 }
 
 extern "C" int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
-                             float* red, int P, int C, int nsplit, void* stream) {
-    if (!b || !gy || !fold || !partial || !red || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
+                             float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, void* stream) {
+    if (!b || !gy || !fold || !partial || !red || P <= 0 || nsplit <= 0 || O <= 0) return FFNO_EINVAL;
+    if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
+    const PadMapDev pm = make_padmap(pad);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
+        FFNO_LAUNCH((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm);
     else if (C == 32)
-        FFNO_LAUNCH((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P);
+        FFNO_LAUNCH((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
     if (rc) return rc;
-    FFNO_LAUNCH(head_bwd_reduce_kernel, dim3(1), dim3(128), 0, s, partial, red, C, nsplit);
+    FFNO_LAUNCH(head_bwd_reduce_kernel, dim3(1), dim3(256), 0, s, partial, red, C, O, nsplit);
     return pw_status();
 }
 
 extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,
-                                     float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int accumulate,
-                                     void* stream) {
-    if (!red || !Wa || !ca || !Wb || !dWa || !dca || !dWb || !dcb) return FFNO_EINVAL;
+                                     float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int O,
+                                     int accumulate, void* stream) {
+    if (!red || !Wa || !ca || !Wb || !dWa || !dca || !dWb || !dcb || O <= 0) return FFNO_EINVAL;
     FFNO_LAUNCH(head_param_grads_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, red, Wa, ca, Wb, dWa, dca,
-                       dWb, dcb, C, D, accumulate);
+                       dWb, dcb, C, D, O, accumulate);
     return pw_status();
 }
 

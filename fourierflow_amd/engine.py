@@ -1,13 +1,18 @@
-"""Host-side driver of the F-FNO 2-D block: sequences the C-ABI kernels of include/ffno.h.
+"""Host-side driver of the F-FNO block: sequences the C-ABI kernels of include/ffno.h.
 
 Mirrors the data flow of the reference's ``FNOFactorized2DBlock.forward``
-(fourierflow/modules/factorized_fno/grid_2d.py:154-177) and of its autograd, but over pre-allocated
-device workspaces and raw pointers:
+(fourierflow/modules/factorized_fno/grid_2d.py:154-177), of the 3-D mesh variant
+``FNOFactorizedMesh3D.forward`` (mesh_3d.py:160-176) and of their autograd, over pre-allocated device
+workspaces and raw pointers:
 
-  forward :  lift -> L x [ dft_fwd(y,x) -> mode_mix -> dft_inv(+sum) -> fused FF(+residual) ] -> head
-  backward:  head_bwd -> L x [ ff_bwd_data, ff_bwd_weights, dft_fwd(adjoint), fw_grad, mode_mix^H,
-                                dft_inv(adjoint, accumulating into the running gradient) ] -> lift_bwd
-             -> weight-norm backward (one batched launch)
+  forward :  lift -> L x [ per axis: DFT -> mode mix -> iDFT (+sum) ; fused FF (+residual) ] -> head
+  backward:  head_bwd -> L x [ ff_bwd_data, ff_bwd_weights, per axis: adjoint DFT/mix/iDFT accumulating into
+             the running gradient ] -> lift_bwd -> Fourier-weight gradients (one launch per weight over all
+             layers) -> weight-norm backward (one batched launch)
+
+Every spatial axis is a *view* of the channels-last activation buffer as [B', M', N', C] plus a flag saying
+whether the transform runs along N' (contiguous lines) or M' (strided lines), so the same spectral kernels
+serve the 2-D grid (2 axes) and the 3-D mesh (3 axes, any sizes incl. the +8 padding).
 
 PyTorch is used for device memory and the stream only.  All parameter gradients land in one flat
 fp32 buffer (``gflat``) so the trainer can run ONE fused AdamW and ONE RCCL all-reduce per step.
@@ -15,7 +20,7 @@ fp32 buffer (``gflat``) so the trainer can run ONE fused AdamW and ONE RCCL all-
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -23,7 +28,7 @@ import torch
 from . import _capi, _lib
 
 MODES = {"full": 0, "low-pass": 1, "no-fourier": 2}
-HEAD_DIM = 128  # grid_2d.py:150-152: WNLinear(width, 128) -> WNLinear(128, 1)
+HEAD_DIM = 128  # grid_2d.py:150-152 / mesh_3d.py:155-157: WNLinear(width, 128) -> WNLinear(128, out)
 _SUPPORTED_CH = {(64, 256), (64, 128), (32, 128), (32, 64)}
 
 
@@ -41,19 +46,47 @@ class _Linear:
         self.wt = None     # transposed effective weight [cols, rows] (feed-forward linears only; backward)
 
 
-class FFNO2DEngine:
-    """Kernel sequencer for one FNOFactorized2DBlock configuration (fp32)."""
+class _View:
+    """One spatial axis as a [Bv, Mv, Nv, C] view: a01 = 0 transforms along Nv, 1 along Mv."""
+    __slots__ = ("Bv", "Mv", "Nv", "a01", "L", "K", "R", "spec")
 
-    def __init__(self, *, modes: int, width: int, input_dim: int, n_layers: int, factor: int,
-                 share_weight: bool, share_fork: bool, ff_weight_norm: bool, mode: str = "full"):
+    def __init__(self, Bv, Mv, Nv, a01, K, C):
+        self.Bv, self.Mv, self.Nv, self.a01, self.K = Bv, Mv, Nv, a01, K
+        self.L = Nv if a01 == 0 else Mv
+        self.R = Bv * Mv if a01 == 0 else Bv * Nv
+        self.spec = K * self.R * 2 * C
+
+
+class FFNOEngine:
+    """Kernel sequencer for one factorized-FNO configuration (fp32).
+
+    spatial_dims = 2: FNOFactorized2DBlock -- fourier_weight[0] mixes the LAST axis, [1] the first
+                      (grid_2d.py:68,86); no padding; one output channel.
+    spatial_dims = 3: FNOFactorizedMesh3D -- fourier_weight[0,1,2] mix x, y, z (mesh_3d.py:71,86,101);
+                      activations zero-padded by ``padding`` at the end of every axis after the lift and
+                      cropped before the head (mesh_3d.py:165,173); ``output_dim`` outputs.
+    """
+
+    def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
+                 share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
+                 padding: int = 0, output_dim: int = 1):
         if mode not in MODES:
             raise ValueError(f"mode must be one of {list(MODES)}, got {mode!r}")
+        if spatial_dims not in (2, 3):
+            raise ValueError("spatial_dims must be 2 or 3")
         C, H = width, factor * width
         if (C, H) not in _SUPPORTED_CH:
             raise ValueError(f"(width, factor*width)=({C},{H}) is outside the compiled HIP kernel set {_SUPPORTED_CH}")
         if not (0 < input_dim < 64):
             raise ValueError("input_dim must be in 1..63")
-        self.K, self.C, self.H, self.Cin, self.L = modes, C, H, input_dim, n_layers
+        if not (1 <= output_dim <= 8):
+            raise ValueError("output_dim must be in 1..8")
+        self.nd = spatial_dims
+        self.Ks: Tuple[int, ...] = tuple(modes) if isinstance(modes, (tuple, list)) else (int(modes),) * spatial_dims
+        if len(self.Ks) != spatial_dims:
+            raise ValueError("one mode count per spatial axis")
+        self.K = self.Ks[0]
+        self.C, self.H, self.Cin, self.L, self.O, self.pad = C, H, input_dim, n_layers, output_dim, padding
         self.mode, self.mode_id = mode, MODES[mode]
         self.share_weight, self.share_fork, self.wnorm = share_weight, share_fork, ff_weight_norm
 
@@ -74,7 +107,7 @@ class FFNO2DEngine:
 
         add_linear("in_proj.", C, input_dim)
         self.ff_prefix: List[str] = []
-        self.fw_names: List[Tuple[str, str]] = []
+        self.fw_names: List[Tuple[str, ...]] = []
         for l in range(n_layers):
             fp = "backcast_ff." if share_fork else f"spectral_layers.{l}.backcast_ff."
             self.ff_prefix.append(fp)
@@ -82,12 +115,12 @@ class FFNO2DEngine:
             add_linear(fp + "layers.1.0.", C, H)
             if mode == "full":
                 base = "fourier_weight." if share_weight else f"spectral_layers.{l}.fourier_weight."
-                names = (base + "0", base + "1")
+                names = tuple(base + str(w) for w in range(self.nd))
                 self.fw_names.append(names)
-                for n in names:
-                    self.param_shapes.setdefault(n, (C, C, modes, 2))
+                for w, n in enumerate(names):
+                    self.param_shapes.setdefault(n, (C, C, self.Ks[w], 2))
         add_linear("out.0.", HEAD_DIM, C)
-        add_linear("out.1.", 1, HEAD_DIM)
+        add_linear("out.1.", output_dim, HEAD_DIM)
         self.param_names = list(self.param_shapes)
         self.n_params = sum(int(np.prod(s)) for s in self.param_shapes.values())
         self._offsets = {}
@@ -95,6 +128,10 @@ class FFNO2DEngine:
         for n in self.param_names:
             self._offsets[n] = off
             off += int(np.prod(self.param_shapes[n]))
+        self._fw_sets: List[Tuple[str, ...]] = []   # unique weight tuples in first-use order
+        for names in self.fw_names:
+            if names not in self._fw_sets:
+                self._fw_sets.append(names)
 
         self.params: Dict[str, torch.Tensor] = {}
         self.device = None
@@ -146,23 +183,19 @@ class FFNO2DEngine:
 
     def _alloc_param_buffers(self):
         dev = self.device
-        self.gflat = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(self.n_params, **f32)
         n_eff = sum(l.rows * l.cols for l in self.linears.values()) if self.wnorm else 0
-        self.weff_flat = torch.empty(max(n_eff, 1), dtype=torch.float32, device=dev)
-        self.gweff_flat = torch.zeros(max(n_eff, 1), dtype=torch.float32, device=dev)
-        self.fold = torch.zeros(self.C + 1, dtype=torch.float32, device=dev)
+        self.weff_flat = torch.empty(max(n_eff, 1), **f32)
+        self.gweff_flat = torch.zeros(max(n_eff, 1), **f32)
+        self.fold = torch.zeros(self.O * (self.C + 1), **f32)
         n_ff = sum(l.rows * l.cols for p, l in self.linears.items() if "_ff." in p)
-        self.wt_flat = torch.empty(max(n_ff, 1), dtype=torch.float32, device=dev)
-        n_sets = len({n for n in self.fw_names})
-        self._fw_sets = []  # unique (name_y, name_x) in first-use order
-        for names in self.fw_names:
-            if names not in self._fw_sets:
-                self._fw_sets.append(names)
-        plane = 2 * self.K * self.C * self.C
-        self.planes = torch.empty((max(len(self._fw_sets), 1), 2, 2, plane), dtype=torch.float32, device=dev)
+        self.wt_flat = torch.empty(max(n_ff, 1), **f32)
+        # mode-major weight planes: planes[set][w] = (wp, wpt), each 2*K_w*C*C floats
+        self.planes = [[(torch.empty(2 * K * self.C * self.C, **f32), torch.empty(2 * K * self.C * self.C, **f32))
+                        for K in self.Ks] for _ in range(max(len(self._fw_sets), 1))]
         self._ws_key = None
         self._tw = {}
-        del n_sets
 
     def grad_view(self, name: str) -> torch.Tensor:
         o = self._offsets[name]
@@ -216,46 +249,62 @@ class FFNO2DEngine:
         return self._tw[L]
 
     # ------------------------------------------------------------------------------------------------
-    def _workspace(self, B, M, N, save: bool):
-        key = (B, M, N, bool(save))
+    def _views(self, B: int, Sp: Sequence[int]) -> List[_View]:
+        """views[w] = the axis mixed by fourier_weight[w], as a [Bv, Mv, Nv, C] view of the (padded) buffer."""
+        C = self.C
+        if self.nd == 2:
+            M, N = Sp
+            return [_View(B, M, N, 0, self.Ks[0], C), _View(B, M, N, 1, self.Ks[1], C)]
+        X, Y, Z = Sp
+        return [_View(B, X, Y * Z, 1, self.Ks[0], C),       # x: lines (b, y, z), stride Y*Z*C
+                _View(B * X, Y, Z, 1, self.Ks[1], C),       # y: lines (b, x, z), stride Z*C
+                _View(B, X * Y, Z, 0, self.Ks[2], C)]       # z: contiguous lines (b, x, y)
+
+    def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
+        key = (B, tuple(S), bool(save))
         if self._ws_key == key:
             return self._ws
         lib = _lib.get_lib()
-        dev, C, H, K, L = self.device, self.C, self.H, self.K, self.L
-        P = B * M * N
+        dev, C, H, L, O = self.device, self.C, self.H, self.L, self.O
+        Sp = tuple(s + self.pad for s in S)
+        P_in = B * int(np.prod(S))            # unpadded pixels (inputs / outputs)
+        P = B * int(np.prod(Sp))              # pixels of the activation buffers
         f32 = dict(dtype=torch.float32, device=dev)
         ns = L if save else 1
         ws = type("WS", (), {})()
-        ws.P, ws.R = P, (B * M, B * N)
+        ws.P, ws.P_in, ws.Sp = P, P_in, Sp
+        ws.views = self._views(B, Sp)
+        ws.padmap = None
+        if self.pad:
+            s3 = (1,) * (3 - self.nd) + tuple(S)
+            p3 = (1,) * (3 - self.nd) + tuple(Sp)
+            ws.padmap = _capi.PadMap((ctypes.c_int32 * 3)(*s3), (ctypes.c_int32 * 3)(*p3))
         ws.X = torch.empty(P, C, **f32)
         ws.Blast = torch.empty(P, C, **f32)
-        ws.Y = torch.empty(P, **f32)
+        ws.Y = torch.empty(P_in * O, **f32)
         ws.S = torch.empty(ns, P, C, **f32)
-        spec = [K * ws.R[0] * 2 * C, K * ws.R[1] * 2 * C]
-        ws.spec = spec
-        ws.SXall = [torch.empty(ns, spec[a], **f32) for a in (0, 1)]      # forward spectra, per axis, layer-major
-        ws.SX = [[ws.SXall[a][i] for a in (0, 1)] for i in range(ns)]
-        ws.SY = torch.empty(max(spec), **f32)
+        nv = len(ws.views)
+        ws.SXall = [torch.empty(ns, v.spec, **f32) for v in ws.views]      # forward spectra, per axis, layer-major
+        ws.SY = torch.empty(max(v.spec for v in ws.views), **f32)
+        ws.SD = torch.empty(max(v.spec for v in ws.views), **f32)    # scratch spectrum of the staged path
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
         if save:
             ws.Hbuf = torch.empty(ns, P, H, **f32)
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
-            ws.DH = [torch.empty(P, H, **f32) for _ in range(2)]   # ping-pong: the side stream reads one while the next layer writes the other
+            ws.DH = [torch.empty(P, H, **f32) for _ in range(2)]   # ping-pong (side-stream option)
             ws.DS = torch.empty(P, C, **f32)
             ws.G = [torch.empty(P, C, **f32) for _ in range(2)]    # running gradient, ping-pong per layer
-            ws.SD = torch.empty(max(spec), **f32)
-            ws.SDall = [torch.empty(L, spec[a], **f32) for a in (0, 1)] if self.mode == "full" else None
+            ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
-            ws.nsplit_fw = [max(1, min(max(1, 512 // K), (L * r + 63) // 64)) for r in ws.R]
-            plane = 2 * K * C * C
-            ws.fwpart = [[torch.empty(ws.nsplit_fw[a] * plane, **f32) for a in (0, 1)]
+            ws.nsplit_fw = [max(1, min(max(1, 512 // v.K), (L * v.R + 63) // 64)) for v in ws.views]
+            ws.fwpart = [[torch.empty(ws.nsplit_fw[w] * 2 * ws.views[w].K * C * C, **f32) for w in range(nv)]
                          for _ in range(max(len(self._fw_sets), 1))]
-            ws.nsplit_lift = max(1, min(256, (P + 255) // 256))
+            ws.nsplit_lift = max(1, min(256, (P_in + 255) // 256))
             ws.liftpart = torch.empty(ws.nsplit_lift * C * (self.Cin + 1), **f32)
-            ws.nsplit_head = max(1, min(256, (P + 255) // 256))
-            ws.headpart = torch.empty(ws.nsplit_head * (C + 1), **f32)
-            ws.red = torch.empty(C + 1, **f32)
+            ws.nsplit_head = max(1, min(256, (P_in + 255) // 256))
+            ws.headpart = torch.empty(ws.nsplit_head * O * (C + 1), **f32)
+            ws.red = torch.empty(O * (C + 1), **f32)
         self._ws, self._ws_key = ws, key
         return ws
 
@@ -264,42 +313,72 @@ class FFNO2DEngine:
         self._refresh_pointers()
         if self._desc_dev is not None:
             self._k("weightnorm_fwd", lib.ffno_weightnorm_fwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
-        for i, (ny, nx) in enumerate(self._fw_sets):
-            for a, n in enumerate((ny, nx)):
-                self._k("fw_pack", lib.ffno_fw_pack, _p(self.params[n]), _p(self.planes[i, a, 0]), _p(self.planes[i, a, 1]),
-                                             self.C, self.K, st)
+        for i, names in enumerate(self._fw_sets):
+            for w, n in enumerate(names):
+                self._k("fw_pack", lib.ffno_fw_pack, _p(self.params[n]), _p(self.planes[i][w][0]), _p(self.planes[i][w][1]),
+                        self.C, self.Ks[w], st)
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         self._k("head_fold", lib.ffno_head_fold, _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
-                                       _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, st)
+                _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, self.O, st)
 
     def _ff_weights(self, l):
         fp = self.ff_prefix[l]
         l0, l1 = self.linears[fp + "layers.0.0."], self.linears[fp + "layers.1.0."]
         return l0, l1, self.params[fp + "layers.0.0.bias"], self.params[fp + "layers.1.0.bias"]
 
+    def _can_fuse(self, views) -> bool:
+        lib = _lib.get_lib()
+        return bool(self.use_fused and self.mode != "no-fourier" and
+                    all(lib.ffno_spectral_fused_supported(self.C, v.K, v.L) for v in views))
+
+    def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st):
+        """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint)."""
+        lib = _lib.get_lib()
+        C = self.C
+        tw = self._twiddle(v.L)
+        ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
+        if fused:
+            self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
+                    v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, ck_i, conj, accumulate, st)
+            return
+        spec = save if save is not None else ws.SD
+        self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(spec), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, st)
+        y = spec
+        if planes is not None:
+            self._k("mode_mix", lib.ffno_mode_mix, _p(spec), _p(planes), _p(ws.SY), v.R, C, v.K, conj, st)
+            y = ws.SY
+        self._k("dft_inv", lib.ffno_dft_inv, _p(y), _p(dst), resid, _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_i,
+                accumulate, st)
+
     # ------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, save_for_backward: bool) -> torch.Tensor:
-        """x [B, M, N, input_dim] fp32 on the device -> forecast [B, M, N, 1] (a fresh tensor)."""
+        """x [B, *spatial, input_dim] fp32 on the device -> [B, *spatial, output_dim] (a fresh tensor)."""
         if not self.params:
             raise RuntimeError("bind() parameters first")
         _lib.require_device_tensor(x, "x")
-        if x.dim() != 4 or x.shape[-1] != self.Cin:
-            raise ValueError(f"x must be [B, M, N, {self.Cin}], got {tuple(x.shape)}")
+        if x.dim() != self.nd + 2 or x.shape[-1] != self.Cin:
+            raise ValueError(f"x must be [B, {'M, N' if self.nd == 2 else 'X, Y, Z'}, {self.Cin}], got {tuple(x.shape)}")
         x = x.contiguous()
-        B, M, N, _ = x.shape
+        B, S = x.shape[0], tuple(x.shape[1:-1])
         lib = _lib.get_lib()
-        C, H, K, L = self.C, self.H, self.K, self.L
-        if self.mode != "no-fourier" and (K > N // 2 + 1 or K > M // 2 + 1):
-            raise ValueError(f"modes={K} exceeds grid//2+1 for grid {M}x{N} (the reference raises an einsum size error)")
-        ws = self._workspace(B, M, N, save_for_backward)
+        C, H, L = self.C, self.H, self.L
+        ws = self._workspace(B, S, save_for_backward)
+        if self.mode != "no-fourier":
+            for v in ws.views:
+                if v.K > v.L // 2 + 1:
+                    raise ValueError(f"modes={v.K} exceeds size//2+1 for an axis of length {v.L} "
+                                     f"(the reference raises an einsum size error)")
         st = _lib.current_stream(self.device)
         P = ws.P
         self._prepare_weights(st)
-        tw = (self._twiddle(N), self._twiddle(M))
-        fused = (self.use_fused and self.mode != "no-fourier" and
-                 all(lib.ffno_spectral_fused_supported(C, K, Lx) for Lx in (N, M)))
+        fused = self._can_fuse(ws.views)
+        full = self.mode == "full"
         lin_in = self.linears["in_proj."]
-        self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), P, self.Cin, C, st)
+        pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
+        if pm is not None:
+            ws.X.zero_()     # F.pad(..., 0) of the lifted features (mesh_3d.py:165)
+        self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
+                self.Cin, C, pm, st)
         for l in range(L):
             sv = l if save_for_backward else 0
             last = l == L - 1
@@ -307,56 +386,45 @@ class FFNO2DEngine:
             if self.mode == "no-fourier":
                 s_l.copy_(ws.X)
             else:
-                for a in (0, 1):
-                    sx = ws.SX[sv][a]
-                    si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
-                    if fused:
-                        self._k("spectral_fused", lib.ffno_spectral_fused, _p(ws.X), _p(s_l), None,
-                                _p(sx) if (save_for_backward and self.mode == "full") else None,
-                                _p(self.planes[si, a, 0]) if self.mode == "full" else None, _p(tw[a]),
-                                B, M, N, C, K, a, 0, 1, 0, int(a == 1), st)
-                        continue
-                    self._k("dft_fwd", lib.ffno_dft_fwd, _p(ws.X), _p(sx), _p(tw[a]), B, M, N, C, K, a, 0, st)
-                    y = sx
-                    if self.mode == "full":
-                        self._k("mode_mix", lib.ffno_mode_mix, _p(sx), _p(self.planes[si, a, 0]), _p(ws.SY), ws.R[a], C, K, 0, st)
-                        y = ws.SY
-                    self._k("dft_inv", lib.ffno_dft_inv, _p(y), _p(s_l), None, _p(tw[a]), B, M, N, C, K, a, 1, int(a == 1), st)
+                si = self._fw_sets.index(self.fw_names[l]) if full else 0
+                for w, v in enumerate(ws.views):
+                    keep = ws.SXall[w][sv] if full else None     # stage-A spectrum (kept per layer when training)
+                    if fused and not save_for_backward:
+                        keep = None
+                    self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
+                                   self.planes[si][w][0] if full else None, True, int(w > 0), fused, st)
             l0, l1, b0, b1 = self._ff_weights(l)
             self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None if last else _p(ws.X), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1),
-                                        _p(ws.Blast if last else ws.X),
-                                        _p(ws.Hbuf[sv]) if save_for_backward else None,
-                                        _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
-        self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), P, C, 0, st)
-        self._saved = (x, B, M, N) if save_for_backward else None
-        return ws.Y.view(B, M, N, 1).clone()
+                    _p(ws.Blast if last else ws.X), _p(ws.Hbuf[sv]) if save_for_backward else None,
+                    _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
+        self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
+        self._saved = (x, B, S, fused) if save_for_backward else None
+        return ws.Y.view(B, *S, self.O).clone()
 
     # ------------------------------------------------------------------------------------------------
     def backward(self, gy: torch.Tensor) -> torch.Tensor:
-        """gy = dL/dforecast [B, M, N, 1].  Fills and returns the flat gradient buffer ``gflat``
+        """gy = dL/dout [B, *spatial, output_dim].  Fills and returns the flat gradient buffer ``gflat``
         (layout: ``param_names`` order; use ``grad_view(name)``)."""
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
-        x, B, M, N = self._saved
+        x, B, S, fused = self._saved
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
-        C, H, K, L = self.C, self.H, self.K, self.L
-        ws = self._workspace(B, M, N, True)
+        C, H, L = self.C, self.H, self.L
+        ws = self._workspace(B, S, True)
         st = _lib.current_stream(self.device)
         P = ws.P
-        tw = (self._twiddle(N), self._twiddle(M))
-        fused = (self.use_fused and self.mode != "no-fourier" and
-                 all(lib.ffno_spectral_fused_supported(C, K, Lx) for Lx in (N, M)))
+        full = self.mode == "full"
+        pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         gv = self.grad_view
-        # Two streams: the main stream carries the dependency chain  ff_bwd_data(l) -> spectral adjoint(l) ->
-        # ff_bwd_data(l-1) ...; the FF weight-gradient GEMMs of layer l only need (G_l, dh_l, s_l, h_l), so they run
-        # on a side stream concurrently with the adjoint of layer l and the data gradient of layer l-1 (the kernels
-        # co-reside on a CU: 67 KiB + 66 KiB of LDS).  G and dh are ping-pong buffers; events order the reuse.
+        # Optional two-stream schedule (self.overlap): the FF weight-gradient GEMMs of layer l only need
+        # (G_l, dh_l, s_l, h_l), so they can run on a side stream next to the adjoint of layer l.  G and dh are
+        # ping-pong buffers; events order the reuse.
         use_side = self.overlap and self.device.type == "cuda" and self.mode != "no-fourier"
-        side = ev_a = ev_b = None
-        main_obj = None
+        side = ev_a = ev_b = main_obj = None
+        st_side = st
         if use_side:
             if getattr(self, "_side", None) is None:
                 self._side = torch.cuda.Stream(self.device)
@@ -364,14 +432,13 @@ class FFNO2DEngine:
             side, main_obj = self._side, torch.cuda.current_stream(self.device)
             ev_a, ev_b = self._ev[0], self._ev[1:]
             st_side = ctypes.c_void_p(side.cuda_stream)
-        else:
-            st_side = st
         cur = 0
-        self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red), P, C,
-                                      ws.nsplit_head, st)
-        self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
-                                              _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")),
-                                              C, HEAD_DIM, 0, st)
+        if pm is not None:
+            ws.G[cur].zero_()    # adjoint of the crop (mesh_3d.py:173): no gradient in the padded region
+        self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red),
+                ws.P_in, C, self.O, ws.nsplit_head, pm, st)
+        self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
+                _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
         self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
         for l in reversed(range(L)):
@@ -403,39 +470,39 @@ class FFNO2DEngine:
                     torch.add(g_in, ws.DS, out=g_out)
                 cur = 1 - cur
                 continue
-            si = self._fw_sets.index(self.fw_names[l]) if self.mode == "full" else 0
-            full = self.mode == "full"
-            resid = None if last else _p(g_in)      # G_{l-1} = G_l (residual path) + adjoint terms; last layer: no residual
-            for a in (0, 1):
-                sd = ws.SDall[a][l] if full else ws.SD   # dY of every layer is kept for the dW launch
-                if fused:
-                    self._k("spectral_fused(adj)", lib.ffno_spectral_fused, _p(ws.DS), _p(g_out), resid if a == 0 else None,
-                            _p(sd) if full else None, _p(self.planes[si, a, 1]) if full else None, _p(tw[a]),
-                            B, M, N, C, K, a, 1, 0, 1, int(a == 1), st)
-                    continue
-                self._k("dft_fwd(adj)", lib.ffno_dft_fwd, _p(ws.DS), _p(sd), _p(tw[a]), B, M, N, C, K, a, 1, st)
-                dxs = sd
-                if full:
-                    self._k("mode_mix(adj)", lib.ffno_mode_mix, _p(sd), _p(self.planes[si, a, 1]), _p(ws.SY), ws.R[a], C, K, 1, st)
-                    dxs = ws.SY
-                self._k("dft_inv(adj)", lib.ffno_dft_inv, _p(dxs), _p(g_out), resid if a == 0 else None, _p(tw[a]), B, M, N, C, K, a,
-                        0, int(a == 1), st)
+            si = self._fw_sets.index(self.fw_names[l]) if full else 0
+            resid = None if last else _p(g_in)      # G_{l-1} = G_l (residual path) + adjoint terms; last layer: none
+            for w, v in enumerate(ws.views):
+                keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
+                self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if w == 0 else None, keep,
+                               self.planes[si][w][1] if full else None, False, int(w > 0), fused, st)
             cur = 1 - cur
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
         g_fin = ws.G[cur]
         lin_in = self.linears["in_proj."]
-        self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")), P,
-                                      self.Cin, C, ws.nsplit_lift, 0, st)
+        self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")),
+                ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
         for si, names in enumerate(self._fw_sets):
             layers = [l for l in range(L) if self.fw_names[l] == names]
             l0_, nl = layers[0], len(layers)
             assert layers == list(range(l0_, l0_ + nl))
-            for a, n in enumerate(names):
+            for w, n in enumerate(names):
+                v = ws.views[w]
                 # dW = sum over the lines of every layer that uses this weight: ONE launch per axis
-                self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SXall[a][l0_]), _p(ws.SDall[a][l0_]),
-                        _p(ws.fwpart[si][a]), ws.R[a], C, K, ws.nsplit_fw[a], 0, nl, ws.spec[a], ws.spec[a], st)
-                self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce, _p(ws.fwpart[si][a]), _p(gv(n)), C, K, ws.nsplit_fw[a], 0, st)
+                self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SXall[w][l0_]), _p(ws.SDall[w][l0_]),
+                        _p(ws.fwpart[si][w]), v.R, C, v.K, ws.nsplit_fw[w], 0, nl, v.spec, v.spec, st)
+                self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce, _p(ws.fwpart[si][w]), _p(gv(n)), C, v.K, ws.nsplit_fw[w], 0, st)
         if self._desc_dev is not None:
             self._k("weightnorm_bwd", lib.ffno_weightnorm_bwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
         return self.gflat
+
+
+class FFNO2DEngine(FFNOEngine):
+    """FNOFactorized2DBlock geometry (the 2-D entry point used by the module mirror and the tests)."""
+
+    def __init__(self, *, modes: int, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
+                 share_fork: bool, ff_weight_norm: bool, mode: str = "full"):
+        super().__init__(modes=modes, width=width, input_dim=input_dim, n_layers=n_layers, factor=factor,
+                         share_weight=share_weight, share_fork=share_fork, ff_weight_norm=ff_weight_norm, mode=mode,
+                         spatial_dims=2, padding=0, output_dim=1)

@@ -1,1 +1,2 @@
 from .grid_2d import FNOFactorized2DBlock, SpectralConv2d  # noqa: F401
+from .mesh_3d import FNOFactorizedMesh3D  # noqa: F401

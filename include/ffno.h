@@ -189,30 +189,42 @@ typedef struct ffno_tr_desc {
 int ffno_transpose_batched(const ffno_tr_desc* descs_dev, int n, int max_rows, int max_cols, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * in_proj (grid_2d.py:112,157): out[P][C] = x[P][Cin] W^T + b, and its parameter gradients
- * (deterministic two-step reduction; partial needs nsplit*C*(Cin+1) floats).
+ * Pad / crop index map (3-D mesh operator, mesh_3d.py:165,173: F.pad by 8 at the END of each spatial
+ * axis after in_proj, crop before the head).  The lift and head kernels address the padded activation
+ * buffer directly: unpadded pixel (b, i0, i1, i2) <-> padded pixel (b, i0, i1, i2) of [B][padded...].
+ * Pass NULL for "no padding" (2-D grid operator).  Host struct, read at enqueue time.
  * --------------------------------------------------------------------------------------------- */
-int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
-                  void* stream);
-int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
-                  int Cin, int C, int nsplit, int accumulate, void* stream);
+typedef struct ffno_padmap {
+    int32_t size[3];    /* unpadded spatial sizes (use {1, M, N} for 2-D) */
+    int32_t padded[3];  /* padded spatial sizes */
+} ffno_padmap;
 
 /* ---------------------------------------------------------------------------------------------
- * Output head (grid_2d.py:150-152,171-172): y[P] = (b W_a^T + c_a) W_b^T + c_b with W_a[D][C],
- * W_b[1][D] and NO activation in between, evaluated as one affine map  y = b . weff + beff.
- *   ffno_head_fold : weff[C] = W_b W_a, beff = W_b c_a + c_b           (fold[C+1])
- *   ffno_head_fwd  : y[p] (+)= b[p] . weff + beff
- *   ffno_head_bwd  : gb[p][c] = gy[p]*weff[c];  red[C+1] = { sum_p gy[p] b[p][:],  sum_p gy[p] }
+ * in_proj (grid_2d.py:112,157 / mesh_3d.py:162): out[q(p)][C] = x[p][Cin] W^T + b, and its parameter
+ * gradients (deterministic two-step reduction; partial needs nsplit*C*(Cin+1) floats).
+ * --------------------------------------------------------------------------------------------- */
+int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
+                  const ffno_padmap* pad, void* stream);
+int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
+                  int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Output head (grid_2d.py:150-152,171-172; mesh_3d.py:155-157,174): y[P][O] = (b W_a^T + c_a) W_b^T + c_b
+ * with W_a[D][C], W_b[O][D] (O <= 8) and NO activation in between, evaluated as one affine map.
+ *   ffno_head_fold : fold[o] = { weff[o][C] = W_b[o] W_a, beff[o] = W_b[o] c_a + c_b[o] }   (fold[O][C+1])
+ *   ffno_head_fwd  : y[p][o] (+)= b[q(p)] . weff[o] + beff[o]
+ *   ffno_head_bwd  : gb[q(p)][c] = sum_o gy[p][o] weff[o][c];  red[o] = { sum_p gy[p][o] b[q(p)][:], sum_p gy[p][o] }
+ *                    (partial needs nsplit*O*(C+1) floats; gb is only written at q(p): pre-zero it when padded)
  *   ffno_head_param_grads : dW_a, dc_a, dW_b, dc_b from red (exact chain rule of the two linears)
  * --------------------------------------------------------------------------------------------- */
 int ffno_head_fold(const float* Wa, const float* ca, const float* Wb, const float* cb, float* fold,
-                   int C, int D, void* stream);
-int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int accumulate,
-                  void* stream);
+                   int C, int D, int O, void* stream);
+int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int O, int accumulate,
+                  const ffno_padmap* pad, void* stream);
 int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
-                  float* red, int P, int C, int nsplit, void* stream);
+                  float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, void* stream);
 int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,
-                          float* dWa, float* dca, float* dWb, float* dcb, int C, int D,
+                          float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int O,
                           int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -203,3 +203,51 @@ def init_block_state_dict(*, modes: int, width: int, input_dim: int, n_layers: i
     add_linear("out.0.", width, 128)
     add_linear("out.1.", 128, 1)
     return sd
+
+
+# --------------------------------------------------------------------------
+# FNOFactorizedMesh3D  (factorized_fno/mesh_3d.py:55-112 forward_fourier, :160-189 forward)
+# --------------------------------------------------------------------------
+def spectral_branch_nd(x_cf: Tensor, w: Tensor, modes: int, dim: int) -> Tensor:
+    """One axis of the 3-D factorized spectral conv on channels-first [B, I, S1, S2, S3]."""
+    L = x_cf.shape[dim]
+    kept = torch.fft.rfft(x_cf, dim=dim, norm="ortho").narrow(dim, 0, modes)
+    letter = {-3: "x", -2: "y", -1: "z"}[dim]
+    kept = torch.einsum(f"bixyz,io{letter}->boxyz", kept, torch.view_as_complex(w.contiguous()))
+    shape = list(kept.shape)
+    shape[dim] = L // 2 + 1
+    padded = kept.new_zeros(shape)
+    padded.narrow(dim, 0, modes).copy_(kept)
+    return torch.fft.irfft(padded, n=L, dim=dim, norm="ortho")
+
+
+def forward_fourier_3d(x: Tensor, weights, modes) -> Tensor:
+    """x [B, S1, S2, S3, I]; weights[0|1|2] mix the x|y|z axis with modes[0|1|2] (mesh_3d.py:62-103)."""
+    x_cf = x.permute(0, 4, 1, 2, 3)
+    out = (spectral_branch_nd(x_cf, weights[2], modes[2], -1) + spectral_branch_nd(x_cf, weights[1], modes[1], -2) +
+           spectral_branch_nd(x_cf, weights[0], modes[0], -3))
+    return out.permute(0, 2, 3, 4, 1)
+
+
+def mesh3d_grid(shape, dtype) -> Tensor:
+    """linspace(0,1) coordinate channels (mesh_3d.py:178-189)."""
+    B, X, Y, Z = shape[0], shape[1], shape[2], shape[3]
+    gx = torch.linspace(0, 1, X, dtype=torch.float64).to(dtype).reshape(1, X, 1, 1, 1).expand(B, X, Y, Z, 1)
+    gy = torch.linspace(0, 1, Y, dtype=torch.float64).to(dtype).reshape(1, 1, Y, 1, 1).expand(B, X, Y, Z, 1)
+    gz = torch.linspace(0, 1, Z, dtype=torch.float64).to(dtype).reshape(1, 1, 1, Z, 1).expand(B, X, Y, Z, 1)
+    return torch.cat((gx, gy, gz), dim=-1)
+
+
+def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, padding: int = 8) -> Tensor:
+    """x [B, X, Y, Z, input_dim - 3] -> [B, X, Y, Z, output_dim] (mesh_3d.py:160-176)."""
+    x = torch.cat((x, mesh3d_grid(x.shape, x.dtype)), dim=-1)
+    x = linear_from_sd(sd, "in_proj.", x)
+    x = F.pad(x.permute(0, 4, 1, 2, 3), [0, padding, 0, padding, 0, padding]).permute(0, 2, 3, 4, 1)
+    b = None
+    for i in range(n_layers):
+        pre = f"spectral_layers.{i}."
+        s = forward_fourier_3d(x, [sd[pre + f"fourier_weight.{w}"] for w in range(3)], modes)
+        b = feedforward(sd, pre + "backcast_ff.", s)
+        x = x + b
+    b = b[:, :-padding, :-padding, :-padding, :]
+    return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", b))

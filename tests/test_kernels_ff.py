@@ -118,6 +118,18 @@ def test_transpose_batched(be):
         np.testing.assert_array_equal(be.get(b), a.T)
 
 
+def padmap(be, size, padded):
+    from fourierflow_amd._capi import PadMap
+    pm = PadMap((ctypes.c_int32 * 3)(*size), (ctypes.c_int32 * 3)(*padded))
+    return pm
+
+
+def pad_index(Bn, size, padded):
+    """unpadded pixel p -> padded pixel q for [B][s0][s1][s2] inside [B][p0][p1][p2] (pad at the END of each axis)."""
+    b, x, y, z = np.meshgrid(np.arange(Bn), np.arange(size[0]), np.arange(size[1]), np.arange(size[2]), indexing="ij")
+    return (((b * padded[0] + x) * padded[1] + y) * padded[2] + z).reshape(-1)
+
+
 @pytest.mark.parametrize("P,Cin,C", [(100, 3, 64), (77, 5, 32), (50, 37, 64)])
 def test_lift(be, P, Cin, C):
     lib, p = be.lib, be.ptr
@@ -126,14 +138,63 @@ def test_lift(be, P, Cin, C):
     W = rs.standard_normal((C, Cin)).astype(np.float32)
     b = rs.standard_normal(C).astype(np.float32)
     dx, dW_, db_, out = be.put(x), be.put(W), be.put(b), be.empty((P, C))
-    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, None) == 0
+    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, None, None) == 0
     assert rel_l2(be.get(out), x.astype(np.float64) @ W.T + b) < TOL
     g = rs.standard_normal((P, C)).astype(np.float32)
     nsplit = 3
     dg, partial, gW, gb = be.put(g), be.zeros(nsplit * C * (Cin + 1)), be.zeros((C, Cin)), be.zeros(C)
-    assert lib.ffno_lift_bwd(p(dx), p(dg), p(partial), p(gW), p(gb), P, Cin, C, nsplit, 0, None) == 0
+    assert lib.ffno_lift_bwd(p(dx), p(dg), p(partial), p(gW), p(gb), P, Cin, C, nsplit, 0, None, None) == 0
     assert rel_l2(be.get(gW), g.astype(np.float64).T @ x) < TOL
     assert rel_l2(be.get(gb), g.astype(np.float64).sum(0)) < TOL
+
+
+def test_lift_and_head_through_pad_map(be):
+    """mesh_3d.py:165,173: the lift writes into / the head reads from the zero-padded activation buffer."""
+    lib, p = be.lib, be.ptr
+    Bn, size, padded, Cin, C, O, D = 2, (3, 4, 5), (5, 7, 6), 4, 64, 4, 128
+    P, Pp = Bn * int(np.prod(size)), Bn * int(np.prod(padded))
+    q = pad_index(Bn, size, padded)
+    pm = padmap(be, size, padded)
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((P, Cin)).astype(np.float32)
+    W = rs.standard_normal((C, Cin)).astype(np.float32)
+    b = rs.standard_normal(C).astype(np.float32)
+    dx, dW_, db_, out = be.put(x), be.put(W), be.put(b), be.zeros((Pp, C))
+    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, ctypes.byref(pm), None) == 0
+    ref = np.zeros((Pp, C))
+    ref[q] = x.astype(np.float64) @ W.T + b
+    assert rel_l2(be.get(out), ref) < TOL            # pad region untouched (stays zero)
+    g = rs.standard_normal((Pp, C)).astype(np.float32)
+    dg, partial, gW, gb = be.put(g), be.zeros(2 * C * (Cin + 1)), be.zeros((C, Cin)), be.zeros(C)
+    assert lib.ffno_lift_bwd(p(dx), p(dg), p(partial), p(gW), p(gb), P, Cin, C, 2, 0, ctypes.byref(pm), None) == 0
+    assert rel_l2(be.get(gW), g[q].astype(np.float64).T @ x) < TOL
+    # head with O outputs reading the padded buffer
+    Wa = (rs.standard_normal((D, C)) / 8).astype(np.float32)
+    ca = rs.standard_normal(D).astype(np.float32)
+    Wb = (rs.standard_normal((O, D)) / 8).astype(np.float32)
+    cb = rs.standard_normal(O).astype(np.float32)
+    feat = rs.standard_normal((Pp, C)).astype(np.float32)
+    dWa, dca_, dWb, dcb_, dft = map(be.put, (Wa, ca, Wb, cb, feat))
+    fold, y = be.zeros(O * (C + 1)), be.empty((P, O))
+    assert lib.ffno_head_fold(p(dWa), p(dca_), p(dWb), p(dcb_), p(fold), C, D, O, None) == 0
+    assert lib.ffno_head_fwd(p(dft), p(fold), p(y), P, C, O, 0, ctypes.byref(pm), None) == 0
+    refy = (feat[q].astype(np.float64) @ Wa.T + ca) @ Wb.T + cb
+    assert rel_l2(be.get(y), refy) < TOL
+    gy = rs.standard_normal((P, O)).astype(np.float32)
+    nsplit = 3
+    dgy, gbuf, part, red = be.put(gy), be.zeros((Pp, C)), be.zeros(nsplit * O * (C + 1)), be.zeros(O * (C + 1))
+    assert lib.ffno_head_bwd(p(dft), p(dgy), p(fold), p(gbuf), p(part), p(red), P, C, O, nsplit, ctypes.byref(pm), None) == 0
+    weff = Wb.astype(np.float64) @ Wa
+    refg = np.zeros((Pp, C))
+    refg[q] = gy.astype(np.float64) @ weff
+    assert rel_l2(be.get(gbuf), refg) < TOL
+    gWa, gca, gWb, gcb = be.zeros(Wa.shape), be.zeros(ca.shape), be.zeros(Wb.shape), be.zeros(cb.shape)
+    assert lib.ffno_head_param_grads(p(red), p(dWa), p(dca_), p(dWb), p(gWa), p(gca), p(gWb), p(gcb), C, D, O, 0, None) == 0
+    hid = feat[q].astype(np.float64) @ Wa.T + ca
+    assert rel_l2(be.get(gWb), gy.astype(np.float64).T @ hid) < 1e-4
+    assert rel_l2(be.get(gWa), (gy.astype(np.float64) @ Wb).T @ feat[q]) < 1e-4
+    assert rel_l2(be.get(gca), (gy.astype(np.float64) @ Wb).sum(0)) < 1e-4
+    assert rel_l2(be.get(gcb), gy.astype(np.float64).sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("P,C", [(300, 64), (77, 32)])
@@ -148,16 +209,16 @@ def test_head(be, P, C):
     bfeat = rs.standard_normal((P, C)).astype(np.float32)
     dWa, dca_, dWb, dcb_, dbf = map(be.put, (Wa, ca, Wb, cb, bfeat))
     fold, y = be.zeros(C + 1), be.empty(P)
-    assert lib.ffno_head_fold(p(dWa), p(dca_), p(dWb), p(dcb_), p(fold), C, D, None) == 0
-    assert lib.ffno_head_fwd(p(dbf), p(fold), p(y), P, C, 0, None) == 0
+    assert lib.ffno_head_fold(p(dWa), p(dca_), p(dWb), p(dcb_), p(fold), C, D, 1, None) == 0
+    assert lib.ffno_head_fwd(p(dbf), p(fold), p(y), P, C, 1, 0, None, None) == 0
     ref = ((bfeat.astype(np.float64) @ Wa.T + ca) @ Wb.T + cb)[:, 0]
     assert rel_l2(be.get(y), ref) < TOL
-    assert lib.ffno_head_fwd(p(dbf), p(fold), p(y), P, C, 1, None) == 0
+    assert lib.ffno_head_fwd(p(dbf), p(fold), p(y), P, C, 1, 1, None, None) == 0
     assert rel_l2(be.get(y), 2 * ref) < TOL
     gy = rs.standard_normal(P).astype(np.float32)
     nsplit = 4
     dgy, gb, partial, red = be.put(gy), be.empty((P, C)), be.zeros(nsplit * (C + 1)), be.zeros(C + 1)
-    assert lib.ffno_head_bwd(p(dbf), p(dgy), p(fold), p(gb), p(partial), p(red), P, C, nsplit, None) == 0
+    assert lib.ffno_head_bwd(p(dbf), p(dgy), p(fold), p(gb), p(partial), p(red), P, C, 1, nsplit, None, None) == 0
     weff = (Wb.astype(np.float64) @ Wa)[0]
     assert rel_l2(be.get(gb), gy[:, None] * weff[None]) < TOL
     G = gy.astype(np.float64) @ bfeat
@@ -165,7 +226,7 @@ def test_head(be, P, C):
     r = be.get(red)
     assert rel_l2(r[:C], G) < TOL and abs(r[C] - S) < 1e-4
     gWa, gca, gWb, gcb = be.zeros(Wa.shape), be.zeros(ca.shape), be.zeros(Wb.shape), be.zeros(cb.shape)
-    assert lib.ffno_head_param_grads(p(red), p(dWa), p(dca_), p(dWb), p(gWa), p(gca), p(gWb), p(gcb), C, D, 0, None) == 0
+    assert lib.ffno_head_param_grads(p(red), p(dWa), p(dca_), p(dWb), p(gWa), p(gca), p(gWb), p(gcb), C, D, 1, 0, None) == 0
     hid = bfeat.astype(np.float64) @ Wa.T + ca
     assert rel_l2(be.get(gWb)[0], gy.astype(np.float64) @ hid) < 1e-4
     assert rel_l2(be.get(gWa), np.outer(Wb[0], G)) < TOL
