@@ -219,39 +219,28 @@ __global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restri
 template <int C, int H>
 struct FFWgCfg {
     static constexpr int HT = H / 32;
-    static constexpr int NW = HT < 4 ? HT : 4;   // tile-owner waves per k-group (each owns TPW hidden tiles)
+    static constexpr int NW = HT < 4 ? HT : 4;   // waves per k-group (each owns TPW hidden tiles)
     static constexpr int TPW = HT / NW;
     static constexpr int CT = C / 32;
-    static constexpr int NT = NW * 128;          // threads: two k-groups of NW waves
-    static constexpr int SP = 16;                // pixels per pipeline stage (8 k-steps: 4 per k-group)
+    static constexpr int UNR = 4;                // k-steps (pixel pairs) per trip, all loads issued up front
     static constexpr int PART = 2 * H * C + H + C;  // floats per slice
     static constexpr int ACC = TPW * CT * 16;    // accumulator floats per lane for one of {dW1, dW2}
-    // stage image in LDS: dh[SP][H] | h[SP][H] | s[SP][C] | db[SP][C]
-    static constexpr int OFF_DH = 0, OFF_H = SP * H, OFF_S = 2 * SP * H, OFF_DB = 2 * SP * H + SP * C;
-    static constexpr int STAGE = 2 * SP * H + 2 * SP * C;         // floats per stage
-    static constexpr int F4 = STAGE / 4;                          // 16-B pieces per stage
-    static constexpr int NL = (F4 + NT - 1) / NT;                 // pieces per thread
-    static constexpr int COMB = NW * 64 * (ACC + 2);              // floats of the end-of-kernel combine buffer
-    static constexpr int LDS = (2 * STAGE > COMB) ? 2 * STAGE : COMB;
 };
 
-// Pixel-sliced "TN" GEMMs.  The operands of a 16-pixel stage are copied HBM -> registers -> LDS with fully
-// coalesced 16-B loads (each stage is four contiguous row blocks), two stages deep, so the HBM stream never
-// waits for the MFMAs; MFMA fragments are then read from LDS (rows of consecutive channels: conflict-free).
-// Two k-groups of NW waves split each stage's 8 k-steps; their accumulators are combined through LDS at the end.
+// Two k-groups of NW waves split the pixel slice (interleaved trips) so every SIMD hosts two waves
+// whose load latencies overlap; the groups' accumulators are combined through LDS at the end.
 template <int C, int H>
-__global__ __launch_bounds__((FFWgCfg<C, H>::NT)) void ff_bwd_weights_partial_kernel(
+__global__ __launch_bounds__((FFWgCfg<C, H>::NW * 128)) void ff_bwd_weights_partial_kernel(
     const float* __restrict__ s, const float* __restrict__ db, const float* __restrict__ h,
     const float* __restrict__ dh, float* __restrict__ partial, int P, int chunk) {
     using G = FFWgCfg<C, H>;
-    constexpr int TPW = G::TPW, CT = G::CT, NW = G::NW, SP = G::SP, NL = G::NL, NT = G::NT;
-    __shared__ __attribute__((aligned(16))) float lds[G::LDS];
+    constexpr int TPW = G::TPW, CT = G::CT, NW = G::NW, UNR = G::UNR;
+    __shared__ float comb[NW * 64 * (G::ACC + 2)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int grp = wv / NW, wave = wv % NW;
     const int j = lane & 31, half = lane >> 5;
     const long pbeg = (long)blockIdx.x * chunk;
     const long pend = min((long)P, pbeg + chunk);
-    const int nstages = (int)((max(pend - pbeg, 0L) + SP - 1) / SP);
 
     f32x16 acc1[TPW][CT], acc2[CT][TPW];
     float bs1[TPW], bs2[CT];
@@ -267,80 +256,40 @@ __global__ __launch_bounds__((FFWgCfg<C, H>::NT)) void ff_bwd_weights_partial_ke
     FFNO_UNROLL
     for (int b = 0; b < CT; ++b) bs2[b] = 0.f;
 
-    float4 rg[NL];
-    // piece i of a stage -> (array, row, col): rows are pixels; every array's SP rows are contiguous in HBM
-    auto fetch = [&](int stage) {
-        const long p0 = pbeg + (long)stage * SP;
+    const int nsteps = (int)((max(pend - pbeg, 0L) + 1) >> 1);
+    for (int t0 = grp * UNR; t0 < nsteps; t0 += 2 * UNR) {
+        float dhA[UNR][TPW], hB[UNR][TPW], sB[UNR][CT], dbA[UNR][CT];
         FFNO_UNROLL
-        for (int u = 0; u < NL; ++u) {
-            const int i = threadIdx.x + u * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < G::F4) {
-                const int e = 4 * i;
-                const float* src;
-                int row, col, ld;
-                if (e < G::OFF_H) {
-                    src = dh; ld = H; row = e / H; col = e % H;
-                } else if (e < G::OFF_S) {
-                    src = h; ld = H; row = (e - G::OFF_H) / H; col = (e - G::OFF_H) % H;
-                } else if (e < G::OFF_DB) {
-                    src = s; ld = C; row = (e - G::OFF_S) / C; col = (e - G::OFF_S) % C;
-                } else {
-                    src = db; ld = C; row = (e - G::OFF_DB) / C; col = (e - G::OFF_DB) % C;
-                }
-                if (p0 + row < pend) v = *reinterpret_cast<const float4*>(src + (p0 + row) * ld + col);
-            }
-            rg[u] = v;
-        }
-    };
-    auto deposit = [&](int buf) {
-        float* dst = lds + buf * G::STAGE;
-        FFNO_UNROLL
-        for (int u = 0; u < NL; ++u) {
-            const int i = threadIdx.x + u * NT;
-            if (i < G::F4) *reinterpret_cast<float4*>(dst + 4 * i) = rg[u];
-        }
-    };
-
-    if (nstages > 0) {
-        fetch(0);
-        deposit(0);
-        if (nstages > 1) fetch(1);
-    }
-    for (int st = 0; st < nstages; ++st) {
-        __syncthreads();   // stage `st` is visible; everybody is done reading the other buffer
-        if (st + 1 < nstages) deposit((st + 1) & 1);
-        if (st + 2 < nstages) fetch(st + 2);
-        const float* cur = lds + (st & 1) * G::STAGE;
-        FFNO_UNROLL
-        for (int u = 0; u < SP / 4; ++u) {                 // this k-group's 4 k-steps (2 pixels each)
-            const int px = 2 * (grp * (SP / 4) + u) + half;
-            float dhA[TPW], hB[TPW], sB[CT], dbA[CT];
+        for (int u = 0; u < UNR; ++u) {
+            const long p = pbeg + 2 * (t0 + u) + half;
+            const bool valid = p < pend;
             FFNO_UNROLL
             for (int a = 0; a < TPW; ++a) {
-                dhA[a] = cur[G::OFF_DH + px * H + 32 * (TPW * wave + a) + j];
-                hB[a] = cur[G::OFF_H + px * H + 32 * (TPW * wave + a) + j];
+                dhA[u][a] = valid ? dh[p * H + 32 * (TPW * wave + a) + j] : 0.f;
+                hB[u][a] = valid ? h[p * H + 32 * (TPW * wave + a) + j] : 0.f;
             }
             FFNO_UNROLL
             for (int b = 0; b < CT; ++b) {
-                sB[b] = cur[G::OFF_S + px * C + 32 * b + j];
-                dbA[b] = cur[G::OFF_DB + px * C + 32 * b + j];
+                sB[u][b] = valid ? s[p * C + 32 * b + j] : 0.f;
+                dbA[u][b] = valid ? db[p * C + 32 * b + j] : 0.f;
             }
+        }
+        FFNO_UNROLL
+        for (int u = 0; u < UNR; ++u) {
             FFNO_UNROLL
             for (int a = 0; a < TPW; ++a) {
-                bs1[a] += dhA[a];
+                bs1[a] += dhA[u][a];
                 FFNO_UNROLL
                 for (int b = 0; b < CT; ++b) {
-                    acc1[a][b] = mfma32(dhA[a], sB[b], acc1[a][b]);
-                    acc2[b][a] = mfma32(dbA[b], hB[a], acc2[b][a]);
+                    acc1[a][b] = mfma32(dhA[u][a], sB[u][b], acc1[a][b]);
+                    acc2[b][a] = mfma32(dbA[u][b], hB[u][a], acc2[b][a]);
                 }
             }
             FFNO_UNROLL
-            for (int b = 0; b < CT; ++b) bs2[b] += dbA[b];
+            for (int b = 0; b < CT; ++b) bs2[b] += dbA[u][b];
         }
     }
     // ---- combine the two k-groups (group 1 -> LDS -> group 0), one accumulator set at a time ----
-    float* comb = lds;   // the stage buffers are dead now
     const int slot = wave * 64 + lane;  // consecutive lanes -> consecutive floats (conflict-free)
     FFNO_UNROLL
     for (int pass = 0; pass < 2; ++pass) {
@@ -517,7 +466,7 @@ extern "C" int ffno_ff_bwd_weights_partial(const float* s, const float* db, cons
                                            float* partial, int P, int C, int H, int nsplit, void* stream) {
     if (!s || !db || !h || !dh || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     int chunk = (P + nsplit - 1) / nsplit;
-    chunk = (chunk + 15) / 16 * 16;   // whole 16-pixel pipeline stages per slice
+    chunk += chunk & 1;
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
         if (live) {
             const float* xl = in + lm.base(line) + CT * j;
             const int nsteps = (L + 1) >> 1;
-            constexpr int UN = 32;   // k-steps whose loads are all in flight together (a whole line at L <= 64)
+            constexpr int UN = 16;   // k-steps whose loads are all in flight together (whole line at L <= 32... 64: two trips)
             for (int t0 = 0; t0 < nsteps; t0 += UN) {
                 ColVec<CT> b[UN];
                 FFNO_UNROLL
@@ -566,28 +566,6 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                 FFNO_UNROLL
                 for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
             }
-            // epilogue operands (accumulate target / residual) are requested BEFORE the MFMAs so their HBM latency
-            // hides behind the K-step loop
-            ColVec<CT> pre[2][16];
-            FFNO_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                FFNO_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int n = 32 * (rt0 + q) + drow(r, half);
-                    FFNO_UNROLL
-                    for (int ct = 0; ct < CT; ++ct) pre[q][r].v[ct] = 0.f;
-                    if (n < L) {
-                        const long a = lbase + (long)n * lm.elem_stride;
-                        if (accumulate) pre[q][r].load(out + a);
-                        if (resid) {
-                            ColVec<CT> p;
-                            p.load(resid + a);
-                            FFNO_UNROLL
-                            for (int ct = 0; ct < CT; ++ct) pre[q][r].v[ct] += p.v[ct];
-                        }
-                    }
-                }
-            }
             for (int t = 0; t < K; ++t) {
                 const float ck = (inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
                 ColVec<CT> b;
@@ -613,7 +591,19 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                         const long a = lbase + (long)n * lm.elem_stride;
                         ColVec<CT> o;
                         FFNO_UNROLL
-                        for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[q][ct][r] + pre[q][r].v[ct];
+                        for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[q][ct][r];
+                        if (accumulate) {
+                            ColVec<CT> p;
+                            p.load(out + a);
+                            FFNO_UNROLL
+                            for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
+                        }
+                        if (resid) {
+                            ColVec<CT> p;
+                            p.load(resid + a);
+                            FFNO_UNROLL
+                            for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
+                        }
                         o.store(out + a);
                     }
                 }
