@@ -286,14 +286,17 @@ def main():
             cpu = cpu_baseline(B, G, args.cpu_steps, kw)
         steps_per_s = world * args.steps / elapsed
         out = {
-            "metric": "training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)",
+            "metric": ("training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)"
+                       if (G, args.layers, K) == (64, 24, 16) else
+                       "training-steps/sec (whole node), F-FNO %dL %dx%d modes %d" % (args.layers, G, G, K)),
             "value": round(steps_per_s, 3), "unit": "steps/s (per-GPU batch %d, summed over ranks)" % B,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic N(0,1) inputs/targets, reference-init weights",
-            "config": {"workload": "torus_li/markov/24_layers train step: FNOFactorized2DBlock(modes=%d,width=64,"
+            "config": {"workload": "%s train step: FNOFactorized2DBlock(modes=%d,width=64,"
                                    "n_layers=%d,input_dim=3,share_weight,factor=4,weight_norm) %dx%d, fp32"
-                                   % (K, args.layers, G, G),
+                                   % ("torus_li/markov/24_layers" if (G, args.layers, K) == (64, 24, 16) else "F-FNO",
+                                      K, args.layers, G, G),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "optimizer": "AdamW(lr 2.5e-3, wd 1e-4) + cosine warm-up, fused flat kernel",
                        "collective": "1 x all_reduce(flat fp32 grads, %d floats) / step" % trainer.pflat.numel()},

@@ -251,3 +251,33 @@ def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, paddi
         x = x + b
     b = b[:, :-padding, :-padding, :-padding, :]
     return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", b))
+
+
+# --------------------------------------------------------------------------
+# FNOZongyi2DBlock  (zongyi_fno/grid_2d.py:16-129) -- BASELINE config 0, CPU plumbing case.
+# The non-factorized baseline: full rfft2, two corner blocks of modes x modes weights, irfft2,
+# + Linear residual + ReLU.  (Reference quirk kept: irfft2 is called with s=(N, M), grid_2d.py:68.)
+# --------------------------------------------------------------------------
+def zongyi_spectral_conv(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_modes: int, conv_residual: bool = True) -> Tensor:
+    B, M, N, I = x.shape
+    lin = F.linear(x, sd[prefix + "linear.weight"], sd[prefix + "linear.bias"])
+    xf = torch.fft.rfft2(x.permute(0, 3, 1, 2), s=(M, N), norm="ortho")
+    out = xf.new_zeros(B, sd[prefix + "fourier_weight.0"].shape[1], M, N // 2 + 1)
+    w0 = torch.view_as_complex(sd[prefix + "fourier_weight.0"].contiguous())
+    w1 = torch.view_as_complex(sd[prefix + "fourier_weight.1"].contiguous())
+    out[:, :, :n_modes, :n_modes] = torch.einsum("bixy,ioxy->boxy", xf[:, :, :n_modes, :n_modes], w0)
+    out[:, :, -n_modes:, :n_modes] = torch.einsum("bixy,ioxy->boxy", xf[:, :, -n_modes:, :n_modes], w1)
+    y = torch.fft.irfft2(out, s=(N, M), norm="ortho").permute(0, 2, 3, 1)
+    if conv_residual:
+        return torch.relu(y + lin)
+    return torch.relu(F.linear(y, sd[prefix + "linear.weight"], sd[prefix + "linear.bias"]))
+
+
+def fno_zongyi_2d(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int, residual: bool = False,
+                  conv_residual: bool = True) -> Dict[str, Tensor]:
+    x = F.linear(x, sd["in_proj.weight"], sd["in_proj.bias"])
+    for i in range(n_layers):
+        y = zongyi_spectral_conv(sd, f"spectral_layers.{i}.", x, modes, conv_residual)
+        x = y + x if residual else y
+    x = torch.relu(F.linear(x, sd["feedforward.0.weight"], sd["feedforward.0.bias"]))
+    return {"forecast": F.linear(x, sd["feedforward.2.weight"], sd["feedforward.2.bias"])}

@@ -204,3 +204,27 @@ def load_golden(name: str):
 
 def golden_kwargs(npz) -> dict:
     return ast.literal_eval(str(npz["kwargs"]))
+
+
+def make_zongyi_state_dict(kw: dict, seed: int = 51):
+    """Deterministic FNOZongyi2DBlock weights (zongyi_fno/grid_2d.py:81-117 layout) + the config-0 input batch
+    [2, 64, 64, input_dim].  Fourier weights use std 0.02 (the reference's init, gain 1/(I*O), is ~1e-5 and
+    would leave the spectral path numerically invisible)."""
+    rs = np.random.RandomState(seed)
+    W, I, K = kw["width"], kw["input_dim"], kw["modes1"]
+    sd = {}
+
+    def lin(prefix, fin, fout):
+        sd[prefix + "weight"] = (rs.standard_normal((fout, fin)) / math.sqrt(fin)).astype(np.float32)
+        sd[prefix + "bias"] = (rs.standard_normal(fout) * 0.1).astype(np.float32)
+
+    lin("in_proj.", I, W)
+    for l in range(kw["n_layers"]):
+        pre = f"spectral_layers.{l}."
+        lin(pre + "linear.", W, W)
+        for j in range(2):
+            sd[pre + f"fourier_weight.{j}"] = (rs.standard_normal((W, W, K, K, 2)) * 0.02).astype(np.float32)
+    lin("feedforward.0.", W, 128)
+    lin("feedforward.2.", 128, 1)
+    x = rs.standard_normal((2, 64, 64, I)).astype(np.float32)
+    return sd, x

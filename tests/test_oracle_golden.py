@@ -68,3 +68,19 @@ def test_misc_lploss_wnlinear_cosine():
     c = gu.load_golden("cosine")
     for s, f in zip(c["steps"], c["factor"]):
         assert abs(orc.cosine_warmup_factor(int(s), 500, 100000, 0.5) - float(f)) < 1e-12
+
+
+def test_zongyi_baseline_config0_matches_reference():
+    """BASELINE config 0 (torus_li/zongyi/4_layers, CPU plumbing case: 64x64, batch 2, modes 12, width 20)."""
+    g = gu.load_golden("zongyi_4l")
+    kw = gu.golden_kwargs(g)
+    sd_np, x = gu.make_zongyi_state_dict(kw, int(g["seed"]))
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
+    out = orc.fno_zongyi_2d(sd, torch.tensor(x), modes=kw["modes1"], n_layers=kw["n_layers"])["forecast"]
+    loss = (out ** 2).mean()
+    loss.backward()
+    assert tuple(out.shape) == (2, 64, 64, 1)
+    assert gu.compare_packed(g, "forecast", out.detach().numpy(), TOL) < TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, float(g["loss"]))
+    for n in [k for k in gu.packed_names(g) if k.startswith("grad.")]:
+        assert gu.compare_packed(g, n, sd[n[5:]].grad.numpy(), TOL) < 5e-5, n

@@ -32,6 +32,10 @@ for st in $STAGES; do
     bench256)
       timeout 900 python bench.py --steps 10 --warmup 3 --grid 256 --layers 12 --modes 32 --batch 2 --cpu-steps 1 > gpurun_out/bench_256.log 2>&1
       echo "[session] bench256 rc=$?"; tail -n 1 gpurun_out/bench_256.log | cut -c1-1200 ;;
+    sq)
+      rm -rf gpurun_out/pmc_SQ
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_SQ" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 > "$OLDPWD/gpurun_out/pmc_SQ.log" 2>&1)
+      echo "[session] pmc SQ rc=$?"; tail -n 2 gpurun_out/pmc_SQ.log | cut -c1-200 ;;
     pmc)
       # HBM traffic counters, one PMC pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel-trace only
       for c in FETCH_SIZE WRITE_SIZE; do
