@@ -308,16 +308,108 @@ __global__ void head_param_grads_kernel(const float* __restrict__ red, const flo
     }
 }
 
+// ---- markov feature build + running normaliser ---------------------------------------------------------
+// Replaces Grid2DMarkovExperiment._build_features (routines/grid_2d_markov.py:124-170, use_position=True,
+// no velocity/force/mu) + Normalizer (modules/normalizer.py:18-77):
+//   raw[p] = [ x[p][0..Cx) , low + (high-low)*m/(M-1) , low + (high-low)*n/(N-1) ]      (linspace, ij meshgrid)
+//   accumulate: sum[c] += sum_p raw, sum_squared[c] += sum_p raw^2, count += P          (deterministic 2-stage)
+//   finalize  : mean = sum/max(count,1) ; std = max(sqrt(sum_squared/max(count,1) - mean^2), eps)
+//   apply     : feat[p][c] = (raw[p][c] - mean[c]) / std[c] + noise[p][c] * noise_std
+__device__ __forceinline__ float markov_raw(const float* __restrict__ x, long p, int c, int Cx, int M, int N,
+                                            float low, float high) {
+    if (c < Cx) return x[p * Cx + c];
+    const int n = (int)(p % N), m = (int)((p / N) % M);
+    const int idx = (c == Cx) ? m : n, size = (c == Cx) ? M : N;
+    return size > 1 ? low + (high - low) * (float)idx / (float)(size - 1) : low;
+}
+
+__global__ __launch_bounds__(256) void markov_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                                   long P, int Cx, int D, int M, int N, float low,
+                                                                   float high, int chunk) {
+    __shared__ float red[2][4][16];
+    const long pbeg = (long)blockIdx.x * chunk, pend = min(P, pbeg + chunk);
+    float s[16], q[16];
+    FFNO_UNROLL
+    for (int c = 0; c < 16; ++c) s[c] = q[c] = 0.f;
+    for (long p = pbeg + threadIdx.x; p < pend; p += 256) {
+        FFNO_UNROLL
+        for (int c = 0; c < 16; ++c) {
+            if (c < D) {
+                const float v = markov_raw(x, p, c, Cx, M, N, low, high);
+                s[c] += v;
+                q[c] = fmaf(v, v, q[c]);
+            }
+        }
+    }
+    FFNO_UNROLL
+    for (int c = 0; c < 16; ++c) {
+        s[c] = wave_sum(s[c]);
+        q[c] = wave_sum(q[c]);
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6][c] = s[c];
+            red[1][threadIdx.x >> 6][c] = q[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int which = threadIdx.x >> 4, c = threadIdx.x & 15;
+        partial[((long)blockIdx.x * 2 + which) * 16 + c] = red[which][0][c] + red[which][1][c] + red[which][2][c] + red[which][3][c];
+    }
+}
+
+// state[0..D) sum, [D..2D) sum_squared, [2D] count, [2D+1] n_accumulations ; derived[0..D) mean, [D..2D) std
+__global__ void markov_stats_finalize_kernel(const float* __restrict__ partial, float* state, float* derived, int D,
+                                             int nsplit, float count_add, float eps, int accumulate) {
+    const int c = threadIdx.x;
+    if (c < D) {
+        if (accumulate) {
+            float s = 0.f, q = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                s += partial[((long)sp * 2 + 0) * 16 + c];
+                q += partial[((long)sp * 2 + 1) * 16 + c];
+            }
+            state[c] += s;
+            state[D + c] += q;
+        }
+        const float cnt = fmaxf(state[2 * D] + (accumulate ? count_add : 0.f), 1.f);
+        const float mean = state[c] / cnt;
+        derived[c] = mean;
+        derived[D + c] = fmaxf(sqrtf(state[D + c] / cnt - mean * mean), eps);
+    }
+    __syncthreads();
+    if (c == 0 && accumulate) {
+        state[2 * D] += count_add;
+        state[2 * D + 1] += 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void markov_features_kernel(const float* __restrict__ x, const float* __restrict__ derived,
+                                                              const float* __restrict__ noise, float* __restrict__ out,
+                                                              long P, int Cx, int D, int M, int N, float low, float high,
+                                                              float noise_std, int normalize) {
+    const long total = P * D;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long p = e / D;
+        const int c = (int)(e % D);
+        float v = markov_raw(x, p, c, Cx, M, N, low, high);
+        if (normalize) v = (v - derived[c]) / derived[D + c];
+        if (noise) v = fmaf(noise[e], noise_std, v);
+        out[e] = v;
+    }
+}
+
 // ---- relative L2 loss -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lploss_reduce_kernel(const float* __restrict__ pred,
-                                                            const float* __restrict__ target, float* tmp, int n) {
+                                                            const float* __restrict__ target, float* tmp, int n,
+                                                            const float* __restrict__ affine) {
     __shared__ float sd[4], sy[4];
     const int bidx = blockIdx.x;
     const float* p = pred + (long)bidx * n;
     const float* t = target + (long)bidx * n;
+    const float sc = affine ? affine[0] : 1.f, sh = affine ? affine[1] : 0.f;   // pred * std + mean (Normalizer.inverse)
     float d2 = 0.f, y2 = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = p[i] - t[i];
+        const float d = fmaf(p[i], sc, sh) - t[i];
         d2 = fmaf(d, d, d2);
         y2 = fmaf(t[i], t[i], y2);
     }
@@ -337,7 +429,8 @@ __global__ __launch_bounds__(256) void lploss_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void lploss_grad_kernel(const float* __restrict__ pred,
                                                           const float* __restrict__ target,
                                                           const float* __restrict__ tmp, float* loss_out,
-                                                          float* gpred, int B, int n, float gscale) {
+                                                          float* gpred, int B, int n, float gscale,
+                                                          const float* __restrict__ affine) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && loss_out) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += sqrtf(tmp[2 * b]) / sqrtf(tmp[2 * b + 1]);
@@ -346,10 +439,11 @@ __global__ __launch_bounds__(256) void lploss_grad_kernel(const float* __restric
     if (!gpred) return;
     const int bidx = blockIdx.y;
     const float dn = sqrtf(tmp[2 * bidx]), yn = sqrtf(tmp[2 * bidx + 1]);
-    const float coef = dn > 0.f ? gscale / ((float)B * dn * yn) : 0.f;
+    const float sc = affine ? affine[0] : 1.f, sh = affine ? affine[1] : 0.f;
+    const float coef = dn > 0.f ? gscale * sc / ((float)B * dn * yn) : 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const long e = (long)bidx * n + i;
-        gpred[e] = coef * (pred[e] - target[e]);
+        gpred[e] = coef * (fmaf(pred[e], sc, sh) - target[e]);
     }
 }
 
@@ -515,15 +609,43 @@ extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const fl
 }
 
 extern "C" int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out, float* gpred,
-                                   float* tmp, int B, int n_per_sample, float gscale, void* stream) {
+                                   float* tmp, int B, int n_per_sample, float gscale, const float* affine,
+                                   void* stream) {
     if (!pred || !target || !tmp || B <= 0 || n_per_sample <= 0) return FFNO_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    FFNO_LAUNCH(lploss_reduce_kernel, dim3(B), dim3(256), 0, s, pred, target, tmp, n_per_sample);
+    FFNO_LAUNCH(lploss_reduce_kernel, dim3(B), dim3(256), 0, s, pred, target, tmp, n_per_sample, affine);
     int rc = pw_status();
     if (rc) return rc;
     const int gx = max(1, min((n_per_sample + 255) / 256, 64));
     FFNO_LAUNCH(lploss_grad_kernel, dim3(gx, B), dim3(256), 0, s, pred, target, tmp, loss_out, gpred, B,
-                       n_per_sample, gscale);
+                       n_per_sample, gscale, affine);
+    return pw_status();
+}
+
+extern "C" int ffno_markov_features(const float* x, float* state, float* derived, const float* noise, float* out,
+                                    float* partial, int B, int M, int N, int Cx, float low, float high,
+                                    float noise_std, float eps, int accumulate, int normalize, void* stream) {
+    if (!x || !out || !state || !derived || !partial || B <= 0 || M <= 0 || N <= 0 || Cx <= 0) return FFNO_EINVAL;
+    const int D = Cx + 2;
+    if (D > 16) return FFNO_EUNSUPPORTED;
+    const long P = (long)B * M * N;
+    hipStream_t s = (hipStream_t)stream;
+    const int nsplit = (int)max(1L, min(256L, (P + 1023) / 1024));
+    const int chunk = (int)((P + nsplit - 1) / nsplit);
+    if (normalize) {
+        if (accumulate) {
+            FFNO_LAUNCH(markov_stats_partial_kernel, dim3(nsplit), dim3(256), 0, s, x, partial, P, Cx, D, M, N, low, high, chunk);
+            int rc = pw_status();
+            if (rc) return rc;
+        }
+        FFNO_LAUNCH(markov_stats_finalize_kernel, dim3(1), dim3(64), 0, s, partial, state, derived, D, nsplit, (float)P, eps,
+                    accumulate);
+        int rc = pw_status();
+        if (rc) return rc;
+    }
+    const unsigned blocks = (unsigned)min((P * D + 255) / 256, 2048L);
+    FFNO_LAUNCH(markov_features_kernel, dim3(blocks), dim3(256), 0, s, x, derived, noise, out, P, Cx, D, M, N, low, high,
+                noise_std, normalize);
     return pw_status();
 }
 

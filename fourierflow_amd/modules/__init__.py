@@ -2,3 +2,4 @@
 from .factorized_fno import FNOFactorized2DBlock, FNOFactorizedMesh3D  # noqa: F401
 from .feedforward import FeedForward  # noqa: F401
 from .linear import WNLinear  # noqa: F401
+from .normalizer import Normalizer  # noqa: F401

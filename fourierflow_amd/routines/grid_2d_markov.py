@@ -1,0 +1,141 @@
+"""Markov one-step training routine around the F-FNO block -- counterpart of
+``fourierflow.routines.Grid2DMarkovExperiment`` (reference routines/grid_2d_markov.py:23-193, 374-390)
+without Lightning / wandb / jax: feature build (positional channels, running normaliser, Gaussian noise),
+the operator, inverse-normalise + relative-L2 loss, the manual optimisation step
+(routines/base.py:27-52), epoch-0 statistics accumulation, and the autoregressive rollout of
+``_valid_step`` (:195-326) used by predict/infer.
+
+Everything on the device is a HIP kernel of libffno_hip.so; torch supplies memory, the stream and the
+Gaussian noise samples.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _capi, _lib
+from ..engine import _p
+from ..modules.normalizer import Normalizer
+from ..trainer import FFNOTrainer
+
+
+class Grid2DMarkovExperiment(nn.Module):
+    def __init__(self, conv: nn.Module, n_steps: Optional[int] = None, low: float = 0, high: float = 1,
+                 use_position: bool = True, append_force: bool = False, append_mu: bool = False,
+                 max_accumulations: float = 1e6, should_normalize: bool = True, use_fourier_position: bool = False,
+                 noise_std: float = 0.0, shuffle_grid: bool = False, use_velocity: bool = False,
+                 learn_difference: bool = False, optimizer: Optional[dict] = None, scheduler: Optional[dict] = None,
+                 **unused):
+        super().__init__()
+        for flag, name in ((append_force, "append_force"), (append_mu, "append_mu"), (shuffle_grid, "shuffle_grid"),
+                           (use_fourier_position, "use_fourier_position"), (use_velocity, "use_velocity")):
+            if flag:
+                raise NotImplementedError(f"{name}=True is outside the torus_li/markov path built here (SURVEY 8 f3)")
+        if not use_position:
+            raise NotImplementedError("use_position=False: the fused feature kernel always appends the two grid channels")
+        self.conv = conv
+        self.n_steps, self.low, self.high = n_steps, low, high
+        self.should_normalize, self.noise_std, self.learn_difference = should_normalize, noise_std, learn_difference
+        self.normalizer = Normalizer([conv.input_dim], max_accumulations)
+        self.register_buffer('_float', torch.FloatTensor([0.1]))
+        self._opt_kw = dict(lr=2.5e-3, weight_decay=1e-4)
+        self._opt_kw.update(optimizer or {})
+        self._sch_kw = dict(num_warmup_steps=500, num_training_steps=100000, num_cycles=0.5)
+        self._sch_kw.update(scheduler or {})
+        self._trainer: Optional[FFNOTrainer] = None
+        self._derived = None
+        self._partial = None
+        self._affine = None
+
+    # ----------------------------------------------------------------------------------------------
+    def trainer(self) -> FFNOTrainer:
+        if self._trainer is None:
+            self._trainer = FFNOTrainer(self.conv, **self._opt_kw, **self._sch_kw)
+        return self._trainer
+
+    def _build_features(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None,
+                        add_noise: bool = True) -> torch.Tensor:
+        """x [B, M, N, Cx] -> normalised features [B, M, N, Cx + 2] (+ noise), accumulating the running
+        statistics while training (grid_2d_markov.py:124-170, normalizer.py:45-55)."""
+        x = batch['x'].contiguous()
+        _lib.require_device_tensor(x, "batch['x']")
+        B, M, N, Cx = x.shape
+        D = Cx + 2
+        if D != self.conv.input_dim:
+            raise ValueError(f"conv.input_dim={self.conv.input_dim} but the features have {D} channels")
+        dev = x.device
+        if self._derived is None or self._derived.device != dev:
+            self._derived = torch.zeros(2 * D, dtype=torch.float32, device=dev)
+            self._partial = torch.empty(256 * 32, dtype=torch.float32, device=dev)
+        nz = self.normalizer
+        acc = self.should_normalize and nz.should_accumulate()
+        state = nz.pack_state()
+        if not add_noise:
+            noise = None
+        elif noise is None and self.noise_std:
+            noise = torch.randn(B, M, N, D, device=dev)      # `x += randn * noise_std` (grid_2d_markov.py:168)
+        out = torch.empty(B, M, N, D, dtype=torch.float32, device=dev)
+        rc = _lib.get_lib().ffno_markov_features(_p(x), _p(state), _p(self._derived), _p(noise), _p(out), _p(self._partial),
+                                                 B, M, N, Cx, float(self.low), float(self.high), float(self.noise_std),
+                                                 self._eps(), int(acc),
+                                                 int(self.should_normalize), _lib.current_stream(dev))
+        _capi.check(rc, "markov_features")
+        if acc:
+            nz.unpack_state(state)
+            nz._n_acc_host += 1.0
+        return out
+
+    def _eps(self) -> float:
+        if not hasattr(self, "_eps_host"):
+            self._eps_host = float(self.normalizer.std_epsilon.flatten()[0].item())   # one sync, at first use
+        return self._eps_host
+
+    def _affine_tensor(self):
+        """{std[0], mean[0]} for Normalizer.inverse(channel=0) fused into the loss kernel."""
+        if not self.should_normalize:
+            return None
+        D = self.conv.input_dim
+        self._affine = torch.stack([self._derived[D], self._derived[0]]).contiguous()
+        return self._affine
+
+    def _training_step(self, batch, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """features -> conv -> inverse-normalise -> LpLoss.rel, then the manual optimisation step."""
+        tr = self.trainer()
+        feats = self._build_features(batch, noise)
+        targets = (batch['dy'] if self.learn_difference else batch['y']).contiguous()
+        pred = tr.engine.forward(feats, True)
+        loss, gy = tr.loss_and_grad(pred, targets, self._affine_tensor())
+        tr.apply_gradients(tr.engine.backward(gy))
+        return loss
+
+    def training_step(self, batch, epoch: int, noise: Optional[torch.Tensor] = None):
+        """Epoch 0 only accumulates the normaliser statistics (grid_2d_markov.py:376-378); later epochs train."""
+        if self.should_normalize and epoch < 1:
+            with torch.no_grad():
+                self._build_features(batch, noise)
+            return None
+        return self._training_step(batch, noise)
+
+    @torch.no_grad()
+    def rollout(self, x0: torch.Tensor, n_steps: Optional[int] = None) -> torch.Tensor:
+        """Autoregressive inference (grid_2d_markov.py:263-321): feed each de-normalised prediction back as the
+        next input.  x0 [B, M, N, 1] -> [B, M, N, n_steps]."""
+        was_training = self.normalizer.training
+        self.normalizer.eval()
+        tr = self.trainer()
+        preds, x, prev = [], x0, x0
+        for _ in range(n_steps or self.n_steps or 1):
+            feats = self._build_features({'x': x}, add_noise=False)   # no noise at validation (:292-293)
+            im = tr.engine.forward(feats, False)
+            if self.should_normalize:
+                D = self.conv.input_dim
+                im = im * self._derived[D] + self._derived[0]
+            if self.learn_difference:
+                im = prev + im
+                prev = im
+            preds.append(im)
+            x = im
+        self.normalizer.train(was_training)
+        return torch.cat(preds, dim=-1)

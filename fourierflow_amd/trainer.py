@@ -74,7 +74,7 @@ class FFNOTrainer:
         """lr used by the NEXT optimiser step (LambdaLR semantics: factor(number of completed steps))."""
         return self.lr * cosine_warmup_factor(self.step_count, *self.sched)
 
-    def loss_and_grad(self, pred: torch.Tensor, target: torch.Tensor):
+    def loss_and_grad(self, pred: torch.Tensor, target: torch.Tensor, affine: Optional[torch.Tensor] = None):
         lib = _lib.get_lib()
         B = pred.shape[0]
         n = pred.numel() // B
@@ -82,7 +82,7 @@ class FFNOTrainer:
             self._gy = torch.empty_like(pred)
             self._tmp = torch.empty(2 * B, dtype=torch.float32, device=pred.device)
         _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(self.loss), _p(self._gy), _p(self._tmp), B, n, 1.0,
-                                            _lib.current_stream(self.device)), "lploss")
+                                            _p(affine), _lib.current_stream(self.device)), "lploss")
         return self.loss, self._gy
 
     def train_step(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
@@ -91,7 +91,11 @@ class FFNOTrainer:
         target = target.contiguous()
         pred = self.engine.forward(x, True)
         loss, gy = self.loss_and_grad(pred, target)
-        gflat = self.engine.backward(gy)
+        return self.apply_gradients(self.engine.backward(gy), loss)
+
+    def apply_gradients(self, gflat: torch.Tensor, loss: Optional[torch.Tensor] = None):
+        """(all-reduce) + fused AdamW/cosine step on the flat buffers."""
+        lib = _lib.get_lib()
         if self.world > 1:
             torch.distributed.all_reduce(gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         lr_t = self.current_lr()

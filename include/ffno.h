@@ -232,8 +232,24 @@ int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, co
  *   loss = mean_b ||pred_b - y_b||_2 / ||y_b||_2 ;  gpred = dloss/dpred * gscale
  * per-sample work buffer `tmp` needs 2*B floats.  loss is written to loss_out[0].
  * --------------------------------------------------------------------------------------------- */
+/* affine (optional, device float[2] = {scale, shift}): the loss is taken on pred*scale + shift, i.e. the
+ * Normalizer.inverse(channel=0) of grid_2d_markov.py:185 fused in (scale = std[0], shift = mean[0]). */
 int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out, float* gpred,
-                        float* tmp, int B, int n_per_sample, float gscale, void* stream);
+                        float* tmp, int B, int n_per_sample, float gscale, const float* affine,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Feature build of the Markov routine + running normaliser, fused
+ * (routines/grid_2d_markov.py:124-170 with use_position=True; modules/normalizer.py:18-77):
+ *   raw[p]  = [ x[p][0..Cx), linspace(low,high,M)[m], linspace(low,high,N)[n] ]          D = Cx + 2 <= 16
+ *   accumulate != 0: state.sum += sum_p raw, state.sum_squared += sum_p raw^2, count += B*M*N, n_accumulations += 1
+ *   derived = { mean[D], std[D] = max(sqrt(sum_squared/count - mean^2), eps) }
+ *   out[p][c] = (normalize ? (raw - mean)/std : raw) + (noise ? noise[p][c]*noise_std : 0)
+ * state = float[2D+2] {sum[D], sum_squared[D], count, n_accumulations}; partial = float[256*32] scratch.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_markov_features(const float* x, float* state, float* derived, const float* noise, float* out,
+                         float* partial, int B, int M, int N, int Cx, float low, float high,
+                         float noise_std, float eps, int accumulate, int normalize, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused AdamW over one flat parameter buffer (torch.optim.AdamW semantics, config.yaml:36-40):

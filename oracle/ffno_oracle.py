@@ -281,3 +281,52 @@ def fno_zongyi_2d(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int
         x = y + x if residual else y
     x = torch.relu(F.linear(x, sd["feedforward.0.weight"], sd["feedforward.0.bias"]))
     return {"forecast": F.linear(x, sd["feedforward.2.weight"], sd["feedforward.2.bias"])}
+
+
+# --------------------------------------------------------------------------
+# Markov routine glue: Normalizer (modules/normalizer.py:18-77) and _build_features / _training_step
+# (routines/grid_2d_markov.py:124-193, use_position=True, no velocity/force/mu).
+# --------------------------------------------------------------------------
+class NormalizerState:
+    """Running sums exactly as the reference's buffers (count, sum, sum_squared, n_accumulations)."""
+
+    def __init__(self, size: int, max_accumulations: float = 1e6, std_epsilon: float = 1e-8, dtype=torch.float32):
+        self.sum = torch.zeros(size, dtype=dtype)
+        self.sum_squared = torch.zeros(size, dtype=dtype)
+        self.count = torch.zeros((), dtype=dtype)
+        self.n_accumulations = torch.zeros((), dtype=dtype)
+        self.max_accumulations, self.eps = max_accumulations, torch.full((size,), std_epsilon, dtype=dtype)
+
+    @property
+    def mean(self):
+        return self.sum / torch.clamp(self.count, min=1.0)
+
+    @property
+    def std(self):
+        return torch.maximum(torch.sqrt(self.sum_squared / torch.clamp(self.count, min=1.0) - self.mean ** 2), self.eps)
+
+    def forward(self, x: Tensor, training: bool = True) -> Tensor:
+        flat = x.reshape(-1, x.shape[-1])
+        if training and self.n_accumulations < self.max_accumulations:
+            self.sum = self.sum + flat.sum(dim=0)
+            self.sum_squared = self.sum_squared + (flat ** 2).sum(dim=0)
+            self.count = self.count + flat.shape[0]
+            self.n_accumulations = self.n_accumulations + 1
+        return ((flat - self.mean) / self.std).reshape(x.shape)
+
+    def inverse(self, x: Tensor, channel: int) -> Tensor:
+        return x * self.std[channel] + self.mean[channel]
+
+
+def markov_features(x: Tensor, norm: Optional[NormalizerState], noise: Optional[Tensor], noise_std: float,
+                    low: float = 0.0, high: float = 1.0, training: bool = True) -> Tensor:
+    B, M, N, _ = x.shape
+    gm = torch.linspace(low, high, M, dtype=x.dtype)
+    gn = torch.linspace(low, high, N, dtype=x.dtype)
+    pos = torch.stack(torch.meshgrid(gm, gn, indexing="ij"), dim=-1).expand(B, M, N, 2)
+    feats = torch.cat([x, pos], dim=-1)
+    if norm is not None:
+        feats = norm.forward(feats, training)
+    if noise is not None:
+        feats = feats + noise * noise_std
+    return feats

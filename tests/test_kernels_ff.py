@@ -242,7 +242,7 @@ def test_lploss_and_adamw_and_axpy(be):
     pred = rs.standard_normal((B, n)).astype(np.float32)
     tgt = rs.standard_normal((B, n)).astype(np.float32)
     dpred, dtgt, loss, gp, tmp = be.put(pred), be.put(tgt), be.zeros(1), be.zeros((B, n)), be.zeros(2 * B)
-    assert lib.ffno_lploss_fwd_bwd(p(dpred), p(dtgt), p(loss), p(gp), p(tmp), B, n, 1.0, None) == 0
+    assert lib.ffno_lploss_fwd_bwd(p(dpred), p(dtgt), p(loss), p(gp), p(tmp), B, n, 1.0, None, None) == 0
     pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
     tt = torch.tensor(tgt, dtype=torch.float64)
     l = ((pt - tt).norm(dim=1) / tt.norm(dim=1)).mean()   # LpLoss.rel, loss.py:33-46

@@ -1,0 +1,125 @@
+"""the training-step glue around the operator -- feature build with positional channels,
+running normaliser, noise, inverse-normalise fused into the loss, epoch-0 accumulation, rollout."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from backend_util import be, host_device, rel_l2  # noqa: F401
+from oracle import ffno_oracle as orc
+
+
+def test_oracle_normalizer_matches_reference_golden():
+    g = gu.load_golden("normalizer")
+    nz = orc.NormalizerState(3, max_accumulations=2)
+    for i in range(3):
+        out = nz.forward(torch.tensor(g["xs"][i]), training=True)
+        np.testing.assert_allclose(out.numpy(), g["outs"][i], rtol=2e-5, atol=2e-6)
+    assert float(nz.count) == float(g["sd.count"]) and float(nz.n_accumulations) == float(g["sd.n_accumulations"])
+    np.testing.assert_allclose(nz.sum.numpy(), g["sd.sum"], rtol=1e-5)
+    np.testing.assert_allclose(nz.sum_squared.numpy(), g["sd.sum_squared"], rtol=1e-5)
+    inv = nz.inverse(torch.tensor(g["outs"][2][..., 0:1]), 0)
+    np.testing.assert_allclose(inv.numpy(), g["inv"], rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,M,N,Cx", [(2, 6, 5, 1), (3, 16, 16, 3)])
+def test_markov_features_kernel(be, B, M, N, Cx):
+    """ffno_markov_features vs the oracle: accumulate twice, then frozen statistics; noise; no-normalise path."""
+    lib, p = be.lib, be.ptr
+    D = Cx + 2
+    rs = np.random.RandomState(B + M + Cx)
+    nz = orc.NormalizerState(D, max_accumulations=2)
+    state, derived, partial = be.zeros(2 * D + 2), be.zeros(2 * D), be.zeros(256 * 32)
+    for it in range(3):
+        x = (rs.standard_normal((B, M, N, Cx)) * 2 + 0.7).astype(np.float32)
+        noise = rs.standard_normal((B, M, N, D)).astype(np.float32)
+        acc = int(it < 2)
+        dx, dn, out = be.put(x), be.put(noise), be.empty((B, M, N, D))
+        assert lib.ffno_markov_features(p(dx), p(state), p(derived), p(dn), p(out), p(partial), B, M, N, Cx, 0.0, 1.0,
+                                        0.01, 1e-8, acc, 1, None) == 0
+        ref = orc.markov_features(torch.tensor(x), nz, torch.tensor(noise), 0.01, training=True)
+        assert rel_l2(be.get(out), ref.numpy()) < 1e-5
+    st = be.get(state)
+    np.testing.assert_allclose(st[:D], nz.sum.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(st[D:2 * D], nz.sum_squared.numpy(), rtol=1e-5)
+    assert st[2 * D] == float(nz.count) and st[2 * D + 1] == 2.0
+    out = be.empty((B, M, N, D))
+    assert lib.ffno_markov_features(p(dx), p(state), p(derived), None, p(out), p(partial), B, M, N, Cx, -1.0, 1.0,
+                                    0.0, 1e-8, 0, 0, None) == 0
+    ref = orc.markov_features(torch.tensor(x), None, None, 0.0, low=-1.0, high=1.0)
+    assert rel_l2(be.get(out), ref.numpy()) < 1e-6
+
+
+def test_lploss_with_inverse_normalisation(be):
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(2)
+    B, n = 3, 300
+    pred, tgt = rs.standard_normal((B, n)).astype(np.float32), rs.standard_normal((B, n)).astype(np.float32)
+    aff = np.array([1.7, -0.4], np.float32)
+    dp, dt, da = be.put(pred), be.put(tgt), be.put(aff)
+    loss, gp, tmp = be.zeros(1), be.zeros((B, n)), be.zeros(2 * B)
+    assert lib.ffno_lploss_fwd_bwd(p(dp), p(dt), p(loss), p(gp), p(tmp), B, n, 1.0, p(da), None) == 0
+    pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
+    l = orc.lp_rel_loss(pt * 1.7 - 0.4, torch.tensor(tgt, dtype=torch.float64))
+    l.backward()
+    assert abs(be.get(loss)[0] - l.item()) < 1e-6
+    assert rel_l2(be.get(gp), pt.grad.numpy()) < 1e-5
+
+
+def test_markov_routine_matches_oracle_composition(host_device):
+    """Epoch 0 accumulates only; then train steps = oracle(features -> block -> inverse -> rel-L2) + AdamW."""
+    import oracle_util as ou
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    seed, B, M, N = 71, 2, 16, 16
+    sd_np = gu.make_block_state_dict(kw, seed)
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    blk = blk.to(host_device)
+    exp = Grid2DMarkovExperiment(blk, n_steps=3, max_accumulations=2, noise_std=0.01,
+                                 scheduler=dict(num_warmup_steps=1, num_training_steps=10)).to(host_device)
+    rs = np.random.RandomState(seed)
+    nz = orc.NormalizerState(3, max_accumulations=2)
+    batches = [dict(x=(rs.standard_normal((B, M, N, 1)) * 3 + 1).astype(np.float32),
+                    y=(rs.standard_normal((B, M, N, 1)) * 3 + 1).astype(np.float32),
+                    noise=rs.standard_normal((B, M, N, 3)).astype(np.float32)) for _ in range(4)]
+    dev = lambda a: torch.from_numpy(a).to(host_device)  # noqa: E731
+    # epoch 0: statistics only, no optimisation
+    for b in batches[:2]:
+        assert exp.training_step(dict(x=dev(b["x"]), y=dev(b["y"])), epoch=0, noise=dev(b["noise"])) is None
+        orc.markov_features(torch.tensor(b["x"]), nz, torch.tensor(b["noise"]), 0.01)
+    assert exp.trainer().step_count == 0
+    np.testing.assert_allclose(exp.normalizer.sum.cpu().numpy(), nz.sum.numpy(), rtol=1e-5)
+    assert float(exp.normalizer.n_accumulations.item()) == 2.0
+    # epoch 1: one train step, compared with autograd through the oracle + torch AdamW
+    sd, uniq = ou.torch_state_dict(sd_np)
+    opt = torch.optim.AdamW(list(uniq.values()), lr=2.5e-3, weight_decay=1e-4)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: orc.cosine_warmup_factor(s, 1, 10, 0.5))
+    for b in batches[2:]:
+        loss = exp.training_step(dict(x=dev(b["x"]), y=dev(b["y"])), epoch=1, noise=dev(b["noise"]))
+        feats = orc.markov_features(torch.tensor(b["x"]), nz, torch.tensor(b["noise"]), 0.01)   # frozen stats now
+        opt.zero_grad()
+        im = orc.ffno2d_block(sd, feats, modes=4, n_layers=2)["forecast"]
+        ref_loss = orc.lp_rel_loss(nz.inverse(im, 0), torch.tensor(b["y"]))
+        ref_loss.backward()
+        opt.step()
+        sch.step()
+        assert abs(loss.item() - ref_loss.item()) < 2e-5
+    named = dict(blk.named_parameters())
+    errs = [rel_l2(named[n].detach().cpu().numpy(), p_.detach().numpy()) for n, p_ in uniq.items()]
+    assert max(errs) < 5e-4, max(errs)
+    # autoregressive rollout (validation path: no noise, frozen statistics)
+    x0 = dev(batches[0]["x"])
+    roll = exp.rollout(x0, 3)
+    assert tuple(roll.shape) == (B, M, N, 3)
+    with torch.no_grad():
+        xr, ref = torch.tensor(batches[0]["x"]), []
+        sdd = {k: v.detach() for k, v in sd.items()}
+        for _ in range(3):
+            f = orc.markov_features(xr, nz, None, 0.0, training=False)
+            xr = nz.inverse(orc.ffno2d_block(sdd, f, modes=4, n_layers=2)["forecast"], 0)
+            ref.append(xr)
+    assert rel_l2(roll.cpu().numpy(), torch.cat(ref, -1).numpy()) < 1e-4
