@@ -1,0 +1,133 @@
+"""Config surface of the reference's experiments without Hydra / OmegaConf / Lightning.
+
+The reference composes ``experiments/**/config.yaml`` with Hydra, resolves the custom OmegaConf resolvers
+``get_method`` / ``import`` / ``eval`` / ``oc.env`` (fourierflow/__init__.py:19-24) and instantiates
+``_target_`` nodes (commands/train.py:38-67).  This module does the same for the part of a config that
+drives the hot path -- ``routine`` with its ``conv`` / ``model``, ``optimizer`` and ``scheduler`` nodes -- and
+maps ``fourierflow.*`` targets onto their MI355X-native mirrors, so an unmodified torus_li config builds
+the HIP-backed routine.  ``builder`` / ``trainer`` / ``callbacks`` / ``wandb`` sections are parsed but not
+instantiated (data loading and the Lightning control plane are out of scope).
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import re
+from typing import Any, Dict, Sequence
+
+import yaml
+
+TARGET_MAP = {
+    "fourierflow.modules.FNOFactorized2DBlock": "fourierflow_amd.modules.FNOFactorized2DBlock",
+    "fourierflow.modules.FNOFactorizedMesh3D": "fourierflow_amd.modules.FNOFactorizedMesh3D",
+    "fourierflow.modules.WNLinear": "fourierflow_amd.modules.WNLinear",
+    "fourierflow.modules.Normalizer": "fourierflow_amd.modules.Normalizer",
+    "fourierflow.routines.Grid2DMarkovExperiment": "fourierflow_amd.routines.Grid2DMarkovExperiment",
+}
+_INTERP = re.compile(r"^\$\{\s*([\w.]+)\s*:\s*(.*?)\s*\}$")
+
+
+class MethodRef:
+    """``${get_method: pkg.mod.attr}`` -- a dotted name, imported lazily (it may not exist here, e.g.
+    fourierflow.schedulers.CosineWithWarmupScheduler: only its NAME and kwargs matter to the fused step)."""
+
+    def __init__(self, name: str):
+        self.name = name.strip()
+
+    def __repr__(self):
+        return f"MethodRef({self.name})"
+
+
+class Partial:
+    """``_target_: functools.partial`` with ``_args_: [method]`` and keyword arguments (config.yaml:36-47)."""
+
+    def __init__(self, func: MethodRef, kwargs: Dict[str, Any]):
+        self.func, self.kwargs = func, kwargs
+
+    def __repr__(self):
+        return f"Partial({self.func.name}, {self.kwargs})"
+
+
+def import_string(name: str):
+    mod, _, attr = name.rpartition(".")
+    return getattr(importlib.import_module(mod), attr)
+
+
+def _resolve_scalar(v: Any) -> Any:
+    if not isinstance(v, str):
+        return v
+    m = _INTERP.match(v.strip())
+    if not m:
+        # embedded ${oc.env:VAR} inside a longer string (data paths)
+        return re.sub(r"\$\{oc\.env:(\w+)\}", lambda mm: os.environ.get(mm.group(1), ""), v)
+    kind, arg = m.group(1), m.group(2)
+    if kind == "get_method":
+        return MethodRef(arg)
+    if kind == "import":
+        return import_string(arg)
+    if kind == "eval":
+        return eval(arg, {"__builtins__": {}}, {})   # arithmetic only, like the reference's resolver use
+    if kind == "oc.env":
+        return os.environ.get(arg, "")
+    raise ValueError(f"unknown resolver ${{{kind}:...}}")
+
+
+def load_config(path: str, overrides: Sequence[str] = ()) -> Dict[str, Any]:
+    """yaml + ``a.b.c=value`` overrides (the positional overrides of `fourierflow train`, train.py:27-34)."""
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    for ov in overrides:
+        key, _, val = ov.partition("=")
+        node = cfg
+        parts = key.split(".")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = yaml.safe_load(val)
+    return cfg
+
+
+def instantiate(node: Any) -> Any:
+    if isinstance(node, list):
+        return [instantiate(v) for v in node]
+    if not isinstance(node, dict):
+        return _resolve_scalar(node)
+    if "_target_" not in node:
+        return {k: instantiate(v) for k, v in node.items()}
+    target = node["_target_"]
+    args = [instantiate(a) for a in node.get("_args_", [])]
+    kwargs = {k: instantiate(v) for k, v in node.items() if not k.startswith("_")}
+    if target == "functools.partial":
+        if not args or not isinstance(args[0], MethodRef):
+            raise ValueError("functools.partial nodes need `_args_: [${get_method: ...}]`")
+        return Partial(args[0], kwargs)
+    mapped = TARGET_MAP.get(target)
+    if mapped is None:
+        if target.startswith("fourierflow."):
+            raise NotImplementedError(f"{target} has no MI355X-native counterpart in fourierflow_amd (see DESIGN.md section 7)")
+        mapped = target
+    return import_string(mapped)(*args, **kwargs)
+
+
+def build_routine(cfg: Dict[str, Any]):
+    """Instantiate ``cfg['routine']`` (the model + optimiser + schedule); other sections are left alone."""
+    r = dict(cfg["routine"])
+    opt = instantiate(r.pop("optimizer", None)) if r.get("optimizer") else None
+    sch = instantiate(r.pop("scheduler", None)) if r.get("scheduler") else None
+    r.pop("optimizer", None)
+    r.pop("scheduler", None)
+    routine_kwargs = {}
+    if opt is not None:
+        if not isinstance(opt, Partial) or opt.func.name != "torch.optim.AdamW":
+            raise NotImplementedError(f"only torch.optim.AdamW maps to the fused flat optimiser kernel, got {opt}")
+        routine_kwargs["optimizer"] = dict(opt.kwargs)
+    if sch is not None:
+        s = sch["scheduler"] if isinstance(sch, dict) else sch
+        if not isinstance(s, Partial) or not s.func.name.endswith("CosineWithWarmupScheduler"):
+            raise NotImplementedError(f"only CosineWithWarmupScheduler is fused into the optimiser step, got {s}")
+        routine_kwargs["scheduler"] = dict(s.kwargs)
+    node = dict(r)
+    target = node.pop("_target_")
+    kwargs = {k: instantiate(v) for k, v in node.items() if not k.startswith("_")}
+    kwargs.update(routine_kwargs)
+    cls = import_string(TARGET_MAP.get(target, target))
+    return cls(**kwargs)

@@ -1,0 +1,49 @@
+"""`python -m fourierflow_amd.train CONFIG.yaml [overrides...]` -- minimal counterpart of `fourierflow train`
+(reference commands/train.py:27-123) for the hot path: build the routine from an experiment config and run
+the accumulation epoch + training steps.  Data files are out of scope: batches are synthetic
+N(0,1) fields of the configured grid; one JSON line per logged step.
+"""
+import argparse
+import json
+import time
+
+import torch
+
+from .config import build_routine, load_config
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("config")
+    ap.add_argument("overrides", nargs="*")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--accumulation-batches", type=int, default=4)
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--trial", type=int, default=0)
+    args = ap.parse_args(argv)
+    cfg = load_config(args.config, args.overrides)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7231 + args.trial)
+    routine = build_routine(cfg).to(dev)
+    B = args.batch_size or int(cfg.get("builder", {}).get("batch_size", 19))
+    G = args.grid
+
+    def batch():
+        return dict(x=torch.randn(B, G, G, 1, device=dev), y=torch.randn(B, G, G, 1, device=dev))
+
+    for _ in range(args.accumulation_batches):          # epoch 0: normaliser statistics only
+        routine.training_step(batch(), epoch=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        loss = routine.training_step(batch(), epoch=1)
+        if step % max(1, args.steps // 5) == 0 or step == args.steps - 1:
+            print(json.dumps(dict(step=step, loss=round(float(loss.item()), 6), lr=routine.trainer().current_lr())), flush=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps(dict(steps=args.steps, batch=B, grid=G, steps_per_s=round(args.steps / dt, 2))), flush=True)
+
+
+if __name__ == "__main__":
+    main()

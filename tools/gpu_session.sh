@@ -32,6 +32,41 @@ for st in $STAGES; do
     bench256)
       timeout 900 python bench.py --steps 10 --warmup 3 --grid 256 --layers 12 --modes 32 --batch 2 --cpu-steps 1 > gpurun_out/bench_256.log 2>&1
       echo "[session] bench256 rc=$?"; tail -n 1 gpurun_out/bench_256.log | cut -c1-1200 ;;
+    traincli)
+      python - <<'PY' > gpurun_out/example_config.yaml
+print("""routine:
+  _target_: fourierflow.routines.Grid2DMarkovExperiment
+  conv:
+    _target_: fourierflow.modules.FNOFactorized2DBlock
+    modes: 16
+    width: 64
+    n_layers: 24
+    input_dim: 3
+    share_weight: true
+    factor: 4
+    ff_weight_norm: true
+    gain: 0.1
+  n_steps: 10
+  max_accumulations: 1000
+  noise_std: 0.01
+  optimizer:
+    _target_: functools.partial
+    _args_: ["${get_method: torch.optim.AdamW}"]
+    lr: 0.0025
+    weight_decay: 0.0001
+  scheduler:
+    scheduler:
+      _target_: functools.partial
+      _args_: ["${get_method: fourierflow.schedulers.CosineWithWarmupScheduler}"]
+      num_warmup_steps: 500
+      num_training_steps: 100000
+      num_cycles: 0.5
+builder:
+  batch_size: 19
+""")
+PY
+      timeout 600 python -m fourierflow_amd.train gpurun_out/example_config.yaml --steps 40 > gpurun_out/train_cli.log 2>&1
+      echo "[session] traincli rc=$?"; tail -n 3 gpurun_out/train_cli.log ;;
     sq)
       rm -rf gpurun_out/pmc_SQ
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_SQ" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 > "$OLDPWD/gpurun_out/pmc_SQ.log" 2>&1)
