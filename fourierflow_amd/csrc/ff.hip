@@ -80,7 +80,9 @@ __global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restri
     // B operand of GEMM1 for the first tile: this lane's pixel, channels [KS*half, KS*half + KS)
     float nB[KS];
     {
-        const long px0 = (long)(blockIdx.x * NW + wave) * 32 + j;
+        // tile order is wave-major (tile = wave*gridDim + block): a partial last round (e.g. the reference batch 19:
+        // 2432 tiles on 2048 waves) then spreads over all CUs instead of piling 8 extra tiles on a few of them
+        const long px0 = (long)(wave * gridDim.x + blockIdx.x) * 32 + j;
         FFNO_UNROLL
         for (int u = 0; u < KS / 4; ++u) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(NW * 64) void ff_chain_kernel(const float* __restri
             nB[4 * u + 3] = v.w;
         }
     }
-    for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += tstride) {
+    for (int tile = wave * gridDim.x + blockIdx.x; tile < ntiles; tile += tstride) {
         const long px = (long)tile * 32 + j;
         const bool valid = px < P;
         float sB[KS];

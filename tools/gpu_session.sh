@@ -32,6 +32,9 @@ for st in $STAGES; do
     bench256)
       timeout 900 python bench.py --steps 10 --warmup 3 --grid 256 --layers 12 --modes 32 --batch 2 --cpu-steps 1 > gpurun_out/bench_256.log 2>&1
       echo "[session] bench256 rc=$?"; tail -n 1 gpurun_out/bench_256.log | cut -c1-1200 ;;
+    bench19)
+      timeout 600 python bench.py --steps 20 --warmup 5 --batch 19 --cpu-steps 0 > gpurun_out/bench_b19.log 2>&1
+      echo "[session] bench19 rc=$?"; grep "timed region" gpurun_out/bench_b19.log ;;
     traincli)
       python - <<'PY' > gpurun_out/example_config.yaml
 print("""routine:
