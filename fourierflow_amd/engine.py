@@ -69,7 +69,7 @@ class FFNOEngine:
 
     def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
                  share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
-                 padding: int = 0, output_dim: int = 1):
+                 padding: int = 0, output_dim: int = 1, use_fork: bool = False):
         if mode not in MODES:
             raise ValueError(f"mode must be one of {list(MODES)}, got {mode!r}")
         if spatial_dims not in (2, 3):
@@ -89,6 +89,7 @@ class FFNOEngine:
         self.C, self.H, self.Cin, self.L, self.O, self.pad = C, H, input_dim, n_layers, output_dim, padding
         self.mode, self.mode_id = mode, MODES[mode]
         self.share_weight, self.share_fork, self.wnorm = share_weight, share_fork, ff_weight_norm
+        self.use_fork = use_fork   # per-layer forecast heads: forecast = sum_l out(forecast_ff_l(s_l))  (grid_2d.py:164-167)
 
         # ---- parameter inventory, in the reference's named_parameters() naming --------------------
         self.linears: Dict[str, _Linear] = {}
@@ -107,8 +108,20 @@ class FFNOEngine:
 
         add_linear("in_proj.", C, input_dim)
         self.ff_prefix: List[str] = []
+        self.fc_prefix: List[str] = []     # forecast feed-forwards (use_fork)
         self.fw_names: List[Tuple[str, ...]] = []
+        if share_fork:                      # registration order of the reference: forecast_ff, backcast_ff (grid_2d.py:116-122)
+            if use_fork:
+                add_linear("forecast_ff.layers.0.0.", H, C)
+                add_linear("forecast_ff.layers.1.0.", C, H)
+            add_linear("backcast_ff.layers.0.0.", H, C)
+            add_linear("backcast_ff.layers.1.0.", C, H)
         for l in range(n_layers):
+            if use_fork:
+                fc = "forecast_ff." if share_fork else f"spectral_layers.{l}.forecast_ff."
+                self.fc_prefix.append(fc)
+                add_linear(fc + "layers.0.0.", H, C)
+                add_linear(fc + "layers.1.0.", C, H)
             fp = "backcast_ff." if share_fork else f"spectral_layers.{l}.backcast_ff."
             self.ff_prefix.append(fp)
             add_linear(fp + "layers.0.0.", H, C)
@@ -288,6 +301,15 @@ class FFNOEngine:
         ws.SY = torch.empty(max(v.spec for v in ws.views), **f32)
         ws.SD = torch.empty(max(v.spec for v in ws.views), **f32)    # scratch spectrum of the staged path
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
+        if self.use_fork:
+            ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
+            ws.YL = torch.empty(L, P_in * O, **f32)             # per-layer head outputs (forecast_list)
+        if save and self.use_fork:
+            ws.HF = torch.empty(ns, P, H, **f32)
+            ws.MASKF = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
+            ws.DSF = torch.empty(P, C, **f32)
+            ws.GF = torch.empty(P, C, **f32)
+            ws.redl = torch.empty(O * (C + 1), **f32)
         if save:
             ws.Hbuf = torch.empty(ns, P, H, **f32)
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
@@ -325,6 +347,11 @@ class FFNOEngine:
         fp = self.ff_prefix[l]
         l0, l1 = self.linears[fp + "layers.0.0."], self.linears[fp + "layers.1.0."]
         return l0, l1, self.params[fp + "layers.0.0.bias"], self.params[fp + "layers.1.0.bias"]
+
+    def _fc_weights(self, l):
+        fc = self.fc_prefix[l]
+        l0, l1 = self.linears[fc + "layers.0.0."], self.linears[fc + "layers.1.0."]
+        return l0, l1, self.params[fc + "layers.0.0.bias"], self.params[fc + "layers.1.0.bias"]
 
     def _can_fuse(self, views) -> bool:
         lib = _lib.get_lib()
@@ -394,10 +421,21 @@ class FFNOEngine:
                     self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
                                    self.planes[si][w][0] if full else None, True, int(w > 0), fused, st)
             l0, l1, b0, b1 = self._ff_weights(l)
-            self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None if last else _p(ws.X), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1),
-                    _p(ws.Blast if last else ws.X), _p(ws.Hbuf[sv]) if save_for_backward else None,
-                    _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
-        self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
+            if not (self.use_fork and last):      # with fork heads the last layer's backcast only feeds the dead x_L
+                self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None if last else _p(ws.X), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1),
+                        _p(ws.Blast if last else ws.X), _p(ws.Hbuf[sv]) if save_for_backward else None,
+                        _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
+            if self.use_fork:
+                c0, c1, cb0, cb1 = self._fc_weights(l)
+                self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None, _p(c0.weff), _p(cb0), _p(c1.weff), _p(cb1), _p(ws.F[sv]),
+                        _p(ws.HF[sv]) if save_for_backward else None, _p(ws.MASKF[sv]) if save_for_backward else None,
+                        P, C, H, st)
+                self._k("head_fwd", lib.ffno_head_fwd, _p(ws.F[sv]), _p(self.fold), _p(ws.YL[l]), ws.P_in, C, self.O, 0, pm, st)
+        if self.use_fork:
+            torch.sum(ws.YL, dim=0, out=ws.Y)     # forecast = sum of the per-layer head outputs
+            self.forecast_list = [ws.YL[l].view(B, *S, self.O).clone() for l in range(L)]
+        else:
+            self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
         self._saved = (x, B, S, fused) if save_for_backward else None
         return ws.Y.view(B, *S, self.O).clone()
 
@@ -422,7 +460,7 @@ class FFNOEngine:
         # Optional two-stream schedule (self.overlap): the FF weight-gradient GEMMs of layer l only need
         # (G_l, dh_l, s_l, h_l), so they can run on a side stream next to the adjoint of layer l.  G and dh are
         # ping-pong buffers; events order the reuse.
-        use_side = self.overlap and self.device.type == "cuda" and self.mode != "no-fourier"
+        use_side = self.overlap and self.device.type == "cuda" and self.mode != "no-fourier" and not self.use_fork
         side = ev_a = ev_b = main_obj = None
         st_side = st
         if use_side:
@@ -434,9 +472,18 @@ class FFNOEngine:
             st_side = ctypes.c_void_p(side.cuda_stream)
         cur = 0
         if pm is not None:
-            ws.G[cur].zero_()    # adjoint of the crop (mesh_3d.py:173): no gradient in the padded region
-        self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red),
-                ws.P_in, C, self.O, ws.nsplit_head, pm, st)
+            (ws.GF if self.use_fork else ws.G[cur]).zero_()    # adjoint of the crop (mesh_3d.py:173)
+        if self.use_fork:
+            # every layer's f_l goes through the same head: d/df_l = gy . weff for all l (computed once), and the
+            # head-parameter reduction sums over layers
+            for l in range(L):
+                self._k("head_bwd", lib.ffno_head_bwd, _p(ws.F[l]), _p(gy), _p(self.fold), _p(ws.GF) if l == 0 else None,
+                        _p(ws.headpart), _p(ws.red if l == 0 else ws.redl), ws.P_in, C, self.O, ws.nsplit_head, pm, st)
+                if l > 0:
+                    self._k("axpy", lib.ffno_axpy, _p(ws.red), _p(ws.redl), 1.0, self.O * (C + 1), st)
+        else:
+            self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red),
+                    ws.P_in, C, self.O, ws.nsplit_head, pm, st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
                 _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
         self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
@@ -446,6 +493,35 @@ class FFNOEngine:
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
             g_in, g_out, dh = ws.G[cur], ws.G[1 - cur], ws.DH[l & 1]
+            if self.use_fork:
+                c0, c1, _, _ = self._fc_weights(l)
+                fc = self.fc_prefix[l]
+                ds_f = ws.DS if last else ws.DSF     # last layer: the forecast path is the only contribution to ds
+                self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.GF), _p(ws.MASKF[l]), _p(c0.wt), _p(c1.wt), _p(dh), _p(ds_f),
+                        P, C, H, st)
+                self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(ws.GF), _p(ws.HF[l]), _p(dh),
+                        _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
+                self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(c0.gweff), _p(c1.gweff),
+                        _p(gv(fc + "layers.0.0.bias")), _p(gv(fc + "layers.1.0.bias")), C, H, ws.nsplit_ff, int(fc in ff_seen), st)
+                ff_seen.add(fc)
+            if self.use_fork and last:
+                # x_L is never used with fork heads: the last backcast_ff gets a zero gradient
+                if fp not in ff_seen:
+                    for nm in (fp + "layers.0.0.bias", fp + "layers.1.0.bias"):
+                        gv(nm).zero_()
+                    l0.gweff.zero_()
+                    l1.gweff.zero_()
+                    ff_seen.add(fp)
+                if self.mode == "no-fourier":
+                    g_out.copy_(ws.DS)
+                else:
+                    si = self._fw_sets.index(self.fw_names[l]) if full else 0
+                    for w, v in enumerate(ws.views):
+                        keep = ws.SDall[w][l] if full else None
+                        self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, None, keep,
+                                       self.planes[si][w][1] if full else None, False, int(w > 0), fused, st)
+                cur = 1 - cur
+                continue
             self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(g_in), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(dh), _p(ws.DS),
                     P, C, H, st)
             if use_side:
@@ -457,6 +533,8 @@ class FFNOEngine:
             self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
                     _p(gv(fp + "layers.0.0.bias")), _p(gv(fp + "layers.1.0.bias")), C, H, ws.nsplit_ff, int(fp in ff_seen), st_side)
             ff_seen.add(fp)
+            if self.use_fork:
+                self._k("axpy", lib.ffno_axpy, _p(ws.DS), _p(ws.DSF), 1.0, P * C, st)     # ds = ds(backcast) + ds(forecast)
             if use_side:
                 self._issue_stream = None
                 ev_b[l & 1].record(side)
@@ -502,7 +580,7 @@ class FFNO2DEngine(FFNOEngine):
     """FNOFactorized2DBlock geometry (the 2-D entry point used by the module mirror and the tests)."""
 
     def __init__(self, *, modes: int, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
-                 share_fork: bool, ff_weight_norm: bool, mode: str = "full"):
+                 share_fork: bool, ff_weight_norm: bool, mode: str = "full", use_fork: bool = False):
         super().__init__(modes=modes, width=width, input_dim=input_dim, n_layers=n_layers, factor=factor,
                          share_weight=share_weight, share_fork=share_fork, ff_weight_norm=ff_weight_norm, mode=mode,
-                         spatial_dims=2, padding=0, output_dim=1)
+                         spatial_dims=2, padding=0, output_dim=1, use_fork=use_fork)

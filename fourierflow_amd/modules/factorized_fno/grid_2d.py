@@ -91,9 +91,6 @@ class FNOFactorized2DBlock(nn.Module):
         super().__init__()
         if in_dropout:
             raise NotImplementedError("in_dropout > 0 is not implemented by the gfx950 kernel set (no config uses it)")
-        if use_fork:
-            raise NotImplementedError("use_fork=True (per-layer forecast heads) is not implemented by the gfx950 "
-                                      "kernel set yet; only experiments/torus_li/ablation uses it")
         self.modes, self.width, self.input_dim = modes, width, input_dim
         self.n_layers, self.use_fork, self.mode = n_layers, use_fork, mode
         self.share_weight, self.share_fork = share_weight, share_fork
@@ -103,6 +100,8 @@ class FNOFactorized2DBlock(nn.Module):
 
         self.forecast_ff = self.backcast_ff = None
         if share_fork:
+            if use_fork:
+                self.forecast_ff = FeedForward(width, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
             self.backcast_ff = FeedForward(width, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
 
         self.fourier_weight = None
@@ -126,7 +125,8 @@ class FNOFactorized2DBlock(nn.Module):
         if self._engine is None:
             self._engine = FFNO2DEngine(modes=self.modes, width=self.width, input_dim=self.input_dim,
                                         n_layers=self.n_layers, factor=self.factor, share_weight=self.share_weight,
-                                        share_fork=self.share_fork, ff_weight_norm=self.ff_weight_norm, mode=self.mode)
+                                        share_fork=self.share_fork, ff_weight_norm=self.ff_weight_norm, mode=self.mode,
+                                        use_fork=self.use_fork)
         return self._engine
 
     def engine_parameters(self):
@@ -147,4 +147,7 @@ class FNOFactorized2DBlock(nn.Module):
         _lib.require_device_tensor(x, "FNOFactorized2DBlock input")
         params = [p for _, p in self.engine_parameters()]
         forecast = _BlockFn.apply(x, self, *params)
-        return {'forecast': forecast, 'forecast_list': []}
+        # forecast_list (per-layer head outputs, use_fork) is returned for logging like the reference does; gradients
+        # flow through 'forecast' only
+        flist = list(getattr(self._engine, "forecast_list", [])) if self.use_fork else []
+        return {'forecast': forecast, 'forecast_list': flist}

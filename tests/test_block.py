@@ -21,7 +21,8 @@ def build_block(kw, seed, device):
     return blk.to(device)
 
 
-TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64_nofourier", "c32_nown",
+TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64_nofourier", "c32_nown", "c64_fork",
+        "c64_sharefork_fork",
         "c64_4l_markov", "c64_24l_markov"]
 GPU_ONLY = {"c64_4l_markov", "c64_24l_markov"}  # too slow for the CPU emulator
 
@@ -41,7 +42,11 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
     out = blk(torch.from_numpy(x_np).to(host_device))
     pred = out["forecast"]
-    assert out["forecast_list"] == []
+    if "forecast_list" in gu.packed_names(g):
+        fl = np.stack([f.detach().cpu().numpy() for f in out["forecast_list"]])
+        assert gu.compare_packed(g, "forecast_list", fl, 1e-5) < 1e-5
+    else:
+        assert out["forecast_list"] == []
     assert gu.compare_packed(g, "forecast", pred.detach().cpu().numpy(), 1e-5) < 1e-5
     loss = orc.lp_rel_loss(pred, torch.from_numpy(t_np).to(host_device))
     assert abs(loss.item() - float(g["loss"])) < 1e-5
@@ -65,7 +70,8 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
 def test_state_dict_keys_match_reference_layout():
     kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
     from fourierflow_amd.modules import FNOFactorized2DBlock
-    for extra in (dict(), dict(share_fork=True), dict(share_weight=False, ff_weight_norm=False)):
+    for extra in (dict(), dict(share_fork=True), dict(share_weight=False, ff_weight_norm=False), dict(use_fork=True),
+                  dict(use_fork=True, share_fork=True)):
         k = {**kw, **extra}
         blk = FNOFactorized2DBlock(**k)
         ref = gu.make_block_state_dict(k, 0)
@@ -81,7 +87,7 @@ def test_state_dict_keys_match_reference_layout():
 def test_unsupported_options_fail_loudly():
     from fourierflow_amd.modules import FNOFactorized2DBlock
     base = dict(modes=4, width=64, input_dim=3, n_layers=2, factor=4)
-    for bad in (dict(use_fork=True), dict(layer_norm=True), dict(n_ff_layers=3), dict(dropout=0.1), dict(in_dropout=0.1)):
+    for bad in (dict(layer_norm=True), dict(n_ff_layers=3), dict(dropout=0.1), dict(in_dropout=0.1)):
         with pytest.raises(NotImplementedError):
             FNOFactorized2DBlock(**{**base, **bad})
     with pytest.raises(ValueError):
