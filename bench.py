@@ -30,6 +30,9 @@ T_START = time.perf_counter()
 MARKOV24 = dict(modes=16, width=64, n_layers=24, input_dim=3, share_weight=True, factor=4, ff_weight_norm=True,
                 gain=0.1, dropout=0.0, in_dropout=0.0)
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+# split-bf16 kernels (ffx.hip): one fp32-accurate multiply-add = 6 bf16 MFMA multiply-adds, so their matrix-core ceiling in
+# ALGORITHMIC (fp32-equivalent) FLOP/s is the dense bf16 peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 6
+BF16X3_PEAK_TFLOPS = 2500.0 / 6.0
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 
 
@@ -69,6 +72,9 @@ class KernelTimer:
         return out
 
 
+FFX_KERNELS = ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial")
+
+
 def algorithmic_work(P, C, H, K, B, M, N, L):
     """Algorithmic FLOPs / HBM bytes per launch of the timed kernels and launches per train step.
     fp32: 4 B per element.  R = lines per axis; spectra are K*R*2C floats."""
@@ -81,9 +87,11 @@ def algorithmic_work(P, C, H, K, B, M, N, L):
         # one spectral branch: read x, write s (+ read s when accumulating the 2nd branch), + save the spectrum (training)
         "spectral_fused": dict(flops=2 * dft + mix, bytes=(act + act + spec) + 0.5 * act, per_step=2 * L, bound="hbm"),
         "spectral_fused(adj)": dict(flops=2 * dft + mix, bytes=(act + act + act + spec), per_step=2 * L, bound="hbm"),
-        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=3 * act + 4.0 * P * H + P * H / 8, per_step=L, bound="mfma"),
-        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=2 * act + 4.0 * P * H + P * H / 8, per_step=L, bound="mfma"),
-        "ff_bwd_weights_partial": dict(flops=4.0 * P * C * H, bytes=2 * act + 8.0 * P * H, per_step=L, bound="mfma"),
+        # split-bf16 feed-forward (ffx.hip): no hidden activations in HBM, only the ReLU sign bits (P*H/8 bytes); the
+        # weight-gradient kernel recomputes h and dh, so its algorithmic FLOPs are 4 GEMMs (2 recomputed + 2 gradients)
+        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=3 * act + P * H / 8, per_step=L, bound="mfma"),
+        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=2 * act + P * H / 8, per_step=L, bound="mfma"),
+        "ff_bwd_weights_partial": dict(flops=8.0 * P * C * H, bytes=2 * act, per_step=L, bound="mfma"),
         "fw_grad_partial": dict(flops=L * mix, bytes=2 * L * spec, per_step=2, bound="hbm"),
     }
 
@@ -253,9 +261,10 @@ def main():
         for n, srow in ksum.items():
             w = work[n]
             us = srow["avg_us"]
+            mpeak = BF16X3_PEAK_TFLOPS if (n in FFX_KERNELS and trainer.engine._ffx()) else FP32_MFMA_PEAK_TFLOPS
             kernels[n] = dict(avg_us=round(us, 2), per_step=w["per_step"], ms_per_step=round(us * w["per_step"] * 1e-3, 3),
                               tflops=round(w["flops"] / us * 1e-6, 2), gbs=round(w["bytes"] / us * 1e-3, 1),
-                              frac_mfma=round(w["flops"] / us * 1e-6 / FP32_MFMA_PEAK_TFLOPS, 3),
+                              mfma_peak_tflops=round(mpeak, 1), frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3),
                               frac_hbm=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3), samples=srow["samples"])
         # dominant kernel = the kernel symbol with the largest share of the step (spectral_fused fwd+adj are one symbol)
         share = {}
@@ -272,7 +281,7 @@ def main():
             if bound == "hbm":
                 ach, peak, unit = by / us * 1e-3, HBM_PEAK_GBS, "GB/s"
             else:
-                ach, peak, unit = fl / us * 1e-6, FP32_MFMA_PEAK_TFLOPS, "TFLOP/s"
+                ach, peak, unit = fl / us * 1e-6, kernels[members[0]]["mfma_peak_tflops"], "TFLOP/s"
             traffic = pmc.get(dom_sym, {}).get("hbm_bytes_per_launch")
             roofline = dict(kernel=dom_sym, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
                             frac=round(ach / peak, 4), traffic=traffic, avg_launch_us=round(us, 2),

@@ -19,6 +19,11 @@ class WnDesc(C.Structure):
                 ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class FxPackDesc(C.Structure):
+    """Mirror of ``ffno_fxpack_desc`` (include/ffno.h)."""
+    _fields_ = [("src", P), ("dst", P), ("sh", C.c_int32), ("sc", C.c_int32), ("type", C.c_int32), ("pad_", C.c_int32)]
+
+
 class PadMap(C.Structure):
     """Mirror of ``ffno_padmap`` (include/ffno.h)."""
     _fields_ = [("size", C.c_int32 * 3), ("padded", C.c_int32 * 3)]
@@ -50,6 +55,13 @@ SIGNATURES = {
     "ffno_ff_wgrad_partial_floats": (SZ, [I, I, I]),
     "ffno_ff_bwd_weights_partial": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ff_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ffno_ffx_supported": (I, [I, I]),
+    "ffno_ffx_pack_bytes": (SZ, [I, I]),
+    "ffno_ffx_pack": (I, [P, I, I, I, P]),
+    "ffno_ffx_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ffx_bwd_data": (I, [P, P, P, P, P, I, I, I, P]),
+    "ffno_ffx_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "ffno_ffx_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),
     "ffno_transpose_batched": (I, [P, I, I, I, P]),

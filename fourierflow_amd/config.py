@@ -23,6 +23,7 @@ TARGET_MAP = {
     "fourierflow.modules.WNLinear": "fourierflow_amd.modules.WNLinear",
     "fourierflow.modules.Normalizer": "fourierflow_amd.modules.Normalizer",
     "fourierflow.routines.Grid2DMarkovExperiment": "fourierflow_amd.routines.Grid2DMarkovExperiment",
+    "fourierflow.routines.StructuredMeshExperiment": "fourierflow_amd.routines.StructuredMeshExperiment",
 }
 _INTERP = re.compile(r"^\$\{\s*([\w.]+)\s*:\s*(.*?)\s*\}$")
 

@@ -58,6 +58,81 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 #endif
 }
 
+// ---- split-bf16 ("bf16x3") matrix arithmetic ---------------------------------------------------------------
+// An fp32 value is the EXACT sum of three bf16 numbers (its 24 significant bits cut into 8+8+8 by truncation), so an
+// fp32 product a*b is recovered from bf16 products: of the nine partial products the six with weight >= 2^-16
+// (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) are kept; the dropped ones are <= 3 * 2^-24 |a b| -- the size of one
+// fp32 rounding.  v_mfma_f32_32x32x16_bf16 (8 passes, 16x the fp32 MFMA rate; MI355X_MICROARCH.md "Matrix cores")
+// accumulates them in fp32, so six of them do the work of eight v_mfma_f32_32x32x2_f32 in 3/8 of the time.
+//   A operand: 8 bf16 per lane, lane l holds A[i = l & 31][k = 8*(l>>5) + e];  B likewise B[k = 8*(l>>5) + e][j = l & 31];
+//   C/D as the fp32 forms.  A and B use the same (lane-half, slot) -> k map, so any k permutation applied to both cancels.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Bf3 {
+    u32x4 hi, mid, lo;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef FFNO_EMU
+    return emu::mfma_32x32x16_bf16(a, b, c);
+#else
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
+__device__ __forceinline__ f32x16 mfma_x3(const Bf3& a, const Bf3& b, f32x16 c) {
+    c = mfma_bf16(a.lo, b.hi, c);
+    c = mfma_bf16(a.hi, b.lo, c);
+    c = mfma_bf16(a.mid, b.mid, c);
+    c = mfma_bf16(a.mid, b.hi, c);
+    c = mfma_bf16(a.hi, b.mid, c);
+    c = mfma_bf16(a.hi, b.hi, c);
+    return c;
+}
+
+__device__ __forceinline__ unsigned f2u(float x) {
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    return u;
+}
+__device__ __forceinline__ float u2f(unsigned u) {
+    float x;
+    __builtin_memcpy(&x, &u, 4);
+    return x;
+}
+// upper halves of two words -> one word (element 0 = x0 in the low half)
+__device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) {
+#ifdef FFNO_EMU
+    return (u0 >> 16) | (u1 & 0xffff0000u);
+#else
+    return __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+#endif
+}
+// exact 3-way truncation split of a pair of floats into packed bf16 pairs
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    const unsigned u0 = f2u(x0), u1 = f2u(x1);
+    h = pack_hi16(u0, u1);
+    const float r0 = x0 - u2f(u0 & 0xffff0000u), r1 = x1 - u2f(u1 & 0xffff0000u);
+    const unsigned v0 = f2u(r0), v1 = f2u(r1);
+    m = pack_hi16(v0, v1);
+    const float q0 = r0 - u2f(v0 & 0xffff0000u), q1 = r1 - u2f(v1 & 0xffff0000u);
+    l = pack_hi16(f2u(q0), f2u(q1));
+}
+// 8 floats (slots e = 0..7 of one k16 step) -> the three operand planes
+__device__ __forceinline__ Bf3 split3_8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    Bf3 f;
+    unsigned h, m, l;
+    split3_pair(v0, v1, h, m, l);
+    f.hi[0] = h, f.mid[0] = m, f.lo[0] = l;
+    split3_pair(v2, v3, h, m, l);
+    f.hi[1] = h, f.mid[1] = m, f.lo[1] = l;
+    split3_pair(v4, v5, h, m, l);
+    f.hi[2] = h, f.mid[2] = m, f.lo[2] = l;
+    split3_pair(v6, v7, h, m, l);
+    f.hi[3] = h, f.mid[3] = m, f.lo[3] = l;
+    return f;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
     FFNO_UNROLL

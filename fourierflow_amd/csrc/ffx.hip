@@ -1,0 +1,621 @@
+// Pointwise feed-forward of the F-FNO layer on the bf16 matrix cores at fp32 accuracy ("bf16x3").
+//
+// Same operator as ff.hip (FeedForward.forward, reference fourierflow/modules/feedforward.py:13-19 with n_layers = 2,
+// + the residual add of grid_2d.py:169, and their autograd):
+//     h = relu(s W1^T + b1)        out = resid + h W2^T + b2
+// but every fp32 operand is cut EXACTLY into three bf16 planes and each product is evaluated with six
+// v_mfma_f32_32x32x16_bf16 (ffno_device.h "split-bf16"): fp32-grade results at 8/3 of the fp32 MFMA rate.  With the
+// matrix work that cheap the kernels are organised around HBM traffic instead:
+//
+//   * the [P][H] hidden activations are never written: the forward keeps only the ReLU sign bits (P*H/8 bytes) and the
+//     weight-gradient kernel RECOMPUTES h and dh from s and db (two extra GEMMs that cost less than reading them back);
+//   * a wave owns a 32-row chunk of the hidden layer for the lifetime of a persistent workgroup and keeps its slices of
+//     both weight matrices (pre-split, pre-permuted by ffx_pack) in registers -- no LDS bandwidth for the A operands;
+//     all waves of a workgroup work on the same 32-pixel tile;
+//   * forward / backward-data: GEMM1 gives the wave h^T[chunk][px]; as in ff.hip the D fragment is re-used directly as
+//     the B operand of GEMM2 (k order = D-fragment order, matched by the packed A2 operand), which yields a PARTIAL
+//     out^T[c][px] over the wave's hidden chunk; the partials meet in LDS (double-buffered, one barrier per tile) and
+//     each wave reduces + stores 1/NW of the output tile;
+//   * weight gradients: h^T / dh^T are recomputed TRANSPOSED (pixels = D rows) so that the D fragment is again a valid
+//     B operand, now of the pixel-contraction GEMMs dW2[c][hid] = sum_px db[px][c] h[px][hid] and
+//     dW1^T[c][hid] = sum_px s[px][c] dh[px][hid]; every wave accumulates its own [C x 32] slice of both for all the
+//     pixels of the workgroup -- no cross-wave reduction at all.
+//
+// Activation tiles are staged through LDS already split (each element is split once per workgroup, not once per wave).
+#include "ffno_device.h"
+#include "ffno.h"
+#include <cstdlib>
+
+namespace ffno {
+
+template <int C, int H>
+struct FxCfg {
+    static constexpr int CPW = 1;                 // hidden chunks (of 32 rows) per wave
+    static constexpr int NW = H / (32 * CPW);     // waves per workgroup (two per SIMD at H = 256)
+    static constexpr int NT = NW * 64;
+    static constexpr int KS = C / 16;             // k16 steps over the channels
+    static constexpr int CTO = C / 32;            // 32-row tiles over the channels
+    static constexpr int NV = (32 * C / 4) / NT;  // float4 per thread per staged [32 px][C] tile
+    static constexpr int G = CTO * 4;             // float4 groups per lane of an output tile
+    static constexpr int GPW = G / NW;            // ... reduced by each wave
+    // pixel-major planes (B operand of GEMM1 / A operand of the recompute): [32 px][C] bf16, 16 B row pad
+    static constexpr int PROW = 2 * C + 16;
+    static constexpr int PPLANE = 32 * PROW;
+    // channel-major planes (A operand of the pixel-contraction GEMMs): [C][32 px in k order] bf16, 16 B row pad
+    static constexpr int TROW = 64 + 16;
+    static constexpr int TPLANE = C * TROW;
+    static constexpr int PART = 2 * H * C + H + C;
+    static_assert(NV >= 1 && NV * NT * 4 == 32 * C, "tile staging map");
+    static_assert(GPW >= 1 && GPW * NW == G, "output reduction map");
+};
+
+// ---- weight packing -----------------------------------------------------------------------------------------------
+// type 1 ("hidden on lanes"):  frag (w, st)      lane (j, half) slot e  <-  W(hid = 32w + j, c = 16 st + 8 half + e)
+// type 2 ("channel on lanes"): frag (w, mt, s2)  lane (j, half) slot e  <-  W(hid = 32w + (e&3) + 8(2 s2 + (e>>2)) + 4 half,
+//                                                                           c = 32 mt + j)
+// with W(hid, c) = src[hid * sh + c * sc]; each fragment is three planes of 64 lanes x 16 B.
+struct FxPackDesc {
+    const float* src;
+    u32x4* dst;
+    int sh, sc, type, pad;
+};
+
+__global__ __launch_bounds__(256) void ffx_pack_kernel(const FxPackDesc* __restrict__ descs, int C, int H) {
+    const FxPackDesc d = descs[blockIdx.y];
+    const int KS = C / 16, CTO = C / 32, NW = H / 32;
+    const int nfrag = d.type == 1 ? NW * KS : NW * CTO * 2;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nfrag * 64) return;
+    const int frag = t >> 6, lane = t & 63, j = lane & 31, half = lane >> 5;
+    float v[8];
+    if (d.type == 1) {
+        const int w = frag / KS, st = frag % KS;
+        for (int e = 0; e < 8; ++e) v[e] = d.src[(long)(32 * w + j) * d.sh + (long)(16 * st + 8 * half + e) * d.sc];
+    } else {
+        const int s2 = frag & 1, mt = (frag >> 1) % CTO, w = (frag >> 1) / CTO;
+        for (int e = 0; e < 8; ++e)
+            v[e] = d.src[(long)(32 * w + (e & 3) + 8 * (2 * s2 + (e >> 2)) + 4 * half) * d.sh + (long)(32 * mt + j) * d.sc];
+    }
+    const Bf3 f = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    d.dst[(frag * 3 + 0) * 64 + lane] = f.hi;
+    d.dst[(frag * 3 + 1) * 64 + lane] = f.mid;
+    d.dst[(frag * 3 + 2) * 64 + lane] = f.lo;
+}
+
+__device__ __forceinline__ Bf3 load_frag(const u32x4* __restrict__ pk, int frag, int lane) {
+    Bf3 f;
+    f.hi = pk[(frag * 3 + 0) * 64 + lane];
+    f.mid = pk[(frag * 3 + 1) * 64 + lane];
+    f.lo = pk[(frag * 3 + 2) * 64 + lane];
+    return f;
+}
+
+// (acc << 1) | msb(x)
+__device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t x) {
+#ifdef FFNO_EMU
+    return (acc << 1) | (x >> 31);
+#else
+    return __builtin_amdgcn_alignbit(acc, x, 31);
+#endif
+}
+// all-ones if bit b of x is set, else 0
+__device__ __forceinline__ uint32_t bit_mask(uint32_t x, int b) {
+#ifdef FFNO_EMU
+    return 0u - ((x >> b) & 1u);
+#else
+    return (uint32_t)__builtin_amdgcn_sbfe((int)x, b, 1);
+#endif
+}
+
+// three planes at the same offset of an LDS tile
+__device__ __forceinline__ Bf3 lds_frag(const char* base, int plane_bytes, int off) {
+    Bf3 f;
+    f.hi = *reinterpret_cast<const u32x4*>(base + off);
+    f.mid = *reinterpret_cast<const u32x4*>(base + plane_bytes + off);
+    f.lo = *reinterpret_cast<const u32x4*>(base + 2 * plane_bytes + off);
+    return f;
+}
+
+// split 4 consecutive values and store them as 8 B per plane
+__device__ __forceinline__ void stage4(char* base, int plane_bytes, int off, float x, float y, float z, float w) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3_pair(x, y, h0, m0, l0);
+    split3_pair(z, w, h1, m1, l1);
+    *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(base + plane_bytes + off) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(base + 2 * plane_bytes + off) = make_uint2(l0, l1);
+}
+
+// ---- forward / backward-data -----------------------------------------------------------------------------------------
+//   forward : in = s,  A1 = pack1(W1),   A2 = pack2(W2)     h = relu(A1 in + b1), sign bits -> mask ; out = A2 h + b2 (+ resid)
+//   backward: in = db, A1 = pack1(W2^T), A2 = pack2(W1^T)   dh = mask ? A1 in : 0                    ; ds  = A2 dh
+template <int C, int H, bool BWD>
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const float* __restrict__ in, const float* resid,
+                                                                     const u32x4* __restrict__ pk1,
+                                                                     const float* __restrict__ bias1,
+                                                                     const u32x4* __restrict__ pk2,
+                                                                     const float* __restrict__ bias2, float* out,
+                                                                     uint32_t* mask, int P, int xy_sel) {
+    using F = FxCfg<C, H>;
+    constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, NV = F::NV, G = F::G, GPW = F::GPW, CPW = F::CPW;
+    __shared__ __attribute__((aligned(16))) char sp[2][3 * F::PPLANE];
+    __shared__ __attribute__((aligned(16))) float part[2][NW * G * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float b1s[H];
+    __shared__ float b2s[C];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+
+    Bf3 A1[CPW][KS], A2[CPW][CTO][2];
+    FFNO_UNROLL
+    for (int ch = 0; ch < CPW; ++ch) {
+        const int q = wave * CPW + ch;
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) A1[ch][st] = load_frag(pk1, q * KS + st, lane);
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int s2 = 0; s2 < 2; ++s2) A2[ch][mt][s2] = load_frag(pk2, (q * CTO + mt) * 2 + s2, lane);
+        }
+    }
+    if (!BWD) {
+        for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e];
+        for (int e = tid; e < C; e += F::NT) b2s[e] = bias2[e];
+    }
+
+    // staging map: float4 number f = tid + v * NT of the [32][C] tile
+    float4 nS[NV];
+    auto gload = [&](int tile) {
+        FFNO_UNROLL
+        for (int v = 0; v < NV; ++v) {
+            const int f = tid + v * F::NT;
+            const long px = (long)tile * 32 + f / (C / 4);
+            nS[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px < P) nS[v] = *reinterpret_cast<const float4*>(in + px * C + 4 * (f % (C / 4)));
+        }
+    };
+    auto stage = [&](int buf) {
+        FFNO_UNROLL
+        for (int v = 0; v < NV; ++v) {
+            const int f = tid + v * F::NT;
+            stage4(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
+        }
+    };
+    // reduce the NW partial tiles of `tile` (this wave owns float4 groups [wave*GPW, +GPW)) and store the output rows
+    float4 rres[GPW];
+    auto rload = [&](int tile) {   // residual rows of the tile, fetched a full MFMA phase before they are needed
+        const long px = (long)tile * 32 + j;
+        FFNO_UNROLL
+        for (int u = 0; u < GPW; ++u) {
+            const int gi = wave * GPW + u;
+            rres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!BWD && resid && px < P)
+                rres[u] = *reinterpret_cast<const float4*>(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
+        }
+    };
+    auto reduce = [&](int tile, int buf) {
+        const long px = (long)tile * 32 + j;
+        FFNO_UNROLL
+        for (int u = 0; u < GPW; ++u) {
+            const int gi = wave * GPW + u;
+            float4 acc = *reinterpret_cast<const float4*>(&part[buf][((0 * G + gi) * 64 + lane) * 4]);
+            FFNO_UNROLL
+            for (int w = 1; w < NW; ++w) {
+                const float4 t = *reinterpret_cast<const float4*>(&part[buf][((w * G + gi) * 64 + lane) * 4]);
+                acc.x += t.x;
+                acc.y += t.y;
+                acc.z += t.z;
+                acc.w += t.w;
+            }
+            const int c0 = 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half;
+            if (!BWD) {
+                acc.x += b2s[c0] + rres[u].x;
+                acc.y += b2s[c0 + 1] + rres[u].y;
+                acc.z += b2s[c0 + 2] + rres[u].z;
+                acc.w += b2s[c0 + 3] + rres[u].w;
+            }
+            if (px < P) *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+        }
+    };
+
+    if ((int)blockIdx.x < ntiles) {
+        gload(blockIdx.x);
+        stage(0);
+    }
+    __syncthreads();
+
+    // Software pipeline: iteration t multiplies tile t and reduces + stores tile t-1.  The two waves that share a SIMD
+    // (w and w + NW/2) place that reduction at opposite ends of the iteration, so between two barriers one of them
+    // runs  [reduce | GEMM1 | epilogue | GEMM2]  and the other  [GEMM1 | epilogue | GEMM2 | reduce]: the VALU/LDS
+    // phases of one fall on the MFMA phases of the other instead of both queueing for the same pipe in lockstep.
+    const bool early = xy_sel == 0 ? (wave < NW / 2) : xy_sel == 1 ? !(wave & 1) : true;
+    int buf = 0, prev = -1;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int nt = tile + gridDim.x;
+        if (nt < ntiles) gload(nt);
+        static_assert(CPW == 1, "one 16-bit sign word per (tile, wave, lane)");
+        uint16_t* mp = mask ? reinterpret_cast<uint16_t*>(mask) + ((long)tile * NW + wave) * 64 + lane : nullptr;
+        uint32_t bits = 0;
+        if (BWD) bits = *mp;
+
+        // GEMM1: this wave's hidden chunks for the 32 pixels of the tile
+        f32x16 d[CPW];
+        FFNO_UNROLL
+        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            const Bf3 b = lds_frag(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) d[ch] = mfma_x3(A1[ch][st], b, d[ch]);
+        }
+        if (early && prev >= 0) reduce(prev, buf ^ 1);
+        // epilogue + GEMM2 partial over the wave's hidden rows, k order = D-fragment order
+        f32x16 o[CTO];
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16();
+        FFNO_UNROLL
+        for (int ch = 0; ch < CPW; ++ch) {
+            if (BWD) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) d[ch][r] = u2f(f2u(d[ch][r]) & bit_mask(bits, 15 - r));
+            } else {
+                FFNO_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(&b1s[32 * (wave * CPW + ch) + 8 * g + 4 * half]);
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                    FFNO_UNROLL
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = fmaxf(d[ch][4 * g + i] + bb[i], 0.f);
+                        d[ch][4 * g + i] = v;
+                        bits = push_sign(bits, 0u - f2u(v));   // msb(-bits(v)) = [v > 0]; element r ends up at bit 15 - r
+                    }
+                }
+            }
+            Bf3 hb[2];
+            hb[0] = split3_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
+            hb[1] = split3_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+            FFNO_UNROLL
+            for (int mt = 0; mt < CTO; ++mt) {
+                o[mt] = mfma_x3(A2[ch][mt][0], hb[0], o[mt]);
+                o[mt] = mfma_x3(A2[ch][mt][1], hb[1], o[mt]);
+            }
+        }
+        if (!BWD && mp) *mp = (uint16_t)bits;
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&part[buf][(((wave * G) + mt * 4 + g) * 64 + lane) * 4]) =
+                    make_float4(o[mt][4 * g], o[mt][4 * g + 1], o[mt][4 * g + 2], o[mt][4 * g + 3]);
+        }
+        if (!early && prev >= 0) reduce(prev, buf ^ 1);
+        rload(tile);
+        if (nt < ntiles) stage(buf ^ 1);
+        prev = tile;
+        __syncthreads();
+    }
+    if (prev >= 0) reduce(prev, buf ^ 1);
+}
+
+// ---- weight gradients with recomputed hidden activations --------------------------------------------------------------
+// Per workgroup slice:  dW1^T[c][hid], dW2[c][hid], db1[hid], db2[c]  (dW1 is stored transposed; the reduce kernel
+// un-transposes).  pk1 = pack1(W1), pk2t = pack1(W2^T) -- the A1 operands of the forward and backward chain kernels.
+template <int C, int H>
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const float* __restrict__ s,
+                                                                     const float* __restrict__ db,
+                                                                     const u32x4* __restrict__ pk1,
+                                                                     const float* __restrict__ bias1,
+                                                                     const u32x4* __restrict__ pk2t,
+                                                                     float* __restrict__ partial, int P) {
+    using F = FxCfg<C, H>;
+    constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV, CPW = F::CPW;
+    constexpr int BUF = 6 * F::PPLANE + 6 * F::TPLANE;   // [sP x3][dbP x3][sT x3][dbT x3]
+    constexpr int OFF_SP = 0, OFF_DP = 3 * F::PPLANE, OFF_ST = 6 * F::PPLANE, OFF_DT = 6 * F::PPLANE + 3 * F::TPLANE;
+    __shared__ __attribute__((aligned(16))) char lds[2][BUF];
+    __shared__ float red[F::NT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+
+    Bf3 W1f[CPW][KS], W2f[CPW][KS];
+    float b1v[CPW];
+    FFNO_UNROLL
+    for (int ch = 0; ch < CPW; ++ch) {
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            W1f[ch][st] = load_frag(pk1, (wave * CPW + ch) * KS + st, lane);
+            W2f[ch][st] = load_frag(pk2t, (wave * CPW + ch) * KS + st, lane);
+        }
+        b1v[ch] = bias1[32 * (wave * CPW + ch) + j];
+    }
+
+    // staging: pixel-major map as in the chain kernel; channel-major map: channel tc, pixel group tg (+ v * NT/C)
+    const int tc = tid % C, tg = tid / C;
+    float4 nSP[NV], nDP[NV], nST[NV], nDT[NV];
+    float bs2 = 0.f;
+    auto gload = [&](int tile) {
+        FFNO_UNROLL
+        for (int v = 0; v < NV; ++v) {
+            const int f = tid + v * F::NT;
+            const long px = (long)tile * 32 + f / (C / 4);
+            nSP[v] = nDP[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px < P) {
+                nSP[v] = *reinterpret_cast<const float4*>(s + px * C + 4 * (f % (C / 4)));
+                nDP[v] = *reinterpret_cast<const float4*>(db + px * C + 4 * (f % (C / 4)));
+            }
+            const long p0 = (long)tile * 32 + 4 * (tg + v * (F::NT / C));
+            float a[4], b[4];
+            FFNO_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = p0 + i < P;
+                a[i] = ok ? s[(p0 + i) * C + tc] : 0.f;
+                b[i] = ok ? db[(p0 + i) * C + tc] : 0.f;
+            }
+            nST[v] = make_float4(a[0], a[1], a[2], a[3]);
+            nDT[v] = make_float4(b[0], b[1], b[2], b[3]);
+        }
+    };
+    auto stage = [&](int buf) {
+        FFNO_UNROLL
+        for (int v = 0; v < NV; ++v) {
+            const int f = tid + v * F::NT;
+            const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
+            stage4(lds[buf] + OFF_SP, F::PPLANE, offp, nSP[v].x, nSP[v].y, nSP[v].z, nSP[v].w);
+            stage4(lds[buf] + OFF_DP, F::PPLANE, offp, nDP[v].x, nDP[v].y, nDP[v].z, nDP[v].w);
+            // pixel group grp = (s2 << 2) | (q << 1) | half  <->  local pixels 16 s2 + 8 q + 4 half + i  <->  k slot 4 q + i
+            const int grp = tg + v * (F::NT / C);
+            const int pos = 16 * (grp & 1) + 8 * (grp >> 2) + 4 * ((grp >> 1) & 1);
+            const int offt = tc * F::TROW + 2 * pos;
+            stage4(lds[buf] + OFF_ST, F::TPLANE, offt, nST[v].x, nST[v].y, nST[v].z, nST[v].w);
+            stage4(lds[buf] + OFF_DT, F::TPLANE, offt, nDT[v].x, nDT[v].y, nDT[v].z, nDT[v].w);
+            bs2 += (nDT[v].x + nDT[v].y) + (nDT[v].z + nDT[v].w);
+        }
+    };
+
+    f32x16 acc1[CPW][CTO], acc2[CPW][CTO];
+    float bs1[CPW];
+    FFNO_UNROLL
+    for (int ch = 0; ch < CPW; ++ch) {
+        bs1[ch] = 0.f;
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) acc1[ch][mt] = zero16(), acc2[ch][mt] = zero16();
+    }
+
+    if ((int)blockIdx.x < ntiles) {
+        gload(blockIdx.x);
+        stage(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int nt = tile + gridDim.x;
+        if (nt < ntiles) gload(nt);
+        const char* L = lds[buf];
+        // h^T[px][hid] = relu(s W1^T + b1), pixels on the D rows
+        f32x16 d[CPW];
+        uint32_t bits = 0;
+        FFNO_UNROLL
+        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            const Bf3 a = lds_frag(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) d[ch] = mfma_x3(a, W1f[ch][st], d[ch]);
+        }
+        Bf3 hb[CPW][2];
+        FFNO_UNROLL
+        for (int ch = 0; ch < CPW; ++ch) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const float v = d[ch][r] + b1v[ch];
+                const bool pos = v > 0.f;
+                d[ch][r] = pos ? v : 0.f;
+                bits |= (pos ? 1u : 0u) << (16 * ch + r);
+            }
+            hb[ch][0] = split3_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
+            hb[ch][1] = split3_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+        }
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Bf3 a = lds_frag(L + OFF_DT, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
+                FFNO_UNROLL
+                for (int ch = 0; ch < CPW; ++ch) acc2[ch][mt] = mfma_x3(a, hb[ch][s2], acc2[ch][mt]);
+            }
+        }
+        // dh^T[px][hid] = (db W2) * [h > 0]
+        FFNO_UNROLL
+        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            const Bf3 a = lds_frag(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) d[ch] = mfma_x3(a, W2f[ch][st], d[ch]);
+        }
+        FFNO_UNROLL
+        for (int ch = 0; ch < CPW; ++ch) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                d[ch][r] = ((bits >> (16 * ch + r)) & 1u) ? d[ch][r] : 0.f;
+                bs1[ch] += d[ch][r];
+            }
+            hb[ch][0] = split3_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
+            hb[ch][1] = split3_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+        }
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Bf3 a = lds_frag(L + OFF_ST, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
+                FFNO_UNROLL
+                for (int ch = 0; ch < CPW; ++ch) acc1[ch][mt] = mfma_x3(a, hb[ch][s2], acc1[ch][mt]);
+            }
+        }
+        if (nt < ntiles) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* part = partial + (long)blockIdx.x * F::PART;
+    float* pW1t = part;              // [c][hid]
+    float* pW2 = part + H * C;       // [c][hid]
+    float* pb1 = part + 2 * H * C;
+    float* pb2 = pb1 + H;
+    FFNO_UNROLL
+    for (int ch = 0; ch < CPW; ++ch) {
+        const int hid = 32 * (wave * CPW + ch) + j;
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * mt + drow(r, half);
+                pW1t[c * H + hid] = acc1[ch][mt][r];
+                pW2[c * H + hid] = acc2[ch][mt][r];
+            }
+        }
+        const float v1 = bs1[ch] + __shfl_xor(bs1[ch], 32);
+        if (half == 0) pb1[hid] = v1;
+    }
+    red[tid] = bs2;
+    __syncthreads();
+    if (tid < C) {
+        float v = 0.f;
+        for (int k = tid; k < F::NT; k += C) v += red[k];
+        pb2[tid] = v;
+    }
+}
+
+// partial slices -> gradients; the dW1 block of a slice is [c][hid] (transposed)
+__global__ __launch_bounds__(256) void ffx_wgrad_reduce_kernel(const float* __restrict__ partial, float* dW1, float* dW2,
+                                                               float* db1, float* db2, int C, int H, int nsplit,
+                                                               int accumulate) {
+    __shared__ float red[4][64];
+    const int part = 2 * H * C + H + C;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    float sum = 0.f;
+    if (e < part) {
+        float t[8];
+        int sp = sg;
+        for (; sp + 28 < nsplit; sp += 32) {
+            FFNO_UNROLL
+            for (int u = 0; u < 8; ++u) t[u] = partial[(long)(sp + 4 * u) * part + e];
+            FFNO_UNROLL
+            for (int u = 0; u < 8; ++u) sum += t[u];
+        }
+        for (; sp < nsplit; sp += 4) sum += partial[(long)sp * part + e];
+    }
+    red[sg][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (sg == 0 && e < part) {
+        sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float* dst;
+        if (e < H * C)
+            dst = dW1 + (e % H) * C + e / H;
+        else if (e < 2 * H * C)
+            dst = dW2 + (e - H * C);
+        else if (e < 2 * H * C + H)
+            dst = db1 + (e - 2 * H * C);
+        else
+            dst = db2 + (e - 2 * H * C - H);
+        *dst = accumulate ? (*dst + sum) : sum;
+    }
+}
+
+static inline int ffx_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+static const int kFxBlocks = 256;   // persistent workgroups: one per CU
+
+}  // namespace ffno
+
+using namespace ffno;
+
+#define FFNO_FX_DISPATCH(MACRO) \
+    MACRO(64, 256)              \
+    MACRO(64, 128)              \
+    MACRO(32, 128)              \
+    MACRO(32, 64)
+
+extern "C" int ffno_ffx_supported(int C, int H) {
+#define CASE(CC, HH) \
+    if (C == CC && H == HH) return 1;
+    FFNO_FX_DISPATCH(CASE)
+#undef CASE
+    return 0;
+}
+
+extern "C" size_t ffno_ffx_pack_bytes(int C, int H) { return (size_t)C * H * 6; }
+
+extern "C" int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
+    if (!descs_dev || n <= 0) return FFNO_EINVAL;
+    if (!ffno_ffx_supported(C, H)) return FFNO_EUNSUPPORTED;
+    static_assert(sizeof(ffno_fxpack_desc) == sizeof(FxPackDesc), "descriptor layout");
+    const int threads = (C * H / 8);   // one thread per (fragment, lane): 8 weights each
+    FFNO_LAUNCH(ffx_pack_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+                reinterpret_cast<const FxPackDesc*>(descs_dev), C, H);
+    return ffx_launch_status();
+}
+
+extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
+                            const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
+    if (!s || !pk1 || !b1 || !pk2 || !b2 || !out || P <= 0) return FFNO_EINVAL;
+    const int ntiles = (P + 31) / 32;
+    const dim3 grid(min(kFxBlocks, ntiles));
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CC, HH)                                                                                                  \
+    if (C == CC && H == HH) {                                                                                         \
+        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, resid,                \
+                    (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, getenv("FFX_XY") ? atoi(getenv("FFX_XY")) : 0);                           \
+        return ffx_launch_status();                                                                                   \
+    }
+    FFNO_FX_DISPATCH(CASE)
+#undef CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds, int P,
+                                 int C, int H, void* stream) {
+    if (!db || !mask || !pk1b || !pk2b || !ds || P <= 0) return FFNO_EINVAL;
+    const int ntiles = (P + 31) / 32;
+    const dim3 grid(min(kFxBlocks, ntiles));
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CC, HH)                                                                                                  \
+    if (C == CC && H == HH) {                                                                                         \
+        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, nullptr,              \
+                    (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds, (uint32_t*)const_cast<void*>(mask), \
+                    P, getenv("FFX_XY") ? atoi(getenv("FFX_XY")) : 0);                                                                                               \
+        return ffx_launch_status();                                                                                   \
+    }
+    FFNO_FX_DISPATCH(CASE)
+#undef CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
+                                            const void* pk1b, float* partial, int P, int C, int H, int nsplit,
+                                            void* stream) {
+    if (!s || !db || !pk1 || !b1 || !pk1b || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define CASE(CC, HH)                                                                                               \
+    if (C == CC && H == HH) {                                                                                      \
+        FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,               \
+                    (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                        \
+        return ffx_launch_status();                                                                                \
+    }
+    FFNO_FX_DISPATCH(CASE)
+#undef CASE
+    return FFNO_EUNSUPPORTED;
+}
+
+extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,
+                                           int H, int nsplit, int accumulate, void* stream) {
+    if (!partial || !dW1 || !dW2 || !db1 || !db2 || nsplit <= 0) return FFNO_EINVAL;
+    const int part = 2 * H * C + H + C;
+    FFNO_LAUNCH(ffx_wgrad_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, dW1, dW2,
+                db1, db2, C, H, nsplit, accumulate);
+    return ffx_launch_status();
+}

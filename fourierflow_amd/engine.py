@@ -37,7 +37,7 @@ def _p(t: Optional[torch.Tensor]):
 
 
 class _Linear:
-    __slots__ = ("prefix", "rows", "cols", "wnorm", "weff", "gweff", "wt")
+    __slots__ = ("prefix", "rows", "cols", "wnorm", "weff", "gweff", "wt", "fx")
 
     def __init__(self, prefix, rows, cols, wnorm):
         self.prefix, self.rows, self.cols, self.wnorm = prefix, rows, cols, wnorm
@@ -153,11 +153,17 @@ class FFNOEngine:
         self._tw: Dict[int, torch.Tensor] = {}
         self._saved = None
         self.use_fused = True   # fused A->B->C branch kernel when (C, K, L) fits its LDS tile; else 3 stage kernels
+        # feed-forward on the bf16 matrix cores at fp32 accuracy (ffx.hip: split-bf16, no stored hidden activations)
+        # when the library has the (C, H) instance; False = the fp32-MFMA kernels of ff.hip
+        self.use_ffx = True
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         # backward: FF weight-gradient kernels on a side stream next to the spectral adjoint.  Measured on MI355X
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
         self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
+
+    def _ffx(self) -> bool:
+        return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
 
     def _k(self, name, fn, *args):
         """Enqueue one C-ABI call; with a timer attached, bracket it with HIP events on the launch stream."""
@@ -243,6 +249,28 @@ class FFNOEngine:
             lin.wt = self.wt_flat[toff:toff + n].view(lin.cols, lin.rows)
             toff += n
             tdescs.append(_capi.TrDesc(lin.weff.data_ptr(), lin.wt.data_ptr(), lin.rows, lin.cols))
+        # split-bf16 operand packs of every feed-forward block (include/ffno.h "packed"): forward A1/A2, backward A1/A2
+        lib = _lib.get_lib()
+        blocks = list(dict.fromkeys(self.ff_prefix + self.fc_prefix))
+        self._n_fx = 0
+        if lib.ffno_ffx_supported(self.C, self.H):
+            words = int(lib.ffno_ffx_pack_bytes(self.C, self.H)) // 4
+            if getattr(self, "_fx_flat", None) is None or self._fx_flat.numel() != 4 * words * len(blocks) \
+                    or self._fx_flat.device != self.device:
+                self._fx_flat = torch.empty(4 * words * len(blocks), dtype=torch.int32, device=self.device)
+            fdescs = []
+            for bi, pfx in enumerate(blocks):
+                l0, l1 = self.linears[pfx + "layers.0.0."], self.linears[pfx + "layers.1.0."]
+                pk = [self._fx_flat[(4 * bi + q) * words:(4 * bi + q + 1) * words] for q in range(4)]
+                l0.fx = pk      # both linears of the block see the four packs
+                l1.fx = pk
+                C_, H_ = self.C, self.H
+                for (src, sh, sc, ty), dst in zip(((l0.weff, C_, 1, 1), (l1.weff, 1, H_, 2), (l1.weff, 1, H_, 1),
+                                                   (l0.weff, C_, 1, 2)), pk):
+                    fdescs.append(_capi.FxPackDesc(src.data_ptr(), dst.data_ptr(), sh, sc, ty, 0))
+            self._n_fx = len(fdescs)
+            arr = (_capi.FxPackDesc * len(fdescs))(*fdescs)
+            self._fx_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
         self._n_tr = len(tdescs)
         arr = (_capi.TrDesc * len(tdescs))(*tdescs)
         self._tr_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
@@ -274,7 +302,7 @@ class FFNOEngine:
                 _View(B, X * Y, Z, 0, self.Ks[2], C)]       # z: contiguous lines (b, x, y)
 
     def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
-        key = (B, tuple(S), bool(save))
+        key = (B, tuple(S), bool(save), self._ffx())
         if self._ws_key == key:
             return self._ws
         lib = _lib.get_lib()
@@ -305,15 +333,15 @@ class FFNOEngine:
             ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
             ws.YL = torch.empty(L, P_in * O, **f32)             # per-layer head outputs (forecast_list)
         if save and self.use_fork:
-            ws.HF = torch.empty(ns, P, H, **f32)
+            ws.HF = torch.empty(ns, P, H, **f32) if not self._ffx() else [None] * ns
             ws.MASKF = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
             ws.DSF = torch.empty(P, C, **f32)
             ws.GF = torch.empty(P, C, **f32)
             ws.redl = torch.empty(O * (C + 1), **f32)
         if save:
-            ws.Hbuf = torch.empty(ns, P, H, **f32)
+            ws.Hbuf = torch.empty(ns, P, H, **f32) if not self._ffx() else [None] * ns
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
-            ws.DH = [torch.empty(P, H, **f32) for _ in range(2)]   # ping-pong (side-stream option)
+            ws.DH = [torch.empty(P, H, **f32) if not self._ffx() else None for _ in range(2)]   # ping-pong (side-stream option)
             ws.DS = torch.empty(P, C, **f32)
             ws.G = [torch.empty(P, C, **f32) for _ in range(2)]    # running gradient, ping-pong per layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
@@ -335,6 +363,8 @@ class FFNOEngine:
         self._refresh_pointers()
         if self._desc_dev is not None:
             self._k("weightnorm_fwd", lib.ffno_weightnorm_fwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
+        if self._ffx() and self._n_fx:
+            self._k("ffx_pack", lib.ffno_ffx_pack, _p(self._fx_dev), self._n_fx, self.C, self.H, st)
         for i, names in enumerate(self._fw_sets):
             for w, n in enumerate(names):
                 self._k("fw_pack", lib.ffno_fw_pack, _p(self.params[n]), _p(self.planes[i][w][0]), _p(self.planes[i][w][1]),
@@ -352,6 +382,39 @@ class FFNOEngine:
         fc = self.fc_prefix[l]
         l0, l1 = self.linears[fc + "layers.0.0."], self.linears[fc + "layers.1.0."]
         return l0, l1, self.params[fc + "layers.0.0.bias"], self.params[fc + "layers.1.0.bias"]
+
+    # ---- feed-forward dispatch: split-bf16 kernels (ffx.hip) or the fp32-MFMA kernels (ff.hip) ---------------------
+    def _ff_fwd(self, s, resid, l0, l1, b0, b1, out, hbuf, mask, P, st):
+        lib = _lib.get_lib()
+        if self._ffx():
+            self._k("ff_fwd", lib.ffno_ffx_fwd, _p(s), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out),
+                    _p(mask), P, self.C, self.H, st)
+        else:
+            self._k("ff_fwd", lib.ffno_ff_fwd, _p(s), _p(resid), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1), _p(out),
+                    _p(hbuf), _p(mask), P, self.C, self.H, st)
+
+    def _ff_bwd_data(self, g, mask, l0, l1, dh, ds, P, st):
+        lib = _lib.get_lib()
+        if self._ffx():
+            self._k("ff_bwd_data", lib.ffno_ffx_bwd_data, _p(g), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds), P,
+                    self.C, self.H, st)
+        else:
+            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(g), _p(mask), _p(l0.wt), _p(l1.wt), _p(dh), _p(ds), P,
+                    self.C, self.H, st)
+
+    def _ff_bwd_weights(self, ws, s, g, hbuf, dh, l0, l1, b0, gb0, gb1, accumulate, P, st):
+        lib = _lib.get_lib()
+        C, H = self.C, self.H
+        if self._ffx():
+            self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0),
+                    _p(l0.fx[2]), _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
+            self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
+                    _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
+        else:
+            self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(s), _p(g), _p(hbuf), _p(dh),
+                    _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
+            self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
+                    _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
 
     def _can_fuse(self, views) -> bool:
         lib = _lib.get_lib()
@@ -422,14 +485,12 @@ class FFNOEngine:
                                    self.planes[si][w][0] if full else None, True, int(w > 0), fused, st)
             l0, l1, b0, b1 = self._ff_weights(l)
             if not (self.use_fork and last):      # with fork heads the last layer's backcast only feeds the dead x_L
-                self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None if last else _p(ws.X), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1),
-                        _p(ws.Blast if last else ws.X), _p(ws.Hbuf[sv]) if save_for_backward else None,
-                        _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
+                self._ff_fwd(s_l, None if last else ws.X, l0, l1, b0, b1, ws.Blast if last else ws.X,
+                             ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st)
             if self.use_fork:
                 c0, c1, cb0, cb1 = self._fc_weights(l)
-                self._k("ff_fwd", lib.ffno_ff_fwd, _p(s_l), None, _p(c0.weff), _p(cb0), _p(c1.weff), _p(cb1), _p(ws.F[sv]),
-                        _p(ws.HF[sv]) if save_for_backward else None, _p(ws.MASKF[sv]) if save_for_backward else None,
-                        P, C, H, st)
+                self._ff_fwd(s_l, None, c0, c1, cb0, cb1, ws.F[sv], ws.HF[sv] if save_for_backward else None,
+                             ws.MASKF[sv] if save_for_backward else None, P, st)
                 self._k("head_fwd", lib.ffno_head_fwd, _p(ws.F[sv]), _p(self.fold), _p(ws.YL[l]), ws.P_in, C, self.O, 0, pm, st)
         if self.use_fork:
             torch.sum(ws.YL, dim=0, out=ws.Y)     # forecast = sum of the per-layer head outputs
@@ -486,7 +547,8 @@ class FFNOEngine:
                     ws.P_in, C, self.O, ws.nsplit_head, pm, st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
                 _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
-        self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
+        if not self._ffx():
+            self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
         for l in reversed(range(L)):
             last = l == L - 1
@@ -497,12 +559,9 @@ class FFNOEngine:
                 c0, c1, _, _ = self._fc_weights(l)
                 fc = self.fc_prefix[l]
                 ds_f = ws.DS if last else ws.DSF     # last layer: the forecast path is the only contribution to ds
-                self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(ws.GF), _p(ws.MASKF[l]), _p(c0.wt), _p(c1.wt), _p(dh), _p(ds_f),
-                        P, C, H, st)
-                self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(ws.GF), _p(ws.HF[l]), _p(dh),
-                        _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
-                self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(c0.gweff), _p(c1.gweff),
-                        _p(gv(fc + "layers.0.0.bias")), _p(gv(fc + "layers.1.0.bias")), C, H, ws.nsplit_ff, int(fc in ff_seen), st)
+                self._ff_bwd_data(ws.GF, ws.MASKF[l], c0, c1, dh, ds_f, P, st)
+                self._ff_bwd_weights(ws, ws.S[l], ws.GF, ws.HF[l], dh, c0, c1, self.params[fc + "layers.0.0.bias"],
+                                     gv(fc + "layers.0.0.bias"), gv(fc + "layers.1.0.bias"), int(fc in ff_seen), P, st)
                 ff_seen.add(fc)
             if self.use_fork and last:
                 # x_L is never used with fork heads: the last backcast_ff gets a zero gradient
@@ -522,16 +581,13 @@ class FFNOEngine:
                                        self.planes[si][w][1] if full else None, False, int(w > 0), fused, st)
                 cur = 1 - cur
                 continue
-            self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(g_in), _p(ws.MASK[l]), _p(l0.wt), _p(l1.wt), _p(dh), _p(ws.DS),
-                    P, C, H, st)
+            self._ff_bwd_data(g_in, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
             if use_side:
                 ev_a.record(main_obj)
                 side.wait_event(ev_a)
                 self._issue_stream = side
-            self._k("ff_bwd_weights_partial", lib.ffno_ff_bwd_weights_partial, _p(ws.S[l]), _p(g_in), _p(ws.Hbuf[l]), _p(dh),
-                    _p(ws.ffpart), P, C, H, ws.nsplit_ff, st_side)
-            self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
-                    _p(gv(fp + "layers.0.0.bias")), _p(gv(fp + "layers.1.0.bias")), C, H, ws.nsplit_ff, int(fp in ff_seen), st_side)
+            self._ff_bwd_weights(ws, ws.S[l], g_in, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
+                                 gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side)
             ff_seen.add(fp)
             if self.use_fork:
                 self._k("axpy", lib.ffno_axpy, _p(ws.DS), _p(ws.DSF), 1.0, P * C, st)     # ds = ds(backcast) + ds(forecast)

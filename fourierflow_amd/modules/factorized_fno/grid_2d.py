@@ -137,6 +137,9 @@ class FNOFactorized2DBlock(nn.Module):
             pass
         return [(n, named[n]) for n in eng.param_names]
 
+    def prepare_input(self, x):
+        return x
+
     def _engine_for(self, params):
         eng = self.engine()
         eng.bind({n: p.detach() for n, p in zip(eng.param_names, params)})

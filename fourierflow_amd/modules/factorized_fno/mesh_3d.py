@@ -114,8 +114,15 @@ class FNOFactorizedMesh3D(nn.Module):
         gz = torch.tensor(np.linspace(0, 1, Z), dtype=torch.float).reshape(1, 1, 1, Z, 1).repeat([B, X, Y, 1, 1])
         return torch.cat((gx, gy, gz), dim=-1).to(device)
 
+    def prepare_input(self, x):
+        """Append the linspace coordinate channels (mesh_3d.py:161-162): [B, X, Y, Z, input_dim - 3] -> [..., input_dim]."""
+        key = (tuple(x.shape[:4]), x.device)
+        if getattr(self, "_grid_key", None) != key:     # the grid only depends on the shape: build it once
+            self._grid, self._grid_key = self.get_grid(x.shape, x.device), key
+        return torch.cat((x, self._grid), dim=-1)
+
     def forward(self, x):
         _lib.require_device_tensor(x, "FNOFactorizedMesh3D input")
-        x = torch.cat((x, self.get_grid(x.shape, x.device)), dim=-1)   # [B, X, Y, Z, input_dim]
+        x = self.prepare_input(x)   # [B, X, Y, Z, input_dim]
         params = [p for _, p in self.engine_parameters()]
         return _Mesh3DFn.apply(x, self, *params)

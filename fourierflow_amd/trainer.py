@@ -35,12 +35,13 @@ def cosine_warmup_factor(step: int, num_warmup_steps: int, num_training_steps: i
 class FFNOTrainer:
     def __init__(self, block, *, lr: float = 2.5e-3, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  num_warmup_steps: int = 500, num_training_steps: int = 100000, num_cycles: float = 0.5,
-                 process_group=None, broadcast_from_rank0: bool = True):
+                 process_group=None, broadcast_from_rank0: bool = True, loss_scale: float = 1.0):
         self.block = block
         self.engine = block.engine()
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.sched = (num_warmup_steps, num_training_steps, num_cycles)
         self.step_count = 0
+        self.loss_scale = loss_scale   # StructuredMeshExperiment: gradients of loss * loss_scale (structured_mesh.py:29)
         self.pg = process_group
         self.world = 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -81,7 +82,7 @@ class FFNOTrainer:
         if self._gy is None or self._gy.shape != pred.shape:
             self._gy = torch.empty_like(pred)
             self._tmp = torch.empty(2 * B, dtype=torch.float32, device=pred.device)
-        _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(self.loss), _p(self._gy), _p(self._tmp), B, n, 1.0,
+        _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(self.loss), _p(self._gy), _p(self._tmp), B, n, float(self.loss_scale),
                                             _p(affine), _lib.current_stream(self.device)), "lploss")
         return self.loss, self._gy
 
@@ -89,7 +90,7 @@ class FFNOTrainer:
         """forward + relative-L2 loss + backward + (all-reduce) + AdamW + schedule; returns the loss (device)."""
         lib = _lib.get_lib()
         target = target.contiguous()
-        pred = self.engine.forward(x, True)
+        pred = self.engine.forward(self.block.prepare_input(x), True)
         loss, gy = self.loss_and_grad(pred, target)
         return self.apply_gradients(self.engine.backward(gy), loss)
 
@@ -107,4 +108,4 @@ class FFNOTrainer:
 
     @torch.no_grad()
     def predict(self, x: torch.Tensor) -> torch.Tensor:
-        return self.engine.forward(x, False)
+        return self.engine.forward(self.block.prepare_input(x), False)

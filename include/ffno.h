@@ -161,6 +161,45 @@ int ffno_ff_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, flo
                                int C, int H, int nsplit, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same feed-forward on the bf16 matrix cores at fp32 accuracy ("bf16x3": every fp32 operand cut
+ * exactly into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per product block).  Replaces the
+ * same reference lines as ffno_ff_* (feedforward.py:13-19 + grid_2d.py:169 and their autograd) and is
+ * the path the engine uses when ffno_ffx_supported(C, H); the hidden activations are never stored:
+ * the forward keeps the ReLU sign bits only and the weight-gradient kernel recomputes h and dh.
+ *
+ * Weights are consumed pre-split / pre-permuted ("packed", ffno_ffx_pack_bytes(C,H) bytes each):
+ *   type 1 (hidden rows on lanes)  and  type 2 (channel rows on lanes, k = hidden in D-fragment order)
+ *   of the matrix element  W(hid, c) = src[hid * sh + c * sc]:
+ *     forward      A1 = type1(W1: sh=C, sc=1)    A2 = type2(W2: sh=1, sc=H)
+ *     backward     A1 = type1(W2: sh=1, sc=H)    A2 = type2(W1: sh=C, sc=1)
+ *     weight grads use the two type-1 packs.
+ * ffno_ffx_pack runs a device-resident table of n descriptors in one launch.
+ * mask: ffno_ff_mask_words(P,H) uint32 words (layout private to the ffx kernels).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ffno_fxpack_desc {
+    const float* src; /* effective weight matrix */
+    void* dst;        /* ffno_ffx_pack_bytes(C,H) bytes, 16-B aligned */
+    int32_t sh, sc;   /* element strides of the hidden / channel index in src */
+    int32_t type;     /* 1 or 2 */
+    int32_t pad_;
+} ffno_fxpack_desc;
+int ffno_ffx_supported(int C, int H);
+size_t ffno_ffx_pack_bytes(int C, int H);
+int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
+int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
+                 const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+/* ds = ((db W2) * relu'(.)) W1 ; pk1b / pk2b = the backward packs */
+int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds,
+                      int P, int C, int H, void* stream);
+/* partial[s] = { dW1^T[C][H], dW2[C][H], db1[H], db2[C] } over the pixels of workgroup s (nsplit
+ * workgroups, ffno_ff_wgrad_partial_floats(C,H,nsplit) floats); pk1 = forward A1, pk1b = backward A1 */
+int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
+                                 const void* pk1b, float* partial, int P, int C, int H, int nsplit,
+                                 void* stream);
+int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2,
+                                int C, int H, int nsplit, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Weight normalisation (linear.py:48-49, torch.nn.utils.weight_norm dim=0), batched over a
  * device-resident descriptor table so one launch covers every linear of the block.
  *   fwd: w = g * v / ||v||_row          bwd: dg = sum_in dw*v/||v|| ; dv = g/||v|| (dw - dg v/||v||)

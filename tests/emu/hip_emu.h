@@ -57,6 +57,7 @@ static const int hipMemcpyDeviceToDevice = 3;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace emu {
 
@@ -69,6 +70,7 @@ struct Fiber {
 
 struct WaveX {  // per-wave exchange state (double-buffered by parity)
     float a[2][64], b[2][64];
+    unsigned xa[2][64][4], xb[2][64][4];   // 8 x bf16 per lane operands of the 32x32x16 forms
     int arrived;
     unsigned gen;
     int parity;
@@ -162,6 +164,38 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
         float acc = c[r];
         acc = fmaf(w.a[p][i], w.b[p][j], acc);            // k = 0
         acc = fmaf(w.a[p][i + 32], w.b[p][j + 32], acc);  // k = 1
+        d[r] = acc;
+    }
+    wave_exchange_done(p);
+    return d;
+}
+
+// v_mfma_f32_32x32x16_bf16: A[i = l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j = l&31] (8 bf16 per lane, element e
+// in bits [16*(e&1), +16) of word e>>1), D as the fp32 32x32 forms.  bf16 products are exact in fp32; the sum is
+// accumulated in fp32 (the hardware's internal summation order is not modelled -- parity tests carry a tolerance).
+inline f32x16 mfma_32x32x16_bf16(emu_u32x4 a, emu_u32x4 b, f32x16 c) {
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int p = w.parity;
+    for (int i = 0; i < 4; ++i) {
+        w.xa[p][lane][i] = a[i];
+        w.xb[p][lane][i] = b[i];
+    }
+    wave_barrier(w);
+    int j = lane & 31, half = lane >> 5;
+    auto bf = [](unsigned word, int e) {
+        unsigned u = (e & 1) ? (word & 0xffff0000u) : (word << 16);
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float acc = c[r];
+        for (int kh = 0; kh < 2; ++kh)
+            for (int e = 0; e < 8; ++e)
+                acc = fmaf(bf(w.xa[p][i + 32 * kh][e >> 1], e), bf(w.xb[p][j + 32 * kh][e >> 1], e), acc);
         d[r] = acc;
     }
     wave_exchange_done(p);

@@ -80,3 +80,28 @@ def test_mesh3d_baseline_config5_shape_on_gpu():
         sd, _ = ou.torch_state_dict(sd_np, torch.float32, requires_grad=False)
         ref = orc.ffno_mesh3d(sd, torch.from_numpy(x_np), modes=(8, 8, 8), n_layers=1)
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+def test_structured_mesh_routine_train_step(host_device):
+    """StructuredMeshExperiment (structured_mesh.py:21-31): model(x) -> LpLoss.rel -> manual optimisation; the loss
+    of the first step equals the oracle's, and training reduces it."""
+    import oracle_util as ou
+    from fourierflow_amd.modules import FNOFactorizedMesh3D
+    from fourierflow_amd.routines import StructuredMeshExperiment
+    kw = dict(modes_x=3, modes_y=2, modes_z=2, width=32, input_dim=4, output_dim=2, n_layers=2, share_weight=False,
+              factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)
+    seed, B, S = 9, 2, (5, 4, 3)
+    sd_np = gu.make_mesh3d_state_dict(kw, seed)
+    blk = FNOFactorizedMesh3D(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    exp = StructuredMeshExperiment(blk.to(host_device), scheduler=dict(num_warmup_steps=1, num_training_steps=20))
+    x_np, t_np = gu.make_mesh3d_io(kw, seed, B, S)
+    batch = dict(x=torch.from_numpy(x_np).to(host_device), y=torch.from_numpy(t_np).to(host_device))
+    sd, _ = ou.torch_state_dict(sd_np, requires_grad=False)
+    ref = orc.lp_rel_loss(orc.ffno_mesh3d(sd, torch.from_numpy(x_np), modes=(3, 2, 2), n_layers=2), torch.from_numpy(t_np))
+    l0 = exp.training_step(batch).item()
+    assert abs(l0 - ref.item()) < 1e-5
+    for _ in range(4):
+        l1 = exp.training_step(batch).item()
+    assert l1 < l0
+    assert abs(exp.validation_step(batch).item() - l1) < 0.2

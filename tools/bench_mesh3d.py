@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE.json configs[4]): training steps/s of the 3-D factorized operator
+`FNOFactorizedMesh3D` under `StructuredMeshExperiment` (reference routines/structured_mesh.py:21-31) on synthetic data.
+
+  python tools/bench_mesh3d.py --preset plasticity     # experiments/plasticity/ffno/12_layers/config.yaml shapes
+  python tools/bench_mesh3d.py --preset cube64         # BASELINE.json configs[4]: 64^3, modes 8, width 32
+
+Prints one JSON line; not the driver's bench contract (that is /bench.py, on configs[1]).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+PRESETS = {
+    # builder s1/s2/t = 101/31/20, batch 2 (config.yaml:11-19); model block of config.yaml:23-35
+    "plasticity": dict(size=(101, 31, 20), batch=2,
+                       model=dict(modes_x=32, modes_y=12, modes_z=8, width=64, input_dim=4, output_dim=4, n_layers=12,
+                                  share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
+    "cube64": dict(size=(64, 64, 64), batch=1,
+                   model=dict(modes_x=8, modes_y=8, modes_z=8, width=32, input_dim=4, output_dim=1, n_layers=12,
+                              share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="plasticity")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=0)
+    args = ap.parse_args()
+    from fourierflow_amd.modules import FNOFactorizedMesh3D
+    from fourierflow_amd.routines import StructuredMeshExperiment
+    ps = PRESETS[args.preset]
+    B = args.batch or ps["batch"]
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model = FNOFactorizedMesh3D(**ps["model"]).to(dev)
+    exp = StructuredMeshExperiment(model, optimizer=dict(lr=1e-3, weight_decay=1e-4),
+                                   scheduler=dict(num_warmup_steps=500, num_training_steps=82800))
+    g = torch.Generator().manual_seed(1)
+    batch = dict(x=torch.randn(B, *ps["size"], ps["model"]["input_dim"] - 3, generator=g).to(dev),
+                 y=torch.randn(B, *ps["size"], ps["model"]["output_dim"], generator=g).to(dev))
+    for _ in range(args.warmup):
+        exp.training_step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = exp.training_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    tr = exp.trainer()
+    for _ in range(2):
+        tr.predict(batch["x"])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.predict(batch["x"])
+    torch.cuda.synchronize()
+    df = (time.perf_counter() - t1) / args.steps
+    print(json.dumps({"metric": "training-steps/sec, FNOFactorizedMesh3D (%s)" % args.preset, "value": round(1 / dt, 2),
+                      "unit": "steps/s (batch %d)" % B, "ms_per_step": round(1e3 * dt, 3), "ms_per_forward": round(1e3 * df, 3),
+                      "dtype": "f32", "data": "synthetic N(0,1)", "final_loss": round(float(loss.item()), 5),
+                      "config": dict(workload="StructuredMeshExperiment train step", size=ps["size"], batch=B, **ps["model"]),
+                      "fused_spectral": bool(tr.engine.use_fused)}))
+
+
+if __name__ == "__main__":
+    main()
