@@ -71,6 +71,7 @@ SIGNATURES = {
     "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
     "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ffno_lploss_tmp_floats": (SZ, [I, I]),
     "ffno_lploss_fwd_bwd": (I, [P, P, P, P, P, I, I, F, P, P]),
     "ffno_markov_features": (I, [P, P, P, P, P, P, I, I, I, I, F, F, F, F, I, I, P]),
     "ffno_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, I, F, P]),

@@ -399,16 +399,20 @@ __global__ __launch_bounds__(256) void markov_features_kernel(const float* __res
 }
 
 // ---- relative L2 loss -----------------------------------------------------------------------------------
+// Two deterministic stages: block (slice, sample) -> partial sums tmp[(sample*S + slice)*2 + {0,1}]; every consumer adds
+// the S partials of a sample in the same order.
 __global__ __launch_bounds__(256) void lploss_reduce_kernel(const float* __restrict__ pred,
                                                             const float* __restrict__ target, float* tmp, int n,
                                                             const float* __restrict__ affine) {
     __shared__ float sd[4], sy[4];
-    const int bidx = blockIdx.x;
+    const int bidx = blockIdx.y, S = gridDim.x;
+    const int chunk = (n + S - 1) / S;
+    const int beg = blockIdx.x * chunk, end = min(n, beg + chunk);
     const float* p = pred + (long)bidx * n;
     const float* t = target + (long)bidx * n;
     const float sc = affine ? affine[0] : 1.f, sh = affine ? affine[1] : 0.f;   // pred * std + mean (Normalizer.inverse)
     float d2 = 0.f, y2 = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
         const float d = fmaf(p[i], sc, sh) - t[i];
         d2 = fmaf(d, d, d2);
         y2 = fmaf(t[i], t[i], y2);
@@ -421,24 +425,30 @@ __global__ __launch_bounds__(256) void lploss_reduce_kernel(const float* __restr
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        tmp[2 * bidx] = sd[0] + sd[1] + sd[2] + sd[3];
-        tmp[2 * bidx + 1] = sy[0] + sy[1] + sy[2] + sy[3];
+        tmp[2 * (bidx * S + blockIdx.x)] = sd[0] + sd[1] + sd[2] + sd[3];
+        tmp[2 * (bidx * S + blockIdx.x) + 1] = sy[0] + sy[1] + sy[2] + sy[3];
     }
 }
 
 __global__ __launch_bounds__(256) void lploss_grad_kernel(const float* __restrict__ pred,
                                                           const float* __restrict__ target,
                                                           const float* __restrict__ tmp, float* loss_out,
-                                                          float* gpred, int B, int n, float gscale,
+                                                          float* gpred, int B, int n, int S, float gscale,
                                                           const float* __restrict__ affine) {
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && loss_out) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += sqrtf(tmp[2 * b]) / sqrtf(tmp[2 * b + 1]);
+        for (int b = 0; b < B; ++b) {
+            float d2 = 0.f, y2 = 0.f;
+            for (int k = 0; k < S; ++k) d2 += tmp[2 * (b * S + k)], y2 += tmp[2 * (b * S + k) + 1];
+            s += sqrtf(d2) / sqrtf(y2);
+        }
         loss_out[0] = s / (float)B;
     }
     if (!gpred) return;
     const int bidx = blockIdx.y;
-    const float dn = sqrtf(tmp[2 * bidx]), yn = sqrtf(tmp[2 * bidx + 1]);
+    float d2 = 0.f, y2 = 0.f;
+    for (int k = 0; k < S; ++k) d2 += tmp[2 * (bidx * S + k)], y2 += tmp[2 * (bidx * S + k) + 1];
+    const float dn = sqrtf(d2), yn = sqrtf(y2);
     const float sc = affine ? affine[0] : 1.f, sh = affine ? affine[1] : 0.f;
     const float coef = dn > 0.f ? gscale * sc / ((float)B * dn * yn) : 0.f;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -608,17 +618,24 @@ extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const fl
     return pw_status();
 }
 
+static inline int lploss_slices(int n) { return max(1, min(64, (n + 8191) / 8192)); }
+
+extern "C" size_t ffno_lploss_tmp_floats(int B, int n_per_sample) {
+    return (size_t)2 * (size_t)B * (size_t)lploss_slices(n_per_sample);
+}
+
 extern "C" int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out, float* gpred,
                                    float* tmp, int B, int n_per_sample, float gscale, const float* affine,
                                    void* stream) {
     if (!pred || !target || !tmp || B <= 0 || n_per_sample <= 0) return FFNO_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    FFNO_LAUNCH(lploss_reduce_kernel, dim3(B), dim3(256), 0, s, pred, target, tmp, n_per_sample, affine);
+    const int S = lploss_slices(n_per_sample);
+    FFNO_LAUNCH(lploss_reduce_kernel, dim3(S, B), dim3(256), 0, s, pred, target, tmp, n_per_sample, affine);
     int rc = pw_status();
     if (rc) return rc;
     const int gx = max(1, min((n_per_sample + 255) / 256, 64));
     FFNO_LAUNCH(lploss_grad_kernel, dim3(gx, B), dim3(256), 0, s, pred, target, tmp, loss_out, gpred, B,
-                       n_per_sample, gscale, affine);
+                       n_per_sample, S, gscale, affine);
     return pw_status();
 }
 

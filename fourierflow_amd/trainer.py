@@ -81,7 +81,7 @@ class FFNOTrainer:
         n = pred.numel() // B
         if self._gy is None or self._gy.shape != pred.shape:
             self._gy = torch.empty_like(pred)
-            self._tmp = torch.empty(2 * B, dtype=torch.float32, device=pred.device)
+            self._tmp = torch.empty(int(lib.ffno_lploss_tmp_floats(B, n)), dtype=torch.float32, device=pred.device)
         _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(self.loss), _p(self._gy), _p(self._tmp), B, n, float(self.loss_scale),
                                             _p(affine), _lib.current_stream(self.device)), "lploss")
         return self.loss, self._gy

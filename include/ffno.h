@@ -269,8 +269,10 @@ int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, co
 /* ---------------------------------------------------------------------------------------------
  * Relative-L2 loss (loss.py:33-46) and its gradient:
  *   loss = mean_b ||pred_b - y_b||_2 / ||y_b||_2 ;  gpred = dloss/dpred * gscale
- * per-sample work buffer `tmp` needs 2*B floats.  loss is written to loss_out[0].
+ * work buffer `tmp`: ffno_lploss_tmp_floats(B, n_per_sample) floats (two-stage deterministic reduction,
+ * up to 64 slices per sample).  loss is written to loss_out[0].
  * --------------------------------------------------------------------------------------------- */
+size_t ffno_lploss_tmp_floats(int B, int n_per_sample);
 /* affine (optional, device float[2] = {scale, shift}): the loss is taken on pred*scale + shift, i.e. the
  * Normalizer.inverse(channel=0) of grid_2d_markov.py:185 fused in (scale = std[0], shift = mean[0]). */
 int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out, float* gpred,

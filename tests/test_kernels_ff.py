@@ -234,14 +234,16 @@ def test_head(be, P, C):
     assert abs(be.get(gcb)[0] - S) < 1e-4
 
 
-def test_lploss_and_adamw_and_axpy(be):
+@pytest.mark.parametrize("B,n", [(3, 500), (2, 20000)])     # one slice per sample / several (two-stage reduction)
+def test_lploss(be, B, n):
     import torch
     lib, p = be.lib, be.ptr
     rs = np.random.RandomState(9)
-    B, n = 3, 500
     pred = rs.standard_normal((B, n)).astype(np.float32)
     tgt = rs.standard_normal((B, n)).astype(np.float32)
-    dpred, dtgt, loss, gp, tmp = be.put(pred), be.put(tgt), be.zeros(1), be.zeros((B, n)), be.zeros(2 * B)
+    ntmp = lib.ffno_lploss_tmp_floats(B, n)
+    assert ntmp == 2 * B * max(1, min(64, (n + 8191) // 8192))
+    dpred, dtgt, loss, gp, tmp = be.put(pred), be.put(tgt), be.zeros(1), be.zeros((B, n)), be.zeros(ntmp)
     assert lib.ffno_lploss_fwd_bwd(p(dpred), p(dtgt), p(loss), p(gp), p(tmp), B, n, 1.0, None, None) == 0
     pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)
     tt = torch.tensor(tgt, dtype=torch.float64)
@@ -249,6 +251,12 @@ def test_lploss_and_adamw_and_axpy(be):
     l.backward()
     assert abs(be.get(loss)[0] - l.item()) < 1e-6
     assert rel_l2(be.get(gp), pt.grad.numpy()) < TOL
+
+
+def test_adamw_and_axpy(be):
+    import torch
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(9)
     # AdamW vs torch.optim.AdamW
     n = 1000
     p0 = rs.standard_normal(n).astype(np.float32)

@@ -24,6 +24,7 @@ for st in $STAGES; do
       rm -rf gpurun_out/prof
       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o ffno -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-steps 0 > "$OLDPWD/gpurun_out/prof.log" 2>&1)
       echo "[session] rocprof rc=$?"; tail -n 2 gpurun_out/prof.log
+      db=$(find gpurun_out/prof -name "*.db" | head -1); python tools/rocpd_stats.py "$db" 7 > gpurun_out/kernel_stats.md 2>&1; head -n 24 gpurun_out/kernel_stats.md | cut -c1-170
       find gpurun_out/prof -name "*kernel_stats*" | head -3
       f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1)
       [ -n "$f" ] && head -n 25 "$f" | cut -c1-200
@@ -90,6 +91,9 @@ PY
         (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/gpurun_out/pmc_$c" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 > "$OLDPWD/gpurun_out/pmc_$c.log" 2>&1)
         echo "[session] pmc $c rc=$?"
       done
-      ls -la gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE ;;
+      f=$(find gpurun_out/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find gpurun_out/pmc_WRITE_SIZE -name "*.db" | head -1)
+      python tools/rocpd_pmc.py "$f" > gpurun_out/pmc_FETCH_SIZE.md; python tools/rocpd_pmc.py "$w" > gpurun_out/pmc_WRITE_SIZE.md
+      (cd tools && python make_pmc_traffic.py "../$f" "../$w") > gpurun_out/pmc_traffic.json; head -c 600 gpurun_out/pmc_traffic.json
+      find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.db" -size +20M -delete ;;
   esac
 done

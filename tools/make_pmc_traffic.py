@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the two rocprofv3 PMC passes of the bench (tools/gpu_session.sh pmc):
+usage: tools/make_pmc_traffic.py FETCH.db WRITE.db > profiles/pmc_traffic.json
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE x2 = the gfx950 correction of
+MI355X_MICROARCH.md, calibrated on adamw_kernel: it reads p, g, m, v = 4 x n floats and writes 3 x n)."""
+import json
+import sys
+
+from rocpd_pmc import per_kernel
+
+NAMES = [("spectral_fused_kernel", "spectral_fused"), ("ffx_chain_kernel<64, 256, false>", "ff_fwd"),
+         ("ffx_chain_kernel<64, 256, true>", "ff_bwd_data"), ("ffx_wgrad_kernel", "ff_bwd_weights_partial"),
+         ("ffx_wgrad_reduce_kernel", "ff_bwd_weights_reduce"), ("ff_chain_kernel<64, 256, 8, false>", "ff_fwd"),
+         ("ff_chain_kernel<64, 256, 8, true>", "ff_bwd_data"), ("ff_bwd_weights_partial_kernel", "ff_bwd_weights_partial"),
+         ("fw_grad_partial_kernel", "fw_grad_partial"), ("fw_grad_reduce_kernel", "fw_grad_reduce"),
+         ("adamw_kernel", "adamw"), ("ffx_pack_kernel", "ffx_pack")]
+
+
+def short(kernel):
+    for pat, name in NAMES:
+        if pat in kernel:
+            return name
+    return None
+
+
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+out = {}
+for k, (_, n, avg, _, _) in fetch.items():
+    name = short(k)
+    if name is None or k not in write or name in out:
+        continue
+    w = write[k][2]
+    out[name] = dict(fetch_kib_raw=round(avg, 1), write_kib=round(w, 1), hbm_bytes_per_launch=int((2 * avg + w) * 1024),
+                     launches_sampled=n, symbol=k)
+print(json.dumps(dict(workload="markov/24 B=32 64x64 fp32 (bench.py defaults)",
+                      method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
+                             "(2*FETCH_SIZE + WRITE_SIZE)*1024; the x2 on FETCH_SIZE is the gfx950 correction of "
+                             "MI355X_MICROARCH.md, confirmed on adamw_kernel; WRITE_SIZE reads exact",
+                      kernels=out), indent=1))
