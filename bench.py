@@ -72,7 +72,8 @@ class KernelTimer:
         return out
 
 
-FFX_KERNELS = ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial")
+FFX_KERNELS = ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial")   # on the split-bf16 path when engine._ffx()
+X3_ALWAYS = ("fw_grad_partial",)                                   # split-bf16 unconditionally
 
 
 def algorithmic_work(P, C, H, K, B, M, N, L):
@@ -261,7 +262,7 @@ def main():
         for n, srow in ksum.items():
             w = work[n]
             us = srow["avg_us"]
-            mpeak = BF16X3_PEAK_TFLOPS if (n in FFX_KERNELS and trainer.engine._ffx()) else FP32_MFMA_PEAK_TFLOPS
+            mpeak = BF16X3_PEAK_TFLOPS if ((n in FFX_KERNELS and trainer.engine._ffx()) or n in X3_ALWAYS) else FP32_MFMA_PEAK_TFLOPS
             kernels[n] = dict(avg_us=round(us, 2), per_step=w["per_step"], ms_per_step=round(us * w["per_step"] * 1e-3, 3),
                               tflops=round(w["flops"] / us * 1e-6, 2), gbs=round(w["bytes"] / us * 1e-3, 1),
                               mfma_peak_tflops=round(mpeak, 1), frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3),

@@ -613,92 +613,112 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
 }
 
 // ---- Fourier weight gradient ----------------------------------------------------------------------
-// Block = (mode k, line slice); wave w -> (part = real/imag of dW, a = 32-row tile of the input channel i).
+// Block = (mode k, line slice).
 //   dWr[i][o] = sum_r Xr[r][i] dYr[r][o] + Xi[r][i] dYi[r][o]
 //   dWi[i][o] = sum_r Xr[r][i] dYi[r][o] - Xi[r][i] dYr[r][o]
 // The contraction index r runs over the R lines of `nlayers` layers (virtual row v = layer*R + line), so a
 // weight tensor shared by all layers gets its whole gradient from ONE launch at the end of the backward
-// pass instead of a read-modify-write of the partials per layer.  Operand rows for trip i+1 are requested
-// before trip i's MFMAs (two statically indexed register buffers).
+// pass instead of a read-modify-write of the partials per layer.
+//
+// Evaluated on the bf16 matrix cores at fp32 accuracy (ffno_device.h "split-bf16": both operands cut exactly
+// into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per product).  Wave (grp, a): a = 32-row tile of the input
+// channel i, grp = one of two k-groups that take alternate 16-row steps of the contraction (combined through LDS at the
+// end).  A wave keeps BOTH parts of dW for its rows (4*CT accumulators), so every loaded spectrum element is split
+// once and used in CT (X) / 2 (dY) products: per 16-row step 8*CT products = 48*CT MFMAs against 16 + 16*CT split
+// fragments-of-8 -- matrix bound, and in fp32-equivalent FLOP/s 2.7x the fp32 MFMA ceiling, i.e. HBM-bound in practice.
 template <int C>
-__global__ __launch_bounds__(C * 4) void fw_grad_partial_kernel(const float* __restrict__ xs,
-                                                                 const float* __restrict__ dys,
-                                                                 float* __restrict__ partial, int R, int K,
-                                                                 int chunk, int beta, int nlayers, long stride_x,
-                                                                 long stride_dy) {
+__global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restrict__ xs, const float* __restrict__ dys,
+                                                           float* __restrict__ partial, int R, int K, int chunk,
+                                                           int beta, int nlayers, long stride_x, long stride_dy) {
     constexpr int CT = C / 32;
-    constexpr int UN = 4;
+    __shared__ float comb[CT * 64 * (4 * CT * 16)];
     const int k = blockIdx.y, split = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int part = wave / CT, a = wave % CT;
+    const int grp = wave / CT, a = wave % CT;
     const long vtot = (long)nlayers * R;
     const long vbeg = (long)split * chunk;
     const long vend = min(vtot, vbeg + chunk);
     const float* xk = xs + (long)k * R * 2 * C;
     const float* dk = dys + (long)k * R * 2 * C;
 
-    f32x16 acc[CT];
+    f32x16 accr[CT], acci[CT];
     FFNO_UNROLL
-    for (int b = 0; b < CT; ++b) acc[b] = zero16();
-    const int nsteps = (int)((max(vend - vbeg, 0L) + 1) >> 1);
-    const int ntrips = (nsteps + UN - 1) / UN;
+    for (int b = 0; b < CT; ++b) accr[b] = zero16(), acci[b] = zero16();
 
-    struct Frag {
-        float xr[UN], xi[UN], dyr[UN][CT], dyi[UN][CT];
-    };
-    Frag f0, f1;
-    auto load = [&](Frag& f, int trip) {
+    // raw rows of one 16-row step: this lane's 8 rows v0 + e of  Xr/Xi[.][32a + j]  and  dYr/dYi[.][32b + j]
+    float rxr[8], rxi[8], rdr[CT][8], rdi[CT][8];
+    auto load = [&](int t) {
+        const long v0 = vbeg + 16 * (long)t + 8 * half;
+        const long l0 = v0 / R;
+        const long row0 = v0 - l0 * R;
         FFNO_UNROLL
-        for (int u = 0; u < UN; ++u) {
-            const long v = vbeg + 2 * ((long)trip * UN + u) + half;
-            f.xr[u] = f.xi[u] = 0.f;
-            FFNO_UNROLL
-            for (int b = 0; b < CT; ++b) f.dyr[u][b] = f.dyi[u][b] = 0.f;
-            if (v < vend) {
-                const long l = v / R, row = v - l * R;
-                const float* xrow = xk + l * stride_x + row * 2 * C;
-                const float* drow_ = dk + l * stride_dy + row * 2 * C;
-                f.xr[u] = xrow[32 * a + j];
-                f.xi[u] = xrow[C + 32 * a + j];
-                FFNO_UNROLL
-                for (int b = 0; b < CT; ++b) {
-                    f.dyr[u][b] = drow_[32 * b + j];
-                    f.dyi[u][b] = drow_[C + 32 * b + j];
-                }
+        for (int e = 0; e < 8; ++e) {
+            long l = l0, row = row0 + e;
+            if (row >= R) {   // the step straddles a layer boundary (R not a multiple of 16)
+                l = (v0 + e) / R;
+                row = (v0 + e) - l * R;
             }
-        }
-    };
-    auto compute = [&](const Frag& f) {
-        FFNO_UNROLL
-        for (int u = 0; u < UN; ++u) {
+            const bool ok = v0 + e < vend;
+            const float* xrow = xk + l * stride_x + row * 2 * C;
+            const float* yrow = dk + l * stride_dy + row * 2 * C;
+            rxr[e] = ok ? xrow[32 * a + j] : 0.f;
+            rxi[e] = ok ? xrow[C + 32 * a + j] : 0.f;
             FFNO_UNROLL
             for (int b = 0; b < CT; ++b) {
-                if (part == 0) {
-                    acc[b] = mfma32(f.xr[u], f.dyr[u][b], acc[b]);
-                    acc[b] = mfma32(f.xi[u], f.dyi[u][b], acc[b]);
-                } else {
-                    acc[b] = mfma32(f.xr[u], f.dyi[u][b], acc[b]);
-                    acc[b] = mfma32(-f.xi[u], f.dyr[u][b], acc[b]);
-                }
+                rdr[b][e] = ok ? yrow[32 * b + j] : 0.f;
+                rdi[b][e] = ok ? yrow[C + 32 * b + j] : 0.f;
             }
         }
     };
-    if (ntrips > 0) load(f0, 0);
-    for (int trip = 0; trip < ntrips; trip += 2) {
-        load(f1, trip + 1);       // past-the-end trips load zeros (predicated)
-        compute(f0);
-        load(f0, trip + 2);
-        compute(f1);
-    }
-    float* pout = partial + (((long)split * K + k) * 2 + part) * C * C;
-    FFNO_UNROLL
-    for (int b = 0; b < CT; ++b) {
+    const int nsteps = (int)((max(vend - vbeg, 0L) + 15) >> 4);
+    if (grp < nsteps) load(grp);
+    for (int t = grp; t < nsteps; t += 2) {
+        const Bf3 xr = split3_8(rxr[0], rxr[1], rxr[2], rxr[3], rxr[4], rxr[5], rxr[6], rxr[7]);
+        const Bf3 xi = split3_8(rxi[0], rxi[1], rxi[2], rxi[3], rxi[4], rxi[5], rxi[6], rxi[7]);
+        Bf3 nxi;   // -Xi: flip the sign bit of every bf16
+        nxi.hi = xi.hi ^ 0x80008000u, nxi.mid = xi.mid ^ 0x80008000u, nxi.lo = xi.lo ^ 0x80008000u;
+        Bf3 dr[CT], di[CT];
         FFNO_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const int i = 32 * a + drow(r, half);
-            float* p = pout + (long)i * C + 32 * b + j;
-            *p = beta ? (*p + acc[b][r]) : acc[b][r];
+        for (int b = 0; b < CT; ++b) {
+            dr[b] = split3_8(rdr[b][0], rdr[b][1], rdr[b][2], rdr[b][3], rdr[b][4], rdr[b][5], rdr[b][6], rdr[b][7]);
+            di[b] = split3_8(rdi[b][0], rdi[b][1], rdi[b][2], rdi[b][3], rdi[b][4], rdi[b][5], rdi[b][6], rdi[b][7]);
+        }
+        if (t + 2 < nsteps) load(t + 2);   // the next step's rows arrive under this step's MFMAs
+        FFNO_UNROLL
+        for (int b = 0; b < CT; ++b) {
+            accr[b] = mfma_x3(xr, dr[b], accr[b]);
+            acci[b] = mfma_x3(xr, di[b], acci[b]);
+            accr[b] = mfma_x3(xi, di[b], accr[b]);
+            acci[b] = mfma_x3(nxi, dr[b], acci[b]);
+        }
+    }
+    // combine the two k-groups (group 1 -> LDS -> group 0); consecutive lanes -> consecutive floats
+    const int slot = a * 64 + lane;
+    if (grp == 1) {
+        FFNO_UNROLL
+        for (int b = 0; b < CT; ++b) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                comb[((b * 2 + 0) * 16 + r) * (CT * 64) + slot] = accr[b][r];
+                comb[((b * 2 + 1) * 16 + r) * (CT * 64) + slot] = acci[b][r];
+            }
+        }
+    }
+    __syncthreads();
+    if (grp == 0) {
+        FFNO_UNROLL
+        for (int b = 0; b < CT; ++b) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * a + drow(r, half);
+                const float vr = accr[b][r] + comb[((b * 2 + 0) * 16 + r) * (CT * 64) + slot];
+                const float vi = acci[b][r] + comb[((b * 2 + 1) * 16 + r) * (CT * 64) + slot];
+                float* pr = partial + (((long)split * K + k) * 2 + 0) * C * C + (long)i * C + 32 * b + j;
+                float* pi = pr + (long)C * C;
+                *pr = beta ? (*pr + vr) : vr;
+                *pi = beta ? (*pi + vi) : vi;
+            }
         }
     }
 }
@@ -814,10 +834,10 @@ extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, f
     const dim3 grid(nsplit, K), block(C * 4);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((fw_grad_partial_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
+        FFNO_LAUNCH((fw_grad_x3_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
                     nlayers, (long)layer_stride_x, (long)layer_stride_dy);
     else
-        FFNO_LAUNCH((fw_grad_partial_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
+        FFNO_LAUNCH((fw_grad_x3_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
                     nlayers, (long)layer_stride_x, (long)layer_stride_dy);
     return launch_status();
 }
