@@ -62,6 +62,8 @@ class FFNOEngine:
 
     spatial_dims = 2: FNOFactorized2DBlock -- fourier_weight[0] mixes the LAST axis, [1] the first
                       (grid_2d.py:68,86); no padding; one output channel.
+                      (``first_axis_first``: FNOFactorizedMesh2D -- [0] mixes x, [1] mixes y (mesh_2d.py:71-75,92-96), +8
+                      zero padding like the 3-D operator (mesh_2d.py:150,158)).
     spatial_dims = 3: FNOFactorizedMesh3D -- fourier_weight[0,1,2] mix x, y, z (mesh_3d.py:71,86,101);
                       activations zero-padded by ``padding`` at the end of every axis after the lift and
                       cropped before the head (mesh_3d.py:165,173); ``output_dim`` outputs.
@@ -69,7 +71,7 @@ class FFNOEngine:
 
     def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
                  share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
-                 padding: int = 0, output_dim: int = 1, use_fork: bool = False):
+                 padding: int = 0, output_dim: int = 1, use_fork: bool = False, first_axis_first: bool = False):
         if mode not in MODES:
             raise ValueError(f"mode must be one of {list(MODES)}, got {mode!r}")
         if spatial_dims not in (2, 3):
@@ -82,6 +84,8 @@ class FFNOEngine:
         if not (1 <= output_dim <= 8):
             raise ValueError("output_dim must be in 1..8")
         self.nd = spatial_dims
+        # 2-D weight order: grid_2d.py has fourier_weight[0] on the LAST axis; mesh_2d.py has [0] on the FIRST (x) axis
+        self.first_axis_first = bool(first_axis_first)
         self.Ks: Tuple[int, ...] = tuple(modes) if isinstance(modes, (tuple, list)) else (int(modes),) * spatial_dims
         if len(self.Ks) != spatial_dims:
             raise ValueError("one mode count per spatial axis")
@@ -295,6 +299,8 @@ class FFNOEngine:
         C = self.C
         if self.nd == 2:
             M, N = Sp
+            if self.first_axis_first:      # mesh_2d.py:71-75,92-96: weight 0 <-> x (first axis), weight 1 <-> y (last axis)
+                return [_View(B, M, N, 1, self.Ks[0], C), _View(B, M, N, 0, self.Ks[1], C)]
             return [_View(B, M, N, 0, self.Ks[0], C), _View(B, M, N, 1, self.Ks[1], C)]
         X, Y, Z = Sp
         return [_View(B, X, Y * Z, 1, self.Ks[0], C),       # x: lines (b, y, z), stride Y*Z*C

@@ -254,6 +254,36 @@ def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, paddi
 
 
 # --------------------------------------------------------------------------
+# FNOFactorizedMesh2D  (factorized_fno/mesh_2d.py:56-106 forward_fourier, :146-175 forward)
+# NOTE the weight order differs from grid_2d.py: here fourier_weight[0] mixes the FIRST spatial axis (x, modes_x)
+# and fourier_weight[1] the LAST (y, modes_y) -- mesh_2d.py:71-75,92-96.
+# --------------------------------------------------------------------------
+def mesh2d_grid(shape, dtype) -> Tensor:
+    """linspace(0,1) coordinate channels (mesh_2d.py:167-175)."""
+    B, X, Y = shape[0], shape[1], shape[2]
+    gx = torch.linspace(0, 1, X, dtype=torch.float64).to(dtype).reshape(1, X, 1, 1).expand(B, X, Y, 1)
+    gy = torch.linspace(0, 1, Y, dtype=torch.float64).to(dtype).reshape(1, 1, Y, 1).expand(B, X, Y, 1)
+    return torch.cat((gx, gy), dim=-1)
+
+
+def ffno_mesh2d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, padding: int = 8) -> Tensor:
+    """x [B, X, Y, input_dim - 2] -> [B, X, Y, 1] (mesh_2d.py:146-165); modes = (modes_x, modes_y)."""
+    x = torch.cat((x, mesh2d_grid(x.shape, x.dtype)), dim=-1)
+    x = linear_from_sd(sd, "in_proj.", x)
+    x = F.pad(x.permute(0, 3, 1, 2), [0, padding, 0, padding]).permute(0, 2, 3, 1)
+    b = None
+    for i in range(n_layers):
+        pre = f"spectral_layers.{i}."
+        x_cf = x.permute(0, 3, 1, 2)
+        s = (spectral_branch(x_cf, sd[pre + "fourier_weight.1"], modes[1], dim=-1, mode="full") +
+             spectral_branch(x_cf, sd[pre + "fourier_weight.0"], modes[0], dim=-2, mode="full")).permute(0, 2, 3, 1)
+        b = feedforward(sd, pre + "backcast_ff.", s)
+        x = x + b
+    b = b[:, :-padding, :-padding, :]
+    return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", b))
+
+
+# --------------------------------------------------------------------------
 # FNOZongyi2DBlock  (zongyi_fno/grid_2d.py:16-129) -- BASELINE config 0, CPU plumbing case.
 # The non-factorized baseline: full rfft2, two corner blocks of modes x modes weights, irfft2,
 # + Linear residual + ReLU.  (Reference quirk kept: irfft2 is called with s=(N, M), grid_2d.py:68.)

@@ -124,6 +124,40 @@ def make_mesh3d_state_dict(kw: dict, seed: int) -> Dict[str, np.ndarray]:
     return sd
 
 
+def make_mesh2d_state_dict(kw: dict, seed: int) -> Dict[str, np.ndarray]:
+    """Reference-layout state_dict for FNOFactorizedMesh2D(**kw) (mesh_2d.py:109-144): fourier_weight [x, y]."""
+    rs = np.random.RandomState(seed)
+    C, wn, f = kw["width"], kw["ff_weight_norm"], kw["factor"]
+    Ks = (kw["modes_x"], kw["modes_y"])
+    sd: Dict[str, np.ndarray] = {}
+    _linear(rs, sd, "in_proj.", kw["input_dim"], C, wn)
+
+    def fourier_pair():
+        return [(rs.standard_normal((C, C, K, 2)) * math.sqrt(2.0 / (2 * C * K * 2))).astype(np.float32) for K in Ks]
+
+    shared = fourier_pair() if kw["share_weight"] else None
+    if shared is not None:
+        for w in range(2):
+            sd[f"fourier_weight.{w}"] = shared[w]
+    for i in range(kw["n_layers"]):
+        pre = f"spectral_layers.{i}."
+        fw = shared if shared is not None else fourier_pair()
+        for w in range(2):
+            sd[pre + f"fourier_weight.{w}"] = fw[w]
+        for k, v in _ff(rs, C, f, wn, 2, False).items():
+            sd[pre + "backcast_ff." + k] = v
+    _linear(rs, sd, "out.0.", C, 128, wn)
+    _linear(rs, sd, "out.1.", 128, 1, wn)
+    return sd
+
+
+def make_mesh2d_io(kw: dict, seed: int, B: int, S):
+    rs = np.random.RandomState(seed + 300007)
+    x = rs.standard_normal((B, *S, kw["input_dim"] - 2)).astype(np.float32)
+    target = rs.standard_normal((B, *S, 1)).astype(np.float32)
+    return x, target
+
+
 def make_mesh3d_io(kw: dict, seed: int, B: int, S):
     rs = np.random.RandomState(seed + 200003)
     x = rs.standard_normal((B, *S, kw["input_dim"] - 3)).astype(np.float32)

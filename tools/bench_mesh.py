@@ -2,8 +2,9 @@
 """Secondary benchmark (BASELINE.json configs[4]): training steps/s of the 3-D factorized operator
 `FNOFactorizedMesh3D` under `StructuredMeshExperiment` (reference routines/structured_mesh.py:21-31) on synthetic data.
 
-  python tools/bench_mesh3d.py --preset plasticity     # experiments/plasticity/ffno/12_layers/config.yaml shapes
-  python tools/bench_mesh3d.py --preset cube64         # BASELINE.json configs[4]: 64^3, modes 8, width 32
+  python tools/bench_mesh.py --preset plasticity     # experiments/plasticity/ffno/12_layers/config.yaml shapes
+  python tools/bench_mesh.py --preset cube64         # BASELINE.json configs[4]: 64^3, modes 8, width 32
+  python tools/bench_mesh.py --preset airfoil        # experiments/airfoil/ffno/24_layers (FNOFactorizedMesh2D)
 
 Prints one JSON line; not the driver's bench contract (that is /bench.py, on configs[1]).
 """
@@ -18,6 +19,10 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 PRESETS = {
+    # experiments/airfoil/ffno/24_layers/config.yaml: 221 x 51 C-grid, batch 10, FNOFactorizedMesh2D
+    "airfoil": dict(size=(221, 51), batch=10, cls="FNOFactorizedMesh2D",
+                    model=dict(modes_x=32, modes_y=16, width=64, input_dim=4, n_layers=24, share_weight=False, factor=4,
+                               ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
     # builder s1/s2/t = 101/31/20, batch 2 (config.yaml:11-19); model block of config.yaml:23-35
     "plasticity": dict(size=(101, 31, 20), batch=2,
                        model=dict(modes_x=32, modes_y=12, modes_z=8, width=64, input_dim=4, output_dim=4, n_layers=12,
@@ -35,18 +40,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0)
     args = ap.parse_args()
-    from fourierflow_amd.modules import FNOFactorizedMesh3D
+    from fourierflow_amd import modules
     from fourierflow_amd.routines import StructuredMeshExperiment
     ps = PRESETS[args.preset]
+    cls = getattr(modules, ps.get("cls", "FNOFactorizedMesh3D"))
     B = args.batch or ps["batch"]
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    model = FNOFactorizedMesh3D(**ps["model"]).to(dev)
+    model = cls(**ps["model"]).to(dev)
     exp = StructuredMeshExperiment(model, optimizer=dict(lr=1e-3, weight_decay=1e-4),
                                    scheduler=dict(num_warmup_steps=500, num_training_steps=82800))
     g = torch.Generator().manual_seed(1)
-    batch = dict(x=torch.randn(B, *ps["size"], ps["model"]["input_dim"] - 3, generator=g).to(dev),
-                 y=torch.randn(B, *ps["size"], ps["model"]["output_dim"], generator=g).to(dev))
+    nd = len(ps["size"])
+    batch = dict(x=torch.randn(B, *ps["size"], ps["model"]["input_dim"] - nd, generator=g).to(dev),
+                 y=torch.randn(B, *ps["size"], ps["model"].get("output_dim", 1), generator=g).to(dev))
     for _ in range(args.warmup):
         exp.training_step(batch)
     torch.cuda.synchronize()
@@ -64,7 +71,7 @@ def main():
         tr.predict(batch["x"])
     torch.cuda.synchronize()
     df = (time.perf_counter() - t1) / args.steps
-    print(json.dumps({"metric": "training-steps/sec, FNOFactorizedMesh3D (%s)" % args.preset, "value": round(1 / dt, 2),
+    print(json.dumps({"metric": "training-steps/sec, %s (%s)" % (cls.__name__, args.preset), "value": round(1 / dt, 2),
                       "unit": "steps/s (batch %d)" % B, "ms_per_step": round(1e3 * dt, 3), "ms_per_forward": round(1e3 * df, 3),
                       "dtype": "f32", "data": "synthetic N(0,1)", "final_loss": round(float(loss.item()), 5),
                       "config": dict(workload="StructuredMeshExperiment train step", size=ps["size"], batch=B, **ps["model"]),

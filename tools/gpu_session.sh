@@ -34,12 +34,14 @@ for st in $STAGES; do
       timeout 900 python bench.py --steps 10 --warmup 3 --grid 256 --layers 12 --modes 32 --batch 2 --cpu-steps 1 > gpurun_out/bench_256.log 2>&1
       echo "[session] bench256 rc=$?"; tail -n 1 gpurun_out/bench_256.log | cut -c1-1200 ;;
     mesh3d)
-      timeout 600 python tools/bench_mesh3d.py --preset plasticity > gpurun_out/bench_mesh3d_plasticity.log 2>&1
+      timeout 600 python tools/bench_mesh.py --preset plasticity > gpurun_out/bench_mesh3d_plasticity.log 2>&1
       echo "[session] mesh3d plasticity rc=$?"; tail -n 1 gpurun_out/bench_mesh3d_plasticity.log | cut -c1-400
-      timeout 600 python tools/bench_mesh3d.py --preset cube64 > gpurun_out/bench_mesh3d_cube64.log 2>&1
+      timeout 600 python tools/bench_mesh.py --preset cube64 > gpurun_out/bench_mesh3d_cube64.log 2>&1
       echo "[session] mesh3d cube64 rc=$?"; tail -n 1 gpurun_out/bench_mesh3d_cube64.log | cut -c1-400
+      timeout 600 python tools/bench_mesh.py --preset airfoil > gpurun_out/bench_mesh2d_airfoil.log 2>&1
+      echo "[session] mesh2d airfoil rc=$?"; tail -n 1 gpurun_out/bench_mesh2d_airfoil.log | cut -c1-400
       rm -rf gpurun_out/prof_mesh3d
-      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_mesh3d" -o m3 -- python "$OLDPWD/tools/bench_mesh3d.py" --preset plasticity --steps 5 --warmup 2 > "$OLDPWD/gpurun_out/prof_mesh3d.log" 2>&1)
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_mesh3d" -o m3 -- python "$OLDPWD/tools/bench_mesh.py" --preset plasticity --steps 5 --warmup 2 > "$OLDPWD/gpurun_out/prof_mesh3d.log" 2>&1)
       db=$(find gpurun_out/prof_mesh3d -name "*.db" | head -1); python tools/rocpd_stats.py "$db" > gpurun_out/mesh3d_kernel_stats.md 2>&1; head -n 30 gpurun_out/mesh3d_kernel_stats.md | cut -c1-180
       find gpurun_out/prof_mesh3d -size +20M -delete ;;
     bench19)
