@@ -1,0 +1,67 @@
+"""Checkpoint / resume for the routines -- counterpart of the reference's Lightning checkpoints
+(``Routine.load_lightning_model_state``, reference routines/base.py:79-102; files written by
+callbacks/model_checkpoint.py ``CustomModelCheckpoint`` and resumed by commands/train.py:74-80,116).
+
+A checkpoint is a ``torch.save``d dict in the Lightning layout the reference reads:
+``{'state_dict': routine.state_dict(), 'epoch', 'global_step', 'optimizer_states', 'lr_schedulers'}``.
+The routine mirrors keep the reference's attribute names (``conv.*`` / ``model.*``, ``normalizer.*``, ``_float``), so the
+``state_dict`` of a checkpoint written by the reference loads here with ``strict=True`` and vice versa.  The optimiser
+part holds this framework's flat AdamW state (first/second moments of the flat parameter buffer + step count).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import torch
+
+# buffers of the reference's velocity / super-resolution code paths that its loader drops (routines/base.py:89-99)
+REMOVE_KEYS = ['kx', 'ky', 'lap', 'kx_32', 'ky_32', 'lap_32', 'kx_64', 'ky_64', 'lap_64', 'kx_128', 'ky_128', 'lap_128',
+               'kx_256', 'ky_256', 'lap_256']
+
+
+class CheckpointMixin:
+    """Needs ``self.trainer() -> FFNOTrainer`` and to be an ``nn.Module``."""
+
+    def checkpoint_dict(self, epoch: int = 0, global_step: Optional[int] = None) -> Dict[str, Any]:
+        tr = self.trainer()
+        return {
+            'epoch': int(epoch),
+            'global_step': int(tr.step_count if global_step is None else global_step),
+            'pytorch-lightning_version': 'ffno-mi355x',
+            'state_dict': {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+            'optimizer_states': [{'flat_adamw': True, 'exp_avg': tr.m.cpu().clone(), 'exp_avg_sq': tr.v.cpu().clone(),
+                                  'step': int(tr.step_count), 'param_names': list(tr.engine.param_names)}],
+            'lr_schedulers': [{'last_epoch': int(tr.step_count)}],
+        }
+
+    def save_checkpoint(self, path: str, epoch: int = 0, global_step: Optional[int] = None) -> None:
+        torch.save(self.checkpoint_dict(epoch, global_step), path)
+
+    def load_lightning_model_state(self, checkpoint_path, map_location=None) -> None:
+        """Model (and normaliser) weights only, like the reference before testing (commands/train.py:125-130)."""
+        ckpt = torch.load(checkpoint_path, map_location=map_location or 'cpu', weights_only=False)
+        state_dict = dict(ckpt['state_dict'])
+        strict = True
+        for key in REMOVE_KEYS:
+            if key in state_dict:
+                del state_dict[key]
+                strict = False
+        self.load_state_dict(state_dict, strict=strict)
+
+    def resume_from_checkpoint(self, checkpoint_path) -> Dict[str, Any]:
+        """Weights + optimiser moments + schedule position (commands/train.py:74-80: ``last.ckpt``)."""
+        self.load_lightning_model_state(checkpoint_path)
+        ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
+        tr = self.trainer()
+        opt = (ckpt.get('optimizer_states') or [None])[0]
+        if opt is not None and opt.get('flat_adamw'):
+            if list(opt['param_names']) != list(tr.engine.param_names):
+                raise ValueError("checkpoint optimiser state belongs to a different parameter layout")
+            tr.m.copy_(opt['exp_avg'])
+            tr.v.copy_(opt['exp_avg_sq'])
+            tr.step_count = int(opt['step'])
+        else:       # a reference (torch.optim.AdamW) checkpoint: moments are per-parameter dicts -- restart the optimiser
+            tr.m.zero_()
+            tr.v.zero_()
+            tr.step_count = int(ckpt.get('global_step', 0))
+        return {'epoch': int(ckpt.get('epoch', 0)), 'global_step': int(ckpt.get('global_step', 0))}

@@ -19,9 +19,10 @@ from .. import _capi, _lib
 from ..engine import _p
 from ..modules.normalizer import Normalizer
 from ..trainer import FFNOTrainer
+from .checkpoint import CheckpointMixin
 
 
-class Grid2DMarkovExperiment(nn.Module):
+class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
     def __init__(self, conv: nn.Module, n_steps: Optional[int] = None, low: float = 0, high: float = 1,
                  use_position: bool = True, append_force: bool = False, append_mu: bool = False,
                  max_accumulations: float = 1e6, should_normalize: bool = True, use_fourier_position: bool = False,

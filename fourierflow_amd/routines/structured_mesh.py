@@ -7,9 +7,10 @@ from typing import Optional
 import torch.nn as nn
 
 from ..trainer import FFNOTrainer
+from .checkpoint import CheckpointMixin
 
 
-class StructuredMeshExperiment(nn.Module):
+class StructuredMeshExperiment(CheckpointMixin, nn.Module):
     def __init__(self, model: nn.Module, loss_scale: float = 1.0, optimizer: Optional[dict] = None,
                  scheduler: Optional[dict] = None, **unused):
         super().__init__()

@@ -80,3 +80,37 @@ def test_unknown_reference_targets_fail_loudly(tmp_path):
     with pytest.raises(ValueError):
         instantiate("${nope: 1}")
     assert instantiate("${eval: 2 * 3}") == 6
+
+
+REFERENCE_CONFIGS = [
+    ("torus_li/markov/24_layers", "Grid2DMarkovExperiment", "conv", "FNOFactorized2DBlock"),
+    ("torus_li/markov/4_layers", "Grid2DMarkovExperiment", "conv", "FNOFactorized2DBlock"),
+    ("plasticity/ffno/12_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh3D"),
+    ("airfoil/ffno/24_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh2D"),
+    ("pipe/ffno/8_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh2D"),
+]
+
+
+@pytest.mark.parametrize("rel,routine_cls,attr,model_cls", REFERENCE_CONFIGS)
+def test_shipped_experiment_configs_build_unchanged(rel, routine_cls, attr, model_cls):
+    """The reference's own experiments/**/config.yaml files (read in place, build container only) instantiate the
+    native routine + operator without edits: same `_target_`s, kwargs, optimiser and schedule."""
+    import os
+    path = os.path.join(os.environ.get("FFNO_REFERENCE", "/root/reference"), "experiments", rel, "config.yaml")
+    if not os.path.exists(path):
+        pytest.skip("reference experiments are only present in the build container")
+    import yaml
+    from fourierflow_amd.config import build_routine, load_config
+    cfg = load_config(path)
+    routine = build_routine(cfg)
+    assert type(routine).__name__ == routine_cls
+    model = getattr(routine, attr)
+    assert type(model).__name__ == model_cls
+    raw = yaml.safe_load(open(path))["routine"]
+    for k, v in raw[attr].items():
+        if not k.startswith("_") and isinstance(v, (int, float, bool)) and hasattr(model, k):
+            assert getattr(model, k) == v, k
+    opt = {k: v for k, v in raw["optimizer"].items() if not k.startswith("_")}
+    sch = {k: v for k, v in raw["scheduler"]["scheduler"].items() if not k.startswith("_")}
+    assert {k: routine._opt_kw[k] for k in opt} == opt
+    assert {k: routine._sch_kw[k] for k in sch} == sch
