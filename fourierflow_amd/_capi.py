@@ -71,6 +71,8 @@ SIGNATURES = {
     "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
     "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ffno_velocity_ws_floats": (SZ, [I, I, I]),
+    "ffno_velocity_features": (I, [P, P, P, I, I, I, F, F, P]),
     "ffno_lploss_tmp_floats": (SZ, [I, I]),
     "ffno_lploss_fwd_bwd": (I, [P, P, P, P, P, I, I, F, P, P]),
     "ffno_markov_features": (I, [P, P, P, P, P, P, I, I, I, I, F, F, F, F, I, I, P]),

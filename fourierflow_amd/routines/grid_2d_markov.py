@@ -10,8 +10,10 @@ Gaussian noise samples.
 """
 from __future__ import annotations
 
+import math
 from typing import Dict, Optional
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -28,10 +30,10 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
                  max_accumulations: float = 1e6, should_normalize: bool = True, use_fourier_position: bool = False,
                  noise_std: float = 0.0, shuffle_grid: bool = False, use_velocity: bool = False,
                  learn_difference: bool = False, optimizer: Optional[dict] = None, scheduler: Optional[dict] = None,
-                 **unused):
+                 domain=((0.0, 2 * math.pi), (0.0, 2 * math.pi)), grid_size=(64,), **unused):
         super().__init__()
         for flag, name in ((append_force, "append_force"), (append_mu, "append_mu"), (shuffle_grid, "shuffle_grid"),
-                           (use_fourier_position, "use_fourier_position"), (use_velocity, "use_velocity")):
+                           (use_fourier_position, "use_fourier_position")):
             if flag:
                 raise NotImplementedError(f"{name}=True is outside the torus_li/markov path built here (SURVEY 8 f3)")
         if not use_position:
@@ -41,6 +43,19 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         self.should_normalize, self.noise_std, self.learn_difference = should_normalize, noise_std, learn_difference
         self.normalizer = Normalizer([conv.input_dim], max_accumulations)
         self.register_buffer('_float', torch.FloatTensor([0.1]))
+        self.use_velocity, self.domain = use_velocity, tuple(tuple(float(v) for v in d) for d in domain)
+        if use_velocity:
+            # same buffers as the reference (grid_2d_markov.py:82-94) so its checkpoints load strictly; the HIP kernel
+            # derives the wavenumbers from the domain lengths itself
+            for size in grid_size:
+                lx, ly = self.domain[0][1] - self.domain[0][0], self.domain[1][1] - self.domain[1][0]
+                kx, ky = np.meshgrid(np.fft.fftfreq(size, d=lx / size), np.fft.rfftfreq(size, d=ly / size), indexing="ij")
+                lap = (2 * np.pi * 1j) ** 2 * (np.abs(kx) ** 2 + np.abs(ky) ** 2)
+                lap[0, 0] = 1
+                self.register_buffer(f'kx_{size}', torch.from_numpy(kx.astype(np.float32)))
+                self.register_buffer(f'ky_{size}', torch.from_numpy(ky.astype(np.float32)))
+                self.register_buffer(f'lap_{size}', torch.from_numpy(lap.astype(np.complex64)))
+        self._vel_ws = None
         self._opt_kw = dict(lr=2.5e-3, weight_decay=1e-4)
         self._opt_kw.update(optimizer or {})
         self._sch_kw = dict(num_warmup_steps=500, num_training_steps=100000, num_cycles=0.5)
@@ -62,6 +77,8 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         statistics while training (grid_2d_markov.py:124-170, normalizer.py:45-55)."""
         x = batch['x'].contiguous()
         _lib.require_device_tensor(x, "batch['x']")
+        if self.use_velocity:       # [B, M, N, 1] vorticity -> [B, M, N, 3] (vorticity, u, v)  (grid_2d_markov.py:130-144)
+            x = self._velocity(x)
         B, M, N, Cx = x.shape
         D = Cx + 2
         if D != self.conv.input_dim:
@@ -86,6 +103,20 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         if acc:
             nz.unpack_state(state)
             nz._n_acc_host += 1.0
+        return out
+
+    def _velocity(self, x: torch.Tensor) -> torch.Tensor:
+        B, M, N, Cx = x.shape
+        if Cx != 1:
+            raise ValueError("use_velocity expects the single-channel vorticity field [B, M, N, 1]")
+        lib = _lib.get_lib()
+        need = int(lib.ffno_velocity_ws_floats(B, M, N))
+        if self._vel_ws is None or self._vel_ws.numel() < need or self._vel_ws.device != x.device:
+            self._vel_ws = torch.empty(need, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, M, N, 3, dtype=torch.float32, device=x.device)
+        lx, ly = self.domain[0][1] - self.domain[0][0], self.domain[1][1] - self.domain[1][0]
+        _capi.check(lib.ffno_velocity_features(_p(x), _p(out), _p(self._vel_ws), B, M, N, lx, ly,
+                                               _lib.current_stream(x.device)), "velocity_features")
         return out
 
     def _eps(self) -> float:

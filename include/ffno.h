@@ -267,6 +267,17 @@ int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, co
                           int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Velocity features of the Markov routine (routines/grid_2d_markov.py:130-144, `use_velocity: true`,
+ * wavenumber buffers :82-94): vorticity[B][X][Y] -> out[B][X][Y][3] = (vorticity, u, v) with
+ *   psi^ = -rfftn(w)/lap,  u = irfftn(2 pi i ky psi^),  v = irfftn(-2 pi i kx psi^)
+ * on the periodic domain [0,len_x) x [0,len_y) (reference default 2 pi).  Y must be even.
+ * ws: ffno_velocity_ws_floats(B, X, Y) floats.  `out` feeds ffno_markov_features with Cx = 3.
+ * --------------------------------------------------------------------------------------------- */
+size_t ffno_velocity_ws_floats(int B, int X, int Y);
+int ffno_velocity_features(const float* vorticity, float* out, float* ws, int B, int X, int Y,
+                           float len_x, float len_y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Relative-L2 loss (loss.py:33-46) and its gradient:
  *   loss = mean_b ||pred_b - y_b||_2 / ||y_b||_2 ;  gpred = dloss/dpred * gscale
  * work buffer `tmp`: ffno_lploss_tmp_floats(B, n_per_sample) floats (two-stage deterministic reduction,

@@ -254,6 +254,40 @@ def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, paddi
 
 
 # --------------------------------------------------------------------------
+# Velocity features of Grid2DMarkovExperiment (routines/grid_2d_markov.py:82-94 buffers, :130-144 use).
+# The wavenumber meshes come from jax_cfd (``Grid(shape, domain).rfft_mesh()``; dependency pinned at git rev
+# eb4d723e in the reference's pyproject.toml:29, NOT present under /root/reference and not installable here), so
+# they are restated from that function's published definition: fftfreq over every axis but the last, rfftfreq over
+# the last, spacing = domain length / n, meshgrid(indexing='ij').  PARITY OF THIS PIECE IS PINNED ANALYTICALLY
+# (plane-wave known answers, curl/divergence identities in tests/test_velocity.py), not by a reference run:
+# fourierflow.routines cannot be imported without jax.
+# --------------------------------------------------------------------------
+def velocity_wavenumbers(X: int, Y: int, domain=((0.0, 2 * math.pi), (0.0, 2 * math.pi))):
+    """-> kx [X, Y//2+1], ky [X, Y//2+1] (float32), lap [X, Y//2+1] (complex64), as registered at :88-94."""
+    import numpy as np
+    lx, ly = domain[0][1] - domain[0][0], domain[1][1] - domain[1][0]
+    kx, ky = np.meshgrid(np.fft.fftfreq(X, d=lx / X), np.fft.rfftfreq(Y, d=ly / Y), indexing="ij")
+    lap = (2 * np.pi * 1j) ** 2 * (np.abs(kx) ** 2 + np.abs(ky) ** 2)
+    lap[0, 0] = 1
+    return (torch.from_numpy(kx.astype(np.float32)), torch.from_numpy(ky.astype(np.float32)),
+            torch.from_numpy(lap.astype(np.complex64)))
+
+
+def velocity_features(x: Tensor, domain=((0.0, 2 * math.pi), (0.0, 2 * math.pi))) -> Tensor:
+    """x = vorticity [B, X, Y, 1] -> cat([x, u, v], -1) exactly as grid_2d_markov.py:130-144."""
+    B, X, Y, _ = x.shape
+    kx, ky, lap = velocity_wavenumbers(X, Y, domain)
+    cdt = torch.complex128 if x.dtype == torch.float64 else torch.complex64
+    omega_hat = torch.fft.rfftn(x, dim=[1, 2], norm="backward")
+    psi_hat = -omega_hat / lap.to(cdt)[None, :, :, None]
+    q = 2 * math.pi * 1j * ky.to(x.dtype)[None, :, :, None] * psi_hat
+    q = torch.fft.irfftn(q, dim=[1, 2], norm="backward")
+    v = -2 * math.pi * 1j * kx.to(x.dtype)[None, :, :, None] * psi_hat
+    v = torch.fft.irfftn(v, dim=[1, 2], norm="backward")
+    return torch.cat([x, q, v], dim=-1)
+
+
+# --------------------------------------------------------------------------
 # FNOFactorizedMesh2D  (factorized_fno/mesh_2d.py:56-106 forward_fourier, :146-175 forward)
 # NOTE the weight order differs from grid_2d.py: here fourier_weight[0] mixes the FIRST spatial axis (x, modes_x)
 # and fourier_weight[1] the LAST (y, modes_y) -- mesh_2d.py:71-75,92-96.

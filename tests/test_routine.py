@@ -167,3 +167,35 @@ def test_checkpoint_roundtrip_and_resume(host_device, tmp_path):
     c.resume_from_checkpoint(path)
     assert c.trainer().step_count == 2
     assert torch.equal(c.state_dict()["conv.in_proj.weight_v"].cpu(), ck["state_dict"]["conv.in_proj.weight_v"])
+
+
+def test_markov_routine_with_velocity_features(host_device):
+    """`use_velocity: true` (torus_kochkov, torus_li/ablation/with_velocity; grid_2d_markov.py:130-144): the conv sees
+    normalised (vorticity, u, v, x, y); first train step's loss equals the oracle's on the same statistics."""
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    import oracle_util as ou
+    import golden_util as gu
+    kw = dict(modes=4, width=32, n_layers=2, input_dim=5, share_weight=True, factor=4, ff_weight_norm=True, gain=0.5)
+    sd_np = gu.make_block_state_dict(kw, 77)
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    exp = Grid2DMarkovExperiment(blk, n_steps=2, use_velocity=True, grid_size=[16], max_accumulations=1000,
+                                 scheduler=dict(num_warmup_steps=2, num_training_steps=50)).to(host_device)
+    assert {"kx_16", "ky_16", "lap_16"} <= set(exp.state_dict()) and exp.state_dict()["lap_16"].dtype == torch.complex64
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(2, 16, 16, 1, generator=g), torch.randn(2, 16, 16, 1, generator=g)
+    batch = dict(x=x.to(host_device), y=y.to(host_device))
+    exp.training_step(batch, epoch=0)
+    loss = exp.training_step(batch, epoch=1).item()
+    # oracle: features -> normalise with the accumulated statistics (2 accumulations of the same batch) -> block -> loss
+    st = orc.NormalizerState(5, max_accumulations=1000)
+    vel = orc.velocity_features(x)
+    orc.markov_features(vel, st, None, 0.0, training=True)               # epoch 0: statistics only
+    feats = orc.markov_features(vel, st, None, 0.0, training=True)       # train step: accumulate again, then normalise
+    sd, _ = ou.torch_state_dict(sd_np, requires_grad=False)
+    pred = orc.ffno2d_block(sd, feats, modes=4, n_layers=2)["forecast"]
+    ref = orc.lp_rel_loss(st.inverse(pred, 0), y)
+    assert abs(loss - ref.item()) < 2e-5
+    roll = exp.rollout(batch["x"], 2)
+    assert tuple(roll.shape) == (2, 16, 16, 2) and bool(torch.isfinite(roll).all())
