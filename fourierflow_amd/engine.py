@@ -422,10 +422,12 @@ class FFNOEngine:
             self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
                     _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
 
-    def _can_fuse(self, views) -> bool:
+    def _can_fuse(self, views):
+        """Per axis: the fused branch kernel when its LDS tile holds (C, K_axis, L_axis), else the three stage kernels
+        (e.g. plasticity: x with 32 modes is staged, y / z with 12 / 8 modes are fused)."""
         lib = _lib.get_lib()
-        return bool(self.use_fused and self.mode != "no-fourier" and
-                    all(lib.ffno_spectral_fused_supported(self.C, v.K, v.L) for v in views))
+        return [bool(self.use_fused and self.mode != "no-fourier" and lib.ffno_spectral_fused_supported(self.C, v.K, v.L))
+                for v in views]
 
     def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st):
         """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint)."""
@@ -485,10 +487,10 @@ class FFNOEngine:
                 si = self._fw_sets.index(self.fw_names[l]) if full else 0
                 for w, v in enumerate(ws.views):
                     keep = ws.SXall[w][sv] if full else None     # stage-A spectrum (kept per layer when training)
-                    if fused and not save_for_backward:
+                    if fused[w] and not save_for_backward:
                         keep = None
                     self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
-                                   self.planes[si][w][0] if full else None, True, int(w > 0), fused, st)
+                                   self.planes[si][w][0] if full else None, True, int(w > 0), fused[w], st)
             l0, l1, b0, b1 = self._ff_weights(l)
             if not (self.use_fork and last):      # with fork heads the last layer's backcast only feeds the dead x_L
                 self._ff_fwd(s_l, None if last else ws.X, l0, l1, b0, b1, ws.Blast if last else ws.X,
@@ -584,7 +586,7 @@ class FFNOEngine:
                     for w, v in enumerate(ws.views):
                         keep = ws.SDall[w][l] if full else None
                         self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, None, keep,
-                                       self.planes[si][w][1] if full else None, False, int(w > 0), fused, st)
+                                       self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
                 cur = 1 - cur
                 continue
             self._ff_bwd_data(g_in, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
@@ -615,7 +617,7 @@ class FFNOEngine:
             for w, v in enumerate(ws.views):
                 keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
                 self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if w == 0 else None, keep,
-                               self.planes[si][w][1] if full else None, False, int(w > 0), fused, st)
+                               self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
             cur = 1 - cur
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
