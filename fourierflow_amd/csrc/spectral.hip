@@ -459,21 +459,26 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
 
     // ---------------- phase 2: per-mode channel mix, in place on XS ----------------
     if (planes) {
-        // D columns: lane column jo of tile e <-> output channel o = 64*og + 4*jo + e, so one 16-B load per lane
-        // fetches the B values of four column tiles and a wave reads full 256-B plane rows.
-        constexpr int NOG = C / 64;
+        // D columns: lane column io of tile e <-> output channel o = 16*EPL*og + EPL*io + e, so one EPL-float load per
+        // lane fetches the B values of EPL column tiles and a wave reads full plane rows (16 B per lane at C = 64, 8 B at
+        // C = 32).
+        constexpr int EPL = C >= 64 ? 4 : C / 16;     // output channels per lane and column group
+        constexpr int NOG = C / (16 * EPL);
         const int io = lane & 15, kq = lane >> 4;       // A row (line, re/im) = io ; B column group = io
         const float* arow = XS + (io >> 1) * LS + (io & 1) * C + kq;
         // Work list of this wave: modes k = wave, wave+8, ...; each mode = 2 chunks of C/8 k-steps.  The weight
-        // fragments of chunk i+1 are requested (16-B loads of full 256-B plane rows, L2-resident) before chunk i's
-        // MFMAs start: two register buffers in ping-pong, statically indexed.
+        // fragments of chunk i+1 are requested (full plane rows, L2-resident) before chunk i's MFMAs start: two
+        // register buffers in ping-pong, statically indexed.
         constexpr int HK = C / 8;                      // k-steps per chunk (each k-step = 4 input channels)
         const int nmodes = (K - wave + F::LINES - 1) / F::LINES;   // modes owned by this wave (K > wave else <= 0)
         const int nch = nmodes > 0 ? 2 * nmodes : 0;
-        float4 wr0[HK][NOG], wi0[HK][NOG], wr1[HK][NOG], wi1[HK][NOG];
-        f32x4 p1[NOG][4], p2[NOG][4];
+        struct WFrag {
+            float r[HK][NOG][EPL], i[HK][NOG][EPL];
+        };
+        WFrag w0, w1;
+        f32x4 p1[NOG][EPL], p2[NOG][EPL];
 
-        auto load_chunk = [&](float4 (&wr)[HK][NOG], float4 (&wi)[HK][NOG], int ch) {
+        auto load_chunk = [&](WFrag& w, int ch) {
             const int k = wave + F::LINES * (ch >> 1), tb = (ch & 1) * HK;
             const float* pr = planes + ((long)k * 2 + 0) * C * C;
             const float* pi = planes + ((long)k * 2 + 1) * C * C;
@@ -482,18 +487,27 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                 const int ic = 4 * (tb + u) + kq;
                 FFNO_UNROLL
                 for (int og = 0; og < NOG; ++og) {
-                    wr[u][og] = *reinterpret_cast<const float4*>(pr + (long)ic * C + 64 * og + 4 * io);
-                    wi[u][og] = *reinterpret_cast<const float4*>(pi + (long)ic * C + 64 * og + 4 * io);
+                    const float* qr = pr + (long)ic * C + 16 * EPL * og + EPL * io;
+                    const float* qi = pi + (long)ic * C + 16 * EPL * og + EPL * io;
+                    if constexpr (EPL == 4) {
+                        const float4 a = *reinterpret_cast<const float4*>(qr), b = *reinterpret_cast<const float4*>(qi);
+                        w.r[u][og][0] = a.x, w.r[u][og][1] = a.y, w.r[u][og][2] = a.z, w.r[u][og][3] = a.w;
+                        w.i[u][og][0] = b.x, w.i[u][og][1] = b.y, w.i[u][og][2] = b.z, w.i[u][og][3] = b.w;
+                    } else {
+                        const float2 a = *reinterpret_cast<const float2*>(qr), b = *reinterpret_cast<const float2*>(qi);
+                        w.r[u][og][0] = a.x, w.r[u][og][1] = a.y;
+                        w.i[u][og][0] = b.x, w.i[u][og][1] = b.y;
+                    }
                 }
             }
         };
-        auto compute_chunk = [&](const float4 (&wr)[HK][NOG], const float4 (&wi)[HK][NOG], int ch) {
+        auto compute_chunk = [&](const WFrag& w, int ch) {
             const int k = wave + F::LINES * (ch >> 1), tb = (ch & 1) * HK;
             if ((ch & 1) == 0) {
                 FFNO_UNROLL
                 for (int og = 0; og < NOG; ++og) {
                     FFNO_UNROLL
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < EPL; ++e) {
                         FFNO_UNROLL
                         for (int r = 0; r < 4; ++r) p1[og][e][r] = p2[og][e][r] = 0.f;
                     }
@@ -504,14 +518,10 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                 const float a = arow[2 * k * C + 4 * (tb + u)];
                 FFNO_UNROLL
                 for (int og = 0; og < NOG; ++og) {
-                    p1[og][0] = mfma16(a, wr[u][og].x, p1[og][0]);
-                    p1[og][1] = mfma16(a, wr[u][og].y, p1[og][1]);
-                    p1[og][2] = mfma16(a, wr[u][og].z, p1[og][2]);
-                    p1[og][3] = mfma16(a, wr[u][og].w, p1[og][3]);
-                    p2[og][0] = mfma16(a, wi[u][og].x, p2[og][0]);
-                    p2[og][1] = mfma16(a, wi[u][og].y, p2[og][1]);
-                    p2[og][2] = mfma16(a, wi[u][og].z, p2[og][2]);
-                    p2[og][3] = mfma16(a, wi[u][og].w, p2[og][3]);
+                    FFNO_UNROLL
+                    for (int e = 0; e < EPL; ++e) p1[og][e] = mfma16(a, w.r[u][og][e], p1[og][e]);
+                    FFNO_UNROLL
+                    for (int e = 0; e < EPL; ++e) p2[og][e] = mfma16(a, w.i[u][og][e], p2[og][e]);
                 }
             }
             if (ch & 1) {
@@ -521,9 +531,9 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                     float* dst = XS + (2 * kq + ll) * LS + 2 * k * C;
                     FFNO_UNROLL
                     for (int og = 0; og < NOG; ++og) {
-                        float yr[4], yi[4];
+                        float yr[EPL], yi[EPL];
                         FFNO_UNROLL
-                        for (int e = 0; e < 4; ++e) {
+                        for (int e = 0; e < EPL; ++e) {
                             const float p1r = p1[og][e][2 * ll], p1i = p1[og][e][2 * ll + 1];
                             const float p2r = p2[og][e][2 * ll], p2i = p2[og][e][2 * ll + 1];
                             if (conj_t == 0) {
@@ -534,18 +544,24 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                                 yi[e] = p1i - p2r;
                             }
                         }
-                        *reinterpret_cast<float4*>(dst + 64 * og + 4 * io) = make_float4(yr[0], yr[1], yr[2], yr[3]);
-                        *reinterpret_cast<float4*>(dst + C + 64 * og + 4 * io) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                        float* dr = dst + 16 * EPL * og + EPL * io;
+                        if constexpr (EPL == 4) {
+                            *reinterpret_cast<float4*>(dr) = make_float4(yr[0], yr[1], yr[2], yr[3]);
+                            *reinterpret_cast<float4*>(dr + C) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                        } else {
+                            *reinterpret_cast<float2*>(dr) = make_float2(yr[0], yr[1]);
+                            *reinterpret_cast<float2*>(dr + C) = make_float2(yi[0], yi[1]);
+                        }
                     }
                 }
             }
         };
-        if (nch > 0) load_chunk(wr0, wi0, 0);
+        if (nch > 0) load_chunk(w0, 0);
         for (int ch = 0; ch < nch; ch += 2) {
-            load_chunk(wr1, wi1, ch + 1);                 // nch is even: chunk ch+1 always exists
-            compute_chunk(wr0, wi0, ch);
-            if (ch + 2 < nch) load_chunk(wr0, wi0, ch + 2);
-            compute_chunk(wr1, wi1, ch + 1);
+            load_chunk(w1, ch + 1);                 // nch is even: chunk ch+1 always exists
+            compute_chunk(w0, ch);
+            if (ch + 2 < nch) load_chunk(w0, ch + 2);
+            compute_chunk(w1, ch + 1);
         }
         __syncthreads();
     }
@@ -853,7 +869,8 @@ extern "C" int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K
 
 
 extern "C" int ffno_spectral_fused_supported(int C, int K, int L) {
-    if (C == 64) return K <= FusedCfg<64>::KMAX && L <= 4096 ? 1 : 0;
+    // phase 1 holds one 32-row tile of (mode, re/im) rows: K <= 16 for either width
+    if (C == 64 || C == 32) return K <= 16 && K <= FusedCfg<64>::KMAX && L <= 4096 ? 1 : 0;
     return 0;
 }
 
@@ -869,8 +886,12 @@ extern "C" int ffno_spectral_fused(const float* in, float* out, const float* res
     const LineMap lm = make_linemap(axis, B, M, N, C);
     const dim3 grid((R + 7) / 8), block(512);
     const size_t smem = sizeof(float) * 2 * L;
-    FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
-                tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
+    if (C == 64)
+        FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
+                    tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
+    else
+        FFNO_LAUNCH((spectral_fused_kernel<32>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
+                    tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
     return launch_status();
 }
 

@@ -188,13 +188,13 @@ def test_spectral2d_full_size_golden_and_properties():
     assert float((lp * x).sum()) > 0 and np.linalg.norm(lp) <= 2 * np.linalg.norm(x) * (1 + 1e-6)
 
 
-@pytest.mark.parametrize("B,M,N,K", [(1, 8, 12, 3), (2, 6, 10, 5), (1, 20, 64, 16), (1, 13, 9, 4), (3, 5, 7, 2), (2, 16, 32, 8)])
+@pytest.mark.parametrize("B,M,N,K,C", [(1, 8, 12, 3, 64), (2, 6, 10, 5, 64), (1, 20, 64, 16, 64), (1, 13, 9, 4, 64), (3, 5, 7, 2, 64),
+                                       (2, 16, 32, 8, 64), (2, 6, 10, 5, 32), (1, 13, 40, 16, 32), (3, 5, 7, 2, 32)])
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
-def test_spectral_fused_branch_equals_three_stage_path(be, B, M, N, K, axis, direction):
+def test_spectral_fused_branch_equals_three_stage_path(be, B, M, N, K, C, axis, direction):
     """The fused branch kernel (DFT -> mix -> iDFT in LDS) against fp64 torch.fft, incl. the saved spectrum,
-    ragged line counts (R % 8 != 0), accumulate + residual epilogue, and the adjoint configuration."""
-    C = 64
+    ragged line counts (R % 8 != 0), accumulate + residual epilogue, and the adjoint configuration; widths 64 and 32."""
     L = N if axis == 0 else M
     if K > L // 2 + 1:
         pytest.skip("modes exceed axis")
@@ -256,6 +256,8 @@ def test_spectral_fused_branch_equals_three_stage_path(be, B, M, N, K, axis, dir
 def test_spectral_fused_support_matrix(be):
     assert be.lib.ffno_spectral_fused_supported(64, 16, 64) == 1
     assert be.lib.ffno_spectral_fused_supported(64, 17, 64) == 0
-    assert be.lib.ffno_spectral_fused_supported(32, 8, 64) == 0
+    assert be.lib.ffno_spectral_fused_supported(32, 8, 64) == 1
+    assert be.lib.ffno_spectral_fused_supported(32, 17, 64) == 0
+    assert be.lib.ffno_spectral_fused_supported(48, 8, 64) == 0
     x, tw = be.zeros((1, 4, 64, 64)), be.twiddle(64)
     assert be.lib.ffno_spectral_fused(be.ptr(x), be.ptr(x), None, None, None, be.ptr(tw), 1, 4, 64, 64, 17, 0, 0, 1, 0, 0, None) == -2
