@@ -24,7 +24,6 @@
 // Activation tiles are staged through LDS already split (each element is split once per workgroup, not once per wave).
 #include "ffno_device.h"
 #include "ffno.h"
-#include <cstdlib>
 
 namespace ffno {
 
@@ -135,7 +134,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2,
                                                                      const float* __restrict__ bias2, float* out,
-                                                                     uint32_t* mask, int P, int xy_sel) {
+                                                                     uint32_t* mask, int P) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, NV = F::NV, G = F::G, GPW = F::GPW, CPW = F::CPW;
     __shared__ __attribute__((aligned(16))) char sp[2][3 * F::PPLANE];
@@ -229,7 +228,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     // (w and w + NW/2) place that reduction at opposite ends of the iteration, so between two barriers one of them
     // runs  [reduce | GEMM1 | epilogue | GEMM2]  and the other  [GEMM1 | epilogue | GEMM2 | reduce]: the VALU/LDS
     // phases of one fall on the MFMA phases of the other instead of both queueing for the same pipe in lockstep.
-    const bool early = xy_sel == 0 ? (wave < NW / 2) : xy_sel == 1 ? !(wave & 1) : true;
+    const bool early = wave < NW / 2 || NW == 1;
     int buf = 0, prev = -1;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int nt = tile + gridDim.x;
@@ -569,7 +568,7 @@ extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1,
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
         FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, resid,                \
-                    (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, getenv("FFX_XY") ? atoi(getenv("FFX_XY")) : 0);                           \
+                    (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                           \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -587,7 +586,7 @@ extern "C" int ffno_ffx_bwd_data(const float* db, const void* mask, const void* 
     if (C == CC && H == HH) {                                                                                         \
         FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, nullptr,              \
                     (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds, (uint32_t*)const_cast<void*>(mask), \
-                    P, getenv("FFX_XY") ? atoi(getenv("FFX_XY")) : 0);                                                                                               \
+                    P);                                                                                               \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
