@@ -24,6 +24,11 @@ class FxPackDesc(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("sh", C.c_int32), ("sc", C.c_int32), ("type", C.c_int32), ("pad_", C.c_int32)]
 
 
+class MarkovExtra(C.Structure):
+    """Mirror of ``ffno_markov_extra`` (include/ffno.h)."""
+    _fields_ = [("force", P), ("mu", P), ("use_position", C.c_int32), ("pad_", C.c_int32)]
+
+
 class PadMap(C.Structure):
     """Mirror of ``ffno_padmap`` (include/ffno.h)."""
     _fields_ = [("size", C.c_int32 * 3), ("padded", C.c_int32 * 3)]
@@ -75,7 +80,7 @@ SIGNATURES = {
     "ffno_velocity_features": (I, [P, P, P, I, I, I, F, F, P]),
     "ffno_lploss_tmp_floats": (SZ, [I, I]),
     "ffno_lploss_fwd_bwd": (I, [P, P, P, P, P, I, I, F, P, P]),
-    "ffno_markov_features": (I, [P, P, P, P, P, P, I, I, I, I, F, F, F, F, I, I, P]),
+    "ffno_markov_features": (I, [P, P, P, P, P, P, I, I, I, I, F, F, F, F, I, I, P, P]),
     "ffno_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, I, F, P]),
     "ffno_axpy": (I, [P, P, F, SZ, P]),
 }

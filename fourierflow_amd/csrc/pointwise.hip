@@ -315,16 +315,34 @@ __global__ void head_param_grads_kernel(const float* __restrict__ red, const flo
 //   accumulate: sum[c] += sum_p raw, sum_squared[c] += sum_p raw^2, count += P          (deterministic 2-stage)
 //   finalize  : mean = sum/max(count,1) ; std = max(sqrt(sum_squared/max(count,1) - mean^2), eps)
 //   apply     : feat[p][c] = (raw[p][c] - mean[c]) / std[c] + noise[p][c] * noise_std
-__device__ __forceinline__ float markov_raw(const float* __restrict__ x, long p, int c, int Cx, int M, int N,
-                                            float low, float high) {
-    if (c < Cx) return x[p * Cx + c];
-    const int n = (int)(p % N), m = (int)((p / N) % M);
-    const int idx = (c == Cx) ? m : n, size = (c == Cx) ? M : N;
-    return size > 1 ? low + (high - low) * (float)idx / (float)(size - 1) : low;
+// channel order of grid_2d_markov.py:146-163: x (and velocity) | position (use_position) | force map | viscosity mu
+struct MarkovSrc {
+    const float* x;
+    const float* force;   // [B][M][N] or null   (append_force, :156-158)
+    const float* mu;      // [B] or null         (append_mu, :160-162)
+    int Cx, use_pos;
+};
+
+__device__ __forceinline__ float markov_raw(const MarkovSrc& src, long p, int c, int M, int N, float low, float high) {
+    if (c < src.Cx) return src.x[p * src.Cx + c];
+    c -= src.Cx;
+    if (src.use_pos) {
+        if (c < 2) {
+            const int n = (int)(p % N), m = (int)((p / N) % M);
+            const int idx = c == 0 ? m : n, size = c == 0 ? M : N;
+            return size > 1 ? low + (high - low) * (float)idx / (float)(size - 1) : low;
+        }
+        c -= 2;
+    }
+    if (src.force) {
+        if (c == 0) return src.force[p];
+        c -= 1;
+    }
+    return src.mu[p / ((long)M * N)];
 }
 
-__global__ __launch_bounds__(256) void markov_stats_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                                   long P, int Cx, int D, int M, int N, float low,
+__global__ __launch_bounds__(256) void markov_stats_partial_kernel(MarkovSrc src, float* __restrict__ partial,
+                                                                   long P, int D, int M, int N, float low,
                                                                    float high, int chunk) {
     __shared__ float red[2][4][16];
     const long pbeg = (long)blockIdx.x * chunk, pend = min(P, pbeg + chunk);
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(256) void markov_stats_partial_kernel(const float* 
         FFNO_UNROLL
         for (int c = 0; c < 16; ++c) {
             if (c < D) {
-                const float v = markov_raw(x, p, c, Cx, M, N, low, high);
+                const float v = markov_raw(src, p, c, M, N, low, high);
                 s[c] += v;
                 q[c] = fmaf(v, v, q[c]);
             }
@@ -383,15 +401,15 @@ __global__ void markov_stats_finalize_kernel(const float* __restrict__ partial, 
     }
 }
 
-__global__ __launch_bounds__(256) void markov_features_kernel(const float* __restrict__ x, const float* __restrict__ derived,
+__global__ __launch_bounds__(256) void markov_features_kernel(MarkovSrc src, const float* __restrict__ derived,
                                                               const float* __restrict__ noise, float* __restrict__ out,
-                                                              long P, int Cx, int D, int M, int N, float low, float high,
+                                                              long P, int D, int M, int N, float low, float high,
                                                               float noise_std, int normalize) {
     const long total = P * D;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const long p = e / D;
         const int c = (int)(e % D);
-        float v = markov_raw(x, p, c, Cx, M, N, low, high);
+        float v = markov_raw(src, p, c, M, N, low, high);
         if (normalize) v = (v - derived[c]) / derived[D + c];
         if (noise) v = fmaf(noise[e], noise_std, v);
         out[e] = v;
@@ -641,9 +659,11 @@ extern "C" int ffno_lploss_fwd_bwd(const float* pred, const float* target, float
 
 extern "C" int ffno_markov_features(const float* x, float* state, float* derived, const float* noise, float* out,
                                     float* partial, int B, int M, int N, int Cx, float low, float high,
-                                    float noise_std, float eps, int accumulate, int normalize, void* stream) {
+                                    float noise_std, float eps, int accumulate, int normalize,
+                                    const ffno_markov_extra* extra, void* stream) {
     if (!x || !out || !state || !derived || !partial || B <= 0 || M <= 0 || N <= 0 || Cx <= 0) return FFNO_EINVAL;
-    const int D = Cx + 2;
+    MarkovSrc src{x, extra ? extra->force : nullptr, extra ? extra->mu : nullptr, Cx, extra ? extra->use_position : 1};
+    const int D = Cx + (src.use_pos ? 2 : 0) + (src.force ? 1 : 0) + (src.mu ? 1 : 0);
     if (D > 16) return FFNO_EUNSUPPORTED;
     const long P = (long)B * M * N;
     hipStream_t s = (hipStream_t)stream;
@@ -651,7 +671,7 @@ extern "C" int ffno_markov_features(const float* x, float* state, float* derived
     const int chunk = (int)((P + nsplit - 1) / nsplit);
     if (normalize) {
         if (accumulate) {
-            FFNO_LAUNCH(markov_stats_partial_kernel, dim3(nsplit), dim3(256), 0, s, x, partial, P, Cx, D, M, N, low, high, chunk);
+            FFNO_LAUNCH(markov_stats_partial_kernel, dim3(nsplit), dim3(256), 0, s, src, partial, P, D, M, N, low, high, chunk);
             int rc = pw_status();
             if (rc) return rc;
         }
@@ -661,7 +681,7 @@ extern "C" int ffno_markov_features(const float* x, float* state, float* derived
         if (rc) return rc;
     }
     const unsigned blocks = (unsigned)min((P * D + 255) / 256, 2048L);
-    FFNO_LAUNCH(markov_features_kernel, dim3(blocks), dim3(256), 0, s, x, derived, noise, out, P, Cx, D, M, N, low, high,
+    FFNO_LAUNCH(markov_features_kernel, dim3(blocks), dim3(256), 0, s, src, derived, noise, out, P, D, M, N, low, high,
                 noise_std, normalize);
     return pw_status();
 }

@@ -10,6 +10,7 @@ Gaussian noise samples.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, Optional
 
@@ -32,13 +33,11 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
                  learn_difference: bool = False, optimizer: Optional[dict] = None, scheduler: Optional[dict] = None,
                  domain=((0.0, 2 * math.pi), (0.0, 2 * math.pi)), grid_size=(64,), **unused):
         super().__init__()
-        for flag, name in ((append_force, "append_force"), (append_mu, "append_mu"), (shuffle_grid, "shuffle_grid"),
-                           (use_fourier_position, "use_fourier_position")):
+        for flag, name in ((shuffle_grid, "shuffle_grid"), (use_fourier_position, "use_fourier_position")):
             if flag:
-                raise NotImplementedError(f"{name}=True is outside the torus_li/markov path built here (SURVEY 8 f3)")
-        if not use_position:
-            raise NotImplementedError("use_position=False: the fused feature kernel always appends the two grid channels")
+                raise NotImplementedError(f"{name}=True is outside the Markov paths built here (one shipped config each)")
         self.conv = conv
+        self.use_position, self.append_force, self.append_mu = bool(use_position), bool(append_force), bool(append_mu)
         self.n_steps, self.low, self.high = n_steps, low, high
         self.should_normalize, self.noise_std, self.learn_difference = should_normalize, noise_std, learn_difference
         self.normalizer = Normalizer([conv.input_dim], max_accumulations)
@@ -80,7 +79,18 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         if self.use_velocity:       # [B, M, N, 1] vorticity -> [B, M, N, 3] (vorticity, u, v)  (grid_2d_markov.py:130-144)
             x = self._velocity(x)
         B, M, N, Cx = x.shape
-        D = Cx + 2
+        extra, keep = None, []
+        if not self.use_position or self.append_force or self.append_mu:      # grid_2d_markov.py:146-162
+            force = batch['f'].contiguous().float() if self.append_force else None
+            mu = batch['mu'].contiguous().float() if self.append_mu else None
+            for t, shape in ((force, (B, M, N)), (mu, (B,))):
+                if t is not None:
+                    _lib.require_device_tensor(t, "batch['f'] / batch['mu']")
+                    if tuple(t.shape) != shape:
+                        raise ValueError(f"expected a tensor of shape {shape}, got {tuple(t.shape)}")
+            keep = [force, mu]
+            extra = ctypes.byref(_capi.MarkovExtra(_p(force), _p(mu), int(self.use_position), 0))
+        D = Cx + (2 if self.use_position else 0) + int(self.append_force) + int(self.append_mu)
         if D != self.conv.input_dim:
             raise ValueError(f"conv.input_dim={self.conv.input_dim} but the features have {D} channels")
         dev = x.device
@@ -98,7 +108,8 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         rc = _lib.get_lib().ffno_markov_features(_p(x), _p(state), _p(self._derived), _p(noise), _p(out), _p(self._partial),
                                                  B, M, N, Cx, float(self.low), float(self.high), float(self.noise_std),
                                                  self._eps(), int(acc),
-                                                 int(self.should_normalize), _lib.current_stream(dev))
+                                                 int(self.should_normalize), extra, _lib.current_stream(dev))
+        del keep
         _capi.check(rc, "markov_features")
         if acc:
             nz.unpack_state(state)
@@ -151,15 +162,16 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         return self._training_step(batch, noise)
 
     @torch.no_grad()
-    def rollout(self, x0: torch.Tensor, n_steps: Optional[int] = None) -> torch.Tensor:
+    def rollout(self, x0: torch.Tensor, n_steps: Optional[int] = None, f: Optional[torch.Tensor] = None,
+                mu: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Autoregressive inference (grid_2d_markov.py:263-321): feed each de-normalised prediction back as the
-        next input.  x0 [B, M, N, 1] -> [B, M, N, n_steps]."""
+        next input (the force map ``f`` [B, M, N] and viscosity ``mu`` [B] stay fixed).  x0 [B, M, N, 1] -> [B, M, N, n_steps]."""
         was_training = self.normalizer.training
         self.normalizer.eval()
         tr = self.trainer()
         preds, x, prev = [], x0, x0
         for _ in range(n_steps or self.n_steps or 1):
-            feats = self._build_features({'x': x}, add_noise=False)   # no noise at validation (:292-293)
+            feats = self._build_features({'x': x, 'f': f, 'mu': mu}, add_noise=False)   # no noise at validation (:292-293)
             im = tr.engine.forward(feats, False)
             if self.should_normalize:
                 D = self.conv.input_dim

@@ -292,16 +292,25 @@ int ffno_lploss_fwd_bwd(const float* pred, const float* target, float* loss_out,
 
 /* ---------------------------------------------------------------------------------------------
  * Feature build of the Markov routine + running normaliser, fused
- * (routines/grid_2d_markov.py:124-170 with use_position=True; modules/normalizer.py:18-77):
+ * (routines/grid_2d_markov.py:124-170; modules/normalizer.py:18-77):
  *   raw[p]  = [ x[p][0..Cx), linspace(low,high,M)[m], linspace(low,high,N)[n] ]          D = Cx + 2 <= 16
+ *   `extra` (optional) selects the other feature channels of :146-162, in the reference's order:
+ *   position (use_position, default 1) | force[B][M][N] (append_force) | mu[B] broadcast (append_mu)
  *   accumulate != 0: state.sum += sum_p raw, state.sum_squared += sum_p raw^2, count += B*M*N, n_accumulations += 1
  *   derived = { mean[D], std[D] = max(sqrt(sum_squared/count - mean^2), eps) }
  *   out[p][c] = (normalize ? (raw - mean)/std : raw) + (noise ? noise[p][c]*noise_std : 0)
  * state = float[2D+2] {sum[D], sum_squared[D], count, n_accumulations}; partial = float[256*32] scratch.
  * --------------------------------------------------------------------------------------------- */
+typedef struct ffno_markov_extra {
+    const float* force; /* [B][M][N] or NULL */
+    const float* mu;    /* [B] or NULL */
+    int32_t use_position;
+    int32_t pad_;
+} ffno_markov_extra;
 int ffno_markov_features(const float* x, float* state, float* derived, const float* noise, float* out,
                          float* partial, int B, int M, int N, int Cx, float low, float high,
-                         float noise_std, float eps, int accumulate, int normalize, void* stream);
+                         float noise_std, float eps, int accumulate, int normalize,
+                         const ffno_markov_extra* extra, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused AdamW over one flat parameter buffer (torch.optim.AdamW semantics, config.yaml:36-40):

@@ -383,12 +383,20 @@ class NormalizerState:
 
 
 def markov_features(x: Tensor, norm: Optional[NormalizerState], noise: Optional[Tensor], noise_std: float,
-                    low: float = 0.0, high: float = 1.0, training: bool = True) -> Tensor:
+                    low: float = 0.0, high: float = 1.0, training: bool = True, use_position: bool = True,
+                    force: Optional[Tensor] = None, mu: Optional[Tensor] = None) -> Tensor:
+    """grid_2d_markov.py:146-170: x | position | force map f [B, M, N] (append_force) | viscosity mu [B] (append_mu)."""
     B, M, N, _ = x.shape
-    gm = torch.linspace(low, high, M, dtype=x.dtype)
-    gn = torch.linspace(low, high, N, dtype=x.dtype)
-    pos = torch.stack(torch.meshgrid(gm, gn, indexing="ij"), dim=-1).expand(B, M, N, 2)
-    feats = torch.cat([x, pos], dim=-1)
+    feats = x
+    if use_position:
+        gm = torch.linspace(low, high, M, dtype=x.dtype)
+        gn = torch.linspace(low, high, N, dtype=x.dtype)
+        pos = torch.stack(torch.meshgrid(gm, gn, indexing="ij"), dim=-1).expand(B, M, N, 2)
+        feats = torch.cat([feats, pos], dim=-1)
+    if force is not None:
+        feats = torch.cat([feats, force.reshape(B, M, N, 1).to(x.dtype)], dim=-1)
+    if mu is not None:
+        feats = torch.cat([feats, mu.reshape(B, 1, 1, 1).to(x.dtype).expand(B, M, N, 1)], dim=-1)
     if norm is not None:
         feats = norm.forward(feats, training)
     if noise is not None:

@@ -38,7 +38,7 @@ def test_markov_features_kernel(be, B, M, N, Cx):
         acc = int(it < 2)
         dx, dn, out = be.put(x), be.put(noise), be.empty((B, M, N, D))
         assert lib.ffno_markov_features(p(dx), p(state), p(derived), p(dn), p(out), p(partial), B, M, N, Cx, 0.0, 1.0,
-                                        0.01, 1e-8, acc, 1, None) == 0
+                                        0.01, 1e-8, acc, 1, None, None) == 0
         ref = orc.markov_features(torch.tensor(x), nz, torch.tensor(noise), 0.01, training=True)
         assert rel_l2(be.get(out), ref.numpy()) < 1e-5
     st = be.get(state)
@@ -47,7 +47,7 @@ def test_markov_features_kernel(be, B, M, N, Cx):
     assert st[2 * D] == float(nz.count) and st[2 * D + 1] == 2.0
     out = be.empty((B, M, N, D))
     assert lib.ffno_markov_features(p(dx), p(state), p(derived), None, p(out), p(partial), B, M, N, Cx, -1.0, 1.0,
-                                    0.0, 1e-8, 0, 0, None) == 0
+                                    0.0, 1e-8, 0, 0, None, None) == 0
     ref = orc.markov_features(torch.tensor(x), None, None, 0.0, low=-1.0, high=1.0)
     assert rel_l2(be.get(out), ref.numpy()) < 1e-6
 
@@ -199,3 +199,55 @@ def test_markov_routine_with_velocity_features(host_device):
     assert abs(loss - ref.item()) < 2e-5
     roll = exp.rollout(batch["x"], 2)
     assert tuple(roll.shape) == (2, 16, 16, 2) and bool(torch.isfinite(roll).all())
+
+
+@pytest.mark.parametrize("use_position,append_force,append_mu", [(True, True, False), (True, True, True), (False, False, True),
+                                                                 (False, True, False)])
+def test_markov_feature_variants(be, use_position, append_force, append_mu):
+    """append_force / append_mu / use_position=False (grid_2d_markov.py:146-162; the torus_vis and ablation configs):
+    channel order x | position | force | mu, normalised over all of them."""
+    from fourierflow_amd._capi import MarkovExtra
+    import ctypes
+    lib, p = be.lib, be.ptr
+    B, M, N, Cx = 2, 6, 5, 1
+    D = Cx + 2 * use_position + append_force + append_mu
+    rs = np.random.RandomState(D)
+    x = rs.standard_normal((B, M, N, Cx)).astype(np.float32)
+    f = rs.standard_normal((B, M, N)).astype(np.float32) if append_force else None
+    mu = rs.uniform(1e-5, 1e-3, B).astype(np.float32) if append_mu else None
+    dx, df, dmu, out = be.put(x), be.put(f), be.put(mu), be.empty((B, M, N, D))
+    state, derived, partial = be.zeros(2 * D + 2), be.zeros(2 * D), be.zeros(256 * 32)
+    extra = MarkovExtra(p(df), p(dmu), int(use_position), 0)
+    assert lib.ffno_markov_features(p(dx), p(state), p(derived), None, p(out), p(partial), B, M, N, Cx, 0.0, 1.0, 0.0, 1e-8,
+                                    1, 1, ctypes.byref(extra), None) == 0
+    nz = orc.NormalizerState(D)
+    ref = orc.markov_features(torch.tensor(x), nz, None, 0.0, use_position=use_position,
+                              force=None if f is None else torch.tensor(f), mu=None if mu is None else torch.tensor(mu))
+    assert tuple(ref.shape) == (B, M, N, D)
+    assert rel_l2(be.get(out), ref.numpy()) < 1e-5
+
+
+def test_markov_routine_with_force_and_viscosity(host_device):
+    """torus_vis_force style routine: conv.input_dim = 1 + 2 + 1 + 1; loss of the first step vs the oracle composition."""
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    import oracle_util as ou
+    kw = dict(modes=4, width=32, n_layers=2, input_dim=5, share_weight=True, factor=4, ff_weight_norm=True, gain=0.5)
+    sd_np = gu.make_block_state_dict(kw, 78)
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    exp = Grid2DMarkovExperiment(blk, n_steps=2, append_force=True, append_mu=True, max_accumulations=1000,
+                                 scheduler=dict(num_warmup_steps=2, num_training_steps=50)).to(host_device)
+    g = torch.Generator().manual_seed(6)
+    x, y = torch.randn(2, 8, 8, 1, generator=g), torch.randn(2, 8, 8, 1, generator=g)
+    f, mu = torch.randn(2, 8, 8, generator=g), torch.rand(2, generator=g) * 1e-3
+    batch = dict(x=x.to(host_device), y=y.to(host_device), f=f.to(host_device), mu=mu.to(host_device))
+    exp.training_step(batch, epoch=0)
+    loss = exp.training_step(batch, epoch=1).item()
+    st = orc.NormalizerState(5, max_accumulations=1000)
+    orc.markov_features(x, st, None, 0.0, training=True, force=f, mu=mu)
+    feats = orc.markov_features(x, st, None, 0.0, training=True, force=f, mu=mu)
+    sd, _ = ou.torch_state_dict(sd_np, requires_grad=False)
+    pred = orc.ffno2d_block(sd, feats, modes=4, n_layers=2)["forecast"]
+    ref = orc.lp_rel_loss(st.inverse(pred, 0), y)
+    assert abs(loss - ref.item()) < 2e-5
