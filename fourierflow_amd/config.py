@@ -55,9 +55,22 @@ def import_string(name: str):
     return getattr(importlib.import_module(mod), attr)
 
 
+_INNER = re.compile(r"\$\{([\w.]+):\s*([^${}]*)\}")    # an interpolation with no interpolation inside
+
+
 def _resolve_scalar(v: Any) -> Any:
     if not isinstance(v, str):
         return v
+    # nested interpolations, innermost first: '${eval:2 * ${import:numpy.pi}}' (torus_kochkov configs, `domain`)
+    while True:
+        inner = None
+        for mm in _INNER.finditer(v):
+            if not (mm.start() == 0 and mm.end() == len(v.strip())) and mm.group(1) in ("import", "eval"):
+                inner = mm
+                break
+        if inner is None:
+            break
+        v = v[:inner.start()] + repr(_resolve_scalar(inner.group(0))) + v[inner.end():]
     m = _INTERP.match(v.strip())
     if not m:
         # embedded ${oc.env:VAR} inside a longer string (data paths)
