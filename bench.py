@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--modes", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 disables)")
+    ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
+                                                       "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,12 +208,12 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.modules import FNOFactorized2DBlock, FNOPlus2DBlock
     from fourierflow_amd.trainer import FFNOTrainer
 
     kw = dict(MARKOV24, n_layers=args.layers, modes=args.modes)
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
-    block = FNOFactorized2DBlock(**kw).to(dev)
+    block = (FNOPlus2DBlock if args.plus else FNOFactorized2DBlock)(**kw).to(dev)
     trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
     B, G = args.batch, args.grid
     gen = torch.Generator().manual_seed(1000 + rank)  # rank r draws its own shard of the global batch
@@ -312,11 +314,14 @@ def main():
                                  "region (minus 0.6 x the measured time of an empty event pair, the share a bracket adds around a kernel); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/pmc_traffic.json "
                                  "(separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE)")
         cpu = None
-        if world == 1 and args.cpu_steps > 0:
+        if args.plus:
+            roofline = None
+        if world == 1 and args.cpu_steps > 0 and not args.plus:
             cpu = cpu_baseline(B, G, args.cpu_steps, kw)
         steps_per_s = world * args.steps / elapsed
         out = {
-            "metric": ("training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)"
+            "metric": ("training-steps/sec (whole node), FNOPlus2DBlock %dL %dx%d modes %d" % (args.layers, G, G, K) if args.plus else
+                       "training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)"
                        if (G, args.layers, K) == (64, 24, 16) else
                        "training-steps/sec (whole node), F-FNO %dL %dx%d modes %d" % (args.layers, G, G, K)),
             "value": round(steps_per_s, 3), "unit": "steps/s (per-GPU batch %d, summed over ranks)" % B,
@@ -325,7 +330,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic N(0,1) inputs/targets, reference-init weights",
             "config": {"workload": "%s train step: FNOFactorized2DBlock(modes=%d,width=64,"
                                    "n_layers=%d,input_dim=3,share_weight,factor=4,weight_norm) %dx%d, fp32"
-                                   % ("torus_li/markov/24_layers" if (G, args.layers, K) == (64, 24, 16) else "F-FNO",
+                                   % ("FNOPlus2DBlock (non-factorized ablation)" if args.plus else
+                                      "torus_li/markov/24_layers" if (G, args.layers, K) == (64, 24, 16) else "F-FNO",
                                       K, args.layers, G, G),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "optimizer": "AdamW(lr 2.5e-3, wd 1e-4) + cosine warm-up, fused flat kernel",

@@ -76,6 +76,9 @@ SIGNATURES = {
     "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
     "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "ffno_cdft_rows": (I, [P, P, I, I, I, I, I, P]),
+    "ffno_fw2d_pack": (I, [P, P, P, P, I, I, P]),
+    "ffno_fw2d_grad_reduce": (I, [P, P, P, I, I, I, I, P]),
     "ffno_velocity_ws_floats": (SZ, [I, I, I]),
     "ffno_velocity_features": (I, [P, P, P, I, I, I, F, F, P]),
     "ffno_lploss_tmp_floats": (SZ, [I, I]),

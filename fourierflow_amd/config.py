@@ -21,6 +21,7 @@ TARGET_MAP = {
     "fourierflow.modules.FNOFactorized2DBlock": "fourierflow_amd.modules.FNOFactorized2DBlock",
     "fourierflow.modules.FNOFactorizedMesh3D": "fourierflow_amd.modules.FNOFactorizedMesh3D",
     "fourierflow.modules.FNOFactorizedMesh2D": "fourierflow_amd.modules.FNOFactorizedMesh2D",
+    "fourierflow.modules.FNOPlus2DBlock": "fourierflow_amd.modules.FNOPlus2DBlock",
     "fourierflow.modules.WNLinear": "fourierflow_amd.modules.WNLinear",
     "fourierflow.modules.Normalizer": "fourierflow_amd.modules.Normalizer",
     "fourierflow.routines.Grid2DMarkovExperiment": "fourierflow_amd.routines.Grid2DMarkovExperiment",

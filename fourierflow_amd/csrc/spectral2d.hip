@@ -1,0 +1,164 @@
+// Non-factorized 2-D spectral convolution (FNOPlus2DBlock, the "no factorization" F-FNO ablation):
+//     out = irfft2( pad( corner_mix( rfft2(x, norm='ortho') ) ), norm='ortho' )
+// reference fourierflow/modules/zongyi_fno/grid_plus_2d.py:52-83 -- two K x K corner blocks of the half spectrum
+// (rows [0,K) and [M-K,M), columns [0,K)) mixed with their own [I,O,K,K,2] weight tensors.
+//
+// The transform along the LAST axis, the per-mode channel mix and the weight-gradient contraction are the kernels of
+// spectral.hip (the 2K*K retained (kx,ky) modes are just "modes" to them, with the B samples as rows).  This file
+// adds what the factorized operator never needs:
+//   * the complex DFT along the FIRST axis of the already y-transformed spectrum, restricted to the 2K retained rows
+//     (forward) / zero-padded back to M rows (inverse);   kx' in [0,K) -> kx = kx',  kx' in [K,2K) -> kx = M - 2K + kx'
+//   * the weight repack  [I][O][Kx][Ky][2] x 2  ->  planes[mode = ky*2K + kx'][re/im][I][O]  (+ transposed copy)
+//   * the gradient scatter back into the two parameter tensors.
+// The 2-D mix streams 2*K*K*C*C*8 B of weights (16.8 MB at K = 16, C = 64) for B rows per mode: weight-bandwidth-bound;
+// the DFT along x is 0.5 GFLOP at the markov shape and runs on the vector ALUs.
+#include "ffno_device.h"
+#include "ffno.h"
+
+#include <cmath>
+
+namespace ffno {
+
+__device__ __forceinline__ void sincos_2pi_frac2(int k, int n, float& s, float& c) {   // angle = 2 pi k / n, 0 <= k < n
+#ifdef FFNO_EMU
+    const double a = 2.0 * 3.14159265358979323846 * (double)k / (double)n;
+    s = (float)sin(a), c = (float)cos(a);
+#else
+    sincospif(2.f * (float)k / (float)n, &s, &c);
+#endif
+}
+
+__device__ __forceinline__ int kx_of(int kxp, int K, int M) { return kxp < K ? kxp : M - 2 * K + kxp; }
+
+// forward:  Z[ky][kx'][b][ri][c] = 1/sqrt(M) sum_m e^{-2 pi i kx m / M} S[ky][b*M + m][ri][c]
+// block = (ky, b); thread = (channel c, group g of output rows); twiddle table in LDS
+__global__ __launch_bounds__(256) void cdft_fwd_kernel(const float* __restrict__ S, float* __restrict__ Z, int B, int M,
+                                                       int C, int K) {
+    FFNO_DYN_SMEM(smem);
+    float* ct = reinterpret_cast<float*>(smem);
+    float* st = ct + M;
+    const int ky = blockIdx.x / B, b = blockIdx.x % B;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) sincos_2pi_frac2(m, M, st[m], ct[m]);
+    __syncthreads();
+    const int G = blockDim.x / C;                 // row groups
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const float* src = S + ((long)ky * B * M + (long)b * M) * 2 * C;       // [m][ri][c]
+    const float scale = rsqrtf((float)M);
+    for (int kxp = g; kxp < 2 * K; kxp += G) {
+        const int kx = kx_of(kxp, K, M);
+        float re = 0.f, im = 0.f;
+        int idx = 0;
+        for (int m = 0; m < M; ++m) {             // (a + i bb)(cos - i sin)
+            const float a = src[(long)m * 2 * C + c], bb = src[(long)m * 2 * C + C + c];
+            const float cs = ct[idx], sn = st[idx];
+            re += a * cs + bb * sn;
+            im += bb * cs - a * sn;
+            idx += kx;
+            if (idx >= M) idx -= M;
+        }
+        float* dst = Z + (((long)ky * 2 * K + kxp) * B + b) * 2 * C;
+        dst[c] = re * scale;
+        dst[C + c] = im * scale;
+    }
+}
+
+// inverse:  S[ky][b*M + m][ri][c] = 1/sqrt(M) sum_{kx'} e^{+2 pi i kx m / M} Z[ky][kx'][b][ri][c]
+__global__ __launch_bounds__(256) void cdft_inv_kernel(const float* __restrict__ Z, float* __restrict__ S, int B, int M,
+                                                       int C, int K) {
+    FFNO_DYN_SMEM(smem);
+    float* ct = reinterpret_cast<float*>(smem);
+    float* st = ct + M;
+    const int ky = blockIdx.x / B, b = blockIdx.x % B;
+    for (int m = threadIdx.x; m < M; m += blockDim.x) sincos_2pi_frac2(m, M, st[m], ct[m]);
+    __syncthreads();
+    const int G = blockDim.x / C;
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    const float scale = rsqrtf((float)M);
+    float* dst = S + ((long)ky * B * M + (long)b * M) * 2 * C;
+    for (int m = g; m < M; m += G) {
+        float re = 0.f, im = 0.f;
+        for (int kxp = 0; kxp < 2 * K; ++kxp) {   // (a + i bb)(cos + i sin)
+            const float* z = Z + (((long)ky * 2 * K + kxp) * B + b) * 2 * C;
+            const float a = z[c], bb = z[C + c];
+            const int idx = (int)(((long)kx_of(kxp, K, M) * m) % M);
+            const float cs = ct[idx], sn = st[idx];
+            re += a * cs - bb * sn;
+            im += a * sn + bb * cs;
+        }
+        dst[(long)m * 2 * C + c] = re * scale;
+        dst[(long)m * 2 * C + C + c] = im * scale;
+    }
+}
+
+// planes[mode = ky*2K + kx'][ri][i][o]  <-  w_{kx' / K}[i][o][kx' % K][ky][ri]   (+ wpt[mode][ri][o][i])
+__global__ void fw2d_pack_kernel(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ wp,
+                                 float* __restrict__ wpt, int C, int K) {
+    const long total = (long)2 * K * K * 2 * C * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const int mode = e / ((long)C * C * 2);
+        const int kxp = mode % (2 * K), ky = mode / (2 * K);
+        const float* w = kxp < K ? w0 : w1;
+        const float v = w[((((long)i * C + o) * K + (kxp % K)) * K + ky) * 2 + ri];
+        wp[e] = v;
+        wpt[(((long)mode * 2 + ri) * C + o) * C + i] = v;
+    }
+}
+
+// partial[split][mode][ri][i][o] summed over splits -> gw_{kx'/K}[i][o][kx' % K][ky][ri]
+__global__ void fw2d_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw0,
+                                        float* __restrict__ gw1, int C, int K, int nsplit, int accumulate) {
+    const long total = (long)2 * K * K * 2 * C * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const int mode = e / ((long)C * C * 2);
+        const int kxp = mode % (2 * K), ky = mode / (2 * K);
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * total + e];
+        float* g = (kxp < K ? gw0 : gw1) + ((((long)i * C + o) * K + (kxp % K)) * K + ky) * 2 + ri;
+        *g = accumulate ? (*g + s) : s;
+    }
+}
+
+static inline int s2d_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+}  // namespace ffno
+
+using namespace ffno;
+
+extern "C" int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, int K, int inverse, void* stream) {
+    if (!in || !out || B <= 0 || M <= 0 || K <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    if (2 * K > M) return FFNO_EMODES;
+    const dim3 grid((unsigned)((long)K * B)), block(256);
+    const size_t smem = sizeof(float) * 2 * M;
+    if (inverse)
+        FFNO_LAUNCH(cdft_inv_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, K);
+    else
+        FFNO_LAUNCH(cdft_fwd_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, K);
+    return s2d_status();
+}
+
+extern "C" int ffno_fw2d_pack(const float* w0, const float* w1, float* wp, float* wpt, int C, int K, void* stream) {
+    if (!w0 || !w1 || !wp || !wpt || C <= 0 || K <= 0) return FFNO_EINVAL;
+    const long total = (long)2 * K * K * 2 * C * C;
+    FFNO_LAUNCH(fw2d_pack_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, (hipStream_t)stream, w0,
+                w1, wp, wpt, C, K);
+    return s2d_status();
+}
+
+extern "C" int ffno_fw2d_grad_reduce(const float* partial, float* gw0, float* gw1, int C, int K, int nsplit,
+                                     int accumulate, void* stream) {
+    if (!partial || !gw0 || !gw1 || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    const long total = (long)2 * K * K * 2 * C * C;
+    FFNO_LAUNCH(fw2d_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
+                (hipStream_t)stream, partial, gw0, gw1, C, K, nsplit, accumulate);
+    return s2d_status();
+}

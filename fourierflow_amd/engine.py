@@ -48,7 +48,7 @@ class _Linear:
 
 class _View:
     """One spatial axis as a [Bv, Mv, Nv, C] view: a01 = 0 transforms along Nv, 1 along Mv."""
-    __slots__ = ("Bv", "Mv", "Nv", "a01", "L", "K", "R", "spec")
+    __slots__ = ("Bv", "Mv", "Nv", "a01", "L", "K", "R", "spec", "K2", "spec_y")
 
     def __init__(self, Bv, Mv, Nv, a01, K, C):
         self.Bv, self.Mv, self.Nv, self.a01, self.K = Bv, Mv, Nv, a01, K
@@ -71,7 +71,8 @@ class FFNOEngine:
 
     def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
                  share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
-                 padding: int = 0, output_dim: int = 1, use_fork: bool = False, first_axis_first: bool = False):
+                 padding: int = 0, output_dim: int = 1, use_fork: bool = False, first_axis_first: bool = False,
+                 spectral: str = "factorized"):
         if mode not in MODES:
             raise ValueError(f"mode must be one of {list(MODES)}, got {mode!r}")
         if spatial_dims not in (2, 3):
@@ -83,6 +84,11 @@ class FFNOEngine:
             raise ValueError("input_dim must be in 1..63")
         if not (1 <= output_dim <= 8):
             raise ValueError("output_dim must be in 1..8")
+        if spectral not in ("factorized", "plus"):
+            raise ValueError("spectral must be 'factorized' or 'plus'")
+        if spectral == "plus" and (spatial_dims != 2 or padding or mode == "low-pass"):
+            raise ValueError("the non-factorized (FNOPlus2DBlock) spectral conv is 2-D, unpadded, mode 'full' or 'no-fourier'")
+        self.spectral = spectral      # "plus": rfft2 + two K x K corner blocks (zongyi_fno/grid_plus_2d.py:52-83)
         self.nd = spatial_dims
         # 2-D weight order: grid_2d.py has fourier_weight[0] on the LAST axis; mesh_2d.py has [0] on the FIRST (x) axis
         self.first_axis_first = bool(first_axis_first)
@@ -135,7 +141,8 @@ class FFNOEngine:
                 names = tuple(base + str(w) for w in range(self.nd))
                 self.fw_names.append(names)
                 for w, n in enumerate(names):
-                    self.param_shapes.setdefault(n, (C, C, self.Ks[w], 2))
+                    self.param_shapes.setdefault(n, (C, C, self.Ks[w], self.Ks[w], 2) if spectral == "plus"
+                                                 else (C, C, self.Ks[w], 2))
         add_linear("out.0.", HEAD_DIM, C)
         add_linear("out.1.", output_dim, HEAD_DIM)
         self.param_names = list(self.param_shapes)
@@ -215,8 +222,9 @@ class FFNOEngine:
         n_ff = sum(l.rows * l.cols for p, l in self.linears.items() if "_ff." in p)
         self.wt_flat = torch.empty(max(n_ff, 1), **f32)
         # mode-major weight planes: planes[set][w] = (wp, wpt), each 2*K_w*C*C floats
+        plane_modes = [2 * self.K * self.K] if self.spectral == "plus" else list(self.Ks)   # plus: one joint (ky, kx') set
         self.planes = [[(torch.empty(2 * K * self.C * self.C, **f32), torch.empty(2 * K * self.C * self.C, **f32))
-                        for K in self.Ks] for _ in range(max(len(self._fw_sets), 1))]
+                        for K in plane_modes] for _ in range(max(len(self._fw_sets), 1))]
         self._ws_key = None
         self._tw = {}
 
@@ -297,6 +305,13 @@ class FFNOEngine:
     def _views(self, B: int, Sp: Sequence[int]) -> List[_View]:
         """views[w] = the axis mixed by fourier_weight[w], as a [Bv, Mv, Nv, C] view of the (padded) buffer."""
         C = self.C
+        if self.spectral == "plus":
+            M, N = Sp
+            v = _View(B, M, N, 0, self.K, C)          # geometry of the last-axis transforms
+            v.R, v.K2 = B, 2 * self.K * self.K         # rows per mode = samples; retained (ky, kx') modes
+            v.spec_y = v.spec                          # y-transformed spectrum [K][B*M][2][C]
+            v.spec = v.K2 * B * 2 * C                  # 2-D spectrum [K2][B][2][C] (what is saved for the weight gradient)
+            return [v]
         if self.nd == 2:
             M, N = Sp
             if self.first_axis_first:      # mesh_2d.py:71-75,92-96: weight 0 <-> x (first axis), weight 1 <-> y (last axis)
@@ -334,6 +349,9 @@ class FFNOEngine:
         ws.SXall = [torch.empty(ns, v.spec, **f32) for v in ws.views]      # forward spectra, per axis, layer-major
         ws.SY = torch.empty(max(v.spec for v in ws.views), **f32)
         ws.SD = torch.empty(max(v.spec for v in ws.views), **f32)    # scratch spectrum of the staged path
+        if self.spectral == "plus":
+            ws.SYa = torch.empty(ws.views[0].spec_y, **f32)           # last-axis spectra on either side of the x transform
+            ws.SYb = torch.empty(ws.views[0].spec_y, **f32)
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
         if self.use_fork:
             ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
@@ -354,7 +372,10 @@ class FFNOEngine:
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
             ws.nsplit_fw = [max(1, min(max(1, 512 // v.K), (L * v.R + 63) // 64)) for v in ws.views]
-            ws.fwpart = [[torch.empty(ws.nsplit_fw[w] * 2 * ws.views[w].K * C * C, **f32) for w in range(nv)]
+            if self.spectral == "plus":
+                ws.nsplit_fw = [1]
+            ws.fwpart = [[torch.empty(ws.nsplit_fw[w] * 2 * (ws.views[w].K2 if self.spectral == "plus" else ws.views[w].K)
+                                      * C * C, **f32) for w in range(nv)]
                          for _ in range(max(len(self._fw_sets), 1))]
             ws.nsplit_lift = max(1, min(256, (P_in + 255) // 256))
             ws.liftpart = torch.empty(ws.nsplit_lift * C * (self.Cin + 1), **f32)
@@ -371,7 +392,10 @@ class FFNOEngine:
             self._k("weightnorm_fwd", lib.ffno_weightnorm_fwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
         if self._ffx() and self._n_fx:
             self._k("ffx_pack", lib.ffno_ffx_pack, _p(self._fx_dev), self._n_fx, self.C, self.H, st)
-        for i, names in enumerate(self._fw_sets):
+        for i, names in enumerate(self._fw_sets if self.spectral == "plus" else []):
+            self._k("fw2d_pack", lib.ffno_fw2d_pack, _p(self.params[names[0]]), _p(self.params[names[1]]),
+                    _p(self.planes[i][0][0]), _p(self.planes[i][0][1]), self.C, self.K, st)
+        for i, names in enumerate(self._fw_sets if self.spectral != "plus" else []):
             for w, n in enumerate(names):
                 self._k("fw_pack", lib.ffno_fw_pack, _p(self.params[n]), _p(self.planes[i][w][0]), _p(self.planes[i][w][1]),
                         self.C, self.Ks[w], st)
@@ -426,6 +450,8 @@ class FFNOEngine:
         """Per axis: the fused branch kernel when its LDS tile holds (C, K_axis, L_axis), else the three stage kernels
         (e.g. plasticity: x with 32 modes is staged, y / z with 12 / 8 modes are fused)."""
         lib = _lib.get_lib()
+        if self.spectral == "plus":
+            return [False]
         return [bool(self.use_fused and self.mode != "no-fourier" and lib.ffno_spectral_fused_supported(self.C, v.K, v.L))
                 for v in views]
 
@@ -435,6 +461,18 @@ class FFNOEngine:
         C = self.C
         tw = self._twiddle(v.L)
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
+        if self.spectral == "plus":
+            # rfft2 = last-axis DFT (K bins) then complex DFT along the first axis (2K retained rows); corner mix with the
+            # (ky, kx') pairs as modes and the samples as rows; zero-padded inverse in the opposite order.  The adjoint
+            # is the same chain with the c_k / conjugate flags swapped (cdft_rows(inverse) is the adjoint of the forward).
+            z = save if save is not None else ws.SD
+            self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(ws.SYa), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_f, st)
+            self._k("cdft_rows", lib.ffno_cdft_rows, _p(ws.SYa), _p(z), v.Bv, v.Mv, C, v.K, 0, st)
+            self._k("mode_mix", lib.ffno_mode_mix, _p(z), _p(planes), _p(ws.SY), v.Bv, C, v.K2, conj, st)
+            self._k("cdft_rows", lib.ffno_cdft_rows, _p(ws.SY), _p(ws.SYb), v.Bv, v.Mv, C, v.K, 1, st)
+            self._k("dft_inv", lib.ffno_dft_inv, _p(ws.SYb), _p(dst), resid, _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_i,
+                    accumulate, st)
+            return
         if fused:
             self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
                     v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, ck_i, conj, accumulate, st)
@@ -629,6 +667,13 @@ class FFNOEngine:
             layers = [l for l in range(L) if self.fw_names[l] == names]
             l0_, nl = layers[0], len(layers)
             assert layers == list(range(l0_, l0_ + nl))
+            if self.spectral == "plus":
+                v = ws.views[0]
+                self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SXall[0][l0_]), _p(ws.SDall[0][l0_]),
+                        _p(ws.fwpart[si][0]), v.R, C, v.K2, ws.nsplit_fw[0], 0, nl, v.spec, v.spec, st)
+                self._k("fw2d_grad_reduce", lib.ffno_fw2d_grad_reduce, _p(ws.fwpart[si][0]), _p(gv(names[0])),
+                        _p(gv(names[1])), C, self.K, ws.nsplit_fw[0], 0, st)
+                continue
             for w, n in enumerate(names):
                 v = ws.views[w]
                 # dW = sum over the lines of every layer that uses this weight: ONE launch per axis

@@ -267,6 +267,21 @@ int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, co
                           int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Non-factorized 2-D spectral convolution (FNOPlus2DBlock, zongyi_fno/grid_plus_2d.py:52-83):
+ *   rfft2 -> two K x K corner blocks (rows [0,K) and [M-K,M), columns [0,K)) mixed with their own
+ *   weights [I][O][K][K][2] -> zero-padded irfft2.  The last-axis transforms, the per-mode mix and the
+ *   weight-gradient contraction are ffno_dft_fwd / ffno_mode_mix / ffno_dft_inv / ffno_fw_grad_partial with
+ *   the 2K*K retained (kx', ky) pairs as modes (mode = ky*2K + kx') and the B samples as rows; these
+ *   entry points add the complex DFT along the first axis and the weight layout conversions.
+ *   ffno_cdft_rows: inverse = 0:  Z[ky][kx'][b][re/im][c] = 1/sqrt(M) sum_m e^{-2 pi i kx m/M} S[ky][b*M+m][re/im][c]
+ *                   inverse = 1:  the zero-padded inverse (also the adjoint of the forward);  2K <= M.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, int K, int inverse, void* stream);
+int ffno_fw2d_pack(const float* w0, const float* w1, float* wp, float* wpt, int C, int K, void* stream);
+int ffno_fw2d_grad_reduce(const float* partial, float* gw0, float* gw1, int C, int K, int nsplit,
+                          int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Velocity features of the Markov routine (routines/grid_2d_markov.py:130-144, `use_velocity: true`,
  * wavenumber buffers :82-94): vorticity[B][X][Y] -> out[B][X][Y][3] = (vorticity, u, v) with
  *   psi^ = -rfftn(w)/lap,  u = irfftn(2 pi i ky psi^),  v = irfftn(-2 pi i kx psi^)

@@ -103,12 +103,27 @@ def forward_fourier(x: Tensor, w_y: Optional[Tensor], w_x: Optional[Tensor], mod
     return (xx + xy).permute(0, 2, 3, 1)
 
 
+def forward_fourier_plus(x: Tensor, w0: Tensor, w1: Tensor, modes: int) -> Tensor:
+    """Non-factorized spectral conv of FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py:52-83): rfft2(norm='ortho'), the two
+    corner blocks [:K, :K] and [-K:, :K] mixed with w0 / w1 [I, O, K, K, 2], zero-padded irfft2."""
+    x_cf = x.permute(0, 3, 1, 2)
+    B, I, M, N = x_cf.shape
+    x_ft = torch.fft.rfft2(x_cf, s=(M, N), norm="ortho")
+    out_ft = x_ft.new_zeros(B, w0.shape[1], M, N // 2 + 1)
+    out_ft[:, :, :modes, :modes] = torch.einsum("bixy,ioxy->boxy", x_ft[:, :, :modes, :modes],
+                                                torch.view_as_complex(w0.contiguous()))
+    out_ft[:, :, -modes:, :modes] = torch.einsum("bixy,ioxy->boxy", x_ft[:, :, -modes:, :modes],
+                                                 torch.view_as_complex(w1.contiguous()))
+    return torch.fft.irfft2(out_ft, s=(M, N), norm="ortho").permute(0, 2, 3, 1)
+
+
 # --------------------------------------------------------------------------
-# FNOFactorized2DBlock.forward  (grid_2d.py:154-177)
+# FNOFactorized2DBlock.forward  (grid_2d.py:154-177); with spectral="plus" the same block around the non-factorized
+# spectral conv = FNOPlus2DBlock.forward (zongyi_fno/grid_plus_2d.py:138-161)
 # --------------------------------------------------------------------------
 def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
                  use_fork: bool = False, mode: str = "full", n_ff_layers: int = 2,
-                 layer_norm: bool = False, return_intermediates: bool = False):
+                 layer_norm: bool = False, return_intermediates: bool = False, spectral: str = "factorized"):
     """Forward of the whole block over a reference-layout state_dict.
 
     Returns {'forecast', 'forecast_list'} like the reference; with
@@ -125,7 +140,9 @@ def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
     for i in range(n_layers):
         pre = f"spectral_layers.{i}."
         s = x
-        if mode != "no-fourier":
+        if mode != "no-fourier" and spectral == "plus":
+            s = forward_fourier_plus(x, sd[pre + "fourier_weight.0"], sd[pre + "fourier_weight.1"], modes)
+        elif mode != "no-fourier":
             s = forward_fourier(x, sd.get(pre + "fourier_weight.0"), sd.get(pre + "fourier_weight.1"),
                                 modes, mode)
         b = feedforward(sd, pre + "backcast_ff.", s, n_ff_layers, layer_norm)

@@ -55,8 +55,9 @@ def _ff(rs, width, factor, wnorm, n_ff_layers, layer_norm):
     return sd
 
 
-def make_block_state_dict(kw: dict, seed: int) -> Dict[str, np.ndarray]:
-    """Reference-layout state_dict (incl. duplicated shared keys) for FNOFactorized2DBlock(**kw)."""
+def make_block_state_dict(kw: dict, seed: int, plus: bool = False) -> Dict[str, np.ndarray]:
+    """Reference-layout state_dict (incl. duplicated shared keys) for FNOFactorized2DBlock(**kw); ``plus``: for
+    FNOPlus2DBlock(**kw) -- identical structure, Fourier weights [C, C, K, K, 2] (grid_plus_2d.py:22-29)."""
     kw = full_kwargs(kw)
     rs = np.random.RandomState(seed)
     C, K = kw["width"], kw["modes"]
@@ -65,6 +66,9 @@ def make_block_state_dict(kw: dict, seed: int) -> Dict[str, np.ndarray]:
     _linear(rs, sd, "in_proj.", kw["input_dim"], C, wn)
 
     def fourier_pair():
+        if plus:
+            std = 2.0 * kw["gain"] * math.sqrt(2.0 / (2 * C * K * K * 2))   # (x2: keeps the spectral path visible)
+            return [(rs.standard_normal((C, C, K, K, 2)) * std).astype(np.float32) for _ in range(2)]
         std = kw["gain"] * math.sqrt(2.0 / (2 * C * K * 2))
         return [(rs.standard_normal((C, C, K, 2)) * std).astype(np.float32) for _ in range(2)]
 

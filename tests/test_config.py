@@ -88,6 +88,8 @@ REFERENCE_CONFIGS = [
     ("plasticity/ffno/12_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh3D"),
     ("airfoil/ffno/24_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh2D"),
     ("pipe/ffno/8_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh2D"),
+    ("torus_kochkov/ffno/ablation/fno++/128", "Grid2DMarkovExperiment", "conv", "FNOPlus2DBlock"),
+    ("torus_kochkov/ffno/grid_sizes/256", "Grid2DMarkovExperiment", "conv", "FNOFactorized2DBlock"),
 ]
 
 
@@ -126,7 +128,7 @@ def test_every_shipped_ffno_config_builds():
     if not paths:
         pytest.skip("reference experiments are only present in the build container")
     from fourierflow_amd.config import build_routine, load_config
-    known = ("FNOPlus2DBlock", "FNOZongyi2DBlock", "FNOMesh2D", "FNOMesh3D", "PointCloud", "CNOFactorized", "IPhi",
+    known = ("FNOZongyi2DBlock", "FNOMesh2D", "FNOMesh3D", "PointCloud", "CNOFactorized", "IPhi",
              "only torch.optim.AdamW", "only CosineWithWarmupScheduler", "optax", "shuffle_grid", "use_fourier_position",
              "MeshGraphNet", "LearnedInterpolator", "Grid2DRolloutExperiment")
     built, unexpected = 0, []
@@ -140,4 +142,4 @@ def test_every_shipped_ffno_config_builds():
         except Exception as e:  # noqa: BLE001 - anything else is a loader bug
             unexpected.append((os.path.relpath(p, root), repr(e)))
     assert not unexpected, unexpected[:5]
-    assert built >= 130, built
+    assert built >= 150, built
