@@ -81,69 +81,62 @@ __global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ 
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
+    const int nsteps = (L + 1) >> 1;
 
-    float amul[RT];
-    int tbase[RT], step[RT], idx0[RT];
-    FFNO_UNROLL
-    for (int rt = 0; rt < RT; ++rt) {
+    // work item = (line, 32-row tile of the (mode, re/im) rows): with more than 16 modes a line is shared by RT waves
+    const long nitems = (long)R * RT;
+    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+        const int line = (int)(item / RT), rt = (int)(item % RT);
         const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
         const bool valid = kk < 2 * K;
         const float ck = (scale_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
-        amul[rt] = valid ? (ri ? -ck : ck) : 0.f;
-        tbase[rt] = ri ? L : 0;
+        const float amul = valid ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
         const int km = valid ? k : 0;
-        step[rt] = (2 * km) % L;
-        idx0[rt] = (km * half) % L;
-    }
-    const int nsteps = (L + 1) >> 1;
-
-    for (int line = blockIdx.x * 4 + wave; line < R; line += gridDim.x * 4) {
+        const int step = (2 * km) % L;
+        int idx = (km * half) % L;
         const float* xl = x + lm.base(line) + CT * j;
-        f32x16 acc[RT][CT];
-        int idx[RT];
+        f32x16 acc[CT];
         FFNO_UNROLL
-        for (int rt = 0; rt < RT; ++rt) {
-            idx[rt] = idx0[rt];
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = zero16();
+        // eight k-steps per trip; the rows of trip i+1 are requested before trip i's MFMAs (two register buffers), so a
+        // long line (L = 256: 16 trips) is not paced by one memory round trip per trip
+        constexpr int UN = 8;
+        ColVec<CT> b[UN], bn[UN];
+        auto load_trip = [&](ColVec<CT> (&dst)[UN], int t0) {
             FFNO_UNROLL
-            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = zero16();
-        }
-        for (int t0 = 0; t0 < nsteps; t0 += 4) {
-            // four k-steps per trip: issue all loads first (tail steps read zeros), then the MFMAs
-            ColVec<CT> b[4];
-            FFNO_UNROLL
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) {
                 const int n = 2 * (t0 + u) + half;
                 if (n < L) {
-                    b[u].load(xl + (long)n * lm.elem_stride);
+                    dst[u].load(xl + (long)n * lm.elem_stride);
                 } else {
                     FFNO_UNROLL
-                    for (int ct = 0; ct < CT; ++ct) b[u].v[ct] = 0.f;
+                    for (int ct = 0; ct < CT; ++ct) dst[u].v[ct] = 0.f;
                 }
             }
+        };
+        load_trip(bn, 0);
+        for (int t0 = 0; t0 < nsteps; t0 += UN) {
             FFNO_UNROLL
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UN; ++u) b[u] = bn[u];
+            if (t0 + UN < nsteps) load_trip(bn, t0 + UN);
+            FFNO_UNROLL
+            for (int u = 0; u < UN; ++u) {
+                const float a = amul * tws[tbase + idx];
+                idx += step;
+                if (idx >= L) idx -= L;
                 FFNO_UNROLL
-                for (int rt = 0; rt < RT; ++rt) {
-                    const float a = amul[rt] * tws[tbase[rt] + idx[rt]];
-                    idx[rt] += step[rt];
-                    if (idx[rt] >= L) idx[rt] -= L;
-                    FFNO_UNROLL
-                    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = mfma32(a, b[u].v[ct], acc[rt][ct]);
-                }
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = mfma32(a, b[u].v[ct], acc[ct]);
             }
         }
         FFNO_UNROLL
-        for (int rt = 0; rt < RT; ++rt) {
-            FFNO_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int kk = 32 * rt + drow(r, half);
-                if (kk < 2 * K) {
-                    const int k = kk >> 1, ri = kk & 1;
-                    ColVec<CT> o;
-                    FFNO_UNROLL
-                    for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[rt][ct][r];
-                    o.store(spec + (((long)k * R + line) * 2 + ri) * C + CT * j);
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int kr = 32 * rt + drow(r, half);
+            if (kr < 2 * K) {
+                ColVec<CT> o;
+                FFNO_UNROLL
+                for (int ct = 0; ct < CT; ++ct) o.v[ct] = acc[ct][r];
+                o.store(spec + (((long)(kr >> 1) * R + line) * 2 + (kr & 1)) * C + CT * j);
             }
         }
     }
@@ -168,9 +161,14 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
     const int tbase = half ? L : 0;
     const int RTtot = (L + 31) >> 5;
 
-    for (int line = blockIdx.x * 4 + wave; line < R; line += gridDim.x * 4) {
+    // work item = (line, pair of 32-row output tiles): long lines (L = 256: four pairs) spread over four waves
+    const int NP = (RTtot + 1) >> 1;
+    const long nitems = (long)R * NP;
+    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+        const int line = (int)(item / NP);
         const long lbase = lm.base(line) + CT * j;
-        for (int rt0 = 0; rt0 < RTtot; rt0 += 2) {
+        {
+            const int rt0 = 2 * (int)(item % NP);
             const int n0 = 32 * rt0 + j, n1 = n0 + 32;  // A-operand rows of the two tiles
             const int st0 = n0 % L, st1 = n1 % L;
             int i0 = 0, i1 = 0;
@@ -180,18 +178,24 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
                 FFNO_UNROLL
                 for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
             }
-            for (int t0 = 0; t0 < K; t0 += 4) {
-                ColVec<CT> b[4];
+            ColVec<CT> b[4], bn[4];
+            auto load_trip = [&](ColVec<CT> (&dst)[4], int t0) {
                 FFNO_UNROLL
                 for (int u = 0; u < 4; ++u) {
                     const int t = t0 + u;
                     if (t < K) {
-                        b[u].load(spec + (((long)t * R + line) * 2 + half) * C + CT * j);
+                        dst[u].load(spec + (((long)t * R + line) * 2 + half) * C + CT * j);
                     } else {
                         FFNO_UNROLL
-                        for (int ct = 0; ct < CT; ++ct) b[u].v[ct] = 0.f;
+                        for (int ct = 0; ct < CT; ++ct) dst[u].v[ct] = 0.f;
                     }
                 }
+            };
+            load_trip(bn, 0);
+            for (int t0 = 0; t0 < K; t0 += 4) {
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) b[u] = bn[u];
+                if (t0 + 4 < K) load_trip(bn, t0 + 4);    // next trip's rows arrive under this trip's MFMAs
                 FFNO_UNROLL
                 for (int u = 0; u < 4; ++u) {
                     const int t = t0 + u;
@@ -772,7 +776,7 @@ extern "C" int ffno_dft_fwd(const float* x, float* spec, const float* tw, int B,
     if (K > L / 2 + 1) return FFNO_EMODES;
     const int RT = (2 * K + 31) / 32;
     const LineMap lm = make_linemap(axis, B, M, N, C);
-    const dim3 grid(min((R + 3) / 4, 4096)), block(256);
+    const dim3 grid((unsigned)min(((long)R * RT + 3) / 4, 8192L)), block(256);
     const size_t smem = sizeof(float) * 2 * L;
     hipStream_t s = (hipStream_t)stream;
 #define FFNO_DFT_FWD_CASE(CC, RR)                                                                        \
@@ -799,7 +803,8 @@ extern "C" int ffno_dft_inv(const float* spec, float* out, const float* resid, c
     const int R = axis == 0 ? B * M : B * N;
     if (K > L / 2 + 1) return FFNO_EMODES;
     const LineMap lm = make_linemap(axis, B, M, N, C);
-    const dim3 grid(min((R + 3) / 4, 4096)), block(256);
+    const long items = (long)R * ((((L + 31) >> 5) + 1) >> 1);       // (line, pair of 32-row output tiles)
+    const dim3 grid((unsigned)min((items + 3) / 4, 8192L)), block(256);
     const size_t smem = sizeof(float) * 2 * L;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64) {
