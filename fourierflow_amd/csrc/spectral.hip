@@ -260,12 +260,14 @@ __global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 }
 
 // ---- stage B ------------------------------------------------------------------------------------
-// Block = (mode k, chunk of row tiles); 4 waves, each owns one 32-line tile at a time.
+// Block = (mode k, chunk of work items); work item = (32-line tile, output part q = re | im), one per wave.
 // D[line][(q,o)] = sum_{(p,i)} X[line][(p,i)] * Wb[(p,i)][(q,o)]  with the 2x2 real block form of the
 // complex product.  A operand: each lane keeps its line's C floats of part `half` (re or im) in
 // registers, loaded straight from global memory with 16-B loads (the [lines][2C] panel of a mode is
-// contiguous, every byte of every fetched line is used).  B operand: the mode's two weight planes in
-// LDS (32 KiB at C=64), lanes read consecutive floats (conflict-free).
+// contiguous, every byte of every fetched line is used; the two waves of a tile read the same panel).
+// B operand: the mode's two weight planes in LDS (32 KiB at C=64), lanes read consecutive floats
+// (conflict-free).  Splitting a tile's two output parts over two waves doubles the number of waves a
+// launch can spread over the chip (256x256 grids: 16 tiles per mode).
 template <int C>
 __global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restrict__ spec_in,
                                                        const float* __restrict__ planes,
@@ -281,23 +283,24 @@ __global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restric
     const int j = lane & 31, half = lane >> 5;
     const float* xin = spec_in + (long)k * R * 2 * C;
     float* yout = spec_out + (long)k * R * 2 * C;
-    const int ntiles = (R + 31) >> 5;
-    int tile = blockIdx.x * 4 + wave;
+    const int nitems = 2 * ((R + 31) >> 5);
+    int item = blockIdx.x * 4 + wave;
 
-    // first tile's A fragment is requested before the weight planes are staged (latencies overlap)
+    // first item's A fragment is requested before the weight planes are staged (latencies overlap)
     float a[C];
-    {
-        const int row = tile * 32 + j;
+    auto load_a = [&](int it) {
+        const int row = (it >> 1) * 32 + j;
         FFNO_UNROLL
         for (int u = 0; u < C / 4; ++u) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tile < ntiles && row < R) v = *reinterpret_cast<const float4*>(xin + ((long)row * 2 + half) * C + 4 * u);
+            if (it < nitems && row < R) v = *reinterpret_cast<const float4*>(xin + ((long)row * 2 + half) * C + 4 * u);
             a[4 * u + 0] = v.x;
             a[4 * u + 1] = v.y;
             a[4 * u + 2] = v.z;
             a[4 * u + 3] = v.w;
         }
-    }
+    };
+    load_a(item);
     {
         const float* pk = planes + (long)k * 2 * C * C;
         for (int i = threadIdx.x * 4; i < 2 * C * C; i += blockDim.x * 4)
@@ -305,62 +308,32 @@ __global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restric
     }
     __syncthreads();
 
-    // per-lane plane selection / sign of the real block form (see ffno_mode_mix in include/ffno.h)
-    const float* plane[2];
-    float sign[2];
-    FFNO_UNROLL
-    for (int q = 0; q < 2; ++q) {
-        plane[q] = (half == q) ? Wr : Wi;
-        if (conj_t == 0)
-            sign[q] = (half == 1 && q == 0) ? -1.f : 1.f;
-        else
-            sign[q] = (half == 0 && q == 1) ? -1.f : 1.f;
-    }
-
-    for (; tile < ntiles; tile += gridDim.x * 4) {
-        const int row0 = tile * 32;
-        f32x16 acc[2][CT];
+    for (; item < nitems; item += gridDim.x * 4) {
+        const int row0 = (item >> 1) * 32, q = item & 1;
+        // per-lane plane selection / sign of the real block form (see ffno_mode_mix in include/ffno.h)
+        const float* plane = (half == q) ? Wr : Wi;
+        const float sign = conj_t == 0 ? ((half == 1 && q == 0) ? -1.f : 1.f) : ((half == 0 && q == 1) ? -1.f : 1.f);
+        f32x16 acc[CT];
         FFNO_UNROLL
-        for (int q = 0; q < 2; ++q) {
-            FFNO_UNROLL
-            for (int ct = 0; ct < CT; ++ct) acc[q][ct] = zero16();
-        }
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = zero16();
         FFNO_UNROLL
         for (int t = 0; t < C; ++t) {
             if ((t & 7) == 0) FFNO_SCHED_FENCE();
             FFNO_UNROLL
-            for (int q = 0; q < 2; ++q) {
-                FFNO_UNROLL
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float b = sign[q] * plane[q][t * C + 32 * ct + j];
-                    acc[q][ct] = mfma32(a[t], b, acc[q][ct]);
-                }
+            for (int ct = 0; ct < CT; ++ct) {
+                const float b = sign * plane[t * C + 32 * ct + j];
+                acc[ct] = mfma32(a[t], b, acc[ct]);
             }
         }
         FFNO_SCHED_FENCE();
-        // next tile's fragment (if any) is in flight while this tile's results are stored
-        {
-            const int nrow = (tile + gridDim.x * 4) * 32 + j;
-            const bool more = (tile + gridDim.x * 4) < ntiles;
-            FFNO_UNROLL
-            for (int u = 0; u < C / 4; ++u) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (more && nrow < R) v = *reinterpret_cast<const float4*>(xin + ((long)nrow * 2 + half) * C + 4 * u);
-                a[4 * u + 0] = v.x;
-                a[4 * u + 1] = v.y;
-                a[4 * u + 2] = v.z;
-                a[4 * u + 3] = v.w;
-            }
-        }
+        // next item's fragment (if any) is in flight while this item's results are stored
+        load_a(item + gridDim.x * 4);
         FFNO_UNROLL
-        for (int q = 0; q < 2; ++q) {
+        for (int ct = 0; ct < CT; ++ct) {
             FFNO_UNROLL
-            for (int ct = 0; ct < CT; ++ct) {
-                FFNO_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + drow(r, half);
-                    if (row < R) yout[((long)row * 2 + q) * C + 32 * ct + j] = acc[q][ct][r];
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + drow(r, half);
+                if (row < R) yout[((long)row * 2 + q) * C + 32 * ct + j] = acc[ct][r];
             }
         }
     }
@@ -831,9 +804,9 @@ extern "C" int ffno_mode_mix(const float* spec_in, const float* planes, float* s
                              int conj_transpose, void* stream) {
     if (!spec_in || !planes || !spec_out || R <= 0 || K <= 0) return FFNO_EINVAL;
     if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
-    const int ntiles = (R + 31) / 32;
-    // enough row-chunks that K * chunks covers the chip (256 CUs), at most one tile per wave per pass
-    int chunks = max(1, min((ntiles + 3) / 4, max(1, 512 / K)));
+    const int nitems = 2 * ((R + 31) / 32);      // (32-line tile, re | im output part) per mode, one per wave
+    // enough item-chunks that K * chunks covers the chip (256 CUs, two workgroups each), at most one item per wave per pass
+    int chunks = max(1, min((nitems + 3) / 4, max(1, 1024 / K)));
     const dim3 grid(chunks, K), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
