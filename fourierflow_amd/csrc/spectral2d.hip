@@ -31,25 +31,29 @@ __device__ __forceinline__ void sincos_2pi_frac2(int k, int n, float& s, float& 
 __device__ __forceinline__ int kx_of(int kxp, int K, int M) { return kxp < K ? kxp : M - 2 * K + kxp; }
 
 // forward:  Z[ky][kx'][b][ri][c] = 1/sqrt(M) sum_m e^{-2 pi i kx m / M} S[ky][b*M + m][ri][c]
-// block = (ky, b); thread = (channel c, group g of output rows); twiddle table in LDS
+// block = (ky, b); the [M][2C] slab of the sample is staged in LDS (coalesced), thread = (channel c, group g of output
+// rows); twiddle table in LDS, index advanced incrementally (kx m mod M)
 __global__ __launch_bounds__(256) void cdft_fwd_kernel(const float* __restrict__ S, float* __restrict__ Z, int B, int M,
                                                        int C, int K) {
     FFNO_DYN_SMEM(smem);
     float* ct = reinterpret_cast<float*>(smem);
     float* st = ct + M;
+    float* slab = st + M;                          // [M][2C]
     const int ky = blockIdx.x / B, b = blockIdx.x % B;
+    const float* src = S + ((long)ky * B * M + (long)b * M) * 2 * C;
     for (int m = threadIdx.x; m < M; m += blockDim.x) sincos_2pi_frac2(m, M, st[m], ct[m]);
+    for (int e = threadIdx.x * 4; e < M * 2 * C; e += blockDim.x * 4)
+        *reinterpret_cast<float4*>(slab + e) = *reinterpret_cast<const float4*>(src + e);
     __syncthreads();
     const int G = blockDim.x / C;                 // row groups
     const int c = threadIdx.x % C, g = threadIdx.x / C;
-    const float* src = S + ((long)ky * B * M + (long)b * M) * 2 * C;       // [m][ri][c]
     const float scale = rsqrtf((float)M);
     for (int kxp = g; kxp < 2 * K; kxp += G) {
         const int kx = kx_of(kxp, K, M);
         float re = 0.f, im = 0.f;
         int idx = 0;
         for (int m = 0; m < M; ++m) {             // (a + i bb)(cos - i sin)
-            const float a = src[(long)m * 2 * C + c], bb = src[(long)m * 2 * C + C + c];
+            const float a = slab[m * 2 * C + c], bb = slab[m * 2 * C + C + c];
             const float cs = ct[idx], sn = st[idx];
             re += a * cs + bb * sn;
             im += bb * cs - a * sn;
@@ -63,13 +67,21 @@ __global__ __launch_bounds__(256) void cdft_fwd_kernel(const float* __restrict__
 }
 
 // inverse:  S[ky][b*M + m][ri][c] = 1/sqrt(M) sum_{kx'} e^{+2 pi i kx m / M} Z[ky][kx'][b][ri][c]
+// the sample's [2K][2C] retained rows are staged in LDS; the two runs of kx (0..K-1 and M-K..M-1) advance the twiddle
+// index by m per step
 __global__ __launch_bounds__(256) void cdft_inv_kernel(const float* __restrict__ Z, float* __restrict__ S, int B, int M,
                                                        int C, int K) {
     FFNO_DYN_SMEM(smem);
     float* ct = reinterpret_cast<float*>(smem);
     float* st = ct + M;
+    float* slab = st + M;                          // [2K][2C]
     const int ky = blockIdx.x / B, b = blockIdx.x % B;
     for (int m = threadIdx.x; m < M; m += blockDim.x) sincos_2pi_frac2(m, M, st[m], ct[m]);
+    for (int e = threadIdx.x * 4; e < 2 * K * 2 * C; e += blockDim.x * 4) {
+        const int kxp = e / (2 * C), off = e % (2 * C);
+        *reinterpret_cast<float4*>(slab + e) =
+            *reinterpret_cast<const float4*>(Z + (((long)ky * 2 * K + kxp) * B + b) * 2 * C + off);
+    }
     __syncthreads();
     const int G = blockDim.x / C;
     const int c = threadIdx.x % C, g = threadIdx.x / C;
@@ -77,13 +89,18 @@ __global__ __launch_bounds__(256) void cdft_inv_kernel(const float* __restrict__
     float* dst = S + ((long)ky * B * M + (long)b * M) * 2 * C;
     for (int m = g; m < M; m += G) {
         float re = 0.f, im = 0.f;
-        for (int kxp = 0; kxp < 2 * K; ++kxp) {   // (a + i bb)(cos + i sin)
-            const float* z = Z + (((long)ky * 2 * K + kxp) * B + b) * 2 * C;
-            const float a = z[c], bb = z[C + c];
-            const int idx = (int)(((long)kx_of(kxp, K, M) * m) % M);
-            const float cs = ct[idx], sn = st[idx];
-            re += a * cs - bb * sn;
-            im += a * sn + bb * cs;
+        FFNO_UNROLL
+        for (int run = 0; run < 2; ++run) {       // kx = 0..K-1, then kx = M-K..M-1
+            int idx = run == 0 ? 0 : (int)(((long)(M - K) * m) % M);
+            for (int t = 0; t < K; ++t) {         // (a + i bb)(cos + i sin)
+                const float* z = slab + (run * K + t) * 2 * C;
+                const float a = z[c], bb = z[C + c];
+                const float cs = ct[idx], sn = st[idx];
+                re += a * cs - bb * sn;
+                im += a * sn + bb * cs;
+                idx += m;
+                if (idx >= M) idx -= M;
+            }
         }
         dst[(long)m * 2 * C + c] = re * scale;
         dst[(long)m * 2 * C + C + c] = im * scale;
@@ -138,7 +155,15 @@ extern "C" int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, 
     if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
     if (2 * K > M) return FFNO_EMODES;
     const dim3 grid((unsigned)((long)K * B)), block(256);
-    const size_t smem = sizeof(float) * 2 * M;
+    const size_t smem = sizeof(float) * (2 * (size_t)M + (inverse ? (size_t)2 * K * 2 * C : (size_t)M * 2 * C));
+    if (smem > 150 * 1024) return FFNO_EUNSUPPORTED;    // the staged slab must fit LDS (M <= 288 at C = 64)
+#ifndef FFNO_EMU
+    if (smem > 48 * 1024) {     // dynamic LDS beyond the default window needs an explicit opt-in
+        hipError_t e = hipFuncSetAttribute(inverse ? (const void*)cdft_inv_kernel : (const void*)cdft_fwd_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+#endif
     if (inverse)
         FFNO_LAUNCH(cdft_inv_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, K);
     else
