@@ -805,8 +805,9 @@ extern "C" int ffno_mode_mix(const float* spec_in, const float* planes, float* s
     if (!spec_in || !planes || !spec_out || R <= 0 || K <= 0) return FFNO_EINVAL;
     if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
     const int nitems = 2 * ((R + 31) / 32);      // (32-line tile, re | im output part) per mode, one per wave
-    // enough item-chunks that K * chunks covers the chip (256 CUs, two workgroups each), at most one item per wave per pass
-    int chunks = max(1, min((nitems + 3) / 4, max(1, 1024 / K)));
+    // enough item-chunks that K * chunks covers the chip once (256 CUs, two resident workgroups each); beyond that a wave
+    // takes several items per staged weight image
+    int chunks = max(1, min((nitems + 3) / 4, max(1, 512 / K)));
     const dim3 grid(chunks, K), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
