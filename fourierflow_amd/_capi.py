@@ -24,6 +24,11 @@ class FxPackDesc(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("sh", C.c_int32), ("sc", C.c_int32), ("type", C.c_int32), ("pad_", C.c_int32)]
 
 
+class FxRedDesc(C.Structure):
+    """Mirror of ``ffno_fxred_desc`` (include/ffno.h)."""
+    _fields_ = [("partial", P), ("dW1", P), ("dW2", P), ("db1", P), ("db2", P)]
+
+
 class MarkovExtra(C.Structure):
     """Mirror of ``ffno_markov_extra`` (include/ffno.h)."""
     _fields_ = [("force", P), ("mu", P), ("use_position", C.c_int32), ("pad_", C.c_int32)]
@@ -67,6 +72,7 @@ SIGNATURES = {
     "ffno_ffx_bwd_data": (I, [P, P, P, P, P, I, I, I, P]),
     "ffno_ffx_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "ffno_ffx_bwd_weights_reduce_batched": (I, [P, I, I, I, I, P]),
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),
     "ffno_transpose_batched": (I, [P, I, I, I, P]),

@@ -522,6 +522,46 @@ __global__ __launch_bounds__(256) void ffx_wgrad_reduce_kernel(const float* __re
     }
 }
 
+// the same reduction for a table of feed-forward blocks in ONE launch (blockIdx.y = block): every layer of a backward pass
+// writes its slices to its own partial buffer and the 24 small reductions become one kernel boundary
+struct FxRedDesc {
+    const float* partial;
+    float *dW1, *dW2, *db1, *db2;
+};
+
+__global__ __launch_bounds__(256) void ffx_wgrad_reduce_batched_kernel(const FxRedDesc* __restrict__ descs, int C, int H,
+                                                                       int nsplit) {
+    __shared__ float red[4][64];
+    const FxRedDesc d = descs[blockIdx.y];
+    const int part = 2 * H * C + H + C;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    float sum = 0.f;
+    if (e < part) {
+        float t[8];
+        int sp = sg;
+        for (; sp + 28 < nsplit; sp += 32) {
+            FFNO_UNROLL
+            for (int u = 0; u < 8; ++u) t[u] = d.partial[(long)(sp + 4 * u) * part + e];
+            FFNO_UNROLL
+            for (int u = 0; u < 8; ++u) sum += t[u];
+        }
+        for (; sp < nsplit; sp += 4) sum += d.partial[(long)sp * part + e];
+    }
+    red[sg][threadIdx.x & 63] = sum;
+    __syncthreads();
+    if (sg == 0 && e < part) {
+        sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (e < H * C)
+            d.dW1[(e % H) * C + e / H] = sum;
+        else if (e < 2 * H * C)
+            d.dW2[e - H * C] = sum;
+        else if (e < 2 * H * C + H)
+            d.db1[e - 2 * H * C] = sum;
+        else
+            d.db2[e - 2 * H * C - H] = sum;
+    }
+}
+
 static inline int ffx_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -616,5 +656,15 @@ extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, flo
     const int part = 2 * H * C + H + C;
     FFNO_LAUNCH(ffx_wgrad_reduce_kernel, dim3((part + 63) / 64), dim3(256), 0, (hipStream_t)stream, partial, dW1, dW2,
                 db1, db2, C, H, nsplit, accumulate);
+    return ffx_launch_status();
+}
+
+extern "C" int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_dev, int n, int C, int H, int nsplit,
+                                                   void* stream) {
+    if (!descs_dev || n <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    static_assert(sizeof(ffno_fxred_desc) == sizeof(FxRedDesc), "descriptor layout");
+    const int part = 2 * H * C + H + C;
+    FFNO_LAUNCH(ffx_wgrad_reduce_batched_kernel, dim3((part + 63) / 64, n), dim3(256), 0, (hipStream_t)stream,
+                reinterpret_cast<const FxRedDesc*>(descs_dev), C, H, nsplit);
     return ffx_launch_status();
 }

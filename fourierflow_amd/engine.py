@@ -371,6 +371,13 @@ class FFNOEngine:
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
+            # split-bf16 path with per-layer feed-forwards: every layer keeps its own slices and ONE batched launch
+            # reduces them all at the end of the backward pass (24 kernel boundaries less per step)
+            ws.defer_reduce = bool(self._ffx() and not self.share_fork)
+            if ws.defer_reduce:
+                njobs = L * (2 if self.use_fork else 1)
+                ws.ffparts = torch.empty(njobs, ws.ffpart.numel(), **f32)
+                ws.red_sig, ws.red_table = None, None
             ws.nsplit_fw = [max(1, min(max(1, 512 // v.K), (L * v.R + 63) // 64)) for v in ws.views]
             if self.spectral == "plus":
                 ws.nsplit_fw = [1]
@@ -435,7 +442,13 @@ class FFNOEngine:
     def _ff_bwd_weights(self, ws, s, g, hbuf, dh, l0, l1, b0, gb0, gb1, accumulate, P, st):
         lib = _lib.get_lib()
         C, H = self.C, self.H
-        if self._ffx():
+        if self._ffx() and ws.defer_reduce:
+            assert not accumulate
+            part = ws.ffparts[len(ws.red_jobs)]
+            self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0),
+                    _p(l0.fx[2]), _p(part), P, C, H, ws.nsplit_ff, st)
+            ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gb0.data_ptr(), gb1.data_ptr()))
+        elif self._ffx():
             self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0),
                     _p(l0.fx[2]), _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
             self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
@@ -596,6 +609,7 @@ class FFNOEngine:
         if not self._ffx():
             self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
+        ws.red_jobs = []
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
@@ -659,6 +673,14 @@ class FFNOEngine:
             cur = 1 - cur
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
+        if getattr(ws, "defer_reduce", False) and ws.red_jobs:
+            sig = tuple(ws.red_jobs)
+            if sig != ws.red_sig:       # pointers only change when parameters are re-bound or the workspace is rebuilt
+                arr = (_capi.FxRedDesc * len(sig))(*[_capi.FxRedDesc(*j) for j in sig])
+                ws.red_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+                ws.red_sig = sig
+            self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce_batched, _p(ws.red_table), len(sig), C, H,
+                    ws.nsplit_ff, st)     # main stream: it has already waited for the side stream's partial kernels
         g_fin = ws.G[cur]
         lin_in = self.linears["in_proj."]
         self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")),

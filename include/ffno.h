@@ -198,6 +198,16 @@ int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk
                                  void* stream);
 int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2,
                                 int C, int H, int nsplit, int accumulate, void* stream);
+/* the same reduction (overwrite) for a device-resident table of n feed-forward blocks in one launch */
+typedef struct ffno_fxred_desc {
+    const float* partial;
+    float* dW1;
+    float* dW2;
+    float* db1;
+    float* db2;
+} ffno_fxred_desc;
+int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_dev, int n, int C, int H, int nsplit,
+                                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight normalisation (linear.py:48-49, torch.nn.utils.weight_norm dim=0), batched over a
