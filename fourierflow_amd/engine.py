@@ -226,6 +226,7 @@ class FFNOEngine:
         self.planes = [[(torch.empty(2 * K * self.C * self.C, **f32), torch.empty(2 * K * self.C * self.C, **f32))
                         for K in plane_modes] for _ in range(max(len(self._fw_sets), 1))]
         self._ws_key = None
+        self._ws_cache = {}
         self._tw = {}
 
     def grad_view(self, name: str) -> torch.Tensor:
@@ -326,6 +327,10 @@ class FFNOEngine:
         key = (B, tuple(S), bool(save), self._ffx())
         if self._ws_key == key:
             return self._ws
+        cache = self.__dict__.setdefault("_ws_cache", {})   # a few recent geometries (train batch / validation batch /
+        if key in cache:                                     # rollout batch alternate in a real run): no re-allocation
+            self._ws, self._ws_key = cache[key], key
+            return self._ws
         lib = _lib.get_lib()
         dev, C, H, L, O = self.device, self.C, self.H, self.L, self.O
         Sp = tuple(s + self.pad for s in S)
@@ -390,6 +395,9 @@ class FFNOEngine:
             ws.headpart = torch.empty(ws.nsplit_head * O * (C + 1), **f32)
             ws.red = torch.empty(O * (C + 1), **f32)
         self._ws, self._ws_key = ws, key
+        cache[key] = ws
+        while len(cache) > 4:
+            cache.pop(next(iter(cache)))
         return ws
 
     def _prepare_weights(self, st):
