@@ -75,7 +75,7 @@ class KernelTimer:
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in prs)
         # a bracket around a real kernel hides part of that latency behind the kernel: 0.6 x the empty-pair time is what
-        # reproduces rocprofv3's kernel-trace averages (profiles/r01_v5_kernel_stats.md: 38.6 us vs 42.0 us raw, pair 5.3 us)
+        # reproduces rocprofv3's kernel-trace averages (profiles/r01_v6_kernel_stats.md: 38.6 us vs 42.0 us raw, pair 5.3 us)
         self.overhead_us = 0.6 * 1e3 * ms[len(ms) // 2]
         return self.overhead_us
 
