@@ -48,21 +48,35 @@ __global__ __launch_bounds__(256) void cdft_fwd_kernel(const float* __restrict__
     const int G = blockDim.x / C;                 // row groups
     const int c = threadIdx.x % C, g = threadIdx.x / C;
     const float scale = rsqrtf((float)M);
-    for (int kxp = g; kxp < 2 * K; kxp += G) {
-        const int kx = kx_of(kxp, K, M);
-        float re = 0.f, im = 0.f;
-        int idx = 0;
+    // four output rows per pass: every slab element read from LDS feeds four complex multiply-adds
+    for (int k0 = 4 * g; k0 < 2 * K; k0 += 4 * G) {
+        int kx[4], idx[4];
+        float re[4], im[4];
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            kx[u] = kx_of(min(k0 + u, 2 * K - 1), K, M);
+            idx[u] = 0;
+            re[u] = im[u] = 0.f;
+        }
         for (int m = 0; m < M; ++m) {             // (a + i bb)(cos - i sin)
             const float a = slab[m * 2 * C + c], bb = slab[m * 2 * C + C + c];
-            const float cs = ct[idx], sn = st[idx];
-            re += a * cs + bb * sn;
-            im += bb * cs - a * sn;
-            idx += kx;
-            if (idx >= M) idx -= M;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const float cs = ct[idx[u]], sn = st[idx[u]];
+                re[u] += a * cs + bb * sn;
+                im[u] += bb * cs - a * sn;
+                idx[u] += kx[u];
+                if (idx[u] >= M) idx[u] -= M;
+            }
         }
-        float* dst = Z + (((long)ky * 2 * K + kxp) * B + b) * 2 * C;
-        dst[c] = re * scale;
-        dst[C + c] = im * scale;
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u < 2 * K) {
+                float* dst = Z + (((long)ky * 2 * K + k0 + u) * B + b) * 2 * C;
+                dst[c] = re[u] * scale;
+                dst[C + c] = im[u] * scale;
+            }
+        }
     }
 }
 
@@ -87,23 +101,39 @@ __global__ __launch_bounds__(256) void cdft_inv_kernel(const float* __restrict__
     const int c = threadIdx.x % C, g = threadIdx.x / C;
     const float scale = rsqrtf((float)M);
     float* dst = S + ((long)ky * B * M + (long)b * M) * 2 * C;
-    for (int m = g; m < M; m += G) {
-        float re = 0.f, im = 0.f;
+    // four output positions per pass: every retained row read from LDS feeds four complex multiply-adds
+    for (int m0 = 4 * g; m0 < M; m0 += 4 * G) {
+        float re[4], im[4];
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) re[u] = im[u] = 0.f;
         FFNO_UNROLL
         for (int run = 0; run < 2; ++run) {       // kx = 0..K-1, then kx = M-K..M-1
-            int idx = run == 0 ? 0 : (int)(((long)(M - K) * m) % M);
+            int idx[4], stp[4];
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                stp[u] = (m0 + u) % M;
+                idx[u] = run == 0 ? 0 : (int)(((long)(M - K) * (m0 + u)) % M);
+            }
             for (int t = 0; t < K; ++t) {         // (a + i bb)(cos + i sin)
                 const float* z = slab + (run * K + t) * 2 * C;
                 const float a = z[c], bb = z[C + c];
-                const float cs = ct[idx], sn = st[idx];
-                re += a * cs - bb * sn;
-                im += a * sn + bb * cs;
-                idx += m;
-                if (idx >= M) idx -= M;
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const float cs = ct[idx[u]], sn = st[idx[u]];
+                    re[u] += a * cs - bb * sn;
+                    im[u] += a * sn + bb * cs;
+                    idx[u] += stp[u];
+                    if (idx[u] >= M) idx[u] -= M;
+                }
             }
         }
-        dst[(long)m * 2 * C + c] = re * scale;
-        dst[(long)m * 2 * C + C + c] = im * scale;
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            if (m0 + u < M) {
+                dst[(long)(m0 + u) * 2 * C + c] = re[u] * scale;
+                dst[(long)(m0 + u) * 2 * C + C + c] = im[u] * scale;
+            }
+        }
     }
 }
 
