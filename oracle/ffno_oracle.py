@@ -18,8 +18,15 @@ build container with tools/make_golden.py -- pin it (tests/test_oracle_golden.py
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The shipped package (fourierflow_amd/) never does.
 
+Also restated here, with their own golden vectors: FNOFactorizedMesh2D / Mesh3D (mesh_2d.py, mesh_3d.py),
+FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), FNOZongyi2DBlock (zongyi_fno/grid_2d.py), Normalizer, the Markov
+feature build (routines/grid_2d_markov.py:124-170).
+
 Parity status: PINNED against golden vectors generated from the imported
-reference (tests/golden/*.npz, generator tools/make_golden.py).
+reference (tests/golden/*.npz, generator tools/make_golden.py) -- with ONE exception: ``velocity_features`` /
+``velocity_wavenumbers`` (the `use_velocity` branch of routines/grid_2d_markov.py:82-94,130-144).  That routine and
+its jax_cfd dependency cannot be imported here, so for that piece PARITY IS UNPINNED by a reference run; it is
+pinned only analytically (plane-wave known answers and curl / divergence identities, tests/test_velocity.py).
 """
 from __future__ import annotations
 
