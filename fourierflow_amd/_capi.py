@@ -24,6 +24,12 @@ class FxPackDesc(C.Structure):
     _fields_ = [("src", P), ("dst", P), ("sh", C.c_int32), ("sc", C.c_int32), ("type", C.c_int32), ("pad_", C.c_int32)]
 
 
+class FusedBranch(C.Structure):
+    """Mirror of ``ffno_fused_branch`` (include/ffno.h)."""
+    _fields_ = [("in_", P), ("out", P), ("resid", P), ("spec_save", P), ("planes", P), ("tw", P),
+                ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32)]
+
+
 class FxRedDesc(C.Structure):
     """Mirror of ``ffno_fxred_desc`` (include/ffno.h)."""
     _fields_ = [("partial", P), ("dW1", P), ("dW2", P), ("db1", P), ("db2", P)]
@@ -54,6 +60,7 @@ SIGNATURES = {
     "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
+    "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),
@@ -70,6 +77,8 @@ SIGNATURES = {
     "ffno_ffx_pack": (I, [P, I, I, I, P]),
     "ffno_ffx_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "ffno_ffx_bwd_data": (I, [P, P, P, P, P, I, I, I, P]),
+    "ffno_ffx_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ffx_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P]),
     "ffno_ffx_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce_batched": (I, [P, I, I, I, I, P]),

@@ -16,6 +16,7 @@
 #define FFNO_UNROLL
 #define FFNO_NOUNROLL
 #define FFNO_SCHED_FENCE() ((void)0)
+#define FFNO_WAVES_PER_SIMD(n)
 #else
 #include <hip/hip_runtime.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,6 +26,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define FFNO_NOUNROLL _Pragma("unroll 1")
 // bounds live ranges: stops the scheduler from hoisting a whole unrolled loop's operand loads
 #define FFNO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// register budget = 512 / n VGPRs per lane, so that n waves (n/2 workgroups of 512 threads) share a SIMD
+#define FFNO_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 #endif
 
 #include <stdint.h>

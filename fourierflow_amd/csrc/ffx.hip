@@ -129,7 +129,9 @@ __device__ __forceinline__ void stage4(char* base, int plane_bytes, int off, flo
 //   forward : in = s,  A1 = pack1(W1),   A2 = pack2(W2)     h = relu(A1 in + b1), sign bits -> mask ; out = A2 h + b2 (+ resid)
 //   backward: in = db, A1 = pack1(W2^T), A2 = pack2(W1^T)   dh = mask ? A1 in : 0                    ; ds  = A2 dh
 template <int C, int H, bool BWD>
-__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const float* __restrict__ in, const float* resid,
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const float* __restrict__ in,
+                                                                     const float* __restrict__ in2, float* sum_out,
+                                                                     const float* resid,
                                                                      const u32x4* __restrict__ pk1,
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2,
@@ -171,7 +173,16 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
             const int f = tid + v * F::NT;
             const long px = (long)tile * 32 + f / (C / 4);
             nS[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (px < P) nS[v] = *reinterpret_cast<const float4*>(in + px * C + 4 * (f % (C / 4)));
+            if (px < P) {
+                const long off = px * C + 4 * (f % (C / 4));
+                nS[v] = *reinterpret_cast<const float4*>(in + off);
+                if (in2) {      // the input is the sum of two tensors (the two spectral branches ran side by side, each into
+                                // its own buffer); the sum is optionally written back for the kernels that follow
+                    const float4 t = *reinterpret_cast<const float4*>(in2 + off);
+                    nS[v].x += t.x, nS[v].y += t.y, nS[v].z += t.z, nS[v].w += t.w;
+                    if (sum_out) *reinterpret_cast<float4*>(sum_out + off) = nS[v];
+                }
+            }
         }
     };
     auto stage = [&](int buf) {
@@ -601,13 +612,19 @@ extern "C" int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, in
 
 extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
                             const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
-    if (!s || !pk1 || !b1 || !pk2 || !b2 || !out || P <= 0) return FFNO_EINVAL;
+    return ffno_ffx_fwd2(s, nullptr, nullptr, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+}
+
+extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1,
+                             const float* b1, const void* pk2, const float* b2, float* out, void* mask, int P, int C,
+                             int H, void* stream) {
+    if (!s || !pk1 || !b1 || !pk2 || !b2 || !out || P <= 0 || (s_sum && !s2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
     const dim3 grid(min(kFxBlocks, ntiles));
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, resid,                \
+        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum, resid,     \
                     (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                           \
         return ffx_launch_status();                                                                                   \
     }
@@ -618,13 +635,18 @@ extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1,
 
 extern "C" int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds, int P,
                                  int C, int H, void* stream) {
-    if (!db || !mask || !pk1b || !pk2b || !ds || P <= 0) return FFNO_EINVAL;
+    return ffno_ffx_bwd_data2(db, nullptr, nullptr, mask, pk1b, pk2b, ds, P, C, H, stream);
+}
+
+extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
+                                  const void* pk2b, float* ds, int P, int C, int H, void* stream) {
+    if (!db || !mask || !pk1b || !pk2b || !ds || P <= 0 || (db_sum && !db2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
     const dim3 grid(min(kFxBlocks, ntiles));
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, nullptr,              \
+        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum, nullptr, \
                     (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds, (uint32_t*)const_cast<void*>(mask), \
                     P);                                                                                               \
         return ffx_launch_status();                                                                                   \

@@ -359,13 +359,30 @@ struct FusedCfg {
     static constexpr int LSMAX = 2 * KMAX * C + 4;   // line stride (floats), 16-B aligned, breaks bank period
 };
 
+// one branch: everything a workgroup needs to know
+struct FusedArgs {
+    const float* in;
+    float* out;
+    const float* resid;
+    float* spec_save;
+    const float* planes;
+    const float* tw;
+    int R, L, K;
+    LineMap lm;
+    int fwd_ck, inv_ck, conj_t, accumulate;
+};
+
 template <int C>
-__global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __restrict__ in, float* out,
-                                                             const float* resid, float* __restrict__ spec_save,
-                                                             const float* __restrict__ planes,
-                                                             const float* __restrict__ tw, int R, int L, int K,
-                                                             LineMap lm, int fwd_ck, int inv_ck, int conj_t,
-                                                             int accumulate) {
+__device__ __forceinline__ void spectral_fused_body(const FusedArgs& A, int bidx) {
+    const float* __restrict__ in = A.in;
+    float* out = A.out;
+    const float* resid = A.resid;
+    float* __restrict__ spec_save = A.spec_save;
+    const float* __restrict__ planes = A.planes;
+    const float* __restrict__ tw = A.tw;
+    const int R = A.R, L = A.L, K = A.K;
+    const LineMap lm = A.lm;
+    const int fwd_ck = A.fwd_ck, inv_ck = A.inv_ck, conj_t = A.conj_t, accumulate = A.accumulate;
     using F = FusedCfg<C>;
     constexpr int CT = C / 32;
     __shared__ __attribute__((aligned(16))) float XS[F::LINES * F::LSMAX];
@@ -376,7 +393,7 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int LS = 2 * K * C + 4;
-    const int line = blockIdx.x * F::LINES + wave;
+    const int line = bidx * F::LINES + wave;
     const bool live = line < R;
     float* xs = XS + wave * LS;
     __syncthreads();
@@ -397,7 +414,7 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
         if (live) {
             const float* xl = in + lm.base(line) + CT * j;
             const int nsteps = (L + 1) >> 1;
-            constexpr int UN = 16;   // k-steps whose loads are all in flight together (whole line at L <= 32... 64: two trips)
+            constexpr int UN = 8;    // k-steps whose loads are all in flight together (a line of 64 points = four trips)
             for (int t0 = 0; t0 < nsteps; t0 += UN) {
                 ColVec<CT> b[UN];
                 FFNO_UNROLL
@@ -443,16 +460,15 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
         constexpr int NOG = C / (16 * EPL);
         const int io = lane & 15, kq = lane >> 4;       // A row (line, re/im) = io ; B column group = io
         const float* arow = XS + (io >> 1) * LS + (io & 1) * C + kq;
-        // Work list of this wave: modes k = wave, wave+8, ...; each mode = 2 chunks of C/8 k-steps.  The weight
-        // fragments of chunk i+1 are requested (full plane rows, L2-resident) before chunk i's MFMAs start: two
-        // register buffers in ping-pong, statically indexed.
+        // Work list of this wave: modes k = wave, wave+8, ...; each mode = 2 chunks of C/8 k-steps of weight fragments
+        // (full plane rows, L2-resident).
         constexpr int HK = C / 8;                      // k-steps per chunk (each k-step = 4 input channels)
         const int nmodes = (K - wave + F::LINES - 1) / F::LINES;   // modes owned by this wave (K > wave else <= 0)
         const int nch = nmodes > 0 ? 2 * nmodes : 0;
         struct WFrag {
             float r[HK][NOG][EPL], i[HK][NOG][EPL];
         };
-        WFrag w0, w1;
+        WFrag w0;
         f32x4 p1[NOG][EPL], p2[NOG][EPL];
 
         auto load_chunk = [&](WFrag& w, int ch) {
@@ -533,12 +549,13 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
                 }
             }
         };
-        if (nch > 0) load_chunk(w0, 0);
-        for (int ch = 0; ch < nch; ch += 2) {
-            load_chunk(w1, ch + 1);                 // nch is even: chunk ch+1 always exists
+        // ONE weight buffer (64 VGPRs): the kernel is kept under 128 VGPRs so that two workgroups -- in practice the two
+        // axes of a layer, launched on two streams -- share a CU and cover each other's L2 / HBM latencies
+        // (measured: a pair of branch launches 78 us back to back, 55-60 us side by side; double-buffering the weights
+        // instead is no faster for a lone workgroup)
+        for (int ch = 0; ch < nch; ++ch) {
+            load_chunk(w0, ch);
             compute_chunk(w0, ch);
-            if (ch + 2 < nch) load_chunk(w0, ch + 2);
-            compute_chunk(w1, ch + 1);
         }
         __syncthreads();
     }
@@ -603,6 +620,23 @@ __global__ __launch_bounds__(512) void spectral_fused_kernel(const float* __rest
             }
         }
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(4) void spectral_fused_kernel(FusedArgs a) {
+    spectral_fused_body<C>(a, blockIdx.x);
+}
+
+// Two branches in ONE launch: workgroups [0, n0) run branch a, the rest branch b.  With <= 128 VGPRs and 65 KiB of LDS two
+// workgroups share a CU, so the 2 x 256 workgroups of a layer's two axes are all resident at once and the load / mix /
+// store phases of one branch run under those of the other (a pair costs 55-60 us instead of 35 + 43 us back to back),
+// without any cross-stream dependency.  The two branches must write different buffers.
+template <int C>
+__global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(4) void spectral_fused_pair_kernel(FusedArgs a, FusedArgs b, int n0) {
+    if ((int)blockIdx.x < n0)
+        spectral_fused_body<C>(a, blockIdx.x);
+    else
+        spectral_fused_body<C>(b, blockIdx.x - n0);
 }
 
 // ---- Fourier weight gradient ----------------------------------------------------------------------
@@ -853,24 +887,54 @@ extern "C" int ffno_spectral_fused_supported(int C, int K, int L) {
     return 0;
 }
 
-extern "C" int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
-                                   const float* planes, const float* tw, int B, int M, int N, int C, int K, int axis,
-                                   int scale_ck_fwd, int apply_ck_inv, int conj_transpose, int accumulate,
-                                   void* stream) {
+static int fused_args(FusedArgs& a, const float* in, float* out, const float* resid, float* spec_save, const float* planes,
+                      const float* tw, int B, int M, int N, int C, int K, int axis, int scale_ck_fwd, int apply_ck_inv,
+                      int conj_transpose, int accumulate) {
     if (!in || !out || !tw || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1)) return FFNO_EINVAL;
     const int L = axis == 0 ? N : M;
     const int R = axis == 0 ? B * M : B * N;
     if (K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_fused_supported(C, K, L)) return FFNO_EUNSUPPORTED;
-    const LineMap lm = make_linemap(axis, B, M, N, C);
-    const dim3 grid((R + 7) / 8), block(512);
-    const size_t smem = sizeof(float) * 2 * L;
+    a = FusedArgs{in, out, resid, spec_save, planes, tw, R, L, K, make_linemap(axis, B, M, N, C), scale_ck_fwd, apply_ck_inv,
+                  conj_transpose, accumulate};
+    return FFNO_OK;
+}
+
+extern "C" int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
+                                   const float* planes, const float* tw, int B, int M, int N, int C, int K, int axis,
+                                   int scale_ck_fwd, int apply_ck_inv, int conj_transpose, int accumulate,
+                                   void* stream) {
+    FusedArgs a;
+    const int rc = fused_args(a, in, out, resid, spec_save, planes, tw, B, M, N, C, K, axis, scale_ck_fwd, apply_ck_inv,
+                              conj_transpose, accumulate);
+    if (rc) return rc;
+    const dim3 grid((a.R + 7) / 8), block(512);
+    const size_t smem = sizeof(float) * 2 * a.L;
     if (C == 64)
-        FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
-                    tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
+        FFNO_LAUNCH((spectral_fused_kernel<64>), grid, block, smem, (hipStream_t)stream, a);
     else
-        FFNO_LAUNCH((spectral_fused_kernel<32>), grid, block, smem, (hipStream_t)stream, in, out, resid, spec_save, planes,
-                    tw, R, L, K, lm, scale_ck_fwd, apply_ck_inv, conj_transpose, accumulate);
+        FFNO_LAUNCH((spectral_fused_kernel<32>), grid, block, smem, (hipStream_t)stream, a);
+    return launch_status();
+}
+
+extern "C" int ffno_spectral_fused_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int B, int M, int N, int C,
+                                        int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream) {
+    if (!ba || !bb) return FFNO_EINVAL;
+    if (ba->out == bb->out) return FFNO_EINVAL;      // concurrent workgroups: the branches may not share an output
+    FusedArgs a, b;
+    int rc = fused_args(a, ba->in, ba->out, ba->resid, ba->spec_save, ba->planes, ba->tw, B, M, N, C, ba->K, ba->axis,
+                        scale_ck_fwd, apply_ck_inv, conj_transpose, ba->accumulate);
+    if (rc) return rc;
+    rc = fused_args(b, bb->in, bb->out, bb->resid, bb->spec_save, bb->planes, bb->tw, B, M, N, C, bb->K, bb->axis,
+                    scale_ck_fwd, apply_ck_inv, conj_transpose, bb->accumulate);
+    if (rc) return rc;
+    const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8;
+    const dim3 grid(n0 + n1), block(512);
+    const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
+    if (C == 64)
+        FFNO_LAUNCH((spectral_fused_pair_kernel<64>), grid, block, smem, (hipStream_t)stream, a, b, n0);
+    else
+        FFNO_LAUNCH((spectral_fused_pair_kernel<32>), grid, block, smem, (hipStream_t)stream, a, b, n0);
     return launch_status();
 }
 

@@ -167,11 +167,30 @@ class FFNOEngine:
         # feed-forward on the bf16 matrix cores at fp32 accuracy (ffx.hip: split-bf16, no stored hidden activations)
         # when the library has the (C, H) instance; False = the fp32-MFMA kernels of ff.hip
         self.use_ffx = True
+        # The first two spectral branches of a layer (and of its adjoint) run in ONE launch whose workgroups are co-resident
+        # (ffno_spectral_fused_pair), each into its own buffer; the feed-forward kernels that consume them add the two
+        # while staging (ffno_ffx_fwd2 / _bwd_data2).  Needs the split-bf16 feed-forward, no fork heads, and both axes on
+        # the fused kernel with the same [B, M, N] view (the 2-D operators).
+        self.concurrent_branches = True
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         # backward: FF weight-gradient kernels on a side stream next to the spectral adjoint.  Measured on MI355X
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
         self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
+
+    def _conc(self) -> bool:
+        return bool(self.concurrent_branches and self._ffx() and not self.use_fork and not self.overlap
+                    and self.mode != "no-fourier" and self.spectral != "plus" and self.nd == 2)
+
+    def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st):
+        """Branches of views v0 and v1 in ONE launch (both fused): dst0 = [resid0 +] branch0(src), dst1 = branch1(src)."""
+        lib = _lib.get_lib()
+        ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
+        assert (v0.Bv, v0.Mv, v0.Nv) == (v1.Bv, v1.Mv, v1.Nv)
+        ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)), v0.K, v0.a01, 0, 0)
+        bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)), v1.K, v1.a01, 0, 0)
+        self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), v0.Bv, v0.Mv, v0.Nv, self.C,
+                ck_f, ck_i, conj, st)
 
     def _ffx(self) -> bool:
         return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
@@ -324,7 +343,7 @@ class FFNOEngine:
                 _View(B, X * Y, Z, 0, self.Ks[2], C)]       # z: contiguous lines (b, x, y)
 
     def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
-        key = (B, tuple(S), bool(save), self._ffx())
+        key = (B, tuple(S), bool(save), self._ffx(), self._conc())
         if self._ws_key == key:
             return self._ws
         cache = self.__dict__.setdefault("_ws_cache", {})   # a few recent geometries (train batch / validation batch /
@@ -354,6 +373,10 @@ class FFNOEngine:
         ws.SXall = [torch.empty(ns, v.spec, **f32) for v in ws.views]      # forward spectra, per axis, layer-major
         ws.SY = torch.empty(max(v.spec for v in ws.views), **f32)
         ws.SD = torch.empty(max(v.spec for v in ws.views), **f32)    # scratch spectrum of the staged path
+        if self._conc():
+            ws.T = torch.empty(P, C, **f32)                           # output of the second branch of a paired launch
+            if save:
+                ws.G1 = torch.empty(P, C, **f32)                      # ... and of the second adjoint branch
         if self.spectral == "plus":
             ws.SYa = torch.empty(ws.views[0].spec_y, **f32)           # last-axis spectra on either side of the x transform
             ws.SYb = torch.empty(ws.views[0].spec_y, **f32)
@@ -498,12 +521,13 @@ class FFNOEngine:
             self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
                     v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, ck_i, conj, accumulate, st)
             return
-        spec = save if save is not None else ws.SD
+        SD, SY = ws.SD, ws.SY
+        spec = save if save is not None else SD
         self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(spec), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, st)
         y = spec
         if planes is not None:
-            self._k("mode_mix", lib.ffno_mode_mix, _p(spec), _p(planes), _p(ws.SY), v.R, C, v.K, conj, st)
-            y = ws.SY
+            self._k("mode_mix", lib.ffno_mode_mix, _p(spec), _p(planes), _p(SY), v.R, C, v.K, conj, st)
+            y = SY
         self._k("dft_inv", lib.ffno_dft_inv, _p(y), _p(dst), resid, _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_i,
                 accumulate, st)
 
@@ -530,6 +554,8 @@ class FFNOEngine:
         self._prepare_weights(st)
         fused = self._can_fuse(ws.views)
         full = self.mode == "full"
+        conc = self._conc() and len(ws.views) == 2 and all(fused) and \
+            (ws.views[0].Bv, ws.views[0].Mv, ws.views[0].Nv) == (ws.views[1].Bv, ws.views[1].Mv, ws.views[1].Nv)
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
@@ -544,14 +570,23 @@ class FFNOEngine:
                 s_l.copy_(ws.X)
             else:
                 si = self._fw_sets.index(self.fw_names[l]) if full else 0
-                for w, v in enumerate(ws.views):
-                    keep = ws.SXall[w][sv] if full else None     # stage-A spectrum (kept per layer when training)
-                    if fused[w] and not save_for_backward:
-                        keep = None
-                    self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
-                                   self.planes[si][w][0] if full else None, True, int(w > 0), fused[w], st)
+                if conc:
+                    keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in (0, 1)]
+                    self._pair("spectral_fused", ws, ws.views[0], ws.views[1], ws.X, s_l, ws.T, None, keep[0], keep[1],
+                               self.planes[si][0][0] if full else None, self.planes[si][1][0] if full else None, True, st)
+                else:
+                    for w, v in enumerate(ws.views):
+                        keep = ws.SXall[w][sv] if full else None     # stage-A spectrum (kept per layer when training)
+                        if fused[w] and not save_for_backward:
+                            keep = None
+                        self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
+                                       self.planes[si][w][0] if full else None, True, int(w > 0), fused[w], st)
             l0, l1, b0, b1 = self._ff_weights(l)
-            if not (self.use_fork and last):      # with fork heads the last layer's backcast only feeds the dead x_L
+            if conc:
+                self._k("ff_fwd", lib.ffno_ffx_fwd2, _p(s_l), _p(ws.T), _p(s_l) if save_for_backward else None,
+                        None if last else _p(ws.X), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(ws.Blast if last else ws.X),
+                        _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
+            elif not (self.use_fork and last):    # with fork heads the last layer's backcast only feeds the dead x_L
                 self._ff_fwd(s_l, None if last else ws.X, l0, l1, b0, b1, ws.Blast if last else ws.X,
                              ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st)
             if self.use_fork:
@@ -564,7 +599,7 @@ class FFNOEngine:
             self.forecast_list = [ws.YL[l].view(B, *S, self.O).clone() for l in range(L)]
         else:
             self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
-        self._saved = (x, B, S, fused) if save_for_backward else None
+        self._saved = (x, B, S, fused, conc) if save_for_backward else None
         return ws.Y.view(B, *S, self.O).clone()
 
     # ------------------------------------------------------------------------------------------------
@@ -573,7 +608,7 @@ class FFNOEngine:
         (layout: ``param_names`` order; use ``grad_view(name)``)."""
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
-        x, B, S, fused = self._saved
+        x, B, S, fused, conc = self._saved
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
@@ -598,6 +633,7 @@ class FFNOEngine:
             side, main_obj = self._side, torch.cuda.current_stream(self.device)
             ev_a, ev_b = self._ev[0], self._ev[1:]
             st_side = ctypes.c_void_p(side.cuda_stream)
+        have_g1 = False      # G1 holds the side-stream part of the running gradient (to be added to g_in)
         cur = 0
         if pm is not None:
             (ws.GF if self.use_fork else ws.G[cur]).zero_()    # adjoint of the crop (mesh_3d.py:173)
@@ -649,7 +685,12 @@ class FFNOEngine:
                                        self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
                 cur = 1 - cur
                 continue
-            self._ff_bwd_data(g_in, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
+            if conc:
+                # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
+                self._k("ff_bwd_data", lib.ffno_ffx_bwd_data2, _p(g_in), _p(ws.G1) if have_g1 else None,
+                        _p(g_in) if have_g1 else None, _p(ws.MASK[l]), _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), P, C, H, st)
+            else:
+                self._ff_bwd_data(g_in, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
             if use_side:
                 ev_a.record(main_obj)
                 side.wait_event(ev_a)
@@ -674,11 +715,19 @@ class FFNOEngine:
                 continue
             si = self._fw_sets.index(self.fw_names[l]) if full else 0
             resid = None if last else _p(g_in)      # G_{l-1} = G_l (residual path) + adjoint terms; last layer: none
-            for w, v in enumerate(ws.views):
-                keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
-                self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if w == 0 else None, keep,
-                               self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
+            if conc:
+                self._pair("spectral_fused(adj)", ws, ws.views[0], ws.views[1], ws.DS, g_out, ws.G1, resid,
+                           ws.SDall[0][l] if full else None, ws.SDall[1][l] if full else None,
+                           self.planes[si][0][1] if full else None, self.planes[si][1][1] if full else None, False, st)
+            else:
+                for w, v in enumerate(ws.views):
+                    keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
+                    self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if w == 0 else None, keep,
+                                   self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
+            have_g1 = conc
             cur = 1 - cur
+        if conc and have_g1:
+            self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(ws.G1), 1.0, P * C, st)     # lift_bwd takes one input
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:

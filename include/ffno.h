@@ -117,6 +117,20 @@ int ffno_spectral_fused(const float* in, float* out, const float* resid, float* 
                         const float* planes, const float* tw, int B, int M, int N, int C, int K,
                         int axis, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
                         int accumulate, void* stream);
+/* Two branches of the SAME [B][M][N][C] geometry (e.g. the two axes of a layer) in one launch: the workgroups of both are
+ * resident together (two per CU) and hide each other's memory phases.  The branches must write different `out` buffers
+ * (accumulate / resid are per branch); scale / conj flags are common (both forward or both adjoint). */
+typedef struct ffno_fused_branch {
+    const float* in;
+    float* out;
+    const float* resid;     /* optional */
+    float* spec_save;       /* optional */
+    const float* planes;    /* optional (low-pass) */
+    const float* tw;        /* twiddle table of this branch's axis length */
+    int32_t K, axis, accumulate, pad_;
+} ffno_fused_branch;
+int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int B, int M, int N, int C,
+                             int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Operator level: SpectralConv2d.forward_fourier (grid_2d.py:51-99) and its backward, composed of
@@ -188,6 +202,13 @@ size_t ffno_ffx_pack_bytes(int C, int H);
 int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
 int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
                  const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+/* ..2 variants: the input is the SUM of two tensors (s + s2, db + db2 -- the two spectral branches of a layer written
+ * side by side by concurrent launches); with s_sum / db_sum the sum is also stored for the kernels that follow
+ * (s_sum may alias s). */
+int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
+                  const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
+                       const void* pk2b, float* ds, int P, int C, int H, void* stream);
 /* ds = ((db W2) * relu'(.)) W1 ; pk1b / pk2b = the backward packs */
 int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds,
                       int P, int C, int H, void* stream);

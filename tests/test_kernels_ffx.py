@@ -134,3 +134,33 @@ def test_ffx_rejects_unsupported_shapes(be):
     assert be.lib.ffno_ffx_supported(48, 192) == 0
     assert be.lib.ffno_ffx_fwd(p(z), None, p(z), p(z), p(z), p(z), p(z), None, 1, 48, 192, None) == -2
     assert be.lib.ffno_ffx_fwd(None, None, p(z), p(z), p(z), p(z), p(z), None, 1, 64, 256, None) == -1
+
+
+def test_ffx_two_input_variants_equal_the_presummed_call(be):
+    """ffno_ffx_fwd2 / ffno_ffx_bwd_data2 (input = sum of the two spectral branch buffers, optionally stored back) are
+    bit-identical to summing first and calling the one-input entry points."""
+    lib, p = be.lib, be.ptr
+    P, C, H = 100, 64, 256
+    rs = np.random.RandomState(11)
+    sa, sb = (rs.standard_normal((P, C)).astype(np.float32) for _ in range(2))
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b1, b2 = (rs.standard_normal(H) * 0.1).astype(np.float32), (rs.standard_normal(C) * 0.1).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights(be, W1, W2)
+    db1_, db2_ = be.put(b1), be.put(b2)
+    ssum_host = sa + sb
+    mask_a = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+    mask_b = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+    out_a, out_b, ssum = be.empty((P, C)), be.empty((P, C)), be.empty((P, C))
+    assert lib.ffno_ffx_fwd(p(be.put(ssum_host)), None, p(a1), p(db1_), p(a2), p(db2_), p(out_a), p(mask_a), P, C, H, None) == 0
+    assert lib.ffno_ffx_fwd2(p(be.put(sa)), p(be.put(sb)), p(ssum), None, p(a1), p(db1_), p(a2), p(db2_), p(out_b), p(mask_b),
+                             P, C, H, None) == 0
+    np.testing.assert_array_equal(be.get(ssum), ssum_host)
+    np.testing.assert_array_equal(be.get(out_a), be.get(out_b))
+    np.testing.assert_array_equal(be.get(mask_a), be.get(mask_b))
+    ds_a, ds_b, gsum = be.empty((P, C)), be.empty((P, C)), be.empty((P, C))
+    assert lib.ffno_ffx_bwd_data(p(be.put(ssum_host)), p(mask_a), p(a1b), p(a2b), p(ds_a), P, C, H, None) == 0
+    assert lib.ffno_ffx_bwd_data2(p(be.put(sa)), p(be.put(sb)), p(gsum), p(mask_a), p(a1b), p(a2b), p(ds_b), P, C, H, None) == 0
+    np.testing.assert_array_equal(be.get(ds_a), be.get(ds_b))
+    np.testing.assert_array_equal(be.get(gsum), ssum_host)
+    assert lib.ffno_ffx_fwd2(p(be.put(sa)), None, p(ssum), None, p(a1), p(db1_), p(a2), p(db2_), p(out_b), None, P, C, H, None) == -1
