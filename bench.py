@@ -94,7 +94,7 @@ FFX_KERNELS = ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial")   # on the spl
 X3_ALWAYS = ("fw_grad_partial",)                                   # split-bf16 unconditionally
 
 
-def algorithmic_work(P, C, H, K, B, M, N, L):
+def algorithmic_work(P, C, H, K, B, M, N, L, paired=True):
     """Algorithmic FLOPs / HBM bytes per launch of the timed kernels and launches per train step.
     fp32: 4 B per element.  R = lines per axis; spectra are K*R*2C floats."""
     R = B * M
@@ -102,14 +102,23 @@ def algorithmic_work(P, C, H, K, B, M, N, L):
     act = 4.0 * P * C
     dft = 2.0 * R * (2 * K) * N * C            # truncated DFT (or its inverse) of R lines as a [2K x N].[N x C] product
     mix = 8.0 * R * K * C * C                   # complex per-mode channel mix
-    return {
+    if paired:
+        # both axes of a layer in one launch (engine "concurrent_branches"): read x once, write the two branch outputs,
+        # save the two spectra (training); the adjoint also reads the residual gradient
+        sf = dict(flops=2 * (2 * dft + mix), bytes=3 * act + 2 * spec, per_step=L, bound="hbm")
+        sa = dict(flops=2 * (2 * dft + mix), bytes=4 * act + 2 * spec, per_step=L, bound="hbm")
+    else:
         # one spectral branch: read x, write s (+ read s when accumulating the 2nd branch), + save the spectrum (training)
-        "spectral_fused": dict(flops=2 * dft + mix, bytes=(act + act + spec) + 0.5 * act, per_step=2 * L, bound="hbm"),
-        "spectral_fused(adj)": dict(flops=2 * dft + mix, bytes=(act + act + act + spec), per_step=2 * L, bound="hbm"),
+        sf = dict(flops=2 * dft + mix, bytes=(act + act + spec) + 0.5 * act, per_step=2 * L, bound="hbm")
+        sa = dict(flops=2 * dft + mix, bytes=(act + act + act + spec), per_step=2 * L, bound="hbm")
+    return {
+        "spectral_fused": sf,
+        "spectral_fused(adj)": sa,
         # split-bf16 feed-forward (ffx.hip): no hidden activations in HBM, only the ReLU sign bits (P*H/8 bytes); the
         # weight-gradient kernel recomputes h and dh, so its algorithmic FLOPs are 4 GEMMs (2 recomputed + 2 gradients)
-        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=3 * act + P * H / 8, per_step=L, bound="mfma"),
-        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=2 * act + P * H / 8, per_step=L, bound="mfma"),
+        # (+ with paired branches: the second branch buffer is read and the sum written back while staging)
+        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=(5 if paired else 3) * act + P * H / 8, per_step=L, bound="mfma"),
+        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=(4 if paired else 2) * act + P * H / 8, per_step=L, bound="mfma"),
         "ff_bwd_weights_partial": dict(flops=8.0 * P * C * H, bytes=2 * act, per_step=L, bound="mfma"),
         "fw_grad_partial": dict(flops=L * mix, bytes=2 * L * spec, per_step=2, bound="hbm"),
     }
@@ -270,7 +279,8 @@ def main():
         log(f"forward-only: {ms_fwd:.3f} ms")
         P = B * G * G
         C, H, K = kw["width"], kw["width"] * kw["factor"], kw["modes"]
-        work = algorithmic_work(P, C, H, K, B, G, G, args.layers)
+        paired = bool(getattr(trainer.engine, "paired_last", False))
+        work = algorithmic_work(P, C, H, K, B, G, G, args.layers, paired)
         ksum = timer.summary()
         pmc = {}
         try:

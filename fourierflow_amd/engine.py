@@ -600,6 +600,7 @@ class FFNOEngine:
         else:
             self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
         self._saved = (x, B, S, fused, conc) if save_for_backward else None
+        self.paired_last = conc      # (bench.py: which algorithmic-work table applies)
         return ws.Y.view(B, *S, self.O).clone()
 
     # ------------------------------------------------------------------------------------------------
