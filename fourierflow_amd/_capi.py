@@ -27,7 +27,8 @@ class FxPackDesc(C.Structure):
 class FusedBranch(C.Structure):
     """Mirror of ``ffno_fused_branch`` (include/ffno.h)."""
     _fields_ = [("in_", P), ("out", P), ("resid", P), ("spec_save", P), ("planes", P), ("tw", P),
-                ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32), ("pad_", C.c_int32)]
+                ("B", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32)]
 
 
 class FxRedDesc(C.Structure):
@@ -60,7 +61,7 @@ SIGNATURES = {
     "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
-    "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, I, I, I, P]),
+    "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),

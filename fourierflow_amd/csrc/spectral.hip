@@ -917,16 +917,16 @@ extern "C" int ffno_spectral_fused(const float* in, float* out, const float* res
     return launch_status();
 }
 
-extern "C" int ffno_spectral_fused_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int B, int M, int N, int C,
-                                        int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream) {
+extern "C" int ffno_spectral_fused_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int C, int scale_ck_fwd,
+                                        int apply_ck_inv, int conj_transpose, void* stream) {
     if (!ba || !bb) return FFNO_EINVAL;
     if (ba->out == bb->out) return FFNO_EINVAL;      // concurrent workgroups: the branches may not share an output
     FusedArgs a, b;
-    int rc = fused_args(a, ba->in, ba->out, ba->resid, ba->spec_save, ba->planes, ba->tw, B, M, N, C, ba->K, ba->axis,
-                        scale_ck_fwd, apply_ck_inv, conj_transpose, ba->accumulate);
+    int rc = fused_args(a, ba->in, ba->out, ba->resid, ba->spec_save, ba->planes, ba->tw, ba->B, ba->M, ba->N, C, ba->K,
+                        ba->axis, scale_ck_fwd, apply_ck_inv, conj_transpose, ba->accumulate);
     if (rc) return rc;
-    rc = fused_args(b, bb->in, bb->out, bb->resid, bb->spec_save, bb->planes, bb->tw, B, M, N, C, bb->K, bb->axis,
-                    scale_ck_fwd, apply_ck_inv, conj_transpose, bb->accumulate);
+    rc = fused_args(b, bb->in, bb->out, bb->resid, bb->spec_save, bb->planes, bb->tw, bb->B, bb->M, bb->N, C, bb->K,
+                    bb->axis, scale_ck_fwd, apply_ck_inv, conj_transpose, bb->accumulate);
     if (rc) return rc;
     const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8;
     const dim3 grid(n0 + n1), block(512);

@@ -180,17 +180,27 @@ class FFNOEngine:
 
     def _conc(self) -> bool:
         return bool(self.concurrent_branches and self._ffx() and not self.use_fork and not self.overlap
-                    and self.mode != "no-fourier" and self.spectral != "plus" and self.nd == 2)
+                    and self.mode != "no-fourier" and self.spectral != "plus")
 
-    def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st):
-        """Branches of views v0 and v1 in ONE launch (both fused): dst0 = [resid0 +] branch0(src), dst1 = branch1(src)."""
+    @staticmethod
+    def _schedule(fused):
+        """(views that run on their own first, (a, b) = the last two fused views for the paired launch | None)."""
+        fz = [w for w, f in enumerate(fused) if f]
+        if len(fz) < 2:
+            return list(range(len(fused))), None
+        pair = (fz[-2], fz[-1])
+        return [w for w in range(len(fused)) if w not in pair], pair
+
+    def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st, acc0: int = 0):
+        """Branches of views v0 and v1 in ONE launch (both fused):
+        dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = branch1(src)."""
         lib = _lib.get_lib()
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
-        assert (v0.Bv, v0.Mv, v0.Nv) == (v1.Bv, v1.Mv, v1.Nv)
-        ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)), v0.K, v0.a01, 0, 0)
-        bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)), v1.K, v1.a01, 0, 0)
-        self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), v0.Bv, v0.Mv, v0.Nv, self.C,
-                ck_f, ck_i, conj, st)
+        ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)),
+                               v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
+        bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)),
+                               v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0)
+        self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
 
     def _ffx(self) -> bool:
         return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
@@ -554,8 +564,8 @@ class FFNOEngine:
         self._prepare_weights(st)
         fused = self._can_fuse(ws.views)
         full = self.mode == "full"
-        conc = self._conc() and len(ws.views) == 2 and all(fused) and \
-            (ws.views[0].Bv, ws.views[0].Mv, ws.views[0].Nv) == (ws.views[1].Bv, ws.views[1].Mv, ws.views[1].Nv)
+        singles, pair = self._schedule(fused) if self._conc() else (list(range(len(ws.views))), None)
+        conc = pair is not None
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
@@ -570,17 +580,21 @@ class FFNOEngine:
                 s_l.copy_(ws.X)
             else:
                 si = self._fw_sets.index(self.fw_names[l]) if full else 0
+                nwrit = 0
+                for w in singles:
+                    v = ws.views[w]
+                    keep = ws.SXall[w][sv] if full else None     # stage-A spectrum (kept per layer when training)
+                    if fused[w] and not save_for_backward:
+                        keep = None
+                    self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
+                                   self.planes[si][w][0] if full else None, True, int(nwrit > 0), fused[w], st)
+                    nwrit += 1
                 if conc:
-                    keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in (0, 1)]
-                    self._pair("spectral_fused", ws, ws.views[0], ws.views[1], ws.X, s_l, ws.T, None, keep[0], keep[1],
-                               self.planes[si][0][0] if full else None, self.planes[si][1][0] if full else None, True, st)
-                else:
-                    for w, v in enumerate(ws.views):
-                        keep = ws.SXall[w][sv] if full else None     # stage-A spectrum (kept per layer when training)
-                        if fused[w] and not save_for_backward:
-                            keep = None
-                        self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
-                                       self.planes[si][w][0] if full else None, True, int(w > 0), fused[w], st)
+                    a, b = pair
+                    keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in pair]
+                    self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
+                               self.planes[si][a][0] if full else None, self.planes[si][b][0] if full else None, True, st,
+                               acc0=int(nwrit > 0))
             l0, l1, b0, b1 = self._ff_weights(l)
             if conc:
                 self._k("ff_fwd", lib.ffno_ffx_fwd2, _p(s_l), _p(ws.T), _p(s_l) if save_for_backward else None,
@@ -610,6 +624,7 @@ class FFNOEngine:
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
         x, B, S, fused, conc = self._saved
+        singles, pair = self._schedule(fused) if conc else (list(range(len(fused))), None)
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
@@ -716,15 +731,19 @@ class FFNOEngine:
                 continue
             si = self._fw_sets.index(self.fw_names[l]) if full else 0
             resid = None if last else _p(g_in)      # G_{l-1} = G_l (residual path) + adjoint terms; last layer: none
+            nwrit = 0
+            for w in singles:
+                v = ws.views[w]
+                keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
+                self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if nwrit == 0 else None, keep,
+                               self.planes[si][w][1] if full else None, False, int(nwrit > 0), fused[w], st)
+                nwrit += 1
             if conc:
-                self._pair("spectral_fused(adj)", ws, ws.views[0], ws.views[1], ws.DS, g_out, ws.G1, resid,
-                           ws.SDall[0][l] if full else None, ws.SDall[1][l] if full else None,
-                           self.planes[si][0][1] if full else None, self.planes[si][1][1] if full else None, False, st)
-            else:
-                for w, v in enumerate(ws.views):
-                    keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
-                    self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if w == 0 else None, keep,
-                                   self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
+                a, b = pair
+                self._pair("spectral_fused(adj)", ws, ws.views[a], ws.views[b], ws.DS, g_out, ws.G1,
+                           resid if nwrit == 0 else None, ws.SDall[a][l] if full else None, ws.SDall[b][l] if full else None,
+                           self.planes[si][a][1] if full else None, self.planes[si][b][1] if full else None, False, st,
+                           acc0=int(nwrit > 0))
             have_g1 = conc
             cur = 1 - cur
         if conc and have_g1:

@@ -117,9 +117,10 @@ int ffno_spectral_fused(const float* in, float* out, const float* resid, float* 
                         const float* planes, const float* tw, int B, int M, int N, int C, int K,
                         int axis, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
                         int accumulate, void* stream);
-/* Two branches of the SAME [B][M][N][C] geometry (e.g. the two axes of a layer) in one launch: the workgroups of both are
- * resident together (two per CU) and hide each other's memory phases.  The branches must write different `out` buffers
- * (accumulate / resid are per branch); scale / conj flags are common (both forward or both adjoint). */
+/* Two branches in one launch (e.g. the two axes of a layer, or two of the three views of the 3-D operator -- each branch
+ * carries its own [B][M][N] view of the buffers): the workgroups of both are resident together (two per CU) and hide each
+ * other's memory phases.  The branches must write different `out` buffers (accumulate / resid are per branch); scale /
+ * conj flags are common (both forward or both adjoint). */
 typedef struct ffno_fused_branch {
     const float* in;
     float* out;
@@ -127,10 +128,11 @@ typedef struct ffno_fused_branch {
     float* spec_save;       /* optional */
     const float* planes;    /* optional (low-pass) */
     const float* tw;        /* twiddle table of this branch's axis length */
-    int32_t K, axis, accumulate, pad_;
+    int32_t B, M, N;        /* view of this branch */
+    int32_t K, axis, accumulate;
 } ffno_fused_branch;
-int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int B, int M, int N, int C,
-                             int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream);
+int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
+                             int apply_ck_inv, int conj_transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Operator level: SpectralConv2d.forward_fourier (grid_2d.py:51-99) and its backward, composed of
