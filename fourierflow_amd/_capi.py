@@ -11,6 +11,7 @@ P = C.c_void_p
 I = C.c_int
 F = C.c_float
 SZ = C.c_size_t
+L = C.c_long
 
 
 class WnDesc(C.Structure):
@@ -44,6 +45,11 @@ class MarkovExtra(C.Structure):
 class PadMap(C.Structure):
     """Mirror of ``ffno_padmap`` (include/ffno.h)."""
     _fields_ = [("size", C.c_int32 * 3), ("padded", C.c_int32 * 3)]
+
+
+class PadDesc(C.Structure):
+    """Mirror of ``ffno_pad_desc`` (include/ffno.h)."""
+    _fields_ = [("plain", P), ("padded", P), ("R", C.c_int32), ("Cc", C.c_int32), ("inner", C.c_int32), ("Cp", C.c_int32)]
 
 
 class TrDesc(C.Structure):
@@ -95,6 +101,13 @@ SIGNATURES = {
     "ffno_cdft_rows": (I, [P, P, I, I, I, I, I, P]),
     "ffno_fw2d_pack": (I, [P, P, P, P, I, I, P]),
     "ffno_fw2d_grad_reduce": (I, [P, P, P, I, I, I, I, P]),
+    "ffno_plin_supported": (I, [I, I]),
+    "ffno_plin_fwd": (I, [P, I, P, P, P, P, I, P, P, L, I, I, I, P]),
+    "ffno_plin_bwd_data": (I, [P, I, P, P, P, I, P, L, I, I, I, P]),
+    "ffno_plin_wgrad_nsplit": (I, [L]),
+    "ffno_plin_wgrad_partial_floats": (SZ, [L, I, I]),
+    "ffno_plin_bwd_weights": (I, [P, I, P, P, I, P, P, P, L, I, I, I, P]),
+    "ffno_pad_copy": (I, [P, I, I, P]),
     "ffno_velocity_ws_floats": (SZ, [I, I, I]),
     "ffno_velocity_features": (I, [P, P, P, I, I, I, F, F, P]),
     "ffno_lploss_tmp_floats": (SZ, [I, I]),

@@ -22,9 +22,11 @@ TARGET_MAP = {
     "fourierflow.modules.FNOFactorizedMesh3D": "fourierflow_amd.modules.FNOFactorizedMesh3D",
     "fourierflow.modules.FNOFactorizedMesh2D": "fourierflow_amd.modules.FNOFactorizedMesh2D",
     "fourierflow.modules.FNOPlus2DBlock": "fourierflow_amd.modules.FNOPlus2DBlock",
+    "fourierflow.modules.FNOZongyi2DBlock": "fourierflow_amd.modules.FNOZongyi2DBlock",
     "fourierflow.modules.WNLinear": "fourierflow_amd.modules.WNLinear",
     "fourierflow.modules.Normalizer": "fourierflow_amd.modules.Normalizer",
     "fourierflow.routines.Grid2DMarkovExperiment": "fourierflow_amd.routines.Grid2DMarkovExperiment",
+    "fourierflow.routines.Grid2DRolloutExperiment": "fourierflow_amd.routines.Grid2DRolloutExperiment",
     "fourierflow.routines.StructuredMeshExperiment": "fourierflow_amd.routines.StructuredMeshExperiment",
 }
 _INTERP = re.compile(r"^\$\{\s*([\w.]+)\s*:\s*(.*?)\s*\}$")
@@ -138,8 +140,11 @@ def build_routine(cfg: Dict[str, Any]):
         routine_kwargs["optimizer"] = dict(opt.kwargs)
     if sch is not None:
         s = sch["scheduler"] if isinstance(sch, dict) else sch
-        if not isinstance(s, Partial) or not s.func.name.endswith("CosineWithWarmupScheduler"):
-            raise NotImplementedError(f"only CosineWithWarmupScheduler is fused into the optimiser step, got {s}")
+        zongyi = "FNOZongyi2DBlock" in str((r.get("conv") or {}).get("_target_", ""))    # the only StepLR users built here
+        ok = ("CosineWithWarmupScheduler",) + (("StepLR",) if zongyi else ())
+        if not isinstance(s, Partial) or not s.func.name.endswith(ok):
+            raise NotImplementedError(f"only CosineWithWarmupScheduler (and StepLR for the FNOZongyi2DBlock baselines) are folded into "
+                                      f"the fused optimiser step, got {s}")
         routine_kwargs["scheduler"] = dict(s.kwargs)
     node = dict(r)
     target = node.pop("_target_")

@@ -1,0 +1,288 @@
+// Pointwise ("1x1") linear layers of the FNOZongyi2DBlock baseline (BASELINE config 0).
+//
+// Replaces, in reference fourierflow/modules/zongyi_fno/grid_2d.py:
+//     SpectralConv2d.linear + residual + ReLU   act(x_spec + linear(x))          :22,45,74-77
+//     FNOZongyi2DBlock.in_proj                  nn.Linear(input_dim, width)      :106
+//     FNOZongyi2DBlock.feedforward              Linear(width,128) ReLU Linear(128,1)   :119-122
+// and their backward passes.  The baseline is 20 channels wide; its activations live in channels-last buffers padded to
+// the 32-channel tiles of the spectral kernels (pad channels are exact zeros end to end), so every routine here takes a
+// leading dimension next to the logical width.  All of this is a few FLOPs per byte: plain VALU code on LDS tiles of 64
+// points, one fused pass per layer (bias, residual add, ReLU and the ReLU mask of the backward pass are folded in).
+#include "ffno_device.h"
+#include "ffno.h"
+
+namespace ffno {
+
+static constexpr int kPlinTile = 64;    // points per LDS tile
+static constexpr int kPlinOB = 8;       // outputs per thread in the weight-gradient kernel
+static constexpr int kPlinMaxJ = 3;     // (output group, input column) items per thread: 16 groups * 33 columns / 256
+
+// out[p][o] = act(b[o] + sum_i W[o][i] x[p][i] + add[p][o])  for o < Cout,  0 for Cout <= o < ldo;
+// optional second output out2 = out + res (the block-level residual x + layer(x), which must not disturb the ReLU mask)
+__global__ __launch_bounds__(256) void plin_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
+                                                       const float* __restrict__ b, const float* __restrict__ add,
+                                                       float* __restrict__ out, int ldo, const float* __restrict__ res,
+                                                       float* __restrict__ out2, long P, int Cin, int Cout, int relu) {
+    FFNO_DYN_SMEM(smem);
+    float* xs = reinterpret_cast<float*>(smem);          // [tile][Cin + 1]
+    float* ws = xs + kPlinTile * (Cin + 1);              // [Cout][Cin + 1]
+    float* bs = ws + Cout * (Cin + 1);
+    const int t = threadIdx.x, sx = Cin + 1;
+    for (int e = t; e < Cout * Cin; e += 256) ws[(e / Cin) * sx + e % Cin] = W[e];
+    for (int e = t; e < Cout; e += 256) bs[e] = b ? b[e] : 0.f;
+    const long ntile = (P + kPlinTile - 1) / kPlinTile;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long p0 = tile * kPlinTile;
+        const int np = (int)((P - p0) < kPlinTile ? (P - p0) : kPlinTile);
+        __syncthreads();
+        for (int e = t; e < np * Cin; e += 256) {
+            const int p = e / Cin, i = e - p * Cin;
+            xs[p * sx + i] = x[(p0 + p) * ldx + i];
+        }
+        __syncthreads();
+        for (int e = t; e < np * ldo; e += 256) {
+            const int p = e / ldo, o = e - p * ldo;
+            float v = 0.f;
+            if (o < Cout) {
+                v = bs[o];
+                const float* wr = ws + o * sx;
+                const float* xr = xs + p * sx;
+                for (int i = 0; i < Cin; ++i) v = fmaf(wr[i], xr[i], v);
+                if (add) v += add[(p0 + p) * ldo + o];
+                if (relu) v = v > 0.f ? v : 0.f;
+            }
+            out[(p0 + p) * ldo + o] = v;
+            if (out2) out2[(p0 + p) * ldo + o] = v + res[(p0 + p) * ldo + o];
+        }
+    }
+}
+
+// dpre[p][o] = g[p][o] * (act ? act[p][o] > 0 : 1);   dx[p][i] (+)= sum_o dpre[p][o] W[o][i];   optional copy of dpre
+__global__ __launch_bounds__(256) void plin_bwd_data_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ act,
+                                                            const float* __restrict__ W, float* __restrict__ dx, int ldx,
+                                                            float* __restrict__ dpre_out, long P, int Cin, int Cout,
+                                                            int accumulate) {
+    FFNO_DYN_SMEM(smem);
+    float* ds = reinterpret_cast<float*>(smem);          // [tile][Cout + 1]
+    float* ws = ds + kPlinTile * (Cout + 1);             // [Cout][Cin]
+    const int t = threadIdx.x, sd = Cout + 1;
+    for (int e = t; e < Cout * Cin; e += 256) ws[e] = W[e];
+    const long ntile = (P + kPlinTile - 1) / kPlinTile;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long p0 = tile * kPlinTile;
+        const int np = (int)((P - p0) < kPlinTile ? (P - p0) : kPlinTile);
+        __syncthreads();
+        for (int e = t; e < np * ldg; e += 256) {
+            const int p = e / ldg, o = e - p * ldg;
+            const long idx = (p0 + p) * ldg + o;
+            float v = 0.f;
+            if (o < Cout) {
+                v = g[idx];
+                if (act && !(act[idx] > 0.f)) v = 0.f;
+                ds[p * sd + o] = v;
+            }
+            if (dpre_out) dpre_out[idx] = v;
+        }
+        __syncthreads();
+        for (int e = t; e < np * ldx; e += 256) {
+            const int p = e / ldx, i = e - p * ldx;
+            const long idx = (p0 + p) * ldx + i;
+            float v = 0.f;
+            if (i < Cin) {
+                const float* dr = ds + p * sd;
+                for (int o = 0; o < Cout; ++o) v = fmaf(dr[o], ws[o * Cin + i], v);
+            }
+            dx[idx] = accumulate ? dx[idx] + v : v;
+        }
+    }
+}
+
+// part[s][o][i] = sum over the points of slice s of dpre[p][o] * x[p][i],  i = Cin is the bias column (x = 1).
+// A thread owns one input column i and kPlinOB consecutive outputs: per point one LDS read of x and kPlinOB / 4 vector
+// reads of dpre (a broadcast: the lanes of a wave share o) feed kPlinOB FMAs.
+__global__ __launch_bounds__(256) void plin_wgrad_partial_kernel(const float* __restrict__ g, int ldg,
+                                                                 const float* __restrict__ act, const float* __restrict__ x,
+                                                                 int ldx, float* __restrict__ part, long P, int Cin, int Cout,
+                                                                 long per) {
+    FFNO_DYN_SMEM(smem);
+    const int t = threadIdx.x, sx = Cin + 1, npairs = Cout * sx;
+    const int sdp = (Cout + kPlinOB - 1) / kPlinOB * kPlinOB;       // dpre row, padded with zeros to whole output groups
+    float* ds = reinterpret_cast<float*>(smem);          // [tile][sdp]
+    float* xs = ds + kPlinTile * sdp;                    // [tile][Cin + 1]
+    const int nog = sdp / kPlinOB, nitems = sx * nog;    // item = (output group, input column), column fastest
+    float acc[kPlinMaxJ][kPlinOB];
+    FFNO_UNROLL
+    for (int j = 0; j < kPlinMaxJ; ++j) {
+        FFNO_UNROLL
+        for (int u = 0; u < kPlinOB; ++u) acc[j][u] = 0.f;
+    }
+    const long pbeg = (long)blockIdx.x * per;
+    const long pend = (pbeg + per) < P ? (pbeg + per) : P;
+    for (long p0 = pbeg; p0 < pend; p0 += kPlinTile) {
+        const int np = (int)((pend - p0) < kPlinTile ? (pend - p0) : kPlinTile);
+        __syncthreads();
+        for (int e = t; e < np * sdp; e += 256) {
+            const int p = e / sdp, o = e - p * sdp;
+            float v = 0.f;
+            if (o < Cout) {
+                const long idx = (p0 + p) * ldg + o;
+                v = g[idx];
+                if (act && !(act[idx] > 0.f)) v = 0.f;
+            }
+            ds[e] = v;
+        }
+        for (int e = t; e < np * sx; e += 256) {
+            const int p = e / sx, i = e - p * sx;
+            xs[e] = i < Cin ? x[(p0 + p) * ldx + i] : 1.f;
+        }
+        __syncthreads();
+        FFNO_UNROLL
+        for (int j = 0; j < kPlinMaxJ; ++j) {
+            const int item = t + 256 * j;
+            if (item < nitems) {
+                const int og = item / sx, i = item - og * sx;
+                const float* dr = ds + og * kPlinOB;
+                const float* xr = xs + i;
+                for (int p = 0; p < np; ++p) {
+                    const float xv = xr[p * sx];
+                    FFNO_UNROLL
+                    for (int u = 0; u < kPlinOB; u += 4) {
+                        const f32x4 d = *reinterpret_cast<const f32x4*>(dr + p * sdp + u);
+                        acc[j][u] = fmaf(d[0], xv, acc[j][u]);
+                        acc[j][u + 1] = fmaf(d[1], xv, acc[j][u + 1]);
+                        acc[j][u + 2] = fmaf(d[2], xv, acc[j][u + 2]);
+                        acc[j][u + 3] = fmaf(d[3], xv, acc[j][u + 3]);
+                    }
+                }
+            }
+        }
+    }
+    FFNO_UNROLL
+    for (int j = 0; j < kPlinMaxJ; ++j) {
+        const int item = t + 256 * j;
+        if (item < nitems) {
+            const int og = item / sx, i = item - og * sx;
+            FFNO_UNROLL
+            for (int u = 0; u < kPlinOB; ++u) {
+                const int o = og * kPlinOB + u;
+                if (o < Cout) part[(long)blockIdx.x * npairs + o * sx + i] = acc[j][u];
+            }
+        }
+    }
+}
+
+// dW[o][i] (+)= sum_s part[s][o][i]: one 64-lane wave per (o, i) pair, the slices spread over the lanes
+__global__ __launch_bounds__(256) void plin_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW,
+                                                                float* __restrict__ db, int Cin, int Cout, int nsplit,
+                                                                int accumulate) {
+    const int sx = Cin + 1, npairs = Cout * sx;
+    __shared__ float red[256];
+    // block = 4 pairs x 64 slices-lanes; consecutive threads take consecutive pairs so the loads stay coalesced
+    const int q = blockIdx.x * 4 + (threadIdx.x & 3);
+    const int lane = threadIdx.x >> 2;
+    float a = 0.f;
+    if (q < npairs)
+        for (int s = lane; s < nsplit; s += 64) a += part[(long)s * npairs + q];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w >= 4; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4 && q < npairs) {
+        const int o = q / sx, i = q - o * sx;
+        float* dst = i < Cin ? dW + o * Cin + i : (db ? db + o : nullptr);
+        if (dst) *dst = accumulate ? *dst + red[threadIdx.x] : red[threadIdx.x];
+    }
+}
+
+// plain [R][Cc][inner]  <->  padded [.][Cp][inner] (rows r < R, columns c < Cc of the padded tensor)
+__global__ __launch_bounds__(256) void pad_copy_kernel(const ffno_pad_desc* __restrict__ descs, int to_padded) {
+    const ffno_pad_desc d = descs[blockIdx.y];
+    const long n = (long)d.R * d.Cc * d.inner;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long k = e % d.inner;
+        const long rc = e / d.inner;
+        const long c = rc % d.Cc, r = rc / d.Cc;
+        const long pidx = (r * d.Cp + c) * d.inner + k;
+        if (to_padded)
+            d.padded[pidx] = d.plain[e];
+        else
+            d.plain[e] = d.padded[pidx];
+    }
+}
+
+static inline int plin_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+static inline unsigned plin_grid(long P) {
+    const long ntile = (P + kPlinTile - 1) / kPlinTile;
+    return (unsigned)(ntile < 2048 ? ntile : 2048);
+}
+
+}  // namespace ffno
+
+using namespace ffno;
+
+extern "C" {
+
+int ffno_plin_supported(int Cin, int Cout) {
+    return (Cin >= 1 && Cout >= 1 && Cin <= 128 && Cout <= 128 && (Cin + 1) * ((Cout + kPlinOB - 1) / kPlinOB) <= 256 * kPlinMaxJ) ? 1 : 0;
+}
+
+int ffno_plin_fwd(const float* x, int ldx, const float* W, const float* b, const float* add, float* out, int ldo,
+                  const float* res, float* out2, long P, int Cin, int Cout, int relu, void* stream) {
+    if (!x || !W || !out || P <= 0 || ldx < Cin || ldo < Cout || (out2 && !res)) return FFNO_EINVAL;
+    if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)kPlinTile * (Cin + 1) + (size_t)Cout * (Cin + 1) + Cout);
+    FFNO_LAUNCH(plin_fwd_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, b, add, out, ldo, res, out2, P,
+                Cin, Cout, relu);
+    return plin_status();
+}
+
+int ffno_plin_bwd_data(const float* g, int ldg, const float* act, const float* W, float* dx, int ldx, float* dpre_out, long P,
+                       int Cin, int Cout, int accumulate, void* stream) {
+    if (!g || !W || !dx || P <= 0 || ldg < Cout || ldx < Cin) return FFNO_EINVAL;
+    if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
+    const size_t lds = sizeof(float) * ((size_t)kPlinTile * (Cout + 1) + (size_t)Cout * Cin);
+    FFNO_LAUNCH(plin_bwd_data_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, g, ldg, act, W, dx, ldx, dpre_out,
+                P, Cin, Cout, accumulate);
+    return plin_status();
+}
+
+int ffno_plin_wgrad_nsplit(long P) {
+    const long n = (P + 255) / 256;
+    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+}
+
+size_t ffno_plin_wgrad_partial_floats(long P, int Cin, int Cout) {
+    return (size_t)ffno_plin_wgrad_nsplit(P) * Cout * (Cin + 1);
+}
+
+int ffno_plin_bwd_weights(const float* g, int ldg, const float* act, const float* x, int ldx, float* part, float* dW, float* db,
+                          long P, int Cin, int Cout, int accumulate, void* stream) {
+    if (!g || !x || !part || !dW || P <= 0 || ldg < Cout || ldx < Cin) return FFNO_EINVAL;
+    if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
+    const int nsplit = ffno_plin_wgrad_nsplit(P);
+    const long per = ((P + nsplit - 1) / nsplit + kPlinTile - 1) / kPlinTile * kPlinTile;
+    const int sdp = (Cout + kPlinOB - 1) / kPlinOB * kPlinOB;
+    const size_t lds = sizeof(float) * ((size_t)kPlinTile * sdp + (size_t)kPlinTile * (Cin + 1));
+    FFNO_LAUNCH(plin_wgrad_partial_kernel, dim3(nsplit), dim3(256), lds, (hipStream_t)stream, g, ldg, act, x, ldx, part, P, Cin,
+                Cout, per);
+    int rc = plin_status();
+    if (rc) return rc;
+    const int npairs = Cout * (Cin + 1);
+    FFNO_LAUNCH(plin_wgrad_reduce_kernel, dim3((npairs + 3) / 4), dim3(256), 0, (hipStream_t)stream, part, dW, db, Cin, Cout,
+                nsplit, accumulate);
+    return plin_status();
+}
+
+int ffno_pad_copy(const ffno_pad_desc* descs, int n, int to_padded, void* stream) {
+    if (!descs || n <= 0) return FFNO_EINVAL;
+    FFNO_LAUNCH(pad_copy_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream, descs, to_padded);
+    return plin_status();
+}
+
+}  // extern "C"

@@ -1,1 +1,2 @@
+from .grid_2d import FNOZongyi2DBlock  # noqa: F401
 from .grid_plus_2d import FNOPlus2DBlock  # noqa: F401

@@ -156,3 +156,33 @@ def feedforward(x, resid, lin0, lin1):
     W1, W2 = weight_norm_weight(lin0), weight_norm_weight(lin1)
     out = _FeedForwardFn.apply(s, r, W1.contiguous(), lin0.bias, W2.contiguous(), lin1.bias)
     return out.view(shp)
+
+
+class _LpRelLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        lib = _lib.get_lib()
+        B = pred.shape[0]
+        n = pred.numel() // B
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        g = torch.empty_like(pred)
+        tmp = torch.empty(int(lib.ffno_lploss_tmp_floats(B, n)), dtype=torch.float32, device=pred.device)
+        _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(loss), _p(g), _p(tmp), B, n, 1.0, None,
+                                            _lib.current_stream(pred.device)), "lploss")
+        ctx.save_for_backward(g)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        return g * gout, None
+
+
+def lp_rel_loss(pred, target):
+    """``LpLoss(size_average=True)(pred.reshape(B, -1), target.reshape(B, -1))`` (reference modules/loss.py:33-46):
+    mean_b ||pred_b - target_b||_2 / ||target_b||_2, loss and gradient from one fused HIP pass."""
+    _lib.require_device_tensor(pred, "pred")
+    _lib.require_device_tensor(target, "target")
+    if pred.numel() != target.numel() or pred.shape[0] != target.shape[0]:
+        raise ValueError(f"shape mismatch: {tuple(pred.shape)} vs {tuple(target.shape)}")
+    return _LpRelLossFn.apply(pred.contiguous(), target.contiguous())

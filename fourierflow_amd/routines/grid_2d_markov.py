@@ -57,8 +57,13 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         self._vel_ws = None
         self._opt_kw = dict(lr=2.5e-3, weight_decay=1e-4)
         self._opt_kw.update(optimizer or {})
-        self._sch_kw = dict(num_warmup_steps=500, num_training_steps=100000, num_cycles=0.5)
+        # the F-FNO configs run cosine-with-warm-up per step; the FNOZongyi2DBlock ablations (torus_li/ablation/zongyi_markov*)
+        # run torch.optim.lr_scheduler.StepLR(step_size, gamma) per EPOCH -- recognised by its keyword arguments
+        self._step_lr = scheduler is not None and "step_size" in scheduler
+        self._sch_kw = dict(step_size=100, gamma=0.5) if self._step_lr else \
+            dict(num_warmup_steps=500, num_training_steps=100000, num_cycles=0.5)
         self._sch_kw.update(scheduler or {})
+        self.current_epoch = 0
         self._trainer: Optional[FFNOTrainer] = None
         self._derived = None
         self._partial = None
@@ -67,7 +72,13 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
     # ----------------------------------------------------------------------------------------------
     def trainer(self) -> FFNOTrainer:
         if self._trainer is None:
-            self._trainer = FFNOTrainer(self.conv, **self._opt_kw, **self._sch_kw)
+            if self._step_lr:
+                tr = FFNOTrainer(self.conv, **self._opt_kw)
+                step, gamma = int(self._sch_kw["step_size"]), float(self._sch_kw["gamma"])
+                tr.lr_factor = lambda: gamma ** (self.current_epoch // step)
+                self._trainer = tr
+            else:
+                self._trainer = FFNOTrainer(self.conv, **self._opt_kw, **self._sch_kw)
         return self._trainer
 
     def _build_features(self, batch: Dict[str, torch.Tensor], noise: Optional[torch.Tensor] = None,
@@ -155,6 +166,7 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
 
     def training_step(self, batch, epoch: int, noise: Optional[torch.Tensor] = None):
         """Epoch 0 only accumulates the normaliser statistics (grid_2d_markov.py:376-378); later epochs train."""
+        self.current_epoch = int(epoch)
         if self.should_normalize and epoch < 1:
             with torch.no_grad():
                 self._build_features(batch, noise)

@@ -34,7 +34,12 @@ def main(argv=None):
     G = args.grid
 
     mesh = hasattr(routine, "model")                     # StructuredMeshExperiment: plain x -> y regression on a mesh
-    if mesh:
+    rollout = type(routine).__name__ == "Grid2DRolloutExperiment"    # 10 input frames + n_steps targets (NSZongyiBuilder)
+    if rollout:
+        def batch():
+            xx = torch.cat([torch.randn(B, G, G, 10, device=dev), routine._positions(B, G, G, dev)], dim=-1)
+            return dict(x=xx, y=torch.randn(B, G, G, routine.n_steps, device=dev))
+    elif mesh:
         size = tuple(args.size or (G, G))
         cin = routine.model.input_dim - len(size)
         cout = getattr(routine.model, "output_dim", 1)
@@ -48,12 +53,15 @@ def main(argv=None):
     start = dict(epoch=0, global_step=0)
     if args.resume:
         start = routine.resume_from_checkpoint(args.resume)
-    for _ in range(0 if (mesh or args.resume) else args.accumulation_batches):   # epoch 0: normaliser statistics only
+    for _ in range(0 if (mesh or rollout or args.resume) else args.accumulation_batches):   # epoch 0: normaliser statistics only
         routine.training_step(batch(), epoch=0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for step in range(args.steps):
-        loss = routine.training_step(batch(), step) if mesh else routine.training_step(batch(), epoch=1)
+        if rollout:
+            loss = routine.training_step(batch(), step)[0]
+        else:
+            loss = routine.training_step(batch(), step) if mesh else routine.training_step(batch(), epoch=1)
         if step % max(1, args.steps // 5) == 0 or step == args.steps - 1:
             print(json.dumps(dict(step=step, loss=round(float(loss.item()), 6), lr=routine.trainer().current_lr())), flush=True)
     torch.cuda.synchronize()

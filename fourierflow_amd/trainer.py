@@ -40,6 +40,7 @@ class FFNOTrainer:
         self.engine = block.engine()
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.sched = (num_warmup_steps, num_training_steps, num_cycles)
+        self.lr_factor = None          # optional callable() -> multiplier replacing the cosine schedule (StepLR per epoch)
         self.step_count = 0
         self.loss_scale = loss_scale   # StructuredMeshExperiment: gradients of loss * loss_scale (structured_mesh.py:29)
         self.pg = process_group
@@ -73,6 +74,8 @@ class FFNOTrainer:
 
     def current_lr(self) -> float:
         """lr used by the NEXT optimiser step (LambdaLR semantics: factor(number of completed steps))."""
+        if self.lr_factor is not None:
+            return self.lr * float(self.lr_factor())
         return self.lr * cosine_warmup_factor(self.step_count, *self.sched)
 
     def loss_and_grad(self, pred: torch.Tensor, target: torch.Tensor, affine: Optional[torch.Tensor] = None):

@@ -369,6 +369,39 @@ int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, floa
                     float beta2, float eps, float weight_decay, int step, float grad_scale,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Pointwise linear layers of the FNOZongyi2DBlock baseline (zongyi_fno/grid_2d.py:22,45,74-77 the per-layer
+ * `linear` + residual + ReLU; :106 in_proj; :119-122 feedforward head) on channels-last buffers whose
+ * leading dimension may exceed the logical width (20 channels live in 32-channel tiles, pad = 0):
+ *   fwd:         out[p][o] = act(b[o] + sum_i W[o][i] x[p*ldx+i] + add[p*ldo+o]),  o < Cout; 0 for Cout <= o < ldo
+ *                out2 (optional) = out + res   (block-level residual `layer(x) + x`, grid_2d.py:126)
+ *   bwd_data:    dpre = g * (act ? act > 0 : 1);  dx[p*ldx+i] (+)= sum_o dpre[p][o] W[o][i]  (i >= Cin: 0);
+ *                dpre_out (optional, layout of g) receives dpre
+ *   bwd_weights: dW[o][i] (+)= sum_p dpre[p][o] x[p][i],  db[o] (+)= sum_p dpre[p][o]   (deterministic two-stage
+ *                reduction through `part`, ffno_plin_wgrad_partial_floats() floats)
+ * W is [Cout][Cin] row-major (nn.Linear.weight).  Cin, Cout <= 128 and (Cin+1)*ceil(Cout/8) <= 768.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_plin_supported(int Cin, int Cout);
+int ffno_plin_fwd(const float* x, int ldx, const float* W, const float* b, const float* add, float* out,
+                  int ldo, const float* res, float* out2, long P, int Cin, int Cout, int relu,
+                  void* stream);
+int ffno_plin_bwd_data(const float* g, int ldg, const float* act, const float* W, float* dx, int ldx,
+                       float* dpre_out, long P, int Cin, int Cout, int accumulate, void* stream);
+int ffno_plin_wgrad_nsplit(long P);
+size_t ffno_plin_wgrad_partial_floats(long P, int Cin, int Cout);
+int ffno_plin_bwd_weights(const float* g, int ldg, const float* act, const float* x, int ldx, float* part,
+                          float* dW, float* db, long P, int Cin, int Cout, int accumulate, void* stream);
+
+/* One launch copying n parameter tensors between their reference shapes and channel-padded twins:
+ * plain [R][Cc][inner] <-> rows r < R, columns c < Cc of padded [.][Cp][inner]; to_padded = 0 copies back
+ * (gradients).  descs is a DEVICE array. */
+typedef struct ffno_pad_desc {
+    float* plain;
+    float* padded;
+    int32_t R, Cc, inner, Cp;
+} ffno_pad_desc;
+int ffno_pad_copy(const ffno_pad_desc* descs, int n, int to_padded, void* stream);
+
 /* small utilities used by the host driver */
 int ffno_axpy(float* y, const float* x, float alpha, size_t n, void* stream); /* y += alpha*x */
 

@@ -23,10 +23,14 @@ FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), FNOZongyi2DBlock (zongyi_fno/grid_2
 feature build (routines/grid_2d_markov.py:124-170).
 
 Parity status: PINNED against golden vectors generated from the imported
-reference (tests/golden/*.npz, generator tools/make_golden.py) -- with ONE exception: ``velocity_features`` /
-``velocity_wavenumbers`` (the `use_velocity` branch of routines/grid_2d_markov.py:82-94,130-144).  That routine and
-its jax_cfd dependency cannot be imported here, so for that piece PARITY IS UNPINNED by a reference run; it is
-pinned only analytically (plane-wave known answers and curl / divergence identities, tests/test_velocity.py).
+reference (tests/golden/*.npz, generator tools/make_golden.py) -- with TWO exceptions:
+  * ``velocity_features`` / ``velocity_wavenumbers`` (the `use_velocity` branch of
+    routines/grid_2d_markov.py:82-94,130-144).  That routine and its jax_cfd dependency cannot be imported here, so for
+    that piece PARITY IS UNPINNED by a reference run; it is pinned only analytically (plane-wave known answers and
+    curl / divergence identities, tests/test_velocity.py).
+  * ``rollout_learning_step`` (routines/grid_2d_rollout.py:75-150): the routine imports wandb / pytorch_lightning (absent),
+    so the loop is restated from the file and PARITY IS UNPINNED by a reference run for the loop itself; every operator
+    inside it (FNOZongyi2DBlock, LpLoss.rel) is pinned by golden vectors.
 """
 from __future__ import annotations
 
@@ -369,6 +373,49 @@ def fno_zongyi_2d(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int
         x = y + x if residual else y
     x = torch.relu(F.linear(x, sd["feedforward.0.weight"], sd["feedforward.0.bias"]))
     return {"forecast": F.linear(x, sd["feedforward.2.weight"], sd["feedforward.2.bias"])}
+
+
+# --------------------------------------------------------------------------
+# Grid2DRolloutExperiment._learning_step (routines/grid_2d_rollout.py:75-150, use_fourier_position=False): feed the
+# model its own forecasts for n_steps; loss = mean of the per-step LpLoss.rel; also the validation metrics.
+# ``conv`` maps [B, X, Y, C] -> forecast [B, X, Y, 1].
+# --------------------------------------------------------------------------
+def rollout_positions(B: int, X: int, Y: int, dtype=torch.float32) -> Tensor:
+    ticks = torch.linspace(0, 1, X, dtype=dtype)                       # :96 (the X ticks serve both axes, :97-98)
+    gx = ticks[None, :, None, None].expand(B, X, Y, 1)
+    gy = ticks[None, None, :, None].expand(B, X, Y, 1)
+    return torch.cat([gx, gy], dim=-1)
+
+
+def rollout_learning_step(conv, xx: Tensor, yy: Tensor, n_steps: int, append_pos: bool = True,
+                          teacher_forcing: bool = False, training: bool = True, step_size: float = 1.0):
+    B, X, Y, _ = xx.shape
+    pos = rollout_positions(B, X, Y, xx.dtype)
+    embeds, P = xx, 2
+    loss, step_losses, preds = 0, [], []
+    for t in range(n_steps):
+        y = yy[..., t:t + 1]
+        im = conv(embeds)
+        l = lp_rel_loss(im.reshape(B, -1), y.reshape(B, -1))           # :112
+        step_losses.append(l)
+        loss = loss + l
+        preds.append(im)
+        if teacher_forcing and training:                               # :117-118
+            im = y
+        if append_pos:                                                 # :123-126
+            embeds = torch.cat((embeds[..., 1:-P], im, pos), dim=-1)
+        else:
+            embeds = torch.cat((embeds[..., 1:], im), dim=-1)
+    pred = torch.cat(preds, dim=-1)
+    loss = loss / n_steps
+    yy = yy[..., :n_steps]
+    loss_full = lp_rel_loss(pred.reshape(B, -1), yy.reshape(B, -1))    # :129
+    pn = torch.norm(pred, dim=[1, 2], keepdim=True)
+    yn = torch.norm(yy, dim=[1, 2], keepdim=True)
+    p = ((pred / pn) * (yy / yn)).sum(dim=[1, 2]).mean(dim=0)          # :131-135
+    div = (p < 0.95).nonzero()
+    time_until = (int(div[0, 0]) if len(div) > 0 else len(p)) * step_size
+    return loss, loss_full, pred, step_losses, p, time_until
 
 
 # --------------------------------------------------------------------------

@@ -244,7 +244,7 @@ def golden_kwargs(npz) -> dict:
     return ast.literal_eval(str(npz["kwargs"]))
 
 
-def make_zongyi_state_dict(kw: dict, seed: int = 51):
+def make_zongyi_state_dict(kw: dict, seed: int = 51, grid: int = 64):
     """Deterministic FNOZongyi2DBlock weights (zongyi_fno/grid_2d.py:81-117 layout) + the config-0 input batch
     [2, 64, 64, input_dim].  Fourier weights use std 0.02 (the reference's init, gain 1/(I*O), is ~1e-5 and
     would leave the spectral path numerically invisible)."""
@@ -264,5 +264,5 @@ def make_zongyi_state_dict(kw: dict, seed: int = 51):
             sd[pre + f"fourier_weight.{j}"] = (rs.standard_normal((W, W, K, K, 2)) * 0.02).astype(np.float32)
     lin("feedforward.0.", W, 128)
     lin("feedforward.2.", 128, 1)
-    x = rs.standard_normal((2, 64, 64, I)).astype(np.float32)
+    x = rs.standard_normal((2, grid, grid, I)).astype(np.float32)
     return sd, x

@@ -76,7 +76,7 @@ def test_reference_style_config_builds_and_trains(tmp_path, host_device):
 def test_unknown_reference_targets_fail_loudly(tmp_path):
     from fourierflow_amd.config import instantiate
     with pytest.raises(NotImplementedError):
-        instantiate({"_target_": "fourierflow.modules.FNOZongyi2DBlock", "modes1": 12})
+        instantiate({"_target_": "fourierflow.modules.FNOMesh2D", "modes1": 12})
     with pytest.raises(ValueError):
         instantiate("${nope: 1}")
     assert instantiate("${eval: 2 * 3}") == 6
@@ -90,6 +90,7 @@ REFERENCE_CONFIGS = [
     ("pipe/ffno/8_layers", "StructuredMeshExperiment", "model", "FNOFactorizedMesh2D"),
     ("torus_kochkov/ffno/ablation/fno++/128", "Grid2DMarkovExperiment", "conv", "FNOPlus2DBlock"),
     ("torus_kochkov/ffno/grid_sizes/256", "Grid2DMarkovExperiment", "conv", "FNOFactorized2DBlock"),
+    ("torus_li/zongyi/4_layers", "Grid2DRolloutExperiment", "conv", "FNOZongyi2DBlock"),       # BASELINE config 0
 ]
 
 
@@ -128,7 +129,7 @@ def test_every_shipped_ffno_config_builds():
     if not paths:
         pytest.skip("reference experiments are only present in the build container")
     from fourierflow_amd.config import build_routine, load_config
-    known = ("FNOZongyi2DBlock", "FNOMesh2D", "FNOMesh3D", "PointCloud", "CNOFactorized", "IPhi",
+    known = ("FNOZongyi2DBlock", "width > 32", "FNOMesh2D", "FNOMesh3D", "PointCloud", "CNOFactorized", "IPhi",
              "only torch.optim.AdamW", "only CosineWithWarmupScheduler", "optax", "shuffle_grid", "use_fourier_position",
              "MeshGraphNet", "LearnedInterpolator", "Grid2DRolloutExperiment")
     built, unexpected = 0, []

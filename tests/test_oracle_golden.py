@@ -84,3 +84,19 @@ def test_zongyi_baseline_config0_matches_reference():
     assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, float(g["loss"]))
     for n in [k for k in gu.packed_names(g) if k.startswith("grad.")]:
         assert gu.compare_packed(g, n, sd[n[5:]].grad.numpy(), TOL) < 5e-5, n
+
+
+def test_zongyi_markov_residual_flags_match_reference():
+    """residual=True, conv_residual=False (torus_li/ablation/zongyi_markov_residual; grid_2d.py:74-77,126)."""
+    g = gu.load_golden("zongyi_markov_residual")
+    kw = gu.golden_kwargs(g)
+    sd_np, x = gu.make_zongyi_state_dict(kw, int(g["seed"]), grid=int(g["grid"]))
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
+    out = orc.fno_zongyi_2d(sd, torch.tensor(x), modes=kw["modes1"], n_layers=kw["n_layers"], residual=kw["residual"],
+                            conv_residual=kw["conv_residual"])["forecast"]
+    loss = (out ** 2).mean()
+    loss.backward()
+    assert gu.compare_packed(g, "forecast", out.detach().numpy(), TOL) < TOL
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * max(1.0, float(g["loss"]))
+    for n in [k for k in gu.packed_names(g) if k.startswith("grad.")]:
+        assert gu.compare_packed(g, n, sd[n[5:]].grad.numpy(), TOL) < 5e-5, n

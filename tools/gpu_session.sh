@@ -44,6 +44,13 @@ for st in $STAGES; do
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_mesh3d" -o m3 -- python "$OLDPWD/tools/bench_mesh.py" --preset plasticity --steps 5 --warmup 2 > "$OLDPWD/gpurun_out/prof_mesh3d.log" 2>&1)
       db=$(find gpurun_out/prof_mesh3d -name "*.db" | head -1); python tools/rocpd_stats.py "$db" > gpurun_out/mesh3d_kernel_stats.md 2>&1; head -n 30 gpurun_out/mesh3d_kernel_stats.md | cut -c1-180
       find gpurun_out/prof_mesh3d -size +20M -delete ;;
+    zongyi)
+      timeout 600 python tools/bench_zongyi.py > gpurun_out/bench_zongyi.log 2>&1
+      echo "[session] zongyi rc=$?"; tail -n 2 gpurun_out/bench_zongyi.log | cut -c1-700
+      rm -rf gpurun_out/prof_zongyi
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_zongyi" -o z -- python "$OLDPWD/tools/bench_zongyi.py" --steps 3 --warmup 1 --cpu 0 > "$OLDPWD/gpurun_out/prof_zongyi.log" 2>&1)
+      db=$(find gpurun_out/prof_zongyi -name "*.db" | head -1); python tools/rocpd_stats.py "$db" > gpurun_out/zongyi_kernel_stats.md 2>&1; head -n 22 gpurun_out/zongyi_kernel_stats.md | cut -c1-180
+      find gpurun_out/prof_zongyi -size +20M -delete ;;
     bench19)
       timeout 600 python bench.py --steps 20 --warmup 5 --batch 19 --cpu-steps 0 > gpurun_out/bench_b19.log 2>&1
       echo "[session] bench19 rc=$?"; grep "timed region" gpurun_out/bench_b19.log ;;
