@@ -422,7 +422,7 @@ class FFNOEngine:
             ws.fwpart = [[torch.empty(ws.nsplit_fw[w] * 2 * (ws.views[w].K2 if self.spectral == "plus" else ws.views[w].K)
                                       * C * C, **f32) for w in range(nv)]
                          for _ in range(max(len(self._fw_sets), 1))]
-            ws.nsplit_lift = max(1, min(256, (P_in + 255) // 256))
+            ws.nsplit_lift = max(1, min(1024, (P_in + 127) // 128))     # all slices co-resident (16 KB LDS per workgroup)
             ws.liftpart = torch.empty(ws.nsplit_lift * C * (self.Cin + 1), **f32)
             ws.nsplit_head = max(1, min(256, (P_in + 255) // 256))
             ws.headpart = torch.empty(ws.nsplit_head * O * (C + 1), **f32)

@@ -21,6 +21,8 @@ def _block(kw, sd_np, device):
 
 @pytest.mark.parametrize("name", ["zongyi_4l", "zongyi_markov_residual"])
 def test_zongyi_hip_path_matches_reference_golden(host_device, name):
+    if host_device == "cpu" and name == "zongyi_4l":
+        pytest.skip("64 x 64 config-0 shape: GPU only (the wave emulator covers the 16 x 16 golden and the ragged shapes)")
     g = gu.load_golden(name)
     kw = gu.golden_kwargs(g)
     grid = int(g["grid"]) if "grid" in g.files else 64
