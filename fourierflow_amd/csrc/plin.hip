@@ -252,9 +252,9 @@ int ffno_plin_bwd_data(const float* g, int ldg, const float* act, const float* W
     return plin_status();
 }
 
-int ffno_plin_wgrad_nsplit(long P) {
-    const long n = (P + 255) / 256;
-    return (int)(n < 1 ? 1 : (n > 256 ? 256 : n));
+int ffno_plin_wgrad_nsplit(long P) {      // two 64-point tiles per slice, all slices co-resident (41 KB of LDS each)
+    const long n = (P + 127) / 128;
+    return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 
 size_t ffno_plin_wgrad_partial_floats(long P, int Cin, int Cout) {

@@ -38,7 +38,7 @@ class _ZongyiFn(torch.autograd.Function):
         slot = 0
         if need_grad:
             slot = module._next_slot()
-        y = eng.forward(x, need_grad, slot=slot, n_slots=module.max_live_passes)
+        y = eng.forward(x, need_grad, slot=slot, n_slots=module.max_live_passes, weights_ready=module.weights_frozen)
         ctx.module, ctx.slot, ctx.ticket = module, slot, module._tickets[slot] if need_grad else None
         return y
 
@@ -78,6 +78,7 @@ class FNOZongyi2DBlock(nn.Module):
             for _ in range(n_layers)])
         self.feedforward = nn.Sequential(nn.Linear(width, 128), nn.ReLU(inplace=True), nn.Linear(128, 1))
         self._engine = None
+        self.weights_frozen = False              # True: the padded / packed weights of the last pass are still valid
         self.fused_grad_accumulation = False     # True: parameter gradients accumulate in engine().gflat, .grad stays None
         self.max_live_passes = 16       # forward passes that may await their backward at once (rollout: n_steps)
         self._tickets, self._cursor, self._ticket = {}, 0, 0

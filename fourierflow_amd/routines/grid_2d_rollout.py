@@ -74,19 +74,23 @@ class Grid2DRolloutExperiment(CheckpointMixin, nn.Module):
         embeds = xx.contiguous()
         loss = 0
         step_losses, preds = [], []
-        for t in range(self.n_steps):
-            y = yy[..., t:t + 1].contiguous()
-            im = self.conv(embeds)['forecast']
-            l = lp_rel_loss(im, y)
-            step_losses.append(l)
-            loss = loss + l
-            preds.append(im)
-            if self.teacher_forcing and self.training:
-                im = y
-            if self.append_pos:
-                embeds = torch.cat((embeds[..., 1:-P], im, pos_feats), dim=-1)
-            else:
-                embeds = torch.cat((embeds[..., 1:], im), dim=-1)
+        try:
+            for t in range(self.n_steps):
+                y = yy[..., t:t + 1].contiguous()
+                self.conv.weights_frozen = t > 0      # the parameters do not change inside a rollout: pack them once
+                im = self.conv(embeds)['forecast']
+                l = lp_rel_loss(im, y)
+                step_losses.append(l)
+                loss = loss + l
+                preds.append(im)
+                if self.teacher_forcing and self.training:
+                    im = y
+                if self.append_pos:
+                    embeds = torch.cat((embeds[..., 1:-P], im, pos_feats), dim=-1)
+                else:
+                    embeds = torch.cat((embeds[..., 1:], im), dim=-1)
+        finally:
+            self.conv.weights_frozen = False
         pred = torch.cat(preds, dim=-1)
         loss = loss / self.n_steps
         with torch.no_grad():

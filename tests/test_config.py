@@ -148,4 +148,4 @@ def test_every_shipped_ffno_config_builds():
         except Exception as e:  # noqa: BLE001 - anything else is a loader bug
             unexpected.append((os.path.relpath(p, root), repr(e)))
     assert not unexpected, unexpected[:5]
-    assert built >= 150, built
+    assert built >= 170, built
