@@ -77,6 +77,7 @@ class ZongyiEngine:
         self._ws = {}
         self._tw = {}
         self._ptr_sig = None
+        self._packed = False
 
     # ------------------------------------------------------------------------------------------------
     def _k(self, name, fn, *args):
@@ -104,6 +105,10 @@ class ZongyiEngine:
             dev = dev or t.device
             if t.device != dev:
                 raise ValueError("all parameters must live on one device")
+        sig = tuple(params[n].data_ptr() for n in self.param_names)
+        if sig != getattr(self, "_bound_sig", None):
+            self._packed = False          # other tensors: the padded twins are stale whatever the caller says
+        self._bound_sig = sig
         self.params = {n: params[n] for n in self.param_names}
         if dev != self.device:
             self.device = dev
@@ -224,6 +229,7 @@ class ZongyiEngine:
     def _prepare_weights(self, st):
         lib = _lib.get_lib()
         self._refresh_pointers()
+        self._packed = True
         self._k("pad_copy", lib.ffno_pad_copy, _p(self._ptab), len(self.param_names), 1, st)
         for l in range(self.L):
             pre = f"spectral_layers.{l}."
@@ -246,7 +252,7 @@ class ZongyiEngine:
         st = _lib.current_stream(self.device)
         self._issue_stream = st
         C, L, P, Cin = self.C, self.L, ws.P, self.Cin
-        if not weights_ready:
+        if not (weights_ready and self._packed):      # weights_ready: the caller vouches the parameters did not change
             self._prepare_weights(st)
         pp = self._pp
         if save_for_backward:
