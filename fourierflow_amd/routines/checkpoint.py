@@ -19,6 +19,16 @@ REMOVE_KEYS = ['kx', 'ky', 'lap', 'kx_32', 'ky_32', 'lap_32', 'kx_64', 'ky_64', 
                'kx_256', 'ky_256', 'lap_256']
 
 
+def reject_unsupported_routine_kwargs(kwargs: Dict[str, Any]) -> None:
+    """The routines accept (and ignore) the reference Routine's logging / Lightning keyword arguments, but options that
+    would change the optimisation (routines/base.py:27-52) and are not built must fail loudly, not silently."""
+    if kwargs.get("clip_val") is not None:
+        raise NotImplementedError("clip_val (torch.nn.utils.clip_grad_value_) is not folded into the fused optimiser step; "
+                                  "no shipped F-FNO config sets it")
+    if kwargs.get("accumulate_grad_batches", 1) not in (None, 1):
+        raise NotImplementedError("accumulate_grad_batches > 1 is not implemented (no shipped config uses it)")
+
+
 class CheckpointMixin:
     """Needs ``self.trainer() -> FFNOTrainer`` and to be an ``nn.Module``."""
 

@@ -22,7 +22,7 @@ from .. import _capi, _lib
 from ..engine import _p
 from ..modules.normalizer import Normalizer
 from ..trainer import FFNOTrainer
-from .checkpoint import CheckpointMixin
+from .checkpoint import CheckpointMixin, reject_unsupported_routine_kwargs
 
 
 class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
@@ -33,6 +33,7 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
                  learn_difference: bool = False, optimizer: Optional[dict] = None, scheduler: Optional[dict] = None,
                  domain=((0.0, 2 * math.pi), (0.0, 2 * math.pi)), grid_size=(64,), **unused):
         super().__init__()
+        reject_unsupported_routine_kwargs(unused)
         for flag, name in ((shuffle_grid, "shuffle_grid"), (use_fourier_position, "use_fourier_position")):
             if flag:
                 raise NotImplementedError(f"{name}=True is outside the Markov paths built here (one shipped config each)")

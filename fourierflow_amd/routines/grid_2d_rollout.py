@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from ..ops import lp_rel_loss
 from ..trainer import FFNOTrainer
-from .checkpoint import CheckpointMixin
+from .checkpoint import CheckpointMixin, reject_unsupported_routine_kwargs
 
 
 class Grid2DRolloutExperiment(CheckpointMixin, nn.Module):
@@ -25,6 +25,7 @@ class Grid2DRolloutExperiment(CheckpointMixin, nn.Module):
                  use_fourier_position: bool = False, append_pos: bool = True, teacher_forcing: bool = False,
                  step_size: float = 1.0, optimizer: Optional[dict] = None, scheduler: Optional[dict] = None, **unused):
         super().__init__()
+        reject_unsupported_routine_kwargs(unused)
         if use_fourier_position:
             raise NotImplementedError("use_fourier_position=True (fourier_encode features) is not used by any shipped "
                                       "config of this routine and is not implemented")

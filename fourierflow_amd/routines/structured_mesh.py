@@ -7,13 +7,14 @@ from typing import Optional
 import torch.nn as nn
 
 from ..trainer import FFNOTrainer
-from .checkpoint import CheckpointMixin
+from .checkpoint import CheckpointMixin, reject_unsupported_routine_kwargs
 
 
 class StructuredMeshExperiment(CheckpointMixin, nn.Module):
     def __init__(self, model: nn.Module, loss_scale: float = 1.0, optimizer: Optional[dict] = None,
                  scheduler: Optional[dict] = None, **unused):
         super().__init__()
+        reject_unsupported_routine_kwargs(unused)
         self.model, self.loss_scale = model, loss_scale
         self._opt_kw = dict(lr=1e-3, weight_decay=1e-4)
         self._opt_kw.update(optimizer or {})

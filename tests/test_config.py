@@ -75,6 +75,14 @@ def test_reference_style_config_builds_and_trains(tmp_path, host_device):
 
 def test_unknown_reference_targets_fail_loudly(tmp_path):
     from fourierflow_amd.config import instantiate
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    conv = FNOFactorized2DBlock(modes=4, width=32, n_layers=1, input_dim=3)
+    Grid2DMarkovExperiment(conv, clip_val=None, automatic_optimization=False, accumulate_grad_batches=1)   # reference defaults
+    with pytest.raises(NotImplementedError, match="clip_val"):
+        Grid2DMarkovExperiment(conv, clip_val=0.1)
+    with pytest.raises(NotImplementedError, match="accumulate_grad_batches"):
+        Grid2DMarkovExperiment(conv, accumulate_grad_batches=4)
     with pytest.raises(NotImplementedError):
         instantiate({"_target_": "fourierflow.modules.FNOMesh2D", "modes1": 12})
     with pytest.raises(ValueError):
