@@ -114,6 +114,10 @@ def algorithmic_work(P, C, H, K, B, M, N, L, paired=True):
     return {
         "spectral_fused": sf,
         "spectral_fused(adj)": sa,
+        # the same two branches through the three paired STAGE launches (K > 16: 256 x 256 grids); one "launch" = the three
+        # kernels of a ffno_spectral_staged_pair call, algorithmic work as above (the spectra that travel are overhead)
+        "spectral_staged_pair": sf,
+        "spectral_staged_pair(adj)": sa,
         # split-bf16 feed-forward (ffx.hip): no hidden activations in HBM, only the ReLU sign bits (P*H/8 bytes); the
         # weight-gradient kernel recomputes h and dh, so its algorithmic FLOPs are 4 GEMMs (2 recomputed + 2 gradients)
         # (+ with paired branches: the second branch buffer is read and the sum written back while staging)
@@ -241,7 +245,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         log("warm-up done; timing")
-    names = ["spectral_fused", "spectral_fused(adj)", "ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial", "fw_grad_partial"]
+    names = ["spectral_fused", "spectral_fused(adj)", "spectral_staged_pair", "spectral_staged_pair(adj)", "ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial", "fw_grad_partial"]
     timer = KernelTimer(names, every=7) if rank == 0 else None   # sample 1 launch in 7 (odd: both branches get sampled)
     trainer.engine.timer = timer
     if timer:

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
+    "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),

@@ -69,10 +69,13 @@ struct ColVec<2> {
 // A operand (F) comes from the LDS twiddle table, B operand (x) straight from global memory:
 // lane (j, half) loads channels CT*j..CT*j+CT-1 of element n = 2t+half, i.e. each load instruction
 // covers two full C-float rows (contiguous 512 B for C=64 on axis 0).
+// (bidx, nblk) = this workgroup's index and the number of workgroups working on THIS branch: the paired launch runs the
+// two axes of a layer side by side in one grid (256 x 256 at batch 2 has 512 lines per axis -- one launch per axis leaves
+// most SIMDs without a wave).
 template <int C, int RT>
-__global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ x, float* __restrict__ spec,
-                                                      const float* __restrict__ tw, int R, int L, int K,
-                                                      LineMap lm, int scale_ck) {
+__device__ __forceinline__ void dft_fwd_body(const float* __restrict__ x, float* __restrict__ spec,
+                                             const float* __restrict__ tw, int R, int L, int K, const LineMap& lm,
+                                             int scale_ck, int bidx, int nblk) {
     constexpr int CT = C / 32;
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ 
 
     // work item = (line, 32-row tile of the (mode, re/im) rows): with more than 16 modes a line is shared by RT waves
     const long nitems = (long)R * RT;
-    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+    for (long item = (long)bidx * 4 + wave; item < nitems; item += (long)nblk * 4) {
         const int line = (int)(item / RT), rt = (int)(item % RT);
         const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
         const bool valid = kk < 2 * K;
@@ -142,13 +145,39 @@ __global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ 
     }
 }
 
+template <int C, int RT>
+__global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ x, float* __restrict__ spec,
+                                                      const float* __restrict__ tw, int R, int L, int K,
+                                                      LineMap lm, int scale_ck) {
+    dft_fwd_body<C, RT>(x, spec, tw, R, L, K, lm, scale_ck, blockIdx.x, gridDim.x);
+}
+
+// one branch of a paired stage launch
+struct StageArgs {
+    const float* in;      // activations (dft_fwd) / spectrum (mode_mix, dft_inv)
+    float* out;           // spectrum (dft_fwd, mode_mix) / activations (dft_inv)
+    const float* resid;
+    const float* planes;
+    const float* tw;
+    int R, L, K;
+    LineMap lm;
+    int accumulate;
+};
+
+template <int C, int RT>
+__global__ __launch_bounds__(256) void dft_fwd_pair_kernel(StageArgs a, StageArgs b, int n0, int scale_ck) {
+    if ((int)blockIdx.x < n0)
+        dft_fwd_body<C, RT>(a.in, a.out, a.tw, a.R, a.L, a.K, a.lm, scale_ck, blockIdx.x, n0);
+    else
+        dft_fwd_body<C, RT>(b.in, b.out, b.tw, b.R, b.L, b.K, b.lm, scale_ck, blockIdx.x - n0, gridDim.x - n0);
+}
+
 // ---- stage C ------------------------------------------------------------------------------------
 // One wave per line.  out[n][c] = sum_kk G[n][kk] Y[kk][c]; two 32-row tiles of n per pass.
 template <int C>
-__global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ spec, float* out,
-                                                      const float* resid, const float* __restrict__ tw,
-                                                      int R, int L, int K, LineMap lm, int apply_ck,
-                                                      int accumulate) {
+__device__ __forceinline__ void dft_inv_body(const float* __restrict__ spec, float* out, const float* resid,
+                                             const float* __restrict__ tw, int R, int L, int K, const LineMap& lm,
+                                             int apply_ck, int accumulate, int bidx, int nblk) {
     constexpr int CT = C / 32;
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
@@ -164,7 +193,7 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
     // work item = (line, pair of 32-row output tiles): long lines (L = 256: four pairs) spread over four waves
     const int NP = (RTtot + 1) >> 1;
     const long nitems = (long)R * NP;
-    for (long item = (long)blockIdx.x * 4 + wave; item < nitems; item += (long)gridDim.x * 4) {
+    for (long item = (long)bidx * 4 + wave; item < nitems; item += (long)nblk * 4) {
         const int line = (int)(item / NP);
         const long lbase = lm.base(line) + CT * j;
         {
@@ -243,6 +272,23 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ spec, float* out,
+                                                      const float* resid, const float* __restrict__ tw,
+                                                      int R, int L, int K, LineMap lm, int apply_ck,
+                                                      int accumulate) {
+    dft_inv_body<C>(spec, out, resid, tw, R, L, K, lm, apply_ck, accumulate, blockIdx.x, gridDim.x);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void dft_inv_pair_kernel(StageArgs a, StageArgs b, int n0, int apply_ck) {
+    if ((int)blockIdx.x < n0)
+        dft_inv_body<C>(a.in, a.out, a.resid, a.tw, a.R, a.L, a.K, a.lm, apply_ck, a.accumulate, blockIdx.x, n0);
+    else
+        dft_inv_body<C>(b.in, b.out, b.resid, b.tw, b.R, b.L, b.K, b.lm, apply_ck, b.accumulate, blockIdx.x - n0,
+                        gridDim.x - n0);
+}
+
 // ---- Fourier weight repack ------------------------------------------------------------------------
 __global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wpt,
                                int C, int K) {
@@ -269,16 +315,13 @@ __global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // (conflict-free).  Splitting a tile's two output parts over two waves doubles the number of waves a
 // launch can spread over the chip (256x256 grids: 16 tiles per mode).
 template <int C>
-__global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restrict__ spec_in,
-                                                       const float* __restrict__ planes,
-                                                       float* __restrict__ spec_out, int R, int K,
-                                                       int conj_t) {
+__device__ __forceinline__ void mode_mix_body(const float* __restrict__ spec_in, const float* __restrict__ planes,
+                                              float* __restrict__ spec_out, int R, int conj_t, int k) {
     constexpr int CT = C / 32;
     __shared__ __attribute__((aligned(16))) float smem_mix[2 * C * C];
     float* Wr = smem_mix;
     float* Wi = Wr + C * C;
 
-    const int k = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
     const float* xin = spec_in + (long)k * R * 2 * C;
@@ -337,6 +380,23 @@ __global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restric
             }
         }
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restrict__ spec_in,
+                                                       const float* __restrict__ planes,
+                                                       float* __restrict__ spec_out, int R, int K,
+                                                       int conj_t) {
+    mode_mix_body<C>(spec_in, planes, spec_out, R, conj_t, blockIdx.y);
+}
+
+// grid.y = Ka + Kb modes: the first Ka rows of workgroups mix branch a, the rest branch b
+template <int C>
+__global__ __launch_bounds__(256, 2) void mode_mix_pair_kernel(StageArgs a, StageArgs b, int conj_t) {
+    if ((int)blockIdx.y < a.K)
+        mode_mix_body<C>(a.in, a.planes, a.out, a.R, conj_t, blockIdx.y);
+    else
+        mode_mix_body<C>(b.in, b.planes, b.out, b.R, conj_t, blockIdx.y - a.K);
 }
 
 // ---- fused branch: stage A -> B -> C with the spectrum tile resident in LDS ---------------------------
@@ -935,6 +995,92 @@ extern "C" int ffno_spectral_fused_pair(const ffno_fused_branch* ba, const ffno_
         FFNO_LAUNCH((spectral_fused_pair_kernel<64>), grid, block, smem, (hipStream_t)stream, a, b, n0);
     else
         FFNO_LAUNCH((spectral_fused_pair_kernel<32>), grid, block, smem, (hipStream_t)stream, a, b, n0);
+    return launch_status();
+}
+
+// The three stage kernels of BOTH axes of a layer as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2): for
+// the shapes the fused kernel does not take (K > 16 at C = 64 -- 256 x 256 with 32 / 64 modes) a single axis has too few
+// lines to fill the chip, so the two independent branches share each launch.
+static int stage_branch(StageArgs& s, const ffno_fused_branch* b, int C) {
+    if (!b || !b->in || !b->out || !b->spec_save || !b->tw || b->B <= 0 || b->M <= 0 || b->N <= 0 || b->K <= 0 ||
+        (b->axis != 0 && b->axis != 1))
+        return FFNO_EINVAL;
+    s.R = b->axis == 0 ? b->B * b->M : b->B * b->N;
+    s.L = b->axis == 0 ? b->N : b->M;
+    s.K = b->K;
+    if (s.K > s.L / 2 + 1) return FFNO_EMODES;
+    s.lm = make_linemap(b->axis, b->B, b->M, b->N, C);
+    s.planes = b->planes;
+    s.tw = b->tw;
+    s.resid = b->resid;
+    s.accumulate = b->accumulate;
+    return FFNO_OK;
+}
+
+extern "C" int ffno_spectral_staged_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, float* mix_a, float* mix_b,
+                                         int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream) {
+    if (!ba || !bb || !mix_a || !mix_b) return FFNO_EINVAL;
+    if (ba->out == bb->out || ba->spec_save == bb->spec_save || mix_a == mix_b) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    if ((ba->planes == nullptr) != (bb->planes == nullptr)) return FFNO_EINVAL;
+    StageArgs a, b;
+    int rc = stage_branch(a, ba, C);
+    if (rc) return rc;
+    rc = stage_branch(b, bb, C);
+    if (rc) return rc;
+    const int RT = (2 * a.K + 31) / 32;
+    if (RT != (2 * b.K + 31) / 32 || RT > 4) return FFNO_EUNSUPPORTED;      // one template instance serves both branches
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
+    // stage A: activations -> spectra (kept in spec_save for the weight gradient)
+    {
+        StageArgs fa = a, fb = b;
+        fa.in = ba->in, fa.out = ba->spec_save, fb.in = bb->in, fb.out = bb->spec_save;
+        const int n0 = (int)min(((long)a.R * RT + 3) / 4, 4096L), n1 = (int)min(((long)b.R * RT + 3) / 4, 4096L);
+        const dim3 grid(n0 + n1), block(256);
+#define FFNO_PAIR_FWD_CASE(CC, RR)                                                                          \
+    if (C == CC && RT == RR) FFNO_LAUNCH((dft_fwd_pair_kernel<CC, RR>), grid, block, smem, s, fa, fb, n0, scale_ck_fwd);
+        FFNO_PAIR_FWD_CASE(64, 1)
+        FFNO_PAIR_FWD_CASE(64, 2)
+        FFNO_PAIR_FWD_CASE(64, 3)
+        FFNO_PAIR_FWD_CASE(64, 4)
+        FFNO_PAIR_FWD_CASE(32, 1)
+        FFNO_PAIR_FWD_CASE(32, 2)
+        FFNO_PAIR_FWD_CASE(32, 3)
+        FFNO_PAIR_FWD_CASE(32, 4)
+#undef FFNO_PAIR_FWD_CASE
+        rc = launch_status();
+        if (rc) return rc;
+    }
+    // stage B: per-mode channel mix (skipped for mode = 'low-pass': no weights)
+    const float* inv_a = ba->spec_save;
+    const float* inv_b = bb->spec_save;
+    if (ba->planes) {
+        StageArgs ma = a, mb = b;
+        ma.in = ba->spec_save, ma.out = mix_a, mb.in = bb->spec_save, mb.out = mix_b;
+        const int nitems = 2 * ((max(a.R, b.R) + 31) / 32);
+        const int chunks = max(1, min((nitems + 3) / 4, max(1, 512 / (a.K + b.K))));
+        const dim3 grid(chunks, a.K + b.K), block(256);
+        if (C == 64)
+            FFNO_LAUNCH((mode_mix_pair_kernel<64>), grid, block, 0, s, ma, mb, conj_transpose);
+        else
+            FFNO_LAUNCH((mode_mix_pair_kernel<32>), grid, block, 0, s, ma, mb, conj_transpose);
+        rc = launch_status();
+        if (rc) return rc;
+        inv_a = mix_a, inv_b = mix_b;
+    }
+    // stage C: zero-padded inverse, fused accumulate / residual
+    {
+        StageArgs ia = a, ib = b;
+        ia.in = inv_a, ia.out = ba->out, ib.in = inv_b, ib.out = bb->out;
+        const long it0 = (long)a.R * ((((a.L + 31) >> 5) + 1) >> 1), it1 = (long)b.R * ((((b.L + 31) >> 5) + 1) >> 1);
+        const int n0 = (int)min((it0 + 3) / 4, 4096L), n1 = (int)min((it1 + 3) / 4, 4096L);
+        const dim3 grid(n0 + n1), block(256);
+        if (C == 64)
+            FFNO_LAUNCH((dft_inv_pair_kernel<64>), grid, block, smem, s, ia, ib, n0, apply_ck_inv);
+        else
+            FFNO_LAUNCH((dft_inv_pair_kernel<32>), grid, block, smem, s, ia, ib, n0, apply_ck_inv);
+    }
     return launch_status();
 }
 

@@ -183,19 +183,41 @@ class FFNOEngine:
                     and self.mode != "no-fourier" and self.spectral != "plus")
 
     @staticmethod
-    def _schedule(fused):
-        """(views that run on their own first, (a, b) = the last two fused views for the paired launch | None)."""
-        fz = [w for w, f in enumerate(fused) if f]
-        if len(fz) < 2:
-            return list(range(len(fused))), None
-        pair = (fz[-2], fz[-1])
-        return [w for w in range(len(fused)) if w not in pair], pair
+    def _schedule(fused, views):
+        """(views that run on their own first, (a, b) = the two views that share paired launches | None).
+        Preferred: the last two FUSED views (one launch); else the last two STAGED views whose stage kernels share a
+        template instance (three paired launches: 256 x 256 with 32 / 64 modes)."""
+        n = len(fused)
+        fz = [w for w in range(n) if fused[w]]
+        sg = [w for w in range(n) if not fused[w]]
+        pair = None
+        if len(fz) >= 2:
+            pair = (fz[-2], fz[-1])
+        elif len(sg) >= 2:
+            a, b = sg[-2], sg[-1]
+            rt = lambda v: (2 * v.K + 31) // 32      # noqa: E731
+            if rt(views[a]) == rt(views[b]) <= 4:
+                pair = (a, b)
+        if pair is None:
+            return list(range(n)), None
+        return [w for w in range(n) if w not in pair], pair
 
-    def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st, acc0: int = 0):
-        """Branches of views v0 and v1 in ONE launch (both fused):
+    def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st, acc0: int = 0,
+              fused: bool = True):
+        """Branches of views v0 and v1 side by side -- ONE launch when both are fused, three paired stage launches else:
         dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = branch1(src)."""
         lib = _lib.get_lib()
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
+        if not fused:
+            sv0 = save0 if save0 is not None else ws.SD
+            sv1 = save1 if save1 is not None else ws.SD2
+            ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(sv0), _p(planes0), _p(self._twiddle(v0.L)),
+                                   v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
+            bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(sv1), _p(planes1), _p(self._twiddle(v1.L)),
+                                   v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0)
+            self._k("spectral_staged_pair" + ("" if fwd else "(adj)"), lib.ffno_spectral_staged_pair, ctypes.byref(ba),
+                    ctypes.byref(bb), _p(ws.SY), _p(ws.SY2), self.C, ck_f, ck_i, conj, st)
+            return
         ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)),
                                v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
         bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)),
@@ -384,6 +406,8 @@ class FFNOEngine:
         ws.SY = torch.empty(max(v.spec for v in ws.views), **f32)
         ws.SD = torch.empty(max(v.spec for v in ws.views), **f32)    # scratch spectrum of the staged path
         if self._conc():
+            ws.SD2 = torch.empty_like(ws.SD)                          # second branch of a paired STAGE launch
+            ws.SY2 = torch.empty_like(ws.SY)
             ws.T = torch.empty(P, C, **f32)                           # output of the second branch of a paired launch
             if save:
                 ws.G1 = torch.empty(P, C, **f32)                      # ... and of the second adjoint branch
@@ -564,7 +588,7 @@ class FFNOEngine:
         self._prepare_weights(st)
         fused = self._can_fuse(ws.views)
         full = self.mode == "full"
-        singles, pair = self._schedule(fused) if self._conc() else (list(range(len(ws.views))), None)
+        singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)
         conc = pair is not None
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
@@ -594,7 +618,7 @@ class FFNOEngine:
                     keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in pair]
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
                                self.planes[si][a][0] if full else None, self.planes[si][b][0] if full else None, True, st,
-                               acc0=int(nwrit > 0))
+                               acc0=int(nwrit > 0), fused=fused[a])
             l0, l1, b0, b1 = self._ff_weights(l)
             if conc:
                 self._k("ff_fwd", lib.ffno_ffx_fwd2, _p(s_l), _p(ws.T), _p(s_l) if save_for_backward else None,
@@ -624,7 +648,7 @@ class FFNOEngine:
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
         x, B, S, fused, conc = self._saved
-        singles, pair = self._schedule(fused) if conc else (list(range(len(fused))), None)
+        singles, pair = self._schedule(fused, self._workspace(B, S, True).views) if conc else (list(range(len(fused))), None)
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
@@ -743,7 +767,7 @@ class FFNOEngine:
                 self._pair("spectral_fused(adj)", ws, ws.views[a], ws.views[b], ws.DS, g_out, ws.G1,
                            resid if nwrit == 0 else None, ws.SDall[a][l] if full else None, ws.SDall[b][l] if full else None,
                            self.planes[si][a][1] if full else None, self.planes[si][b][1] if full else None, False, st,
-                           acc0=int(nwrit > 0))
+                           acc0=int(nwrit > 0), fused=fused[a])
             have_g1 = conc
             cur = 1 - cur
         if conc and have_g1:

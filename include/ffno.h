@@ -133,6 +133,13 @@ typedef struct ffno_fused_branch {
 } ffno_fused_branch;
 int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                              int apply_ck_inv, int conj_transpose, void* stream);
+/* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),
+ * for the shapes the fused kernel does not take (K > 16 at C = 64: 256 x 256 grids with 32 / 64 modes have only 512 lines
+ * per axis at batch 2 -- one launch per axis cannot fill the chip).  spec_save must be set in both branches (scratch when
+ * nothing is kept); mix_a / mix_b receive the mixed spectra (same size); planes == NULL in both = mode 'low-pass'. */
+int ffno_spectral_staged_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, float* mix_a,
+                              float* mix_b, int C, int scale_ck_fwd, int apply_ck_inv,
+                              int conj_transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Operator level: SpectralConv2d.forward_fourier (grid_2d.py:51-99) and its backward, composed of

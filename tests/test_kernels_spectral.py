@@ -1,5 +1,7 @@
 """Spectral kernels through the C ABI vs fp64 torch.fft / einsum references and the reference's golden
 vectors -- on the CPU wave emulator (-m "not gpu") and on the MI355X (-m gpu)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -261,3 +263,62 @@ def test_spectral_fused_support_matrix(be):
     assert be.lib.ffno_spectral_fused_supported(48, 8, 64) == 0
     x, tw = be.zeros((1, 4, 64, 64)), be.twiddle(64)
     assert be.lib.ffno_spectral_fused(be.ptr(x), be.ptr(x), None, None, None, be.ptr(tw), 1, 4, 64, 64, 17, 0, 0, 1, 0, 0, None) == -2
+
+
+@pytest.mark.parametrize("B,M,N,K,C", [(2, 10, 12, 5, 64), (1, 40, 48, 20, 64), (2, 9, 14, 4, 32), (1, 34, 36, 17, 32)])
+@pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
+def test_paired_launches_equal_the_single_branch_kernels(be, B, M, N, K, C, direction):
+    """ffno_spectral_staged_pair (and, where the shape fits its LDS tile, ffno_spectral_fused_pair) run the two axes of a
+    layer side by side; results must be bit-identical to the single-branch stage kernels: same code, other grid."""
+    from fourierflow_amd._capi import FusedBranch
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + K)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    resid = rs.standard_normal(x.shape).astype(np.float32)
+    base = rs.standard_normal(x.shape).astype(np.float32)
+    dx, dres = be.put(x), be.put(resid)
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br = []
+    for axis in (0, 1):
+        L = N if axis == 0 else M
+        R = B * M if axis == 0 else B * N
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        wp, wpt = be.zeros((K, 2, C, C)), be.zeros((K, 2, C, C))
+        assert lib.ffno_fw_pack(p(be.put(w)), p(wp), p(wpt), C, K, None) == 0
+        planes = None if direction == "lowpass" else (wpt if direction == "adj" else wp)
+        br.append(dict(axis=axis, L=L, R=R, tw=be.twiddle(L), planes=planes, keep=(wp, wpt)))
+    # reference: the single-branch stage kernels; branch 0 accumulates onto `base` with a residual, branch 1 overwrites
+    refs, specs = [], []
+    for i, b in enumerate(br):
+        spec, mix = be.empty((K, b["R"], 2, C)), be.empty((K, b["R"], 2, C))
+        out = be.put(base) if i == 0 else be.empty(x.shape)
+        assert lib.ffno_dft_fwd(p(dx), p(spec), p(b["tw"]), B, M, N, C, K, b["axis"], fwd_ck, None) == 0
+        src = spec
+        if b["planes"] is not None:
+            assert lib.ffno_mode_mix(p(spec), p(b["planes"]), p(mix), b["R"], C, K, conj, None) == 0
+            src = mix
+        assert lib.ffno_dft_inv(p(src), p(out), p(dres) if i == 0 else None, p(b["tw"]), B, M, N, C, K, b["axis"], inv_ck,
+                                int(i == 0), None) == 0
+        refs.append(be.get(out).copy())
+        specs.append(be.get(spec).copy())
+
+    def run(fn, *extra):
+        outs = [be.put(base), be.empty(x.shape)]
+        sv = [be.empty((K, b["R"], 2, C)) for b in br]
+        args = [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"]), p(b["tw"]), B, M, N, K,
+                            b["axis"], int(i == 0)) for i, b in enumerate(br)]
+        assert fn(ctypes.byref(args[0]), ctypes.byref(args[1]), *extra, C, fwd_ck, inv_ck, conj, None) == 0
+        return [be.get(o) for o in outs], [be.get(s_) for s_ in sv]
+
+    mixes = [be.empty((K, b["R"], 2, C)) for b in br]
+    outs, sv = run(lib.ffno_spectral_staged_pair, p(mixes[0]), p(mixes[1]))
+    for i in range(2):
+        np.testing.assert_array_equal(outs[i], refs[i])
+        np.testing.assert_array_equal(sv[i], specs[i])
+    if all(lib.ffno_spectral_fused_supported(C, K, b["L"]) for b in br):
+        outs, sv = run(lib.ffno_spectral_fused_pair)
+        for i in range(2):
+            assert rel_l2(outs[i], refs[i]) < TOL and rel_l2(sv[i], specs[i]) < TOL
+    # argument checks: shared outputs / scratch are refused
+    a = FusedBranch(p(dx), p(dres), None, p(mixes[0]), None, p(br[0]["tw"]), B, M, N, K, 0, 0)
+    assert lib.ffno_spectral_staged_pair(ctypes.byref(a), ctypes.byref(a), p(mixes[0]), p(mixes[1]), C, 0, 1, 0, None) == -1
