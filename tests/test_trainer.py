@@ -88,3 +88,34 @@ def test_ddp_two_ranks_gloo_equals_single_process(tmp_path):
             assert gu.compare_packed(g, "final." + n, got, 1e-5) < 2e-4, n
     finally:
         _lib._install_test_backend(None)
+
+
+@pytest.mark.gpu
+def test_training_learns_a_spectral_operator_on_gpu():
+    """End-to-end sanity beyond per-step parity: 150 fused train steps of a 4-layer F-FNO on a learnable target (a fixed
+    low-pass + shift of the input field) must cut the relative-L2 loss by more than half, with finite weights."""
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.trainer import FFNOTrainer
+    torch.manual_seed(0)
+    dev = "cuda:0"
+    blk = FNOFactorized2DBlock(modes=8, width=32, n_layers=4, input_dim=3, share_weight=True, factor=4,
+                               ff_weight_norm=True, gain=0.1).to(dev)
+    tr = FFNOTrainer(blk, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=10, num_training_steps=1000)
+    B, G = 8, 32
+    g = torch.Generator().manual_seed(1)
+    ticks = torch.linspace(0, 1, G)
+    pos = torch.stack(torch.meshgrid(ticks, ticks, indexing="ij"), dim=-1)[None].expand(B, G, G, 2)
+
+    def batch():
+        w = torch.randn(B, G, G, 1, generator=g)
+        wf = torch.fft.rfft2(w[..., 0])
+        wf[:, 5:-4] = 0
+        wf[:, :, 5:] = 0
+        y = torch.roll(torch.fft.irfft2(wf, s=(G, G)), shifts=(2, -1), dims=(1, 2))[..., None]
+        return torch.cat([w, pos], dim=-1).contiguous().to(dev), y.contiguous().to(dev)
+
+    first = tr.train_step(*batch()).item()
+    for _ in range(150):
+        last = tr.train_step(*batch()).item()
+    assert np.isfinite(last) and last < 0.5 * first, (first, last)
+    assert bool(torch.isfinite(tr.pflat).all())
