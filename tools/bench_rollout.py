@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Inference latency of the Markov rollout (the reference's `inference_time`, routines/grid_2d_markov.py:263-326):
 ms per autoregressive model step at small batch (host loop; a hipGraph capture of the same launches was measured and is
-no faster -- 1.70 vs 1.64 ms/step at batch 1: the step is bound by ~170 dependent kernel boundaries on the device, not by
+no faster -- 1.70 vs 1.64 ms/step at batch 1 at the time (0.87 ms/step today with the paired spectral launch): the step is bound by ~170 dependent kernel boundaries on the device, not by
 the host enqueue -- see DESIGN.md "Negative results")."""
 import argparse
 import json
