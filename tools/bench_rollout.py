@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--n-steps", type=int, default=10)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--velocity", action="store_true")
+    ap.add_argument("--staged", action="store_true", help="three (paired) stage kernels instead of the fused spectral kernel")
     args = ap.parse_args()
     from fourierflow_amd.modules import FNOFactorized2DBlock
     from fourierflow_amd.routines import Grid2DMarkovExperiment
@@ -30,6 +31,7 @@ def main():
                                factor=4, ff_weight_norm=True, gain=0.1)
     exp = Grid2DMarkovExperiment(blk, n_steps=args.n_steps, use_velocity=args.velocity, grid_size=[args.grid]).cuda()
     G, B = args.grid, args.batch
+    blk.engine().use_fused = not args.staged
     exp.training_step(dict(x=torch.randn(4, G, G, 1).cuda(), y=torch.randn(4, G, G, 1).cuda()), epoch=0)
     x0 = torch.randn(B, G, G, 1).cuda()
 
