@@ -397,11 +397,22 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
         gload(blockIdx.x);
         stage(0);
     }
+    // The two waves that share a SIMD (w and w + NW/2) stage the next tile at opposite ends of an iteration: the "early"
+    // half runs one tile ahead with its global loads and converts + writes the next tile BEFORE its MFMA phases, the other
+    // half after them, so the split / LDS-write work of one wave falls on the matrix phases of the other instead of both
+    // queueing for the same pipe in lockstep (same idea as the reduce placement in the chain kernel).
+    const bool early = F::NW > 1 && wave < F::NW / 2;
+    if (early && (int)(blockIdx.x + gridDim.x) < ntiles) gload(blockIdx.x + gridDim.x);
     __syncthreads();
     int buf = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int nt = tile + gridDim.x;
-        if (nt < ntiles) gload(nt);
+        if (early) {
+            if (nt < ntiles) stage(buf ^ 1);            // requested during the previous iteration
+            if (nt + (int)gridDim.x < ntiles) gload(nt + gridDim.x);
+        } else if (nt < ntiles) {
+            gload(nt);
+        }
         const char* L = lds[buf];
         // h^T[px][hid] = relu(s W1^T + b1), pixels on the D rows
         f32x16 d[CPW];
@@ -464,7 +475,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
                 for (int ch = 0; ch < CPW; ++ch) acc1[ch][mt] = mfma_x3(a, hb[ch][s2], acc1[ch][mt]);
             }
         }
-        if (nt < ntiles) stage(buf ^ 1);
+        if (!early && nt < ntiles) stage(buf ^ 1);
         __syncthreads();
     }
 
