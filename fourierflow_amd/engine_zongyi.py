@@ -15,7 +15,7 @@ Unlike the F-FNO engine this one returns the INPUT gradient as well and keeps se
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, Optional
+from typing import Dict
 
 import numpy as np
 import torch
