@@ -278,6 +278,19 @@ def main():
         trainer.predict(x)
     sync()
     ms_fwd = 1e3 * (time.perf_counter() - t1) / nf
+    # ... and at batch 1 ("also report B=1 latency"; what an autoregressive rollout pays per model step)
+    ms_fwd_b1 = None
+    if rank == 0:
+        x1 = x[:1].contiguous()
+        for _ in range(3):
+            trainer.predict(x1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            trainer.predict(x1)
+        torch.cuda.synchronize()
+        ms_fwd_b1 = 1e3 * (time.perf_counter() - t1) / 20
+        trainer.predict(x)      # back to the timed geometry (keeps `paired_last` describing the timed workload)
 
     if rank == 0:
         log(f"forward-only: {ms_fwd:.3f} ms")
@@ -351,6 +364,7 @@ def main():
                        "optimizer": "AdamW(lr 2.5e-3, wd 1e-4) + cosine warm-up, fused flat kernel",
                        "collective": "1 x all_reduce(flat fp32 grads, %d floats) / step" % trainer.pflat.numel()},
             "samples_per_s": round(steps_per_s * B, 1), "ms_per_forward": round(ms_fwd, 3),
+            "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5),
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
