@@ -103,11 +103,11 @@ SIGNATURES = {
     "ffno_fw2d_pack": (I, [P, P, P, P, I, I, P]),
     "ffno_fw2d_grad_reduce": (I, [P, P, P, I, I, I, I, P]),
     "ffno_plin_supported": (I, [I, I]),
-    "ffno_plin_fwd": (I, [P, I, P, P, P, P, I, P, P, L, I, I, I, P]),
-    "ffno_plin_bwd_data": (I, [P, I, P, P, P, I, P, L, I, I, I, P]),
+    "ffno_plin_fwd": (I, [P, I, P, P, P, P, I, P, P, P, L, I, I, I, P]),
+    "ffno_plin_bwd_data": (I, [P, I, P, P, P, I, P, L, I, I, I, I, P]),
     "ffno_plin_wgrad_nsplit": (I, [L]),
     "ffno_plin_wgrad_partial_floats": (SZ, [L, I, I]),
-    "ffno_plin_bwd_weights": (I, [P, I, P, P, I, P, P, P, L, I, I, I, P]),
+    "ffno_plin_bwd_weights": (I, [P, I, P, P, I, P, P, P, L, I, I, I, I, P]),
     "ffno_pad_copy": (I, [P, I, I, P]),
     "ffno_velocity_ws_floats": (SZ, [I, I, I]),
     "ffno_velocity_features": (I, [P, P, P, I, I, I, F, F, P]),

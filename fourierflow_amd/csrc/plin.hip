@@ -14,15 +14,29 @@
 namespace ffno {
 
 static constexpr int kPlinTile = 64;    // points per LDS tile
+
+// activation modes (include/ffno.h FFNO_ACT_*): 0 none, 1 ReLU, 2 GELU (exact, erf: torch.nn.functional.gelu default)
+__device__ __forceinline__ float plin_act(float v, int mode) {
+    if (mode == 1) return v > 0.f ? v : 0.f;
+    if (mode == 2) return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    return v;
+}
+// d act / d pre.  `a` is what the forward pass kept: the OUTPUT for ReLU (sign is enough), the PRE-activation for GELU.
+__device__ __forceinline__ float plin_dact(float a, int mode) {
+    if (mode == 1) return a > 0.f ? 1.f : 0.f;
+    if (mode == 2) return 0.5f * (1.f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * expf(-0.5f * a * a);
+    return 1.f;
+}
 static constexpr int kPlinOB = 8;       // outputs per thread in the weight-gradient kernel
-static constexpr int kPlinMaxJ = 3;     // (output group, input column) items per thread: 16 groups * 33 columns / 256
+static constexpr int kPlinMaxJ = 5;     // (output group, input column) items per thread: 16 groups * 65 columns / 256
 
 // out[p][o] = act(b[o] + sum_i W[o][i] x[p][i] + add[p][o])  for o < Cout,  0 for Cout <= o < ldo;
 // optional second output out2 = out + res (the block-level residual x + layer(x), which must not disturb the ReLU mask)
 __global__ __launch_bounds__(256) void plin_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                        const float* __restrict__ b, const float* __restrict__ add,
                                                        float* __restrict__ out, int ldo, const float* __restrict__ res,
-                                                       float* __restrict__ out2, long P, int Cin, int Cout, int relu) {
+                                                       float* __restrict__ out2, float* __restrict__ pre_out, long P,
+                                                       int Cin, int Cout, int act_mode) {
     FFNO_DYN_SMEM(smem);
     float* xs = reinterpret_cast<float*>(smem);          // [tile][Cin + 1]
     float* ws = xs + kPlinTile * (Cin + 1);              // [Cout][Cin + 1]
@@ -49,7 +63,10 @@ __global__ __launch_bounds__(256) void plin_fwd_kernel(const float* __restrict__
                 const float* xr = xs + p * sx;
                 for (int i = 0; i < Cin; ++i) v = fmaf(wr[i], xr[i], v);
                 if (add) v += add[(p0 + p) * ldo + o];
-                if (relu) v = v > 0.f ? v : 0.f;
+                if (pre_out) pre_out[(p0 + p) * ldo + o] = v;
+                v = plin_act(v, act_mode);
+            } else if (pre_out) {
+                pre_out[(p0 + p) * ldo + o] = 0.f;
             }
             out[(p0 + p) * ldo + o] = v;
             if (out2) out2[(p0 + p) * ldo + o] = v + res[(p0 + p) * ldo + o];
@@ -61,7 +78,7 @@ __global__ __launch_bounds__(256) void plin_fwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void plin_bwd_data_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ act,
                                                             const float* __restrict__ W, float* __restrict__ dx, int ldx,
                                                             float* __restrict__ dpre_out, long P, int Cin, int Cout,
-                                                            int accumulate) {
+                                                            int accumulate, int act_mode) {
     FFNO_DYN_SMEM(smem);
     float* ds = reinterpret_cast<float*>(smem);          // [tile][Cout + 1]
     float* ws = ds + kPlinTile * (Cout + 1);             // [Cout][Cin]
@@ -78,7 +95,7 @@ __global__ __launch_bounds__(256) void plin_bwd_data_kernel(const float* __restr
             float v = 0.f;
             if (o < Cout) {
                 v = g[idx];
-                if (act && !(act[idx] > 0.f)) v = 0.f;
+                if (act) v *= plin_dact(act[idx], act_mode);
                 ds[p * sd + o] = v;
             }
             if (dpre_out) dpre_out[idx] = v;
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(256) void plin_bwd_data_kernel(const float* __restr
 __global__ __launch_bounds__(256) void plin_wgrad_partial_kernel(const float* __restrict__ g, int ldg,
                                                                  const float* __restrict__ act, const float* __restrict__ x,
                                                                  int ldx, float* __restrict__ part, long P, int Cin, int Cout,
-                                                                 long per) {
+                                                                 long per, int act_mode) {
     FFNO_DYN_SMEM(smem);
     const int t = threadIdx.x, sx = Cin + 1, npairs = Cout * sx;
     const int sdp = (Cout + kPlinOB - 1) / kPlinOB * kPlinOB;       // dpre row, padded with zeros to whole output groups
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(256) void plin_wgrad_partial_kernel(const float* __
             if (o < Cout) {
                 const long idx = (p0 + p) * ldg + o;
                 v = g[idx];
-                if (act && !(act[idx] > 0.f)) v = 0.f;
+                if (act) v *= plin_dact(act[idx], act_mode);
             }
             ds[e] = v;
         }
@@ -233,22 +250,23 @@ int ffno_plin_supported(int Cin, int Cout) {
 }
 
 int ffno_plin_fwd(const float* x, int ldx, const float* W, const float* b, const float* add, float* out, int ldo,
-                  const float* res, float* out2, long P, int Cin, int Cout, int relu, void* stream) {
-    if (!x || !W || !out || P <= 0 || ldx < Cin || ldo < Cout || (out2 && !res)) return FFNO_EINVAL;
+                  const float* res, float* out2, float* pre_out, long P, int Cin, int Cout, int act_mode, void* stream) {
+    if (!x || !W || !out || P <= 0 || ldx < Cin || ldo < Cout || (out2 && !res) || act_mode < 0 || act_mode > 2)
+        return FFNO_EINVAL;
     if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
     const size_t lds = sizeof(float) * ((size_t)kPlinTile * (Cin + 1) + (size_t)Cout * (Cin + 1) + Cout);
-    FFNO_LAUNCH(plin_fwd_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, b, add, out, ldo, res, out2, P,
-                Cin, Cout, relu);
+    FFNO_LAUNCH(plin_fwd_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, b, add, out, ldo, res, out2, pre_out,
+                P, Cin, Cout, act_mode);
     return plin_status();
 }
 
 int ffno_plin_bwd_data(const float* g, int ldg, const float* act, const float* W, float* dx, int ldx, float* dpre_out, long P,
-                       int Cin, int Cout, int accumulate, void* stream) {
-    if (!g || !W || !dx || P <= 0 || ldg < Cout || ldx < Cin) return FFNO_EINVAL;
+                       int Cin, int Cout, int accumulate, int act_mode, void* stream) {
+    if (!g || !W || !dx || P <= 0 || ldg < Cout || ldx < Cin || act_mode < 0 || act_mode > 2) return FFNO_EINVAL;
     if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
     const size_t lds = sizeof(float) * ((size_t)kPlinTile * (Cout + 1) + (size_t)Cout * Cin);
     FFNO_LAUNCH(plin_bwd_data_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, g, ldg, act, W, dx, ldx, dpre_out,
-                P, Cin, Cout, accumulate);
+                P, Cin, Cout, accumulate, act_mode);
     return plin_status();
 }
 
@@ -262,15 +280,15 @@ size_t ffno_plin_wgrad_partial_floats(long P, int Cin, int Cout) {
 }
 
 int ffno_plin_bwd_weights(const float* g, int ldg, const float* act, const float* x, int ldx, float* part, float* dW, float* db,
-                          long P, int Cin, int Cout, int accumulate, void* stream) {
-    if (!g || !x || !part || !dW || P <= 0 || ldg < Cout || ldx < Cin) return FFNO_EINVAL;
+                          long P, int Cin, int Cout, int accumulate, int act_mode, void* stream) {
+    if (!g || !x || !part || !dW || P <= 0 || ldg < Cout || ldx < Cin || act_mode < 0 || act_mode > 2) return FFNO_EINVAL;
     if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
     const int nsplit = ffno_plin_wgrad_nsplit(P);
     const long per = ((P + nsplit - 1) / nsplit + kPlinTile - 1) / kPlinTile * kPlinTile;
     const int sdp = (Cout + kPlinOB - 1) / kPlinOB * kPlinOB;
     const size_t lds = sizeof(float) * ((size_t)kPlinTile * sdp + (size_t)kPlinTile * (Cin + 1));
     FFNO_LAUNCH(plin_wgrad_partial_kernel, dim3(nsplit), dim3(256), lds, (hipStream_t)stream, g, ldg, act, x, ldx, part, P, Cin,
-                Cout, per);
+                Cout, per, act_mode);
     int rc = plin_status();
     if (rc) return rc;
     const int npairs = Cout * (Cin + 1);

@@ -264,7 +264,7 @@ class ZongyiEngine:
             xin, X, H = x.contiguous().view(P, Cin), None, ws.H0
         cur = X[0] if X is not None else ws.Xa[0]
         self._k("in_proj", lib.ffno_plin_fwd, _p(xin), Cin, _p(pp("in_proj.weight")), _p(pp("in_proj.bias")), None, _p(cur), C,
-                None, None, P, Cin, C, 0, st)
+                None, None, None, P, Cin, C, 0, st)
         for l in range(L):
             pre = f"spectral_layers.{l}."
             nxt = X[l + 1] if X is not None else ws.Xa[(l + 1) & 1]
@@ -275,13 +275,13 @@ class ZongyiEngine:
             A = nxt if not self.residual else (sl.A[l] if save_for_backward else ws.A0)
             src, add = (cur, S) if self.conv_residual else (S, None)
             self._k("layer_linear", lib.ffno_plin_fwd, _p(src), C, _p(pp(pre + "linear.weight")), _p(pp(pre + "linear.bias")),
-                    _p(add), _p(A), C, _p(cur) if self.residual else None, _p(nxt) if self.residual else None, P, C, C, 1, st)
+                    _p(add), _p(A), C, _p(cur) if self.residual else None, _p(nxt) if self.residual else None, None, P, C, C, 1, st)
             cur = nxt
         self._k("head_fc1", lib.ffno_plin_fwd, _p(cur), C, _p(pp("feedforward.0.weight")), _p(pp("feedforward.0.bias")), None,
-                _p(H), HEAD_DIM, None, None, P, C, HEAD_DIM, 1, st)
+                _p(H), HEAD_DIM, None, None, None, P, C, HEAD_DIM, 1, st)
         y = torch.empty(P, 1, dtype=torch.float32, device=self.device)
         self._k("head_fc2", lib.ffno_plin_fwd, _p(H), HEAD_DIM, _p(pp("feedforward.2.weight")), _p(pp("feedforward.2.bias")),
-                None, _p(y), 1, None, None, P, HEAD_DIM, 1, 0, st)
+                None, _p(y), 1, None, None, None, P, HEAD_DIM, 1, 0, st)
         return y.view(B, M, N, 1)
 
     # ------------------------------------------------------------------------------------------------
@@ -306,14 +306,14 @@ class ZongyiEngine:
         XL = sl.X[L]
         # head: y = W2 relu(W1 x + b1) + b2
         self._k("head_fc2_bwd_w", lib.ffno_plin_bwd_weights, _p(gy), 1, None, _p(sl.H), HEAD_DIM, _p(ws.part),
-                _p(gp("feedforward.2.weight")), _p(gp("feedforward.2.bias")), P, HEAD_DIM, 1, acc, st)
+                _p(gp("feedforward.2.weight")), _p(gp("feedforward.2.bias")), P, HEAD_DIM, 1, acc, 0, st)
         self._k("head_fc2_bwd", lib.ffno_plin_bwd_data, _p(gy), 1, None, _p(pp("feedforward.2.weight")), _p(ws.DH), HEAD_DIM,
-                None, P, HEAD_DIM, 1, 0, st)
+                None, P, HEAD_DIM, 1, 0, 0, st)
         self._k("head_fc1_bwd_w", lib.ffno_plin_bwd_weights, _p(ws.DH), HEAD_DIM, _p(sl.H), _p(XL), C, _p(ws.part),
-                _p(gp("feedforward.0.weight")), _p(gp("feedforward.0.bias")), P, C, HEAD_DIM, acc, st)
+                _p(gp("feedforward.0.weight")), _p(gp("feedforward.0.bias")), P, C, HEAD_DIM, acc, 1, st)
         g = ws.G[0]
         self._k("head_fc1_bwd", lib.ffno_plin_bwd_data, _p(ws.DH), HEAD_DIM, _p(sl.H), _p(pp("feedforward.0.weight")), _p(g), C,
-                None, P, C, HEAD_DIM, 0, st)
+                None, P, C, HEAD_DIM, 0, 1, st)
         cur = 0
         v = ws.v
         for l in range(L - 1, -1, -1):
@@ -324,15 +324,15 @@ class ZongyiEngine:
             res = g if self.residual else None                    # x = layer(x) + x: g also flows straight through
             lin_in = xin if self.conv_residual else sl.S[l]
             self._k("layer_linear_bwd_w", lib.ffno_plin_bwd_weights, _p(g), C, _p(act), _p(lin_in), C, _p(ws.part),
-                    _p(gp(pre + "linear.weight")), _p(gp(pre + "linear.bias")), P, C, C, acc, st)
+                    _p(gp(pre + "linear.weight")), _p(gp(pre + "linear.bias")), P, C, C, acc, 1, st)
             if self.conv_residual:
                 # dpre = g * 1[out > 0] feeds both the linear (here) and the spectral adjoint (below)
                 self._k("layer_linear_bwd", lib.ffno_plin_bwd_data, _p(g), C, _p(act), _p(pp(pre + "linear.weight")), _p(gn),
-                        C, _p(ws.DP), P, C, C, 0, st)
+                        C, _p(ws.DP), P, C, C, 0, 1, st)
                 self._spectral(ws, ws.DP, gn, ws.SD, self.planes[l][1], False, 1, st, resid=res)
             else:
                 self._k("layer_linear_bwd", lib.ffno_plin_bwd_data, _p(g), C, _p(act), _p(pp(pre + "linear.weight")),
-                        _p(ws.DP), C, None, P, C, C, 0, st)
+                        _p(ws.DP), C, None, P, C, C, 0, 1, st)
                 self._spectral(ws, ws.DP, gn, ws.SD, self.planes[l][1], False, 0, st, resid=res)
             self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(sl.SX[l]), _p(ws.SD), _p(ws.fwpart), v.R, C, v.K2, 1, 0, 1,
                     v.spec, v.spec, st)
@@ -340,12 +340,12 @@ class ZongyiEngine:
                     _p(gp(pre + "fourier_weight.1")), C, self.K, 1, acc, st)
             g, cur = gn, 1 - cur
         self._k("in_proj_bwd_w", lib.ffno_plin_bwd_weights, _p(g), C, None, _p(sl.x), Cin, _p(ws.part),
-                _p(gp("in_proj.weight")), _p(gp("in_proj.bias")), P, Cin, C, acc, st)
+                _p(gp("in_proj.weight")), _p(gp("in_proj.bias")), P, Cin, C, acc, 0, st)
         dx = None
         if need_dx:
             dx = torch.empty(P, Cin, dtype=torch.float32, device=self.device)
             self._k("in_proj_bwd", lib.ffno_plin_bwd_data, _p(g), C, None, _p(pp("in_proj.weight")), _p(dx), Cin, None, P, Cin,
-                    C, 0, st)
+                    C, 0, 0, st)
             dx = dx.view(B, M, N, Cin)
         self._k("pad_copy(grads)", lib.ffno_pad_copy, _p(self._gtab), len(self.param_names), 0, st)
         return (self.gflat, dx) if need_dx else self.gflat

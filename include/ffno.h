@@ -380,24 +380,31 @@ int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, floa
  * Pointwise linear layers of the FNOZongyi2DBlock baseline (zongyi_fno/grid_2d.py:22,45,74-77 the per-layer
  * `linear` + residual + ReLU; :106 in_proj; :119-122 feedforward head) on channels-last buffers whose
  * leading dimension may exceed the logical width (20 channels live in 32-channel tiles, pad = 0):
- *   fwd:         out[p][o] = act(b[o] + sum_i W[o][i] x[p*ldx+i] + add[p*ldo+o]),  o < Cout; 0 for Cout <= o < ldo
+ *   fwd:         pre = b[o] + sum_i W[o][i] x[p*ldx+i] + add[p*ldo+o];  out[p][o] = act(pre),  o < Cout; 0 for Cout <= o < ldo
+ *                act_mode: FFNO_ACT_NONE | FFNO_ACT_RELU | FFNO_ACT_GELU (exact erf form = torch.nn.functional.gelu)
  *                out2 (optional) = out + res   (block-level residual `layer(x) + x`, grid_2d.py:126)
- *   bwd_data:    dpre = g * (act ? act > 0 : 1);  dx[p*ldx+i] (+)= sum_o dpre[p][o] W[o][i]  (i >= Cin: 0);
- *                dpre_out (optional, layout of g) receives dpre
+ *                pre_out (optional) = pre      (what the GELU backward needs; ReLU only needs the sign of out)
+ *   bwd_data:    dpre = g * act'(.) with `act` = the kept OUTPUT for ReLU, the kept PRE-activation for GELU (NULL: dpre = g);
+ *                dx[p*ldx+i] (+)= sum_o dpre[p][o] W[o][i]  (i >= Cin: 0);  dpre_out (optional, layout of g) receives dpre
  *   bwd_weights: dW[o][i] (+)= sum_p dpre[p][o] x[p][i],  db[o] (+)= sum_p dpre[p][o]   (deterministic two-stage
  *                reduction through `part`, ffno_plin_wgrad_partial_floats() floats)
- * W is [Cout][Cin] row-major (nn.Linear.weight).  Cin, Cout <= 128 and (Cin+1)*ceil(Cout/8) <= 768.
+ * W is [Cout][Cin] row-major (nn.Linear.weight).  Cin, Cout <= 128 and (Cin+1)*ceil(Cout/8) <= 1280.
  * --------------------------------------------------------------------------------------------- */
+#define FFNO_ACT_NONE 0
+#define FFNO_ACT_RELU 1
+#define FFNO_ACT_GELU 2
 int ffno_plin_supported(int Cin, int Cout);
 int ffno_plin_fwd(const float* x, int ldx, const float* W, const float* b, const float* add, float* out,
-                  int ldo, const float* res, float* out2, long P, int Cin, int Cout, int relu,
-                  void* stream);
+                  int ldo, const float* res, float* out2, float* pre_out, long P, int Cin, int Cout,
+                  int act_mode, void* stream);
 int ffno_plin_bwd_data(const float* g, int ldg, const float* act, const float* W, float* dx, int ldx,
-                       float* dpre_out, long P, int Cin, int Cout, int accumulate, void* stream);
+                       float* dpre_out, long P, int Cin, int Cout, int accumulate, int act_mode,
+                       void* stream);
 int ffno_plin_wgrad_nsplit(long P);
 size_t ffno_plin_wgrad_partial_floats(long P, int Cin, int Cout);
 int ffno_plin_bwd_weights(const float* g, int ldg, const float* act, const float* x, int ldx, float* part,
-                          float* dW, float* db, long P, int Cin, int Cout, int accumulate, void* stream);
+                          float* dW, float* db, long P, int Cin, int Cout, int accumulate, int act_mode,
+                          void* stream);
 
 /* One launch copying n parameter tensors between their reference shapes and channel-padded twins:
  * plain [R][Cc][inner] <-> rows r < R, columns c < Cc of padded [.][Cp][inner]; to_padded = 0 copies back

@@ -13,7 +13,7 @@ TOL = 2e-6
 
 # (P, Cin, ldx, Cout, ldo): in_proj, the per-layer linear, the two head linears, a ragged tail
 SHAPES = [(2 * 64 * 64, 12, 12, 32, 32), (300, 20, 32, 20, 32), (1000, 32, 32, 128, 128), (777, 128, 128, 1, 1),
-          (65, 5, 8, 7, 16)]
+          (65, 5, 8, 7, 16), (500, 64, 64, 128, 128), (200, 64, 64, 64, 64)]
 
 
 def _data(P, Cin, ldx, Cout, ldo, seed=0):
@@ -28,27 +28,38 @@ def _data(P, Cin, ldx, Cout, ldo, seed=0):
 
 
 @pytest.mark.parametrize("P,Cin,ldx,Cout,ldo", SHAPES)
-@pytest.mark.parametrize("relu,with_add", [(1, True), (0, False)])
-def test_plin_forward(be, P, Cin, ldx, Cout, ldo, relu, with_add):
+def _gelu(v):
+    from scipy.special import erf
+    return 0.5 * v * (1 + erf(v / np.sqrt(2)))
+
+
+def _dgelu(v):
+    from scipy.special import erf
+    return 0.5 * (1 + erf(v / np.sqrt(2))) + v * np.exp(-0.5 * v * v) / np.sqrt(2 * np.pi)
+
+
+@pytest.mark.parametrize("P,Cin,ldx,Cout,ldo", SHAPES)
+@pytest.mark.parametrize("act_mode,with_add", [(1, True), (0, False), (2, True)])
+def test_plin_forward(be, P, Cin, ldx, Cout, ldo, act_mode, with_add):
     x, W, b, add = _data(P, Cin, ldx, Cout, ldo)
-    out, out2 = be.empty((P, ldo)), be.empty((P, ldo))
+    out, out2, pre = be.empty((P, ldo)), be.empty((P, ldo)), be.empty((P, ldo))
     hx, hW, hb, hadd = be.put(x), be.put(W), be.put(b), be.put(add)      # handles stay alive across the launch
     rc = be.lib.ffno_plin_fwd(be.ptr(hx), ldx, be.ptr(hW), be.ptr(hb), be.ptr(hadd) if with_add else None, be.ptr(out), ldo,
-                              be.ptr(hadd), be.ptr(out2), P, Cin, Cout, relu, None)
+                              be.ptr(hadd), be.ptr(out2), be.ptr(pre), P, Cin, Cout, act_mode, None)
     assert rc == 0
-    ref = x[:, :Cin].astype(np.float64) @ W.astype(np.float64).T + b
+    ref_pre = x[:, :Cin].astype(np.float64) @ W.astype(np.float64).T + b
     if with_add:
-        ref = ref + add[:, :Cout]
-    if relu:
-        ref = np.maximum(ref, 0)
+        ref_pre = ref_pre + add[:, :Cout]
+    ref = np.maximum(ref_pre, 0) if act_mode == 1 else (_gelu(ref_pre) if act_mode == 2 else ref_pre)
     got = be.get(out)
     assert rel_l2(got[:, :Cout], ref) < TOL
-    assert not got[:, Cout:].any()          # the pad channels are exact zeros
+    assert rel_l2(be.get(pre)[:, :Cout], ref_pre) < TOL        # pre-activation copy (what the GELU backward reads)
+    assert not got[:, Cout:].any() and not be.get(pre)[:, Cout:].any()          # the pad channels are exact zeros
     np.testing.assert_array_equal(be.get(out2), got + add)      # second output: out + res
 
 
 @pytest.mark.parametrize("P,Cin,ldx,Cout,ldo", SHAPES)
-@pytest.mark.parametrize("masked", [True, False])
+@pytest.mark.parametrize("masked", [True, False, "gelu"])
 def test_plin_backward(be, P, Cin, ldx, Cout, ldo, masked):
     x, W, b, _ = _data(P, Cin, ldx, Cout, ldo, seed=1)
     rs = np.random.RandomState(2)
@@ -56,7 +67,12 @@ def test_plin_backward(be, P, Cin, ldx, Cout, ldo, masked):
     g[:, :Cout] = rs.standard_normal((P, Cout))
     act = np.zeros((P, ldo), np.float32)
     act[:, :Cout] = np.maximum(rs.standard_normal((P, Cout)), 0)
-    dpre = g[:, :Cout].astype(np.float64) * ((act[:, :Cout] > 0) if masked else 1.0)
+    mode = 0
+    if masked == "gelu":          # `act` = the kept PRE-activation, dpre = g * gelu'(pre)
+        act[:, :Cout] = rs.standard_normal((P, Cout)) * 1.5
+        dpre, mode = g[:, :Cout].astype(np.float64) * _dgelu(act[:, :Cout].astype(np.float64)), 2
+    else:
+        dpre, mode = g[:, :Cout].astype(np.float64) * ((act[:, :Cout] > 0) if masked else 1.0), int(bool(masked))
 
     hg, hact, hW, hx = be.put(g), be.put(act), be.put(W), be.put(x)
     base = rs.standard_normal((P, ldx)).astype(np.float32)
@@ -64,7 +80,7 @@ def test_plin_backward(be, P, Cin, ldx, Cout, ldo, masked):
         dx = be.put(base)
         dp = be.empty((P, ldo))
         rc = be.lib.ffno_plin_bwd_data(be.ptr(hg), ldo, be.ptr(hact) if masked else None, be.ptr(hW), be.ptr(dx), ldx,
-                                       be.ptr(dp), P, Cin, Cout, accumulate, None)
+                                       be.ptr(dp), P, Cin, Cout, accumulate, mode, None)
         assert rc == 0
         ref = np.zeros((P, ldx))
         ref[:, :Cin] = dpre @ W.astype(np.float64)
@@ -72,7 +88,10 @@ def test_plin_backward(be, P, Cin, ldx, Cout, ldo, masked):
             ref = ref + base
         assert rel_l2(be.get(dx), ref) < TOL
         got_dp = be.get(dp)
-        np.testing.assert_array_equal(got_dp[:, :Cout], dpre.astype(np.float32))
+        if masked == "gelu":
+            assert rel_l2(got_dp[:, :Cout], dpre) < TOL
+        else:
+            np.testing.assert_array_equal(got_dp[:, :Cout], dpre.astype(np.float32))
         assert not got_dp[:, Cout:].any()
 
     part = be.empty(int(be.lib.ffno_plin_wgrad_partial_floats(P, Cin, Cout)))
@@ -81,7 +100,7 @@ def test_plin_backward(be, P, Cin, ldx, Cout, ldo, masked):
     for accumulate in (0, 1):
         dW, db = be.put(dW0), be.put(db0)
         rc = be.lib.ffno_plin_bwd_weights(be.ptr(hg), ldo, be.ptr(hact) if masked else None, be.ptr(hx), ldx, be.ptr(part),
-                                          be.ptr(dW), be.ptr(db), P, Cin, Cout, accumulate, None)
+                                          be.ptr(dW), be.ptr(db), P, Cin, Cout, accumulate, mode, None)
         assert rc == 0
         rW = dpre.T @ x[:, :Cin].astype(np.float64) + (dW0 if accumulate else 0)
         rb = dpre.sum(0) + (db0 if accumulate else 0)
@@ -114,7 +133,8 @@ def test_pad_copy_round_trip(be):
 
 def test_plin_rejects_bad_arguments(be):
     x = be.zeros((4, 8))
-    assert be.lib.ffno_plin_fwd(None, 8, be.ptr(x), None, None, be.ptr(x), 8, None, None, 4, 8, 8, 0, None) == -1
-    assert be.lib.ffno_plin_fwd(be.ptr(x), 4, be.ptr(x), None, None, be.ptr(x), 8, None, None, 4, 8, 8, 0, None) == -1     # ldx < Cin
-    assert be.lib.ffno_plin_fwd(be.ptr(x), 200, be.ptr(x), None, None, be.ptr(x), 8, None, None, 4, 200, 8, 0, None) == -2
-    assert be.lib.ffno_plin_supported(128, 128) == 0 and be.lib.ffno_plin_supported(32, 128) == 1
+    assert be.lib.ffno_plin_fwd(None, 8, be.ptr(x), None, None, be.ptr(x), 8, None, None, None, 4, 8, 8, 0, None) == -1
+    assert be.lib.ffno_plin_fwd(be.ptr(x), 4, be.ptr(x), None, None, be.ptr(x), 8, None, None, None, 4, 8, 8, 0, None) == -1     # ldx < Cin
+    assert be.lib.ffno_plin_fwd(be.ptr(x), 200, be.ptr(x), None, None, be.ptr(x), 8, None, None, None, 4, 200, 8, 0, None) == -2
+    assert be.lib.ffno_plin_supported(128, 128) == 0 and be.lib.ffno_plin_supported(64, 128) == 1
+    assert be.lib.ffno_plin_fwd(be.ptr(x), 8, be.ptr(x), None, None, be.ptr(x), 8, None, None, None, 4, 8, 8, 3, None) == -1   # act_mode
