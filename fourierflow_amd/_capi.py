@@ -102,6 +102,9 @@ SIGNATURES = {
     "ffno_cdft_rows": (I, [P, P, I, I, I, I, I, P]),
     "ffno_fw2d_pack": (I, [P, P, P, P, I, I, P]),
     "ffno_fw2d_grad_reduce": (I, [P, P, P, I, I, I, I, P]),
+    "ffno_cdft_rows2": (I, [P, P, I, I, I, I, I, I, P]),
+    "ffno_fw2d_pack2": (I, [P, P, P, P, I, I, I, P]),
+    "ffno_fw2d_grad_reduce2": (I, [P, P, P, I, I, I, I, I, P]),
     "ffno_plin_supported": (I, [I, I]),
     "ffno_plin_fwd": (I, [P, I, P, P, P, P, I, P, P, P, L, I, I, I, P]),
     "ffno_plin_bwd_data": (I, [P, I, P, P, P, I, P, L, I, I, I, I, P]),

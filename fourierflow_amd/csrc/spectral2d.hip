@@ -137,10 +137,11 @@ __global__ __launch_bounds__(256) void cdft_inv_kernel(const float* __restrict__
     }
 }
 
-// planes[mode = ky*2K + kx'][ri][i][o]  <-  w_{kx' / K}[i][o][kx' % K][ky][ri]   (+ wpt[mode][ri][o][i])
+// planes[mode = ky*2K + kx'][ri][i][o]  <-  w_{kx' / K}[i][o][kx' % K][ky][ri]   (+ wpt[mode][ri][o][i]);  K = Kx retained
+// rows per corner block, Ky retained columns (FNOMesh2D keeps modes1 != modes2, zongyi_fno/mesh_2d.py:46-49)
 __global__ void fw2d_pack_kernel(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ wp,
-                                 float* __restrict__ wpt, int C, int K) {
-    const long total = (long)2 * K * K * 2 * C * C;
+                                 float* __restrict__ wpt, int C, int K, int Ky) {
+    const long total = (long)2 * K * Ky * 2 * C * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int o = e % C;
         const int i = (e / C) % C;
@@ -148,7 +149,7 @@ __global__ void fw2d_pack_kernel(const float* __restrict__ w0, const float* __re
         const int mode = e / ((long)C * C * 2);
         const int kxp = mode % (2 * K), ky = mode / (2 * K);
         const float* w = kxp < K ? w0 : w1;
-        const float v = w[((((long)i * C + o) * K + (kxp % K)) * K + ky) * 2 + ri];
+        const float v = w[((((long)i * C + o) * K + (kxp % K)) * Ky + ky) * 2 + ri];
         wp[e] = v;
         wpt[(((long)mode * 2 + ri) * C + o) * C + i] = v;
     }
@@ -156,8 +157,8 @@ __global__ void fw2d_pack_kernel(const float* __restrict__ w0, const float* __re
 
 // partial[split][mode][ri][i][o] summed over splits -> gw_{kx'/K}[i][o][kx' % K][ky][ri]
 __global__ void fw2d_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw0,
-                                        float* __restrict__ gw1, int C, int K, int nsplit, int accumulate) {
-    const long total = (long)2 * K * K * 2 * C * C;
+                                        float* __restrict__ gw1, int C, int K, int Ky, int nsplit, int accumulate) {
+    const long total = (long)2 * K * Ky * 2 * C * C;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int o = e % C;
         const int i = (e / C) % C;
@@ -166,7 +167,7 @@ __global__ void fw2d_grad_reduce_kernel(const float* __restrict__ partial, float
         const int kxp = mode % (2 * K), ky = mode / (2 * K);
         float s = 0.f;
         for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * total + e];
-        float* g = (kxp < K ? gw0 : gw1) + ((((long)i * C + o) * K + (kxp % K)) * K + ky) * 2 + ri;
+        float* g = (kxp < K ? gw0 : gw1) + ((((long)i * C + o) * K + (kxp % K)) * Ky + ky) * 2 + ri;
         *g = accumulate ? (*g + s) : s;
     }
 }
@@ -180,12 +181,13 @@ static inline int s2d_status() {
 
 using namespace ffno;
 
-extern "C" int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, int K, int inverse, void* stream) {
-    if (!in || !out || B <= 0 || M <= 0 || K <= 0) return FFNO_EINVAL;
+// Kx = retained rows per corner block (2 Kx rows in all), Ky = retained columns (the K of the preceding ffno_dft_fwd)
+extern "C" int ffno_cdft_rows2(const float* in, float* out, int B, int M, int C, int Kx, int Ky, int inverse, void* stream) {
+    if (!in || !out || B <= 0 || M <= 0 || Kx <= 0 || Ky <= 0) return FFNO_EINVAL;
     if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
-    if (2 * K > M) return FFNO_EMODES;
-    const dim3 grid((unsigned)((long)K * B)), block(256);
-    const size_t smem = sizeof(float) * (2 * (size_t)M + (inverse ? (size_t)2 * K * 2 * C : (size_t)M * 2 * C));
+    if (2 * Kx > M) return FFNO_EMODES;
+    const dim3 grid((unsigned)((long)Ky * B)), block(256);
+    const size_t smem = sizeof(float) * (2 * (size_t)M + (inverse ? (size_t)2 * Kx * 2 * C : (size_t)M * 2 * C));
     if (smem > 150 * 1024) return FFNO_EUNSUPPORTED;    // the staged slab must fit LDS (M <= 288 at C = 64)
 #ifndef FFNO_EMU
     if (smem > 48 * 1024) {     // dynamic LDS beyond the default window needs an explicit opt-in
@@ -195,25 +197,38 @@ extern "C" int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, 
     }
 #endif
     if (inverse)
-        FFNO_LAUNCH(cdft_inv_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, K);
+        FFNO_LAUNCH(cdft_inv_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, Kx);
     else
-        FFNO_LAUNCH(cdft_fwd_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, K);
+        FFNO_LAUNCH(cdft_fwd_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, Kx);
+    return s2d_status();
+}
+
+extern "C" int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, int K, int inverse, void* stream) {
+    return ffno_cdft_rows2(in, out, B, M, C, K, K, inverse, stream);
+}
+
+extern "C" int ffno_fw2d_pack2(const float* w0, const float* w1, float* wp, float* wpt, int C, int Kx, int Ky, void* stream) {
+    if (!w0 || !w1 || !wp || !wpt || C <= 0 || Kx <= 0 || Ky <= 0) return FFNO_EINVAL;
+    const long total = (long)2 * Kx * Ky * 2 * C * C;
+    FFNO_LAUNCH(fw2d_pack_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, (hipStream_t)stream, w0,
+                w1, wp, wpt, C, Kx, Ky);
     return s2d_status();
 }
 
 extern "C" int ffno_fw2d_pack(const float* w0, const float* w1, float* wp, float* wpt, int C, int K, void* stream) {
-    if (!w0 || !w1 || !wp || !wpt || C <= 0 || K <= 0) return FFNO_EINVAL;
-    const long total = (long)2 * K * K * 2 * C * C;
-    FFNO_LAUNCH(fw2d_pack_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, (hipStream_t)stream, w0,
-                w1, wp, wpt, C, K);
+    return ffno_fw2d_pack2(w0, w1, wp, wpt, C, K, K, stream);
+}
+
+extern "C" int ffno_fw2d_grad_reduce2(const float* partial, float* gw0, float* gw1, int C, int Kx, int Ky, int nsplit,
+                                      int accumulate, void* stream) {
+    if (!partial || !gw0 || !gw1 || C <= 0 || Kx <= 0 || Ky <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    const long total = (long)2 * Kx * Ky * 2 * C * C;
+    FFNO_LAUNCH(fw2d_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
+                (hipStream_t)stream, partial, gw0, gw1, C, Kx, Ky, nsplit, accumulate);
     return s2d_status();
 }
 
 extern "C" int ffno_fw2d_grad_reduce(const float* partial, float* gw0, float* gw1, int C, int K, int nsplit,
                                      int accumulate, void* stream) {
-    if (!partial || !gw0 || !gw1 || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
-    const long total = (long)2 * K * K * 2 * C * C;
-    FFNO_LAUNCH(fw2d_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0,
-                (hipStream_t)stream, partial, gw0, gw1, C, K, nsplit, accumulate);
-    return s2d_status();
+    return ffno_fw2d_grad_reduce2(partial, gw0, gw1, C, K, K, nsplit, accumulate, stream);
 }

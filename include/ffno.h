@@ -320,6 +320,14 @@ int ffno_cdft_rows(const float* in, float* out, int B, int M, int C, int K, int 
 int ffno_fw2d_pack(const float* w0, const float* w1, float* wp, float* wpt, int C, int K, void* stream);
 int ffno_fw2d_grad_reduce(const float* partial, float* gw0, float* gw1, int C, int K, int nsplit,
                           int accumulate, void* stream);
+/* the same with different numbers of retained rows (Kx per corner block) and columns (Ky): FNOMesh2D keeps
+ * modes1 != modes2 (zongyi_fno/mesh_2d.py:46-49); weights [I][O][Kx][Ky][2], modes = ky*2Kx + kx' */
+int ffno_cdft_rows2(const float* in, float* out, int B, int M, int C, int Kx, int Ky, int inverse,
+                    void* stream);
+int ffno_fw2d_pack2(const float* w0, const float* w1, float* wp, float* wpt, int C, int Kx, int Ky,
+                    void* stream);
+int ffno_fw2d_grad_reduce2(const float* partial, float* gw0, float* gw1, int C, int Kx, int Ky, int nsplit,
+                           int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Velocity features of the Markov routine (routines/grid_2d_markov.py:130-144, `use_velocity: true`,

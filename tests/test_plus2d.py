@@ -122,3 +122,41 @@ def test_plus_kochkov_ablation_shape_on_gpu():
         sd, _ = ou.torch_state_dict(sd_np, torch.float32, requires_grad=False)
         ref = orc.ffno2d_block(sd, torch.from_numpy(x_np), modes=16, n_layers=2, spectral="plus")["forecast"]
     assert rel_l2(out.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,M,C,Kx,Ky", [(2, 12, 32, 3, 5), (1, 20, 64, 6, 2)])
+def test_rectangular_mode_blocks(be, B, M, C, Kx, Ky):
+    """modes1 != modes2 (FNOMesh2D, zongyi_fno/mesh_2d.py:46-49): Kx retained rows per corner block, Ky retained columns."""
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(M + Kx)
+    S = rs.standard_normal((Ky, B, M, 2, C)).astype(np.float32)          # [ky][b][m][re/im][c]
+    Z = be.empty((Ky, 2 * Kx, B, 2, C))
+    hS = be.put(S)
+    assert lib.ffno_cdft_rows2(p(hS), p(Z), B, M, C, Kx, Ky, 0, None) == 0
+    Sc = S[:, :, :, 0].astype(np.float64) + 1j * S[:, :, :, 1]
+    rows = np.r_[0:Kx, M - Kx:M]
+    full = np.fft.fft(Sc, axis=2, norm="ortho")[:, :, rows]              # [ky][b][kx'][c]
+    ref = np.stack([full.real, full.imag], axis=3).transpose(0, 2, 1, 3, 4)
+    assert rel_l2(be.get(Z), ref) < 1e-5
+    Zin = rs.standard_normal((Ky, 2 * Kx, B, 2, C)).astype(np.float32)
+    Sout, hZ = be.empty((Ky, B, M, 2, C)), be.put(Zin)
+    assert lib.ffno_cdft_rows2(p(hZ), p(Sout), B, M, C, Kx, Ky, 1, None) == 0
+    Zc = (Zin[:, :, :, 0].astype(np.float64) + 1j * Zin[:, :, :, 1]).transpose(0, 2, 1, 3)
+    pad = np.zeros((Ky, B, M, C), np.complex128)
+    pad[:, :, rows] = Zc
+    inv = np.fft.ifft(pad, axis=2, norm="ortho")
+    assert rel_l2(be.get(Sout), np.stack([inv.real, inv.imag], axis=3)) < 1e-5
+    # weight layouts [i][o][Kx][Ky][2]
+    w0, w1 = (rs.standard_normal((C, C, Kx, Ky, 2)).astype(np.float32) for _ in range(2))
+    wp, wpt = be.empty((Ky * 2 * Kx, 2, C, C)), be.empty((Ky * 2 * Kx, 2, C, C))
+    h0, h1 = be.put(w0), be.put(w1)
+    assert lib.ffno_fw2d_pack2(p(h0), p(h1), p(wp), p(wpt), C, Kx, Ky, None) == 0
+    W = np.concatenate([w0, w1], axis=2)                                 # [i][o][kx'][ky][ri]
+    refp = W.transpose(3, 2, 4, 0, 1).reshape(Ky * 2 * Kx, 2, C, C)      # [ky][kx'][ri][i][o]
+    np.testing.assert_array_equal(be.get(wp), refp)
+    np.testing.assert_array_equal(be.get(wpt), refp.transpose(0, 1, 3, 2))
+    part = rs.standard_normal((2, Ky * 2 * Kx, 2, C, C)).astype(np.float32)
+    g0, g1, hp = be.put(np.ones_like(w0)), be.put(np.ones_like(w1)), be.put(part)
+    assert lib.ffno_fw2d_grad_reduce2(p(hp), p(g0), p(g1), C, Kx, Ky, 2, 1, None) == 0
+    tot = part.sum(0).reshape(Ky, 2 * Kx, 2, C, C).transpose(3, 4, 1, 0, 2)
+    assert rel_l2(be.get(g0), 1 + tot[:, :, :Kx]) < 1e-6 and rel_l2(be.get(g1), 1 + tot[:, :, Kx:]) < 1e-6
