@@ -118,6 +118,7 @@ SIGNATURES = {
     "ffno_lploss_fwd_bwd": (I, [P, P, P, P, P, I, I, F, P, P]),
     "ffno_markov_features": (I, [P, P, P, P, P, P, I, I, I, I, F, F, F, F, I, I, P, P]),
     "ffno_adamw_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, I, F, P]),
+    "ffno_adam_flat": (I, [P, P, P, P, SZ, F, F, F, F, F, I, F, P]),
     "ffno_axpy": (I, [P, P, F, SZ, P]),
 }
 

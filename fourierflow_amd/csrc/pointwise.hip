@@ -501,10 +501,11 @@ __global__ __launch_bounds__(256) void lploss_grad_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                                                     float beta1, float beta2, float eps, float wd, float bc1,
-                                                    float bc2_sqrt, float gscale) {
+                                                    float bc2_sqrt, float gscale, int decoupled) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gi = g[i] * gscale;
-        float pi = p[i] * (1.f - lr * wd);
+        // decoupled = 1: torch.optim.AdamW (p *= 1 - lr wd);  0: torch.optim.Adam (L2: the decay joins the gradient)
+        const float gi = decoupled ? g[i] * gscale : fmaf(wd, p[i], g[i] * gscale);
+        float pi = decoupled ? p[i] * (1.f - lr * wd) : p[i];
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
@@ -709,16 +710,27 @@ extern "C" int ffno_markov_features(const float* x, float* state, float* derived
     return pw_status();
 }
 
-extern "C" int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, int step, float grad_scale,
-                               void* stream) {
+static int adam_launch(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, int step, float grad_scale, int decoupled, void* stream) {
     if (!p || !g || !m || !v || n == 0 || step <= 0) return FFNO_EINVAL;
     const float bc1 = 1.f - (float)pow((double)beta1, (double)step);
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     const unsigned blocks = (unsigned)min((n + 255) / 256, (size_t)2048);
     FFNO_LAUNCH(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2,
-                       eps, weight_decay, bc1, bc2s, grad_scale);
+                       eps, weight_decay, bc1, bc2s, grad_scale, decoupled);
     return pw_status();
+}
+
+extern "C" int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, float grad_scale,
+                               void* stream) {
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 1, stream);
+}
+
+extern "C" int ffno_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              void* stream) {
+    return adam_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, 0, stream);
 }
 
 extern "C" int ffno_axpy(float* y, const float* x, float alpha, size_t n, void* stream) {

@@ -35,11 +35,12 @@ def cosine_warmup_factor(step: int, num_warmup_steps: int, num_training_steps: i
 class FFNOTrainer:
     def __init__(self, block, *, lr: float = 2.5e-3, weight_decay: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  num_warmup_steps: int = 500, num_training_steps: int = 100000, num_cycles: float = 0.5,
-                 process_group=None, broadcast_from_rank0: bool = True, loss_scale: float = 1.0):
+                 process_group=None, broadcast_from_rank0: bool = True, loss_scale: float = 1.0, decoupled: bool = True):
         self.block = block
         self.engine = block.engine()
         self.lr, self.wd, self.betas, self.eps = lr, weight_decay, betas, eps
         self.sched = (num_warmup_steps, num_training_steps, num_cycles)
+        self.decoupled = decoupled     # True: torch.optim.AdamW; False: torch.optim.Adam (L2 weight decay)
         self.lr_factor = None          # optional callable() -> multiplier replacing the cosine schedule (StepLR per epoch)
         self.step_count = 0
         self.loss_scale = loss_scale   # StructuredMeshExperiment: gradients of loss * loss_scale (structured_mesh.py:29)
@@ -104,9 +105,10 @@ class FFNOTrainer:
             torch.distributed.all_reduce(gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         lr_t = self.current_lr()
         self.step_count += 1
-        _capi.check(lib.ffno_adamw_flat(_p(self.pflat), _p(gflat), _p(self.m), _p(self.v), self.pflat.numel(), lr_t,
-                                        self.betas[0], self.betas[1], self.eps, self.wd, self.step_count,
-                                        1.0 / self.world, _lib.current_stream(self.device)), "adamw")
+        fn = lib.ffno_adamw_flat if self.decoupled else lib.ffno_adam_flat
+        _capi.check(fn(_p(self.pflat), _p(gflat), _p(self.m), _p(self.v), self.pflat.numel(), lr_t, self.betas[0],
+                       self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world,
+                       _lib.current_stream(self.device)), "adamw" if self.decoupled else "adam")
         return loss
 
     @torch.no_grad()

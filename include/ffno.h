@@ -383,6 +383,10 @@ int ffno_markov_features(const float* x, float* state, float* derived, const flo
 int ffno_adamw_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale,
                     void* stream);
+/* torch.optim.Adam instead (the geo-FNO baselines' optimiser): weight decay is L2, g := grad * grad_scale + wd * p, and
+ * p is not decayed. */
+int ffno_adam_flat(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Pointwise linear layers of the FNOZongyi2DBlock baseline (zongyi_fno/grid_2d.py:22,45,74-77 the per-layer

@@ -270,6 +270,17 @@ def test_adamw_and_axpy(be):
         tp.grad = torch.tensor(g)
         opt.step()
     assert rel_l2(be.get(dp), tp.detach().numpy()) < 1e-6
+    # Adam with L2 weight decay vs torch.optim.Adam (the geo-FNO baselines' optimiser)
+    dp, m, v = be.put(p0), be.zeros(n), be.zeros(n)
+    tp = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.Adam([tp], lr=1e-3, weight_decay=1e-4)
+    for step in range(1, 4):
+        g = rs.standard_normal(n).astype(np.float32)
+        dg = be.put(g)
+        assert lib.ffno_adam_flat(p(dp), p(dg), p(m), p(v), n, 1e-3, 0.9, 0.999, 1e-8, 1e-4, step, 1.0, None) == 0
+        tp.grad = torch.tensor(g)
+        opt.step()
+    assert rel_l2(be.get(dp), tp.detach().numpy()) < 1e-6
     yv = rs.standard_normal(100).astype(np.float32)
     xv = rs.standard_normal(100).astype(np.float32)
     dy, dxv = be.put(yv), be.put(xv)
