@@ -23,6 +23,7 @@ TARGET_MAP = {
     "fourierflow.modules.FNOFactorizedMesh2D": "fourierflow_amd.modules.FNOFactorizedMesh2D",
     "fourierflow.modules.FNOPlus2DBlock": "fourierflow_amd.modules.FNOPlus2DBlock",
     "fourierflow.modules.FNOZongyi2DBlock": "fourierflow_amd.modules.FNOZongyi2DBlock",
+    "fourierflow.modules.FNOMesh2D": "fourierflow_amd.modules.FNOMesh2D",
     "fourierflow.modules.WNLinear": "fourierflow_amd.modules.WNLinear",
     "fourierflow.modules.Normalizer": "fourierflow_amd.modules.Normalizer",
     "fourierflow.routines.Grid2DMarkovExperiment": "fourierflow_amd.routines.Grid2DMarkovExperiment",
@@ -134,16 +135,21 @@ def build_routine(cfg: Dict[str, Any]):
     r.pop("optimizer", None)
     r.pop("scheduler", None)
     routine_kwargs = {}
+    model_target = str((r.get("conv") or r.get("model") or {}).get("_target_", ""))
+    baseline = model_target.endswith(("FNOZongyi2DBlock", "FNOMesh2D"))        # the StepLR (and Adam) users built here
     if opt is not None:
-        if not isinstance(opt, Partial) or opt.func.name != "torch.optim.AdamW":
-            raise NotImplementedError(f"only torch.optim.AdamW maps to the fused flat optimiser kernel, got {opt}")
+        names = ("torch.optim.AdamW",) + (("torch.optim.Adam",) if model_target.endswith("FNOMesh2D") else ())
+        if not isinstance(opt, Partial) or opt.func.name not in names:
+            raise NotImplementedError(f"only torch.optim.AdamW (and torch.optim.Adam for FNOMesh2D) map to the fused flat "
+                                      f"optimiser kernel, got {opt}")
         routine_kwargs["optimizer"] = dict(opt.kwargs)
+        if opt.func.name == "torch.optim.Adam":
+            routine_kwargs["optimizer_type"] = "adam"
     if sch is not None:
         s = sch["scheduler"] if isinstance(sch, dict) else sch
-        zongyi = "FNOZongyi2DBlock" in str((r.get("conv") or {}).get("_target_", ""))    # the only StepLR users built here
-        ok = ("CosineWithWarmupScheduler",) + (("StepLR",) if zongyi else ())
+        ok = ("CosineWithWarmupScheduler",) + (("StepLR",) if baseline else ())
         if not isinstance(s, Partial) or not s.func.name.endswith(ok):
-            raise NotImplementedError(f"only CosineWithWarmupScheduler (and StepLR for the FNOZongyi2DBlock baselines) are folded into "
+            raise NotImplementedError(f"only CosineWithWarmupScheduler (and StepLR for the FNOZongyi2DBlock / FNOMesh2D baselines) are folded into "
                                       f"the fused optimiser step, got {s}")
         routine_kwargs["scheduler"] = dict(s.kwargs)
     node = dict(r)

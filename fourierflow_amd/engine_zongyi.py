@@ -131,8 +131,15 @@ class ZongyiEngine:
         o = self._offsets[name]
         return self.gflat[o:o + int(np.prod(self.param_shapes[name]))].view(self.param_shapes[name])
 
+    def _aliased(self, name) -> bool:
+        """The padded twin has the parameter's own shape (width == channel tile): use the tensor itself, no copy."""
+        R, Cc, inner, Rp, Cp = self._pad_geom[name]
+        return R == Rp and Cc == Cp
+
     def _pp(self, name, buf=None) -> torch.Tensor:
         R, Cc, inner, Rp, Cp = self._pad_geom[name]
+        if self._aliased(name):
+            return (self.params[name] if buf is None else self.grad_view(name)).reshape(-1)
         o = self._poffsets[name]
         return (self.ppad if buf is None else buf)[o:o + Rp * Cp * inner]
 
@@ -145,8 +152,13 @@ class ZongyiEngine:
         def table(plain_of, padded_buf):
             descs = []
             for n in self.param_names:
+                if self._aliased(n):
+                    continue
                 R, Cc, inner, Rp, Cp = self._pad_geom[n]
                 descs.append(_capi.PadDesc(plain_of(n).data_ptr(), self._pp(n, padded_buf).data_ptr(), R, Cc, inner, Cp))
+            self._n_pad = len(descs)
+            if not descs:
+                return None
             arr = (_capi.PadDesc * len(descs))(*descs)
             return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
 
@@ -230,7 +242,8 @@ class ZongyiEngine:
         lib = _lib.get_lib()
         self._refresh_pointers()
         self._packed = True
-        self._k("pad_copy", lib.ffno_pad_copy, _p(self._ptab), len(self.param_names), 1, st)
+        if self._n_pad:
+            self._k("pad_copy", lib.ffno_pad_copy, _p(self._ptab), self._n_pad, 1, st)
         for l in range(self.L):
             pre = f"spectral_layers.{l}."
             self._k("fw2d_pack", lib.ffno_fw2d_pack, _p(self._pp(pre + "fourier_weight.0")),
@@ -347,5 +360,6 @@ class ZongyiEngine:
             self._k("in_proj_bwd", lib.ffno_plin_bwd_data, _p(g), C, None, _p(pp("in_proj.weight")), _p(dx), Cin, None, P, Cin,
                     C, 0, 0, st)
             dx = dx.view(B, M, N, Cin)
-        self._k("pad_copy(grads)", lib.ffno_pad_copy, _p(self._gtab), len(self.param_names), 0, st)
+        if self._n_pad:
+            self._k("pad_copy(grads)", lib.ffno_pad_copy, _p(self._gtab), self._n_pad, 0, st)
         return (self.gflat, dx) if need_dx else self.gflat

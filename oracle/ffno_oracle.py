@@ -19,7 +19,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The shipped package (fourierflow_amd/) never does.
 
 Also restated here, with their own golden vectors: FNOFactorizedMesh2D / Mesh3D (mesh_2d.py, mesh_3d.py),
-FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), FNOZongyi2DBlock (zongyi_fno/grid_2d.py), Normalizer, the Markov
+FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), FNOZongyi2DBlock (zongyi_fno/grid_2d.py), FNOMesh2D
+(zongyi_fno/mesh_2d.py), Normalizer, the Markov
 feature build (routines/grid_2d_markov.py:124-170).
 
 Parity status: PINNED against golden vectors generated from the imported
@@ -373,6 +374,37 @@ def fno_zongyi_2d(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int
         x = y + x if residual else y
     x = torch.relu(F.linear(x, sd["feedforward.0.weight"], sd["feedforward.0.bias"]))
     return {"forecast": F.linear(x, sd["feedforward.2.weight"], sd["feedforward.2.bias"])}
+
+
+# --------------------------------------------------------------------------
+# FNOMesh2D (zongyi_fno/mesh_2d.py:14-106), the geo-FNO baseline: fc0 on (x, grid) -> pad 8 at the far ends ->
+# n_layers x [rfft2 -> corner blocks [:m1, :m2] / [-m1:, :m2] x complex weights -> irfft2, + 1x1 conv, GELU except
+# last] -> crop -> fc1 -> GELU -> fc2.  State-dict layout of the reference (weights1/2 complex [I, O, m1, m2]).
+# --------------------------------------------------------------------------
+def fno_mesh2d_grid(B: int, X: int, Y: int, dtype=torch.float32) -> Tensor:
+    gx = torch.linspace(0, 1, X, dtype=dtype).reshape(1, X, 1, 1).expand(B, X, Y, 1)          # :99-105
+    gy = torch.linspace(0, 1, Y, dtype=dtype).reshape(1, 1, Y, 1).expand(B, X, Y, 1)
+    return torch.cat((gx, gy), dim=-1)
+
+
+def fno_mesh2d(sd: Dict[str, Tensor], x: Tensor, *, modes1: int, modes2: int, n_layers: int, padding: int = 8) -> Tensor:
+    B, X, Y, _ = x.shape
+    h = torch.cat((x, fno_mesh2d_grid(B, X, Y, x.dtype)), dim=-1)                              # :79-80
+    h = F.linear(h, sd["fc0.weight"], sd["fc0.bias"]).permute(0, 3, 1, 2)                      # :81-82
+    h = F.pad(h, [0, padding, 0, padding])                                                     # :84
+    for i in range(n_layers):
+        hf = torch.fft.rfft2(h)                                                                # :41
+        out = hf.new_zeros(B, h.shape[1], h.shape[-2], h.shape[-1] // 2 + 1)
+        out[:, :, :modes1, :modes2] = torch.einsum("bixy,ioxy->boxy", hf[:, :, :modes1, :modes2], sd[f"convs.{i}.weights1"])
+        out[:, :, -modes1:, :modes2] = torch.einsum("bixy,ioxy->boxy", hf[:, :, -modes1:, :modes2], sd[f"convs.{i}.weights2"])
+        x1 = torch.fft.irfft2(out, s=(h.shape[-2], h.shape[-1]))                               # :52
+        x2 = F.conv2d(h, sd[f"ws.{i}.weight"], sd[f"ws.{i}.bias"])                             # :89
+        h = x1 + x2
+        if i < n_layers - 1:
+            h = F.gelu(h)                                                                      # :91-92
+    h = h[..., :-padding, :-padding].permute(0, 2, 3, 1)                                       # :94-95
+    h = F.gelu(F.linear(h, sd["fc1.weight"], sd["fc1.bias"]))
+    return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
 
 
 # --------------------------------------------------------------------------

@@ -266,3 +266,32 @@ def make_zongyi_state_dict(kw: dict, seed: int = 51, grid: int = 64):
     lin("feedforward.2.", 128, 1)
     x = rs.standard_normal((2, grid, grid, I)).astype(np.float32)
     return sd, x
+
+
+def make_geofno_state_dict(kw: dict, seed: int):
+    """Deterministic FNOMesh2D weights (zongyi_fno/mesh_2d.py:56-76 layout; convs.{i}.weights1/2 complex64).  The spectral
+    weights use std 0.05 (the reference's init, scale / (in*out) * U[0,1), is ~5e-4 and would leave the spectral path
+    numerically invisible next to the 1x1 convolutions)."""
+    rs = np.random.RandomState(seed)
+    W, m1, m2 = kw["width"], kw["modes1"], kw["modes2"]
+    sd = {}
+
+    def lin(prefix, fin, fout, shape=None):
+        sd[prefix + "weight"] = (rs.standard_normal(shape or (fout, fin)) / math.sqrt(fin)).astype(np.float32)
+        sd[prefix + "bias"] = (rs.standard_normal(fout) * 0.1).astype(np.float32)
+
+    lin("fc0.", 4, W)
+    for l in range(kw["n_layers"]):
+        for j in (1, 2):
+            w = rs.standard_normal((W, W, m1, m2, 2)) * 0.05
+            sd[f"convs.{l}.weights{j}"] = (w[..., 0] + 1j * w[..., 1]).astype(np.complex64)
+    for l in range(kw["n_layers"]):
+        lin(f"ws.{l}.", W, W, shape=(W, W, 1, 1))
+    lin("fc1.", W, 128)
+    lin("fc2.", 128, 1)
+    return sd
+
+
+def make_geofno_io(seed: int, B: int, X: int, Y: int):
+    rs = np.random.RandomState(seed + 100)
+    return rs.standard_normal((B, X, Y, 2)).astype(np.float32), rs.standard_normal((B, X, Y, 1)).astype(np.float32)

@@ -84,7 +84,7 @@ def test_unknown_reference_targets_fail_loudly(tmp_path):
     with pytest.raises(NotImplementedError, match="accumulate_grad_batches"):
         Grid2DMarkovExperiment(conv, accumulate_grad_batches=4)
     with pytest.raises(NotImplementedError):
-        instantiate({"_target_": "fourierflow.modules.FNOMesh2D", "modes1": 12})
+        instantiate({"_target_": "fourierflow.modules.FNOMesh3D", "modes1": 12})
     with pytest.raises(ValueError):
         instantiate("${nope: 1}")
     assert instantiate("${eval: 2 * 3}") == 6
@@ -99,6 +99,7 @@ REFERENCE_CONFIGS = [
     ("torus_kochkov/ffno/ablation/fno++/128", "Grid2DMarkovExperiment", "conv", "FNOPlus2DBlock"),
     ("torus_kochkov/ffno/grid_sizes/256", "Grid2DMarkovExperiment", "conv", "FNOFactorized2DBlock"),
     ("torus_li/zongyi/4_layers", "Grid2DRolloutExperiment", "conv", "FNOZongyi2DBlock"),       # BASELINE config 0
+    ("pipe/geo-fno/8_layers", "StructuredMeshExperiment", "model", "FNOMesh2D"),               # geo-FNO baseline, Adam + StepLR
 ]
 
 
@@ -156,4 +157,4 @@ def test_every_shipped_ffno_config_builds():
         except Exception as e:  # noqa: BLE001 - anything else is a loader bug
             unexpected.append((os.path.relpath(p, root), repr(e)))
     assert not unexpected, unexpected[:5]
-    assert built >= 170, built
+    assert built >= 190, built

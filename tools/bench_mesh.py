@@ -27,6 +27,12 @@ PRESETS = {
     "plasticity": dict(size=(101, 31, 20), batch=2,
                        model=dict(modes_x=32, modes_y=12, modes_z=8, width=64, input_dim=4, output_dim=4, n_layers=12,
                                   share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
+    # geo-FNO baselines (FNOMesh2D, torch.optim.Adam + StepLR, loss_scale 20): experiments/pipe/geo-fno/8_layers (129 x 129
+    # mesh) and experiments/airfoil/geo-fno-big/12_layers (221 x 51), batch 20
+    "pipe_geofno": dict(size=(129, 129), batch=20, cls="FNOMesh2D", model=dict(modes1=12, modes2=12, width=32, n_layers=8),
+                        routine=dict(optimizer_type="adam", loss_scale=20, scheduler=dict(step_size=100, gamma=0.5))),
+    "airfoil_geofno": dict(size=(221, 51), batch=20, cls="FNOMesh2D", model=dict(modes1=32, modes2=16, width=64, n_layers=12),
+                           routine=dict(optimizer_type="adam", loss_scale=20, scheduler=dict(step_size=100, gamma=0.5))),
     "cube64": dict(size=(64, 64, 64), batch=1,
                    model=dict(modes_x=8, modes_y=8, modes_z=8, width=32, input_dim=4, output_dim=1, n_layers=12,
                               share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
@@ -48,11 +54,12 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model = cls(**ps["model"]).to(dev)
-    exp = StructuredMeshExperiment(model, optimizer=dict(lr=1e-3, weight_decay=1e-4),
-                                   scheduler=dict(num_warmup_steps=500, num_training_steps=82800))
+    rkw = dict(scheduler=dict(num_warmup_steps=500, num_training_steps=82800))
+    rkw.update(ps.get("routine", {}))
+    exp = StructuredMeshExperiment(model, optimizer=dict(lr=1e-3, weight_decay=1e-4), **rkw)
     g = torch.Generator().manual_seed(1)
     nd = len(ps["size"])
-    batch = dict(x=torch.randn(B, *ps["size"], ps["model"]["input_dim"] - nd, generator=g).to(dev),
+    batch = dict(x=torch.randn(B, *ps["size"], ps["model"].get("input_dim", 4) - nd, generator=g).to(dev),
                  y=torch.randn(B, *ps["size"], ps["model"].get("output_dim", 1), generator=g).to(dev))
     for _ in range(args.warmup):
         exp.training_step(batch)
@@ -75,7 +82,7 @@ def main():
                       "unit": "steps/s (batch %d)" % B, "ms_per_step": round(1e3 * dt, 3), "ms_per_forward": round(1e3 * df, 3),
                       "dtype": "f32", "data": "synthetic N(0,1)", "final_loss": round(float(loss.item()), 5),
                       "config": dict(workload="StructuredMeshExperiment train step", size=ps["size"], batch=B, **ps["model"]),
-                      "fused_spectral": bool(tr.engine.use_fused)}))
+                      "fused_spectral": bool(getattr(tr.engine, "use_fused", False))}))
 
 
 if __name__ == "__main__":
