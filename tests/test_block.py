@@ -24,7 +24,7 @@ def build_block(kw, seed, device):
 TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64_nofourier", "c32_nown", "c64_fork",
         "c64_sharefork_fork",
         "c64_4l_markov", "c64_24l_markov"]
-GPU_ONLY = {"c64_4l_markov", "c64_24l_markov"}  # too slow for the CPU emulator
+GPU_ONLY = {"c64_4l_markov", "c64_24l_markov", "c64_3l_unshared"}  # too slow for the CPU emulator
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])

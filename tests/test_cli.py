@@ -78,7 +78,7 @@ def _run(args, device):
 def test_cli_train_resume_test_predict_markov(tmp_path, host_device):
     cfg = tmp_path / "config.yaml"
     cfg.write_text(MARKOV)
-    out = _run(["train", str(cfg), "routine.noise_std=0.0", "--steps", "3", "--grid", "16", "--accumulation-batches", "1"],
+    out = _run(["train", str(cfg), "routine.noise_std=0.0", "--steps", "3", "--grid", "8", "--accumulation-batches", "1"],
                host_device)
     assert [o["step"] for o in out[:-1]] == [0, 1, 2] and out[-1]["resumed_from_step"] == 0
     tdirs = os.listdir(tmp_path / "checkpoints")
@@ -86,19 +86,19 @@ def test_cli_train_resume_test_predict_markov(tmp_path, host_device):
     files = sorted(os.listdir(tmp_path / "checkpoints" / tdirs[0]))
     assert files[1] == "last.ckpt" and files[0].startswith("epoch=1-step=3-valid_loss=") and files[0].endswith(".ckpt")
     # --resume continues the step count and the schedule from last.ckpt; the single best file is replaced
-    out = _run(["train", str(cfg), "--steps", "2", "--grid", "16", "--resume"], host_device)
+    out = _run(["train", str(cfg), "--steps", "2", "--grid", "8", "--resume"], host_device)
     assert out[0]["step"] == 3 and out[-1]["resumed_from_step"] == 3
     assert abs(out[0]["lr"] - 0.0025 * 4 / 5) < 1e-12            # warm-up factor of step 3 (next step = 4 of 5)
     files = sorted(os.listdir(tmp_path / "checkpoints" / tdirs[0]))
     assert len(files) == 2 and files[0].startswith("epoch=1-step=5-")
-    t = _run(["test", str(cfg), "--grid", "16", "--batches", "2"], host_device)[-1]
+    t = _run(["test", str(cfg), "--grid", "8", "--batches", "2"], host_device)[-1]
     assert t["checkpoint"].endswith(files[0]) and 0.5 < t["test_loss"] < 1.5
-    p = _run(["predict", str(cfg), "--grid", "16"], host_device)[-1]
+    p = _run(["predict", str(cfg), "--grid", "8"], host_device)[-1]
     preds = np.load(p["predictions"])["preds"]
-    assert preds.shape == (1, 16, 16, 3) and np.isfinite(preds).all() and p["inference_time_ms_per_step"] > 0
+    assert preds.shape == (1, 8, 8, 3) and np.isfinite(preds).all() and p["inference_time_ms_per_step"] > 0
     # a second trial directory makes `test` ambiguous only for its own trial number
     with pytest.raises(AssertionError):
-        _run(["test", str(cfg), "--grid", "16", "--trial", "1"], host_device)
+        _run(["test", str(cfg), "--grid", "8", "--trial", "1"], host_device)
 
 
 def test_cli_rollout_routine_with_data_file(tmp_path, host_device):

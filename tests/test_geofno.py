@@ -39,6 +39,8 @@ def test_oracle_geofno_matches_reference_golden(tag):
 @pytest.mark.parametrize("tag", TAGS)
 def test_geofno_hip_path_matches_reference_golden(tag, host_device):
     from fourierflow_amd.modules import FNOMesh2D
+    if host_device == "cpu" and tag == "c64":
+        pytest.skip("width-64 golden: GPU only (the wave emulator runs the width-32 golden)")
     g, kw, sd_np, x, t = _case(tag)
     blk = FNOMesh2D(**kw)
     sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
