@@ -826,6 +826,67 @@ __global__ void fw_grad_reduce_kernel(const float* __restrict__ partial, float* 
     }
 }
 
+// ---- complex DFT along the first axis of a 2-D spectrum on the matrix cores -----------------------------------------
+// (the "cdft" step of the non-factorized spectral convs: FNOPlus2DBlock, FNOZongyi2DBlock, FNOMesh2D)
+// A complex line S = Sr + i Si is two REAL lines with Hermitian spectra A = DFT(Sr), B = DFT(Si), so the 2 Kx retained rows
+// of its DFT (frequencies 0..Kx-1 and -Kx..-1) follow from k = 0..Kx of A and B -- two launches of the truncated real DFT
+// kernel (dft_fwd) and one element-wise combination:
+//     row kx' <  Kx (k = kx'):        Z = A[k] + i B[k]              = (Ar - Bi) + i (Ai + Br)
+//     row kx' >= Kx (k = 2Kx - kx'):  Z = conj(A[k]) + i conj(B[k])  = (Ar + Bi) + i (Br - Ai)
+// and, for the zero-padded inverse, the other way round (dft_inv with c_k applied sums 2 Re(H[k] e^{i th}) for k >= 1):
+//     P[k] = Z[row k] (k < Kx),  N[k] = Z[row 2Kx - k] (1 <= k <= Kx)
+//     A[k] = h (P[k] + conj N[k]),   B[k] = -i h (P[k] - conj N[k]),   h = 1/2 (1 at k = 0 and at the Nyquist bin)
+// AB holds A then B, each [K'][R][2][C] with K' = Kx + 1, R = Ky * B lines (ky, b); Z is [ky][kx'][b][2][C].
+__global__ __launch_bounds__(256) void cdft_combine_fwd_kernel(const float* __restrict__ AB, float* __restrict__ Z, int Bn, int Ky,
+                                                               int Kx, int C) {
+    const long R = (long)Ky * Bn, plane = (long)(Kx + 1) * R * 2 * C;
+    const long total = (long)Ky * 2 * Kx * Bn * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int b = (int)((e / C) % Bn);
+        const int kxp = (int)((e / ((long)C * Bn)) % (2 * Kx));
+        const int ky = (int)(e / ((long)C * Bn * 2 * Kx));
+        const int k = kxp < Kx ? kxp : 2 * Kx - kxp;
+        const long a = (((long)k * R + (long)ky * Bn + b) * 2) * C + c;
+        const float Ar = AB[a], Ai = AB[a + C], Br = AB[plane + a], Bi = AB[plane + a + C];
+        float* z = Z + ((((long)ky * 2 * Kx + kxp) * Bn + b) * 2) * C + c;
+        if (kxp < Kx) {
+            z[0] = Ar - Bi;
+            z[C] = Ai + Br;
+        } else {
+            z[0] = Ar + Bi;
+            z[C] = Br - Ai;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cdft_combine_inv_kernel(const float* __restrict__ Z, float* __restrict__ AB, int Bn, int Ky,
+                                                               int Kx, int C, int M) {
+    const long R = (long)Ky * Bn, plane = (long)(Kx + 1) * R * 2 * C;
+    const long total = (long)(Kx + 1) * R * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long line = (e / C) % R;
+        const int k = (int)(e / ((long)C * R));
+        const int ky = (int)(line / Bn), b = (int)(line % Bn);
+        float Pr = 0.f, Pi = 0.f, Nr = 0.f, Ni = 0.f;
+        if (k < Kx) {
+            const float* z = Z + ((((long)ky * 2 * Kx + k) * Bn + b) * 2) * C + c;
+            Pr = z[0], Pi = z[C];
+        }
+        if (k >= 1) {
+            const float* z = Z + ((((long)ky * 2 * Kx + (2 * Kx - k)) * Bn + b) * 2) * C + c;
+            Nr = z[0], Ni = z[C];
+        }
+        const float h = (k == 0 || 2 * k == M) ? 1.f : 0.5f;
+        const long a = (((long)k * R + line) * 2) * C + c;
+        AB[a] = h * (Pr + Nr);                 // A = h (P + conj N)
+        AB[a + C] = h * (Pi - Ni);
+        AB[plane + a] = h * (Pi + Ni);         // B = -i h (P - conj N):  -i (x + i y) = y - i x  with x = Pr - Nr, y = Pi + Ni
+        AB[plane + a + C] = -h * (Pr - Nr);
+    }
+}
+
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -1082,6 +1143,70 @@ extern "C" int ffno_spectral_staged_pair(const ffno_fused_branch* ba, const ffno
             FFNO_LAUNCH((dft_inv_pair_kernel<32>), grid, block, smem, s, ia, ib, n0, apply_ck_inv);
     }
     return launch_status();
+}
+
+extern "C" size_t ffno_cdft_rows_ws_floats(int B, int C, int Kx, int Ky) {
+    return (size_t)2 * (Kx + 1) * (size_t)Ky * B * 2 * C;
+}
+
+// MFMA version of ffno_cdft_rows2 (same layouts and results to fp32 rounding): ws = ffno_cdft_rows_ws_floats() floats,
+// tw = twiddle table of length M (ffno_twiddle_fill_host).
+extern "C" int ffno_cdft_rows_mfma(const float* in, float* out, float* ws, const float* tw, int B, int M, int C, int Kx, int Ky,
+                                   int inverse, void* stream) {
+    if (!in || !out || !ws || !tw || B <= 0 || M <= 0 || Kx <= 0 || Ky <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    if (2 * Kx > M) return FFNO_EMODES;
+    const int K1 = Kx + 1, RT = (2 * K1 + 31) / 32;
+    if (RT > 4) return FFNO_EUNSUPPORTED;
+    const int R = Ky * B;
+    LineMap lm;                 // lines (ky, b) of the [ky][b][m][re/im][c] spectrum: element m at stride 2C, re / im = +0 / +C
+    lm.lines_per_group = R;
+    lm.group_stride = 0;
+    lm.line_stride = (long)M * 2 * C;
+    lm.elem_stride = 2 * C;
+    const size_t plane = (size_t)K1 * R * 2 * C;
+    const size_t smem = sizeof(float) * 2 * M;
+    hipStream_t s = (hipStream_t)stream;
+    const long ncomb = inverse ? (long)K1 * R * C : (long)Ky * 2 * Kx * B * C;
+    const dim3 cgrid((unsigned)min((ncomb + 255) / 256, 4096L));
+    if (!inverse) {
+        const dim3 grid((unsigned)min(((long)R * RT + 3) / 4, 8192L)), block(256);
+        for (int part = 0; part < 2; ++part) {
+            const float* x = in + (size_t)part * C;
+            float* spec = ws + part * plane;
+#define FFNO_CDFT_FWD_CASE(CC, RR) \
+    if (C == CC && RT == RR) FFNO_LAUNCH((dft_fwd_kernel<CC, RR>), grid, block, smem, s, x, spec, tw, R, M, K1, lm, 0);
+            FFNO_CDFT_FWD_CASE(64, 1)
+            FFNO_CDFT_FWD_CASE(64, 2)
+            FFNO_CDFT_FWD_CASE(64, 3)
+            FFNO_CDFT_FWD_CASE(64, 4)
+            FFNO_CDFT_FWD_CASE(32, 1)
+            FFNO_CDFT_FWD_CASE(32, 2)
+            FFNO_CDFT_FWD_CASE(32, 3)
+            FFNO_CDFT_FWD_CASE(32, 4)
+#undef FFNO_CDFT_FWD_CASE
+            const int rc = launch_status();
+            if (rc) return rc;
+        }
+        FFNO_LAUNCH(cdft_combine_fwd_kernel, cgrid, dim3(256), 0, s, ws, out, B, Ky, Kx, C);
+        return launch_status();
+    }
+    FFNO_LAUNCH(cdft_combine_inv_kernel, cgrid, dim3(256), 0, s, in, ws, B, Ky, Kx, C, M);
+    int rc = launch_status();
+    if (rc) return rc;
+    const long items = (long)R * ((((M + 31) >> 5) + 1) >> 1);
+    const dim3 grid((unsigned)min((items + 3) / 4, 8192L)), block(256);
+    for (int part = 0; part < 2; ++part) {
+        const float* spec = ws + part * plane;
+        float* o = out + (size_t)part * C;
+        if (C == 64)
+            FFNO_LAUNCH((dft_inv_kernel<64>), grid, block, smem, s, spec, o, nullptr, tw, R, M, K1, lm, 1, 0);
+        else
+            FFNO_LAUNCH((dft_inv_kernel<32>), grid, block, smem, s, spec, o, nullptr, tw, R, M, K1, lm, 1, 0);
+        rc = launch_status();
+        if (rc) return rc;
+    }
+    return FFNO_OK;
 }
 
 // ---- operator level -----------------------------------------------------------------------------

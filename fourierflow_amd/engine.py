@@ -414,6 +414,7 @@ class FFNOEngine:
         if self.spectral == "plus":
             ws.SYa = torch.empty(ws.views[0].spec_y, **f32)           # last-axis spectra on either side of the x transform
             ws.SYb = torch.empty(ws.views[0].spec_y, **f32)
+            ws.CW = torch.empty(int(lib.ffno_cdft_rows_ws_floats(B, C, self.K, self.K)), **f32)   # first-axis DFT scratch
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
         if self.use_fork:
             ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
@@ -545,9 +546,11 @@ class FFNOEngine:
             # is the same chain with the c_k / conjugate flags swapped (cdft_rows(inverse) is the adjoint of the forward).
             z = save if save is not None else ws.SD
             self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(ws.SYa), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_f, st)
-            self._k("cdft_rows", lib.ffno_cdft_rows, _p(ws.SYa), _p(z), v.Bv, v.Mv, C, v.K, 0, st)
+            twm = self._twiddle(v.Mv)
+            self._k("cdft_rows", lib.ffno_cdft_rows_mfma, _p(ws.SYa), _p(z), _p(ws.CW), _p(twm), v.Bv, v.Mv, C, v.K, v.K, 0, st)
             self._k("mode_mix", lib.ffno_mode_mix, _p(z), _p(planes), _p(ws.SY), v.Bv, C, v.K2, conj, st)
-            self._k("cdft_rows", lib.ffno_cdft_rows, _p(ws.SY), _p(ws.SYb), v.Bv, v.Mv, C, v.K, 1, st)
+            self._k("cdft_rows", lib.ffno_cdft_rows_mfma, _p(ws.SY), _p(ws.SYb), _p(ws.CW), _p(twm), v.Bv, v.Mv, C, v.K, v.K, 1,
+                    st)
             self._k("dft_inv", lib.ffno_dft_inv, _p(ws.SYb), _p(dst), resid, _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_i,
                     accumulate, st)
             return

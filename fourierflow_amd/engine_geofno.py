@@ -115,6 +115,7 @@ class GeoFNO2DEngine(ZongyiEngine):
         P, P_in = ws.P, ws.P_in
         ws.SYa, ws.SYb = torch.empty(v.spec_y, **f32), torch.empty(v.spec_y, **f32)
         ws.SY, ws.SD = torch.empty(v.spec, **f32), torch.empty(v.spec, **f32)
+        ws.CW = torch.empty(int(lib.ffno_cdft_rows_ws_floats(B, C, self.Kx, self.Ky)), **f32)      # first-axis DFT scratch
         ws.S = torch.empty(P, C, **f32)
         ws.x = torch.empty(P_in, self.Cin, **f32)
         ws.X = torch.zeros(L + 1, P, C, **f32)           # X[0]: fc0 output in the padded frame (pad stays 0 for ever)
@@ -142,9 +143,12 @@ class GeoFNO2DEngine(ZongyiEngine):
         tw = self._twiddle(v.L)
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
         self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(ws.SYa), _p(tw), v.Bv, v.Mv, v.Nv, C, self.Ky, 0, ck_f, st)
-        self._k("cdft_rows", lib.ffno_cdft_rows2, _p(ws.SYa), _p(save), v.Bv, v.Mv, C, self.Kx, self.Ky, 0, st)
+        twm = self._twiddle(v.Mv)
+        self._k("cdft_rows", lib.ffno_cdft_rows_mfma, _p(ws.SYa), _p(save), _p(ws.CW), _p(twm), v.Bv, v.Mv, C, self.Kx, self.Ky,
+                0, st)
         self._k("mode_mix", lib.ffno_mode_mix, _p(save), _p(planes), _p(ws.SY), v.Bv, C, v.K2, conj, st)
-        self._k("cdft_rows", lib.ffno_cdft_rows2, _p(ws.SY), _p(ws.SYb), v.Bv, v.Mv, C, self.Kx, self.Ky, 1, st)
+        self._k("cdft_rows", lib.ffno_cdft_rows_mfma, _p(ws.SY), _p(ws.SYb), _p(ws.CW), _p(twm), v.Bv, v.Mv, C, self.Kx, self.Ky,
+                1, st)
         self._k("dft_inv", lib.ffno_dft_inv, _p(ws.SYb), _p(dst), _p(resid), _p(tw), v.Bv, v.Mv, v.Nv, C, self.Ky, 0, ck_i,
                 accumulate, st)
 

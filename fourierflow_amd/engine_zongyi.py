@@ -197,6 +197,7 @@ class ZongyiEngine:
             ws.v = v
             ws.SYa = torch.empty(v.spec_y, **f32)
             ws.SYb = torch.empty(v.spec_y, **f32)
+            ws.CW = torch.empty(int(lib.ffno_cdft_rows_ws_floats(B, C, self.K, self.K)), **f32)     # first-axis DFT scratch
             ws.SY = torch.empty(v.spec, **f32)
             ws.SX0 = torch.empty(v.spec, **f32)             # forward spectrum when nothing is saved
             ws.SD = torch.empty(v.spec, **f32)              # adjoint spectrum dY of the current layer
@@ -232,9 +233,10 @@ class ZongyiEngine:
         tw = self._twiddle(v.L)
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
         self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(ws.SYa), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_f, st)
-        self._k("cdft_rows", lib.ffno_cdft_rows, _p(ws.SYa), _p(save), v.Bv, v.Mv, C, v.K, 0, st)
+        twm = self._twiddle(v.Mv)
+        self._k("cdft_rows", lib.ffno_cdft_rows_mfma, _p(ws.SYa), _p(save), _p(ws.CW), _p(twm), v.Bv, v.Mv, C, v.K, v.K, 0, st)
         self._k("mode_mix", lib.ffno_mode_mix, _p(save), _p(planes), _p(ws.SY), v.Bv, C, v.K2, conj, st)
-        self._k("cdft_rows", lib.ffno_cdft_rows, _p(ws.SY), _p(ws.SYb), v.Bv, v.Mv, C, v.K, 1, st)
+        self._k("cdft_rows", lib.ffno_cdft_rows_mfma, _p(ws.SY), _p(ws.SYb), _p(ws.CW), _p(twm), v.Bv, v.Mv, C, v.K, v.K, 1, st)
         self._k("dft_inv", lib.ffno_dft_inv, _p(ws.SYb), _p(dst), _p(resid), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_i,
                 accumulate, st)
 

@@ -328,6 +328,13 @@ int ffno_fw2d_pack2(const float* w0, const float* w1, float* wp, float* wpt, int
                     void* stream);
 int ffno_fw2d_grad_reduce2(const float* partial, float* gw0, float* gw1, int C, int Kx, int Ky, int nsplit,
                            int accumulate, void* stream);
+/* ffno_cdft_rows2 on the matrix cores: a complex line is two real lines, so the retained rows follow from the truncated
+ * real-DFT kernels (ffno_dft_fwd / ffno_dft_inv internals) over k = 0..Kx plus an element-wise combination -- same
+ * layouts, same results to fp32 rounding, the inverse is still the exact adjoint of the forward.
+ * ws: ffno_cdft_rows_ws_floats(B, C, Kx, Ky) floats; tw: twiddle table of length M (ffno_twiddle_fill_host). */
+size_t ffno_cdft_rows_ws_floats(int B, int C, int Kx, int Ky);
+int ffno_cdft_rows_mfma(const float* in, float* out, float* ws, const float* tw, int B, int M, int C,
+                        int Kx, int Ky, int inverse, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Velocity features of the Markov routine (routines/grid_2d_markov.py:130-144, `use_velocity: true`,

@@ -160,3 +160,28 @@ def test_rectangular_mode_blocks(be, B, M, C, Kx, Ky):
     assert lib.ffno_fw2d_grad_reduce2(p(hp), p(g0), p(g1), C, Kx, Ky, 2, 1, None) == 0
     tot = part.sum(0).reshape(Ky, 2 * Kx, 2, C, C).transpose(3, 4, 1, 0, 2)
     assert rel_l2(be.get(g0), 1 + tot[:, :, :Kx]) < 1e-6 and rel_l2(be.get(g1), 1 + tot[:, :, Kx:]) < 1e-6
+
+
+@pytest.mark.parametrize("B,M,C,Kx,Ky", [(2, 12, 32, 3, 5), (1, 20, 64, 6, 2), (2, 8, 32, 4, 3), (1, 13, 64, 5, 4), (3, 9, 32, 2, 2)])
+def test_cdft_rows_on_the_matrix_cores_equals_the_vector_version(be, B, M, C, Kx, Ky):
+    """ffno_cdft_rows_mfma (two truncated real DFTs + an element-wise combination) vs ffno_cdft_rows2, forward and
+    zero-padded inverse, incl. 2 Kx == M (the Nyquist row) and odd M; and inverse == adjoint of forward."""
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(M + Kx + Ky)
+    S = rs.standard_normal((Ky, B, M, 2, C)).astype(np.float32)
+    Zin = rs.standard_normal((Ky, 2 * Kx, B, 2, C)).astype(np.float32)
+    hS, hZ, tw = be.put(S), be.put(Zin), be.twiddle(M)
+    ws = be.empty(int(lib.ffno_cdft_rows_ws_floats(B, C, Kx, Ky)))
+    Zv, Zm = be.empty(Zin.shape), be.empty(Zin.shape)
+    assert lib.ffno_cdft_rows2(p(hS), p(Zv), B, M, C, Kx, Ky, 0, None) == 0
+    assert lib.ffno_cdft_rows_mfma(p(hS), p(Zm), p(ws), p(tw), B, M, C, Kx, Ky, 0, None) == 0
+    assert rel_l2(be.get(Zm), be.get(Zv)) < 2e-6
+    Sv, Sm = be.empty(S.shape), be.empty(S.shape)
+    assert lib.ffno_cdft_rows2(p(hZ), p(Sv), B, M, C, Kx, Ky, 1, None) == 0
+    assert lib.ffno_cdft_rows_mfma(p(hZ), p(Sm), p(ws), p(tw), B, M, C, Kx, Ky, 1, None) == 0
+    assert rel_l2(be.get(Sm), be.get(Sv)) < 2e-6
+    lhs = (be.get(Zm).astype(np.float64) * Zin).sum()
+    rhs = (S.astype(np.float64) * be.get(Sm)).sum()
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+    assert lib.ffno_cdft_rows_mfma(p(hS), p(Zm), None, p(tw), B, M, C, Kx, Ky, 0, None) == -1
+    assert lib.ffno_cdft_rows_mfma(p(hS), p(Zm), p(ws), p(tw), B, 2 * Kx - 1, C, Kx, Ky, 0, None) == -3
