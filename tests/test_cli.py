@@ -105,7 +105,7 @@ def test_cli_rollout_routine_with_data_file(tmp_path, host_device):
     cfg = tmp_path / "config.yaml"
     cfg.write_text(ROLLOUT)
     rs = np.random.RandomState(0)
-    np.savez(tmp_path / "data.npz", data=rs.standard_normal((4, 12, 12, 12)).astype(np.float32))
+    np.savez(tmp_path / "data.npz", data=rs.standard_normal((4, 8, 8, 12)).astype(np.float32))
     out = _run(["train", str(cfg), "--steps", "2", "--data", str(tmp_path / "data.npz"), "--steps-per-epoch", "1",
                 "--checkpoint-id", "abc"], host_device)
     assert os.path.isdir(tmp_path / "checkpoints" / "trial-0-abc")
@@ -113,7 +113,7 @@ def test_cli_rollout_routine_with_data_file(tmp_path, host_device):
     t = _run(["test", str(cfg), "--data", str(tmp_path / "data.npz")], host_device)[-1]
     assert set(t) >= {"test_loss", "test_loss_avg", "test_time_until"}
     p = _run(["predict", str(cfg), "--data", str(tmp_path / "data.npz"), "--batch-size", "2"], host_device)[-1]
-    assert p["shape"] == [2, 12, 12, 2]
+    assert p["shape"] == [2, 8, 8, 2]
     bad = tmp_path / "bad.npz"
     np.savez(bad, x=np.zeros((2, 4, 4, 1), np.float32))
     from fourierflow_amd.cli import app

@@ -13,7 +13,7 @@ TOL = 2e-6
 
 # (P, Cin, ldx, Cout, ldo): in_proj, the per-layer linear, the two head linears, a ragged tail
 SHAPES = [(2 * 64 * 64, 12, 12, 32, 32), (300, 20, 32, 20, 32), (1000, 32, 32, 128, 128), (777, 128, 128, 1, 1),
-          (65, 5, 8, 7, 16), (500, 64, 64, 128, 128), (200, 64, 64, 64, 64)]
+          (65, 5, 8, 7, 16), (150, 64, 64, 128, 128), (100, 64, 64, 64, 64)]
 
 
 def _data(P, Cin, ldx, Cout, ldo, seed=0):
