@@ -103,6 +103,8 @@ SIGNATURES = {
     "ffno_fw2d_pack": (I, [P, P, P, P, I, I, P]),
     "ffno_fw2d_grad_reduce": (I, [P, P, P, I, I, I, I, P]),
     "ffno_cdft_rows2": (I, [P, P, I, I, I, I, I, I, P]),
+    "ffno_fw3d_pack": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "ffno_fw3d_grad_reduce": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_cdft_rows_ws_floats": (SZ, [I, I, I, I]),
     "ffno_cdft_rows_mfma": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_fw2d_pack2": (I, [P, P, P, P, I, I, I, P]),

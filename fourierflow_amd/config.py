@@ -24,6 +24,7 @@ TARGET_MAP = {
     "fourierflow.modules.FNOPlus2DBlock": "fourierflow_amd.modules.FNOPlus2DBlock",
     "fourierflow.modules.FNOZongyi2DBlock": "fourierflow_amd.modules.FNOZongyi2DBlock",
     "fourierflow.modules.FNOMesh2D": "fourierflow_amd.modules.FNOMesh2D",
+    "fourierflow.modules.FNOMesh3D": "fourierflow_amd.modules.FNOMesh3D",
     "fourierflow.modules.WNLinear": "fourierflow_amd.modules.WNLinear",
     "fourierflow.modules.Normalizer": "fourierflow_amd.modules.Normalizer",
     "fourierflow.routines.Grid2DMarkovExperiment": "fourierflow_amd.routines.Grid2DMarkovExperiment",
@@ -136,11 +137,11 @@ def build_routine(cfg: Dict[str, Any]):
     r.pop("scheduler", None)
     routine_kwargs = {}
     model_target = str((r.get("conv") or r.get("model") or {}).get("_target_", ""))
-    baseline = model_target.endswith(("FNOZongyi2DBlock", "FNOMesh2D"))        # the StepLR (and Adam) users built here
+    baseline = model_target.endswith(("FNOZongyi2DBlock", "FNOMesh2D", "FNOMesh3D"))     # the StepLR (and Adam) users built here
     if opt is not None:
-        names = ("torch.optim.AdamW",) + (("torch.optim.Adam",) if model_target.endswith("FNOMesh2D") else ())
+        names = ("torch.optim.AdamW",) + (("torch.optim.Adam",) if model_target.endswith(("FNOMesh2D", "FNOMesh3D")) else ())
         if not isinstance(opt, Partial) or opt.func.name not in names:
-            raise NotImplementedError(f"only torch.optim.AdamW (and torch.optim.Adam for FNOMesh2D) map to the fused flat "
+            raise NotImplementedError(f"only torch.optim.AdamW (and torch.optim.Adam for FNOMesh2D / FNOMesh3D) map to the fused flat "
                                       f"optimiser kernel, got {opt}")
         routine_kwargs["optimizer"] = dict(opt.kwargs)
         if opt.func.name == "torch.optim.Adam":

@@ -172,6 +172,45 @@ __global__ void fw2d_grad_reduce_kernel(const float* __restrict__ partial, float
     }
 }
 
+// ---- 3-D corner blocks (FNOMesh3D, zongyi_fno/mesh_3d.py:38-57): four weight tensors [I][O][K1][K2][K3][2], one per sign
+// pair of (kx, ky):  w[0] = (+x, +y), w[1] = (-x, +y), w[2] = (+x, -y), w[3] = (-x, -y).
+// planes[mode = (kz * 2K2 + ky') * 2K1 + kx'][ri][i][o],  kx' >= K1 / ky' >= K2 = the negative-frequency rows.
+struct Fw3dPtrs {
+    float* w[4];
+};
+
+__global__ void fw3d_pack_kernel(Fw3dPtrs W, float* __restrict__ wp, float* __restrict__ wpt, int C, int K1, int K2, int K3) {
+    const long total = (long)K3 * 2 * K2 * 2 * K1 * 2 * C * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const long mode = e / ((long)C * C * 2);
+        const int kxp = mode % (2 * K1), kyp = (mode / (2 * K1)) % (2 * K2), kz = (int)(mode / ((long)4 * K1 * K2));
+        const float* w = W.w[(kxp >= K1 ? 1 : 0) + (kyp >= K2 ? 2 : 0)];
+        const float v = w[(((((long)i * C + o) * K1 + (kxp % K1)) * K2 + (kyp % K2)) * K3 + kz) * 2 + ri];
+        wp[e] = v;
+        wpt[((mode * 2 + ri) * C + o) * C + i] = v;
+    }
+}
+
+__global__ void fw3d_grad_reduce_kernel(const float* __restrict__ partial, Fw3dPtrs G, int C, int K1, int K2, int K3, int nsplit,
+                                        int accumulate) {
+    const long total = (long)K3 * 2 * K2 * 2 * K1 * 2 * C * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const long mode = e / ((long)C * C * 2);
+        const int kxp = mode % (2 * K1), kyp = (mode / (2 * K1)) % (2 * K2), kz = (int)(mode / ((long)4 * K1 * K2));
+        float s = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(long)sp * total + e];
+        float* g = G.w[(kxp >= K1 ? 1 : 0) + (kyp >= K2 ? 2 : 0)] +
+                   (((((long)i * C + o) * K1 + (kxp % K1)) * K2 + (kyp % K2)) * K3 + kz) * 2 + ri;
+        *g = accumulate ? (*g + s) : s;
+    }
+}
+
 static inline int s2d_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -231,4 +270,24 @@ extern "C" int ffno_fw2d_grad_reduce2(const float* partial, float* gw0, float* g
 extern "C" int ffno_fw2d_grad_reduce(const float* partial, float* gw0, float* gw1, int C, int K, int nsplit,
                                      int accumulate, void* stream) {
     return ffno_fw2d_grad_reduce2(partial, gw0, gw1, C, K, K, nsplit, accumulate, stream);
+}
+
+extern "C" int ffno_fw3d_pack(const float* w1, const float* w2, const float* w3, const float* w4, float* wp, float* wpt, int C,
+                              int K1, int K2, int K3, void* stream) {
+    if (!w1 || !w2 || !w3 || !w4 || !wp || !wpt || C <= 0 || K1 <= 0 || K2 <= 0 || K3 <= 0) return FFNO_EINVAL;
+    const long total = (long)K3 * 2 * K2 * 2 * K1 * 2 * C * C;
+    Fw3dPtrs W{{const_cast<float*>(w1), const_cast<float*>(w2), const_cast<float*>(w3), const_cast<float*>(w4)}};
+    FFNO_LAUNCH(fw3d_pack_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream, W, wp, wpt,
+                C, K1, K2, K3);
+    return s2d_status();
+}
+
+extern "C" int ffno_fw3d_grad_reduce(const float* partial, float* g1, float* g2, float* g3, float* g4, int C, int K1, int K2,
+                                     int K3, int nsplit, int accumulate, void* stream) {
+    if (!partial || !g1 || !g2 || !g3 || !g4 || C <= 0 || K1 <= 0 || K2 <= 0 || K3 <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    const long total = (long)K3 * 2 * K2 * 2 * K1 * 2 * C * C;
+    Fw3dPtrs G{{g1, g2, g3, g4}};
+    FFNO_LAUNCH(fw3d_grad_reduce_kernel, dim3((unsigned)min((total + 255) / 256, 8192L)), dim3(256), 0, (hipStream_t)stream,
+                partial, G, C, K1, K2, K3, nsplit, accumulate);
+    return s2d_status();
 }

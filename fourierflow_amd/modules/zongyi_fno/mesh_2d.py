@@ -13,32 +13,41 @@ from ... import _lib
 from ...engine_geofno import GeoFNO2DEngine
 
 
-class SpectralConv2d(nn.Module):
-    """Parameter container of one Fourier layer (mesh_2d.py:15-32): two complex corner-block weight tensors."""
+class _ComplexCornerWeights(nn.Module):
+    """Parameter container of one Fourier layer: ``weights1..n``, complex64 ``[in, out, *modes]`` in the state_dict, stored as
+    their ``view_as_real`` twins."""
 
-    def __init__(self, in_channels, out_channels, modes1, modes2):
+    def __init__(self, in_channels, out_channels, modes, n_weights):
         super().__init__()
-        self.in_channels, self.out_channels, self.modes1, self.modes2 = in_channels, out_channels, modes1, modes2
+        self.in_channels, self.out_channels = in_channels, out_channels
         self.scale = 1 / (in_channels * out_channels)
-        for name in ("weights1", "weights2"):       # scale * torch.rand(..., dtype=cfloat): real and imaginary parts U[0, 1)
-            setattr(self, name, nn.Parameter(self.scale * torch.rand(in_channels, out_channels, modes1, modes2, 2)))
+        self._names = tuple(f"weights{j}" for j in range(1, n_weights + 1))
+        for name in self._names:       # scale * torch.rand(..., dtype=cfloat): real and imaginary parts U[0, 1)
+            setattr(self, name, nn.Parameter(self.scale * torch.rand(in_channels, out_channels, *modes, 2)))
         self._register_state_dict_hook(self._complex_out)
         self._register_load_state_dict_pre_hook(self._complex_in)
 
     @staticmethod
     def _complex_out(module, state_dict, prefix, local_metadata):
-        for name in ("weights1", "weights2"):
+        for name in module._names:
             state_dict[prefix + name] = torch.view_as_complex(state_dict[prefix + name].contiguous())
 
-    @staticmethod
-    def _complex_in(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        for name in ("weights1", "weights2"):
+    def _complex_in(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for name in self._names:
             t = state_dict.get(prefix + name)
             if t is not None and t.is_complex():
                 state_dict[prefix + name] = torch.view_as_real(t.to(torch.complex64))
 
     def forward(self, x):
-        raise RuntimeError("layers of FNOMesh2D run inside the model's fused HIP pass; call the model")
+        raise RuntimeError("Fourier layers of FNOMesh2D / FNOMesh3D run inside the model's fused HIP pass; call the model")
+
+
+class SpectralConv2d(_ComplexCornerWeights):
+    """mesh_2d.py:15-32: two corner-block weight tensors [in, out, modes1, modes2]."""
+
+    def __init__(self, in_channels, out_channels, modes1, modes2):
+        super().__init__(in_channels, out_channels, (modes1, modes2), 2)
+        self.modes1, self.modes2 = modes1, modes2
 
 
 class _MeshFn(torch.autograd.Function):
@@ -55,7 +64,7 @@ class _MeshFn(torch.autograd.Function):
     def backward(ctx, gy):
         module = ctx.module
         if module._generation != ctx.gen:
-            raise RuntimeError("FNOMesh2D: only the most recent forward pass can be back-propagated")
+            raise RuntimeError("FNOMesh2D / FNOMesh3D: only the most recent forward pass can be back-propagated")
         eng = module._engine
         flat = eng.backward(gy.contiguous()).clone()
         grads, off = [], 0

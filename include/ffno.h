@@ -336,6 +336,16 @@ size_t ffno_cdft_rows_ws_floats(int B, int C, int Kx, int Ky);
 int ffno_cdft_rows_mfma(const float* in, float* out, float* ws, const float* tw, int B, int M, int C,
                         int Kx, int Ky, int inverse, void* stream);
 
+/* 3-D corner blocks (FNOMesh3D, zongyi_fno/mesh_3d.py:38-57): rfftn -> four blocks (+-x, +-y, low z) x their own complex
+ * weights [I][O][K1][K2][K3][2] (w1 = (+x,+y), w2 = (-x,+y), w3 = (+x,-y), w4 = (-x,-y)) -> irfftn.  The transforms are
+ * ffno_dft_fwd (z) -> ffno_cdft_rows_mfma (y, with B := B*X lines) -> ffno_cdft_rows_mfma (x, with Ky := K3*2K2) and back;
+ * the mix and the weight-gradient contraction are ffno_mode_mix / ffno_fw_grad_partial over the K3*2K2*2K1 retained modes
+ * (mode = (kz*2K2 + ky')*2K1 + kx') with the B samples as rows.  These two convert the weight layouts. */
+int ffno_fw3d_pack(const float* w1, const float* w2, const float* w3, const float* w4, float* wp, float* wpt,
+                   int C, int K1, int K2, int K3, void* stream);
+int ffno_fw3d_grad_reduce(const float* partial, float* g1, float* g2, float* g3, float* g4, int C, int K1,
+                          int K2, int K3, int nsplit, int accumulate, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Velocity features of the Markov routine (routines/grid_2d_markov.py:130-144, `use_velocity: true`,
  * wavenumber buffers :82-94): vorticity[B][X][Y] -> out[B][X][Y][3] = (vorticity, u, v) with

@@ -19,8 +19,8 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.  The shipped package (fourierflow_amd/) never does.
 
 Also restated here, with their own golden vectors: FNOFactorizedMesh2D / Mesh3D (mesh_2d.py, mesh_3d.py),
-FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), FNOZongyi2DBlock (zongyi_fno/grid_2d.py), FNOMesh2D
-(zongyi_fno/mesh_2d.py), Normalizer, the Markov
+FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), FNOZongyi2DBlock (zongyi_fno/grid_2d.py), FNOMesh2D / FNOMesh3D
+(zongyi_fno/mesh_2d.py, mesh_3d.py), Normalizer, the Markov
 feature build (routines/grid_2d_markov.py:124-170).
 
 Parity status: PINNED against golden vectors generated from the imported
@@ -403,6 +403,34 @@ def fno_mesh2d(sd: Dict[str, Tensor], x: Tensor, *, modes1: int, modes2: int, n_
         if i < n_layers - 1:
             h = F.gelu(h)                                                                      # :91-92
     h = h[..., :-padding, :-padding].permute(0, 2, 3, 1)                                       # :94-95
+    h = F.gelu(F.linear(h, sd["fc1.weight"], sd["fc1.bias"]))
+    return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
+
+
+def fno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes1: int, modes2: int, modes3: int, n_layers: int,
+               padding: int = 5) -> Tensor:
+    """FNOMesh3D (zongyi_fno/mesh_3d.py:63-113): x [B, X, Y, Z, 1] -> [B, X, Y, Z, 4]; four corner blocks (:38-57)."""
+    B, X, Y, Z, _ = x.shape
+    lin = lambda n, d: torch.linspace(0, 1, n, dtype=x.dtype).reshape([n if i == d else 1 for i in range(3)])   # noqa: E731
+    grid = torch.stack([lin(X, 0).expand(X, Y, Z), lin(Y, 1).expand(X, Y, Z), lin(Z, 2).expand(X, Y, Z)], dim=-1)
+    h = torch.cat((x, grid[None].expand(B, X, Y, Z, 3)), dim=-1)                               # :87-88
+    h = F.linear(h, sd["fc0.weight"], sd["fc0.bias"]).permute(0, 4, 1, 2, 3)                   # :89-90
+    h = F.pad(h, [0, padding, 0, padding, 0, padding])                                         # :91
+    m1, m2, m3 = modes1, modes2, modes3
+    for i in range(n_layers):
+        hf = torch.fft.rfftn(h, dim=[-3, -2, -1])                                              # :40
+        out = hf.new_zeros(B, h.shape[1], h.shape[-3], h.shape[-2], h.shape[-1] // 2 + 1)
+        mul = lambda a, w: torch.einsum("bixyz,ioxyz->boxyz", a, w)                            # noqa: E731
+        out[:, :, :m1, :m2, :m3] = mul(hf[:, :, :m1, :m2, :m3], sd[f"convs.{i}.weights1"])     # :45-52
+        out[:, :, -m1:, :m2, :m3] = mul(hf[:, :, -m1:, :m2, :m3], sd[f"convs.{i}.weights2"])
+        out[:, :, :m1, -m2:, :m3] = mul(hf[:, :, :m1, -m2:, :m3], sd[f"convs.{i}.weights3"])
+        out[:, :, -m1:, -m2:, :m3] = mul(hf[:, :, -m1:, -m2:, :m3], sd[f"convs.{i}.weights4"])
+        x1 = torch.fft.irfftn(out, s=(h.shape[-3], h.shape[-2], h.shape[-1]))                  # :56
+        x2 = F.conv3d(h, sd[f"ws.{i}.weight"], sd[f"ws.{i}.bias"])                             # :95
+        h = x1 + x2
+        if i < n_layers - 1:
+            h = F.gelu(h)
+    h = h[..., :-padding, :-padding, :-padding].permute(0, 2, 3, 4, 1)                         # :100-101
     h = F.gelu(F.linear(h, sd["fc1.weight"], sd["fc1.bias"]))
     return F.linear(h, sd["fc2.weight"], sd["fc2.bias"])
 

@@ -273,7 +273,9 @@ def make_geofno_state_dict(kw: dict, seed: int):
     weights use std 0.05 (the reference's init, scale / (in*out) * U[0,1), is ~5e-4 and would leave the spectral path
     numerically invisible next to the 1x1 convolutions)."""
     rs = np.random.RandomState(seed)
-    W, m1, m2 = kw["width"], kw["modes1"], kw["modes2"]
+    W = kw["width"]
+    modes = (kw["modes1"], kw["modes2"]) + ((kw["modes3"],) if "modes3" in kw else ())
+    nd = len(modes)
     sd = {}
 
     def lin(prefix, fin, fout, shape=None):
@@ -282,16 +284,18 @@ def make_geofno_state_dict(kw: dict, seed: int):
 
     lin("fc0.", 4, W)
     for l in range(kw["n_layers"]):
-        for j in (1, 2):
-            w = rs.standard_normal((W, W, m1, m2, 2)) * 0.05
+        for j in range(1, (2 if nd == 2 else 4) + 1):
+            w = rs.standard_normal((W, W, *modes, 2)) * 0.05
             sd[f"convs.{l}.weights{j}"] = (w[..., 0] + 1j * w[..., 1]).astype(np.complex64)
     for l in range(kw["n_layers"]):
-        lin(f"ws.{l}.", W, W, shape=(W, W, 1, 1))
+        lin(f"ws.{l}.", W, W, shape=(W, W) + (1,) * nd)
     lin("fc1.", W, 128)
-    lin("fc2.", 128, 1)
+    lin("fc2.", 128, 1 if nd == 2 else 4)
     return sd
 
 
-def make_geofno_io(seed: int, B: int, X: int, Y: int):
+def make_geofno_io(seed: int, B: int, X: int, Y: int, Z: int = 0):
     rs = np.random.RandomState(seed + 100)
+    if Z:       # FNOMesh3D: one input channel, four output channels
+        return rs.standard_normal((B, X, Y, Z, 1)).astype(np.float32), rs.standard_normal((B, X, Y, Z, 4)).astype(np.float32)
     return rs.standard_normal((B, X, Y, 2)).astype(np.float32), rs.standard_normal((B, X, Y, 1)).astype(np.float32)

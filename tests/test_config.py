@@ -84,7 +84,7 @@ def test_unknown_reference_targets_fail_loudly(tmp_path):
     with pytest.raises(NotImplementedError, match="accumulate_grad_batches"):
         Grid2DMarkovExperiment(conv, accumulate_grad_batches=4)
     with pytest.raises(NotImplementedError):
-        instantiate({"_target_": "fourierflow.modules.FNOMesh3D", "modes1": 12})
+        instantiate({"_target_": "fourierflow.modules.FNOPointCloud2D", "modes1": 12})
     with pytest.raises(ValueError):
         instantiate("${nope: 1}")
     assert instantiate("${eval: 2 * 3}") == 6
@@ -100,6 +100,7 @@ REFERENCE_CONFIGS = [
     ("torus_kochkov/ffno/grid_sizes/256", "Grid2DMarkovExperiment", "conv", "FNOFactorized2DBlock"),
     ("torus_li/zongyi/4_layers", "Grid2DRolloutExperiment", "conv", "FNOZongyi2DBlock"),       # BASELINE config 0
     ("pipe/geo-fno/8_layers", "StructuredMeshExperiment", "model", "FNOMesh2D"),               # geo-FNO baseline, Adam + StepLR
+    ("plasticity/geo-fno/4_layers", "StructuredMeshExperiment", "model", "FNOMesh3D"),
 ]
 
 
@@ -115,7 +116,7 @@ def test_shipped_experiment_configs_build_unchanged(rel, routine_cls, attr, mode
     from fourierflow_amd.config import build_routine, load_config
     # the non-factorized configs carry ~0.5 GB of [C, C, K, K, 2] weights per 24 layers: two layers are enough to check
     # that every constructor argument of the file arrives
-    shrink = [f"routine.{attr}.n_layers=2"] if model_cls in ("FNOPlus2DBlock",) else []
+    shrink = [f"routine.{attr}.n_layers=2"] if model_cls in ("FNOPlus2DBlock", "FNOMesh3D") else []
     cfg = load_config(path, shrink)
     routine = build_routine(cfg)
     assert type(routine).__name__ == routine_cls
@@ -160,4 +161,4 @@ def test_every_shipped_ffno_config_builds():
         except Exception as e:  # noqa: BLE001 - anything else is a loader bug
             unexpected.append((os.path.relpath(p, root), repr(e)))
     assert not unexpected, unexpected[:5]
-    assert built >= 190, built
+    assert built >= 200, built

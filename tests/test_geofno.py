@@ -1,6 +1,7 @@
-"""FNOMesh2D, the geo-FNO baseline of the airfoil / pipe experiments (reference zongyi_fno/mesh_2d.py:14-106): the oracle
-against the reference's golden vectors, the HIP path against both (complex64 state_dict, modes1 != modes2, non-square
-meshes, widths 32 and 64), and the StructuredMeshExperiment step with torch.optim.Adam + StepLR."""
+"""FNOMesh2D / FNOMesh3D, the geo-FNO baselines of the airfoil / pipe / plasticity experiments (reference
+zongyi_fno/mesh_2d.py:14-106, mesh_3d.py:7-113): the oracle against the reference's golden vectors, the HIP path against both
+(complex64 state_dict, unequal mode counts, non-square meshes, widths 32 and 64, four 3-D corner blocks), and the
+StructuredMeshExperiment step with torch.optim.Adam + StepLR."""
 import numpy as np
 import pytest
 import torch
@@ -9,23 +10,29 @@ import golden_util as gu
 from backend_util import host_device, rel_l2  # noqa: F401
 from oracle import ffno_oracle as orc
 
-TAGS = ["c32", "c64"]
+TAGS = ["c32", "c64", "3d_c32"]
 
 
 def _case(tag):
     g = gu.load_golden("geofno_" + tag)
     kw = gu.golden_kwargs(g)
-    B, X, Y, seed = [int(v) for v in g["meta"]]
+    B, X, Y, seed, Z = [int(v) for v in g["meta"]]
     sd_np = gu.make_geofno_state_dict(kw, seed)
-    x, t = gu.make_geofno_io(seed, B, X, Y)
+    x, t = gu.make_geofno_io(seed, B, X, Y, Z)
     return g, kw, sd_np, x, t
+
+
+def _oracle(kw, sd, x):
+    if "modes3" in kw:
+        return orc.fno_mesh3d(sd, x, modes1=kw["modes1"], modes2=kw["modes2"], modes3=kw["modes3"], n_layers=kw["n_layers"])
+    return orc.fno_mesh2d(sd, x, modes1=kw["modes1"], modes2=kw["modes2"], n_layers=kw["n_layers"])
 
 
 @pytest.mark.parametrize("tag", TAGS)
 def test_oracle_geofno_matches_reference_golden(tag):
     g, kw, sd_np, x, t = _case(tag)
     sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
-    out = orc.fno_mesh2d(sd, torch.tensor(x), modes1=kw["modes1"], modes2=kw["modes2"], n_layers=kw["n_layers"])
+    out = _oracle(kw, sd, torch.tensor(x))
     loss = ((out - torch.tensor(t)) ** 2).mean()
     loss.backward()
     assert gu.compare_packed(g, "out", out.detach().numpy(), 2e-5) < 2e-5
@@ -38,11 +45,11 @@ def test_oracle_geofno_matches_reference_golden(tag):
 
 @pytest.mark.parametrize("tag", TAGS)
 def test_geofno_hip_path_matches_reference_golden(tag, host_device):
-    from fourierflow_amd.modules import FNOMesh2D
+    from fourierflow_amd.modules import FNOMesh2D, FNOMesh3D
     if host_device == "cpu" and tag == "c64":
-        pytest.skip("width-64 golden: GPU only (the wave emulator runs the width-32 golden)")
+        pytest.skip("width-64 golden: GPU only (the wave emulator runs the width-32 goldens)")
     g, kw, sd_np, x, t = _case(tag)
-    blk = FNOMesh2D(**kw)
+    blk = (FNOMesh3D if "modes3" in kw else FNOMesh2D)(**kw)
     sd = {k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}
     assert list(blk.state_dict().keys()) == list(sd.keys())
     assert all(blk.state_dict()[k].dtype == sd[k].dtype and blk.state_dict()[k].shape == sd[k].shape for k in sd)   # complex64
@@ -76,7 +83,7 @@ def test_geofno_structured_mesh_routine_adam_steplr(host_device):
     xb, tb = torch.from_numpy(x).to(host_device), torch.from_numpy(t).to(host_device)
     for step in range(2):
         opt.zero_grad()
-        out = orc.fno_mesh2d(sd, torch.tensor(x), modes1=kw["modes1"], modes2=kw["modes2"], n_layers=kw["n_layers"])
+        out = _oracle(kw, sd, torch.tensor(x))
         lref = orc.lp_rel_loss(out, torch.tensor(t))
         (lref * 20).backward()
         opt.step()

@@ -33,6 +33,11 @@ PRESETS = {
                         routine=dict(optimizer_type="adam", loss_scale=20, scheduler=dict(step_size=100, gamma=0.5))),
     "airfoil_geofno": dict(size=(221, 51), batch=20, cls="FNOMesh2D", model=dict(modes1=32, modes2=16, width=64, n_layers=12),
                            routine=dict(optimizer_type="adam", loss_scale=20, scheduler=dict(step_size=100, gamma=0.5))),
+    # experiments/plasticity/geo-fno/8_layers/config.yaml (FNOMesh3D: 101 x 31 x 20 mesh, modes 12 / 12 / 8, width 32); the file
+    # trains at batch 20, batch 4 keeps the synthetic run short (--batch overrides)
+    "plasticity_geofno": dict(size=(101, 31, 20), batch=4, cls="FNOMesh3D", out_dim=4,
+                              model=dict(modes1=12, modes2=12, modes3=8, width=32, n_layers=8),
+                              routine=dict(optimizer_type="adam", loss_scale=20, scheduler=dict(step_size=100, gamma=0.5))),
     "cube64": dict(size=(64, 64, 64), batch=1,
                    model=dict(modes_x=8, modes_y=8, modes_z=8, width=32, input_dim=4, output_dim=1, n_layers=12,
                               share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
@@ -60,7 +65,7 @@ def main():
     g = torch.Generator().manual_seed(1)
     nd = len(ps["size"])
     batch = dict(x=torch.randn(B, *ps["size"], ps["model"].get("input_dim", 4) - nd, generator=g).to(dev),
-                 y=torch.randn(B, *ps["size"], ps["model"].get("output_dim", 1), generator=g).to(dev))
+                 y=torch.randn(B, *ps["size"], ps.get("out_dim", ps["model"].get("output_dim", 1)), generator=g).to(dev))
     for _ in range(args.warmup):
         exp.training_step(batch)
     torch.cuda.synchronize()
