@@ -113,7 +113,7 @@ def _valid_loss(routine, kind, batch) -> float:
         if kind == "mesh":
             return float(routine.validation_step(batch).item())
         tr = routine.trainer()
-        pred = tr.engine.forward(routine._build_features(batch, add_noise=False), False)
+        pred = routine._unshuffle(tr.engine.forward(routine._shuffle(routine._build_features(batch, add_noise=False)), False))
         target = (batch["dy"] if routine.learn_difference else batch["y"]).contiguous()
         return float(tr.loss_and_grad(pred, target, routine._affine_tensor())[0].item())
 

@@ -34,10 +34,15 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
                  domain=((0.0, 2 * math.pi), (0.0, 2 * math.pi)), grid_size=(64,), **unused):
         super().__init__()
         reject_unsupported_routine_kwargs(unused)
-        for flag, name in ((shuffle_grid, "shuffle_grid"), (use_fourier_position, "use_fourier_position")):
-            if flag:
-                raise NotImplementedError(f"{name}=True is outside the Markov paths built here (one shipped config each)")
+        if use_fourier_position:
+            raise NotImplementedError("use_fourier_position=True is outside the Markov paths built here (one shipped config)")
         self.conv = conv
+        self.shuffle_grid = bool(shuffle_grid)
+        if self.shuffle_grid:       # torus_li/ablation/shuffle_xy_grid: fixed random row / column permutations around the model
+            assert len(grid_size) == 1, 'shuffle_grid only supports one size'         # grid_2d_markov.py:75-80
+            for name, idx in (("x", torch.randperm(grid_size[0])), ("y", torch.randperm(grid_size[0]))):
+                self.register_buffer(f"_{name}_idx", idx, persistent=False)            # plain attributes in the reference:
+                self.register_buffer(f"_{name}_inv", torch.argsort(idx), persistent=False)   # not part of the state_dict
         self.use_position, self.append_force, self.append_mu = bool(use_position), bool(append_force), bool(append_mu)
         self.n_steps, self.low, self.high = n_steps, low, high
         self.should_normalize, self.noise_std, self.learn_difference = should_normalize, noise_std, learn_difference
@@ -160,10 +165,22 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         tr = self.trainer()
         feats = self._build_features(batch, noise)
         targets = (batch['dy'] if self.learn_difference else batch['y']).contiguous()
-        pred = tr.engine.forward(feats, True)
+        pred = self._unshuffle(tr.engine.forward(self._shuffle(feats), True))
         loss, gy = tr.loss_and_grad(pred, targets, self._affine_tensor())
-        tr.apply_gradients(tr.engine.backward(gy))
+        tr.apply_gradients(tr.engine.backward(self._shuffle(gy)))      # adjoint of the inverse gather = the forward gather
         return loss
+
+    def _shuffle(self, t: torch.Tensor) -> torch.Tensor:
+        """x[:, x_idx][:, :, y_idx] (grid_2d_markov.py:177-178)."""
+        if not self.shuffle_grid:
+            return t
+        return t.index_select(1, self._x_idx).index_select(2, self._y_idx).contiguous()
+
+    def _unshuffle(self, t: torch.Tensor) -> torch.Tensor:
+        """im[:, :, y_inv][:, x_inv] (grid_2d_markov.py:182-183)."""
+        if not self.shuffle_grid:
+            return t
+        return t.index_select(2, self._y_inv).index_select(1, self._x_inv).contiguous()
 
     def training_step(self, batch, epoch: int, noise: Optional[torch.Tensor] = None):
         """Epoch 0 only accumulates the normaliser statistics (grid_2d_markov.py:376-378); later epochs train."""
@@ -185,7 +202,7 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         preds, x, prev = [], x0, x0
         for _ in range(n_steps or self.n_steps or 1):
             feats = self._build_features({'x': x, 'f': f, 'mu': mu}, add_noise=False)   # no noise at validation (:292-293)
-            im = tr.engine.forward(feats, False)
+            im = self._unshuffle(tr.engine.forward(self._shuffle(feats), False))      # :297-304
             if self.should_normalize:
                 D = self.conv.input_dim
                 im = im * self._derived[D] + self._derived[0]

@@ -143,7 +143,7 @@ def test_every_shipped_ffno_config_builds():
         pytest.skip("reference experiments are only present in the build container")
     from fourierflow_amd.config import build_routine, load_config
     known = ("FNOZongyi2DBlock", "width > 32", "FNOMesh2D", "FNOMesh3D", "PointCloud", "CNOFactorized", "IPhi",
-             "only torch.optim.AdamW", "only CosineWithWarmupScheduler", "optax", "shuffle_grid", "use_fourier_position",
+             "only torch.optim.AdamW", "only CosineWithWarmupScheduler", "optax", "use_fourier_position",
              "MeshGraphNet", "LearnedInterpolator", "Grid2DRolloutExperiment")
     built, unexpected = 0, []
     for p in paths:

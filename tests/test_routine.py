@@ -251,3 +251,48 @@ def test_markov_routine_with_force_and_viscosity(host_device):
     pred = orc.ffno2d_block(sd, feats, modes=4, n_layers=2)["forecast"]
     ref = orc.lp_rel_loss(st.inverse(pred, 0), y)
     assert abs(loss - ref.item()) < 2e-5
+
+
+def test_markov_routine_with_shuffled_grid(host_device):
+    """torus_li/ablation/shuffle_xy_grid (`shuffle_grid: true`, grid_2d_markov.py:75-80,177-183): fixed random row / column
+    permutations around the model; one train step and a rollout against the oracle with the same permutations."""
+    import oracle_util as ou
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    kw = dict(modes=3, width=32, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    seed, B, G = 81, 2, 8
+    sd_np = gu.make_block_state_dict(kw, seed)
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    torch.manual_seed(3)
+    exp = Grid2DMarkovExperiment(blk, n_steps=2, should_normalize=False, shuffle_grid=True, grid_size=[G],
+                                 scheduler=dict(num_warmup_steps=1, num_training_steps=10)).to(host_device)
+    assert "_x_idx" not in exp.state_dict()                                # plain attributes in the reference
+    xi, yi = exp._x_idx.cpu(), exp._y_idx.cpu()
+    xv, yv = torch.argsort(xi), torch.argsort(yi)
+    assert sorted(xi.tolist()) == list(range(G)) and xi.tolist() != list(range(G))
+    rs = np.random.RandomState(seed)
+    x, y = (rs.standard_normal((B, G, G, 1)).astype(np.float32) for _ in range(2))
+    sd, uniq = ou.torch_state_dict(sd_np)
+
+    def model(feats):                                                      # :177-183
+        im = orc.ffno2d_block(sd, feats[:, xi][:, :, yi], modes=3, n_layers=2)["forecast"]
+        return im[:, :, yv][:, xv]
+
+    ref_loss = orc.lp_rel_loss(model(orc.markov_features(torch.tensor(x), None, None, 0.0)), torch.tensor(y))
+    ref_loss.backward()
+    dev = lambda a: torch.from_numpy(a).to(host_device)  # noqa: E731
+    loss = exp.training_step(dict(x=dev(x), y=dev(y)), epoch=0)
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    eng = exp.trainer().engine
+    for n, p_ in uniq.items():
+        assert rel_l2(eng.grad_view(n).cpu().numpy(), p_.grad.numpy()) < 3e-3, n
+    with torch.no_grad():                                                  # weights moved by one AdamW step: compare rollouts
+        sd2 = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+        xr, ref = torch.tensor(x), []
+        for _ in range(2):
+            f = orc.markov_features(xr, None, None, 0.0)
+            xr = orc.ffno2d_block(sd2, f[:, xi][:, :, yi], modes=3, n_layers=2)["forecast"][:, :, yv][:, xv]
+            ref.append(xr)
+    roll = exp.rollout(dev(x), 2)
+    assert rel_l2(roll.cpu().numpy(), torch.cat(ref, -1).numpy()) < 1e-4
