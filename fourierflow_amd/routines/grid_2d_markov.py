@@ -35,7 +35,9 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         super().__init__()
         reject_unsupported_routine_kwargs(unused)
         if use_fourier_position:
-            raise NotImplementedError("use_fourier_position=True is outside the Markov paths built here (one shipped config)")
+            raise NotImplementedError("use_fourier_position=True is not built: the reference's own Markov routine cannot run it "
+                                      "either (encode_positions reads self.k_max, which its constructor never sets: "
+                                      "grid_2d_markov.py:23-45,116)")
         self.conv = conv
         self.shuffle_grid = bool(shuffle_grid)
         if self.shuffle_grid:       # torus_li/ablation/shuffle_xy_grid: fixed random row / column permutations around the model
