@@ -3,4 +3,5 @@ from .factorized_fno import FNOFactorized2DBlock, FNOFactorizedMesh2D, FNOFactor
 from .feedforward import FeedForward  # noqa: F401
 from .linear import WNLinear  # noqa: F401
 from .normalizer import Normalizer  # noqa: F401
+from .position import fourier_encode  # noqa: F401
 from .zongyi_fno import FNOMesh2D, FNOMesh3D, FNOPlus2DBlock, FNOZongyi2DBlock  # noqa: F401

@@ -296,3 +296,32 @@ def test_markov_routine_with_shuffled_grid(host_device):
             ref.append(xr)
     roll = exp.rollout(dev(x), 2)
     assert rel_l2(roll.cpu().numpy(), torch.cat(ref, -1).numpy()) < 1e-4
+
+
+def test_fourier_encode_and_lploss_mirrors(host_device):
+    """modules.position.fourier_encode (position.py:6-31) against its closed form, and modules.loss.LpLoss (loss.py:4-46,
+    the relative-L2 form the routines use) on the HIP loss kernel, value and gradient."""
+    import math
+    from fourierflow_amd.modules import fourier_encode
+    from fourierflow_amd.modules.loss import LpLoss
+    pos = torch.stack(torch.meshgrid(torch.linspace(-1, 1, 5), torch.linspace(-1, 1, 7), indexing="ij"), dim=-1)
+    enc = fourier_encode(pos, 32, 8, base=2)
+    assert tuple(enc.shape) == (5, 7, 2, 17)
+    scales = 2.0 ** torch.linspace(0, math.log2(16), 8)
+    ref = torch.cat([(pos[..., None] * scales * math.pi).sin(), (pos[..., None] * scales * math.pi).cos(), pos[..., None]], -1)
+    np.testing.assert_allclose(enc.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    g = gu.load_golden("position")                                   # the reference's own outputs
+    np.testing.assert_allclose(fourier_encode(torch.tensor(g["pos"]), 32, 8, base=2).numpy(), g["enc"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(fourier_encode(torch.tensor(g["pos"]), 20, 4, base=3).numpy(), g["enc_b3"], rtol=1e-6, atol=1e-6)
+    rs = np.random.RandomState(4)
+    a = torch.tensor(rs.standard_normal((3, 6, 6, 1)).astype(np.float32), requires_grad=True)
+    b = torch.tensor(rs.standard_normal((3, 6, 6, 1)).astype(np.float32))
+    want = orc.lp_rel_loss(a, b)
+    want.backward()
+    ad = a.detach().to(host_device).requires_grad_(True)
+    got = LpLoss(size_average=True)(ad, b.to(host_device))
+    got.backward()
+    assert abs(got.item() - want.item()) < 1e-6
+    assert rel_l2(ad.grad.cpu().numpy(), a.grad.numpy()) < 1e-5
+    with pytest.raises(NotImplementedError):
+        LpLoss(p=1)
