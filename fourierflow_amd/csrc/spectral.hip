@@ -75,7 +75,8 @@ struct ColVec<2> {
 template <int C, int RT>
 __device__ __forceinline__ void dft_fwd_body(const float* __restrict__ x, float* __restrict__ spec,
                                              const float* __restrict__ tw, int R, int L, int K, const LineMap& lm,
-                                             int scale_ck, int bidx, int nblk) {
+                                             int scale_ck, int bidx, int nblk, int Lv) {
+    // Lv <= L samples of the line exist, the rest of the length-L transform is zero padding (DCT through a length-2L DFT)
     constexpr int CT = C / 32;
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
@@ -84,7 +85,7 @@ __device__ __forceinline__ void dft_fwd_body(const float* __restrict__ x, float*
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int nsteps = (L + 1) >> 1;
+    const int nsteps = (Lv + 1) >> 1;
 
     // work item = (line, 32-row tile of the (mode, re/im) rows): with more than 16 modes a line is shared by RT waves
     const long nitems = (long)R * RT;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void dft_fwd_body(const float* __restrict__ x, float*
             FFNO_UNROLL
             for (int u = 0; u < UN; ++u) {
                 const int n = 2 * (t0 + u) + half;
-                if (n < L) {
+                if (n < Lv) {
                     dst[u].load(xl + (long)n * lm.elem_stride);
                 } else {
                     FFNO_UNROLL
@@ -149,7 +150,15 @@ template <int C, int RT>
 __global__ __launch_bounds__(256) void dft_fwd_kernel(const float* __restrict__ x, float* __restrict__ spec,
                                                       const float* __restrict__ tw, int R, int L, int K,
                                                       LineMap lm, int scale_ck) {
-    dft_fwd_body<C, RT>(x, spec, tw, R, L, K, lm, scale_ck, blockIdx.x, gridDim.x);
+    dft_fwd_body<C, RT>(x, spec, tw, R, L, K, lm, scale_ck, blockIdx.x, gridDim.x, L);
+}
+
+// the same over the first Lv samples of a length-L transform (zero padding beyond)
+template <int C, int RT>
+__global__ __launch_bounds__(256) void dft_fwd_lv_kernel(const float* __restrict__ x, float* __restrict__ spec,
+                                                         const float* __restrict__ tw, int R, int L, int K, LineMap lm,
+                                                         int scale_ck, int Lv) {
+    dft_fwd_body<C, RT>(x, spec, tw, R, L, K, lm, scale_ck, blockIdx.x, gridDim.x, Lv);
 }
 
 // one branch of a paired stage launch
@@ -167,9 +176,9 @@ struct StageArgs {
 template <int C, int RT>
 __global__ __launch_bounds__(256) void dft_fwd_pair_kernel(StageArgs a, StageArgs b, int n0, int scale_ck) {
     if ((int)blockIdx.x < n0)
-        dft_fwd_body<C, RT>(a.in, a.out, a.tw, a.R, a.L, a.K, a.lm, scale_ck, blockIdx.x, n0);
+        dft_fwd_body<C, RT>(a.in, a.out, a.tw, a.R, a.L, a.K, a.lm, scale_ck, blockIdx.x, n0, a.L);
     else
-        dft_fwd_body<C, RT>(b.in, b.out, b.tw, b.R, b.L, b.K, b.lm, scale_ck, blockIdx.x - n0, gridDim.x - n0);
+        dft_fwd_body<C, RT>(b.in, b.out, b.tw, b.R, b.L, b.K, b.lm, scale_ck, blockIdx.x - n0, gridDim.x - n0, b.L);
 }
 
 // ---- stage C ------------------------------------------------------------------------------------
@@ -177,7 +186,8 @@ __global__ __launch_bounds__(256) void dft_fwd_pair_kernel(StageArgs a, StageArg
 template <int C>
 __device__ __forceinline__ void dft_inv_body(const float* __restrict__ spec, float* out, const float* resid,
                                              const float* __restrict__ tw, int R, int L, int K, const LineMap& lm,
-                                             int apply_ck, int accumulate, int bidx, int nblk) {
+                                             int apply_ck, int accumulate, int bidx, int nblk, int Lv) {
+    // only the first Lv <= L samples of the length-L inverse are produced (DCT through a length-2L DFT)
     constexpr int CT = C / 32;
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
@@ -188,7 +198,7 @@ __device__ __forceinline__ void dft_inv_body(const float* __restrict__ spec, flo
     const int j = lane & 31, half = lane >> 5;
     const float sgn = half ? -1.f : 1.f;
     const int tbase = half ? L : 0;
-    const int RTtot = (L + 31) >> 5;
+    const int RTtot = (Lv + 31) >> 5;
 
     // work item = (line, pair of 32-row output tiles): long lines (L = 256: four pairs) spread over four waves
     const int NP = (RTtot + 1) >> 1;
@@ -247,7 +257,7 @@ __device__ __forceinline__ void dft_inv_body(const float* __restrict__ spec, flo
                 FFNO_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int n = 32 * (rt0 + q) + drow(r, half);
-                    if (n < L) {
+                    if (n < Lv) {
                         const long a = lbase + (long)n * lm.elem_stride;
                         ColVec<CT> o;
                         FFNO_UNROLL
@@ -277,16 +287,23 @@ __global__ __launch_bounds__(256) void dft_inv_kernel(const float* __restrict__ 
                                                       const float* resid, const float* __restrict__ tw,
                                                       int R, int L, int K, LineMap lm, int apply_ck,
                                                       int accumulate) {
-    dft_inv_body<C>(spec, out, resid, tw, R, L, K, lm, apply_ck, accumulate, blockIdx.x, gridDim.x);
+    dft_inv_body<C>(spec, out, resid, tw, R, L, K, lm, apply_ck, accumulate, blockIdx.x, gridDim.x, L);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void dft_inv_lv_kernel(const float* __restrict__ spec, float* out, const float* resid,
+                                                         const float* __restrict__ tw, int R, int L, int K, LineMap lm,
+                                                         int apply_ck, int accumulate, int Lv) {
+    dft_inv_body<C>(spec, out, resid, tw, R, L, K, lm, apply_ck, accumulate, blockIdx.x, gridDim.x, Lv);
 }
 
 template <int C>
 __global__ __launch_bounds__(256) void dft_inv_pair_kernel(StageArgs a, StageArgs b, int n0, int apply_ck) {
     if ((int)blockIdx.x < n0)
-        dft_inv_body<C>(a.in, a.out, a.resid, a.tw, a.R, a.L, a.K, a.lm, apply_ck, a.accumulate, blockIdx.x, n0);
+        dft_inv_body<C>(a.in, a.out, a.resid, a.tw, a.R, a.L, a.K, a.lm, apply_ck, a.accumulate, blockIdx.x, n0, a.L);
     else
         dft_inv_body<C>(b.in, b.out, b.resid, b.tw, b.R, b.L, b.K, b.lm, apply_ck, b.accumulate, blockIdx.x - n0,
-                        gridDim.x - n0);
+                        gridDim.x - n0, b.L);
 }
 
 // ---- Fourier weight repack ------------------------------------------------------------------------
@@ -887,6 +904,67 @@ __global__ __launch_bounds__(256) void cdft_combine_inv_kernel(const float* __re
     }
 }
 
+// ---- DCT-II (norm = 'ortho') along one axis through the truncated real-DFT kernels -------------------------------------
+// (the transform of the CNOFactorized* operators, reference factorized_cno/grid_2d.py:58,69 with modules/dct.py)
+//     X[k] = s_k sum_n x[n] cos(pi (2n+1) k / 2L) = a_k Re( e^{-i phi_k} F[k] ),   phi_k = pi k / 2L,
+//     F = truncated DFT of length 2L over the L samples (dft_fwd with Lv = L and the length-2L twiddle table, 1/sqrt(2L)
+//     folded in), a_0 = sqrt 2, a_k = 2; the DCT coefficients are kept as complex numbers with zero imaginary part so that
+//     the per-mode mix and the weight-gradient contraction are the complex kernels with Wi = 0.
+//     inverse (zero-padded, = transpose: the transform is orthonormal):  x[n] = sum_k s_k Y[k] cos(pi (2n+1) k / 2L)
+//     = dft_inv(length 2L, c_k applied, first L samples) of  H[k] = b_k Y[k] e^{+i phi_k},  b_0 = sqrt 2, b_k = 1.
+__global__ __launch_bounds__(256) void dct_rotate_kernel(float* __restrict__ spec, long RC, int K, int C, int L, int inverse) {
+    const long total = (long)K * RC;            // RC = R * C elements per mode and part
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int k = (int)(e / RC);
+        const long rc = e % RC;
+        const long a = ((long)k * (RC / C) + rc / C) * 2 * C + rc % C;     // [k][r][re/im][c]
+        float sn, cs;
+#ifdef FFNO_EMU
+        sn = (float)sin(3.14159265358979323846 * k / (2.0 * L)), cs = (float)cos(3.14159265358979323846 * k / (2.0 * L));
+#else
+        sincospif((float)k / (float)(2 * L), &sn, &cs);
+#endif
+        const float re = spec[a], im = spec[a + C];
+        if (!inverse) {
+            const float ak = k == 0 ? 1.41421356237309505f : 2.f;
+            spec[a] = ak * (re * cs + im * sn);
+            spec[a + C] = 0.f;
+        } else {
+            const float bk = k == 0 ? 1.41421356237309505f : 1.f;
+            spec[a] = bk * re * cs;
+            spec[a + C] = bk * re * sn;
+        }
+    }
+}
+
+// real per-mode weights [I][O][K] (factorized_cno/grid_2d.py:26-29)  <->  complex planes with a zero imaginary plane
+__global__ void fw_pack_real_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ wpt, int C, int K) {
+    const long total = (long)C * C * K * 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const int k = e / ((long)C * C * 2);
+        const float v = ri ? 0.f : w[((long)i * C + o) * K + k];
+        wp[e] = v;
+        wpt[(((long)k * 2 + ri) * C + o) * C + i] = v;
+    }
+}
+
+__global__ void fw_grad_reduce_real_kernel(const float* __restrict__ partial, float* __restrict__ gw, int C, int K, int nsplit,
+                                           int accumulate) {
+    const long total = (long)C * C * K;
+    const long stride = (long)2 * K * C * C;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int k = e % K;
+        const int o = (e / K) % C;
+        const int i = e / ((long)K * C);
+        float sum = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) sum += partial[sp * stride + (((long)k * 2 + 0) * C + i) * C + o];
+        gw[e] = accumulate ? gw[e] + sum : sum;
+    }
+}
+
 static inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -1207,6 +1285,84 @@ extern "C" int ffno_cdft_rows_mfma(const float* in, float* out, float* ws, const
         if (rc) return rc;
     }
     return FFNO_OK;
+}
+
+// One DCT branch  out (+)= [resid +] iDCT(mix(DCT(in)))  along one axis (CNOFactorized*: factorized_cno/grid_2d.py:51-96):
+// dft_fwd over the L samples of a length-2L transform -> phase rotation -> per-mode mix (real weights as complex planes with
+// Wi = 0; planes = NULL skips it) -> rotation -> dft_inv restricted to the first L samples.  tw2 = twiddle table of length 2L;
+// spec (kept for the weight gradient: the real DCT coefficients, imaginary parts 0) and mix are K*R*2*C floats each.
+extern "C" int ffno_dct_branch(const float* in, float* out, const float* resid, float* spec, float* mix, const float* planes,
+                               const float* tw2, int B, int M, int N, int C, int K, int axis, int conj_transpose,
+                               int accumulate, void* stream) {
+    if (!in || !out || !spec || !mix || !tw2 || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1))
+        return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    const int L = axis == 0 ? N : M;
+    const int R = axis == 0 ? B * M : B * N;
+    if (K > L) return FFNO_EMODES;
+    const int RT = (2 * K + 31) / 32;
+    if (RT > 4) return FFNO_EUNSUPPORTED;
+    const LineMap lm = make_linemap(axis, B, M, N, C);
+    const size_t smem = sizeof(float) * 4 * L;            // twiddle table of the length-2L transform
+    hipStream_t s = (hipStream_t)stream;
+    {
+        const dim3 grid((unsigned)min(((long)R * RT + 3) / 4, 8192L)), block(256);
+#define FFNO_DCT_FWD_CASE(CC, RR) \
+    if (C == CC && RT == RR) FFNO_LAUNCH((dft_fwd_lv_kernel<CC, RR>), grid, block, smem, s, in, spec, tw2, R, 2 * L, K, lm, 0, L);
+        FFNO_DCT_FWD_CASE(64, 1)
+        FFNO_DCT_FWD_CASE(64, 2)
+        FFNO_DCT_FWD_CASE(64, 3)
+        FFNO_DCT_FWD_CASE(64, 4)
+        FFNO_DCT_FWD_CASE(32, 1)
+        FFNO_DCT_FWD_CASE(32, 2)
+        FFNO_DCT_FWD_CASE(32, 3)
+        FFNO_DCT_FWD_CASE(32, 4)
+#undef FFNO_DCT_FWD_CASE
+        int rc = launch_status();
+        if (rc) return rc;
+    }
+    const long RC = (long)R * C;
+    const dim3 rgrid((unsigned)min(((long)K * RC + 255) / 256, 4096L));
+    FFNO_LAUNCH(dct_rotate_kernel, rgrid, dim3(256), 0, s, spec, RC, K, C, L, 0);
+    int rc = launch_status();
+    if (rc) return rc;
+    float* y = spec;
+    if (planes) {
+        rc = ffno_mode_mix(spec, planes, mix, R, C, K, conj_transpose, stream);
+        if (rc) return rc;
+        y = mix;
+    } else {       // keep `spec` intact for the caller: rotate a copy
+        if (hipMemcpyAsync(mix, spec, sizeof(float) * (size_t)K * R * 2 * C, hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return launch_status();
+        y = mix;
+    }
+    FFNO_LAUNCH(dct_rotate_kernel, rgrid, dim3(256), 0, s, y, RC, K, C, L, 1);
+    rc = launch_status();
+    if (rc) return rc;
+    const long items = (long)R * ((((L + 31) >> 5) + 1) >> 1);
+    const dim3 grid((unsigned)min((items + 3) / 4, 8192L)), block(256);
+    if (C == 64)
+        FFNO_LAUNCH((dft_inv_lv_kernel<64>), grid, block, smem, s, y, out, resid, tw2, R, 2 * L, K, lm, 1, accumulate, L);
+    else
+        FFNO_LAUNCH((dft_inv_lv_kernel<32>), grid, block, smem, s, y, out, resid, tw2, R, 2 * L, K, lm, 1, accumulate, L);
+    return launch_status();
+}
+
+extern "C" int ffno_fw_pack_real(const float* w, float* wp, float* wpt, int C, int K, void* stream) {
+    if (!w || !wp || !wpt || C <= 0 || K <= 0) return FFNO_EINVAL;
+    const long total = (long)C * C * K * 2;
+    FFNO_LAUNCH(fw_pack_real_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, (hipStream_t)stream, w, wp,
+                wpt, C, K);
+    return launch_status();
+}
+
+extern "C" int ffno_fw_grad_reduce_real(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
+                                        void* stream) {
+    if (!partial || !gw || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    const long total = (long)C * C * K;
+    FFNO_LAUNCH(fw_grad_reduce_real_kernel, dim3((unsigned)min((total + 255) / 256, 4096L)), dim3(256), 0, (hipStream_t)stream,
+                partial, gw, C, K, nsplit, accumulate);
+    return launch_status();
 }
 
 // ---- operator level -----------------------------------------------------------------------------

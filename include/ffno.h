@@ -347,6 +347,23 @@ int ffno_fw3d_grad_reduce(const float* partial, float* g1, float* g2, float* g3,
                           int K2, int K3, int nsplit, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * CNOFactorized* operators (factorized_cno/grid_2d.py:51-96 with modules/dct.py): the F-FNO layer with an
+ * orthonormal DCT-II per axis and REAL per-mode weights [I][O][K].  One branch
+ *     out (+)= [resid +] iDCT_zero-padded( W (.) DCT(in)[:K] )          (conj_transpose: W^T, the adjoint branch)
+ * runs on the truncated real-DFT kernels: X[k] = a_k Re(e^{-i pi k/2L} F_2L[k]) over the L samples of a length-2L
+ * transform, and the transpose for the inverse (the DCT is orthonormal, so forward and adjoint branches use the same two
+ * transforms).  tw2 = twiddle table of length 2L.  spec keeps the DCT coefficients (complex layout, imaginary parts 0)
+ * for ffno_fw_grad_partial; mix is scratch of the same size (K*R*2*C floats).  planes from ffno_fw_pack_real
+ * (complex planes with a zero imaginary plane); NULL = no weights.  K <= min(L, 64).
+ * --------------------------------------------------------------------------------------------- */
+int ffno_dct_branch(const float* in, float* out, const float* resid, float* spec, float* mix,
+                    const float* planes, const float* tw2, int B, int M, int N, int C, int K, int axis,
+                    int conj_transpose, int accumulate, void* stream);
+int ffno_fw_pack_real(const float* w, float* wp, float* wpt, int C, int K, void* stream);
+int ffno_fw_grad_reduce_real(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Velocity features of the Markov routine (routines/grid_2d_markov.py:130-144, `use_velocity: true`,
  * wavenumber buffers :82-94): vorticity[B][X][Y] -> out[B][X][Y][3] = (vorticity, u, v) with
  *   psi^ = -rfftn(w)/lap,  u = irfftn(2 pi i ky psi^),  v = irfftn(-2 pi i kx psi^)
