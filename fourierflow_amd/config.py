@@ -22,6 +22,9 @@ TARGET_MAP = {
     "fourierflow.modules.FNOFactorizedMesh3D": "fourierflow_amd.modules.FNOFactorizedMesh3D",
     "fourierflow.modules.FNOFactorizedMesh2D": "fourierflow_amd.modules.FNOFactorizedMesh2D",
     "fourierflow.modules.FNOPlus2DBlock": "fourierflow_amd.modules.FNOPlus2DBlock",
+    "fourierflow.modules.CNOFactorized2DBlock": "fourierflow_amd.modules.CNOFactorized2DBlock",
+    "fourierflow.modules.CNOFactorizedMesh2D": "fourierflow_amd.modules.CNOFactorizedMesh2D",
+    "fourierflow.modules.CNOFactorizedMesh3D": "fourierflow_amd.modules.CNOFactorizedMesh3D",
     "fourierflow.modules.FNOZongyi2DBlock": "fourierflow_amd.modules.FNOZongyi2DBlock",
     "fourierflow.modules.FNOMesh2D": "fourierflow_amd.modules.FNOMesh2D",
     "fourierflow.modules.FNOMesh3D": "fourierflow_amd.modules.FNOMesh3D",

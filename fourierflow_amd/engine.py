@@ -84,11 +84,15 @@ class FFNOEngine:
             raise ValueError("input_dim must be in 1..63")
         if not (1 <= output_dim <= 8):
             raise ValueError("output_dim must be in 1..8")
-        if spectral not in ("factorized", "plus"):
-            raise ValueError("spectral must be 'factorized' or 'plus'")
+        if spectral not in ("factorized", "plus", "dct"):
+            raise ValueError("spectral must be 'factorized', 'plus' or 'dct'")
+        if spectral == "dct" and mode != "full":
+            raise ValueError("the DCT operators (CNOFactorized*) have no `mode` switch")
         if spectral == "plus" and (spatial_dims != 2 or padding or mode == "low-pass"):
             raise ValueError("the non-factorized (FNOPlus2DBlock) spectral conv is 2-D, unpadded, mode 'full' or 'no-fourier'")
-        self.spectral = spectral      # "plus": rfft2 + two K x K corner blocks (zongyi_fno/grid_plus_2d.py:52-83)
+        # "plus": rfft2 + two K x K corner blocks (zongyi_fno/grid_plus_2d.py:52-83);  "dct": orthonormal DCT-II per axis with
+        # real per-mode weights [C, C, K] (CNOFactorized*, factorized_cno/grid_2d.py:51-96)
+        self.spectral = spectral
         self.nd = spatial_dims
         # 2-D weight order: grid_2d.py has fourier_weight[0] on the LAST axis; mesh_2d.py has [0] on the FIRST (x) axis
         self.first_axis_first = bool(first_axis_first)
@@ -142,7 +146,7 @@ class FFNOEngine:
                 self.fw_names.append(names)
                 for w, n in enumerate(names):
                     self.param_shapes.setdefault(n, (C, C, self.Ks[w], self.Ks[w], 2) if spectral == "plus"
-                                                 else (C, C, self.Ks[w], 2))
+                                                 else (C, C, self.Ks[w]) if spectral == "dct" else (C, C, self.Ks[w], 2))
         add_linear("out.0.", HEAD_DIM, C)
         add_linear("out.1.", output_dim, HEAD_DIM)
         self.param_names = list(self.param_shapes)
@@ -180,7 +184,7 @@ class FFNOEngine:
 
     def _conc(self) -> bool:
         return bool(self.concurrent_branches and self._ffx() and not self.use_fork and not self.overlap
-                    and self.mode != "no-fourier" and self.spectral != "plus")
+                    and self.mode != "no-fourier" and self.spectral == "factorized")
 
     @staticmethod
     def _schedule(fused, views):
@@ -469,9 +473,10 @@ class FFNOEngine:
             self._k("fw2d_pack", lib.ffno_fw2d_pack, _p(self.params[names[0]]), _p(self.params[names[1]]),
                     _p(self.planes[i][0][0]), _p(self.planes[i][0][1]), self.C, self.K, st)
         for i, names in enumerate(self._fw_sets if self.spectral != "plus" else []):
+            pack = lib.ffno_fw_pack_real if self.spectral == "dct" else lib.ffno_fw_pack
             for w, n in enumerate(names):
-                self._k("fw_pack", lib.ffno_fw_pack, _p(self.params[n]), _p(self.planes[i][w][0]), _p(self.planes[i][w][1]),
-                        self.C, self.Ks[w], st)
+                self._k("fw_pack", pack, _p(self.params[n]), _p(self.planes[i][w][0]), _p(self.planes[i][w][1]), self.C,
+                        self.Ks[w], st)
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         self._k("head_fold", lib.ffno_head_fold, _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                 _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, self.O, st)
@@ -531,6 +536,8 @@ class FFNOEngine:
         lib = _lib.get_lib()
         if self.spectral == "plus":
             return [False]
+        if self.spectral == "dct":
+            return [False] * len(views)
         return [bool(self.use_fused and self.mode != "no-fourier" and lib.ffno_spectral_fused_supported(self.C, v.K, v.L))
                 for v in views]
 
@@ -553,6 +560,11 @@ class FFNOEngine:
                     st)
             self._k("dft_inv", lib.ffno_dft_inv, _p(ws.SYb), _p(dst), resid, _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, 0, ck_i,
                     accumulate, st)
+            return
+        if self.spectral == "dct":       # DCT branch: the same transform pair serves the forward and the adjoint (orthonormal)
+            spec = save if save is not None else ws.SD
+            self._k("dct_branch" + ("" if fwd else "(adj)"), lib.ffno_dct_branch, _p(src), _p(dst), resid, _p(spec), _p(ws.SY),
+                    _p(planes), _p(self._twiddle(2 * v.L)), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, conj, accumulate, st)
             return
         if fused:
             self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
@@ -805,7 +817,8 @@ class FFNOEngine:
                 # dW = sum over the lines of every layer that uses this weight: ONE launch per axis
                 self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SXall[w][l0_]), _p(ws.SDall[w][l0_]),
                         _p(ws.fwpart[si][w]), v.R, C, v.K, ws.nsplit_fw[w], 0, nl, v.spec, v.spec, st)
-                self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce, _p(ws.fwpart[si][w]), _p(gv(n)), C, v.K, ws.nsplit_fw[w], 0, st)
+                reduce = lib.ffno_fw_grad_reduce_real if self.spectral == "dct" else lib.ffno_fw_grad_reduce
+                self._k("fw_grad_reduce", reduce, _p(ws.fwpart[si][w]), _p(gv(n)), C, v.K, ws.nsplit_fw[w], 0, st)
         if self._desc_dev is not None:
             self._k("weightnorm_bwd", lib.ffno_weightnorm_bwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
         return self.gflat

@@ -299,3 +299,16 @@ def make_geofno_io(seed: int, B: int, X: int, Y: int, Z: int = 0):
     if Z:       # FNOMesh3D: one input channel, four output channels
         return rs.standard_normal((B, X, Y, Z, 1)).astype(np.float32), rs.standard_normal((B, X, Y, Z, 4)).astype(np.float32)
     return rs.standard_normal((B, X, Y, 2)).astype(np.float32), rs.standard_normal((B, X, Y, 1)).astype(np.float32)
+
+
+def make_cno_case(kind: str, kw: dict, seed: int, B: int, S):
+    """State dict + (x, target) of a CNOFactorized* golden: the F-FNO generators with the trailing (re, im) axis of every
+    Fourier weight dropped (real [in, out, modes] weights, factorized_cno/grid_2d.py:26-29) and scaled to a visible size."""
+    if kind == "2d":
+        sd, (x, t) = make_block_state_dict(kw, seed), make_block_io(kw, seed, B, *S)
+    elif kind == "mesh2d":
+        sd, (x, t) = make_mesh2d_state_dict(kw, seed), make_mesh2d_io(kw, seed, B, S)
+    else:
+        sd, (x, t) = make_mesh3d_state_dict(kw, seed), make_mesh3d_io(kw, seed, B, S)
+    sd = {k: (np.ascontiguousarray(v[..., 0]) * 3 if "fourier_weight" in k else v) for k, v in sd.items()}
+    return sd, x, t

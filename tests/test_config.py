@@ -101,6 +101,7 @@ REFERENCE_CONFIGS = [
     ("torus_li/zongyi/4_layers", "Grid2DRolloutExperiment", "conv", "FNOZongyi2DBlock"),       # BASELINE config 0
     ("pipe/geo-fno/8_layers", "StructuredMeshExperiment", "model", "FNOMesh2D"),               # geo-FNO baseline, Adam + StepLR
     ("plasticity/geo-fno/4_layers", "StructuredMeshExperiment", "model", "FNOMesh3D"),
+    ("plasticity/fcno/12_layers", "StructuredMeshExperiment", "model", "CNOFactorizedMesh3D"),   # DCT operators
 ]
 
 
@@ -161,4 +162,4 @@ def test_every_shipped_ffno_config_builds():
         except Exception as e:  # noqa: BLE001 - anything else is a loader bug
             unexpected.append((os.path.relpath(p, root), repr(e)))
     assert not unexpected, unexpected[:5]
-    assert built >= 200, built
+    assert built >= 218, built
