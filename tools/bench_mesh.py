@@ -38,6 +38,10 @@ PRESETS = {
     "plasticity_geofno": dict(size=(101, 31, 20), batch=4, cls="FNOMesh3D", out_dim=4,
                               model=dict(modes1=12, modes2=12, modes3=8, width=32, n_layers=8),
                               routine=dict(optimizer_type="adam", loss_scale=20, scheduler=dict(step_size=100, gamma=0.5))),
+    # experiments/plasticity/fcno/12_layers/config.yaml: the DCT operator CNOFactorizedMesh3D on the plasticity mesh
+    "plasticity_fcno": dict(size=(101, 31, 20), batch=2, cls="CNOFactorizedMesh3D",
+                            model=dict(modes_x=32, modes_y=12, modes_z=8, width=64, input_dim=4, output_dim=4, n_layers=12,
+                                       share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
     "cube64": dict(size=(64, 64, 64), batch=1,
                    model=dict(modes_x=8, modes_y=8, modes_z=8, width=32, input_dim=4, output_dim=1, n_layers=12,
                               share_weight=False, factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)),
