@@ -913,26 +913,31 @@ __global__ __launch_bounds__(256) void cdft_combine_inv_kernel(const float* __re
 //     inverse (zero-padded, = transpose: the transform is orthonormal):  x[n] = sum_k s_k Y[k] cos(pi (2n+1) k / 2L)
 //     = dft_inv(length 2L, c_k applied, first L samples) of  H[k] = b_k Y[k] e^{+i phi_k},  b_0 = sqrt 2, b_k = 1.
 __global__ __launch_bounds__(256) void dct_rotate_kernel(float* __restrict__ spec, long RC, int K, int C, int L, int inverse) {
-    const long total = (long)K * RC;            // RC = R * C elements per mode and part
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int k = (int)(e / RC);
-        const long rc = e % RC;
-        const long a = ((long)k * (RC / C) + rc / C) * 2 * C + rc % C;     // [k][r][re/im][c]
-        float sn, cs;
+    // grid.y = mode k: one sincos per thread; four channels of the re and of the im part per step (C % 4 == 0)
+    const int k = blockIdx.y;
+    float sn, cs;
 #ifdef FFNO_EMU
-        sn = (float)sin(3.14159265358979323846 * k / (2.0 * L)), cs = (float)cos(3.14159265358979323846 * k / (2.0 * L));
+    sn = (float)sin(3.14159265358979323846 * k / (2.0 * L)), cs = (float)cos(3.14159265358979323846 * k / (2.0 * L));
 #else
-        sincospif((float)k / (float)(2 * L), &sn, &cs);
+    sincospif((float)k / (float)(2 * L), &sn, &cs);
 #endif
-        const float re = spec[a], im = spec[a + C];
+    const int C4 = C / 4;
+    const long n4 = RC / 4;                          // float4 groups per mode and part
+    float* base = spec + (long)k * RC * 2;           // [r][re/im][c]
+    const float ak = k == 0 ? 1.41421356237309505f : 2.f, bk = k == 0 ? 1.41421356237309505f : 1.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const long r = e / C4;
+        const int c4 = (int)(e - r * C4) * 4;
+        float4* pr = reinterpret_cast<float4*>(base + r * 2 * C + c4);
+        float4* pi = reinterpret_cast<float4*>(base + r * 2 * C + C + c4);
+        const float4 re = *pr, im = *pi;
         if (!inverse) {
-            const float ak = k == 0 ? 1.41421356237309505f : 2.f;
-            spec[a] = ak * (re * cs + im * sn);
-            spec[a + C] = 0.f;
+            *pr = make_float4(ak * (re.x * cs + im.x * sn), ak * (re.y * cs + im.y * sn), ak * (re.z * cs + im.z * sn),
+                              ak * (re.w * cs + im.w * sn));
+            *pi = make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
-            const float bk = k == 0 ? 1.41421356237309505f : 1.f;
-            spec[a] = bk * re * cs;
-            spec[a + C] = bk * re * sn;
+            *pr = make_float4(bk * re.x * cs, bk * re.y * cs, bk * re.z * cs, bk * re.w * cs);
+            *pi = make_float4(bk * re.x * sn, bk * re.y * sn, bk * re.z * sn, bk * re.w * sn);
         }
     }
 }
@@ -1322,7 +1327,7 @@ extern "C" int ffno_dct_branch(const float* in, float* out, const float* resid, 
         if (rc) return rc;
     }
     const long RC = (long)R * C;
-    const dim3 rgrid((unsigned)min(((long)K * RC + 255) / 256, 4096L));
+    const dim3 rgrid((unsigned)max(1L, min((RC / 4 + 255) / 256, 4096L / K)), K);
     FFNO_LAUNCH(dct_rotate_kernel, rgrid, dim3(256), 0, s, spec, RC, K, C, L, 0);
     int rc = launch_status();
     if (rc) return rc;
