@@ -107,6 +107,7 @@ SIGNATURES = {
     "ffno_fw3d_grad_reduce": (I, [P, P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_dct_branch": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_fw_pack_real": (I, [P, P, P, I, I, P]),
+    "ffno_mode_mix_real": (I, [P, P, P, I, I, I, P]),
     "ffno_fw_grad_reduce_real": (I, [P, P, I, I, I, I, P]),
     "ffno_cdft_rows_ws_floats": (SZ, [I, I, I, I]),
     "ffno_cdft_rows_mfma": (I, [P, P, P, P, I, I, I, I, I, I, P]),

@@ -331,10 +331,13 @@ __global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
 // B operand: the mode's two weight planes in LDS (32 KiB at C=64), lanes read consecutive floats
 // (conflict-free).  Splitting a tile's two output parts over two waves doubles the number of waves a
 // launch can spread over the chip (256x256 grids: 16 tiles per mode).
-template <int C>
+template <int C, bool REAL = false>
 __device__ __forceinline__ void mode_mix_body(const float* __restrict__ spec_in, const float* __restrict__ planes,
                                               float* __restrict__ spec_out, int R, int conj_t, int k) {
+    // REAL (DCT operators: real spectra, real weights): only the real output part exists -- one item per 32-line tile, the
+    // imaginary weight plane is not staged and the imaginary output part is left untouched (its consumer ignores it)
     constexpr int CT = C / 32;
+    constexpr int PARTS = REAL ? 1 : 2;
     __shared__ __attribute__((aligned(16))) float smem_mix[2 * C * C];
     float* Wr = smem_mix;
     float* Wi = Wr + C * C;
@@ -343,13 +346,13 @@ __device__ __forceinline__ void mode_mix_body(const float* __restrict__ spec_in,
     const int j = lane & 31, half = lane >> 5;
     const float* xin = spec_in + (long)k * R * 2 * C;
     float* yout = spec_out + (long)k * R * 2 * C;
-    const int nitems = 2 * ((R + 31) >> 5);
+    const int nitems = PARTS * ((R + 31) >> 5);
     int item = blockIdx.x * 4 + wave;
 
     // first item's A fragment is requested before the weight planes are staged (latencies overlap)
     float a[C];
     auto load_a = [&](int it) {
-        const int row = (it >> 1) * 32 + j;
+        const int row = (it / PARTS) * 32 + j;
         FFNO_UNROLL
         for (int u = 0; u < C / 4; ++u) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -363,16 +366,19 @@ __device__ __forceinline__ void mode_mix_body(const float* __restrict__ spec_in,
     load_a(item);
     {
         const float* pk = planes + (long)k * 2 * C * C;
-        for (int i = threadIdx.x * 4; i < 2 * C * C; i += blockDim.x * 4)
+        for (int i = threadIdx.x * 4; i < PARTS * C * C; i += blockDim.x * 4)
             *reinterpret_cast<float4*>(Wr + i) = *reinterpret_cast<const float4*>(pk + i);
     }
     __syncthreads();
 
     for (; item < nitems; item += gridDim.x * 4) {
-        const int row0 = (item >> 1) * 32, q = item & 1;
+        const int row0 = (item / PARTS) * 32, q = REAL ? 0 : (item & 1);
         // per-lane plane selection / sign of the real block form (see ffno_mode_mix in include/ffno.h)
-        const float* plane = (half == q) ? Wr : Wi;
-        const float sign = conj_t == 0 ? ((half == 1 && q == 0) ? -1.f : 1.f) : ((half == 0 && q == 1) ? -1.f : 1.f);
+        // REAL: the lanes of the imaginary input part multiply exact zeros; they read the (finite) real plane too, the
+        // imaginary plane is not in LDS
+        const float* plane = (REAL || half == q) ? Wr : Wi;
+        const float sign = REAL ? 1.f
+                                : (conj_t == 0 ? ((half == 1 && q == 0) ? -1.f : 1.f) : ((half == 0 && q == 1) ? -1.f : 1.f));
         f32x16 acc[CT];
         FFNO_UNROLL
         for (int ct = 0; ct < CT; ++ct) acc[ct] = zero16();
@@ -405,6 +411,13 @@ __global__ __launch_bounds__(256, 2) void mode_mix_kernel(const float* __restric
                                                        float* __restrict__ spec_out, int R, int K,
                                                        int conj_t) {
     mode_mix_body<C>(spec_in, planes, spec_out, R, conj_t, blockIdx.y);
+}
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void mode_mix_real_kernel(const float* __restrict__ spec_in,
+                                                            const float* __restrict__ planes,
+                                                            float* __restrict__ spec_out, int R, int K) {
+    mode_mix_body<C, true>(spec_in, planes, spec_out, R, 0, blockIdx.y);
 }
 
 // grid.y = Ka + Kb modes: the first Ka rows of workgroups mix branch a, the rest branch b
@@ -1055,6 +1068,22 @@ extern "C" int ffno_mode_mix(const float* spec_in, const float* planes, float* s
     return launch_status();
 }
 
+// real spectra x real weights (DCT operators): Y[k][r][re][o] = sum_i X[k][r][re][i] * planes[k][re][i][o]; the imaginary part of
+// spec_out is NOT written.  Pass the transposed planes for the adjoint.
+extern "C" int ffno_mode_mix_real(const float* spec_in, const float* planes, float* spec_out, int R, int C, int K, void* stream) {
+    if (!spec_in || !planes || !spec_out || R <= 0 || K <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    const int nitems = (R + 31) / 32;
+    const int chunks = max(1, min((nitems + 3) / 4, max(1, 512 / K)));
+    const dim3 grid(chunks, K), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        FFNO_LAUNCH((mode_mix_real_kernel<64>), grid, block, 0, s, spec_in, planes, spec_out, R, K);
+    else
+        FFNO_LAUNCH((mode_mix_real_kernel<32>), grid, block, 0, s, spec_in, planes, spec_out, R, K);
+    return launch_status();
+}
+
 extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* partial, int R, int C,
                                     int K, int nsplit, int beta, int nlayers, size_t layer_stride_x,
                                     size_t layer_stride_dy, void* stream) {
@@ -1333,7 +1362,7 @@ extern "C" int ffno_dct_branch(const float* in, float* out, const float* resid, 
     if (rc) return rc;
     float* y = spec;
     if (planes) {
-        rc = ffno_mode_mix(spec, planes, mix, R, C, K, conj_transpose, stream);
+        rc = ffno_mode_mix_real(spec, planes, mix, R, C, K, stream);     // conj_transpose only selects the planes (caller)
         if (rc) return rc;
         y = mix;
     } else {       // keep `spec` intact for the caller: rotate a copy

@@ -360,6 +360,9 @@ int ffno_dct_branch(const float* in, float* out, const float* resid, float* spec
                     const float* planes, const float* tw2, int B, int M, int N, int C, int K, int axis,
                     int conj_transpose, int accumulate, void* stream);
 int ffno_fw_pack_real(const float* w, float* wp, float* wpt, int C, int K, void* stream);
+/* per-mode mix of REAL spectra with real weights (the planes' real parts): only the real part of spec_out is written */
+int ffno_mode_mix_real(const float* spec_in, const float* planes, float* spec_out, int R, int C, int K,
+                       void* stream);
 int ffno_fw_grad_reduce_real(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
                              void* stream);
 
