@@ -32,18 +32,30 @@ static constexpr int kPlinMaxJ = 5;     // (output group, input column) items pe
 
 // out[p][o] = act(b[o] + sum_i W[o][i] x[p][i] + add[p][o])  for o < Cout,  0 for Cout <= o < ldo;
 // optional second output out2 = out + res (the block-level residual x + layer(x), which must not disturb the ReLU mask)
+// VEC (ldo % 4 == 0): a thread owns four consecutive outputs of a point -- one LDS read of x[p][i] and one 16-byte read of
+// the transposed weights per four FMAs (the scalar form spends two LDS reads per FMA and is LDS-bound).
+template <bool VEC>
 __global__ __launch_bounds__(256) void plin_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ W,
                                                        const float* __restrict__ b, const float* __restrict__ add,
                                                        float* __restrict__ out, int ldo, const float* __restrict__ res,
                                                        float* __restrict__ out2, float* __restrict__ pre_out, long P,
                                                        int Cin, int Cout, int act_mode) {
     FFNO_DYN_SMEM(smem);
-    float* xs = reinterpret_cast<float*>(smem);          // [tile][Cin + 1]
-    float* ws = xs + kPlinTile * (Cin + 1);              // [Cout][Cin + 1]
-    float* bs = ws + Cout * (Cin + 1);
     const int t = threadIdx.x, sx = Cin + 1;
-    for (int e = t; e < Cout * Cin; e += 256) ws[(e / Cin) * sx + e % Cin] = W[e];
-    for (int e = t; e < Cout; e += 256) bs[e] = b ? b[e] : 0.f;
+    const int cp = VEC ? (Cout + 3) / 4 * 4 : Cout;       // VEC: weights transposed to [Cin][cp], zero-padded columns
+    float* xs = reinterpret_cast<float*>(smem);          // [tile][Cin + 1]
+    float* ws = xs + (kPlinTile * sx + 3) / 4 * 4;       // VEC: [Cin][cp]   scalar: [Cout][Cin + 1]
+    float* bs = ws + (VEC ? Cin * cp : Cout * sx);       // [cp]
+    if (VEC) {
+        for (int e = t; e < Cin * cp; e += 256) {
+            const int i = e / cp, o = e - i * cp;
+            ws[e] = o < Cout ? W[o * Cin + i] : 0.f;
+        }
+        for (int e = t; e < cp; e += 256) bs[e] = (b && e < Cout) ? b[e] : 0.f;
+    } else {
+        for (int e = t; e < Cout * Cin; e += 256) ws[(e / Cin) * sx + e % Cin] = W[e];
+        for (int e = t; e < Cout; e += 256) bs[e] = b ? b[e] : 0.f;
+    }
     const long ntile = (P + kPlinTile - 1) / kPlinTile;
     for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
         const long p0 = tile * kPlinTile;
@@ -54,35 +66,75 @@ __global__ __launch_bounds__(256) void plin_fwd_kernel(const float* __restrict__
             xs[p * sx + i] = x[(p0 + p) * ldx + i];
         }
         __syncthreads();
-        for (int e = t; e < np * ldo; e += 256) {
-            const int p = e / ldo, o = e - p * ldo;
-            float v = 0.f;
-            if (o < Cout) {
-                v = bs[o];
-                const float* wr = ws + o * sx;
-                const float* xr = xs + p * sx;
-                for (int i = 0; i < Cin; ++i) v = fmaf(wr[i], xr[i], v);
-                if (add) v += add[(p0 + p) * ldo + o];
-                if (pre_out) pre_out[(p0 + p) * ldo + o] = v;
-                v = plin_act(v, act_mode);
-            } else if (pre_out) {
-                pre_out[(p0 + p) * ldo + o] = 0.f;
+        if (VEC) {
+            const int l4 = ldo / 4;
+            for (int e = t; e < np * l4; e += 256) {
+                const int p = e / l4, o = 4 * (e - p * l4);
+                const long idx = (p0 + p) * ldo + o;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (o < Cout) {
+                    const f32x4 bb = *reinterpret_cast<const f32x4*>(bs + o);
+                    v[0] = bb[0], v[1] = bb[1], v[2] = bb[2], v[3] = bb[3];
+                    const float* xr = xs + p * sx;
+                    for (int i = 0; i < Cin; ++i) {
+                        const float xv = xr[i];
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + i * cp + o);
+                        v[0] = fmaf(w4[0], xv, v[0]);
+                        v[1] = fmaf(w4[1], xv, v[1]);
+                        v[2] = fmaf(w4[2], xv, v[2]);
+                        v[3] = fmaf(w4[3], xv, v[3]);
+                    }
+                }
+                float prev[4], outv[4];
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const bool live = o + u < Cout;
+                    float a = live ? v[u] : 0.f;
+                    if (live && add) a += add[idx + u];
+                    prev[u] = a;
+                    outv[u] = live ? plin_act(a, act_mode) : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(out + idx) = f32x4{outv[0], outv[1], outv[2], outv[3]};
+                if (pre_out) *reinterpret_cast<f32x4*>(pre_out + idx) = f32x4{prev[0], prev[1], prev[2], prev[3]};
+                if (out2) {
+                    const f32x4 r4 = *reinterpret_cast<const f32x4*>(res + idx);
+                    *reinterpret_cast<f32x4*>(out2 + idx) = f32x4{outv[0] + r4[0], outv[1] + r4[1], outv[2] + r4[2], outv[3] + r4[3]};
+                }
             }
-            out[(p0 + p) * ldo + o] = v;
-            if (out2) out2[(p0 + p) * ldo + o] = v + res[(p0 + p) * ldo + o];
+        } else {
+            for (int e = t; e < np * ldo; e += 256) {
+                const int p = e / ldo, o = e - p * ldo;
+                float v = 0.f;
+                if (o < Cout) {
+                    v = bs[o];
+                    const float* wr = ws + o * sx;
+                    const float* xr = xs + p * sx;
+                    for (int i = 0; i < Cin; ++i) v = fmaf(wr[i], xr[i], v);
+                    if (add) v += add[(p0 + p) * ldo + o];
+                    if (pre_out) pre_out[(p0 + p) * ldo + o] = v;
+                    v = plin_act(v, act_mode);
+                } else if (pre_out) {
+                    pre_out[(p0 + p) * ldo + o] = 0.f;
+                }
+                out[(p0 + p) * ldo + o] = v;
+                if (out2) out2[(p0 + p) * ldo + o] = v + res[(p0 + p) * ldo + o];
+            }
         }
     }
 }
 
-// dpre[p][o] = g[p][o] * (act ? act[p][o] > 0 : 1);   dx[p][i] (+)= sum_o dpre[p][o] W[o][i];   optional copy of dpre
+// dpre[p][o] = g[p][o] * act'(.);   dx[p][i] (+)= sum_o dpre[p][o] W[o][i];   optional copy of dpre
+// VEC (ldx % 4 == 0, Cin % 4 == 0): a thread owns four consecutive inputs of a point (one broadcast read of dpre[p][o] and one
+// 16-byte read of a weight row per four FMAs).
+template <bool VEC>
 __global__ __launch_bounds__(256) void plin_bwd_data_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ act,
                                                             const float* __restrict__ W, float* __restrict__ dx, int ldx,
                                                             float* __restrict__ dpre_out, long P, int Cin, int Cout,
                                                             int accumulate, int act_mode) {
     FFNO_DYN_SMEM(smem);
-    float* ds = reinterpret_cast<float*>(smem);          // [tile][Cout + 1]
-    float* ws = ds + kPlinTile * (Cout + 1);             // [Cout][Cin]
     const int t = threadIdx.x, sd = Cout + 1;
+    float* ws = reinterpret_cast<float*>(smem);          // [Cout][Cin]   (first: 16-byte aligned rows when Cin % 4 == 0)
+    float* ds = ws + (Cout * Cin + 3) / 4 * 4;           // [tile][Cout + 1]
     for (int e = t; e < Cout * Cin; e += 256) ws[e] = W[e];
     const long ntile = (P + kPlinTile - 1) / kPlinTile;
     for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
@@ -101,15 +153,41 @@ __global__ __launch_bounds__(256) void plin_bwd_data_kernel(const float* __restr
             if (dpre_out) dpre_out[idx] = v;
         }
         __syncthreads();
-        for (int e = t; e < np * ldx; e += 256) {
-            const int p = e / ldx, i = e - p * ldx;
-            const long idx = (p0 + p) * ldx + i;
-            float v = 0.f;
-            if (i < Cin) {
-                const float* dr = ds + p * sd;
-                for (int o = 0; o < Cout; ++o) v = fmaf(dr[o], ws[o * Cin + i], v);
+        if (VEC) {
+            const int l4 = ldx / 4;
+            for (int e = t; e < np * l4; e += 256) {
+                const int p = e / l4, i = 4 * (e - p * l4);
+                const long idx = (p0 + p) * ldx + i;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (i < Cin) {
+                    const float* dr = ds + p * sd;
+                    for (int o = 0; o < Cout; ++o) {
+                        const float d = dr[o];
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(ws + o * Cin + i);
+                        v[0] = fmaf(d, w4[0], v[0]);
+                        v[1] = fmaf(d, w4[1], v[1]);
+                        v[2] = fmaf(d, w4[2], v[2]);
+                        v[3] = fmaf(d, w4[3], v[3]);
+                    }
+                }
+                f32x4 r = f32x4{v[0], v[1], v[2], v[3]};
+                if (accumulate) {
+                    const f32x4 old = *reinterpret_cast<const f32x4*>(dx + idx);
+                    r = f32x4{old[0] + v[0], old[1] + v[1], old[2] + v[2], old[3] + v[3]};
+                }
+                *reinterpret_cast<f32x4*>(dx + idx) = r;
             }
-            dx[idx] = accumulate ? dx[idx] + v : v;
+        } else {
+            for (int e = t; e < np * ldx; e += 256) {
+                const int p = e / ldx, i = e - p * ldx;
+                const long idx = (p0 + p) * ldx + i;
+                float v = 0.f;
+                if (i < Cin) {
+                    const float* dr = ds + p * sd;
+                    for (int o = 0; o < Cout; ++o) v = fmaf(dr[o], ws[o * Cin + i], v);
+                }
+                dx[idx] = accumulate ? dx[idx] + v : v;
+            }
         }
     }
 }
@@ -254,9 +332,18 @@ int ffno_plin_fwd(const float* x, int ldx, const float* W, const float* b, const
     if (!x || !W || !out || P <= 0 || ldx < Cin || ldo < Cout || (out2 && !res) || act_mode < 0 || act_mode > 2)
         return FFNO_EINVAL;
     if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)kPlinTile * (Cin + 1) + (size_t)Cout * (Cin + 1) + Cout);
-    FFNO_LAUNCH(plin_fwd_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, b, add, out, ldo, res, out2, pre_out,
-                P, Cin, Cout, act_mode);
+    const bool vec = ldo % 4 == 0 && ((uintptr_t)out % 16 == 0) && (!add || (uintptr_t)add % 16 == 0) &&
+                     (!res || (uintptr_t)res % 16 == 0) && (!out2 || (uintptr_t)out2 % 16 == 0) &&
+                     (!pre_out || (uintptr_t)pre_out % 16 == 0);
+    const int cp = (Cout + 3) / 4 * 4;
+    const size_t xsz = ((size_t)kPlinTile * (Cin + 1) + 3) / 4 * 4;
+    const size_t lds = sizeof(float) * (xsz + (vec ? (size_t)Cin * cp + cp : (size_t)Cout * (Cin + 1) + Cout));
+    if (vec)
+        FFNO_LAUNCH(plin_fwd_kernel<true>, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, b, add, out, ldo,
+                    res, out2, pre_out, P, Cin, Cout, act_mode);
+    else
+        FFNO_LAUNCH(plin_fwd_kernel<false>, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, x, ldx, W, b, add, out, ldo,
+                    res, out2, pre_out, P, Cin, Cout, act_mode);
     return plin_status();
 }
 
@@ -264,9 +351,14 @@ int ffno_plin_bwd_data(const float* g, int ldg, const float* act, const float* W
                        int Cin, int Cout, int accumulate, int act_mode, void* stream) {
     if (!g || !W || !dx || P <= 0 || ldg < Cout || ldx < Cin || act_mode < 0 || act_mode > 2) return FFNO_EINVAL;
     if (!ffno_plin_supported(Cin, Cout)) return FFNO_EUNSUPPORTED;
-    const size_t lds = sizeof(float) * ((size_t)kPlinTile * (Cout + 1) + (size_t)Cout * Cin);
-    FFNO_LAUNCH(plin_bwd_data_kernel, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, g, ldg, act, W, dx, ldx, dpre_out,
-                P, Cin, Cout, accumulate, act_mode);
+    const bool vec = ldx % 4 == 0 && Cin % 4 == 0 && (uintptr_t)dx % 16 == 0;
+    const size_t lds = sizeof(float) * (((size_t)Cout * Cin + 3) / 4 * 4 + (size_t)kPlinTile * (Cout + 1));
+    if (vec)
+        FFNO_LAUNCH(plin_bwd_data_kernel<true>, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, g, ldg, act, W, dx, ldx,
+                    dpre_out, P, Cin, Cout, accumulate, act_mode);
+    else
+        FFNO_LAUNCH(plin_bwd_data_kernel<false>, dim3(plin_grid(P)), dim3(256), lds, (hipStream_t)stream, g, ldg, act, W, dx, ldx,
+                    dpre_out, P, Cin, Cout, accumulate, act_mode);
     return plin_status();
 }
 
