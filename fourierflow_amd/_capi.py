@@ -52,6 +52,11 @@ class PadDesc(C.Structure):
     _fields_ = [("plain", P), ("padded", P), ("R", C.c_int32), ("Cc", C.c_int32), ("inner", C.c_int32), ("Cp", C.c_int32)]
 
 
+class FwPackDesc(C.Structure):
+    """Mirror of ``ffno_fwpack_desc`` (include/ffno.h)."""
+    _fields_ = [("w", P), ("wp", P), ("wpt", P), ("K", C.c_int32), ("real", C.c_int32)]
+
+
 class TrDesc(C.Structure):
     """Mirror of ``ffno_tr_desc`` (include/ffno.h)."""
     _fields_ = [("src", P), ("dst", P), ("rows", C.c_int32), ("cols", C.c_int32)]
@@ -63,6 +68,7 @@ SIGNATURES = {
     "ffno_twiddle_fill_host": (I, [P, I]),
     "ffno_dft_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "ffno_fw_pack": (I, [P, P, P, I, I, P]),
+    "ffno_fw_pack_batched": (I, [P, I, I, I, P]),
     "ffno_mode_mix": (I, [P, P, P, I, I, I, I, P]),
     "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),

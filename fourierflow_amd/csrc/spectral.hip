@@ -322,6 +322,23 @@ __global__ void fw_pack_kernel(const float* __restrict__ w, float* __restrict__ 
     }
 }
 
+// all Fourier weights of a model in one launch (per-layer weights: 3 axes x 12 layers = 36 tensors per pass in the 3-D
+// configs): blockIdx.y selects the tensor; real = 1: [I][O][K] weights of the DCT operators (imaginary plane = 0)
+__global__ void fw_pack_batched_kernel(const ffno_fwpack_desc* __restrict__ descs, int C) {
+    const ffno_fwpack_desc d = descs[blockIdx.y];
+    const int K = d.K;
+    const long total = (long)C * C * K * 2;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int o = e % C;
+        const int i = (e / C) % C;
+        const int ri = (e / ((long)C * C)) % 2;
+        const int k = e / ((long)C * C * 2);
+        const float v = d.real ? (ri ? 0.f : d.w[((long)i * C + o) * K + k]) : d.w[(((long)i * C + o) * K + k) * 2 + ri];
+        d.wp[e] = v;
+        d.wpt[(((long)k * 2 + ri) * C + o) * C + i] = v;
+    }
+}
+
 // ---- stage B ------------------------------------------------------------------------------------
 // Block = (mode k, chunk of work items); work item = (32-line tile, output part q = re | im), one per wave.
 // D[line][(q,o)] = sum_{(p,i)} X[line][(p,i)] * Wb[(p,i)][(q,o)]  with the 2x2 real block form of the
@@ -1059,6 +1076,14 @@ extern "C" int ffno_fw_pack(const float* w, float* wp, float* wpt, int C, int K,
     const long total = (long)C * C * K * 2;
     FFNO_LAUNCH(fw_pack_kernel, dim3((unsigned)min((total + 255) / 256, 1024L)), dim3(256), 0,
                        (hipStream_t)stream, w, wp, wpt, C, K);
+    return launch_status();
+}
+
+extern "C" int ffno_fw_pack_batched(const ffno_fwpack_desc* descs_dev, int n, int C, int max_K, void* stream) {
+    if (!descs_dev || n <= 0 || C <= 0 || max_K <= 0) return FFNO_EINVAL;
+    const long total = (long)C * C * max_K * 2;
+    FFNO_LAUNCH(fw_pack_batched_kernel, dim3((unsigned)min((total + 255) / 256, 256L), n), dim3(256), 0, (hipStream_t)stream,
+                descs_dev, C);
     return launch_status();
 }
 

@@ -472,11 +472,17 @@ class FFNOEngine:
         for i, names in enumerate(self._fw_sets if self.spectral == "plus" else []):
             self._k("fw2d_pack", lib.ffno_fw2d_pack, _p(self.params[names[0]]), _p(self.params[names[1]]),
                     _p(self.planes[i][0][0]), _p(self.planes[i][0][1]), self.C, self.K, st)
-        for i, names in enumerate(self._fw_sets if self.spectral != "plus" else []):
-            pack = lib.ffno_fw_pack_real if self.spectral == "dct" else lib.ffno_fw_pack
-            for w, n in enumerate(names):
-                self._k("fw_pack", pack, _p(self.params[n]), _p(self.planes[i][w][0]), _p(self.planes[i][w][1]), self.C,
-                        self.Ks[w], st)
+        if self.spectral != "plus" and self._fw_sets:      # every (weight set, axis) tensor in ONE launch
+            sig = tuple((self.params[n].data_ptr(), self.planes[i][w][0].data_ptr())
+                        for i, names in enumerate(self._fw_sets) for w, n in enumerate(names))
+            if sig != getattr(self, "_fwpack_sig", None):
+                descs = [_capi.FwPackDesc(self.params[n].data_ptr(), self.planes[i][w][0].data_ptr(),
+                                          self.planes[i][w][1].data_ptr(), self.Ks[w], int(self.spectral == "dct"))
+                         for i, names in enumerate(self._fw_sets) for w, n in enumerate(names)]
+                arr = (_capi.FwPackDesc * len(descs))(*descs)
+                self._fwpack_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+                self._fwpack_sig, self._fwpack_n = sig, len(descs)
+            self._k("fw_pack", lib.ffno_fw_pack_batched, _p(self._fwpack_dev), self._fwpack_n, self.C, max(self.Ks), st)
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         self._k("head_fold", lib.ffno_head_fold, _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                 _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, self.O, st)

@@ -66,6 +66,15 @@ int ffno_dft_fwd(const float* x, float* spec, const float* tw, int B, int M, int
  * mode-major planes wp[K][2][I][O] and the transposed copy wpt[K][2][O][I] (for the backward mix).
  * --------------------------------------------------------------------------------------------- */
 int ffno_fw_pack(const float* w, float* wp, float* wpt, int C, int K, void* stream);
+/* the same for n weight tensors in one launch (descs is a DEVICE array); real = 1: real [I][O][K] weights (DCT operators,
+ * as ffno_fw_pack_real) */
+typedef struct ffno_fwpack_desc {
+    const float* w;
+    float* wp;
+    float* wpt;
+    int32_t K, real;
+} ffno_fwpack_desc;
+int ffno_fw_pack_batched(const ffno_fwpack_desc* descs, int n, int C, int max_K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage B -- per-mode complex channel mix on R lines.
