@@ -72,6 +72,8 @@ SIGNATURES = {
     "ffno_mode_mix": (I, [P, P, P, I, I, I, I, P]),
     "ffno_dft_inv": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
+    "ffno_fw_grad_partial_multi": (I, [P, P, P, I, I, I, I, I, SZ, SZ, SZ, P]),
+    "ffno_fw_grad_reduce_multi": (I, [P, P, I, I, I, I, SZ, I, I, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),

@@ -763,9 +763,14 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(4) void spectral_fused_pai
 template <int C>
 __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restrict__ xs, const float* __restrict__ dys,
                                                            float* __restrict__ partial, int R, int K, int chunk,
-                                                           int beta, int nlayers, long stride_x, long stride_dy) {
+                                                           int beta, int nlayers, long stride_x, long stride_dy, long zstride_x,
+                                                           long zstride_dy, long zstride_p) {
     constexpr int CT = C / 32;
     __shared__ float comb[CT * 64 * (4 * CT * 16)];
+    // blockIdx.z: independent problems (the per-layer weights of an unshared model: one launch for all layers)
+    xs += (long)blockIdx.z * zstride_x;
+    dys += (long)blockIdx.z * zstride_dy;
+    partial += (long)blockIdx.z * zstride_p;
     const int k = blockIdx.y, split = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -860,8 +865,14 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
 // 64 consecutive elements per block, the slices spread over the block's four waves (a launch covers only 2 K C^2 elements --
 // 16 K at K = 8, C = 32 -- so a serial loop over up to 64 slices per thread is pure latency: 17.6 -> ~5 us)
 __global__ __launch_bounds__(256) void fw_grad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw, int C,
-                                                             int K, int nsplit, int accumulate) {
+                                                             int K, int nsplit, int accumulate, float* const* __restrict__ gws,
+                                                             long pstride, int real) {
     __shared__ float red[256];
+    // gws != NULL: blockIdx.y selects one of several independent reductions (per-layer weights), partial + y * pstride -> gws[y]
+    if (gws) {
+        gw = gws[blockIdx.y];
+        partial += (long)blockIdx.y * pstride;
+    }
     const long total = (long)C * C * K * 2;
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6;
     for (long e0 = (long)blockIdx.x * 64; e0 < total; e0 += (long)gridDim.x * 64) {
@@ -877,8 +888,15 @@ __global__ __launch_bounds__(256) void fw_grad_reduce_kernel(const float* __rest
             const int i = (e / C) % C;
             const int ri = (e / ((long)C * C)) % 2;
             const int k = e / ((long)C * C * 2);
-            float* g = gw + (((long)i * C + o) * K + k) * 2 + ri;
-            *g = accumulate ? (*g + s) : s;
+            if (real) {          // real [I][O][K] weights (DCT operators): the imaginary part is identically zero
+                if (ri == 0) {
+                    float* g = gw + ((long)i * C + o) * K + k;
+                    *g = accumulate ? (*g + s) : s;
+                }
+            } else {
+                float* g = gw + (((long)i * C + o) * K + k) * 2 + ri;
+                *g = accumulate ? (*g + s) : s;
+            }
         }
         __syncthreads();
     }
@@ -1133,10 +1151,29 @@ extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, f
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
         FFNO_LAUNCH((fw_grad_x3_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
-                    nlayers, (long)layer_stride_x, (long)layer_stride_dy);
+                    nlayers, (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L);
     else
         FFNO_LAUNCH((fw_grad_x3_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
-                    nlayers, (long)layer_stride_x, (long)layer_stride_dy);
+                    nlayers, (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L);
+    return launch_status();
+}
+
+// n independent contractions in one launch (per-layer Fourier weights): problem z reads spec_x + z*stride_x,
+// spec_dy + z*stride_dy and writes partial + z*stride_p (each nsplit*2*K*C*C floats)
+extern "C" int ffno_fw_grad_partial_multi(const float* spec_x, const float* spec_dy, float* partial, int R, int C, int K,
+                                          int nsplit, int n, size_t stride_x, size_t stride_dy, size_t stride_p, void* stream) {
+    if (!spec_x || !spec_dy || !partial || R <= 0 || K <= 0 || nsplit <= 0 || n <= 0 || n > 65535) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    long chunk = ((long)R + nsplit - 1) / nsplit;
+    chunk += chunk & 1;
+    const dim3 grid(nsplit, K, n), block(C * 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        FFNO_LAUNCH((fw_grad_x3_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L,
+                    (long)stride_x, (long)stride_dy, (long)stride_p);
+    else
+        FFNO_LAUNCH((fw_grad_x3_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L,
+                    (long)stride_x, (long)stride_dy, (long)stride_p);
     return launch_status();
 }
 
@@ -1145,7 +1182,17 @@ extern "C" int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K
     if (!partial || !gw || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
     const long total = (long)C * C * K * 2;
     FFNO_LAUNCH(fw_grad_reduce_kernel, dim3((unsigned)min((total + 63) / 64, 4096L)), dim3(256), 0, (hipStream_t)stream, partial,
-                gw, C, K, nsplit, accumulate);
+                gw, C, K, nsplit, accumulate, (float* const*)nullptr, 0L, 0);
+    return launch_status();
+}
+
+// n reductions in one launch: partial + y * stride_p -> gws[y] (DEVICE array of n pointers); real: [I][O][K] outputs
+extern "C" int ffno_fw_grad_reduce_multi(const float* partial, float* const* gws_dev, int n, int C, int K, int nsplit,
+                                         size_t stride_p, int accumulate, int real, void* stream) {
+    if (!partial || !gws_dev || n <= 0 || n > 65535 || C <= 0 || K <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    const long total = (long)C * C * K * 2;
+    FFNO_LAUNCH(fw_grad_reduce_kernel, dim3((unsigned)min((total + 63) / 64, 1024L), n), dim3(256), 0, (hipStream_t)stream,
+                partial, (float*)nullptr, C, K, nsplit, accumulate, gws_dev, (long)stride_p, real);
     return launch_status();
 }
 

@@ -807,7 +807,25 @@ class FFNOEngine:
         lin_in = self.linears["in_proj."]
         self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")),
                 ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
-        for si, names in enumerate(self._fw_sets):
+        multi = self.spectral != "plus" and len(self._fw_sets) == L and L > 1      # per-layer weights: one launch per axis
+        if multi:
+            real = int(self.spectral == "dct")
+            for w in range(len(ws.views)):
+                v = ws.views[w]
+                pstride = ws.nsplit_fw[w] * 2 * v.K * C * C
+                if getattr(ws, "fwpart_multi", None) is None:
+                    ws.fwpart_multi, ws.fwgrad_tab, ws.fwgrad_sig = {}, {}, {}
+                if w not in ws.fwpart_multi:
+                    ws.fwpart_multi[w] = torch.empty(L * pstride, dtype=torch.float32, device=self.device)
+                ptrs = tuple(gv(self._fw_sets[l][w]).data_ptr() for l in range(L))
+                if ws.fwgrad_sig.get(w) != ptrs:
+                    ws.fwgrad_tab[w] = torch.tensor(ptrs, dtype=torch.int64).to(self.device)
+                    ws.fwgrad_sig[w] = ptrs
+                self._k("fw_grad_partial", lib.ffno_fw_grad_partial_multi, _p(ws.SXall[w]), _p(ws.SDall[w]),
+                        _p(ws.fwpart_multi[w]), v.R, C, v.K, ws.nsplit_fw[w], L, v.spec, v.spec, pstride, st)
+                self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce_multi, _p(ws.fwpart_multi[w]), _p(ws.fwgrad_tab[w]), L, C, v.K,
+                        ws.nsplit_fw[w], pstride, 0, real, st)
+        for si, names in enumerate(self._fw_sets if not multi else []):
             layers = [l for l in range(L) if self.fw_names[l] == names]
             l0_, nl = layers[0], len(layers)
             assert layers == list(range(l0_, l0_ + nl))

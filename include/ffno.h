@@ -110,6 +110,14 @@ int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* parti
                          size_t layer_stride_dy, void* stream);
 int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
                         void* stream);
+/* the two steps for n independent weight tensors in one launch each (per-layer Fourier weights of an unshared model):
+ * problem z reads spec_x + z*stride_x / spec_dy + z*stride_dy, its slices live at partial + z*stride_p and are reduced into
+ * gws[z] (DEVICE array of n pointers); real = 1: real [I][O][K] outputs (DCT operators). */
+int ffno_fw_grad_partial_multi(const float* spec_x, const float* spec_dy, float* partial, int R, int C, int K,
+                               int nsplit, int n, size_t stride_x, size_t stride_dy, size_t stride_p,
+                               void* stream);
+int ffno_fw_grad_reduce_multi(const float* partial, float* const* gws, int n, int C, int K, int nsplit,
+                              size_t stride_p, int accumulate, int real, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused branch (stage A -> B -> C in ONE launch, the spectrum tile stays in LDS; fast path):
