@@ -92,6 +92,7 @@ SIGNATURES = {
     "ffno_ffx_pack_bytes": (SZ, [I, I]),
     "ffno_ffx_pack": (I, [P, I, I, I, P]),
     "ffno_ffx_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ffx_mask_unpack": (I, [P, P, I, I, I, P]),
     "ffno_ffx_bwd_data": (I, [P, P, P, P, P, I, I, I, P]),
     "ffno_ffx_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
     "ffno_ffx_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P]),

@@ -584,6 +584,22 @@ __global__ __launch_bounds__(256) void ffx_wgrad_reduce_batched_kernel(const FxR
     }
 }
 
+// ReLU sign bits of the chain kernel -> one byte per (pixel, hidden unit): word (tile, wave, lane = (j, half)) holds the 16
+// accumulator rows of pixel 32 tile + j, hidden units 32 wave + drow(r, half) at bit 15 - r.
+__global__ __launch_bounds__(256) void ffx_mask_unpack_kernel(const uint16_t* __restrict__ mask, uint8_t* __restrict__ out, int P,
+                                                              int H) {
+    const int NW = H / 32;
+    const long nwords = (long)((P + 31) >> 5) * NW * 64;
+    for (long w = (long)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(w & 63), j = lane & 31, half = lane >> 5;
+        const int wave = (int)((w >> 6) % NW);
+        const long px = (w >> 6) / NW * 32 + j;
+        if (px >= P) continue;
+        const uint32_t bits = mask[w];
+        for (int r = 0; r < 16; ++r) out[px * H + 32 * wave + drow(r, half)] = (uint8_t)((bits >> (15 - r)) & 1u);
+    }
+}
+
 static inline int ffx_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -610,6 +626,13 @@ extern "C" int ffno_ffx_supported(int C, int H) {
 }
 
 extern "C" size_t ffno_ffx_pack_bytes(int C, int H) { return (size_t)C * H * 6; }
+
+extern "C" int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, int C, int H, void* stream) {
+    if (!mask || !active || P <= 0) return FFNO_EINVAL;
+    if (!ffno_ffx_supported(C, H)) return FFNO_EUNSUPPORTED;
+    FFNO_LAUNCH(ffx_mask_unpack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)mask, active, P, H);
+    return ffx_launch_status();
+}
 
 extern "C" int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
     if (!descs_dev || n <= 0) return FFNO_EINVAL;

@@ -848,6 +848,27 @@ class FFNOEngine:
         return self.gflat
 
 
+    def relu_active_sets(self) -> Dict[Tuple[str, int], torch.Tensor]:
+        """Diagnostics / parity tests: the ReLU active sets of the last ``forward(save_for_backward=True)``,
+        {("backcast" | "forecast", layer): uint8 [pixels of the (padded) activation buffer, hidden]} -- what
+        ``threshold_backward`` of feedforward.py:17 would see.  Split-bf16 feed-forward only."""
+        if self._saved is None or not self._ffx():
+            raise RuntimeError("relu_active_sets() needs a preceding forward(save_for_backward=True) on the ffx path")
+        _, B, S, _, _ = self._saved
+        ws = self._workspace(B, S, True)
+        lib = _lib.get_lib()
+        st = _lib.current_stream(self.device)
+        out = {}
+        for kind, masks in (("backcast", ws.MASK), ("forecast", getattr(ws, "MASKF", None))):
+            if masks is None:
+                continue
+            for l in range(self.L):
+                a = torch.zeros(ws.P, self.H, dtype=torch.uint8, device=self.device)
+                self._k("mask_unpack", lib.ffno_ffx_mask_unpack, _p(masks[l]), _p(a), ws.P, self.C, self.H, st)
+                out[(kind, l)] = a
+        return out
+
+
 class FFNO2DEngine(FFNOEngine):
     """FNOFactorized2DBlock geometry (the 2-D entry point used by the module mirror and the tests)."""
 

@@ -228,6 +228,9 @@ size_t ffno_ffx_pack_bytes(int C, int H);
 int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
 int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
                  const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+/* decode the private sign-bit layout: active[p * H + h] = 1 iff the forward's hidden unit (p, h) passed the ReLU
+ * (= torch's threshold_backward mask of feedforward.py:17); diagnostics and parity tests */
+int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, int C, int H, void* stream);
 /* ..2 variants: the input is the SUM of two tensors (s + s2, db + db2 -- the two spectral branches of a layer written
  * side by side by concurrent launches); with s_sum / db_sum the sum is also stored for the kernels that follow
  * (s_sum may alias s). */

@@ -65,12 +65,21 @@ def linear_from_sd(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
 # FeedForward  (feedforward.py:6-24)
 # --------------------------------------------------------------------------
 def feedforward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int = 2,
-                layer_norm: bool = False) -> Tensor:
-    """n_layers x [linear -> (dropout p=0) -> ReLU except last -> LayerNorm iff last & layer_norm]."""
+                layer_norm: bool = False, relu_mask=None) -> Tensor:
+    """n_layers x [linear -> (dropout p=0) -> ReLU except last -> LayerNorm iff last & layer_norm].
+
+    ``relu_mask`` (tests only): a list with one boolean tensor per hidden activation, [pixels, hidden] -- the ACTIVE SET
+    another implementation chose.  The ReLU is then evaluated as ``pre * mask``: identical to relu(pre) wherever the two
+    implementations agree on the sign, and it removes the one discontinuity of the block (a pre-activation within an ulp
+    of zero flips between any two correct fp32 implementations and moves the gradients by ~1e-3), so gradients can be
+    compared at rounding level."""
     for i in range(n_layers):
         x = linear_from_sd(sd, f"{prefix}layers.{i}.0.", x)
         if i < n_layers - 1:
-            x = torch.relu(x)
+            if relu_mask is not None:
+                x = x * relu_mask[i].reshape(x.shape).to(x.dtype)
+            else:
+                x = torch.relu(x)
         elif layer_norm:
             x = F.layer_norm(x, x.shape[-1:], sd[f"{prefix}layers.{i}.3.weight"],
                              sd[f"{prefix}layers.{i}.3.bias"])
@@ -157,12 +166,15 @@ def forward_fourier_plus(x: Tensor, w0: Tensor, w1: Tensor, modes: int) -> Tenso
 # --------------------------------------------------------------------------
 def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
                  use_fork: bool = False, mode: str = "full", n_ff_layers: int = 2,
-                 layer_norm: bool = False, return_intermediates: bool = False, spectral: str = "factorized"):
+                 layer_norm: bool = False, return_intermediates: bool = False, spectral: str = "factorized",
+                 relu_masks=None):
     """Forward of the whole block over a reference-layout state_dict.
 
     Returns {'forecast', 'forecast_list'} like the reference; with
     ``return_intermediates`` also the per-layer inputs for test diagnostics.
+    ``relu_masks`` (tests only): {("backcast" | "forecast", layer): [mask per hidden activation]}, see ``feedforward``.
     """
+    rm = relu_masks or {}
     def head(t: Tensor) -> Tensor:
         return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", t))
 
@@ -179,9 +191,9 @@ def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
         elif mode != "no-fourier":
             s = forward_fourier(x, sd.get(pre + "fourier_weight.0"), sd.get(pre + "fourier_weight.1"),
                                 modes, mode)
-        b = feedforward(sd, pre + "backcast_ff.", s, n_ff_layers, layer_norm)
+        b = feedforward(sd, pre + "backcast_ff.", s, n_ff_layers, layer_norm, rm.get(("backcast", i)))
         if use_fork:
-            f_out = head(feedforward(sd, pre + "forecast_ff.", s, n_ff_layers, layer_norm))
+            f_out = head(feedforward(sd, pre + "forecast_ff.", s, n_ff_layers, layer_norm, rm.get(("forecast", i))))
             forecast = forecast + f_out
             forecast_list.append(f_out)
         x = x + b
@@ -291,8 +303,9 @@ def mesh3d_grid(shape, dtype) -> Tensor:
     return torch.cat((gx, gy, gz), dim=-1)
 
 
-def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, padding: int = 8) -> Tensor:
+def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, padding: int = 8, relu_masks=None) -> Tensor:
     """x [B, X, Y, Z, input_dim - 3] -> [B, X, Y, Z, output_dim] (mesh_3d.py:160-176)."""
+    rm = relu_masks or {}
     x = torch.cat((x, mesh3d_grid(x.shape, x.dtype)), dim=-1)
     x = linear_from_sd(sd, "in_proj.", x)
     x = F.pad(x.permute(0, 4, 1, 2, 3), [0, padding, 0, padding, 0, padding]).permute(0, 2, 3, 4, 1)
@@ -300,7 +313,7 @@ def ffno_mesh3d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, paddi
     for i in range(n_layers):
         pre = f"spectral_layers.{i}."
         s = forward_fourier_3d(x, [sd[pre + f"fourier_weight.{w}"] for w in range(3)], modes)
-        b = feedforward(sd, pre + "backcast_ff.", s)
+        b = feedforward(sd, pre + "backcast_ff.", s, relu_mask=rm.get(("backcast", i)))
         x = x + b
     b = b[:, :-padding, :-padding, :-padding, :]
     return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", b))
@@ -353,8 +366,9 @@ def mesh2d_grid(shape, dtype) -> Tensor:
     return torch.cat((gx, gy), dim=-1)
 
 
-def ffno_mesh2d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, padding: int = 8) -> Tensor:
+def ffno_mesh2d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, padding: int = 8, relu_masks=None) -> Tensor:
     """x [B, X, Y, input_dim - 2] -> [B, X, Y, 1] (mesh_2d.py:146-165); modes = (modes_x, modes_y)."""
+    rm = relu_masks or {}
     x = torch.cat((x, mesh2d_grid(x.shape, x.dtype)), dim=-1)
     x = linear_from_sd(sd, "in_proj.", x)
     x = F.pad(x.permute(0, 3, 1, 2), [0, padding, 0, padding]).permute(0, 2, 3, 1)
@@ -364,7 +378,7 @@ def ffno_mesh2d(sd: Dict[str, Tensor], x: Tensor, *, modes, n_layers: int, paddi
         x_cf = x.permute(0, 3, 1, 2)
         s = (spectral_branch(x_cf, sd[pre + "fourier_weight.1"], modes[1], dim=-1, mode="full") +
              spectral_branch(x_cf, sd[pre + "fourier_weight.0"], modes[0], dim=-2, mode="full")).permute(0, 2, 3, 1)
-        b = feedforward(sd, pre + "backcast_ff.", s)
+        b = feedforward(sd, pre + "backcast_ff.", s, relu_mask=rm.get(("backcast", i)))
         x = x + b
     b = b[:, :-padding, :-padding, :]
     return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", b))
