@@ -57,6 +57,11 @@ class FwPackDesc(C.Structure):
     _fields_ = [("w", P), ("wp", P), ("wpt", P), ("K", C.c_int32), ("real", C.c_int32)]
 
 
+class X3PackDesc(C.Structure):
+    """Mirror of ``ffno_x3pack_desc`` (include/ffno.h)."""
+    _fields_ = [("planes", P), ("dst", P), ("K", C.c_int32), ("pad_", C.c_int32)]
+
+
 class TrDesc(C.Structure):
     """Mirror of ``ffno_tr_desc`` (include/ffno.h)."""
     _fields_ = [("src", P), ("dst", P), ("rows", C.c_int32), ("cols", C.c_int32)]
@@ -76,6 +81,11 @@ SIGNATURES = {
     "ffno_fw_grad_reduce_multi": (I, [P, P, I, I, I, I, SZ, I, I, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
+    "ffno_spectral_x3_supported": (I, [I, I, I]),
+    "ffno_spectral_x3_pack_bytes": (SZ, [I, I]),
+    "ffno_spectral_x3_pack": (I, [P, I, I, I, P]),
+    "ffno_spectral_x3": (I, [P, I, I, I, I, P]),
+    "ffno_spectral_x3_pair": (I, [P, P, I, I, I, I, I, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),

@@ -1,8 +1,9 @@
 """Loader of the gfx950 C-ABI library (fourierflow_amd/lib/libffno_hip.so).
 
 There is NO CPU fallback: if the HIP library cannot be loaded every operator raises.  (The tests can
-install the CPU wave-emulator build of the *same kernel sources* through ``_install_test_backend`` --
-that hook is only ever called from tests/ and is never consulted otherwise.)
+install the CPU wave-emulator build of the *same kernel sources* through ``_install_test_backend``.  That
+hook refuses to work unless the process was started with ``FFNO_ALLOW_TEST_BACKEND=1`` -- tests/conftest.py
+sets it, nothing in the package does -- so no stray call can re-route the operators of a product run.)
 """
 from __future__ import annotations
 
@@ -33,13 +34,16 @@ def get_lib() -> ctypes.CDLL:
         return _lib
     with _lock:
         if _lib is None:
-            if not os.path.exists(LIB_PATH):
+            from . import build as _build
+            if not os.path.exists(LIB_PATH) or _build.is_stale():
+                # absent, or built from different kernel sources / ABI header than the ones in this tree (a stale .so would
+                # silently run old kernels behind new host code): rebuild, or refuse to load
                 try:
-                    from . import build as _build
                     _build.build(verbose=False)
                 except Exception as e:  # noqa: BLE001
+                    what = "is missing" if not os.path.exists(LIB_PATH) else "was built from other sources than this tree's"
                     raise FFNOLibraryError(
-                        f"libffno_hip.so is missing and could not be built ({e}). Run "
+                        f"libffno_hip.so {what} and could not be rebuilt ({e}). Run "
                         f"`python -m fourierflow_amd.build` (needs hipcc, ROCm >= 7.0). "
                         f"There is no CPU fallback for the F-FNO operators.") from e
             # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the
@@ -64,6 +68,9 @@ def is_test_backend() -> bool:
 def _install_test_backend(lib):
     """tests/ only: route the host code to the CPU wave-emulator build of the kernel sources."""
     global _test_backend
+    if lib is not None and os.environ.get("FFNO_ALLOW_TEST_BACKEND") != "1":
+        raise FFNOLibraryError("the emulator test backend can only be installed in a process started with "
+                               "FFNO_ALLOW_TEST_BACKEND=1 (tests/conftest.py); product runs use libffno_hip.so only")
     _test_backend = lib
 
 

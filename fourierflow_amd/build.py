@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libffno_hip.so")
-SOURCES = ["spectral.hip", "ff.hip", "ffx.hip", "pointwise.hip", "velocity.hip", "spectral2d.hip", "plin.hip"]
+SOURCES = ["spectral.hip", "spectral_x3.hip", "ff.hip", "ffx.hip", "pointwise.hip", "velocity.hip", "spectral2d.hip", "plin.hip"]
 ARCH = "gfx950"
 
 
@@ -33,10 +33,20 @@ def source_files():
 
 def _stamp() -> str:
     h = hashlib.sha256()
-    for p in sorted(source_files() + [os.path.join(CSRC, "ffno_device.h"), os.path.join(ROOT, "include", "ffno.h")]):
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]
+    for p in sorted(source_files() + headers + [os.path.join(ROOT, "include", "ffno.h")]):
         with open(p, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """True when the library on disk was built from other sources than the ones in this tree (stamp mismatch / no stamp)."""
+    stamp_file = LIB + ".stamp"
+    try:
+        return not (os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == _stamp())
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:

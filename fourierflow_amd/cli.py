@@ -107,15 +107,22 @@ def _train_step(routine, kind, batch, epoch, step):
 
 def _valid_loss(routine, kind, batch) -> float:
     """`valid_loss` of the checkpoint file name: the routine's validation metric on one batch."""
-    with torch.no_grad():
-        if kind == "rollout":
-            return float(routine.validation_step(batch)["valid_loss"].item())
-        if kind == "mesh":
-            return float(routine.validation_step(batch).item())
-        tr = routine.trainer()
-        pred = routine._unshuffle(tr.engine.forward(routine._shuffle(routine._build_features(batch, add_noise=False)), False))
-        target = (batch["dy"] if routine.learn_difference else batch["y"]).contiguous()
-        return float(tr.loss_and_grad(pred, target, routine._affine_tensor())[0].item())
+    # the reference validates / tests under model.eval(): the Normalizer must NOT accumulate the validation batch into its
+    # running statistics (normalizer.py:45-49) -- and they must not leak into the checkpoints written afterwards
+    was_training = routine.training
+    routine.eval()
+    try:
+        with torch.no_grad():
+            if kind == "rollout":
+                return float(routine.validation_step(batch)["valid_loss"].item())
+            if kind == "mesh":
+                return float(routine.validation_step(batch).item())
+            tr = routine.trainer()
+            pred = routine._unshuffle(tr.engine.forward(routine._shuffle(routine._build_features(batch, add_noise=False)), False))
+            target = (batch["dy"] if routine.learn_difference else batch["y"]).contiguous()
+            return float(tr.loss_and_grad(pred, target, routine._affine_tensor())[0].item())
+    finally:
+        routine.train(was_training)
 
 
 def _trial_dir(config_dir: Path, trial: int, checkpoint_id: Optional[str], create: bool) -> Path:
@@ -222,6 +229,7 @@ def test(config_path: Path, overrides: Optional[List[str]] = Argument(None), for
     ckpt = _best_checkpoint(config_path.parent, trial, cfg.get("checkpoint_path"))
     routine.load_lightning_model_state(str(ckpt), map_location)
     routine.to(dev)
+    routine.eval()       # trainer.test / predict run under eval(): no statistics accumulation (commands/test.py, normalizer.py:48)
     src = _Batches(routine, cfg, dev, data, batch_size, grid, size, seed=7231 + trial)
     it = iter(src)
     acc: Dict[str, float] = {}
@@ -252,6 +260,7 @@ def predict(config_path: Path, overrides: Optional[List[str]] = Argument(None), 
     ckpt = _best_checkpoint(config_path.parent, trial, cfg.get("checkpoint_path"))
     routine.load_lightning_model_state(str(ckpt), map_location)
     routine.to(dev)
+    routine.eval()       # trainer.test / predict run under eval(): no statistics accumulation (commands/test.py, normalizer.py:48)
     b = next(iter(_Batches(routine, cfg, dev, data, batch_size, grid, size, seed=7231 + trial)))
 
     def run():

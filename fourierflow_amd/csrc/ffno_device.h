@@ -6,31 +6,10 @@
 //   B operand: one float per lane, lane l holds B[k = l >> 5][j = l & 31]
 //   C/D      : 16 floats per lane, reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l & 31]
 //
-// With -DFFNO_EMU the same sources compile for the CPU wave emulator used by the tests
-// (tests/emu/hip_emu.h); that build is test infrastructure and is never loaded by the package.
+// Compiler / ISA specifics live in <ffno_platform.h> (csrc/ffno_platform.h: gfx950).
 #pragma once
 
-#ifdef FFNO_EMU
-#include "hip_emu.h"
-#define FFNO_DYN_SMEM(name) char* name = (char*)(((uintptr_t)emu::S().dyn_smem.data() + 63) & ~(uintptr_t)63)
-#define FFNO_UNROLL
-#define FFNO_NOUNROLL
-#define FFNO_SCHED_FENCE() ((void)0)
-#define FFNO_WAVES_PER_SIMD(n)
-#else
-#include <hip/hip_runtime.h>
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define FFNO_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#define FFNO_UNROLL _Pragma("unroll")
-#define FFNO_NOUNROLL _Pragma("unroll 1")
-// bounds live ranges: stops the scheduler from hoisting a whole unrolled loop's operand loads
-#define FFNO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// register budget = 512 / n VGPRs per lane, so that n waves (n/2 workgroups of 512 threads) share a SIMD
-#define FFNO_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
-#endif
-
-#include <stdint.h>
+#include <ffno_platform.h>
 
 // Every launch first clears any stale (non-sticky) error another HIP user of the process left behind
 // (e.g. PyTorch probing a capability), so the status a C-ABI entry point returns belongs to OUR launch.
@@ -45,21 +24,16 @@ namespace ffno {
 static constexpr int kWave = 64;
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-#ifdef FFNO_EMU
-    return emu::mfma_32x32x2(a, b, c);
-#else
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-#endif
+    return plat::mfma_f32_32x32x2(a, b, c);
 }
 
 // v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D reg r = D[4*(l>>4) + r][l & 15]
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-#ifdef FFNO_EMU
-    return emu::mfma_16x16x4(a, b, c);
-#else
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
+    return plat::mfma_f32_16x16x4(a, b, c);
 }
+
+// v_mfma_f32_16x16x32_bf16 (4 passes): A[i = l & 15][k = 8*(l>>4) + e], B[k = 8*(l>>4) + e][j = l & 15], D as mfma16
+__device__ __forceinline__ f32x4 mfma16_bf16(u32x4 a, u32x4 b, f32x4 c) { return plat::mfma_bf16_16x16x32(a, b, c); }
 
 // ---- split-bf16 ("bf16x3") matrix arithmetic ---------------------------------------------------------------
 // An fp32 value is the EXACT sum of three bf16 numbers (its 24 significant bits cut into 8+8+8 by truncation), so an
@@ -69,18 +43,12 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // accumulates them in fp32, so six of them do the work of eight v_mfma_f32_32x32x2_f32 in 3/8 of the time.
 //   A operand: 8 bf16 per lane, lane l holds A[i = l & 31][k = 8*(l>>5) + e];  B likewise B[k = 8*(l>>5) + e][j = l & 31];
 //   C/D as the fp32 forms.  A and B use the same (lane-half, slot) -> k map, so any k permutation applied to both cancels.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Bf3 {
     u32x4 hi, mid, lo;
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
-#ifdef FFNO_EMU
-    return emu::mfma_32x32x16_bf16(a, b, c);
-#else
-    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-#endif
+    return plat::mfma_bf16_32x32x16(a, b, c);
 }
 
 __device__ __forceinline__ f32x16 mfma_x3(const Bf3& a, const Bf3& b, f32x16 c) {
@@ -105,11 +73,7 @@ __device__ __forceinline__ float u2f(unsigned u) {
 }
 // upper halves of two words -> one word (element 0 = x0 in the low half)
 __device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) {
-#ifdef FFNO_EMU
-    return (u0 >> 16) | (u1 & 0xffff0000u);
-#else
-    return __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-#endif
+    return plat::pack_hi16(u0, u1);
 }
 // exact 3-way truncation split of a pair of floats into packed bf16 pairs
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {

@@ -1,0 +1,63 @@
+// Platform layer of the F-FNO kernels: gfx950 (CDNA4) through HIP.  Everything the kernel sources need from the
+// compiler / ISA is named here once: vector types, the MFMA builtins, the few bit-field instructions, scheduling
+// pragmas, dynamic-LDS plumbing.  The kernel sources include it as <ffno_platform.h> (include-path lookup), so a test
+// harness can put a different implementation of the SAME names first on the include path (tests/emu/ does, to run
+// the kernels lane by lane on the CPU); no such switch exists in this tree.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define FFNO_BUILD_TARGET "gfx950"
+#define FFNO_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define FFNO_UNROLL _Pragma("unroll")
+#define FFNO_NOUNROLL _Pragma("unroll 1")
+// bounds live ranges: stops the scheduler from hoisting a whole unrolled loop's operand loads
+#define FFNO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// register budget = 512 / n VGPRs per lane, so that n waves (n/2 workgroups of 512 threads) share a SIMD
+#define FFNO_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+
+namespace ffno {
+namespace plat {
+
+// v_mfma_f32_32x32x2_f32
+__device__ __forceinline__ f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x4_f32
+__device__ __forceinline__ f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_32x32x16_bf16 (8 bf16 per lane and operand, packed in four dwords)
+__device__ __forceinline__ f32x16 mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x32_bf16
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// upper halves of two words -> one word (u0's in the low half): v_perm_b32
+__device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }
+// (acc << 1) | msb(x): v_alignbit_b32
+__device__ __forceinline__ uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return __builtin_amdgcn_alignbit(acc, x, 31); }
+// all-ones if bit b of x is set, else 0: v_bfe_i32
+__device__ __forceinline__ uint32_t bit_to_mask(uint32_t x, int b) { return (uint32_t)__builtin_amdgcn_sbfe((int)x, b, 1); }
+// sin / cos of pi * x
+__device__ __forceinline__ void sincos_pi(float x, float& s, float& c) { sincospif(x, &s, &c); }
+
+}  // namespace plat
+
+// dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel
+template <class K>
+static inline int allow_dynamic_lds(K kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return 0;
+    return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+}  // namespace ffno

@@ -91,19 +91,11 @@ __device__ __forceinline__ Bf3 load_frag(const u32x4* __restrict__ pk, int frag,
 
 // (acc << 1) | msb(x)
 __device__ __forceinline__ uint32_t push_sign(uint32_t acc, uint32_t x) {
-#ifdef FFNO_EMU
-    return (acc << 1) | (x >> 31);
-#else
-    return __builtin_amdgcn_alignbit(acc, x, 31);
-#endif
+    return plat::shift_in_msb(acc, x);
 }
 // all-ones if bit b of x is set, else 0
 __device__ __forceinline__ uint32_t bit_mask(uint32_t x, int b) {
-#ifdef FFNO_EMU
-    return 0u - ((x >> b) & 1u);
-#else
-    return (uint32_t)__builtin_amdgcn_sbfe((int)x, b, 1);
-#endif
+    return plat::bit_to_mask(x, b);
 }
 
 // three planes at the same offset of an LDS tile

@@ -527,11 +527,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
 using namespace ffno;
 
 extern "C" const char* ffno_build_target(void) {
-#ifdef FFNO_EMU
-    return "emu";
-#else
-    return "gfx950";
-#endif
+    return FFNO_BUILD_TARGET;
 }
 extern "C" int ffno_abi_version(void) { return 1; }
 

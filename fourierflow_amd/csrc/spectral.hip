@@ -13,37 +13,10 @@
 // channels-last [B][M][N][C]; spectra are mode-major spec[k][line][re/im][c] so stage B reads one
 // contiguous [lines][2C] panel per mode.
 #include "ffno_device.h"
+#include "ffno_lines.h"
 #include "ffno.h"
 
 namespace ffno {
-
-// ---- line addressing ---------------------------------------------------------------------------
-// axis 0: lines (b,m), element n at stride C.      axis 1: lines (b,n), element m at stride N*C.
-struct LineMap {
-    int lines_per_group;   // axis0: R (one group)   axis1: N
-    long group_stride;     // axis0: 0               axis1: M*N*C
-    long line_stride;      // axis0: N*C             axis1: C
-    long elem_stride;      // axis0: C               axis1: N*C
-    __host__ __device__ long base(int r) const {
-        return (long)(r / lines_per_group) * group_stride + (long)(r % lines_per_group) * line_stride;
-    }
-};
-
-static inline LineMap make_linemap(int axis, int B, int M, int N, int C) {
-    LineMap m;
-    if (axis == 0) {
-        m.lines_per_group = B * M;
-        m.group_stride = 0;
-        m.line_stride = (long)N * C;
-        m.elem_stride = C;
-    } else {
-        m.lines_per_group = N;
-        m.group_stride = (long)M * N * C;
-        m.line_stride = C;
-        m.elem_stride = (long)N * C;
-    }
-    return m;
-}
 
 template <int CT>
 struct ColVec;
@@ -975,11 +948,7 @@ __global__ __launch_bounds__(256) void dct_rotate_kernel(float* __restrict__ spe
     // grid.y = mode k: one sincos per thread; four channels of the re and of the im part per step (C % 4 == 0)
     const int k = blockIdx.y;
     float sn, cs;
-#ifdef FFNO_EMU
-    sn = (float)sin(3.14159265358979323846 * k / (2.0 * L)), cs = (float)cos(3.14159265358979323846 * k / (2.0 * L));
-#else
-    sincospif((float)k / (float)(2 * L), &sn, &cs);
-#endif
+    plat::sincos_pi((float)k / (float)(2 * L), sn, cs);
     const int C4 = C / 4;
     const long n4 = RC / 4;                          // float4 groups per mode and part
     float* base = spec + (long)k * RC * 2;           // [r][re/im][c]

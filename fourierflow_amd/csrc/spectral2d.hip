@@ -20,12 +20,7 @@
 namespace ffno {
 
 __device__ __forceinline__ void sincos_2pi_frac2(int k, int n, float& s, float& c) {   // angle = 2 pi k / n, 0 <= k < n
-#ifdef FFNO_EMU
-    const double a = 2.0 * 3.14159265358979323846 * (double)k / (double)n;
-    s = (float)sin(a), c = (float)cos(a);
-#else
-    sincospif(2.f * (float)k / (float)n, &s, &c);
-#endif
+    plat::sincos_pi(2.f * (float)k / (float)n, s, c);
 }
 
 __device__ __forceinline__ int kx_of(int kxp, int K, int M) { return kxp < K ? kxp : M - 2 * K + kxp; }
@@ -228,13 +223,10 @@ extern "C" int ffno_cdft_rows2(const float* in, float* out, int B, int M, int C,
     const dim3 grid((unsigned)((long)Ky * B)), block(256);
     const size_t smem = sizeof(float) * (2 * (size_t)M + (inverse ? (size_t)2 * Kx * 2 * C : (size_t)M * 2 * C));
     if (smem > 150 * 1024) return FFNO_EUNSUPPORTED;    // the staged slab must fit LDS (M <= 288 at C = 64)
-#ifndef FFNO_EMU
-    if (smem > 48 * 1024) {     // dynamic LDS beyond the default window needs an explicit opt-in
-        hipError_t e = hipFuncSetAttribute(inverse ? (const void*)cdft_inv_kernel : (const void*)cdft_fwd_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
+    {     // dynamic LDS beyond the default window needs an explicit opt-in
+        const int e = inverse ? allow_dynamic_lds(cdft_inv_kernel, smem) : allow_dynamic_lds(cdft_fwd_kernel, smem);
+        if (e) return e;
     }
-#endif
     if (inverse)
         FFNO_LAUNCH(cdft_inv_kernel, grid, block, smem, (hipStream_t)stream, in, out, B, M, C, Kx);
     else

@@ -1,0 +1,407 @@
+// Fused spectral branch of the factorized Fourier layer on the bf16 matrix cores at fp32 accuracy ("bf16x3").
+//
+// Same operator as spectral_fused_kernel (spectral.hip): SpectralConv2d.forward_fourier along ONE axis
+// (reference fourierflow/modules/factorized_fno/grid_2d.py:58-72 / :76-90: rfft(norm='ortho') -> [:K] -> complex einsum with
+// fourier_weight -> zero-filled irfft) and its adjoint, with the spectrum tile resident in LDS -- rebuilt around three
+// measurements of round 1 (profiles/r01_v8_kernel_stats.md):
+//   * the kernel is MATRIX-bound on the fp32 MFMA (27 us of v_mfma_f32_32x32x2_f32 per paired launch at batch 32): every
+//     product here is six v_mfma_f32_32x32x16_bf16 over exact three-way bf16 splits of both operands (ffno_device.h),
+//     3/8 of the matrix time at unchanged accuracy.  The DFT matrices are split once per wave and kept in registers; the
+//     activations are split as they arrive from HBM / LDS;
+//   * every 8-line workgroup streamed all 512 KiB of weight planes from L2 (134 MB of L2 -> CU traffic per launch):
+//     a workgroup now owns 16 lines, so the per-mode mix is a full 32-row tile ((line, re/im) pairs) and the weight stream
+//     per line halves; the weights arrive pre-split and pre-permuted in MFMA fragment order (ffno_spectral_x3_pack), one
+//     coalesced 16-byte load per lane, plane and fragment, double-buffered one k-step ahead;
+//   * a wave's input line was requested in four dependent trips: the whole line (16 KiB) is now requested at once, and the
+//     second line of the wave is requested while the first is being transformed.
+//
+// Workgroup = 8 waves = 16 lines of one axis.  LDS tile XS[line][kk = 2k + ri][c] (row stride 68 floats, line stride
+// 32 * 68 + 8: the 16-byte row reads of phase 2 are bank-conflict free).
+//   phase 1  wave w: truncated DFT of lines 2w, 2w+1:   X[kk][c] = sum_n F[kk][n] x[n][c]        (A = F in registers)
+//   phase 2  wave w: modes k = w, w + 8: in-place channel mix, rows = (line, re/im) of all 16 lines:
+//            P1 = X Wr, P2 = X Wi;  Yr = P1[re] - P2[im], Yi = P2[re] + P1[im]   (adjoint: planes of W^T, signs flipped)
+//   phase 3  wave w: zero-padded inverse DFT of lines 2w, 2w+1 with the accumulate / residual epilogue.
+// Column tile ct of every 32-column MFMA tile holds channels c = 2 j + ct (j = lane & 31), so a lane owns two adjacent
+// channels: 8-byte global loads / stores and LDS accesses throughout.
+#include "ffno_device.h"
+#include "ffno_lines.h"
+#include "ffno.h"
+
+namespace ffno {
+
+struct X3Cfg {
+    static constexpr int C = 64;
+    static constexpr int NL = 16;              // lines per workgroup
+    static constexpr int NW = 8;               // waves per workgroup (two lines each)
+    static constexpr int KK = 32;              // (mode, re/im) rows per line: K <= 16
+    static constexpr int RS = 68;              // row stride (floats): +4 shifts the re / im rows of a line by 4 banks
+    static constexpr int LSF = KK * RS + 8;    // line stride (floats): +8 shifts consecutive lines by 8 banks
+    static constexpr int FRAG = 3 * 64;        // u32x4 per packed fragment (three planes x 64 lanes)
+    static constexpr int MODE_FRAGS = 16;      // per mode: 4 k-steps x (2 planes x 2 column tiles)
+};
+
+struct X3Args {
+    const float* in;
+    float* out;
+    const float* resid;
+    float* spec_save;
+    const u32x4* wpk;     // packed weights (ffno_spectral_x3_pack), NULL = no mix ('low-pass')
+    const float* tw;
+    int R, L, K;
+    LineMap lm;
+    int fwd_ck, inv_ck, conj_t, accumulate;
+};
+
+// ---- weight packing --------------------------------------------------------------------------------------------------
+// planes[k][p][i][o] (p = re | im; ffno_fw_pack: forward planes, or the transposed planes for the adjoint) ->
+// fragment (k, st, p, t), lane (j, half), slot e  <-  planes[k][p][i = 16 st + 8 half + e][o = 2 j + t], split in three.
+struct X3PackDesc {
+    const float* planes;
+    u32x4* dst;
+    int K, pad;
+};
+
+__global__ __launch_bounds__(256) void x3_pack_kernel(const X3PackDesc* __restrict__ descs) {
+    constexpr int C = X3Cfg::C;
+    const X3PackDesc d = descs[blockIdx.y];
+    const int nfrag = d.K * X3Cfg::MODE_FRAGS;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nfrag * 64) return;
+    const int frag = t >> 6, lane = t & 63, j = lane & 31, half = lane >> 5;
+    const int pt = frag & 3, st = (frag >> 2) & 3, k = frag >> 4;
+    const int p = pt >> 1, tt = pt & 1;
+    const float* src = d.planes + ((long)(k * 2 + p) * C + (16 * st + 8 * half)) * C + 2 * j + tt;
+    float v[8];
+    FFNO_UNROLL
+    for (int e = 0; e < 8; ++e) v[e] = src[(long)e * C];
+    const Bf3 f = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    d.dst[(frag * 3 + 0) * 64 + lane] = f.hi;
+    d.dst[(frag * 3 + 1) * 64 + lane] = f.mid;
+    d.dst[(frag * 3 + 2) * 64 + lane] = f.lo;
+}
+
+__device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int frag, int lane) {
+    Bf3 f;
+    f.hi = pk[(frag * 3 + 0) * 64 + lane];
+    f.mid = pk[(frag * 3 + 1) * 64 + lane];
+    f.lo = pk[(frag * 3 + 2) * 64 + lane];
+    return f;
+}
+
+// ---- the branch --------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
+    using F = X3Cfg;
+    constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
+    __shared__ __attribute__((aligned(16))) float XS[F::NL * F::LSF];
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+
+    const float* __restrict__ in = A.in;
+    const int R = A.R, L = A.L, K = A.K;
+    const LineMap lm = A.lm;
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int lw = 2 * wave;                       // first of this wave's two lines inside the tile
+    const int line0 = bidx * F::NL + lw;
+    const bool live0 = line0 < R, live1 = line0 + 1 < R;
+    // Addresses = wave-uniform part (tensor base + sample index x element stride: scalar registers) + a 32-bit per-lane byte
+    // offset (line base + the lane's channel pair + its half-wave's sample / row offset): one VGPR per line instead of a
+    // 64-bit address per access.  (The host side refuses tensors of 4 GiB or more.)
+    const long es = lm.elem_stride;
+    // Lines past the end of the axis read (and transform) line R - 1 again: rows of the tile are independent, and nothing of
+    // a dead line is ever stored.
+    const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + 2 * j) * 4);
+    const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + 2 * j) * 4);
+    __syncthreads();
+
+    // ---------------- phase 1: truncated forward DFT of the wave's two lines ----------------
+    {
+        const int kk = j, k = kk >> 1, ri = kk & 1;              // A-operand row of this lane
+        const bool rowok = kk < 2 * K;
+        const float ck = (A.fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
+        const int km = rowok ? k : 0;
+
+        float2 raw[4][8];      // one 64-sample chunk of one line: k-step u, slot e -> sample 16 (4 chunk + u) + 8 half + e
+        // samples past the end of the line (L not a multiple of 16) re-read sample L - 1: finite data under a zero of F
+        const unsigned esb = (unsigned)(es * 4);
+        auto load_rows = [&](int chunk, int u, unsigned lo) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
+                raw[u][e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(in) + (lo + (unsigned)n * esb));
+            }
+        };
+        // DFT-matrix fragments of one chunk (exact three-way splits; built while the loads are in flight).  The table index
+        // k n mod L advances incrementally: +k per sample, +8 k across the other half-wave's samples.
+        Bf3 Ff[4];
+        const int k8 = (km * 8) % L;
+        auto build_F = [&](int chunk) {
+            int idx = (km * (64 * chunk + 8 * half)) % L;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * (4 * chunk + u) + 8 * half + e;
+                    f[e] = n < L ? amul * tws[tbase + idx] : 0.f;
+                    idx += km;
+                    if (idx >= L) idx -= L;
+                }
+                idx += k8;
+                if (idx >= L) idx -= L;
+                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+            }
+        };
+        const int nchunks = (L + 63) >> 6;
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u, lo0);
+        build_F(0);
+        FFNO_UNROLL
+        for (int ln = 0; ln < 2; ++ln) {
+            f32x16 acc0 = zero16(), acc1 = zero16();
+            FFNO_NOUNROLL
+            for (int chunk = 0; chunk < nchunks; ++chunk) {
+                if (nchunks > 1 && (ln | chunk)) build_F(chunk);      // one chunk (L <= 64): the fragments serve both lines
+                // as each k-step's rows are consumed, the rows of the next (chunk, line) are requested into the same registers
+                const bool more = chunk + 1 < nchunks;
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) {
+                    const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
+                                            raw[u][6].x, raw[u][7].x);
+                    const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
+                                            raw[u][6].y, raw[u][7].y);
+                    if (more)
+                        load_rows(chunk + 1, u, ln ? lo1 : lo0);
+                    else if (ln == 0)
+                        load_rows(0, u, lo1);
+                    acc0 = mfma_x3(Ff[u], b0, acc0);
+                    acc1 = mfma_x3(Ff[u], b1, acc1);
+                }
+            }
+            float* xs = XS + (lw + ln) * LSF + 2 * j;
+            const bool live = ln ? live1 : live0;
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row = drow(r, half);
+                if (row < 2 * K) {
+                    const float2 v = make_float2(acc0[r], acc1[r]);
+                    *reinterpret_cast<float2*>(xs + row * RS) = v;
+                    if (A.spec_save && live)
+                        *reinterpret_cast<float2*>(A.spec_save + (((long)(row >> 1) * R + line0 + ln) * 2 + (row & 1)) * C + 2 * j) = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: per-mode channel mix of all 16 lines, in place ----------------
+    if (A.wpk) {
+        const float* arow = XS + (j >> 1) * LSF + (j & 1) * RS + 8 * half;     // MFMA row j = (line j >> 1, part j & 1)
+        for (int k = wave; k < K; k += F::NW) {
+            const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * F::FRAG;
+            // weight fragments: a ring of four, requested four products (24 MFMAs) before they are used
+            Bf3 ring[4];
+            FFNO_UNROLL
+            for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(wk, f, lane);
+            Bf3 a[4];
+            FFNO_UNROLL
+            for (int st = 0; st < 4; ++st) {
+                const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st);
+                const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st + 4);
+                a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+            }
+            f32x16 p[4];
+            FFNO_UNROLL
+            for (int pt = 0; pt < 4; ++pt) p[pt] = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < 4; ++st) {
+                FFNO_UNROLL
+                for (int pt = 0; pt < 4; ++pt) {
+                    const Bf3 b = ring[pt];
+                    if (st < 3) ring[pt] = x3_load_frag(wk, (st + 1) * 4 + pt, lane);
+                    p[pt] = mfma_x3(a[st], b, p[pt]);
+                }
+            }
+            // D rows 2q, 2q+1 of this lane = (re, im) of line (q & 1) + 4 (q >> 1) + 2 half
+            FFNO_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                const int line = (q & 1) + 4 * (q >> 1) + 2 * half;
+                float yr[2], yi[2];
+                FFNO_UNROLL
+                for (int t = 0; t < 2; ++t) {
+                    const float p1r = p[t][2 * q], p1i = p[t][2 * q + 1];
+                    const float p2r = p[2 + t][2 * q], p2i = p[2 + t][2 * q + 1];
+                    if (A.conj_t == 0) {
+                        yr[t] = p1r - p2i;
+                        yi[t] = p2r + p1i;
+                    } else {
+                        yr[t] = p1r + p2i;
+                        yi[t] = p1i - p2r;
+                    }
+                }
+                float* dst = XS + line * LSF + 2 * k * RS + 2 * j;
+                *reinterpret_cast<float2*>(dst) = make_float2(yr[0], yr[1]);
+                *reinterpret_cast<float2*>(dst + RS) = make_float2(yi[0], yi[1]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 3: zero-padded inverse DFT of the wave's two lines ----------------
+    {
+        const int RTtot = (L + 31) >> 5;
+        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        FFNO_NOUNROLL
+        for (int rt0 = 0; rt0 < RTtot; rt0 += 2) {
+            // inverse-DFT matrix fragments of two 32-row output tiles: row n, slot e of k-step st <-> kk = (mode t, part)
+            Bf3 G[2][2];
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                const int n = 32 * (rt0 + q) + j;
+                FFNO_UNROLL
+                for (int st = 0; st < 2; ++st) {
+                    float g[8];
+                    const int nm = n < L ? n : 0;
+                    int idx = (nm * (8 * st + 4 * half)) % L;          // n t mod L, advanced by n per mode
+                    FFNO_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+                        const float ck = (A.inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                        g[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tws[(part ? L : 0) + idx] : 0.f;
+                        if (part) {
+                            idx += nm;
+                            if (idx >= L) idx -= L;
+                        }
+                    }
+                    G[q][st] = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                }
+            }
+            FFNO_UNROLL
+            for (int ln = 0; ln < 2; ++ln) {
+                if (!(ln ? live1 : live0)) continue;
+                const unsigned lo = (ln ? lo1 : lo0) + hoff;
+                // B operands: the line's spectrum, split: slot e of k-step st <-> row kk = 16 st + 8 half + e
+                Bf3 y[2][2];
+                const float* xs = XS + (lw + ln) * LSF + 2 * j;
+                FFNO_UNROLL
+                for (int st = 0; st < 2; ++st) {
+                    float2 v[8];
+                    FFNO_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        const int kk = 16 * st + 8 * half + e;
+                        v[e] = make_float2(0.f, 0.f);
+                        if (kk < 2 * K) v[e] = *reinterpret_cast<const float2*>(xs + kk * RS);
+                    }
+                    y[st][0] = split3_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+                    y[st][1] = split3_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+                }
+                FFNO_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    if (rt0 + q >= RTtot) continue;
+                    f32x16 o0 = zero16(), o1 = zero16();
+                    FFNO_UNROLL
+                    for (int st = 0; st < 2; ++st) {
+                        o0 = mfma_x3(G[q][st], y[st][0], o0);
+                        o1 = mfma_x3(G[q][st], y[st][1], o1);
+                    }
+                    FFNO_UNROLL
+                    for (int r = 0; r < 16; ++r) {
+                        const int nu = 32 * (rt0 + q) + (r & 3) + 8 * (r >> 2);     // uniform part of the output sample index
+                        if (nu + 4 * half < L) {
+                            const long uo = (long)nu * es * 4;
+                            float2 o = make_float2(o0[r], o1[r]);
+                            if (A.accumulate) {
+                                const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lo);
+                                o.x += pv.x, o.y += pv.y;
+                            }
+                            if (A.resid) {
+                                const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.resid) + uo + lo);
+                                o.x += pv.x, o.y += pv.y;
+                            }
+                            *reinterpret_cast<float2*>(reinterpret_cast<char*>(A.out) + uo + lo) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) { spectral_x3_body(a, blockIdx.x); }
+
+// Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
+// workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
+// weights of ONE branch only; otherwise [0, n0) run a and the rest b.
+__global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave) {
+    const int w = blockIdx.x;
+    const bool second = interleave ? (w & 1) : (w >= n0);
+    const int idx = interleave ? (w >> 1) : (second ? w - n0 : w);
+    spectral_x3_body(second ? b : a, idx);
+}
+
+static inline int x3_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
+}  // namespace ffno
+
+using namespace ffno;
+
+extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && 2 * K <= X3Cfg::KK && L >= 2 && L <= 2048) ? 1 : 0; }
+
+extern "C" size_t ffno_spectral_x3_pack_bytes(int C, int K) {
+    return C == X3Cfg::C ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
+}
+
+extern "C" int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream) {
+    if (!descs_dev || n <= 0 || max_K <= 0) return FFNO_EINVAL;
+    if (C != X3Cfg::C || 2 * max_K > X3Cfg::KK) return FFNO_EUNSUPPORTED;
+    static_assert(sizeof(ffno_x3pack_desc) == sizeof(X3PackDesc), "descriptor layout");
+    const int threads = max_K * X3Cfg::MODE_FRAGS * 64;
+    FFNO_LAUNCH(x3_pack_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+                reinterpret_cast<const X3PackDesc*>(descs_dev));
+    return x3_status();
+}
+
+static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose) {
+    if (!b || !b->in || !b->out || !b->tw || b->B <= 0 || b->M <= 0 || b->N <= 0 || b->K <= 0 || (b->axis != 0 && b->axis != 1))
+        return FFNO_EINVAL;
+    const int L = b->axis == 0 ? b->N : b->M;
+    const int R = b->axis == 0 ? b->B * b->M : b->B * b->N;
+    if (b->K > L / 2 + 1) return FFNO_EMODES;
+    if (!ffno_spectral_x3_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
+    a = X3Args{b->in, b->out, b->resid, b->spec_save, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
+               make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate};
+    return FFNO_OK;
+}
+
+extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
+                                void* stream) {
+    X3Args a;
+    const int rc = x3_args(a, br, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
+    if (rc) return rc;
+    const dim3 grid((a.R + X3Cfg::NL - 1) / X3Cfg::NL), block(512);
+    FFNO_LAUNCH(spectral_x3_kernel, grid, block, sizeof(float) * 2 * a.L, (hipStream_t)stream, a);
+    return x3_status();
+}
+
+extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int C, int scale_ck_fwd,
+                                     int apply_ck_inv, int conj_transpose, int interleave, void* stream) {
+    if (!ba || !bb) return FFNO_EINVAL;
+    if (ba->out == bb->out) return FFNO_EINVAL;      // concurrent workgroups: the branches may not share an output
+    X3Args a, b;
+    int rc = x3_args(a, ba, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
+    if (rc) return rc;
+    rc = x3_args(b, bb, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
+    if (rc) return rc;
+    const int n0 = (a.R + X3Cfg::NL - 1) / X3Cfg::NL, n1 = (b.R + X3Cfg::NL - 1) / X3Cfg::NL;
+    const dim3 grid(n0 + n1), block(512);
+    const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
+    FFNO_LAUNCH(spectral_x3_pair_kernel, grid, block, smem, (hipStream_t)stream, a, b, n0, (interleave && n0 == n1) ? 1 : 0);
+    return x3_status();
+}

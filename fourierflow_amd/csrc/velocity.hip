@@ -19,12 +19,7 @@
 namespace ffno {
 
 __device__ __forceinline__ void sincos_2pi_frac(int k, int n, float& s, float& c) {   // angle = 2 pi k / n, 0 <= k < n
-#ifdef FFNO_EMU
-    const double a = 2.0 * 3.14159265358979323846 * (double)k / (double)n;
-    s = (float)sin(a), c = (float)cos(a);
-#else
-    sincospif(2.f * (float)k / (float)n, &s, &c);
-#endif
+    plat::sincos_pi(2.f * (float)k / (float)n, s, c);
 }
 
 // A[b][x][n] (complex) = sum_y w[b][x][y] e^{-2 pi i n y / Y};  one block per (b, x) row, LDS: row + tables

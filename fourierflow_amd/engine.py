@@ -176,6 +176,12 @@ class FFNOEngine:
         # while staging (ffno_ffx_fwd2 / _bwd_data2).  Needs the split-bf16 feed-forward, no fork heads, and both axes on
         # the fused kernel with the same [B, M, N] view (the 2-D operators).
         self.concurrent_branches = True
+        # fused branches on the bf16 matrix cores at fp32 accuracy (spectral_x3.hip: 16 lines per workgroup, packed pre-split
+        # weights) for the axes the library takes (C = 64, K <= 16) with at least ``x3_min_lines`` lines -- below that the
+        # 8-line fp32-MFMA kernel spreads a small launch (batch-1 rollout: 64 lines per axis) over twice as many CUs
+        self.use_x3 = True
+        self.x3_min_lines = 512
+        self.x3_interleave = 1       # paired launch: even workgroups branch a, odd ones branch b (one branch's weights per XCD)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         # backward: FF weight-gradient kernels on a side stream next to the spectral adjoint.  Measured on MI355X
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
@@ -207,7 +213,7 @@ class FFNOEngine:
         return [w for w in range(n) if w not in pair], pair
 
     def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st, acc0: int = 0,
-              fused: bool = True):
+              fused: bool = True, x3: bool = False):
         """Branches of views v0 and v1 side by side -- ONE launch when both are fused, three paired stage launches else:
         dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = branch1(src)."""
         lib = _lib.get_lib()
@@ -226,6 +232,10 @@ class FFNOEngine:
                                v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
         bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)),
                                v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0)
+        if x3:       # planes0 / planes1 are the packed split-bf16 sets
+            self._k(name, lib.ffno_spectral_x3_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj,
+                    int(self.x3_interleave), st)
+            return
         self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
 
     def _ffx(self) -> bool:
@@ -280,6 +290,16 @@ class FFNOEngine:
         plane_modes = [2 * self.K * self.K] if self.spectral == "plus" else list(self.Ks)   # plus: one joint (ky, kx') set
         self.planes = [[(torch.empty(2 * K * self.C * self.C, **f32), torch.empty(2 * K * self.C * self.C, **f32))
                         for K in plane_modes] for _ in range(max(len(self._fw_sets), 1))]
+        # packed split-bf16 twins of the planes for the x3 branch kernel: xplanes[set][w] = (forward, adjoint) or None
+        lib = _lib.get_lib()
+        self.xplanes = [[None] * len(plane_modes) for _ in self.planes]
+        if self.spectral == "factorized" and self.mode == "full":
+            for si in range(len(self.planes)):
+                for w, K in enumerate(plane_modes):
+                    nb = int(lib.ffno_spectral_x3_pack_bytes(self.C, K)) if lib.ffno_spectral_x3_supported(self.C, K, 2 * K) else 0
+                    if nb:
+                        self.xplanes[si][w] = tuple(torch.empty(nb // 4, dtype=torch.int32, device=dev) for _ in range(2))
+        self._x3pack_sig = None
         self._ws_key = None
         self._ws_cache = {}
         self._tw = {}
@@ -483,6 +503,17 @@ class FFNOEngine:
                 self._fwpack_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
                 self._fwpack_sig, self._fwpack_n = sig, len(descs)
             self._k("fw_pack", lib.ffno_fw_pack_batched, _p(self._fwpack_dev), self._fwpack_n, self.C, max(self.Ks), st)
+            if self.use_x3 and any(x is not None for row in self.xplanes for x in row):
+                sig = tuple((self.planes[i][w][d].data_ptr(), xp[d].data_ptr()) for i, row in enumerate(self.xplanes)
+                            for w, xp in enumerate(row) if xp is not None for d in range(2))
+                if sig != self._x3pack_sig:
+                    descs = [_capi.X3PackDesc(self.planes[i][w][d].data_ptr(), xp[d].data_ptr(), self.Ks[w], 0)
+                             for i, row in enumerate(self.xplanes) for w, xp in enumerate(row) if xp is not None
+                             for d in range(2)]
+                    arr = (_capi.X3PackDesc * len(descs))(*descs)
+                    self._x3pack_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+                    self._x3pack_sig, self._x3pack_n = sig, len(descs)
+                self._k("fw_pack_x3", lib.ffno_spectral_x3_pack, _p(self._x3pack_dev), self._x3pack_n, self.C, max(self.Ks), st)
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         self._k("head_fold", lib.ffno_head_fold, _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                 _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, self.O, st)
@@ -536,6 +567,11 @@ class FFNOEngine:
             self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
                     _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
 
+    def _planes_for(self, si, w, adj: int, x3: bool):
+        if self.mode != "full":
+            return None
+        return self.xplanes[si][w][adj] if x3 else self.planes[si][w][adj]
+
     def _can_fuse(self, views):
         """Per axis: the fused branch kernel when its LDS tile holds (C, K_axis, L_axis), else the three stage kernels
         (e.g. plasticity: x with 32 modes is staged, y / z with 12 / 8 modes are fused)."""
@@ -547,7 +583,17 @@ class FFNOEngine:
         return [bool(self.use_fused and self.mode != "no-fourier" and lib.ffno_spectral_fused_supported(self.C, v.K, v.L))
                 for v in views]
 
-    def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st):
+    def _use_x3(self, views, fused):
+        """Per axis: the split-bf16 fused branch instead of the fp32-MFMA one (same operator, same flags)."""
+        lib = _lib.get_lib()
+        if not (self.use_x3 and self.spectral == "factorized" and self.mode != "no-fourier"):
+            return [False] * len(views)
+        P4 = 4 * self.C * max(v.Bv * v.Mv * v.Nv for v in views)       # 32-bit byte offsets inside the kernel
+        return [bool(fused[w] and v.R >= self.x3_min_lines and P4 < 2 ** 32 and lib.ffno_spectral_x3_supported(self.C, v.K, v.L)
+                     and (self.mode != "full" or self.xplanes[0][w] is not None)) for w, v in enumerate(views)]
+
+    def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st,
+                  x3: bool = False):
         """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint)."""
         lib = _lib.get_lib()
         C = self.C
@@ -571,6 +617,10 @@ class FFNOEngine:
             spec = save if save is not None else ws.SD
             self._k("dct_branch" + ("" if fwd else "(adj)"), lib.ffno_dct_branch, _p(src), _p(dst), resid, _p(spec), _p(ws.SY),
                     _p(planes), _p(self._twiddle(2 * v.L)), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, conj, accumulate, st)
+            return
+        if fused and x3:     # ``planes`` is the packed split-bf16 set
+            br = _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(tw), v.Bv, v.Mv, v.Nv, v.K, v.a01, accumulate)
+            self._k(name, lib.ffno_spectral_x3, ctypes.byref(br), C, ck_f, ck_i, conj, st)
             return
         if fused:
             self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
@@ -608,9 +658,11 @@ class FFNOEngine:
         P = ws.P
         self._prepare_weights(st)
         fused = self._can_fuse(ws.views)
+        x3 = self._use_x3(ws.views, fused)
         full = self.mode == "full"
         singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)
         conc = pair is not None
+        x3pair = bool(conc and x3[pair[0]] and x3[pair[1]])
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
@@ -632,14 +684,14 @@ class FFNOEngine:
                     if fused[w] and not save_for_backward:
                         keep = None
                     self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
-                                   self.planes[si][w][0] if full else None, True, int(nwrit > 0), fused[w], st)
+                                   self._planes_for(si, w, 0, x3[w]), True, int(nwrit > 0), fused[w], st, x3=x3[w])
                     nwrit += 1
                 if conc:
                     a, b = pair
                     keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in pair]
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
-                               self.planes[si][a][0] if full else None, self.planes[si][b][0] if full else None, True, st,
-                               acc0=int(nwrit > 0), fused=fused[a])
+                               self._planes_for(si, a, 0, x3pair), self._planes_for(si, b, 0, x3pair), True, st,
+                               acc0=int(nwrit > 0), fused=fused[a], x3=x3pair)
             l0, l1, b0, b1 = self._ff_weights(l)
             if conc:
                 self._k("ff_fwd", lib.ffno_ffx_fwd2, _p(s_l), _p(ws.T), _p(s_l) if save_for_backward else None,
@@ -659,6 +711,7 @@ class FFNOEngine:
         else:
             self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
         self._saved = (x, B, S, fused, conc) if save_for_backward else None
+        self._saved_x3 = (x3, x3pair)
         self.paired_last = conc      # (bench.py: which algorithmic-work table applies)
         return ws.Y.view(B, *S, self.O).clone()
 
@@ -669,6 +722,7 @@ class FFNOEngine:
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
         x, B, S, fused, conc = self._saved
+        x3, x3pair = self._saved_x3
         singles, pair = self._schedule(fused, self._workspace(B, S, True).views) if conc else (list(range(len(fused))), None)
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
@@ -743,7 +797,7 @@ class FFNOEngine:
                     for w, v in enumerate(ws.views):
                         keep = ws.SDall[w][l] if full else None
                         self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, None, keep,
-                                       self.planes[si][w][1] if full else None, False, int(w > 0), fused[w], st)
+                                       self._planes_for(si, w, 1, x3[w]), False, int(w > 0), fused[w], st, x3=x3[w])
                 cur = 1 - cur
                 continue
             if conc:
@@ -781,14 +835,14 @@ class FFNOEngine:
                 v = ws.views[w]
                 keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
                 self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if nwrit == 0 else None, keep,
-                               self.planes[si][w][1] if full else None, False, int(nwrit > 0), fused[w], st)
+                               self._planes_for(si, w, 1, x3[w]), False, int(nwrit > 0), fused[w], st, x3=x3[w])
                 nwrit += 1
             if conc:
                 a, b = pair
                 self._pair("spectral_fused(adj)", ws, ws.views[a], ws.views[b], ws.DS, g_out, ws.G1,
                            resid if nwrit == 0 else None, ws.SDall[a][l] if full else None, ws.SDall[b][l] if full else None,
-                           self.planes[si][a][1] if full else None, self.planes[si][b][1] if full else None, False, st,
-                           acc0=int(nwrit > 0), fused=fused[a])
+                           self._planes_for(si, a, 1, x3pair), self._planes_for(si, b, 1, x3pair), False, st,
+                           acc0=int(nwrit > 0), fused=fused[a], x3=x3pair)
             have_g1 = conc
             cur = 1 - cur
         if conc and have_g1:

@@ -68,6 +68,11 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         module = ctx.module
+        if ctx.needs_input_grad[0]:
+            # the reference modules are ordinary autograd modules and would propagate dL/dx; this operator's kernels stop at
+            # the lift's parameter gradients -- fail loudly instead of silently training upstream parameters without that term
+            raise RuntimeError(f"{type(module).__name__}: the gradient with respect to the INPUT tensor is not computed by the "
+                               "gfx950 kernel set (feed it a tensor that does not require grad)")
         if module._generation != ctx.gen:
             raise RuntimeError("FNOFactorized2DBlock: only the most recent forward pass can be back-propagated "
                                "(activations live in one pre-allocated workspace)")

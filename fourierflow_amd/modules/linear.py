@@ -3,9 +3,9 @@
 
 Same constructor, same parameter names (``weight_g`` [out,1], ``weight_v`` [out,in], ``bias`` -- or
 ``weight``/``bias`` without weight-norm) and the same initialisation (nn.Linear's kaiming-uniform,
-g = ||v|| per row), so reference checkpoints load with strict=True.  The arithmetic
-(W = g v/||v||, y = x W^T + b and its gradients) runs inside the HIP kernels of the owning block;
-a WNLinear is never evaluated on its own.
+g = ||v|| per row), so reference checkpoints load with strict=True.  Inside a block the arithmetic
+(W = g v/||v||, y = x W^T + b and its gradients) runs in the fused HIP kernels of the owner; called on
+its own, ``forward`` runs the weight-norm + pointwise-linear kernels (ops.wn_linear).
 """
 import math
 
@@ -37,10 +37,11 @@ class WNLinear(nn.Module):
             return self.weight
         return self.weight_v * (self.weight_g / self.weight_v.norm(2, dim=1, keepdim=True))
 
-    def forward(self, x):  # pragma: no cover - deliberate
-        raise NotImplementedError(
-            "WNLinear is evaluated inside the fused HIP kernels of its parent block (lift / feed-forward / head); "
-            "it has no standalone forward in fourierflow_amd.")
+    def forward(self, x):
+        """Stand-alone evaluation (reference linear.py:41-52): weight-norm kernel + pointwise-linear kernel, with autograd.
+        Inside the F-FNO block the same arithmetic runs in the fused lift / feed-forward / head kernels instead."""
+        from ..ops import wn_linear
+        return wn_linear(x, self)
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, wnorm={self.wnorm}"

@@ -108,6 +108,50 @@ def weight_norm_weight(lin) -> torch.Tensor:
     return _WeightNormFn.apply(lin.weight_g.contiguous(), lin.weight_v.contiguous())
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on [P, Cin] rows through the pointwise-linear kernels (csrc/plin.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        lib = _lib.get_lib()
+        P, Cin, Cout = x.shape[0], x.shape[1], W.shape[0]
+        out = torch.empty(P, Cout, dtype=torch.float32, device=x.device)
+        _capi.check(lib.ffno_plin_fwd(_p(x), Cin, _p(W), _p(b), None, _p(out), Cout, None, None, None, P, Cin, Cout, 0,
+                                      _lib.current_stream(x.device)), "plin_fwd")
+        ctx.save_for_backward(x, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        lib = _lib.get_lib()
+        P, Cin, Cout = x.shape[0], x.shape[1], W.shape[0]
+        st = _lib.current_stream(x.device)
+        g = g.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _capi.check(lib.ffno_plin_bwd_data(_p(g), Cout, None, _p(W), _p(dx), Cin, None, P, Cin, Cout, 0, 0, st), "plin_bwd_data")
+        part = torch.empty(int(lib.ffno_plin_wgrad_partial_floats(P, Cin, Cout)), dtype=torch.float32, device=x.device)
+        dW, db = torch.empty_like(W), torch.empty(Cout, dtype=torch.float32, device=x.device)
+        _capi.check(lib.ffno_plin_bwd_weights(_p(g), Cout, None, _p(x), Cin, _p(part), _p(dW), _p(db), P, Cin, Cout, 0, 0, st),
+                    "plin_bwd_weights")
+        return dx, dW, db
+
+
+def wn_linear(x, lin):
+    """``WNLinear.forward`` (reference linear.py:41-52 = nn.Linear with weight_norm): x [..., in] -> [..., out]."""
+    _lib.require_device_tensor(x, "WNLinear input")
+    if x.shape[-1] != lin.in_features:
+        raise ValueError(f"expected {lin.in_features} input features, got {tuple(x.shape)}")
+    if not _lib.get_lib().ffno_plin_supported(lin.in_features, lin.out_features):
+        raise NotImplementedError(f"stand-alone WNLinear({lin.in_features}, {lin.out_features}) is outside the pointwise-linear "
+                                  "kernel set (both widths <= 128); inside the F-FNO block the linears run in the fused kernels")
+    W = weight_norm_weight(lin)
+    y = _LinearFn.apply(x.reshape(-1, lin.in_features).contiguous(), W.contiguous(), lin.bias)
+    return y.view(*x.shape[:-1], lin.out_features)
+
+
 class _FeedForwardFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, resid, W1, b1, W2, b2):

@@ -40,7 +40,7 @@ class CheckpointMixin:
             'pytorch-lightning_version': 'ffno-mi355x',
             'state_dict': {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
             'optimizer_states': [{'flat_adamw': True, 'exp_avg': tr.m.cpu().clone(), 'exp_avg_sq': tr.v.cpu().clone(),
-                                  'step': int(tr.step_count), 'param_names': list(tr.engine.param_names)}],
+                                  'step': int(tr.opt_step), 'param_names': list(tr.engine.param_names)}],
             'lr_schedulers': [{'last_epoch': int(tr.step_count)}],
         }
 
@@ -69,9 +69,55 @@ class CheckpointMixin:
                 raise ValueError("checkpoint optimiser state belongs to a different parameter layout")
             tr.m.copy_(opt['exp_avg'])
             tr.v.copy_(opt['exp_avg_sq'])
-            tr.step_count = int(opt['step'])
-        else:       # a reference (torch.optim.AdamW) checkpoint: moments are per-parameter dicts -- restart the optimiser
+            tr.opt_step = int(opt['step'])
+            tr.step_count = int((ckpt.get('lr_schedulers') or [{}])[0].get('last_epoch', opt['step']))
+        elif opt is not None and self._load_reference_optimizer_state(tr, opt):
+            # a checkpoint written by the reference (torch.optim.AdamW.state_dict()): per-parameter moments, converted
+            tr.step_count = int((ckpt.get('lr_schedulers') or [{}])[0].get('last_epoch', ckpt.get('global_step', 0)))
+        else:
+            # no usable optimiser state: restart the moments AND the bias correction (a bias-correction step far from 0
+            # with zero moments would scale the first updates by ~1/(1-beta1) / sqrt(1/(1-beta2)) ~ 3x lr); the schedule
+            # keeps its position
             tr.m.zero_()
             tr.v.zero_()
+            tr.opt_step = 0
             tr.step_count = int(ckpt.get('global_step', 0))
         return {'epoch': int(ckpt.get('epoch', 0)), 'global_step': int(ckpt.get('global_step', 0))}
+
+    def _load_reference_optimizer_state(self, tr, opt) -> bool:
+        """torch.optim.Adam(W).state_dict() -> the flat moment buffers.  Parameter i of the optimiser is the i-th entry of
+        the routine's ``parameters()`` (routines/base.py:60-66 passes ``self.parameters()``), whose order the module
+        mirrors reproduce (same registration order, shared tensors reported once).  Returns False if the state does not fit."""
+        state = opt.get('state') if isinstance(opt, dict) else None
+        groups = opt.get('param_groups') if isinstance(opt, dict) else None
+        if not state or not groups:
+            return False
+        names = [n for n, _ in self.named_parameters()]
+        idx = [i for g in groups for i in g['params']]
+        if len(idx) != len(names):
+            return False
+        eng = tr.engine
+        prefix = next((p for p in ("conv.", "model.") if any(n.startswith(p) for n in names)), "")
+        step = None
+        tr.m.zero_()
+        tr.v.zero_()
+        for i, name in zip(idx, names):
+            short = name[len(prefix):] if name.startswith(prefix) else name
+            if short not in eng._offsets:       # a parameter the engine does not train (unused Fourier weights of mode != 'full')
+                continue
+            st = state.get(i)
+            if st is None:
+                continue
+            o, shape = eng._offsets[short], eng.param_shapes[short]
+            cnt = 1
+            for d in shape:
+                cnt *= d
+            if tuple(st['exp_avg'].shape) != tuple(shape):
+                return False
+            tr.m[o:o + cnt].copy_(st['exp_avg'].reshape(-1))
+            tr.v[o:o + cnt].copy_(st['exp_avg_sq'].reshape(-1))
+            step = int(st['step']) if step is None else step
+        if step is None:
+            return False
+        tr.opt_step = step
+        return True

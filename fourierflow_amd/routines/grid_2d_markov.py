@@ -133,6 +133,11 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         if acc:
             nz.unpack_state(state)
             nz._n_acc_host += 1.0
+            # data parallel: every rank accumulated its own shard -- sum the increments so all ranks normalise (and
+            # checkpoint) with the statistics of the GLOBAL batch; mean / std are re-derived by the next feature build
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                    torch.distributed.get_world_size() > 1:
+                nz.sync_across_ranks()
         return out
 
     def _velocity(self, x: torch.Tensor) -> torch.Tensor:

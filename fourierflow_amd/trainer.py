@@ -42,7 +42,9 @@ class FFNOTrainer:
         self.sched = (num_warmup_steps, num_training_steps, num_cycles)
         self.decoupled = decoupled     # True: torch.optim.AdamW; False: torch.optim.Adam (L2 weight decay)
         self.lr_factor = None          # optional callable() -> multiplier replacing the cosine schedule (StepLR per epoch)
-        self.step_count = 0
+        self.step_count = 0            # schedule position (LambdaLR's last_epoch = completed optimiser steps)
+        self.opt_step = 0              # Adam bias-correction step; differs from step_count only after a resume that had to
+                                       # restart the moments (routines/checkpoint.py)
         self.loss_scale = loss_scale   # StructuredMeshExperiment: gradients of loss * loss_scale (structured_mesh.py:29)
         self.pg = process_group
         self.world = 1
@@ -88,7 +90,7 @@ class FFNOTrainer:
             self._tmp = torch.empty(int(lib.ffno_lploss_tmp_floats(B, n)), dtype=torch.float32, device=pred.device)
         _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(self.loss), _p(self._gy), _p(self._tmp), B, n, float(self.loss_scale),
                                             _p(affine), _lib.current_stream(self.device)), "lploss")
-        return self.loss, self._gy
+        return self.loss, self._gy     # persistent buffers, overwritten by the next call (train_step returns a copy)
 
     def train_step(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """forward + relative-L2 loss + backward + (all-reduce) + AdamW + schedule; returns the loss (device)."""
@@ -102,14 +104,21 @@ class FFNOTrainer:
         """(all-reduce) + fused AdamW/cosine step on the flat buffers."""
         lib = _lib.get_lib()
         if self.world > 1:
+            # ONE collective per step, enqueued behind the backward kernels (stream-ordered by ProcessGroupNCCL).  Not split
+            # or overlapped on purpose: the buffer is complete only after the last backward kernel (weight-norm backward
+            # reads the reduced feed-forward gradients), 4.3 MB over xGMI is ~0.1-0.2 ms of an ~7 ms step, and a second
+            # collective would add its own launch latency (DESIGN.md section 5).
             torch.distributed.all_reduce(gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
         lr_t = self.current_lr()
         self.step_count += 1
+        self.opt_step += 1
+        # a fresh 4-byte tensor per step: the reference returns a new loss tensor each step and callers stack them
+        loss_out = loss.clone() if loss is not None else None
         fn = lib.ffno_adamw_flat if self.decoupled else lib.ffno_adam_flat
         _capi.check(fn(_p(self.pflat), _p(gflat), _p(self.m), _p(self.v), self.pflat.numel(), lr_t, self.betas[0],
-                       self.betas[1], self.eps, self.wd, self.step_count, 1.0 / self.world,
+                       self.betas[1], self.eps, self.wd, self.opt_step, 1.0 / self.world,
                        _lib.current_stream(self.device)), "adamw" if self.decoupled else "adam")
-        return loss
+        return loss_out
 
     @torch.no_grad()
     def predict(self, x: torch.Tensor) -> torch.Tensor:

@@ -150,6 +150,30 @@ typedef struct ffno_fused_branch {
 } ffno_fused_branch;
 int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                              int apply_ck_inv, int conj_transpose, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * The fused branch on the bf16 matrix cores at fp32 accuracy ("bf16x3": both operands of every product -- DFT matrices,
+ * activations, spectra, weights -- cut exactly into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per product block).
+ * Same operator and flags as ffno_spectral_fused[_pair] (grid_2d.py:58-72 / :76-90 and the adjoint); a workgroup owns 16
+ * lines.  The branch descriptor is ffno_fused_branch with `planes` pointing at PACKED weights:
+ *   ffno_spectral_x3_pack: planes[k][re|im][i][o] (forward: wp, adjoint: wpt of ffno_fw_pack) -> fragment order, split;
+ *   ffno_spectral_x3_pack_bytes(C, K) bytes per packed set.  descs is a DEVICE array, one launch for all sets.
+ * Supported: C = 64, K <= 16, L <= 2048 (ffno_spectral_x3_supported); the fp32-MFMA kernels above cover the rest.
+ * interleave != 0 (pair, equal workgroup counts): even workgroups run branch a, odd ones branch b.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ffno_x3pack_desc {
+    const float* planes; /* [K][2][C][C] */
+    void* dst;           /* ffno_spectral_x3_pack_bytes(C, K) bytes, 16-B aligned */
+    int32_t K;
+    int32_t pad_;
+} ffno_x3pack_desc;
+int ffno_spectral_x3_supported(int C, int K, int L);
+size_t ffno_spectral_x3_pack_bytes(int C, int K);
+int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream);
+int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
+                     void* stream);
+int ffno_spectral_x3_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
+                          int apply_ck_inv, int conj_transpose, int interleave, void* stream);
+
 /* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),
  * for the shapes the fused kernel does not take (K > 16 at C = 64: 256 x 256 grids with 32 / 64 modes have only 512 lines
  * per axis at batch 2 -- one launch per axis cannot fill the chip).  spec_save must be set in both branches (scratch when

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("FFNO_ALLOW_TEST_BACKEND", "1")   # the emulator hook of fourierflow_amd._lib is inert without it
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "fourierflow_amd", "csrc")
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libffno_emu.so")
-SOURCES = ["spectral.hip", "ff.hip", "ffx.hip", "pointwise.hip", "velocity.hip", "spectral2d.hip", "plin.hip"]
+SOURCES = ["spectral.hip", "spectral_x3.hip", "ff.hip", "ffx.hip", "pointwise.hip", "velocity.hip", "spectral2d.hip", "plin.hip"]
 
 
 def _cxx():
@@ -27,8 +27,9 @@ def build(verbose=False):
     os.makedirs(OUT, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     h = hashlib.sha256()
-    for p in sorted(srcs + [os.path.join(CSRC, "ffno_device.h"), os.path.join(HERE, "hip_emu.h"),
-                            os.path.join(ROOT, "include", "ffno.h")]):
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+              [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    for p in sorted(srcs + headers + [os.path.join(ROOT, "include", "ffno.h")]):
         h.update(open(p, "rb").read())
     stamp = h.hexdigest()
     sf = LIB + ".stamp"
@@ -37,7 +38,7 @@ def build(verbose=False):
     objs = []
     for src in srcs:
         obj = os.path.join(OUT, os.path.basename(src) + ".o")
-        cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-DFFNO_EMU", "-I", HERE, "-I", CSRC,
+        cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC,
                "-I", os.path.join(ROOT, "include"), "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-psabi", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -1,0 +1,39 @@
+// TEST INFRASTRUCTURE: the names of fourierflow_amd/csrc/ffno_platform.h implemented on the CPU wave emulator
+// (hip_emu.h).  tests/emu/build_emu.py puts this directory first on the include path, so the UNCHANGED kernel sources
+// compile against it; the package never sees this file.
+#pragma once
+
+#include "hip_emu.h"
+#include <math.h>
+#include <stdint.h>
+
+typedef emu_u32x4 u32x4;
+
+#define FFNO_BUILD_TARGET "emu"
+#define FFNO_DYN_SMEM(name) char* name = (char*)(((uintptr_t)emu::S().dyn_smem.data() + 63) & ~(uintptr_t)63)
+#define FFNO_UNROLL
+#define FFNO_NOUNROLL
+#define FFNO_SCHED_FENCE() ((void)0)
+#define FFNO_WAVES_PER_SIMD(n)
+
+namespace ffno {
+namespace plat {
+
+inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) { return emu::mfma_32x32x2(a, b, c); }
+inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) { return emu::mfma_16x16x4(a, b, c); }
+inline f32x16 mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_bf16(a, b, c); }
+inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) { return emu::mfma_16x16x32_bf16(a, b, c); }
+inline unsigned pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xffff0000u); }
+inline uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return (acc << 1) | (x >> 31); }
+inline uint32_t bit_to_mask(uint32_t x, int b) { return 0u - ((x >> b) & 1u); }
+inline void sincos_pi(float x, float& s, float& c) {
+    const double a = 3.14159265358979323846 * (double)x;
+    s = (float)sin(a), c = (float)cos(a);
+}
+
+}  // namespace plat
+
+template <class K>
+static inline int allow_dynamic_lds(K, size_t) { return 0; }
+
+}  // namespace ffno

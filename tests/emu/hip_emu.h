@@ -1,7 +1,7 @@
 // Minimal HIP-on-CPU shim -- TEST INFRASTRUCTURE ONLY (never built into the shipped library).
 //
 // Lets the *actual* kernel sources under fourierflow_amd/csrc/ be compiled with a host
-// compiler (-DFFNO_EMU) and executed lane-by-lane on the CPU so that index math, MFMA fragment
+// compiler (against tests/emu/ffno_platform.h) and executed lane-by-lane on the CPU so that index math, MFMA fragment
 // layouts, LDS addressing and barrier placement can be checked against the oracle without a GPU.
 //
 // Execution model: workgroups run one after another; every thread of a workgroup is a ucontext
@@ -196,6 +196,36 @@ inline f32x16 mfma_32x32x16_bf16(emu_u32x4 a, emu_u32x4 b, f32x16 c) {
         for (int kh = 0; kh < 2; ++kh)
             for (int e = 0; e < 8; ++e)
                 acc = fmaf(bf(w.xa[p][i + 32 * kh][e >> 1], e), bf(w.xb[p][j + 32 * kh][e >> 1], e), acc);
+        d[r] = acc;
+    }
+    wave_exchange_done(p);
+    return d;
+}
+
+// v_mfma_f32_16x16x32_bf16: A[i = l&15][k = 8*(l>>4) + e], B[k = 8*(l>>4) + e][j = l&15], D as the fp32 16x16 form.
+inline f32x4 mfma_16x16x32_bf16(emu_u32x4 a, emu_u32x4 b, f32x4 c) {
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int p = w.parity;
+    for (int i = 0; i < 4; ++i) {
+        w.xa[p][lane][i] = a[i];
+        w.xb[p][lane][i] = b[i];
+    }
+    wave_barrier(w);
+    int j = lane & 15, q = lane >> 4;
+    auto bf = [](unsigned word, int e) {
+        unsigned u = (e & 1) ? (word & 0xffff0000u) : (word << 16);
+        float f;
+        memcpy(&f, &u, 4);
+        return f;
+    };
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * q + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int e = 0; e < 8; ++e)
+                acc = fmaf(bf(w.xa[p][i + 16 * g][e >> 1], e), bf(w.xb[p][j + 16 * g][e >> 1], e), acc);
         d[r] = acc;
     }
     wave_exchange_done(p);

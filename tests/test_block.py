@@ -27,16 +27,24 @@ TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64
 GPU_ONLY = {"c64_4l_markov", "c64_24l_markov", "c64_3l_unshared"}  # too slow for the CPU emulator
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "staged"])
+@pytest.mark.parametrize("fused", ["x3", True, False], ids=["x3", "fused", "staged"])
 @pytest.mark.parametrize("tag", TAGS)
 def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     if host_device == "cpu" and tag in GPU_ONLY:
         pytest.skip("emulator too slow for this size; runs with -m gpu")
+    x3 = fused == "x3"          # the split-bf16 branch kernel (forced on for the small golden grids) / the fp32-MFMA one
+    fused = bool(fused)
+    if x3 and (tag in ("c32_nown", "c64_nofourier")):
+        pytest.skip("no split-bf16 branch for this configuration (width 32 / no spectral branch)")
+    if x3 and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass", "c64_sharefork_fork"):
+        pytest.skip("x3 path on the emulator: three representative configs are enough")
     g = gu.load_golden("block_" + tag)
     kw = gu.golden_kwargs(g)
     B, M, N, seed = [int(v) for v in g["meta"]]
     blk = build_block(kw, seed, host_device)
     blk.engine().use_fused = fused   # fused A->B->C branch kernel vs the three stage kernels
+    blk.engine().use_x3 = x3
+    blk.engine().x3_min_lines = 1
     if not fused and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass"):
         pytest.skip("staged path on the emulator: two representative configs are enough")
     x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
@@ -70,7 +78,9 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     import oracle_util as ou
     eng = blk.engine()
     masks = ou.engine_relu_masks(eng)
-    label = f"block {tag} {'fused' if fused else 'staged'} {host_device}"
+    label = f"block {tag} {'x3' if x3 else 'fused' if fused else 'staged'} {host_device}"
+    if x3:
+        assert any(blk.engine()._saved_x3[0]), "the split-bf16 branch kernel did not run"
     print(f"[{label}] worst gradient vs reference golden {errs[worst]:.2e} ({worst})")
     ou.check_grads_at_rounding_level(label, {n: named[n].grad.cpu().numpy() for n in eng.param_names},
                                      lambda dt: ou.oracle_block_run(kw, seed, B, M, N, dtype=dt, relu_masks=masks)[2])

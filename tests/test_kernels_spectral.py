@@ -322,3 +322,138 @@ def test_paired_launches_equal_the_single_branch_kernels(be, B, M, N, K, C, dire
     # argument checks: shared outputs / scratch are refused
     a = FusedBranch(p(dx), p(dres), None, p(mixes[0]), None, p(br[0]["tw"]), B, M, N, K, 0, 0)
     assert lib.ffno_spectral_staged_pair(ctypes.byref(a), ctypes.byref(a), p(mixes[0]), p(mixes[1]), C, 0, 1, 0, None) == -1
+
+
+# ---- the split-bf16 fused branch (spectral_x3.hip): 16 lines per workgroup, packed pre-split weights ------------------------
+def _branch_reference(x, w, K, axis, direction):
+    """fp64 reference of one branch (forward / adjoint / low-pass) -> (out [B,M,N,C], stage-A spectrum [K,R,2,C])."""
+    B, M, N, C = x.shape
+    L = N if axis == 0 else M
+    R = B * M if axis == 0 else B * N
+    xt = torch.tensor(x, dtype=torch.float64)
+    dim = 2 if axis == 0 else 1
+    f = torch.fft.rfft(xt, dim=dim, norm="ortho").narrow(dim, 0, K)
+    ck = torch.tensor([1.0 if (k == 0 or 2 * k == L) else 2.0 for k in range(K)], dtype=torch.float64)
+    shape = [1, 1, 1, 1]
+    shape[dim] = K
+    wc = torch.tensor(w[..., 0].astype(np.float64) + 1j * w[..., 1])
+    if direction == "adj":
+        f = f * ck.view(shape)                                    # adjoint of the zero-padded irfft
+        y = torch.einsum("bmko,iok->bmki" if axis == 0 else "bkno,iok->bkni", f, wc.conj())
+        n = torch.arange(L, dtype=torch.float64)
+        ang = 2 * np.pi * torch.outer(n, torch.arange(K, dtype=torch.float64)) / L
+        Gr, Gi = torch.cos(ang) / np.sqrt(L), -torch.sin(ang) / np.sqrt(L)
+        eq = "nk,bmkc->bmnc" if axis == 0 else "mk,bknc->bmnc"
+        ref = torch.einsum(eq, Gr, y.real) + torch.einsum(eq, Gi, y.imag)   # adjoint of the truncated rfft: plain sum
+    else:
+        y = torch.einsum("bmki,iok->bmko" if axis == 0 else "bkni,iok->bkno", f, wc) if direction == "fwd" else f
+        full_shape = list(y.shape)
+        full_shape[dim] = L // 2 + 1
+        full = torch.zeros(full_shape, dtype=torch.complex128)
+        full.narrow(dim, 0, K).copy_(y)
+        ref = torch.fft.irfft(full, n=L, dim=dim, norm="ortho")
+    fs = f.permute(2, 0, 1, 3).reshape(K, R, C) if axis == 0 else f.permute(1, 0, 2, 3).reshape(K, R, C)
+    return ref.numpy(), torch.stack([fs.real, fs.imag], dim=2).numpy()
+
+
+def _x3_pack(be, w, K, C=64):
+    """(forward pack, adjoint pack) of a [C, C, K, 2] Fourier weight through ffno_fw_pack + ffno_spectral_x3_pack."""
+    from fourierflow_amd._capi import X3PackDesc
+    lib, p = be.lib, be.ptr
+    wp, wpt = be.zeros((K, 2, C, C)), be.zeros((K, 2, C, C))
+    assert lib.ffno_fw_pack(p(be.put(w)), p(wp), p(wpt), C, K, None) == 0
+    nbytes = int(lib.ffno_spectral_x3_pack_bytes(C, K))
+    assert nbytes == K * 16 * 3 * 64 * 16
+    pk = [be.zeros((nbytes // 4,), np.uint32) for _ in range(2)]
+    descs = (X3PackDesc * 2)(X3PackDesc(p(wp), p(pk[0]), K, 0), X3PackDesc(p(wpt), p(pk[1]), K, 0))
+    dtab = be.put(np.frombuffer(bytes(descs), dtype=np.uint8).copy())
+    assert lib.ffno_spectral_x3_pack(p(dtab), 2, C, K, None) == 0
+    return pk[0], pk[1], (wp, wpt, dtab)
+
+
+X3_SHAPES = [(1, 8, 12, 3), (2, 6, 10, 5), (1, 20, 64, 16), (1, 13, 9, 4), (3, 5, 7, 2), (2, 16, 32, 8), (1, 3, 72, 16), (1, 100, 4, 2)]
+
+
+@pytest.mark.parametrize("B,M,N,K", X3_SHAPES)
+@pytest.mark.parametrize("axis", [0, 1])
+@pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
+def test_spectral_x3_branch(be, B, M, N, K, axis, direction):
+    """The split-bf16 fused branch against fp64 torch.fft at the fp32 tolerance: forward / adjoint / low-pass, the saved
+    spectrum, ragged line counts (R % 16 != 0), lines longer than one 64-sample chunk (72) and odd lengths, accumulate +
+    residual epilogue."""
+    from fourierflow_amd._capi import FusedBranch
+    C = 64
+    L = N if axis == 0 else M
+    if K > L // 2 + 1:
+        pytest.skip("modes exceed axis")
+    lib, p = be.lib, be.ptr
+    assert lib.ffno_spectral_x3_supported(C, K, L) == 1
+    rs = np.random.RandomState(B + 10 * M + 100 * N + K + axis)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+    R = B * M if axis == 0 else B * N
+    ref, ref_spec_ = _branch_reference(x, w, K, axis, direction)
+    dx, tw = be.put(x), be.twiddle(L)
+    pk_f, pk_a, keep = _x3_pack(be, w, K)
+    out, spec = be.empty(x.shape), be.empty((K, R, 2, C))
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    planes = None if direction == "lowpass" else (pk_a if direction == "adj" else pk_f)
+    br = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0)
+    assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
+    got = be.get(out)
+    assert not np.isnan(got).any()
+    assert rel_l2(got, ref) < TOL
+    assert rel_l2(be.get(spec), ref_spec_) < TOL
+    resid = rs.standard_normal(x.shape).astype(np.float32)       # accumulate + residual epilogue, no spectrum save
+    dres = be.put(resid)
+    br = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1)
+    assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
+    assert rel_l2(be.get(out), 2 * ref + resid) < TOL
+
+
+@pytest.mark.parametrize("B,M,N,K", [(2, 10, 12, 5), (1, 16, 16, 8), (1, 40, 34, 16)])
+@pytest.mark.parametrize("direction", ["fwd", "adj"])
+@pytest.mark.parametrize("interleave", [0, 1])
+def test_spectral_x3_pair_equals_single_branches(be, B, M, N, K, direction, interleave):
+    """Both axes of a layer in one launch (either workgroup -> branch map): bit-identical to the single-branch launches."""
+    from fourierflow_amd._capi import FusedBranch
+    C = 64
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + K)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    resid = rs.standard_normal(x.shape).astype(np.float32)
+    base = rs.standard_normal(x.shape).astype(np.float32)
+    dx, dres = be.put(x), be.put(resid)
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br, keep = [], []
+    for axis in (0, 1):
+        L = N if axis == 0 else M
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        pk_f, pk_a, kp = _x3_pack(be, w, K)
+        keep.append(kp)
+        br.append(dict(axis=axis, R=B * M if axis == 0 else B * N, tw=be.twiddle(L), planes=pk_a if direction == "adj" else pk_f))
+
+    def branches(outs, sv):
+        return [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"]), p(b["tw"]), B, M, N, K,
+                            b["axis"], int(i == 0)) for i, b in enumerate(br)]
+
+    outs1, sv1 = [be.put(base), be.empty(x.shape)], [be.empty((K, b["R"], 2, C)) for b in br]
+    for a in branches(outs1, sv1):
+        assert lib.ffno_spectral_x3(ctypes.byref(a), C, fwd_ck, inv_ck, conj, None) == 0
+    outs2, sv2 = [be.put(base), be.empty(x.shape)], [be.empty((K, b["R"], 2, C)) for b in br]
+    a2 = branches(outs2, sv2)
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(a2[0]), ctypes.byref(a2[1]), C, fwd_ck, inv_ck, conj, interleave, None) == 0
+    for i in range(2):
+        np.testing.assert_array_equal(be.get(outs2[i]), be.get(outs1[i]))
+        np.testing.assert_array_equal(be.get(sv2[i]), be.get(sv1[i]))
+    # the first branch against fp64 as well (accumulate onto `base` with a residual)
+    wdummy = None
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(a2[0]), ctypes.byref(a2[0]), C, fwd_ck, inv_ck, conj, 0, None) == -1   # shared output
+
+
+def test_spectral_x3_support_matrix(be):
+    lib = be.lib
+    assert lib.ffno_spectral_x3_supported(64, 16, 64) == 1
+    assert lib.ffno_spectral_x3_supported(64, 17, 64) == 0
+    assert lib.ffno_spectral_x3_supported(32, 8, 64) == 0
+    assert lib.ffno_spectral_x3_pack_bytes(32, 8) == 0
