@@ -207,7 +207,7 @@ def main():
     ap.add_argument("--modes", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
-    ap.add_argument("--x3-interleave", type=int, default=1)
+    ap.add_argument("--x3-interleave", type=int, default=1, help="bit 0: workgroup->branch interleave; bits 8..: start skew / 256 cycles")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()

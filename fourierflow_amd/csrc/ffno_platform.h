@@ -48,6 +48,10 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) { return
 __device__ __forceinline__ uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return __builtin_amdgcn_alignbit(acc, x, 31); }
 // all-ones if bit b of x is set, else 0: v_bfe_i32
 __device__ __forceinline__ uint32_t bit_to_mask(uint32_t x, int b) { return (uint32_t)__builtin_amdgcn_sbfe((int)x, b, 1); }
+// park the wave for about n cycles (s_sleep: 64-cycle units)
+__device__ __forceinline__ void sleep_cycles(int n) {
+    for (int i = 0; i < n; i += 64 * 16) __builtin_amdgcn_s_sleep(16);
+}
 // sin / cos of pi * x
 __device__ __forceinline__ void sincos_pi(float x, float& s, float& c) { sincospif(x, &s, &c); }
 

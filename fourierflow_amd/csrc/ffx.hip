@@ -157,22 +157,35 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
         for (int e = tid; e < C; e += F::NT) b2s[e] = bias2[e];
     }
 
-    // staging map: float4 number f = tid + v * NT of the [32][C] tile
-    float4 nS[NV];
-    auto gload = [&](int tile) {
+    // staging map: float4 number f = tid + v * NT of the [32][C] tile.  Loads run TWO tiles ahead of the matrix work: the
+    // raw rows of tile t + 2 are requested at the top of iteration t (pA / pB), summed and handed to the staging registers
+    // (nS) at the top of iteration t + 1, and split into LDS at its end -- a full iteration (~3 us) between request and use,
+    // so an HBM round trip under load (~2 us) is never on the critical path of a tile (profiles/r01_v4_ablation.md: 8.5 of
+    // 51 us were exposed staging latency with one tile of distance).
+    float4 nS[NV], pA[NV], pB[NV];
+    auto gload_raw = [&](int tile) {
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
             const long px = (long)tile * 32 + f / (C / 4);
-            nS[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pA[v] = pB[v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (px < P) {
                 const long off = px * C + 4 * (f % (C / 4));
-                nS[v] = *reinterpret_cast<const float4*>(in + off);
-                if (in2) {      // the input is the sum of two tensors (the two spectral branches ran side by side, each into
-                                // its own buffer); the sum is optionally written back for the kernels that follow
-                    const float4 t = *reinterpret_cast<const float4*>(in2 + off);
-                    nS[v].x += t.x, nS[v].y += t.y, nS[v].z += t.z, nS[v].w += t.w;
-                    if (sum_out) *reinterpret_cast<float4*>(sum_out + off) = nS[v];
+                pA[v] = *reinterpret_cast<const float4*>(in + off);
+                if (in2) pB[v] = *reinterpret_cast<const float4*>(in2 + off);
+            }
+        }
+    };
+    auto consume = [&](int tile) {       // raw rows -> staging registers (the input may be the sum of two tensors: the two
+        FFNO_UNROLL                      // spectral branches ran side by side; the sum is optionally written back)
+        for (int v = 0; v < NV; ++v) {
+            nS[v] = pA[v];
+            if (in2) {
+                nS[v].x += pB[v].x, nS[v].y += pB[v].y, nS[v].z += pB[v].z, nS[v].w += pB[v].w;
+                if (sum_out) {
+                    const int f = tid + v * F::NT;
+                    const long px = (long)tile * 32 + f / (C / 4);
+                    if (px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = nS[v];
                 }
             }
         }
@@ -185,15 +198,15 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
         }
     };
     // reduce the NW partial tiles of `tile` (this wave owns float4 groups [wave*GPW, +GPW)) and store the output rows
-    float4 rres[GPW];
-    auto rload = [&](int tile) {   // residual rows of the tile, fetched a full MFMA phase before they are needed
+    float4 rres[GPW], rnext[GPW];
+    auto rload = [&](int tile) {   // residual rows of the tile, requested a whole iteration before its reduction
         const long px = (long)tile * 32 + j;
         FFNO_UNROLL
         for (int u = 0; u < GPW; ++u) {
             const int gi = wave * GPW + u;
-            rres[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rnext[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!BWD && resid && px < P)
-                rres[u] = *reinterpret_cast<const float4*>(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
+                rnext[u] = *reinterpret_cast<const float4*>(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
         }
     };
     auto reduce = [&](int tile, int buf) {
@@ -222,9 +235,14 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     };
 
     if ((int)blockIdx.x < ntiles) {
-        gload(blockIdx.x);
+        gload_raw(blockIdx.x);
+        consume(blockIdx.x);
         stage(0);
+        if ((int)(blockIdx.x + gridDim.x) < ntiles) gload_raw(blockIdx.x + gridDim.x);
     }
+    uint32_t bits_next = 0;
+    if (BWD && (int)blockIdx.x < ntiles)
+        bits_next = reinterpret_cast<const uint16_t*>(mask)[((long)blockIdx.x * NW + wave) * 64 + lane];
     __syncthreads();
 
     // Software pipeline: iteration t multiplies tile t and reduces + stores tile t-1.  The two waves that share a SIMD
@@ -234,12 +252,19 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     const bool early = wave < NW / 2 || NW == 1;
     int buf = 0, prev = -1;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        const int nt = tile + gridDim.x;
-        if (nt < ntiles) gload(nt);
+        const int nt = tile + gridDim.x, nt2 = nt + gridDim.x;
+        if (nt < ntiles) consume(nt);            // requested one iteration ago
+        rload(tile);                             // consumed by this tile's reduction, one iteration from now
         static_assert(CPW == 1, "one 16-bit sign word per (tile, wave, lane)");
         uint16_t* mp = mask ? reinterpret_cast<uint16_t*>(mask) + ((long)tile * NW + wave) * 64 + lane : nullptr;
         uint32_t bits = 0;
-        if (BWD) bits = *mp;
+        if (BWD) {                               // this tile's sign word arrived during the previous iteration
+            bits = bits_next;
+            if (nt < ntiles) bits_next = reinterpret_cast<const uint16_t*>(mask)[((long)nt * NW + wave) * 64 + lane];
+        }
+        // youngest requests of the iteration (memory operations retire in order: whoever waits for the residual rows or the
+        // sign word at the end of this iteration must not wait for these)
+        if (nt2 < ntiles) gload_raw(nt2);
 
         // GEMM1: this wave's hidden chunks for the 32 pixels of the tile
         f32x16 d[CPW];
@@ -292,7 +317,8 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                     make_float4(o[mt][4 * g], o[mt][4 * g + 1], o[mt][4 * g + 2], o[mt][4 * g + 3]);
         }
         if (!early && prev >= 0) reduce(prev, buf ^ 1);
-        rload(tile);
+        FFNO_UNROLL
+        for (int u = 0; u < GPW; ++u) rres[u] = rnext[u];
         if (nt < ntiles) stage(buf ^ 1);
         prev = tile;
         __syncthreads();

@@ -89,7 +89,7 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 }
 
 // ---- the branch --------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
+__device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
     __shared__ __attribute__((aligned(16))) float XS[F::NL * F::LSF];
@@ -99,7 +99,6 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
     const float* __restrict__ in = A.in;
     const int R = A.R, L = A.L, K = A.K;
     const LineMap lm = A.lm;
-    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -114,7 +113,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
     // a dead line is ever stored.
     const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + 2 * j) * 4);
     const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + 2 * j) * 4);
-    __syncthreads();
+    if (skew_cycles > 0) plat::sleep_cycles(skew_cycles);      // optional start skew (see spectral_x3_pair_kernel)
 
     // ---------------- phase 1: truncated forward DFT of the wave's two lines ----------------
     {
@@ -157,8 +156,12 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
             }
         };
         const int nchunks = (L + 63) >> 6;
+        // the first line is requested before anything else: the twiddle table is staged (and the DFT-matrix fragments are
+        // built from it) while those 16 KiB are on their way
         FFNO_UNROLL
         for (int u = 0; u < 4; ++u) load_rows(0, u, lo0);
+        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+        __syncthreads();
         build_F(0);
         FFNO_UNROLL
         for (int ln = 0; ln < 2; ++ln) {
@@ -196,6 +199,13 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
             }
         }
     }
+    // weight fragments of phase 2: a ring of four, requested four products (24 MFMAs) before they are used; the first four
+    // of the wave's first mode are requested on this side of the barrier
+    Bf3 ring[4];
+    if (A.wpk && wave < K) {
+        FFNO_UNROLL
+        for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(A.wpk + (long)wave * F::MODE_FRAGS * F::FRAG, f, lane);
+    }
     __syncthreads();
 
     // ---------------- phase 2: per-mode channel mix of all 16 lines, in place ----------------
@@ -203,10 +213,10 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
         const float* arow = XS + (j >> 1) * LSF + (j & 1) * RS + 8 * half;     // MFMA row j = (line j >> 1, part j & 1)
         for (int k = wave; k < K; k += F::NW) {
             const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * F::FRAG;
-            // weight fragments: a ring of four, requested four products (24 MFMAs) before they are used
-            Bf3 ring[4];
-            FFNO_UNROLL
-            for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(wk, f, lane);
+            if (k != wave) {
+                FFNO_UNROLL
+                for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(wk, f, lane);
+            }
             Bf3 a[4];
             FFNO_UNROLL
             for (int st = 0; st < 4; ++st) {
@@ -302,6 +312,17 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
                 FFNO_UNROLL
                 for (int q = 0; q < 2; ++q) {
                     if (rt0 + q >= RTtot) continue;
+                    // rows the epilogue adds (residual / accumulate) are requested before the tile's products
+                    float2 pre[16];
+                    const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
+                                                 : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
+                    if (addsrc) {
+                        FFNO_UNROLL
+                        for (int r = 0; r < 16; ++r) {
+                            const int nu = min(32 * (rt0 + q) + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
+                            pre[r] = *reinterpret_cast<const float2*>(addsrc + (lo - hoff) + (unsigned)nu * (unsigned)(es * 4));
+                        }
+                    }
                     f32x16 o0 = zero16(), o1 = zero16();
                     FFNO_UNROLL
                     for (int st = 0; st < 2; ++st) {
@@ -314,12 +335,9 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
                         if (nu + 4 * half < L) {
                             const long uo = (long)nu * es * 4;
                             float2 o = make_float2(o0[r], o1[r]);
-                            if (A.accumulate) {
+                            if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
+                            if (A.accumulate && A.resid) {      // both at once (rare): the second addend is read in place
                                 const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lo);
-                                o.x += pv.x, o.y += pv.y;
-                            }
-                            if (A.resid) {
-                                const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.resid) + uo + lo);
                                 o.x += pv.x, o.y += pv.y;
                             }
                             *reinterpret_cast<float2*>(reinterpret_cast<char*>(A.out) + uo + lo) = o;
@@ -331,16 +349,18 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx) {
     }
 }
 
-__global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) { spectral_x3_body(a, blockIdx.x); }
+__global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) { spectral_x3_body(a, blockIdx.x, 0); }
 
 // Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
 // workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
 // weights of ONE branch only; otherwise [0, n0) run a and the rest b.
-__global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave) {
+__global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
     const bool second = interleave ? (w & 1) : (w >= n0);
     const int idx = interleave ? (w >> 1) : (second ? w - n0 : w);
-    spectral_x3_body(second ? b : a, idx);
+    // skew > 0: every other workgroup of each branch starts `skew` cycles late, so that its HBM-bound phases (line loads,
+    // output stores) fall on the L2 / matrix phase of its neighbours instead of all 256 CUs hitting HBM in lockstep
+    spectral_x3_body(second ? b : a, idx, (idx & 1) ? skew : 0);
 }
 
 static inline int x3_status() {
@@ -402,6 +422,8 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     const int n0 = (a.R + X3Cfg::NL - 1) / X3Cfg::NL, n1 = (b.R + X3Cfg::NL - 1) / X3Cfg::NL;
     const dim3 grid(n0 + n1), block(512);
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
-    FFNO_LAUNCH(spectral_x3_pair_kernel, grid, block, smem, (hipStream_t)stream, a, b, n0, (interleave && n0 == n1) ? 1 : 0);
+    // interleave: bit 0 = workgroup -> branch map; bits 8.. = start skew of every other workgroup in units of 256 cycles
+    FFNO_LAUNCH(spectral_x3_pair_kernel, grid, block, smem, (hipStream_t)stream, a, b, n0, ((interleave & 1) && n0 == n1) ? 1 : 0,
+                (interleave >> 8) * 256);
     return x3_status();
 }

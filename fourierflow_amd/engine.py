@@ -513,7 +513,8 @@ class FFNOEngine:
                     arr = (_capi.X3PackDesc * len(descs))(*descs)
                     self._x3pack_dev = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
                     self._x3pack_sig, self._x3pack_n = sig, len(descs)
-                self._k("fw_pack_x3", lib.ffno_spectral_x3_pack, _p(self._x3pack_dev), self._x3pack_n, self.C, max(self.Ks), st)
+                    self._x3pack_maxk = max(d.K for d in descs)
+                self._k("fw_pack_x3", lib.ffno_spectral_x3_pack, _p(self._x3pack_dev), self._x3pack_n, self.C, self._x3pack_maxk, st)
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         self._k("head_fold", lib.ffno_head_fold, _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                 _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, self.O, st)

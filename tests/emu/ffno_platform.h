@@ -26,6 +26,7 @@ inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) { return emu::mfma_16
 inline unsigned pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xffff0000u); }
 inline uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return (acc << 1) | (x >> 31); }
 inline uint32_t bit_to_mask(uint32_t x, int b) { return 0u - ((x >> b) & 1u); }
+inline void sleep_cycles(int) {}
 inline void sincos_pi(float x, float& s, float& c) {
     const double a = 3.14159265358979323846 * (double)x;
     s = (float)sin(a), c = (float)cos(a);
