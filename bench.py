@@ -208,6 +208,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--x3-interleave", type=int, default=1, help="bit 0: workgroup->branch interleave; bits 8..: start skew / 256 cycles")
+    ap.add_argument("--ffx-schedule", type=int, default=1, help="1 = role-split feed-forward kernels (default), 0 = round-1 in-phase kernels")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()
@@ -230,6 +231,8 @@ def main():
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     block = (FNOPlus2DBlock if args.plus else FNOFactorized2DBlock)(**kw).to(dev)
     trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
+    from fourierflow_amd import _lib as _fl
+    _fl.get_lib().ffno_ffx_set_schedule(args.ffx_schedule)
     trainer.engine.use_x3 = not args.no_x3
     trainer.engine.x3_interleave = args.x3_interleave
     B, G = args.batch, args.grid

@@ -99,6 +99,8 @@ SIGNATURES = {
     "ffno_ff_bwd_weights_partial": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ff_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_supported": (I, [I, I]),
+    "ffno_ffx_set_schedule": (I, [I]),
+    "ffno_ffx_set_max_workgroups": (I, [I]),
     "ffno_ffx_pack_bytes": (SZ, [I, I]),
     "ffno_ffx_pack": (I, [P, I, I, I, P]),
     "ffno_ffx_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),

@@ -326,6 +326,245 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     if (prev >= 0) reduce(prev, buf ^ 1);
 }
 
+// ---- forward / backward-data, role-split schedule ---------------------------------------------------------------------
+// Same arithmetic, operands and results as ffx_chain_kernel (bit-identical: same products, same summation order), other
+// schedule.  In ffx_chain_kernel the two waves that share a SIMD (w and w + NW/2) run the same code in phase: after every
+// barrier both want the matrix pipe (GEMM1), then both want the vector ALU (bias / ReLU / three-way split), then both the
+// matrix pipe again -- the pipes are used one after the other and the phases ADD (measured: 7600 cycles per tile against
+// 3072 cycles of MFMA per SIMD; the matrix pipe is busy 40 % of the launch).  Here the halves take ROLES that keep them one
+// slot apart, with a barrier after every slot so that they stay apart:
+//
+//     slot            1                2                  3                    4
+//     waves 0..NW/2   GEMM1(t)         epilogue(t)        GEMM2(t) -> part     stage tile t+1 (split -> LDS)
+//     waves NW/2..    reduce(t-1)      GEMM1(t)           epilogue(t)          GEMM2(t) -> part
+//
+// so every slot pairs a matrix segment on one wave with a vector / LDS segment on its SIMD partner.  The first half
+// stages all input tiles, the second half reduces and stores all output tiles; the partial-output exchange needs ONE
+// buffer (reduce(t-1) is over before the first half writes part(t)), i.e. 64 KiB of LDS less.
+template <int C, int H, bool BWD>
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const float* __restrict__ in,
+                                                                        const float* __restrict__ in2, float* sum_out,
+                                                                        const float* resid,
+                                                                        const u32x4* __restrict__ pk1,
+                                                                        const float* __restrict__ bias1,
+                                                                        const u32x4* __restrict__ pk2,
+                                                                        const float* __restrict__ bias2, float* out,
+                                                                        uint32_t* mask, int P) {
+    using F = FxCfg<C, H>;
+    constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, G = F::G;
+    constexpr int NWA = NW / 2;                      // waves per role
+    constexpr int NTA = NWA * 64;                    // threads that stage
+    constexpr int NVA = (32 * C / 4) / NTA;          // float4 per staging thread and tile
+    constexpr int GPB = G / NWA;                     // float4 groups per reducing wave
+    static_assert(NW >= 2 && NWA * 2 == NW && NVA * NTA * 4 == 32 * C && GPB * NWA == G, "role split");
+    __shared__ __attribute__((aligned(16))) char sp[2][3 * F::PPLANE];
+    __shared__ __attribute__((aligned(16))) float part[NW * G * 64 * 4];
+    __shared__ __attribute__((aligned(16))) float b1s[H];
+    __shared__ float b2s[C];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+    const bool first = wave < NWA;                   // role: first half stages, second half reduces
+    const int rw = wave - NWA;                       // index inside the reducing half
+
+    Bf3 A1[KS], A2[CTO][2];
+    FFNO_UNROLL
+    for (int st = 0; st < KS; ++st) A1[st] = load_frag(pk1, wave * KS + st, lane);
+    FFNO_UNROLL
+    for (int mt = 0; mt < CTO; ++mt) {
+        FFNO_UNROLL
+        for (int s2 = 0; s2 < 2; ++s2) A2[mt][s2] = load_frag(pk2, (wave * CTO + mt) * 2 + s2, lane);
+    }
+    if (!BWD) {
+        for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e];
+        for (int e = tid; e < C; e += F::NT) b2s[e] = bias2[e];
+    }
+
+    // ---- staging half: raw rows requested two tiles ahead (qA / qB), summed into pS one tile ahead, split into LDS in slot 4 ----
+    float4 pS[NVA], qA[NVA], qB[NVA];
+    auto gload_raw = [&](int tile) {
+        FFNO_UNROLL
+        for (int v = 0; v < NVA; ++v) {
+            const int f = tid + v * NTA;
+            const long px = (long)tile * 32 + f / (C / 4);
+            qA[v] = qB[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px < P) {
+                const long off = px * C + 4 * (f % (C / 4));
+                qA[v] = *reinterpret_cast<const float4*>(in + off);
+                if (in2) qB[v] = *reinterpret_cast<const float4*>(in2 + off);
+            }
+        }
+    };
+    auto consume = [&](int tile) {      // raw rows -> pS (the input may be the sum of two tensors; the sum is optionally stored)
+        FFNO_UNROLL
+        for (int v = 0; v < NVA; ++v) {
+            pS[v] = qA[v];
+            if (in2) {
+                pS[v].x += qB[v].x, pS[v].y += qB[v].y, pS[v].z += qB[v].z, pS[v].w += qB[v].w;
+                const int f = tid + v * NTA;
+                const long px = (long)tile * 32 + f / (C / 4);
+                if (sum_out && px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = pS[v];
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        FFNO_UNROLL
+        for (int v = 0; v < NVA; ++v) {
+            const int f = tid + v * NTA;
+            stage4(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, pS[v].x, pS[v].y, pS[v].z, pS[v].w);
+        }
+    };
+    // ---- reducing half: residual rows one tile ahead; reduce the NW partial tiles and store the output rows ----
+    float4 rres[GPB], rnext[GPB];
+    auto rload = [&](int tile) {
+        const long px = (long)tile * 32 + j;
+        FFNO_UNROLL
+        for (int u = 0; u < GPB; ++u) {
+            const int gi = rw * GPB + u;
+            rnext[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!BWD && resid && px < P)
+                rnext[u] = *reinterpret_cast<const float4*>(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
+        }
+    };
+    auto reduce = [&](int tile) {
+        const long px = (long)tile * 32 + j;
+        FFNO_UNROLL
+        for (int u = 0; u < GPB; ++u) {
+            const int gi = rw * GPB + u;
+            float4 acc = *reinterpret_cast<const float4*>(&part[((0 * G + gi) * 64 + lane) * 4]);
+            FFNO_UNROLL
+            for (int w = 1; w < NW; ++w) {
+                const float4 t = *reinterpret_cast<const float4*>(&part[((w * G + gi) * 64 + lane) * 4]);
+                acc.x += t.x;
+                acc.y += t.y;
+                acc.z += t.z;
+                acc.w += t.w;
+            }
+            const int c0 = 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half;
+            if (!BWD) {
+                acc.x += b2s[c0] + rres[u].x;
+                acc.y += b2s[c0 + 1] + rres[u].y;
+                acc.z += b2s[c0 + 2] + rres[u].z;
+                acc.w += b2s[c0 + 3] + rres[u].w;
+            }
+            if (px < P) *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+        }
+    };
+
+    // ---- the three compute segments of a wave (its hidden chunk of the current tile) ----
+    f32x16 d;
+    Bf3 hb[2];
+    uint32_t bits = 0, bits_next = 0;
+    auto gemm1 = [&](int buf) {
+        d = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            const Bf3 b = lds_frag(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            d = mfma_x3(A1[st], b, d);
+        }
+    };
+    auto epilogue = [&](int tile) {
+        uint16_t* mp = mask ? reinterpret_cast<uint16_t*>(mask) + ((long)tile * NW + wave) * 64 + lane : nullptr;
+        if (BWD) {
+            bits = bits_next;                          // this tile's sign word was requested during the previous tile
+            const int nt = tile + gridDim.x;
+            if (nt < ntiles) bits_next = reinterpret_cast<const uint16_t*>(mask)[((long)nt * NW + wave) * 64 + lane];
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) d[r] = u2f(f2u(d[r]) & bit_mask(bits, 15 - r));
+        } else {
+            bits = 0;
+            FFNO_UNROLL
+            for (int g = 0; g < 4; ++g) {
+                const float4 bv = *reinterpret_cast<const float4*>(&b1s[32 * wave + 8 * g + 4 * half]);
+                const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                FFNO_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const float v = fmaxf(d[4 * g + i] + bb[i], 0.f);
+                    d[4 * g + i] = v;
+                    bits = push_sign(bits, 0u - f2u(v));   // msb(-bits(v)) = [v > 0]; element r ends up at bit 15 - r
+                }
+            }
+            if (mp) *mp = (uint16_t)bits;
+        }
+        hb[0] = split3_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        hb[1] = split3_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+    };
+    auto gemm2 = [&]() {
+        f32x16 o[CTO];
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16();
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            o[mt] = mfma_x3(A2[mt][0], hb[0], o[mt]);
+            o[mt] = mfma_x3(A2[mt][1], hb[1], o[mt]);
+        }
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(&part[(((wave * G) + mt * 4 + g) * 64 + lane) * 4]) =
+                    make_float4(o[mt][4 * g], o[mt][4 * g + 1], o[mt][4 * g + 2], o[mt][4 * g + 3]);
+        }
+    };
+
+    const int t0 = blockIdx.x, gs = gridDim.x;
+    if (first) {
+        if (t0 < ntiles) {
+            gload_raw(t0);
+            consume(t0);
+            stage(0);
+        }
+        if (t0 + gs < ntiles) {
+            gload_raw(t0 + gs);
+            consume(t0 + gs);
+        }
+        if (t0 + 2 * gs < ntiles) gload_raw(t0 + 2 * gs);
+    } else if (t0 < ntiles) {
+        rload(t0);
+    }
+    if (BWD && t0 < ntiles) bits_next = reinterpret_cast<const uint16_t*>(mask)[((long)t0 * NW + wave) * 64 + lane];
+    __syncthreads();
+
+    int buf = 0, prev = -1;
+    for (int tile = t0; tile < ntiles; tile += gs, buf ^= 1) {
+        const int nt = tile + gs;
+        // slot 1
+        if (first) {
+            gemm1(buf);
+        } else {
+            if (prev >= 0) reduce(prev);
+            FFNO_UNROLL
+            for (int u = 0; u < GPB; ++u) rres[u] = rnext[u];
+            if (nt < ntiles) rload(nt);
+        }
+        __syncthreads();
+        // slot 2
+        if (first)
+            epilogue(tile);
+        else
+            gemm1(buf);
+        __syncthreads();
+        // slot 3
+        if (first)
+            gemm2();
+        else
+            epilogue(tile);
+        __syncthreads();
+        // slot 4
+        if (first) {
+            if (nt < ntiles) stage(buf ^ 1);                       // pS holds tile nt
+            if (nt + gs < ntiles) consume(nt + gs);                // requested one iteration ago
+            if (nt + 2 * gs < ntiles) gload_raw(nt + 2 * gs);
+        } else {
+            gemm2();
+        }
+        prev = tile;
+        __syncthreads();
+    }
+    if (!first && prev >= 0) reduce(prev);
+}
+
 // ---- weight gradients with recomputed hidden activations --------------------------------------------------------------
 // Per workgroup slice:  dW1^T[c][hid], dW2[c][hid], db1[hid], db2[c]  (dW1 is stored transposed; the reduce kernel
 // un-transposes).  pk1 = pack1(W1), pk2t = pack1(W2^T) -- the A1 operands of the forward and backward chain kernels.
@@ -526,6 +765,230 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
     }
 }
 
+// ---- weight gradients, role-split schedule --------------------------------------------------------------------------------
+// Same arithmetic and results as ffx_wgrad_kernel (bit-identical partial slices), scheduled like ffx_chain_rs_kernel: the
+// two waves of a SIMD (w and w + NW/2) stay one slot apart, a barrier after every slot, so that a matrix segment on one of
+// them always runs beside a vector / LDS segment on the other:
+//
+//     slot            1          2          3                   4                   5          6
+//     waves 0..NW/2   h^T GEMM   ReLU+split dW2 += , dh^T GEMM  mask+split          dW1 +=     stage tile t+1
+//     waves NW/2..    (idle)     h^T GEMM   ReLU+split          dW2 += , dh^T GEMM  mask+split dW1 +=
+//
+// The first half stages the whole next tile (both layouts of s and db); its rows are requested in slot 1, five slots
+// before they are split into LDS.
+template <int C, int H>
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_rs_kernel(const float* __restrict__ s,
+                                                                        const float* __restrict__ db,
+                                                                        const u32x4* __restrict__ pk1,
+                                                                        const float* __restrict__ bias1,
+                                                                        const u32x4* __restrict__ pk2t,
+                                                                        float* __restrict__ partial, int P) {
+    using F = FxCfg<C, H>;
+    constexpr int KS = F::KS, CTO = F::CTO, NW = F::NW;
+    constexpr int NWA = NW / 2, NTA = NWA * 64, NVA = (32 * C / 4) / NTA;
+    static_assert(NW >= 2 && NWA * 2 == NW && NVA * NTA * 4 == 32 * C && NTA % C == 0 && (NTA / C) * NVA == 8, "role split");
+    constexpr int BUF = 6 * F::PPLANE + 6 * F::TPLANE;   // [sP x3][dbP x3][sT x3][dbT x3]
+    constexpr int OFF_SP = 0, OFF_DP = 3 * F::PPLANE, OFF_ST = 6 * F::PPLANE, OFF_DT = 6 * F::PPLANE + 3 * F::TPLANE;
+    __shared__ __attribute__((aligned(16))) char lds[2][BUF];
+    __shared__ float red[F::NT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+    const bool first = wave < NWA;
+
+    Bf3 W1f[KS], W2f[KS];
+    FFNO_UNROLL
+    for (int st = 0; st < KS; ++st) {
+        W1f[st] = load_frag(pk1, wave * KS + st, lane);
+        W2f[st] = load_frag(pk2t, wave * KS + st, lane);
+    }
+    const float b1v = bias1[32 * wave + j];
+
+    // staging, split by role so that no wave holds more than 2 * NVA rows in registers:
+    //   first half : pixel-major planes (sP, dbP; map f = tid + v * NTA), requested in slot 1, split into LDS in slot 6
+    //   second half: channel-major planes (sT, dbT; channel tc, pixel group tg + v * NTA / C), requested in slot 2 of the
+    //                previous tile, split into LDS in slot 1 -- two slots before the first reader (slot 3)
+    const int rt = first ? tid : tid - NTA;
+    const int tc = rt % C, tg = rt / C;
+    float4 nS[NVA], nD[NVA];
+    float bs2 = 0.f;
+    auto gload = [&](int tile) {
+        FFNO_UNROLL
+        for (int v = 0; v < NVA; ++v) {
+            if (first) {
+                const int f = rt + v * NTA;
+                const long px = (long)tile * 32 + f / (C / 4);
+                nS[v] = nD[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (px < P) {
+                    nS[v] = *reinterpret_cast<const float4*>(s + px * C + 4 * (f % (C / 4)));
+                    nD[v] = *reinterpret_cast<const float4*>(db + px * C + 4 * (f % (C / 4)));
+                }
+            } else {
+                const long p0 = (long)tile * 32 + 4 * (tg + v * (NTA / C));
+                float a[4], b[4];
+                FFNO_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = p0 + i < P;
+                    a[i] = ok ? s[(p0 + i) * C + tc] : 0.f;
+                    b[i] = ok ? db[(p0 + i) * C + tc] : 0.f;
+                }
+                nS[v] = make_float4(a[0], a[1], a[2], a[3]);
+                nD[v] = make_float4(b[0], b[1], b[2], b[3]);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        FFNO_UNROLL
+        for (int v = 0; v < NVA; ++v) {
+            if (first) {
+                const int f = rt + v * NTA;
+                const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
+                stage4(lds[buf] + OFF_SP, F::PPLANE, offp, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
+                stage4(lds[buf] + OFF_DP, F::PPLANE, offp, nD[v].x, nD[v].y, nD[v].z, nD[v].w);
+            } else {
+                // pixel group grp = (s2 << 2) | (q << 1) | half  <->  local pixels 16 s2 + 8 q + 4 half + i  <->  k slot 4 q + i
+                const int grp = tg + v * (NTA / C);
+                const int pos = 16 * (grp & 1) + 8 * (grp >> 2) + 4 * ((grp >> 1) & 1);
+                const int offt = tc * F::TROW + 2 * pos;
+                stage4(lds[buf] + OFF_ST, F::TPLANE, offt, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
+                stage4(lds[buf] + OFF_DT, F::TPLANE, offt, nD[v].x, nD[v].y, nD[v].z, nD[v].w);
+                bs2 += (nD[v].x + nD[v].y) + (nD[v].z + nD[v].w);
+            }
+        }
+    };
+
+    f32x16 acc1[CTO], acc2[CTO], d;
+    Bf3 hb[2];
+    float bs1 = 0.f;
+    uint32_t bits = 0;
+    FFNO_UNROLL
+    for (int mt = 0; mt < CTO; ++mt) acc1[mt] = zero16(), acc2[mt] = zero16();
+
+    auto seg_h = [&](const char* L) {          // h^T[px][hid] = s W1^T, pixels on the D rows
+        d = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            const Bf3 a = lds_frag(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            d = mfma_x3(a, W1f[st], d);
+        }
+    };
+    auto seg_relu = [&]() {
+        bits = 0;
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const float v = d[r] + b1v;
+            const bool pos = v > 0.f;
+            d[r] = pos ? v : 0.f;
+            bits |= (pos ? 1u : 0u) << r;
+        }
+        hb[0] = split3_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        hb[1] = split3_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+    };
+    auto seg_w2_dh = [&](const char* L) {      // dW2 += db^T h ; then dh^T[px][hid] = db W2
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Bf3 a = lds_frag(L + OFF_DT, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
+                acc2[mt] = mfma_x3(a, hb[s2], acc2[mt]);
+            }
+        }
+        FFNO_SCHED_FENCE();
+        d = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            const Bf3 a = lds_frag(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            d = mfma_x3(a, W2f[st], d);
+        }
+    };
+    auto seg_mask = [&]() {
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            d[r] = ((bits >> r) & 1u) ? d[r] : 0.f;
+            bs1 += d[r];
+        }
+        hb[0] = split3_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        hb[1] = split3_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+    };
+    auto seg_w1 = [&](const char* L) {         // dW1^T += s^T dh
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Bf3 a = lds_frag(L + OFF_ST, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
+                acc1[mt] = mfma_x3(a, hb[s2], acc1[mt]);
+            }
+        }
+    };
+
+    const int t0 = blockIdx.x, gs = gridDim.x;
+    if (t0 < ntiles) {
+        gload(t0);
+        stage(0);
+        if (!first && t0 + gs < ntiles) gload(t0 + gs);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int tile = t0; tile < ntiles; tile += gs, buf ^= 1) {
+        const int nt = tile + gs;
+        const char* L = lds[buf];
+        if (first) {                      // slot 1
+            if (nt < ntiles) gload(nt);
+            seg_h(L);
+        } else if (tile != t0) {
+            stage(buf);                   // this tile's channel-major planes (first read in slot 3)
+        }
+        __syncthreads();
+        if (first) {                      // slot 2
+            seg_relu();
+        } else {
+            if (tile != t0 && nt < ntiles) gload(nt);
+            seg_h(L);
+        }
+        __syncthreads();
+        if (first) seg_w2_dh(L); else seg_relu();          // slot 3
+        __syncthreads();
+        if (first) seg_mask(); else seg_w2_dh(L);          // slot 4
+        __syncthreads();
+        if (first) seg_w1(L); else seg_mask();             // slot 5
+        __syncthreads();
+        if (first) {                      // slot 6
+            if (nt < ntiles) stage(buf ^ 1);
+        } else {
+            seg_w1(L);
+        }
+        __syncthreads();
+    }
+
+    float* part = partial + (long)blockIdx.x * F::PART;
+    float* pW1t = part;              // [c][hid]
+    float* pW2 = part + H * C;       // [c][hid]
+    float* pb1 = part + 2 * H * C;
+    float* pb2 = pb1 + H;
+    {
+        const int hid = 32 * wave + j;
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int c = 32 * mt + drow(r, half);
+                pW1t[c * H + hid] = acc1[mt][r];
+                pW2[c * H + hid] = acc2[mt][r];
+            }
+        }
+        const float v1 = bs1 + __shfl_xor(bs1, 32);
+        if (half == 0) pb1[hid] = v1;
+    }
+    red[tid] = bs2;
+    __syncthreads();
+    if (tid < C) {
+        float v = 0.f;
+        for (int k = tid; k < F::NT; k += C) v += red[k];
+        pb2[tid] = v;
+    }
+}
+
 // partial slices -> gradients; the dW1 block of a slice is [c][hid] (transposed)
 __global__ __launch_bounds__(256) void ffx_wgrad_reduce_kernel(const float* __restrict__ partial, float* dW1, float* dW2,
                                                                float* db1, float* db2, int C, int H, int nsplit,
@@ -623,7 +1086,8 @@ static inline int ffx_launch_status() {
     return e == hipSuccess ? FFNO_OK : (int)e;
 }
 
-static const int kFxBlocks = 256;   // persistent workgroups: one per CU
+static int kFxBlocks = 256;         // persistent workgroups: one per CU (ffno_ffx_set_max_workgroups)
+static int g_chain_schedule = 1;    // 1: role-split slots (ffx_chain_rs_kernel), 0: both halves in phase (ffx_chain_kernel)
 
 }  // namespace ffno
 
@@ -644,6 +1108,18 @@ extern "C" int ffno_ffx_supported(int C, int H) {
 }
 
 extern "C" size_t ffno_ffx_pack_bytes(int C, int H) { return (size_t)C * H * 6; }
+
+extern "C" int ffno_ffx_set_max_workgroups(int n) {
+    if (n <= 0 || n > 65535) return FFNO_EINVAL;
+    kFxBlocks = n;
+    return FFNO_OK;
+}
+
+extern "C" int ffno_ffx_set_schedule(int schedule) {
+    if (schedule != 0 && schedule != 1) return FFNO_EINVAL;
+    g_chain_schedule = schedule;
+    return FFNO_OK;
+}
 
 extern "C" int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, int C, int H, void* stream) {
     if (!mask || !active || P <= 0) return FFNO_EINVAL;
@@ -676,8 +1152,12 @@ extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, cons
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum, resid,     \
-                    (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                           \
+        if (g_chain_schedule == 1 && HH >= 64)                                                                        \
+            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,     \
+                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                \
+        else                                                                                                          \
+            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum, resid, \
+                        (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                       \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -698,9 +1178,14 @@ extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_s
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum, nullptr, \
-                    (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds, (uint32_t*)const_cast<void*>(mask), \
-                    P);                                                                                               \
+        if (g_chain_schedule == 1 && HH >= 64)                                                                        \
+            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,   \
+                        nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
+                        (uint32_t*)const_cast<void*>(mask), P);                                                       \
+        else                                                                                                          \
+            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,      \
+                        nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
+                        (uint32_t*)const_cast<void*>(mask), P);                                                       \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -715,8 +1200,12 @@ extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, con
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \
-        FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,               \
-                    (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                        \
+        if (g_chain_schedule == 1)                                                                                 \
+            FFNO_LAUNCH((ffx_wgrad_rs_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
+                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                    \
+        else                                                                                                       \
+            FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,           \
+                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                    \
         return ffx_launch_status();                                                                                \
     }
     FFNO_FX_DISPATCH(CASE)

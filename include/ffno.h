@@ -248,6 +248,12 @@ typedef struct ffno_fxpack_desc {
     int32_t pad_;
 } ffno_fxpack_desc;
 int ffno_ffx_supported(int C, int H);
+/* Schedule of the forward / backward-data kernel (process-wide; results are bit-identical): 1 (default) = the two halves
+ * of a workgroup take roles one slot apart (matrix segment on one wave of a SIMD beside a vector / LDS segment on the
+ * other), 0 = both halves in phase (the round-1 kernel; kept for A/B measurements). */
+int ffno_ffx_set_schedule(int schedule);
+/* Persistent workgroups of the forward / backward-data kernel (default 256 = one per CU of an MI355X; process-wide). */
+int ffno_ffx_set_max_workgroups(int n);
 size_t ffno_ffx_pack_bytes(int C, int H);
 int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
 int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,

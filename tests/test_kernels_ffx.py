@@ -164,3 +164,50 @@ def test_ffx_two_input_variants_equal_the_presummed_call(be):
     np.testing.assert_array_equal(be.get(ds_a), be.get(ds_b))
     np.testing.assert_array_equal(be.get(gsum), ssum_host)
     assert lib.ffno_ffx_fwd2(p(be.put(sa)), None, p(ssum), None, p(a1), p(db1_), p(a2), p(db2_), p(out_b), None, P, C, H, None) == -1
+
+
+@pytest.mark.parametrize("P,C,H,wgs", [(200, 64, 256, 2), (150, 32, 128, 1), (97, 64, 128, 3), (5000, 64, 256, 256)])
+def test_ffx_chain_schedules_are_bit_identical(be, P, C, H, wgs):
+    """The role-split schedule of the forward / backward-data kernel (default) against the in-phase round-1 kernel: same
+    products in the same order, so outputs, stored sums and sign words must be IDENTICAL -- with several tiles per
+    persistent workgroup (the software pipeline: loads two tiles ahead, residual rows / sign words one tile ahead), ragged
+    last tile, in-place residual."""
+    if be.kind == "emu" and P > 1000:
+        pytest.skip("large case runs on the GPU only")
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(P + H)
+    sa, sb, resid, db = (rs.standard_normal((P, C)).astype(np.float32) for _ in range(4))
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b1, b2 = (rs.standard_normal(H) * 0.1).astype(np.float32), (rs.standard_normal(C) * 0.1).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights(be, W1, W2)
+    db1_, db2_ = be.put(b1), be.put(b2)
+    res = {}
+    try:
+        assert lib.ffno_ffx_set_max_workgroups(wgs) == 0
+        for sched in (0, 1):
+            assert lib.ffno_ffx_set_schedule(sched) == 0
+            mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+            ssum, x = be.empty((P, C)), be.put(resid)          # out aliases resid (the layer's x <- x + b update)
+            assert lib.ffno_ffx_fwd2(p(be.put(sa)), p(be.put(sb)), p(ssum), p(x), p(a1), p(db1_), p(a2), p(db2_), p(x), p(mask),
+                                     P, C, H, None) == 0
+            gsum, ds = be.empty((P, C)), be.empty((P, C))
+            assert lib.ffno_ffx_bwd_data2(p(be.put(db)), p(be.put(sa)), p(gsum), p(mask), p(a1b), p(a2b), p(ds), P, C, H, None) == 0
+            nsplit = max(1, min(wgs, 4))
+            partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
+            assert lib.ffno_ffx_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, None) == 0
+            res[sched] = [np.array(be.get(t)).copy() for t in (ssum, x, mask, gsum, ds, partial)]
+    finally:
+        lib.ffno_ffx_set_schedule(1)
+        lib.ffno_ffx_set_max_workgroups(256)
+    for a, b in zip(res[0][:5], res[1][:5]):
+        np.testing.assert_array_equal(a, b)
+    # weight-gradient slices: identical except the db2 column sums, which the role-split kernel accumulates from other
+    # threads' staging registers (another summation order, same values to rounding)
+    part = 2 * H * C + H + C
+    pa, pb = res[0][5].reshape(-1, part), res[1][5].reshape(-1, part)
+    np.testing.assert_array_equal(pa[:, :2 * H * C + H], pb[:, :2 * H * C + H])
+    assert rel_l2(pb[:, 2 * H * C + H:], pa[:, 2 * H * C + H:]) < 1e-6
+    ref_out, _ = ff_ref(sa + sb, resid, W1, b1, W2, b2)
+    assert rel_l2(res[1][1], ref_out) < TOL
+    assert lib.ffno_ffx_set_schedule(7) == -1
