@@ -208,7 +208,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 disables)")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--x3-interleave", type=int, default=1, help="bit 0: workgroup->branch interleave; bits 8..: start skew / 256 cycles")
-    ap.add_argument("--ffx-schedule", type=int, default=1, help="1 = role-split feed-forward kernels (default), 0 = round-1 in-phase kernels")
+    ap.add_argument("--ffx-schedule", type=int, default=1, help="bit mask: 1 forward, 2 backward-data, 4 weight gradients on the role-split schedule (default 1)")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()

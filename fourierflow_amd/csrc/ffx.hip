@@ -1087,7 +1087,10 @@ static inline int ffx_launch_status() {
 }
 
 static int kFxBlocks = 256;         // persistent workgroups: one per CU (ffno_ffx_set_max_workgroups)
-static int g_chain_schedule = 1;    // 1: role-split slots (ffx_chain_rs_kernel), 0: both halves in phase (ffx_chain_kernel)
+// which kernels run the role-split schedule (bit 0: forward, bit 1: backward-data, bit 2: weight gradients); the others run
+// the in-phase kernels.  Default = forward only: measured on MI355X at markov/24 batch 32 (profiles/r02_ffx_schedules.md)
+// forward 53 vs 57 us, backward-data 56 vs 50 us, weight gradients 108 vs 89 us.
+static int g_chain_schedule = 1;
 
 }  // namespace ffno
 
@@ -1116,7 +1119,7 @@ extern "C" int ffno_ffx_set_max_workgroups(int n) {
 }
 
 extern "C" int ffno_ffx_set_schedule(int schedule) {
-    if (schedule != 0 && schedule != 1) return FFNO_EINVAL;
+    if (schedule < 0 || schedule > 7) return FFNO_EINVAL;
     g_chain_schedule = schedule;
     return FFNO_OK;
 }
@@ -1152,7 +1155,7 @@ extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, cons
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        if (g_chain_schedule == 1 && HH >= 64)                                                                        \
+        if ((g_chain_schedule & 1) && HH >= 64)                                                                       \
             FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,     \
                         resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                \
         else                                                                                                          \
@@ -1178,7 +1181,7 @@ extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_s
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        if (g_chain_schedule == 1 && HH >= 64)                                                                        \
+        if ((g_chain_schedule & 2) && HH >= 64)                                                                       \
             FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,   \
                         nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
                         (uint32_t*)const_cast<void*>(mask), P);                                                       \
@@ -1200,7 +1203,7 @@ extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, con
     hipStream_t st = (hipStream_t)stream;
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \
-        if (g_chain_schedule == 1)                                                                                 \
+        if (g_chain_schedule & 4)                                                                                  \
             FFNO_LAUNCH((ffx_wgrad_rs_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
                         (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                    \
         else                                                                                                       \

@@ -248,9 +248,10 @@ typedef struct ffno_fxpack_desc {
     int32_t pad_;
 } ffno_fxpack_desc;
 int ffno_ffx_supported(int C, int H);
-/* Schedule of the forward / backward-data kernel (process-wide; results are bit-identical): 1 (default) = the two halves
- * of a workgroup take roles one slot apart (matrix segment on one wave of a SIMD beside a vector / LDS segment on the
- * other), 0 = both halves in phase (the round-1 kernel; kept for A/B measurements). */
+/* Schedule of the three feed-forward kernels (process-wide; results identical up to the summation order of db2): bit 0 =
+ * forward, bit 1 = backward-data, bit 2 = weight gradients run "role-split" (the two halves of a workgroup one slot apart:
+ * a matrix segment on one wave of a SIMD beside a vector / LDS segment on the other); a clear bit = both halves in phase.
+ * Default 1 (forward only), from measurements on MI355X. */
 int ffno_ffx_set_schedule(int schedule);
 /* Persistent workgroups of the forward / backward-data kernel (default 256 = one per CU of an MI355X; process-wide). */
 int ffno_ffx_set_max_workgroups(int n);
