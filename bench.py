@@ -14,10 +14,23 @@ weights, factor 4, weight-norm), fp32, per-GPU batch 32 (weak scaling: global ba
 
 Prints ONE JSON line (rank 0).  `value` = whole-node training steps/s = N * K / T, where every rank
 runs K steps of per-GPU batch 32 and T is the max over ranks of the barrier-bracketed wall time.
+
+How the per-kernel numbers are taken (no hand-tuned corrections):
+  * `avg_us` of a hot kernel = one pair of HIP events around 200 back-to-back replays of a launch captured from the middle
+    layer of a real training step (same arguments, same stream), divided by 200;
+  * `in_step_event_us` = mean of raw HIP-event brackets around sampled launches inside the timed region (it contains the
+    bracket's own cost, reported separately as `event_pair_us`; nothing is subtracted);
+  * `rocprofv3 --kernel-trace --stats` of this same command is committed under profiles/ (its per-kernel average is the
+    third opinion);
+  * roofline: `bound` = hbm when the kernel's arithmetic intensity (algorithmic FLOPs / training bytes) is below the ridge of
+    the matrix pipe it runs on (peak / 8 TB/s), else mfma; both fractions are always reported, the HBM one against two byte
+    counts: the bytes a training launch must move (`bytes_training`) and SURVEY 8(d)'s floor for a fused A+B+C kernel
+    (read x + write s, `bytes_floor_8d`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,26 +42,43 @@ T_START = time.perf_counter()
 
 MARKOV24 = dict(modes=16, width=64, n_layers=24, input_dim=3, share_weight=True, factor=4, ff_weight_norm=True,
                 gain=0.1, dropout=0.0, in_dropout=0.0)
+CUBE64 = dict(modes_x=8, modes_y=8, modes_z=8, width=32, input_dim=4, output_dim=1, n_layers=12, share_weight=False, factor=4,
+              ff_weight_norm=True, n_ff_layers=2, layer_norm=False)     # BASELINE.json configs[4]
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
-# split-bf16 kernels (ffx.hip): one fp32-accurate multiply-add = 6 bf16 MFMA multiply-adds, so their matrix-core ceiling in
-# ALGORITHMIC (fp32-equivalent) FLOP/s is the dense bf16 peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 6
+# split-bf16 kernels: one fp32-accurate multiply-add = 6 bf16 MFMA multiply-adds, so their matrix-core ceiling in ALGORITHMIC
+# (fp32-equivalent) FLOP/s is the dense bf16 peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 6
 BF16X3_PEAK_TFLOPS = 2500.0 / 6.0
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
+REPLAYS = 200
+
+HOT = ["spectral_fused", "spectral_fused(adj)", "spectral_staged_pair", "spectral_staged_pair(adj)", "ff_fwd", "ff_bwd_data",
+       "ff_bwd_weights_partial", "fw_grad_partial"]
 
 
-class KernelTimer:
-    """HIP-event timing of selected launches on the stream they are enqueued on (torch's current stream)."""
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    def __init__(self, names, every=1):
+
+class KernelProbe:
+    """engine.timer hook: (a) raw HIP-event brackets around every `every`-th launch of the named kernels, on the stream they
+    are enqueued on; (b) capture of (entry point, arguments) of every named launch of ONE step, for the replay timing."""
+
+    def __init__(self, names, every=7):
         self.names = set(names)
         self.pairs = {n: [] for n in names}
-        self._open = {}
-        self.enabled = False
+        self.calls = {n: [] for n in names}
         self.count = {n: 0 for n in names}
         self.every = every
+        self.sample = False
+        self.capture = False
+        self._open = {}
+
+    def seen(self, name, fn, args):
+        if self.capture and name in self.names:
+            self.calls[name].append((fn, args))
 
     def want(self, name):
-        if not self.enabled or name not in self.names:
+        if not self.sample or name not in self.names:
             return False
         self.count[name] += 1
         return self.count[name] % self.every == 0
@@ -63,9 +93,7 @@ class KernelTimer:
         ev.record(stream) if stream is not None else ev.record()
         self.pairs[name].append((self._open.pop(name), ev))
 
-    def calibrate(self, n=50):
-        """Elapsed time of an EMPTY start/stop pair on the same stream: what the event bracket itself adds to a launch
-        (subtracted in summary(), so the per-launch times line up with rocprofv3's kernel-trace durations)."""
+    def event_pair_us(self, n=50):
         prs = []
         for _ in range(n):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -74,68 +102,92 @@ class KernelTimer:
             prs.append((a, b))
         torch.cuda.synchronize()
         ms = sorted(a.elapsed_time(b) for a, b in prs)
-        # a bracket around a real kernel hides part of that latency behind the kernel: 0.6 x the empty-pair time is what
-        # reproduces rocprofv3's kernel-trace averages (profiles/r01_v6_kernel_stats.md: 38.6 us vs 42.0 us raw, pair 5.3 us)
-        self.overhead_us = 0.6 * 1e3 * ms[len(ms) // 2]
-        return self.overhead_us
+        return 1e3 * ms[len(ms) // 2]
 
-    def summary(self):
+    def in_step(self):
+        return {n: (1e3 * sum(a.elapsed_time(b) for a, b in prs) / len(prs), len(prs)) for n, prs in self.pairs.items() if prs}
+
+    def replay(self, n=REPLAYS):
+        """{name: us per launch} -- the launch of the middle layer, n times back to back between two events."""
         out = {}
-        ov = getattr(self, "overhead_us", 0.0)
-        for n, prs in self.pairs.items():
-            if prs:
-                ms = [a.elapsed_time(b) for a, b in prs]
-                out[n] = dict(avg_us=max(1e3 * sum(ms) / len(ms) - ov, 0.0), samples=len(ms), launches_per_sample=self.every,
-                              event_overhead_us=round(ov, 2))
+        for name, calls in self.calls.items():
+            if not calls:
+                continue
+            fn, args = calls[len(calls) // 2]
+            for _ in range(3):
+                fn(*args)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(n):
+                fn(*args)
+            b.record()
+            torch.cuda.synchronize()
+            out[name] = 1e3 * a.elapsed_time(b) / n
         return out
 
 
-FFX_KERNELS = ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial")   # on the split-bf16 path when engine._ffx()
-X3_ALWAYS = ("fw_grad_partial",)                                   # split-bf16 unconditionally
-
-
 def algorithmic_work(P, C, H, K, B, M, N, L, paired=True):
-    """Algorithmic FLOPs / HBM bytes per launch of the timed kernels and launches per train step.
-    fp32: 4 B per element.  R = lines per axis; spectra are K*R*2C floats."""
+    """Algorithmic FLOPs / HBM bytes per launch of the hot kernels and launches per train step.
+    fp32: 4 B per element.  R = lines per axis; spectra are K*R*2C floats.  `floor` = SURVEY 8(d)'s byte floor."""
     R = B * M
     spec = 4.0 * K * R * 2 * C
     act = 4.0 * P * C
     dft = 2.0 * R * (2 * K) * N * C            # truncated DFT (or its inverse) of R lines as a [2K x N].[N x C] product
     mix = 8.0 * R * K * C * C                   # complex per-mode channel mix
     if paired:
-        # both axes of a layer in one launch (engine "concurrent_branches"): read x once, write the two branch outputs,
-        # save the two spectra (training); the adjoint also reads the residual gradient
-        sf = dict(flops=2 * (2 * dft + mix), bytes=3 * act + 2 * spec, per_step=L, bound="hbm")
-        sa = dict(flops=2 * (2 * dft + mix), bytes=4 * act + 2 * spec, per_step=L, bound="hbm")
+        # both axes of a layer in one launch: read x (each branch its own lines), write the two branch outputs, save the two
+        # spectra (training); the adjoint also reads the residual gradient.  8(d) floor of a fused A+B+C layer: read x + write s
+        sf = dict(flops=2 * (2 * dft + mix), bytes=3 * act + 2 * spec, floor=2 * act, per_step=L,
+                  formula="read x + write 2 branch outputs + save 2 spectra = 3*P*C*4 + 2*K*R*2C*4")
+        sa = dict(flops=2 * (2 * dft + mix), bytes=4 * act + 2 * spec, floor=2 * act, per_step=L,
+                  formula="read ds + residual + write 2 branch gradients + save 2 spectra = 4*P*C*4 + 2*K*R*2C*4")
     else:
-        # one spectral branch: read x, write s (+ read s when accumulating the 2nd branch), + save the spectrum (training)
-        sf = dict(flops=2 * dft + mix, bytes=(act + act + spec) + 0.5 * act, per_step=2 * L, bound="hbm")
-        sa = dict(flops=2 * dft + mix, bytes=(act + act + act + spec), per_step=2 * L, bound="hbm")
+        sf = dict(flops=2 * dft + mix, bytes=(act + act + spec) + 0.5 * act, floor=2 * act, per_step=2 * L,
+                  formula="read x + write (every second launch: read-modify-write) s + save the spectrum")
+        sa = dict(flops=2 * dft + mix, bytes=(act + act + act + spec), floor=2 * act, per_step=2 * L,
+                  formula="read ds + residual / accumulate + write + save the spectrum")
+    ffb = P * H / 8
     return {
-        "spectral_fused": sf,
-        "spectral_fused(adj)": sa,
-        # the same two branches through the three paired STAGE launches (K > 16: 256 x 256 grids); one "launch" = the three
-        # kernels of a ffno_spectral_staged_pair call, algorithmic work as above (the spectra that travel are overhead)
-        "spectral_staged_pair": sf,
-        "spectral_staged_pair(adj)": sa,
-        # split-bf16 feed-forward (ffx.hip): no hidden activations in HBM, only the ReLU sign bits (P*H/8 bytes); the
-        # weight-gradient kernel recomputes h and dh, so its algorithmic FLOPs are 4 GEMMs (2 recomputed + 2 gradients)
-        # (+ with paired branches: the second branch buffer is read and the sum written back while staging)
-        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=(5 if paired else 3) * act + P * H / 8, per_step=L, bound="mfma"),
-        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=(4 if paired else 2) * act + P * H / 8, per_step=L, bound="mfma"),
-        "ff_bwd_weights_partial": dict(flops=8.0 * P * C * H, bytes=2 * act, per_step=L, bound="mfma"),
-        "fw_grad_partial": dict(flops=L * mix, bytes=2 * L * spec, per_step=2, bound="hbm"),
+        "spectral_fused": sf, "spectral_fused(adj)": sa,
+        # the same two branches through the three paired STAGE launches (shapes outside the fused kernels' LDS tile); one
+        # "launch" = the three kernels of a ffno_spectral_staged_pair call (the spectra that travel are overhead)
+        "spectral_staged_pair": sf, "spectral_staged_pair(adj)": sa,
+        # split-bf16 feed-forward: no hidden activations in HBM, only the ReLU sign bits (P*H/8 bytes); the weight-gradient
+        # kernel recomputes h and dh (4 GEMMs).  Paired branches: the second branch buffer is read and the sum written back.
+        "ff_fwd": dict(flops=4.0 * P * C * H, bytes=(5 if paired else 3) * act + ffb, floor=2 * act, per_step=L,
+                       formula="read s (+ second branch, write the sum) + residual + write x' + sign bits"),
+        "ff_bwd_data": dict(flops=4.0 * P * C * H, bytes=(4 if paired else 2) * act + ffb, floor=2 * act, per_step=L,
+                            formula="read g (+ second branch, write the sum) + sign bits + write ds"),
+        "ff_bwd_weights_partial": dict(flops=8.0 * P * C * H, bytes=2 * act, floor=2 * act, per_step=L, formula="read s + g"),
+        "fw_grad_partial": dict(flops=L * mix, bytes=2 * L * spec, floor=2 * L * spec, per_step=2,
+                                formula="read the saved X and dY spectra of all layers"),
     }
 
 
-def log(msg):
-    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+def matrix_peak(name, engine):
+    """Ceiling (fp32-equivalent TFLOP/s) of the matrix pipe a kernel runs on."""
+    if name in ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial"):
+        return BF16X3_PEAK_TFLOPS if engine._ffx() else FP32_MFMA_PEAK_TFLOPS
+    if name == "fw_grad_partial":
+        return BF16X3_PEAK_TFLOPS
+    if name.startswith("spectral_fused"):
+        return BF16X3_PEAK_TFLOPS if getattr(engine, "_saved_x3", (None, False))[1] else FP32_MFMA_PEAK_TFLOPS
+    return FP32_MFMA_PEAK_TFLOPS
 
 
-def cpu_baseline(batch, grid, steps, kw):
-    """The oracle (op-for-op CPU torch restatement of the reference, certified against its golden
-    vectors) timed on this box's host cores: same model, batch and synthetic data distribution.
-    The intra-op thread count is calibrated first (all cores is NOT the fastest on a 256-core box)."""
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def cpu_baseline(batch, grid, kw, warm=2, timed=5, threads=None):
+    """The oracle (op-for-op CPU torch restatement of the reference, certified against its golden vectors) timed on this
+    box's host cores: same model, batch and synthetic data distribution, whole TRAIN steps (2 warm-up + 5 timed).
+    The intra-op thread count is calibrated on the train step at the timed batch (all cores is not the fastest on a
+    256-core box)."""
     from oracle import ffno_oracle as orc
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     sd = orc.init_block_state_dict(modes=kw["modes"], width=kw["width"], input_dim=kw["input_dim"],
@@ -144,26 +196,8 @@ def cpu_baseline(batch, grid, steps, kw):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(batch, grid, grid, kw["input_dim"], generator=g)
     y = torch.randn(batch, grid, grid, 1, generator=g)
-
-    def fwd(xb):
-        with torch.no_grad():
-            t0 = time.perf_counter()
-            orc.ffno2d_block(sd, xb, modes=kw["modes"], n_layers=kw["n_layers"])
-            return time.perf_counter() - t0
-
-    best_t, best_n = None, None
-    for nthr in sorted({n for n in (8, 16, 32, 64, 128, ncpu) if n <= ncpu}):
-        torch.set_num_threads(nthr)
-        fwd(x[:4])
-        t = fwd(x[:4])
-        log(f"cpu baseline calibration: {nthr} threads -> {1e3 * t:.0f} ms / forward(B=4)")
-        if best_t is None or t < best_t:
-            best_t, best_n = t, nthr
-        if t > 3 * best_t:
-            break
-    torch.set_num_threads(best_n)
     uniq, seen = [], set()
-    for k, v in sd.items():
+    for v in sd.values():
         if id(v) not in seen:
             seen.add(id(v))
             uniq.append(v.requires_grad_(True))
@@ -180,20 +214,96 @@ def cpu_baseline(batch, grid, steps, kw):
         sch.step()
         return time.perf_counter() - t0
 
-    t_warm = step()
-    log(f"cpu baseline warm-up step: {t_warm:.2f} s ({best_n} threads)")
-    times = []
-    for _ in range(steps):
-        times.append(step())
-        if sum(times) > 60:
-            break
+    calib = {}
+    if threads is None:
+        best_t = None
+        for nthr in sorted({n for n in (8, 16, 32, 64, 128, ncpu) if n <= ncpu}):
+            torch.set_num_threads(nthr)
+            t = step()
+            if best_t is None:      # the first step of the process also pays allocator warm-up: repeat it
+                t = min(t, step())
+            calib[nthr] = round(t, 2)
+            log(f"cpu baseline calibration (train step, batch {batch}): {nthr} threads -> {t:.2f} s")
+            if best_t is None or t < best_t:
+                best_t, threads = t, nthr
+            if t > 1.5 * best_t:
+                break
+    torch.set_num_threads(threads)
+    for _ in range(warm):
+        step()
+    times = [step() for _ in range(timed)]
     dt = sum(times) / len(times)
-    f = fwd(x)
-    return dict(value=round(1.0 / dt, 4), unit="steps/s", cores=best_n, kind="port", host_cores_available=ncpu,
-                s_per_step=round(dt, 3), ms_per_forward=round(1e3 * f, 1),
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.ffno2d_block(sd, x, modes=kw["modes"], n_layers=kw["n_layers"])
+        f = time.perf_counter() - t0
+    return dict(value=round(1.0 / dt, 4), unit="steps/s", cores=threads, kind="port", host_cores_available=ncpu,
+                s_per_step=round(dt, 3), samples_per_s=round(batch / dt, 2), ms_per_forward=round(1e3 * f, 1),
+                thread_calibration_s_per_step=calib,
                 sample=f"oracle (CPU torch restatement of the reference op sequence, pinned to its golden vectors) "
-                       f"train step, same model/batch ({batch}, {grid}x{grid}, fp32): 1 warm-up + {len(times)} timed "
-                       f"steps on {best_n} threads (best of a thread-count calibration)")
+                       f"train step, same model / batch ({batch}, {grid}x{grid}, fp32): {warm} warm-up + {timed} timed steps on "
+                       f"{threads} threads (best of a thread-count calibration on the train step itself)")
+
+
+def time_steps(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    sync()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def secondary_workloads(dev, steps=10, warmup=3):
+    """The other single-GPU BASELINE configs, in the same run so the driver's line carries them (north_star: 64x64 AND 256x256
+    in the same run): torus_kochkov 256 x 256 (12 layers, 32 modes, batch 2) and the 64^3 plasticity-shaped 3-D operator."""
+    from fourierflow_amd.modules import FNOFactorized2DBlock, FNOFactorizedMesh3D
+    from fourierflow_amd.routines import StructuredMeshExperiment
+    from fourierflow_amd.trainer import FFNOTrainer
+    out = []
+    sync = torch.cuda.synchronize
+    # -- 256 x 256, 12 layers, 32 modes, batch 2 (BASELINE.json configs[3]) --
+    kw = dict(MARKOV24, n_layers=12, modes=32, input_dim=5)
+    torch.manual_seed(0)
+    blk = FNOFactorized2DBlock(**kw).to(dev)
+    tr = FFNOTrainer(blk, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(2, 256, 256, 5, generator=g).to(dev), torch.randn(2, 256, 256, 1, generator=g).to(dev)
+    probe = KernelProbe(HOT)
+    tr.engine.timer = probe
+    dt, _ = time_steps(lambda: tr.train_step(x, y), steps, warmup, sync)
+    probe.capture = True
+    tr.train_step(x, y)
+    probe.capture = False
+    sync()
+    rep = probe.replay(50)
+    tr.engine.timer = None
+    df, _ = time_steps(lambda: tr.predict(x), steps, 2, sync)
+    P, C, H, K = 2 * 256 * 256, 64, 256, 32
+    work = algorithmic_work(P, C, H, K, 2, 256, 256, 12, True)
+    spectral = {}
+    for n, us in rep.items():
+        if n.startswith("spectral"):
+            w, mpeak = work[n], matrix_peak(n, tr.engine)
+            spectral[n] = dict(us_per_layer_direction=round(us, 1), frac_hbm_training_bytes=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3),
+                               frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3), mfma_peak_tflops=round(mpeak, 1))
+    out.append(dict(workload="torus_kochkov-shaped F-FNO train step: 256x256, 12 layers, 32 modes, width 64, batch 2, fp32",
+                    value=round(1.0 / dt, 2), unit="steps/s", ms_per_step=round(1e3 * dt, 3), ms_per_forward=round(1e3 * df, 3),
+                    spectral=spectral))
+    del tr, blk
+    # -- 64^3 -> 72^3 padded, modes 8, width 32, 12 layers, batch 1 (BASELINE.json configs[4]) --
+    torch.manual_seed(0)
+    model = FNOFactorizedMesh3D(**CUBE64).to(dev)
+    exp = StructuredMeshExperiment(model, optimizer=dict(lr=1e-3, weight_decay=1e-4),
+                                   scheduler=dict(num_warmup_steps=500, num_training_steps=82800))
+    batch = dict(x=torch.randn(1, 64, 64, 64, 1, generator=g).to(dev), y=torch.randn(1, 64, 64, 64, 1, generator=g).to(dev))
+    dt, _ = time_steps(lambda: exp.training_step(batch), steps, warmup, sync)
+    df, _ = time_steps(lambda: exp.trainer().predict(batch["x"]), steps, 2, sync)
+    out.append(dict(workload="FNOFactorizedMesh3D train step: 64^3 (72^3 padded), modes 8, width 32, 12 layers, batch 1, fp32",
+                    value=round(1.0 / dt, 2), unit="steps/s", ms_per_step=round(1e3 * dt, 3), ms_per_forward=round(1e3 * df, 3)))
+    return out
 
 
 def main():
@@ -205,7 +315,8 @@ def main():
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--modes", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed CPU-baseline steps (0 disables)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline train steps (0 disables the CPU leg)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 256x256 and 64^3 secondary workloads")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--x3-interleave", type=int, default=1, help="bit 0: workgroup->branch interleave; bits 8..: start skew / 256 cycles")
     ap.add_argument("--ffx-schedule", type=int, default=1, help="bit mask: 1 forward, 2 backward-data, 4 weight gradients on the role-split schedule (default 1)")
@@ -224,14 +335,15 @@ def main():
     if world > 1:
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from fourierflow_amd import _lib as _fl
     from fourierflow_amd.modules import FNOFactorized2DBlock, FNOPlus2DBlock
     from fourierflow_amd.trainer import FFNOTrainer
 
     kw = dict(MARKOV24, n_layers=args.layers, modes=args.modes)
+    headline = (args.grid, args.layers, args.modes, args.batch) == (64, 24, 16, 32) and not args.plus
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     block = (FNOPlus2DBlock if args.plus else FNOFactorized2DBlock)(**kw).to(dev)
     trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
-    from fourierflow_amd import _lib as _fl
     _fl.get_lib().ffno_ffx_set_schedule(args.ffx_schedule)
     trainer.engine.use_x3 = not args.no_x3
     trainer.engine.x3_interleave = args.x3_interleave
@@ -246,27 +358,24 @@ def main():
         torch.cuda.synchronize()
 
     if rank == 0:
-        log(f"model + trainer ready on {dev}; warm-up {args.warmup} steps")
+        log(f"model + trainer ready on {dev} (world {world}); warm-up {args.warmup} steps")
     for _ in range(args.warmup):
         trainer.train_step(x, y)
     torch.cuda.synchronize()
     if rank == 0:
         log("warm-up done; timing")
-    names = ["spectral_fused", "spectral_fused(adj)", "spectral_staged_pair", "spectral_staged_pair(adj)", "ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial", "fw_grad_partial"]
-    timer = KernelTimer(names, every=7) if rank == 0 else None   # sample 1 launch in 7 (odd: both branches get sampled)
-    trainer.engine.timer = timer
-    if timer:
-        timer.enabled = True
+    probe = KernelProbe(HOT, every=7) if rank == 0 else None   # sample 1 launch in 7 (odd: fwd / adj, all layers get sampled)
+    trainer.engine.timer = probe
+    if probe:
+        probe.sample = True
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.train_step(x, y)
     sync()
     elapsed = time.perf_counter() - t0
-    if timer:
-        timer.enabled = False
-        timer.calibrate()
-    trainer.engine.timer = None
+    if probe:
+        probe.sample = False
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -276,6 +385,7 @@ def main():
     loss_val = float(loss.item())
 
     # forward-only latency (the reference's `infer` path), same batch
+    trainer.engine.timer = None
     for _ in range(2):
         trainer.predict(x)
     sync()
@@ -297,62 +407,109 @@ def main():
             trainer.predict(x1)
         torch.cuda.synchronize()
         ms_fwd_b1 = 1e3 * (time.perf_counter() - t1) / 20
-        trainer.predict(x)      # back to the timed geometry (keeps `paired_last` describing the timed workload)
 
     if rank == 0:
-        log(f"forward-only: {ms_fwd:.3f} ms")
+        log(f"forward-only: {ms_fwd:.3f} ms (batch 1: {ms_fwd_b1:.3f} ms)")
+        # one more training step with the launches captured, then the replay timing of the middle layer's launches
+        trainer.engine.timer = probe
+        probe.capture = True
+        trainer.train_step(x, y)
+        probe.capture = False
+        torch.cuda.synchronize()
+        paired = bool(getattr(trainer.engine, "paired_last", False))
+        rep = probe.replay()
+        trainer.engine.timer = None
+        pair_us = probe.event_pair_us()
+        instep = probe.in_step()
         P = B * G * G
         C, H, K = kw["width"], kw["width"] * kw["factor"], kw["modes"]
-        paired = bool(getattr(trainer.engine, "paired_last", False))
         work = algorithmic_work(P, C, H, K, B, G, G, args.layers, paired)
-        ksum = timer.summary()
-        pmc = {}
+        pmc, pmc_meta = {}, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if B == 32 and G == 64 and args.layers == 24 and K == 16:
-                pmc = pj["kernels"]
+            if headline:
+                pmc, pmc_meta = pj["kernels"], {k: pj.get(k) for k in ("git_head", "method", "workload")}
         except Exception:  # noqa: BLE001 - the PMC summary is optional evidence
             pass
         kernels = {}
-        for n, srow in ksum.items():
+        for n, us in rep.items():
             w = work[n]
-            us = srow["avg_us"]
-            mpeak = BF16X3_PEAK_TFLOPS if ((n in FFX_KERNELS and trainer.engine._ffx()) or n in X3_ALWAYS) else FP32_MFMA_PEAK_TFLOPS
-            kernels[n] = dict(avg_us=round(us, 2), per_step=w["per_step"], ms_per_step=round(us * w["per_step"] * 1e-3, 3),
-                              tflops=round(w["flops"] / us * 1e-6, 2), gbs=round(w["bytes"] / us * 1e-3, 1),
+            mpeak = matrix_peak(n, trainer.engine)
+            inten = w["flops"] / w["bytes"]
+            ridge = mpeak * 1e12 / (HBM_PEAK_GBS * 1e9)
+            kernels[n] = dict(avg_us=round(us, 2), replays=REPLAYS,
+                              in_step_event_us=round(instep[n][0], 2) if n in instep else None,
+                              in_step_samples=instep[n][1] if n in instep else 0,
+                              per_step=w["per_step"], ms_per_step=round(us * w["per_step"] * 1e-3, 3),
+                              tflops=round(w["flops"] / us * 1e-6, 2), gbs_training_bytes=round(w["bytes"] / us * 1e-3, 1),
                               mfma_peak_tflops=round(mpeak, 1), frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3),
-                              frac_hbm=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3), samples=srow["samples"])
-        # dominant kernel = the kernel symbol with the largest share of the step (spectral_fused fwd+adj are one symbol)
+                              frac_hbm=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3),
+                              frac_hbm_floor_8d=round(w["floor"] / us * 1e-3 / HBM_PEAK_GBS, 3),
+                              intensity_flop_per_byte=round(inten, 1), ridge_flop_per_byte=round(ridge, 1),
+                              bound="hbm" if inten < ridge else "mfma")
+        # dominant kernel = the entry point with the largest share of the step (forward and adjoint launches of one kernel
+        # symbol are one entry)
         share = {}
         for n, kr in kernels.items():
             share[n.split("(")[0]] = share.get(n.split("(")[0], 0.0) + kr["ms_per_step"]
-        dom_sym = max(share, key=share.get) if share else None
+        dom = max(share, key=share.get) if share else None
         roofline = None
-        if dom_sym:
-            members = [n for n in kernels if n.split("(")[0] == dom_sym]
-            us = sum(kernels[n]["avg_us"] * kernels[n]["per_step"] for n in members) / sum(kernels[n]["per_step"] for n in members)
-            fl = sum(work[n]["flops"] * work[n]["per_step"] for n in members) / sum(work[n]["per_step"] for n in members)
-            by = sum(work[n]["bytes"] * work[n]["per_step"] for n in members) / sum(work[n]["per_step"] for n in members)
-            bound = work[members[0]]["bound"]
+        if dom and not args.plus:
+            members = [n for n in kernels if n.split("(")[0] == dom]
+            tot = sum(kernels[n]["per_step"] for n in members)
+            us = sum(kernels[n]["avg_us"] * kernels[n]["per_step"] for n in members) / tot
+            fl = sum(work[n]["flops"] * work[n]["per_step"] for n in members) / tot
+            by = sum(work[n]["bytes"] * work[n]["per_step"] for n in members) / tot
+            fo = sum(work[n]["floor"] * work[n]["per_step"] for n in members) / tot
+            mpeak = kernels[members[0]]["mfma_peak_tflops"]
+            bound = "hbm" if fl / by < mpeak * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"
             if bound == "hbm":
                 ach, peak, unit = by / us * 1e-3, HBM_PEAK_GBS, "GB/s"
             else:
-                ach, peak, unit = fl / us * 1e-6, kernels[members[0]]["mfma_peak_tflops"], "TFLOP/s"
-            traffic = pmc.get(dom_sym, {}).get("hbm_bytes_per_launch")
-            roofline = dict(kernel=dom_sym, bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
-                            frac=round(ach / peak, 4), traffic=traffic, avg_launch_us=round(us, 2),
-                            share_of_step=round(share[dom_sym] / (1e3 * elapsed / args.steps), 3),
-                            algorithmic_bytes_per_launch=int(by), algorithmic_flops_per_launch=int(fl),
-                            event_overhead_us=round(timer.overhead_us, 2),
-                            note="achieved = algorithmic bytes (or FLOPs) per launch / mean HIP-event launch time in the timed "
-                                 "region (minus 0.6 x the measured time of an empty event pair, the share a bracket adds around a kernel); traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from profiles/pmc_traffic.json "
-                                 "(separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE)")
-        cpu = None
-        if args.plus:
-            roofline = None
-        if world == 1 and args.cpu_steps > 0 and not args.plus:
-            cpu = cpu_baseline(B, G, args.cpu_steps, kw)
+                ach, peak, unit = fl / us * 1e-6, mpeak, "TFLOP/s"
+            tr = pmc.get(dom, {})
+            roofline = dict(kernel=dom, symbol=tr.get("symbol"), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
+                            frac=round(ach / peak, 4),
+                            traffic=tr.get("hbm_bytes_per_launch"), traffic_source=pmc_meta,
+                            avg_launch_us=round(us, 2), share_of_step=round(share[dom] / (1e3 * elapsed / args.steps), 3),
+                            frac_hbm=round(by / us * 1e-3 / HBM_PEAK_GBS, 4), frac_mfma=round(fl / us * 1e-6 / mpeak, 4),
+                            frac_hbm_floor_8d=round(fo / us * 1e-3 / HBM_PEAK_GBS, 4),
+                            mfma_peak_tflops=mpeak, intensity_flop_per_byte=round(fl / by, 1),
+                            ridge_flop_per_byte=round(mpeak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
+                            algorithmic_bytes_per_launch=int(by), bytes_floor_8d_per_launch=int(fo),
+                            algorithmic_flops_per_launch=int(fl),
+                            byte_formula={n: work[n]["formula"] for n in members},
+                            floor_formula="SURVEY 8(d): a fused A+B+C layer reads x and writes s once = 2*P*C*4 bytes",
+                            event_pair_us=round(pair_us, 2),
+                            note=f"achieved = algorithmic (training) bytes or FLOPs per launch / avg_launch_us; avg_launch_us = one HIP-event "
+                                 f"pair around {REPLAYS} back-to-back replays of the middle layer's launch (forward and adjoint weighted by "
+                                 f"launches per step), nothing subtracted; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from "
+                                 f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE), "
+                                 f"taken at the git head named in traffic_source")
         steps_per_s = world * args.steps / elapsed
+        cpu = cpu19 = None
+        if world == 1 and args.cpu_steps > 0 and not args.plus:
+            cpu = cpu_baseline(B, G, kw, warm=2, timed=args.cpu_steps)
+            log(f"cpu baseline: {cpu['s_per_step']} s / step on {cpu['cores']} threads")
+            if headline:   # the reference's own batch (config.yaml: batch_size 19), same thread count, shorter sample
+                cpu19 = cpu_baseline(19, G, kw, warm=1, timed=2, threads=cpu["cores"])
+                cpu["batch19"] = dict(value=cpu19["value"], s_per_step=cpu19["s_per_step"], samples_per_s=cpu19["samples_per_s"],
+                                      sample="same oracle, batch 19 (the reference config's batch size), 1 warm-up + 2 timed steps")
+        secondary = None
+        if headline and world == 1 and not args.no_secondary:
+            log("secondary workloads (256x256 and 64^3)")
+            try:
+                secondary = secondary_workloads(dev)
+            except Exception as e:  # noqa: BLE001 - never lose the headline line to a secondary workload
+                secondary = [dict(error=repr(e))]
+        dist_info = None
+        if world > 1:
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                ver = None
+            dist_info = dict(world_size=world, backend=torch.distributed.get_backend(), rccl_version=ver,
+                             hip=torch.version.hip)
         out = {
             "metric": ("training-steps/sec (whole node), FNOPlus2DBlock %dL %dx%d modes %d" % (args.layers, G, G, K) if args.plus else
                        "training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)"
@@ -369,11 +526,13 @@ def main():
                                       K, args.layers, G, G),
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "optimizer": "AdamW(lr 2.5e-3, wd 1e-4) + cosine warm-up, fused flat kernel",
-                       "collective": "1 x all_reduce(flat fp32 grads, %d floats) / step" % trainer.pflat.numel()},
+                       "collective": "1 x all_reduce(flat fp32 grads, %d floats) / step" % trainer.pflat.numel(),
+                       "arithmetic": "fp32 results; matrix work as exact three-way bf16 splits on v_mfma_f32_32x32x16_bf16 "
+                                     "(feed-forward, spectral branches, Fourier-weight gradient)"},
             "samples_per_s": round(steps_per_s * B, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
-            "final_loss": round(loss_val, 5),
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "final_loss": round(loss_val, 5), "git_head": git_head(),
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "secondary": secondary, "distributed": dist_info,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)

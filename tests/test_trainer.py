@@ -119,3 +119,49 @@ def test_training_learns_a_spectral_operator_on_gpu():
         last = tr.train_step(*batch()).item()
     assert np.isfinite(last) and last < 0.5 * first, (first, last)
     assert bool(torch.isfinite(tr.pflat).all())
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    g = gu.load_golden("train_c64_2l")
+    kw = gu.golden_kwargs(g)
+    B, M, N, seed, steps = [int(v) for v in g["meta"]]
+    blk, tr = make_trainer(kw, seed + 7 * rank, dev)       # different start weights per rank: the rank-0 broadcast fixes it
+    losses = []
+    for s in range(steps):
+        x_np, t_np = gu.make_block_io(kw, seed + 1 + s, B, M, N)
+        sl = slice(rank * B // world, (rank + 1) * B // world)
+        loss = tr.train_step(torch.from_numpy(x_np[sl].copy()).to(dev), torch.from_numpy(t_np[sl].copy()).to(dev))
+        losses.append(loss.item())
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), pflat=tr.pflat.cpu().numpy(), losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_ddp_two_ranks_rccl_equals_reference_full_batch(tmp_path):
+    """The data-parallel step over RCCL on two MI355X: one process per GPU, one all-reduce of the flat gradient buffer per
+    step.  Replicas stay bit-identical and end at the reference's single-process full-batch weights.  Needs two GPUs:
+    skips itself on a one-GPU box (the world-size-2 gloo test covers the same logic on the CPU emulator)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_nccl_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["pflat"], r1["pflat"])
+    g = gu.load_golden("train_c64_2l")
+    np.testing.assert_allclose((r0["losses"] + r1["losses"]) / 2, g["losses"], rtol=2e-5)
+    kw = gu.golden_kwargs(g)
+    blk, _ = make_trainer(kw, int(g["meta"][3]), "cuda:0")
+    off = 0
+    for n in [n for n, _ in blk.engine_parameters()]:
+        shape = blk.engine().param_shapes[n]
+        cnt = int(np.prod(shape))
+        assert gu.compare_packed(g, "final." + n, r0["pflat"][off:off + cnt].reshape(shape), 1e-5) < 2e-4, n
+        off += cnt

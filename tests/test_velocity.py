@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from backend_util import be, rel_l2  # noqa: F401
+from backend_util import be, host_device, rel_l2  # noqa: F401
 from oracle import ffno_oracle as orc
 
 
@@ -86,3 +86,56 @@ def test_velocity_rejects_bad_arguments(be):
     assert be.lib.ffno_velocity_features(p(z), p(z), p(z), 1, 4, 5, 1.0, 1.0, None) == -2     # odd last axis
     assert be.lib.ffno_velocity_features(None, p(z), p(z), 1, 4, 4, 1.0, 1.0, None) == -1
     assert be.lib.ffno_velocity_features(p(z), p(z), p(z), 1, 4, 4, 0.0, 1.0, None) == -1
+
+
+# ---- pinned by a reference run: tests/golden/markov_velocity.npz holds the outputs of the reference's OWN
+# Grid2DMarkovExperiment._build_features (routines/grid_2d_markov.py:124-170, executed by tools/make_golden_velocity.py with the
+# wavenumber buffers rebuilt from jax_cfd's published rfft_mesh definition): vorticity -> (w, u, v) [-> + position] -> running
+# normaliser, two consecutive accumulating calls.
+import os
+
+import golden_util as gu
+
+_VEL = os.path.join(gu.GOLDEN_DIR, "markov_velocity.npz")
+
+
+def _vel_cases():
+    g = np.load(_VEL)
+    for tag in ("a", "b", "c"):
+        size, B, use_pos, norm = [int(v) for v in g[f"{tag}.meta"]]
+        yield tag, g, size, B, bool(use_pos), bool(norm), tuple(map(tuple, g[f"{tag}.domain"])), tuple(g[f"{tag}.lowhigh"])
+
+
+def test_oracle_velocity_and_features_match_the_reference_run():
+    for tag, g, size, B, use_pos, norm, domain, (low, high) in _vel_cases():
+        D = 3 + (2 if use_pos else 0)
+        st = orc.NormalizerState(D, max_accumulations=1000) if norm else None
+        for i in (0, 1):
+            x = torch.from_numpy(g[f"{tag}.x{i}"])
+            feats = orc.markov_features(orc.velocity_features(x, domain), st, None, 0.0, low=low, high=high, training=True,
+                                        use_position=use_pos)
+            assert rel_l2(feats.numpy(), g[f"{tag}.f{i}"]) < 2e-6, (tag, i)
+        if norm:
+            assert rel_l2(st.sum.numpy(), g[f"{tag}.norm_sum"]) < 1e-5 and float(st.count) == float(g[f"{tag}.norm_count"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_routine_features_match_the_reference_run(host_device, tag):
+    """Grid2DMarkovExperiment._build_features on the HIP path (velocity kernels + fused feature / normaliser kernel)."""
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    case = {c[0]: c for c in _vel_cases()}[tag]
+    _, g, size, B, use_pos, norm, domain, (low, high) = case
+    if host_device == "cpu" and size > 32:
+        pytest.skip("64 x 64 case runs on the GPU")
+    D = 3 + (2 if use_pos else 0)
+    blk = FNOFactorized2DBlock(modes=4, width=32, n_layers=1, input_dim=D, factor=2)
+    exp = Grid2DMarkovExperiment(blk, use_velocity=True, use_position=use_pos, should_normalize=norm, low=low, high=high,
+                                 domain=domain, grid_size=[size], max_accumulations=1000, noise_std=0.0).to(host_device)
+    exp.train()
+    for i in (0, 1):
+        feats = exp._build_features({"x": torch.from_numpy(g[f"{tag}.x{i}"].copy()).to(host_device)})
+        assert rel_l2(feats.cpu().numpy(), g[f"{tag}.f{i}"]) < 1e-5, (tag, i)
+    if norm:
+        assert rel_l2(exp.normalizer.sum.cpu().numpy(), g[f"{tag}.norm_sum"]) < 1e-5
+        assert float(exp.normalizer.count.item()) == float(g[f"{tag}.norm_count"])
