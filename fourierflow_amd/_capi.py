@@ -32,6 +32,20 @@ class FusedBranch(C.Structure):
                 ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32)]
 
 
+class LayerFwdDesc(C.Structure):
+    """Mirror of ``ffno_layer_fwd_desc`` (include/ffno.h)."""
+    _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
+                ("pk1", P), ("b1", P), ("pk2", P), ("b2", P), ("s_sum", P), ("resid", P), ("out", P), ("mask", P),
+                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("pad_", C.c_int32)]
+
+
+class LayerBwdDesc(C.Structure):
+    """Mirror of ``ffno_layer_bwd_desc`` (include/ffno.h)."""
+    _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
+                ("g", P), ("g2", P), ("g_sum", P), ("mask", P), ("pk1b", P), ("pk2b", P), ("ds", P), ("s", P), ("pk1", P),
+                ("b1", P), ("partial", P), ("nsplit", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32)]
+
+
 class FxRedDesc(C.Structure):
     """Mirror of ``ffno_fxred_desc`` (include/ffno.h)."""
     _fields_ = [("partial", P), ("dW1", P), ("dW2", P), ("db1", P), ("db2", P)]
@@ -86,6 +100,8 @@ SIGNATURES = {
     "ffno_spectral_x3_pack": (I, [P, I, I, I, P]),
     "ffno_spectral_x3": (I, [P, I, I, I, I, P]),
     "ffno_spectral_x3_pair": (I, [P, P, I, I, I, I, I, P]),
+    "ffno_layer_fwd": (I, [P, P]),
+    "ffno_layer_bwd": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),

@@ -182,6 +182,9 @@ class FFNOEngine:
         self.use_x3 = True
         self.x3_min_lines = 512
         self.x3_interleave = 1       # paired launch: even workgroups branch a, odd ones branch b (one branch's weights per XCD)
+        # one C call per layer and direction (ffno_layer_fwd / ffno_layer_bwd: paired branches + feed-forward) instead of two /
+        # three; per-kernel timing (a timer attached) needs the individual calls
+        self.use_layer_calls = True
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         # backward: FF weight-gradient kernels on a side stream next to the spectral adjoint.  Measured on MI355X
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
@@ -237,6 +240,10 @@ class FFNOEngine:
                     int(self.x3_interleave), st)
             return
         self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
+
+    def _branch(self, v, src, dst, resid, save, planes, acc):
+        return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
+                                 v.a01, acc)
 
     def _ffx(self) -> bool:
         return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
@@ -666,6 +673,7 @@ class FFNOEngine:
         singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)
         conc = pair is not None
         x3pair = bool(conc and x3[pair[0]] and x3[pair[1]])
+        layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork)
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
@@ -692,6 +700,16 @@ class FFNOEngine:
                 if conc:
                     a, b = pair
                     keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in pair]
+                    if layer_calls:
+                        l0, l1, b0, b1 = self._ff_weights(l)
+                        d = _capi.LayerFwdDesc(
+                            self._branch(ws.views[a], ws.X, s_l, None, keep[0], self._planes_for(si, a, 0, x3pair), int(nwrit > 0)),
+                            self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0),
+                            int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
+                            _p(s_l) if save_for_backward else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
+                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, 0)
+                        self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
+                        continue
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
                                self._planes_for(si, a, 0, x3pair), self._planes_for(si, b, 0, x3pair), True, st,
                                acc0=int(nwrit > 0), fused=fused[a], x3=x3pair)
@@ -772,6 +790,9 @@ class FFNOEngine:
             self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
         ws.red_jobs = []
+        layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
+                           and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
+                           and self.mode != "no-fourier")
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
@@ -801,6 +822,26 @@ class FFNOEngine:
                         keep = ws.SDall[w][l] if full else None
                         self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, None, keep,
                                        self._planes_for(si, w, 1, x3[w]), False, int(w > 0), fused[w], st, x3=x3[w])
+                cur = 1 - cur
+                continue
+            if layer_calls:
+                # the whole layer backward in one call: FF data gradient (g_in (+)= G1), weight-gradient slices, adjoint pair
+                si = self._fw_sets.index(self.fw_names[l]) if full else 0
+                a, b = pair
+                part = ws.ffparts[len(ws.red_jobs)]
+                d = _capi.LayerBwdDesc(
+                    self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
+                                 self._planes_for(si, a, 1, x3pair), 0),
+                    self._branch(ws.views[b], ws.DS, ws.G1, None, ws.SDall[b][l] if full else None,
+                                 self._planes_for(si, b, 1, x3pair), 0),
+                    int(x3pair), int(self.x3_interleave), _p(g_in), _p(ws.G1) if have_g1 else None, _p(g_in), _p(ws.MASK[l]),
+                    _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
+                    _p(part), ws.nsplit_ff, P, C, H)
+                self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
+                ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
+                                    gv(fp + "layers.1.0.bias").data_ptr()))
+                ff_seen.add(fp)
+                have_g1 = True
                 cur = 1 - cur
                 continue
             if conc:

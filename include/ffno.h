@@ -174,6 +174,53 @@ int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck_fwd, int a
 int ffno_spectral_x3_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                           int apply_ck_inv, int conj_transpose, int interleave, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Layer level (SURVEY 8b "signature level 2"): one call enqueues a whole factorized Fourier layer -- SpectralConv2d.forward
+ * plus the residual add (grid_2d.py:42-49,169) -- or its backward, from device-resident operands.
+ *   fwd:  a.out <- branch_a(a.in), b.out <- branch_b(b.in)   (one paired launch; a.in == b.in == x)
+ *         out = resid + FF(a.out + b.out);  s_sum (optional, may alias a.out) keeps the FF input for the backward pass,
+ *         mask (optional) the ReLU sign bits.
+ *   bwd:  ds = FF^T(g [+ g2])  (the sum is stored to g_sum when g2 is given);  partial <- feed-forward weight-gradient slices
+ *         (ffno_ffx_bwd_weights_partial: reduce them with ffno_ffx_bwd_weights_reduce[_batched]);  then the adjoint branches
+ *         a, b (a.in == b.in == ds; a.resid = the residual gradient), which also save the dY spectra for the Fourier-weight
+ *         gradient through a.spec_save / b.spec_save.
+ * branch_kernel selects the fused branch kernel: FFNO_BRANCH_X3 (planes = packed split-bf16 sets) or FFNO_BRANCH_FUSED
+ * (planes = fp32 planes).  Weight packs as for ffno_ffx_*: pk1 / pk2 forward, pk1b / pk2b backward.
+ * --------------------------------------------------------------------------------------------- */
+#define FFNO_BRANCH_FUSED 0
+#define FFNO_BRANCH_X3 1
+typedef struct ffno_layer_fwd_desc {
+    ffno_fused_branch a, b;
+    int32_t branch_kernel, interleave;
+    const void* pk1;
+    const float* b1;
+    const void* pk2;
+    const float* b2;
+    float* s_sum;
+    const float* resid;
+    float* out;
+    void* mask;
+    int32_t P, C, H, pad_;
+} ffno_layer_fwd_desc;
+typedef struct ffno_layer_bwd_desc {
+    ffno_fused_branch a, b;
+    int32_t branch_kernel, interleave;
+    const float* g;
+    const float* g2;
+    float* g_sum;
+    const void* mask;
+    const void* pk1b;
+    const void* pk2b;
+    float* ds;
+    const float* s;
+    const void* pk1;
+    const float* b1;
+    float* partial;
+    int32_t nsplit, P, C, H;
+} ffno_layer_bwd_desc;
+int ffno_layer_fwd(const ffno_layer_fwd_desc* d, void* stream);
+int ffno_layer_bwd(const ffno_layer_bwd_desc* d, void* stream);
+
 /* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),
  * for the shapes the fused kernel does not take (K > 16 at C = 64: 256 x 256 grids with 32 / 64 modes have only 512 lines
  * per axis at batch 2 -- one launch per axis cannot fill the chip).  spec_save must be set in both branches (scratch when
