@@ -100,6 +100,8 @@ SIGNATURES = {
     "ffno_spectral_x3_pack": (I, [P, I, I, I, P]),
     "ffno_spectral_x3": (I, [P, I, I, I, I, P]),
     "ffno_spectral_x3_pair": (I, [P, P, I, I, I, I, I, P]),
+    "ffno_spectral_x3_staged_supported": (I, [I, I, I]),
+    "ffno_spectral_x3_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_layer_fwd": (I, [P, P]),
     "ffno_layer_bwd": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),

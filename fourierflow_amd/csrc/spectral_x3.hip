@@ -363,6 +363,254 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     spectral_x3_body(second ? b : a, idx, (idx & 1) ? skew : 0);
 }
 
+// ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
+// Same operators and spectrum layout (spec[k][line][re|im][c]) as dft_fwd / mode_mix / dft_inv of spectral.hip; every
+// product is the exact three-way bf16 split.  One wave per work item, four waves per workgroup, no LDS tile:
+//   stage A  item = (line, 32-row tile of the (mode, part) rows)          -> spectrum in HBM
+//   stage B  item = (mode, 16-line tile): rows = (line, part), weights streamed from the packed sets through a ring
+//   stage C  item = (line, pair of 32-sample output tiles)
+struct X3Stage {
+    const float* in;
+    float* out;
+    const float* resid;
+    const u32x4* wpk;
+    const float* tw;
+    int R, L, K;
+    LineMap lm;
+    int accumulate;
+};
+
+__device__ __forceinline__ void x3_dft_fwd_body(const X3Stage& S, int scale_ck, int bidx, int nblk) {
+    constexpr int C = X3Cfg::C;
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+    const int R = S.R, L = S.L, K = S.K;
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = S.tw[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int RT = (2 * K + 31) >> 5;
+    const long es = S.lm.elem_stride;
+    const unsigned esb = (unsigned)(es * 4);
+    const int nchunks = (L + 63) >> 6;
+    const long nitems = (long)R * RT;
+    for (long item = (long)bidx * 4 + wave; item < nitems; item += (long)nblk * 4) {
+        const int line = (int)(item / RT), rt = (int)(item % RT);
+        const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
+        const bool rowok = kk < 2 * K;
+        const float ck = (scale_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
+        const int km = rowok ? k : 0;
+        const int k8 = (km * 8) % L;
+        const unsigned lo = (unsigned)((S.lm.base(line) + 2 * j) * 4);
+        float2 raw[4][8];
+        auto load_rows = [&](int chunk, int u) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
+                raw[u][e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(S.in) + (lo + (unsigned)n * esb));
+            }
+        };
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u);
+        f32x16 acc0 = zero16(), acc1 = zero16();
+        FFNO_NOUNROLL
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            Bf3 Ff[4];
+            int idx = (km * (64 * chunk + 8 * half)) % L;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * (4 * chunk + u) + 8 * half + e;
+                    f[e] = n < L ? amul * tws[tbase + idx] : 0.f;
+                    idx += km;
+                    if (idx >= L) idx -= L;
+                }
+                idx += k8;
+                if (idx >= L) idx -= L;
+                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+            }
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
+                                        raw[u][6].x, raw[u][7].x);
+                const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
+                                        raw[u][6].y, raw[u][7].y);
+                if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
+                acc0 = mfma_x3(Ff[u], b0, acc0);
+                acc1 = mfma_x3(Ff[u], b1, acc1);
+            }
+        }
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int kr = 32 * rt + drow(r, half);
+            if (kr < 2 * K)
+                *reinterpret_cast<float2*>(S.out + (((long)(kr >> 1) * R + line) * 2 + (kr & 1)) * C + 2 * j) =
+                    make_float2(acc0[r], acc1[r]);
+        }
+    }
+}
+
+__device__ __forceinline__ void x3_mode_mix_body(const X3Stage& S, int conj_t, int k, int bx, int nbx) {
+    using F = X3Cfg;
+    constexpr int C = F::C;
+    const int R = S.R;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const u32x4* __restrict__ wk = S.wpk + (long)k * F::MODE_FRAGS * F::FRAG;
+    const float* xin = S.in + (long)k * R * 2 * C;
+    float* yout = S.out + (long)k * R * 2 * C;
+    const int ntiles = (R + 15) >> 4;
+    for (int tile = bx * 4 + wave; tile < ntiles; tile += nbx * 4) {
+        Bf3 ring[4];
+        FFNO_UNROLL
+        for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(wk, f, lane);
+        const int line = min(16 * tile + (j >> 1), R - 1);           // MFMA row j = (line, part j & 1); dead rows re-read R - 1
+        const float* arow = xin + ((long)line * 2 + (j & 1)) * C + 8 * half;
+        Bf3 a[4];
+        FFNO_UNROLL
+        for (int st = 0; st < 4; ++st) {
+            const float4 v0 = *reinterpret_cast<const float4*>(arow + 16 * st);
+            const float4 v1 = *reinterpret_cast<const float4*>(arow + 16 * st + 4);
+            a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+        }
+        f32x16 p[4];
+        FFNO_UNROLL
+        for (int pt = 0; pt < 4; ++pt) p[pt] = zero16();
+        FFNO_UNROLL
+        for (int st = 0; st < 4; ++st) {
+            FFNO_UNROLL
+            for (int pt = 0; pt < 4; ++pt) {
+                const Bf3 b = ring[pt];
+                if (st < 3) ring[pt] = x3_load_frag(wk, (st + 1) * 4 + pt, lane);
+                p[pt] = mfma_x3(a[st], b, p[pt]);
+            }
+        }
+        FFNO_UNROLL
+        for (int q = 0; q < 8; ++q) {
+            const int ol = 16 * tile + (q & 1) + 4 * (q >> 1) + 2 * half;
+            float yr[2], yi[2];
+            FFNO_UNROLL
+            for (int t = 0; t < 2; ++t) {
+                const float p1r = p[t][2 * q], p1i = p[t][2 * q + 1];
+                const float p2r = p[2 + t][2 * q], p2i = p[2 + t][2 * q + 1];
+                if (conj_t == 0) {
+                    yr[t] = p1r - p2i;
+                    yi[t] = p2r + p1i;
+                } else {
+                    yr[t] = p1r + p2i;
+                    yi[t] = p1i - p2r;
+                }
+            }
+            if (ol < R) {
+                float* dst = yout + (long)ol * 2 * C + 2 * j;
+                *reinterpret_cast<float2*>(dst) = make_float2(yr[0], yr[1]);
+                *reinterpret_cast<float2*>(dst + C) = make_float2(yi[0], yi[1]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void x3_dft_inv_body(const X3Stage& S, int apply_ck, int bidx, int nblk) {
+    constexpr int C = X3Cfg::C;
+    constexpr int NST = 4;                    // k-steps over the (mode, part) rows: K <= 32
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+    const int R = S.R, L = S.L, K = S.K;
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = S.tw[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const long es = S.lm.elem_stride;
+    const int RTtot = (L + 31) >> 5, NP = (RTtot + 1) >> 1;
+    const unsigned hoff = (unsigned)(4 * half * es * 4);
+    const long nitems = (long)R * NP;
+    for (long item = (long)bidx * 4 + wave; item < nitems; item += (long)nblk * 4) {
+        const int line = (int)(item / NP), rt0 = 2 * (int)(item % NP);
+        const unsigned lo = (unsigned)((S.lm.base(line) + 2 * j) * 4) + hoff;
+        Bf3 y[NST][2];
+        FFNO_UNROLL
+        for (int st = 0; st < NST; ++st) {
+            float2 v[8];
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * st + 8 * half + e;
+                v[e] = make_float2(0.f, 0.f);
+                if (kk < 2 * K) v[e] = *reinterpret_cast<const float2*>(S.in + (((long)(kk >> 1) * R + line) * 2 + (kk & 1)) * C + 2 * j);
+            }
+            y[st][0] = split3_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+            y[st][1] = split3_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+        }
+        FFNO_NOUNROLL
+        for (int q = 0; q < 2; ++q) {
+            const int rt = rt0 + q;
+            if (rt >= RTtot) break;
+            const int n = 32 * rt + j;
+            const int nm = n < L ? n : 0;
+            float2 pre[16];
+            const char* addsrc = S.resid ? reinterpret_cast<const char*>(S.resid)
+                                         : (S.accumulate ? reinterpret_cast<const char*>(S.out) : nullptr);
+            if (addsrc) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int nu = min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
+                    pre[r] = *reinterpret_cast<const float2*>(addsrc + (lo - hoff) + (unsigned)nu * (unsigned)(es * 4));
+                }
+            }
+            f32x16 o0 = zero16(), o1 = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < NST; ++st) {
+                float g[8];
+                int idx = (nm * (8 * st + 4 * half)) % L;
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+                    const float ck = (apply_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                    g[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tws[(part ? L : 0) + idx] : 0.f;
+                    if (part) {
+                        idx += nm;
+                        if (idx >= L) idx -= L;
+                    }
+                }
+                const Bf3 G = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                o0 = mfma_x3(G, y[st][0], o0);
+                o1 = mfma_x3(G, y[st][1], o1);
+            }
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
+                if (nu + 4 * half < L) {
+                    const long uo = (long)nu * es * 4;
+                    float2 o = make_float2(o0[r], o1[r]);
+                    if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
+                    if (S.accumulate && S.resid) {
+                        const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(S.out) + uo + lo);
+                        o.x += pv.x, o.y += pv.y;
+                    }
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(S.out) + uo + lo) = o;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void x3_dft_fwd_pair_kernel(X3Stage a, X3Stage b, int n0, int scale_ck) {
+    const bool second = (int)blockIdx.x >= n0;
+    x3_dft_fwd_body(second ? b : a, scale_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
+}
+// grid.y = Ka + Kb modes: the first Ka rows of workgroups mix branch a, the rest branch b
+__global__ __launch_bounds__(256) void x3_mode_mix_pair_kernel(X3Stage a, X3Stage b, int conj_t) {
+    const bool second = (int)blockIdx.y >= a.K;
+    x3_mode_mix_body(second ? b : a, conj_t, second ? blockIdx.y - a.K : blockIdx.y, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage b, int n0, int apply_ck) {
+    const bool second = (int)blockIdx.x >= n0;
+    x3_dft_inv_body(second ? b : a, apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
+}
+
 static inline int x3_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -374,13 +622,17 @@ using namespace ffno;
 
 extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && 2 * K <= X3Cfg::KK && L >= 2 && L <= 2048) ? 1 : 0; }
 
+extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
+    return (C == X3Cfg::C && K >= 1 && K <= 32 && L >= 2 && L <= 2048) ? 1 : 0;
+}
+
 extern "C" size_t ffno_spectral_x3_pack_bytes(int C, int K) {
-    return C == X3Cfg::C ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
+    return (C == X3Cfg::C && K >= 1 && K <= 32) ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
 }
 
 extern "C" int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream) {
     if (!descs_dev || n <= 0 || max_K <= 0) return FFNO_EINVAL;
-    if (C != X3Cfg::C || 2 * max_K > X3Cfg::KK) return FFNO_EUNSUPPORTED;
+    if (C != X3Cfg::C || max_K > 32) return FFNO_EUNSUPPORTED;
     static_assert(sizeof(ffno_x3pack_desc) == sizeof(X3PackDesc), "descriptor layout");
     const int threads = max_K * X3Cfg::MODE_FRAGS * 64;
     FFNO_LAUNCH(x3_pack_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
@@ -425,5 +677,55 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     // interleave: bit 0 = workgroup -> branch map; bits 8.. = start skew of every other workgroup in units of 256 cycles
     FFNO_LAUNCH(spectral_x3_pair_kernel, grid, block, smem, (hipStream_t)stream, a, b, n0, ((interleave & 1) && n0 == n1) ? 1 : 0,
                 (interleave >> 8) * 256);
+    return x3_status();
+}
+
+// The two branches through the three split-bf16 STAGE kernels, as three paired launches (see ffno_spectral_staged_pair).
+static int x3_stage_args(X3Stage& s, const ffno_fused_branch* b, int C) {
+    if (!b || !b->in || !b->out || !b->spec_save || !b->tw || b->B <= 0 || b->M <= 0 || b->N <= 0 || b->K <= 0 ||
+        (b->axis != 0 && b->axis != 1))
+        return FFNO_EINVAL;
+    const int L = b->axis == 0 ? b->N : b->M;
+    const int R = b->axis == 0 ? b->B * b->M : b->B * b->N;
+    if (b->K > L / 2 + 1) return FFNO_EMODES;
+    if (!ffno_spectral_x3_staged_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
+    s = X3Stage{b->in, b->out, b->resid, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
+                make_linemap(b->axis, b->B, b->M, b->N, C), b->accumulate};
+    return FFNO_OK;
+}
+
+extern "C" int ffno_spectral_x3_staged_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, float* mix_a, float* mix_b,
+                                            int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream) {
+    if (!ba || !bb || !mix_a || !mix_b) return FFNO_EINVAL;
+    if (ba->out == bb->out || ba->spec_save == bb->spec_save || mix_a == mix_b) return FFNO_EINVAL;
+    if ((ba->planes == nullptr) != (bb->planes == nullptr)) return FFNO_EINVAL;
+    X3Stage a, b;
+    int rc = x3_stage_args(a, ba, C);
+    if (rc) return rc;
+    rc = x3_stage_args(b, bb, C);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
+    // stage A: activations -> spectra (spec_save)
+    X3Stage fa = a, fb = b;
+    fa.out = ba->spec_save, fb.out = bb->spec_save;
+    const int rta = (2 * a.K + 31) / 32, rtb = (2 * b.K + 31) / 32;
+    int n0 = (int)(((long)a.R * rta + 3) / 4), n1 = (int)(((long)b.R * rtb + 3) / 4);
+    FFNO_LAUNCH(x3_dft_fwd_pair_kernel, dim3(n0 + n1), dim3(256), smem, st, fa, fb, n0, scale_ck_fwd);
+    // stage B: spectra -> mixed spectra
+    const float *ya = ba->spec_save, *yb = bb->spec_save;
+    if (ba->planes) {
+        X3Stage ma = a, mb = b;
+        ma.in = ba->spec_save, ma.out = mix_a, mb.in = bb->spec_save, mb.out = mix_b;
+        const int tiles = (max(a.R, b.R) + 15) / 16;
+        FFNO_LAUNCH(x3_mode_mix_pair_kernel, dim3((tiles + 3) / 4, a.K + b.K), dim3(256), 0, st, ma, mb, conj_transpose);
+        ya = mix_a, yb = mix_b;
+    }
+    // stage C: spectra -> activations (+ accumulate / residual)
+    X3Stage ia = a, ib = b;
+    ia.in = ya, ib.in = yb;
+    const int npa = (((a.L + 31) / 32) + 1) / 2, npb = (((b.L + 31) / 32) + 1) / 2;
+    n0 = (int)(((long)a.R * npa + 3) / 4), n1 = (int)(((long)b.R * npb + 3) / 4);
+    FFNO_LAUNCH(x3_dft_inv_pair_kernel, dim3(n0 + n1), dim3(256), smem, st, ia, ib, n0, apply_ck_inv);
     return x3_status();
 }

@@ -228,7 +228,8 @@ class FFNOEngine:
                                    v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
             bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(sv1), _p(planes1), _p(self._twiddle(v1.L)),
                                    v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0)
-            self._k("spectral_staged_pair" + ("" if fwd else "(adj)"), lib.ffno_spectral_staged_pair, ctypes.byref(ba),
+            fn = lib.ffno_spectral_x3_staged_pair if x3 else lib.ffno_spectral_staged_pair      # x3: planes are the packed sets
+            self._k("spectral_staged_pair" + ("" if fwd else "(adj)"), fn, ctypes.byref(ba),
                     ctypes.byref(bb), _p(ws.SY), _p(ws.SY2), self.C, ck_f, ck_i, conj, st)
             return
         ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)),
@@ -305,7 +306,7 @@ class FFNOEngine:
         if self.spectral == "factorized" and self.mode == "full":
             for si in range(len(self.planes)):
                 for w, K in enumerate(plane_modes):
-                    nb = int(lib.ffno_spectral_x3_pack_bytes(self.C, K)) if lib.ffno_spectral_x3_supported(self.C, K, 2 * K) else 0
+                    nb = int(lib.ffno_spectral_x3_pack_bytes(self.C, K)) if lib.ffno_spectral_x3_staged_supported(self.C, K, 2 * K) else 0
                     if nb:
                         self.xplanes[si][w] = tuple(torch.empty(nb // 4, dtype=torch.int32, device=dev) for _ in range(2))
         self._x3pack_sig = None
@@ -673,6 +674,11 @@ class FFNOEngine:
         singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)
         conc = pair is not None
         x3pair = bool(conc and x3[pair[0]] and x3[pair[1]])
+        if conc and not fused[pair[0]]:      # both axes staged: the split-bf16 stage kernels when the library takes the shape
+            x3pair = bool(self.use_x3 and self.spectral == "factorized" and all(
+                lib.ffno_spectral_x3_staged_supported(C, ws.views[w].K, ws.views[w].L)
+                and (not full or self.xplanes[0][w] is not None) for w in pair)
+                and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork)
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None

@@ -157,7 +157,8 @@ int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch
  * lines.  The branch descriptor is ffno_fused_branch with `planes` pointing at PACKED weights:
  *   ffno_spectral_x3_pack: planes[k][re|im][i][o] (forward: wp, adjoint: wpt of ffno_fw_pack) -> fragment order, split;
  *   ffno_spectral_x3_pack_bytes(C, K) bytes per packed set.  descs is a DEVICE array, one launch for all sets.
- * Supported: C = 64, K <= 16, L <= 2048 (ffno_spectral_x3_supported); the fp32-MFMA kernels above cover the rest.
+ * Supported by the fused kernel: C = 64, K <= 16, L <= 2048 (ffno_spectral_x3_supported); packs exist for K <= 32 (the
+ * staged variant below); the fp32-MFMA kernels above cover the rest.
  * interleave != 0 (pair, equal workgroup counts): even workgroups run branch a, odd ones branch b.
  * --------------------------------------------------------------------------------------------- */
 typedef struct ffno_x3pack_desc {
@@ -173,6 +174,13 @@ int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck_fwd, int a
                      void* stream);
 int ffno_spectral_x3_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                           int apply_ck_inv, int conj_transpose, int interleave, void* stream);
+/* The same arithmetic for the shapes outside the fused tile (17..32 modes: 256 x 256 grids with 32 modes, the 32-mode axis
+ * of the plasticity / airfoil meshes): the two branches through three paired STAGE launches, spectra through HBM, exactly like
+ * ffno_spectral_staged_pair (same arguments; `planes` = packed sets; spec_save must be set; mix_a / mix_b scratch spectra).
+ * Supported: C = 64, K <= 32, L <= 2048 (ffno_spectral_x3_staged_supported). */
+int ffno_spectral_x3_staged_supported(int C, int K, int L);
+int ffno_spectral_x3_staged_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, float* mix_a, float* mix_b, int C,
+                                 int scale_ck_fwd, int apply_ck_inv, int conj_transpose, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layer level (SURVEY 8b "signature level 2"): one call enqueues a whole factorized Fourier layer -- SpectralConv2d.forward

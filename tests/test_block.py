@@ -27,13 +27,13 @@ TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64
 GPU_ONLY = {"c64_4l_markov", "c64_24l_markov", "c64_3l_unshared"}  # too slow for the CPU emulator
 
 
-@pytest.mark.parametrize("fused", ["x3", True, False], ids=["x3", "fused", "staged"])
+@pytest.mark.parametrize("fused", ["x3", True, False, "x3staged"], ids=["x3", "fused", "staged", "x3staged"])
 @pytest.mark.parametrize("tag", TAGS)
 def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     if host_device == "cpu" and tag in GPU_ONLY:
         pytest.skip("emulator too slow for this size; runs with -m gpu")
-    x3 = fused == "x3"          # the split-bf16 branch kernel (forced on for the small golden grids) / the fp32-MFMA one
-    fused = bool(fused)
+    x3 = fused in ("x3", "x3staged")    # the split-bf16 branch kernels (forced on for the small golden grids) / the fp32-MFMA ones
+    fused = fused in ("x3", True)         # "x3staged": the three split-bf16 STAGE kernels (the 17..32-mode path)
     if x3 and (tag in ("c32_nown", "c64_nofourier")):
         pytest.skip("no split-bf16 branch for this configuration (width 32 / no spectral branch)")
     if x3 and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass", "c64_sharefork_fork"):
@@ -78,9 +78,9 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     import oracle_util as ou
     eng = blk.engine()
     masks = ou.engine_relu_masks(eng)
-    label = f"block {tag} {'x3' if x3 else 'fused' if fused else 'staged'} {host_device}"
+    label = f"block {tag} {('x3' if fused else 'x3staged') if x3 else 'fused' if fused else 'staged'} {host_device}"
     if x3:
-        assert any(blk.engine()._saved_x3[0]), "the split-bf16 branch kernel did not run"
+        assert any(blk.engine()._saved_x3[0]) or blk.engine()._saved_x3[1], "the split-bf16 branch kernels did not run"
     print(f"[{label}] worst gradient vs reference golden {errs[worst]:.2e} ({worst})")
     ou.check_grads_at_rounding_level(label, {n: named[n].grad.cpu().numpy() for n in eng.param_names},
                                      lambda dt: ou.oracle_block_run(kw, seed, B, M, N, dtype=dt, relu_masks=masks)[2])

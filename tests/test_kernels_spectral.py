@@ -457,3 +457,41 @@ def test_spectral_x3_support_matrix(be):
     assert lib.ffno_spectral_x3_supported(64, 17, 64) == 0
     assert lib.ffno_spectral_x3_supported(32, 8, 64) == 0
     assert lib.ffno_spectral_x3_pack_bytes(32, 8) == 0
+
+
+@pytest.mark.parametrize("B,M,N,K", [(2, 10, 12, 5), (1, 40, 48, 20), (1, 66, 70, 32), (3, 7, 9, 3)])
+@pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
+def test_spectral_x3_staged_pair(be, B, M, N, K, direction):
+    """The split-bf16 STAGE kernels (17..32 modes: the 256 x 256 regime) as three paired launches: both axes against the
+    fp64 reference, with the saved spectra, accumulate + residual on the first branch, ragged line counts and lengths."""
+    from fourierflow_amd._capi import FusedBranch
+    C = 64
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + K)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    resid = rs.standard_normal(x.shape).astype(np.float32)
+    base = rs.standard_normal(x.shape).astype(np.float32)
+    dx, dres = be.put(x), be.put(resid)
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br, keep, refs = [], [], []
+    for axis in (0, 1):
+        L = N if axis == 0 else M
+        assert lib.ffno_spectral_x3_staged_supported(C, K, L) == 1
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        pk_f, pk_a, kp = _x3_pack(be, w, K)
+        keep.append(kp)
+        planes = None if direction == "lowpass" else (pk_a if direction == "adj" else pk_f)
+        br.append(dict(axis=axis, R=B * M if axis == 0 else B * N, tw=be.twiddle(L), planes=planes))
+        refs.append(_branch_reference(x, w, K, axis, direction))
+    outs, sv = [be.put(base), be.empty(x.shape)], [be.empty((K, b["R"], 2, C)) for b in br]
+    mixes = [be.empty((K, b["R"], 2, C)) for b in br]
+    args = [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"]), p(b["tw"]), B, M, N, K,
+                        b["axis"], int(i == 0)) for i, b in enumerate(br)]
+    assert lib.ffno_spectral_x3_staged_pair(ctypes.byref(args[0]), ctypes.byref(args[1]), p(mixes[0]), p(mixes[1]), C, fwd_ck,
+                                            inv_ck, conj, None) == 0
+    assert rel_l2(be.get(outs[0]), base + resid + refs[0][0]) < TOL
+    assert rel_l2(be.get(outs[1]), refs[1][0]) < TOL
+    for i in range(2):
+        assert rel_l2(be.get(sv[i]), refs[i][1]) < TOL
+    assert lib.ffno_spectral_x3_staged_pair(ctypes.byref(args[0]), ctypes.byref(args[0]), p(mixes[0]), p(mixes[1]), C, 0, 1, 0, None) == -1
+    assert lib.ffno_spectral_x3_staged_supported(64, 33, 128) == 0 and lib.ffno_spectral_x3_staged_supported(32, 8, 64) == 0
