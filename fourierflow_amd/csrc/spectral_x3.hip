@@ -89,7 +89,7 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 }
 
 // ---- the branch --------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void spectral_x3_body(const X3Args& A, int bidx, int skew_cycles) {
+__device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
     __shared__ __attribute__((aligned(16))) float XS[F::NL * F::LSF];
@@ -360,7 +360,23 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     const int idx = interleave ? (w >> 1) : (second ? w - n0 : w);
     // skew > 0: every other workgroup of each branch starts `skew` cycles late, so that its HBM-bound phases (line loads,
     // output stores) fall on the L2 / matrix phase of its neighbours instead of all 256 CUs hitting HBM in lockstep
-    spectral_x3_body(second ? b : a, idx, (idx & 1) ? skew : 0);
+    X3Args s;
+    s.in = second ? b.in : a.in;
+    s.out = second ? b.out : a.out;
+    s.resid = second ? b.resid : a.resid;
+    s.spec_save = second ? b.spec_save : a.spec_save;
+    s.wpk = second ? b.wpk : a.wpk;
+    s.tw = second ? b.tw : a.tw;
+    s.R = second ? b.R : a.R;
+    s.L = second ? b.L : a.L;
+    s.K = second ? b.K : a.K;
+    s.lm.lines_per_group = second ? b.lm.lines_per_group : a.lm.lines_per_group;
+    s.lm.group_stride = second ? b.lm.group_stride : a.lm.group_stride;
+    s.lm.line_stride = second ? b.lm.line_stride : a.lm.line_stride;
+    s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
+    s.fwd_ck = a.fwd_ck, s.inv_ck = a.inv_ck, s.conj_t = a.conj_t;      // common to both branches
+    s.accumulate = second ? b.accumulate : a.accumulate;
+    spectral_x3_body(s, idx, (idx & 1) ? skew : 0);
 }
 
 // ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
@@ -380,7 +396,7 @@ struct X3Stage {
     int accumulate;
 };
 
-__device__ __forceinline__ void x3_dft_fwd_body(const X3Stage& S, int scale_ck, int bidx, int nblk) {
+__device__ __forceinline__ void x3_dft_fwd_body(const X3Stage S, int scale_ck, int bidx, int nblk) {
     constexpr int C = X3Cfg::C;
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
@@ -393,9 +409,9 @@ __device__ __forceinline__ void x3_dft_fwd_body(const X3Stage& S, int scale_ck, 
     const long es = S.lm.elem_stride;
     const unsigned esb = (unsigned)(es * 4);
     const int nchunks = (L + 63) >> 6;
-    const long nitems = (long)R * RT;
-    for (long item = (long)bidx * 4 + wave; item < nitems; item += (long)nblk * 4) {
-        const int line = (int)(item / RT), rt = (int)(item % RT);
+    const int nitems = R * RT;
+    for (int item = bidx * 4 + wave; item < nitems; item += nblk * 4) {
+        const int line = item / RT, rt = item - line * RT;
         const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
         const bool rowok = kk < 2 * K;
         const float ck = (scale_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
@@ -454,7 +470,7 @@ __device__ __forceinline__ void x3_dft_fwd_body(const X3Stage& S, int scale_ck, 
     }
 }
 
-__device__ __forceinline__ void x3_mode_mix_body(const X3Stage& S, int conj_t, int k, int bx, int nbx) {
+__device__ __forceinline__ void x3_mode_mix_body(const X3Stage S, int conj_t, int k, int bx, int nbx) {
     using F = X3Cfg;
     constexpr int C = F::C;
     const int R = S.R;
@@ -514,7 +530,7 @@ __device__ __forceinline__ void x3_mode_mix_body(const X3Stage& S, int conj_t, i
     }
 }
 
-__device__ __forceinline__ void x3_dft_inv_body(const X3Stage& S, int apply_ck, int bidx, int nblk) {
+__device__ __forceinline__ void x3_dft_inv_body(const X3Stage S, int apply_ck, int bidx, int nblk) {
     constexpr int C = X3Cfg::C;
     constexpr int NST = 4;                    // k-steps over the (mode, part) rows: K <= 32
     FFNO_DYN_SMEM(smem);
@@ -527,13 +543,18 @@ __device__ __forceinline__ void x3_dft_inv_body(const X3Stage& S, int apply_ck, 
     const long es = S.lm.elem_stride;
     const int RTtot = (L + 31) >> 5, NP = (RTtot + 1) >> 1;
     const unsigned hoff = (unsigned)(4 * half * es * 4);
-    const long nitems = (long)R * NP;
-    for (long item = (long)bidx * 4 + wave; item < nitems; item += (long)nblk * 4) {
-        const int line = (int)(item / NP), rt0 = 2 * (int)(item % NP);
+    const int nitems = R * NP;
+    for (int item = bidx * 4 + wave; item < nitems; item += nblk * 4) {
+        const int line = item / NP, rt0 = 2 * (item - line * NP);
         const unsigned lo = (unsigned)((S.lm.base(line) + 2 * j) * 4) + hoff;
-        Bf3 y[NST][2];
+        // k-step outer, output tile inner: the spectrum rows of a k-step are split once and serve both 32-sample tiles; only
+        // the four accumulators stay live across k-steps (<= 128 VGPRs: four waves per SIMD hide the epilogue's reads)
+        f32x16 o[2][2];
+        FFNO_UNROLL
+        for (int q = 0; q < 2; ++q) o[q][0] = zero16(), o[q][1] = zero16();
         FFNO_UNROLL
         for (int st = 0; st < NST; ++st) {
+            if (16 * st >= 2 * K) continue;
             float2 v[8];
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
@@ -541,28 +562,12 @@ __device__ __forceinline__ void x3_dft_inv_body(const X3Stage& S, int apply_ck, 
                 v[e] = make_float2(0.f, 0.f);
                 if (kk < 2 * K) v[e] = *reinterpret_cast<const float2*>(S.in + (((long)(kk >> 1) * R + line) * 2 + (kk & 1)) * C + 2 * j);
             }
-            y[st][0] = split3_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
-            y[st][1] = split3_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
-        }
-        FFNO_NOUNROLL
-        for (int q = 0; q < 2; ++q) {
-            const int rt = rt0 + q;
-            if (rt >= RTtot) break;
-            const int n = 32 * rt + j;
-            const int nm = n < L ? n : 0;
-            float2 pre[16];
-            const char* addsrc = S.resid ? reinterpret_cast<const char*>(S.resid)
-                                         : (S.accumulate ? reinterpret_cast<const char*>(S.out) : nullptr);
-            if (addsrc) {
-                FFNO_UNROLL
-                for (int r = 0; r < 16; ++r) {
-                    const int nu = min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
-                    pre[r] = *reinterpret_cast<const float2*>(addsrc + (lo - hoff) + (unsigned)nu * (unsigned)(es * 4));
-                }
-            }
-            f32x16 o0 = zero16(), o1 = zero16();
+            const Bf3 y0 = split3_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+            const Bf3 y1 = split3_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
             FFNO_UNROLL
-            for (int st = 0; st < NST; ++st) {
+            for (int q = 0; q < 2; ++q) {
+                const int n = 32 * (rt0 + q) + j;
+                const int nm = n < L ? n : 0;
                 float g[8];
                 int idx = (nm * (8 * st + 4 * half)) % L;
                 FFNO_UNROLL
@@ -576,39 +581,69 @@ __device__ __forceinline__ void x3_dft_inv_body(const X3Stage& S, int apply_ck, 
                     }
                 }
                 const Bf3 G = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
-                o0 = mfma_x3(G, y[st][0], o0);
-                o1 = mfma_x3(G, y[st][1], o1);
+                o[q][0] = mfma_x3(G, y0, o[q][0]);
+                o[q][1] = mfma_x3(G, y1, o[q][1]);
             }
+        }
+        const char* addsrc = S.resid ? reinterpret_cast<const char*>(S.resid)
+                                     : (S.accumulate ? reinterpret_cast<const char*>(S.out) : nullptr);
+        FFNO_UNROLL
+        for (int q = 0; q < 2; ++q) {
+            const int rt = rt0 + q;
+            if (rt >= RTtot) continue;
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
                 if (nu + 4 * half < L) {
                     const long uo = (long)nu * es * 4;
-                    float2 o = make_float2(o0[r], o1[r]);
-                    if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
+                    float2 ov = make_float2(o[q][0][r], o[q][1][r]);
+                    if (addsrc) {
+                        const float2 pv = *reinterpret_cast<const float2*>(addsrc + uo + lo);
+                        ov.x += pv.x, ov.y += pv.y;
+                    }
                     if (S.accumulate && S.resid) {
                         const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(S.out) + uo + lo);
-                        o.x += pv.x, o.y += pv.y;
+                        ov.x += pv.x, ov.y += pv.y;
                     }
-                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(S.out) + uo + lo) = o;
+                    *reinterpret_cast<float2*>(reinterpret_cast<char*>(S.out) + uo + lo) = ov;
                 }
             }
         }
     }
 }
 
+// one of two kernel-argument structs, selected field by field (a reference to `second ? b : a` would force an addressable
+// copy in scratch memory and turn every field access into a scratch load)
+__device__ __forceinline__ X3Stage x3_pick(const X3Stage& a, const X3Stage& b, bool second) {
+    X3Stage s;
+    s.in = second ? b.in : a.in;
+    s.out = second ? b.out : a.out;
+    s.resid = second ? b.resid : a.resid;
+    s.wpk = second ? b.wpk : a.wpk;
+    s.tw = second ? b.tw : a.tw;
+    s.R = second ? b.R : a.R;
+    s.L = second ? b.L : a.L;
+    s.K = second ? b.K : a.K;
+    s.lm.lines_per_group = second ? b.lm.lines_per_group : a.lm.lines_per_group;
+    s.lm.group_stride = second ? b.lm.group_stride : a.lm.group_stride;
+    s.lm.line_stride = second ? b.lm.line_stride : a.lm.line_stride;
+    s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
+    s.accumulate = second ? b.accumulate : a.accumulate;
+    return s;
+}
+
 __global__ __launch_bounds__(256) void x3_dft_fwd_pair_kernel(X3Stage a, X3Stage b, int n0, int scale_ck) {
     const bool second = (int)blockIdx.x >= n0;
-    x3_dft_fwd_body(second ? b : a, scale_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
+    x3_dft_fwd_body(x3_pick(a, b, second), scale_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 // grid.y = Ka + Kb modes: the first Ka rows of workgroups mix branch a, the rest branch b
 __global__ __launch_bounds__(256) void x3_mode_mix_pair_kernel(X3Stage a, X3Stage b, int conj_t) {
     const bool second = (int)blockIdx.y >= a.K;
-    x3_mode_mix_body(second ? b : a, conj_t, second ? blockIdx.y - a.K : blockIdx.y, blockIdx.x, gridDim.x);
+    x3_mode_mix_body(x3_pick(a, b, second), conj_t, second ? blockIdx.y - a.K : blockIdx.y, blockIdx.x, gridDim.x);
 }
 __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage b, int n0, int apply_ck) {
     const bool second = (int)blockIdx.x >= n0;
-    x3_dft_inv_body(second ? b : a, apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
+    x3_dft_inv_body(x3_pick(a, b, second), apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 
 static inline int x3_status() {

@@ -36,6 +36,8 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     fused = fused in ("x3", True)         # "x3staged": the three split-bf16 STAGE kernels (the 17..32-mode path)
     if x3 and (tag in ("c32_nown", "c64_nofourier")):
         pytest.skip("no split-bf16 branch for this configuration (width 32 / no spectral branch)")
+    if x3 and not fused and "fork" in tag.replace("sharefork", ""):
+        pytest.skip("fork heads run the branches one by one: the paired split-bf16 stage launch is not scheduled")
     if x3 and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass", "c64_sharefork_fork"):
         pytest.skip("x3 path on the emulator: three representative configs are enough")
     g = gu.load_golden("block_" + tag)
