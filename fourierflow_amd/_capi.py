@@ -96,6 +96,7 @@ SIGNATURES = {
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_x3_supported": (I, [I, I, I]),
+    "ffno_spectral_x3_set_round": (I, [I]),
     "ffno_spectral_x3_pack_bytes": (SZ, [I, I]),
     "ffno_spectral_x3_pack": (I, [P, I, I, I, P]),
     "ffno_spectral_x3": (I, [P, I, I, I, I, P]),

@@ -31,8 +31,7 @@ namespace ffno {
 
 struct X3Cfg {
     static constexpr int C = 64;
-    static constexpr int NL = 16;              // lines per workgroup
-    static constexpr int NW = 8;               // waves per workgroup (two lines each)
+    static constexpr int NW = 8;               // waves per workgroup (one or two lines each: 8- or 16-line tiles)
     static constexpr int KK = 32;              // (mode, re/im) rows per line: K <= 16
     static constexpr int RS = 68;              // row stride (floats): +4 shifts the re / im rows of a line by 4 banks
     static constexpr int LSF = KK * RS + 8;    // line stride (floats): +8 shifts consecutive lines by 8 banks
@@ -89,10 +88,16 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 }
 
 // ---- the branch --------------------------------------------------------------------------------------------------------
+// NL = lines per workgroup: 16 (two per wave; the per-mode mix fills its 32-row tile) or 8 (one per wave: launches with few
+// lines -- batch-1 rollout: 64 lines per axis -- spread over twice as many CUs; the mix then uses rows 0..15 of the tile,
+// rows 16..31 repeat them and are dropped).
+template <int NL>
 __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
-    __shared__ __attribute__((aligned(16))) float XS[F::NL * F::LSF];
+    constexpr int NLW = NL / F::NW;                 // lines per wave
+    static_assert(NL == 16 || NL == 8, "16 or 8 lines per workgroup");
+    __shared__ __attribute__((aligned(16))) float XS[NL * F::LSF];
     FFNO_DYN_SMEM(smem);
     float* tws = reinterpret_cast<float*>(smem);
 
@@ -102,9 +107,9 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
-    const int lw = 2 * wave;                       // first of this wave's two lines inside the tile
-    const int line0 = bidx * F::NL + lw;
-    const bool live0 = line0 < R, live1 = line0 + 1 < R;
+    const int lw = NLW * wave;                     // first of this wave's lines inside the tile
+    const int line0 = bidx * NL + lw;
+    const bool live0 = line0 < R, live1 = NLW > 1 && line0 + 1 < R;
     // Addresses = wave-uniform part (tensor base + sample index x element stride: scalar registers) + a 32-bit per-lane byte
     // offset (line base + the lane's channel pair + its half-wave's sample / row offset): one VGPR per line instead of a
     // 64-bit address per access.  (The host side refuses tensors of 4 GiB or more.)
@@ -164,7 +169,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         __syncthreads();
         build_F(0);
         FFNO_UNROLL
-        for (int ln = 0; ln < 2; ++ln) {
+        for (int ln = 0; ln < NLW; ++ln) {
             f32x16 acc0 = zero16(), acc1 = zero16();
             FFNO_NOUNROLL
             for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -179,7 +184,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                                             raw[u][6].y, raw[u][7].y);
                     if (more)
                         load_rows(chunk + 1, u, ln ? lo1 : lo0);
-                    else if (ln == 0)
+                    else if (ln == 0 && NLW > 1)
                         load_rows(0, u, lo1);
                     acc0 = mfma_x3(Ff[u], b0, acc0);
                     acc1 = mfma_x3(Ff[u], b1, acc1);
@@ -210,7 +215,8 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
 
     // ---------------- phase 2: per-mode channel mix of all 16 lines, in place ----------------
     if (A.wpk) {
-        const float* arow = XS + (j >> 1) * LSF + (j & 1) * RS + 8 * half;     // MFMA row j = (line j >> 1, part j & 1)
+        // MFMA row j = (line (j mod 2 NL) >> 1, part j & 1); with 8 lines rows 16..31 repeat rows 0..15
+        const float* arow = XS + ((j & (2 * NL - 1)) >> 1) * LSF + (j & 1) * RS + 8 * half;
         for (int k = wave; k < K; k += F::NW) {
             const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * F::FRAG;
             if (k != wave) {
@@ -238,7 +244,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
             }
             // D rows 2q, 2q+1 of this lane = (re, im) of line (q & 1) + 4 (q >> 1) + 2 half
             FFNO_UNROLL
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < NL / 2; ++q) {           // (8 lines: accumulator registers 0..7 hold the 16 live rows)
                 const int line = (q & 1) + 4 * (q >> 1) + 2 * half;
                 float yr[2], yi[2];
                 FFNO_UNROLL
@@ -291,7 +297,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 }
             }
             FFNO_UNROLL
-            for (int ln = 0; ln < 2; ++ln) {
+            for (int ln = 0; ln < NLW; ++ln) {
                 if (!(ln ? live1 : live0)) continue;
                 const unsigned lo = (ln ? lo1 : lo0) + hoff;
                 // B operands: the line's spectrum, split: slot e of k-step st <-> row kk = 16 st + 8 half + e
@@ -349,11 +355,15 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     }
 }
 
-__global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) { spectral_x3_body(a, blockIdx.x, 0); }
+template <int NL>
+__global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
+    spectral_x3_body<NL>(a, blockIdx.x, 0);
+}
 
 // Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
 // workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
 // weights of ONE branch only; otherwise [0, n0) run a and the rest b.
+template <int NL>
 __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
     const bool second = interleave ? (w & 1) : (w >= n0);
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
     s.fwd_ck = a.fwd_ck, s.inv_ck = a.inv_ck, s.conj_t = a.conj_t;      // common to both branches
     s.accumulate = second ? b.accumulate : a.accumulate;
-    spectral_x3_body(s, idx, (idx & 1) ? skew : 0);
+    spectral_x3_body<NL>(s, idx, (idx & 1) ? skew : 0);
 }
 
 // ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
@@ -646,6 +656,10 @@ __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage
     x3_dft_inv_body(x3_pick(a, b, second), apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 
+static int g_x3_tile_wgs = 256;      // workgroups of one round (one per CU of an MI355X); ffno_spectral_x3_set_round
+// 8-line tiles while the launch still fits one round of workgroups: more CUs busy, same weight stream per workgroup
+static inline bool x3_small_tiles(int Ra, int Rb) { return (Ra + 7) / 8 + (Rb + 7) / 8 <= g_x3_tile_wgs; }
+
 static inline int x3_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -656,6 +670,12 @@ static inline int x3_status() {
 using namespace ffno;
 
 extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && 2 * K <= X3Cfg::KK && L >= 2 && L <= 2048) ? 1 : 0; }
+
+extern "C" int ffno_spectral_x3_set_round(int workgroups) {
+    if (workgroups < 0) return FFNO_EINVAL;
+    g_x3_tile_wgs = workgroups;        // 0: always 16-line tiles
+    return FFNO_OK;
+}
 
 extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
     return (C == X3Cfg::C && K >= 1 && K <= 32 && L >= 2 && L <= 2048) ? 1 : 0;
@@ -692,8 +712,11 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     X3Args a;
     const int rc = x3_args(a, br, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
     if (rc) return rc;
-    const dim3 grid((a.R + X3Cfg::NL - 1) / X3Cfg::NL), block(512);
-    FFNO_LAUNCH(spectral_x3_kernel, grid, block, sizeof(float) * 2 * a.L, (hipStream_t)stream, a);
+    // 8-line tiles when they still fit one round of workgroups (one per CU), else 16-line tiles
+    if (x3_small_tiles(a.R, 0))
+        FFNO_LAUNCH(spectral_x3_kernel<8>, dim3((a.R + 7) / 8), dim3(512), sizeof(float) * 2 * a.L, (hipStream_t)stream, a);
+    else
+        FFNO_LAUNCH(spectral_x3_kernel<16>, dim3((a.R + 15) / 16), dim3(512), sizeof(float) * 2 * a.L, (hipStream_t)stream, a);
     return x3_status();
 }
 
@@ -706,12 +729,17 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     if (rc) return rc;
     rc = x3_args(b, bb, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
     if (rc) return rc;
-    const int n0 = (a.R + X3Cfg::NL - 1) / X3Cfg::NL, n1 = (b.R + X3Cfg::NL - 1) / X3Cfg::NL;
-    const dim3 grid(n0 + n1), block(512);
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
     // interleave: bit 0 = workgroup -> branch map; bits 8.. = start skew of every other workgroup in units of 256 cycles
-    FFNO_LAUNCH(spectral_x3_pair_kernel, grid, block, smem, (hipStream_t)stream, a, b, n0, ((interleave & 1) && n0 == n1) ? 1 : 0,
-                (interleave >> 8) * 256);
+    if (x3_small_tiles(a.R, b.R)) {
+        const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8;
+        FFNO_LAUNCH(spectral_x3_pair_kernel<8>, dim3(n0 + n1), dim3(512), smem, (hipStream_t)stream, a, b, n0,
+                    ((interleave & 1) && n0 == n1) ? 1 : 0, (interleave >> 8) * 256);
+    } else {
+        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16;
+        FFNO_LAUNCH(spectral_x3_pair_kernel<16>, dim3(n0 + n1), dim3(512), smem, (hipStream_t)stream, a, b, n0,
+                    ((interleave & 1) && n0 == n1) ? 1 : 0, (interleave >> 8) * 256);
+    }
     return x3_status();
 }
 

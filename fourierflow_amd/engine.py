@@ -176,11 +176,11 @@ class FFNOEngine:
         # while staging (ffno_ffx_fwd2 / _bwd_data2).  Needs the split-bf16 feed-forward, no fork heads, and both axes on
         # the fused kernel with the same [B, M, N] view (the 2-D operators).
         self.concurrent_branches = True
-        # fused branches on the bf16 matrix cores at fp32 accuracy (spectral_x3.hip: 16 lines per workgroup, packed pre-split
-        # weights) for the axes the library takes (C = 64, K <= 16) with at least ``x3_min_lines`` lines -- below that the
-        # 8-line fp32-MFMA kernel spreads a small launch (batch-1 rollout: 64 lines per axis) over twice as many CUs
+        # fused branches on the bf16 matrix cores at fp32 accuracy (spectral_x3.hip: 16 or 8 lines per workgroup -- the library
+        # picks 8 while the launch still fits one round of workgroups -- packed pre-split weights) for the axes the library
+        # takes (C = 64, K <= 16); 17..32 modes go through the split-bf16 stage kernels
         self.use_x3 = True
-        self.x3_min_lines = 512
+        self.x3_min_lines = 1
         self.x3_interleave = 1       # paired launch: even workgroups branch a, odd ones branch b (one branch's weights per XCD)
         # one C call per layer and direction (ffno_layer_fwd / ffno_layer_bwd: paired branches + feed-forward) instead of two /
         # three; per-kernel timing (a timer attached) needs the individual calls

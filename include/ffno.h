@@ -168,6 +168,10 @@ typedef struct ffno_x3pack_desc {
     int32_t pad_;
 } ffno_x3pack_desc;
 int ffno_spectral_x3_supported(int C, int K, int L);
+/* Tile choice of the fused x3 kernels: 8-line workgroups while ceil(Ra/8) + ceil(Rb/8) <= `workgroups` (default 256 = one
+ * round on an MI355X: small launches such as a batch-1 rollout step reach twice as many CUs), 16-line workgroups otherwise;
+ * 0 = always 16.  Results are bit-identical either way.  Process-wide. */
+int ffno_spectral_x3_set_round(int workgroups);
 size_t ffno_spectral_x3_pack_bytes(int C, int K);
 int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream);
 int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,

@@ -374,10 +374,20 @@ def _x3_pack(be, w, K, C=64):
 X3_SHAPES = [(1, 8, 12, 3), (2, 6, 10, 5), (1, 20, 64, 16), (1, 13, 9, 4), (3, 5, 7, 2), (2, 16, 32, 8), (1, 3, 72, 16), (1, 100, 4, 2)]
 
 
+@pytest.fixture(params=[16, 8], ids=["tile16", "tile8"])
+def x3_tile(request, be):
+    """Lines per workgroup of the fused x3 kernels: force 16-line tiles, or let small launches take 8-line tiles."""
+    assert be.lib.ffno_spectral_x3_set_round(0 if request.param == 16 else 256) == 0
+    yield request.param
+    be.lib.ffno_spectral_x3_set_round(256)
+
+
 @pytest.mark.parametrize("B,M,N,K", X3_SHAPES)
 @pytest.mark.parametrize("axis", [0, 1])
 @pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
-def test_spectral_x3_branch(be, B, M, N, K, axis, direction):
+def test_spectral_x3_branch(be, x3_tile, B, M, N, K, axis, direction):
+    if be.kind == "emu" and x3_tile == 8 and (B, M, N, K) not in ((1, 8, 12, 3), (1, 20, 64, 16), (1, 3, 72, 16)):
+        pytest.skip("8-line tiles on the emulator: three shapes (the GPU run covers all)")
     """The split-bf16 fused branch against fp64 torch.fft at the fp32 tolerance: forward / adjoint / low-pass, the saved
     spectrum, ragged line counts (R % 16 != 0), lines longer than one 64-sample chunk (72) and odd lengths, accumulate +
     residual epilogue."""
@@ -414,7 +424,7 @@ def test_spectral_x3_branch(be, B, M, N, K, axis, direction):
 @pytest.mark.parametrize("B,M,N,K", [(2, 10, 12, 5), (1, 16, 16, 8), (1, 40, 34, 16)])
 @pytest.mark.parametrize("direction", ["fwd", "adj"])
 @pytest.mark.parametrize("interleave", [0, 1])
-def test_spectral_x3_pair_equals_single_branches(be, B, M, N, K, direction, interleave):
+def test_spectral_x3_pair_equals_single_branches(be, x3_tile, B, M, N, K, direction, interleave):
     """Both axes of a layer in one launch (either workgroup -> branch map): bit-identical to the single-branch launches."""
     from fourierflow_amd._capi import FusedBranch
     C = 64
@@ -446,8 +456,14 @@ def test_spectral_x3_pair_equals_single_branches(be, B, M, N, K, direction, inte
     for i in range(2):
         np.testing.assert_array_equal(be.get(outs2[i]), be.get(outs1[i]))
         np.testing.assert_array_equal(be.get(sv2[i]), be.get(sv1[i]))
-    # the first branch against fp64 as well (accumulate onto `base` with a residual)
-    wdummy = None
+    # ... and to the other tile size (rows of the per-mode mix are independent: same products, same order)
+    assert lib.ffno_spectral_x3_set_round(256 if x3_tile == 16 else 0) == 0
+    outs3, sv3 = [be.put(base), be.empty(x.shape)], [be.empty((K, b["R"], 2, C)) for b in br]
+    a3 = branches(outs3, sv3)
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(a3[0]), ctypes.byref(a3[1]), C, fwd_ck, inv_ck, conj, interleave, None) == 0
+    for i in range(2):
+        np.testing.assert_array_equal(be.get(outs3[i]), be.get(outs1[i]))
+        np.testing.assert_array_equal(be.get(sv3[i]), be.get(sv1[i]))
     assert lib.ffno_spectral_x3_pair(ctypes.byref(a2[0]), ctypes.byref(a2[0]), C, fwd_ck, inv_ck, conj, 0, None) == -1   # shared output
 
 
