@@ -130,6 +130,9 @@ SIGNATURES = {
     "ffno_ffx_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce_batched": (I, [P, I, I, I, I, P]),
+    "ffno_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
+    "ffno_layernorm_nsplit": (I, [L]),
+    "ffno_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),
     "ffno_transpose_batched": (I, [P, I, I, I, P]),

@@ -204,12 +204,15 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
             }
         }
     }
-    // weight fragments of phase 2: a ring of four, requested four products (24 MFMAs) before they are used; the first four
-    // of the wave's first mode are requested on this side of the barrier
-    Bf3 ring[4];
+    // weight fragments of phase 2: a ring of RING, requested RING products (6 RING MFMAs ~ 0.6 us at RING = 8) before they are
+    // used -- a wave streams 96 KiB of fragments from L2 and each round trip costs ~0.5-1 us, so the depth of the ring is what
+    // sets its streaming rate (measured: the batch-1 launch, 16 workgroups, is paced by this stream, not by the MFMAs).  The
+    // first RING fragments of the wave's first mode are requested on this side of the barrier.
+    constexpr int RING = 8;
+    Bf3 ring[RING];
     if (A.wpk && wave < K) {
         FFNO_UNROLL
-        for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(A.wpk + (long)wave * F::MODE_FRAGS * F::FRAG, f, lane);
+        for (int f = 0; f < RING; ++f) ring[f] = x3_load_frag(A.wpk + (long)wave * F::MODE_FRAGS * F::FRAG, f, lane);
     }
     __syncthreads();
 
@@ -221,7 +224,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
             const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * F::FRAG;
             if (k != wave) {
                 FFNO_UNROLL
-                for (int f = 0; f < 4; ++f) ring[f] = x3_load_frag(wk, f, lane);
+                for (int f = 0; f < RING; ++f) ring[f] = x3_load_frag(wk, f, lane);
             }
             Bf3 a[4];
             FFNO_UNROLL
@@ -237,8 +240,9 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
             for (int st = 0; st < 4; ++st) {
                 FFNO_UNROLL
                 for (int pt = 0; pt < 4; ++pt) {
-                    const Bf3 b = ring[pt];
-                    if (st < 3) ring[pt] = x3_load_frag(wk, (st + 1) * 4 + pt, lane);
+                    const int f = st * 4 + pt;                       // fragment f lives in ring slot f mod RING
+                    const Bf3 b = ring[f % RING];
+                    if (f + RING < F::MODE_FRAGS) ring[f % RING] = x3_load_frag(wk, f + RING, lane);
                     p[pt] = mfma_x3(a[st], b, p[pt]);
                 }
             }

@@ -72,7 +72,7 @@ class FFNOEngine:
     def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
                  share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
                  padding: int = 0, output_dim: int = 1, use_fork: bool = False, first_axis_first: bool = False,
-                 spectral: str = "factorized"):
+                 spectral: str = "factorized", layer_norm: bool = False):
         if mode not in MODES:
             raise ValueError(f"mode must be one of {list(MODES)}, got {mode!r}")
         if spatial_dims not in (2, 3):
@@ -84,6 +84,10 @@ class FFNOEngine:
             raise ValueError("input_dim must be in 1..63")
         if not (1 <= output_dim <= 8):
             raise ValueError("output_dim must be in 1..8")
+        if layer_norm and use_fork:
+            raise NotImplementedError("layer_norm together with use_fork (per-layer forecast heads) is not built")
+        # FeedForward(layer_norm=True): nn.LayerNorm(width) after the last linear of every feed-forward (feedforward.py:18-19)
+        self.layer_norm = bool(layer_norm)
         if spectral not in ("factorized", "plus", "dct"):
             raise ValueError("spectral must be 'factorized', 'plus' or 'dct'")
         if spectral == "dct" and mode != "full":
@@ -119,6 +123,9 @@ class FFNOEngine:
             else:
                 self.param_shapes[prefix + "weight"] = (rows, cols)
             self.param_shapes[prefix + "bias"] = (rows,)
+            if layer_norm and prefix.endswith("_ff.layers.1.0."):       # the Sequential slot of the reference: layers.1.3
+                self.param_shapes[prefix[:-2] + "3.weight"] = (rows,)
+                self.param_shapes[prefix[:-2] + "3.bias"] = (rows,)
 
         add_linear("in_proj.", C, input_dim)
         self.ff_prefix: List[str] = []
@@ -450,6 +457,12 @@ class FFNOEngine:
             ws.SYb = torch.empty(ws.views[0].spec_y, **f32)
             ws.CW = torch.empty(int(lib.ffno_cdft_rows_ws_floats(B, C, self.K, self.K)), **f32)   # first-axis DFT scratch
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
+        if self.layer_norm:
+            ws.TL = torch.empty(ns, P, C, **f32)                     # feed-forward outputs before the LayerNorm
+            ws.LNS = torch.empty(ns, P, 2, **f32)                    # {mean, rstd} per pixel
+            if save:
+                ws.DT = torch.empty(P, C, **f32)
+                ws.lnpart = torch.empty(2 * C * int(lib.ffno_layernorm_nsplit(P)), **f32)
         if self.use_fork:
             ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
             ws.YL = torch.empty(L, P_in * O, **f32)             # per-layer head outputs (forecast_list)
@@ -679,7 +692,8 @@ class FFNOEngine:
                 lib.ffno_spectral_x3_staged_supported(C, ws.views[w].K, ws.views[w].L)
                 and (not full or self.xplanes[0][w] is not None) for w in pair)
                 and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
-        layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork)
+        layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
+                           and not self.layer_norm)
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
@@ -720,13 +734,21 @@ class FFNOEngine:
                                self._planes_for(si, a, 0, x3pair), self._planes_for(si, b, 0, x3pair), True, st,
                                acc0=int(nwrit > 0), fused=fused[a], x3=x3pair)
             l0, l1, b0, b1 = self._ff_weights(l)
+            # FeedForward(layer_norm=True): the feed-forward writes its raw output, the LayerNorm kernel adds the residual
+            ff_out = ws.TL[sv] if self.layer_norm else (ws.Blast if last else ws.X)
+            ff_res = None if (self.layer_norm or last) else ws.X
             if conc:
                 self._k("ff_fwd", lib.ffno_ffx_fwd2, _p(s_l), _p(ws.T), _p(s_l) if save_for_backward else None,
-                        None if last else _p(ws.X), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(ws.Blast if last else ws.X),
+                        _p(ff_res), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(ff_out),
                         _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
             elif not (self.use_fork and last):    # with fork heads the last layer's backcast only feeds the dead x_L
-                self._ff_fwd(s_l, None if last else ws.X, l0, l1, b0, b1, ws.Blast if last else ws.X,
+                self._ff_fwd(s_l, ff_res, l0, l1, b0, b1, ff_out,
                              ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st)
+            if self.layer_norm:
+                ln = self.ff_prefix[l] + "layers.1.3."
+                self._k("layernorm_fwd", lib.ffno_layernorm_fwd, _p(ws.TL[sv]), _p(self.params[ln + "weight"]),
+                        _p(self.params[ln + "bias"]), None if last else _p(ws.X), _p(ws.Blast if last else ws.X), _p(ws.LNS[sv]),
+                        P, C, 1e-5, st)
             if self.use_fork:
                 c0, c1, cb0, cb1 = self._fc_weights(l)
                 self._ff_fwd(s_l, None, c0, c1, cb0, cb1, ws.F[sv], ws.HF[sv] if save_for_backward else None,
@@ -798,7 +820,7 @@ class FFNOEngine:
         ws.red_jobs = []
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
                            and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
-                           and self.mode != "no-fourier")
+                           and self.mode != "no-fourier" and not self.layer_norm)
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
@@ -850,17 +872,27 @@ class FFNOEngine:
                 have_g1 = True
                 cur = 1 - cur
                 continue
+            g_ff = g_in       # gradient w.r.t. the feed-forward output
+            if self.layer_norm:
+                # through the LayerNorm first (it also folds in the second gradient buffer of a paired adjoint launch)
+                ln = fp + "layers.1.3."
+                two = bool(conc and have_g1)
+                self._k("layernorm_bwd", lib.ffno_layernorm_bwd, _p(ws.TL[l]), _p(ws.LNS[l]), _p(self.params[ln + "weight"]),
+                        _p(g_in), _p(ws.G1) if two else None, _p(g_in) if two else None, _p(ws.DT), _p(ws.lnpart),
+                        _p(gv(ln + "weight")), _p(gv(ln + "bias")), P, C, int(fp in ff_seen), st)
+                g_ff = ws.DT
             if conc:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
-                self._k("ff_bwd_data", lib.ffno_ffx_bwd_data2, _p(g_in), _p(ws.G1) if have_g1 else None,
-                        _p(g_in) if have_g1 else None, _p(ws.MASK[l]), _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), P, C, H, st)
+                two = bool(have_g1 and not self.layer_norm)
+                self._k("ff_bwd_data", lib.ffno_ffx_bwd_data2, _p(g_ff), _p(ws.G1) if two else None,
+                        _p(g_ff) if two else None, _p(ws.MASK[l]), _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), P, C, H, st)
             else:
-                self._ff_bwd_data(g_in, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
+                self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
             if use_side:
                 ev_a.record(main_obj)
                 side.wait_event(ev_a)
                 self._issue_stream = side
-            self._ff_bwd_weights(ws, ws.S[l], g_in, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
+            self._ff_bwd_weights(ws, ws.S[l], g_ff, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
                                  gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side)
             ff_seen.add(fp)
             if self.use_fork:
@@ -977,7 +1009,7 @@ class FFNO2DEngine(FFNOEngine):
     """FNOFactorized2DBlock geometry (the 2-D entry point used by the module mirror and the tests)."""
 
     def __init__(self, *, modes: int, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
-                 share_fork: bool, ff_weight_norm: bool, mode: str = "full", use_fork: bool = False):
+                 share_fork: bool, ff_weight_norm: bool, mode: str = "full", use_fork: bool = False, layer_norm: bool = False):
         super().__init__(modes=modes, width=width, input_dim=input_dim, n_layers=n_layers, factor=factor,
                          share_weight=share_weight, share_fork=share_fork, ff_weight_norm=ff_weight_norm, mode=mode,
-                         spatial_dims=2, padding=0, output_dim=1, use_fork=use_fork)
+                         spatial_dims=2, padding=0, output_dim=1, use_fork=use_fork, layer_norm=layer_norm)

@@ -96,10 +96,12 @@ class FNOFactorized2DBlock(nn.Module):
         super().__init__()
         if in_dropout:
             raise NotImplementedError("in_dropout > 0 is not implemented by the gfx950 kernel set (no config uses it)")
+        if layer_norm and use_fork:
+            raise NotImplementedError("layer_norm together with use_fork is not implemented by the gfx950 kernel set")
         self.modes, self.width, self.input_dim = modes, width, input_dim
         self.n_layers, self.use_fork, self.mode = n_layers, use_fork, mode
         self.share_weight, self.share_fork = share_weight, share_fork
-        self.factor, self.ff_weight_norm = factor, ff_weight_norm
+        self.factor, self.ff_weight_norm, self.layer_norm = factor, ff_weight_norm, bool(layer_norm)
         self.in_proj = WNLinear(input_dim, width, wnorm=ff_weight_norm)
         self.drop = nn.Identity()  # nn.Dropout(in_dropout=0)
 
@@ -131,7 +133,7 @@ class FNOFactorized2DBlock(nn.Module):
             self._engine = FFNO2DEngine(modes=self.modes, width=self.width, input_dim=self.input_dim,
                                         n_layers=self.n_layers, factor=self.factor, share_weight=self.share_weight,
                                         share_fork=self.share_fork, ff_weight_norm=self.ff_weight_norm, mode=self.mode,
-                                        use_fork=self.use_fork)
+                                        use_fork=self.use_fork, layer_norm=self.layer_norm)
         return self._engine
 
     def engine_parameters(self):

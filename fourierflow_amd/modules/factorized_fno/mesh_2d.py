@@ -93,6 +93,7 @@ class FNOFactorizedMesh2D(nn.Module):
                 fourier_weight=self.fourier_weight, factor=factor, ff_weight_norm=ff_weight_norm, n_ff_layers=n_ff_layers,
                 layer_norm=layer_norm, use_fork=False, dropout=0.0, mode='full'))
         self.out = nn.Sequential(WNLinear(self.width, 128, wnorm=ff_weight_norm), WNLinear(128, 1, wnorm=ff_weight_norm))
+        self.layer_norm = bool(layer_norm)
         self._engine = None
         self._generation = 0
 
@@ -101,7 +102,7 @@ class FNOFactorizedMesh2D(nn.Module):
             self._engine = FFNOEngine(modes=(self.modes_x, self.modes_y), width=self.width, input_dim=self.input_dim,
                                       n_layers=self.n_layers, factor=self.factor, share_weight=self.share_weight,
                                       share_fork=False, ff_weight_norm=self.ff_weight_norm, mode="full", spatial_dims=2,
-                                      padding=self.padding, output_dim=1, first_axis_first=True)
+                                      padding=self.padding, output_dim=1, first_axis_first=True, layer_norm=self.layer_norm)
         return self._engine
 
     def engine_parameters(self):

@@ -91,6 +91,7 @@ class FNOFactorizedMesh3D(nn.Module):
                 n_ff_layers=n_ff_layers, layer_norm=layer_norm, use_fork=False, dropout=0.0))
         self.out = nn.Sequential(WNLinear(self.width, 128, wnorm=ff_weight_norm),
                                  WNLinear(128, output_dim, wnorm=ff_weight_norm))
+        self.layer_norm = bool(layer_norm)
         self._engine = None
         self._generation = 0
 
@@ -100,7 +101,7 @@ class FNOFactorizedMesh3D(nn.Module):
                                       input_dim=self.input_dim, n_layers=self.n_layers, factor=self.factor,
                                       share_weight=self.share_weight, share_fork=False,
                                       ff_weight_norm=self.ff_weight_norm, mode="full", spatial_dims=3,
-                                      padding=self.padding, output_dim=self.output_dim)
+                                      padding=self.padding, output_dim=self.output_dim, layer_norm=self.layer_norm)
         return self._engine
 
     def engine_parameters(self):

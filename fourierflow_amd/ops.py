@@ -202,6 +202,40 @@ def feedforward(x, resid, lin0, lin1):
     return out.view(shp)
 
 
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, gamma, beta, eps):
+        lib = _lib.get_lib()
+        P, C = t.shape
+        out = torch.empty_like(t)
+        stats = torch.empty(P, 2, dtype=torch.float32, device=t.device)
+        _capi.check(lib.ffno_layernorm_fwd(_p(t), _p(gamma), _p(beta), None, _p(out), _p(stats), P, C, float(eps),
+                                           _lib.current_stream(t.device)), "layernorm_fwd")
+        ctx.save_for_backward(t, gamma, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        t, gamma, stats = ctx.saved_tensors
+        lib = _lib.get_lib()
+        P, C = t.shape
+        g = g.contiguous()
+        dt = torch.empty_like(t)
+        part = torch.empty(2 * C * int(lib.ffno_layernorm_nsplit(P)), dtype=torch.float32, device=t.device)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        _capi.check(lib.ffno_layernorm_bwd(_p(t), _p(stats), _p(gamma), _p(g), None, None, _p(dt), _p(part), _p(dgamma),
+                                           _p(dbeta), P, C, 0, _lib.current_stream(t.device)), "layernorm_bwd")
+        return dt, dgamma, dbeta, None
+
+
+def layer_norm(x, ln):
+    """``nn.LayerNorm(C)`` over the last axis (the final stage of FeedForward(layer_norm=True), feedforward.py:18-19)."""
+    _lib.require_device_tensor(x, "layer_norm input")
+    C = x.shape[-1]
+    y = _LayerNormFn.apply(x.reshape(-1, C).contiguous(), ln.weight.contiguous(), ln.bias.contiguous(), ln.eps)
+    return y.view(x.shape)
+
+
 class _LpRelLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target):

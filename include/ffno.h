@@ -350,6 +350,20 @@ int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_dev, int n,
                                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),
+ * eps 1e-5, biased variance, elementwise affine), fused with the layer's residual add (grid_2d.py:169):
+ *   fwd:  out = (t - mean) * rstd * gamma + beta (+ resid);  stats[p] = {mean, rstd} (2 floats per pixel, kept for backward)
+ *   bwd:  gy = g (+ g2, the sum optionally stored to g_sum);  dt = dL/dt;  dgamma / dbeta (+)= their gradients
+ *         (deterministic two-stage reduction through `partial`: 2 * C * ffno_layernorm_nsplit(P) floats)
+ * C = 64 or 32.
+ * --------------------------------------------------------------------------------------------- */
+int ffno_layernorm_fwd(const float* t, const float* gamma, const float* beta, const float* resid, float* out, float* stats,
+                       long P, int C, float eps, void* stream);
+int ffno_layernorm_nsplit(long P);
+int ffno_layernorm_bwd(const float* t, const float* stats, const float* gamma, const float* g, const float* g2, float* g_sum,
+                       float* dt, float* partial, float* dgamma, float* dbeta, long P, int C, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Weight normalisation (linear.py:48-49, torch.nn.utils.weight_norm dim=0), batched over a
  * device-resident descriptor table so one launch covers every linear of the block.
  *   fwd: w = g * v / ||v||_row          bwd: dg = sum_in dw*v/||v|| ; dv = g/||v|| (dw - dg v/||v||)

@@ -22,7 +22,7 @@ def build_block(kw, seed, device):
 
 
 TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64_nofourier", "c32_nown", "c64_fork",
-        "c64_sharefork_fork",
+        "c64_sharefork_fork", "c64_layernorm",
         "c64_4l_markov", "c64_24l_markov"]
 GPU_ONLY = {"c64_4l_markov", "c64_24l_markov", "c64_3l_unshared"}  # too slow for the CPU emulator
 
@@ -38,7 +38,7 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
         pytest.skip("no split-bf16 branch for this configuration (width 32 / no spectral branch)")
     if x3 and not fused and "fork" in tag.replace("sharefork", ""):
         pytest.skip("fork heads run the branches one by one: the paired split-bf16 stage launch is not scheduled")
-    if x3 and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass", "c64_sharefork_fork"):
+    if x3 and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass", "c64_sharefork_fork", "c64_layernorm"):
         pytest.skip("x3 path on the emulator: three representative configs are enough")
     g = gu.load_golden("block_" + tag)
     kw = gu.golden_kwargs(g)
@@ -108,7 +108,7 @@ def test_state_dict_keys_match_reference_layout():
 def test_unsupported_options_fail_loudly():
     from fourierflow_amd.modules import FNOFactorized2DBlock
     base = dict(modes=4, width=64, input_dim=3, n_layers=2, factor=4)
-    for bad in (dict(layer_norm=True), dict(n_ff_layers=3), dict(dropout=0.1), dict(in_dropout=0.1)):
+    for bad in (dict(n_ff_layers=3), dict(dropout=0.1), dict(in_dropout=0.1), dict(layer_norm=True, use_fork=True)):
         with pytest.raises(NotImplementedError):
             FNOFactorized2DBlock(**{**base, **bad})
     with pytest.raises(ValueError):

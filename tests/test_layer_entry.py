@@ -93,3 +93,33 @@ def test_engine_drives_the_block_through_layer_calls(host_device):
         outs[layer_calls] = [pred.detach().cpu().numpy()] + [p.grad.cpu().numpy() for _, p in blk.engine_parameters()]
     for a, b in zip(outs[True], outs[False]):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("P,C", [(37, 64), (300, 32), (5000, 64)])
+def test_layernorm_kernels_vs_torch(be, P, C):
+    """ffno_layernorm_fwd / _bwd (FeedForward(layer_norm=True), feedforward.py:18-19) against torch.nn.functional.layer_norm
+    in fp64: forward with the fused residual, backward with the fused sum of two gradient buffers, accumulate flag."""
+    if be.kind == "emu" and P > 1000:
+        pytest.skip("large case runs on the GPU only")
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(P + C)
+    t, resid, g, g2 = (rs.standard_normal((P, C)).astype(np.float32) for _ in range(4))
+    gamma, beta = rs.uniform(0.5, 1.5, C).astype(np.float32), rs.uniform(-0.2, 0.2, C).astype(np.float32)
+    dt_, dga, dbe = be.put(t), be.put(gamma), be.put(beta)
+    out, stats = be.empty((P, C)), be.empty((P, 2))
+    assert lib.ffno_layernorm_fwd(p(dt_), p(dga), p(dbe), p(be.put(resid)), p(out), p(stats), P, C, 1e-5, None) == 0
+    tt = torch.tensor(t, dtype=torch.float64, requires_grad=True)
+    gt, bt = torch.tensor(gamma, dtype=torch.float64, requires_grad=True), torch.tensor(beta, dtype=torch.float64, requires_grad=True)
+    ref = torch.nn.functional.layer_norm(tt, (C,), gt, bt, 1e-5)
+    assert rel_l2(be.get(out), ref.detach().numpy() + resid) < 1e-6
+    ref.backward(torch.tensor((g + g2).astype(np.float64)))
+    gsum, dx = be.empty((P, C)), be.empty((P, C))
+    part = be.zeros(2 * C * lib.ffno_layernorm_nsplit(P))
+    dgm, dbt = be.zeros(C), be.zeros(C)
+    for acc in (0, 1):
+        assert lib.ffno_layernorm_bwd(p(dt_), p(stats), p(dga), p(be.put(g)), p(be.put(g2)), p(gsum), p(dx), p(part), p(dgm), p(dbt),
+                                      P, C, acc, None) == 0
+    np.testing.assert_array_equal(be.get(gsum), g + g2)
+    assert rel_l2(be.get(dx), tt.grad.numpy()) < 1e-5
+    assert rel_l2(be.get(dgm), 2 * gt.grad.numpy()) < 1e-5 and rel_l2(be.get(dbt), 2 * bt.grad.numpy()) < 1e-5
+    assert lib.ffno_layernorm_fwd(p(dt_), p(dga), p(dbe), None, p(out), p(stats), P, 48, 1e-5, None) == -2
