@@ -8,7 +8,10 @@ import sys
 
 from rocpd_pmc import per_kernel
 
-NAMES = [("spectral_fused_pair_kernel", "spectral_fused"), ("spectral_fused_kernel", "spectral_fused"), ("ffx_chain_kernel<64, 256, false>", "ff_fwd"),
+NAMES = [("spectral_x3_pair_kernel<16>", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false>", "ff_fwd"),
+         ("ffx_chain_rs_kernel<64, 256, true>", "ff_bwd_data"), ("ffx_wgrad_rs_kernel", "ff_bwd_weights_partial"),
+         ("fw_grad_x3_kernel", "fw_grad_partial"),
+         ("spectral_fused_pair_kernel", "spectral_fused"), ("spectral_fused_kernel", "spectral_fused"), ("ffx_chain_kernel<64, 256, false>", "ff_fwd"),
          ("ffx_chain_kernel<64, 256, true>", "ff_bwd_data"), ("ffx_wgrad_kernel", "ff_bwd_weights_partial"),
          ("ffx_wgrad_reduce_kernel", "ff_bwd_weights_reduce"), ("ff_chain_kernel<64, 256, 8, false>", "ff_fwd"),
          ("ff_chain_kernel<64, 256, 8, true>", "ff_bwd_data"), ("ff_bwd_weights_partial_kernel", "ff_bwd_weights_partial"),
@@ -24,6 +27,7 @@ def short(kernel):
 
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+GIT_HEAD = sys.argv[3] if len(sys.argv) > 3 else None
 out = {}
 for k, (_, n, avg, _, _) in fetch.items():
     name = short(k)
@@ -32,7 +36,7 @@ for k, (_, n, avg, _, _) in fetch.items():
     w = write[k][2]
     out[name] = dict(fetch_kib_raw=round(avg, 1), write_kib=round(w, 1), hbm_bytes_per_launch=int((2 * avg + w) * 1024),
                      launches_sampled=n, symbol=k)
-print(json.dumps(dict(workload="markov/24 B=32 64x64 fp32 (bench.py defaults)",
+print(json.dumps(dict(workload="markov/24 B=32 64x64 fp32 (bench.py defaults)", git_head=GIT_HEAD,
                       method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
                              "(2*FETCH_SIZE + WRITE_SIZE)*1024; the x2 on FETCH_SIZE is the gfx950 correction of "
                              "MI355X_MICROARCH.md, confirmed on adamw_kernel; WRITE_SIZE reads exact",
