@@ -23,15 +23,19 @@ FNOPlus2DBlock (zongyi_fno/grid_plus_2d.py), CNOFactorized2DBlock / Mesh2D / Mes
 (zongyi_fno/mesh_2d.py, mesh_3d.py), Normalizer, the Markov
 feature build (routines/grid_2d_markov.py:124-170).
 
-Parity status: PINNED against golden vectors generated from the imported
-reference (tests/golden/*.npz, generator tools/make_golden.py) -- with TWO exceptions:
-  * ``velocity_features`` / ``velocity_wavenumbers`` (the `use_velocity` branch of
-    routines/grid_2d_markov.py:82-94,130-144).  That routine and its jax_cfd dependency cannot be imported here, so for
-    that piece PARITY IS UNPINNED by a reference run; it is pinned only analytically (plane-wave known answers and
-    curl / divergence identities, tests/test_velocity.py).
-  * ``rollout_learning_step`` (routines/grid_2d_rollout.py:75-150): the routine imports wandb / pytorch_lightning (absent),
-    so the loop is restated from the file and PARITY IS UNPINNED by a reference run for the loop itself; every operator
-    inside it (FNOZongyi2DBlock, LpLoss.rel) is pinned by golden vectors.
+Parity status: PINNED against golden vectors generated from the imported reference (tests/golden/*.npz, generator
+tools/make_golden.py).  Two pieces restate reference routines whose modules cannot be imported here (they need jax /
+wandb / pytorch_lightning):
+  * ``velocity_features`` / ``velocity_wavenumbers`` (the `use_velocity` branch of routines/grid_2d_markov.py:82-94,130-144):
+    PINNED since round 2 by a run of the reference's own `_build_features` / `encode_positions` bodies, lifted from the
+    file at generation time (tools/make_golden_velocity.py -> tests/golden/markov_velocity.npz); only the wavenumber meshes
+    (jax_cfd ``Grid.rfft_mesh()``, an un-vendored dependency pinned at git rev eb4d723e) are restated from that
+    function's published definition.  Also held to analytic known answers (tests/test_velocity.py).
+  * ``rollout_learning_step`` (routines/grid_2d_rollout.py:75-150): the loop is restated from the file and PARITY IS UNPINNED
+    by a reference run for the loop itself; every operator inside it (FNOZongyi2DBlock, LpLoss.rel) is pinned by golden
+    vectors.
+``relu_mask`` / ``relu_masks`` arguments are a test device (gradient comparisons without the ReLU bit-flip
+discontinuity, see ``feedforward``); they change nothing when absent.
 """
 from __future__ import annotations
 
