@@ -18,6 +18,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define FFNO_NOUNROLL _Pragma("unroll 1")
 // bounds live ranges: stops the scheduler from hoisting a whole unrolled loop's operand loads
 #define FFNO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// scheduling hint: the next `size` instructions of class `mask` (0x8 MFMA, 0x2 VALU, 0x100 DS read, ...) form one group; a
+// sequence of such groups asks the scheduler to emit that pattern (llvm.amdgcn.sched.group.barrier)
+#define FFNO_SCHED_GROUP(mask, size) __builtin_amdgcn_sched_group_barrier(mask, size, 0)
+// pins a register value to this point of the instruction stream: whatever computes x is emitted before, whatever uses it after
+// (an empty volatile asm; FFNO_SCHED_FENCE alone orders memory operations but not pure arithmetic, which instruction selection
+// is free to emit anywhere in the basic block)
+#define FFNO_PIN(x) asm volatile("" : "+v"(x))
+// drains every outstanding memory operation of the wave (s_waitcnt 0).  Placed in front of a software-pipelined loop so that the
+// compiler's counter analysis starts the loop with nothing pending (else it re-waits for the prologue's loads every iteration)
+#define FFNO_DRAIN_MEMORY() __builtin_amdgcn_s_waitcnt(0)
 // register budget = 512 / n VGPRs per lane, so that n waves (n/2 workgroups of 512 threads) share a SIMD
 #define FFNO_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
 

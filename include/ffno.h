@@ -310,7 +310,10 @@ int ffno_ffx_supported(int C, int H);
 /* Schedule of the three feed-forward kernels (process-wide; results identical up to the summation order of db2): bit 0 =
  * forward, bit 1 = backward-data, bit 2 = weight gradients run "role-split" (the two halves of a workgroup one slot apart:
  * a matrix segment on one wave of a SIMD beside a vector / LDS segment on the other); a clear bit = both halves in phase.
- * Default 1 (forward only), from measurements on MI355X. */
+ * Bit 3 = forward, bit 4 = backward-data run the software-pipelined kernel instead (GEMM1 one tile ahead, every MFMA group
+ * beside vector work of other tiles in the same wave; C = 64 with both addends, the stored sum, residual and sign words
+ * present, otherwise the bit is ignored) -- bit-identical results.  Default 1 (forward role-split), from measurements on
+ * MI355X (profiles/r02_ffx_sp.md: the pipelined kernels are within noise of the default inside a training step). */
 int ffno_ffx_set_schedule(int schedule);
 /* Persistent workgroups of the forward / backward-data kernel (default 256 = one per CU of an MI355X; process-wide). */
 int ffno_ffx_set_max_workgroups(int n);

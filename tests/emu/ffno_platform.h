@@ -14,6 +14,9 @@ typedef emu_u32x4 u32x4;
 #define FFNO_UNROLL
 #define FFNO_NOUNROLL
 #define FFNO_SCHED_FENCE() ((void)0)
+#define FFNO_SCHED_GROUP(mask, size) ((void)0)
+#define FFNO_DRAIN_MEMORY() ((void)0)
+#define FFNO_PIN(x) ((void)0)
 #define FFNO_WAVES_PER_SIMD(n)
 
 namespace ffno {
