@@ -393,6 +393,7 @@ __global__ __launch_bounds__(H / (32 * CPW) * 64) void ffx_chain_sp_kernel(const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int ntiles = (P + 31) >> 5;
+    FFX_STAMP(10);
 
     Bf3 A1[CPW][KS], A2[CPW][CTO][2];
     FFNO_UNROLL
@@ -745,6 +746,7 @@ __global__ __launch_bounds__(H / (32 * CPW) * 64) void ffx_chain_sp_kernel(const
         run(Safe{});
     else
         run(Pred{});
+    FFX_STAMP(11);
     // partials of the last tile: written by an iteration of parity `last`, reduced with the rows of the opposite set
     if (prev >= 0) {
         if (last == 0)
@@ -752,6 +754,7 @@ __global__ __launch_bounds__(H / (32 * CPW) * 64) void ffx_chain_sp_kernel(const
         else
             reduce(Pred{}, Even{}, prev, true);
     }
+    FFX_STAMP(12);
 }
 
 // ---- forward / backward-data, role-split schedule ---------------------------------------------------------------------

@@ -16,8 +16,8 @@ if [ "$1" = bench ]; then
 else
     ABL=${2:-0}
     (echo '#include <hip/hip_runtime.h>'; echo '__device__ long long* g_dbg;'; echo "#define FFX_ABL $ABL"
-     echo '#define FFX_STAMP(i) { long long tn_ = clock64(); if ((threadIdx.x & 63) == 0 && g_dbg) { long long* T_ = g_dbg + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 4; if (i == 0) { if (tl_) T_[2] += tn_ - tl_; } else if (i == 1) T_[0] += tn_ - tl_; else T_[1] += tn_ - tl_; } tl_ = tn_; }'
-     sed 's/    int last = 1, prev = -1, tile = t0;/    int last = 1, prev = -1, tile = t0; long long tl_ = 0; long long tk0_ = clock64();/; s/    \/\/ partials of the last tile: written by an iteration of parity `last`/    if ((threadIdx.x \& 63) == 0 \&\& g_dbg) g_dbg[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 4 + 3] += clock64() - tk0_;\n    \/\/ partials of the last tile/' $SRC/ffx.hip
+     echo '#define FFX_STAMP(i) { long long tn_ = clock64(); if ((threadIdx.x & 63) == 0 && g_dbg) { long long* T_ = g_dbg + (blockIdx.x * 8 + (threadIdx.x >> 6)) * 8; if (i == 0) { if (tl_) T_[2] += tn_ - tl_; else T_[4] += tn_ - tk_; } else if (i == 1) T_[0] += tn_ - tl_; else if (i == 2) T_[1] += tn_ - tl_; else if (i == 11) T_[3] += tn_ - tk_; else if (i == 12) { T_[5] += tn_ - tk_; T_[6] += wall_clock64() - tw_; } } if (i == 10) { tk_ = tn_; tl_ = 0; tw_ = wall_clock64(); } else tl_ = tn_; }'
+     sed 's/    FFX_STAMP(10);/    long long tl_ = 0, tk_ = 0, tw_ = 0; FFX_STAMP(10);/' $SRC/ffx.hip
      echo "$EXTRA"; cat stamp_main.inc) > bin/ffx_stamp_$ABL.hip
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -I $SRC -I ../../include bin/ffx_stamp_$ABL.hip -o bin/ffx_stamp_$ABL
 fi
