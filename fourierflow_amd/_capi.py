@@ -130,6 +130,12 @@ SIGNATURES = {
     "ffno_ffx_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce_batched": (I, [P, I, I, I, I, P]),
+    "ffno_ffh_pack_bytes": (SZ, [I, I]),
+    "ffno_ffh_pack": (I, [P, I, I, I, P]),
+    "ffno_ffh_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ffh_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
+    "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
+    "ffno_ffh_grad_scale": (I, [P, L, P, P]),
     "ffno_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ffno_layernorm_nsplit": (I, [L]),
     "ffno_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),

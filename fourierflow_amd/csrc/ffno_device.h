@@ -100,6 +100,44 @@ __device__ __forceinline__ Bf3 split3_8(float v0, float v1, float v2, float v3, 
     return f;
 }
 
+// ---- "split-fp16" (fp16x2): fp32-accurate products from THREE half MFMAs --------------------------------------------
+// x = hi + lo / 2^11 with hi = fp16(x) (round to nearest: |x - hi| <= 2^-12 |x|) and lo = fp16((x - hi) * 2^11), so that
+// |x - hi - lo / 2^11| <= max(2^-24 |x|, 2^-36): as good as fp32 while both planes are normal halves (2.4e-4 <= |x| < 65504),
+// a fixed absolute error below; at 65504 the half format overflows -- the caller keeps its data in range (ffno_ffh_*, ffno.h).  Of the four
+// partial products hi*hi, hi*lo, lo*hi are kept (lo*lo <= 2^-24 |a b|); half products are exact in fp32 and
+// v_mfma_f32_32x32x16_f16 accumulates in fp32.  The two cross products carry the factor 2^11 and go to their own accumulator:
+//     main += a.hi b.hi        corr += a.hi b.lo + a.lo b.hi        a b = main + corr / 2^11
+// Half the matrix work of split-bf16 (3 instead of 6 MFMAs), two operand planes instead of three, 6 instead of 11 vector
+// instructions per split pair -- at the price of the half format's exponent range.
+struct Hf2 {
+    u32x4 hi, lo;
+};
+constexpr float kHf2Scale = 2048.f, kHf2Unscale = 1.f / 2048.f;
+
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+    h = plat::pack_f16(x0, x1);
+    l = plat::pack_f16((x0 - plat::f16_lo(h)) * kHf2Scale, (x1 - plat::f16_hi(h)) * kHf2Scale);
+}
+__device__ __forceinline__ Hf2 split2_8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    Hf2 f;
+    unsigned h, l;
+    split2_pair(v0, v1, h, l);
+    f.hi[0] = h, f.lo[0] = l;
+    split2_pair(v2, v3, h, l);
+    f.hi[1] = h, f.lo[1] = l;
+    split2_pair(v4, v5, h, l);
+    f.hi[2] = h, f.lo[2] = l;
+    split2_pair(v6, v7, h, l);
+    f.hi[3] = h, f.lo[3] = l;
+    return f;
+}
+// one product block on the main / correction accumulator tiles of a 32x32 output tile
+__device__ __forceinline__ void mfma_h2(const Hf2& a, const Hf2& b, f32x16& m, f32x16& c) {
+    c = plat::mfma_f16_32x32x16(a.lo, b.hi, c);
+    c = plat::mfma_f16_32x32x16(a.hi, b.lo, c);
+    m = plat::mfma_f16_32x32x16(a.hi, b.hi, m);
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
     FFNO_UNROLL

@@ -52,6 +52,25 @@ __device__ __forceinline__ f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// v_mfma_f32_32x32x16_f16 (8 passes, the rate of the bf16 form)
+__device__ __forceinline__ f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b, f32x16 c) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// two floats -> one word of IEEE halves, round to nearest even (x0 in the low half): v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned pack_f16(float x0, float x1) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 v = {(_Float16)x0, (_Float16)x1};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ float f16_lo(unsigned w) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(f16x2, w)[0];
+}
+__device__ __forceinline__ float f16_hi(unsigned w) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    return (float)__builtin_bit_cast(f16x2, w)[1];
+}
 // upper halves of two words -> one word (u0's in the low half): v_perm_b32
 __device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }
 // (acc << 1) | msb(x): v_alignbit_b32

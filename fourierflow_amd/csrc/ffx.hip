@@ -59,6 +59,7 @@ struct FxPackDesc {
     int sh, sc, type, pad;
 };
 
+template <class S>
 __global__ __launch_bounds__(256) void ffx_pack_kernel(const FxPackDesc* __restrict__ descs, int C, int H) {
     const FxPackDesc d = descs[blockIdx.y];
     const int KS = C / 16, CTO = C / 32, NW = H / 32;
@@ -75,10 +76,9 @@ __global__ __launch_bounds__(256) void ffx_pack_kernel(const FxPackDesc* __restr
         for (int e = 0; e < 8; ++e)
             v[e] = d.src[(long)(32 * w + (e & 3) + 8 * (2 * s2 + (e >> 2)) + 4 * half) * d.sh + (long)(32 * mt + j) * d.sc];
     }
-    const Bf3 f = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-    d.dst[(frag * 3 + 0) * 64 + lane] = f.hi;
-    d.dst[(frag * 3 + 1) * 64 + lane] = f.mid;
-    d.dst[(frag * 3 + 2) * 64 + lane] = f.lo;
+    const typename S::Frag f = S::split8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    FFNO_UNROLL
+    for (int p = 0; p < S::NP; ++p) d.dst[(frag * S::NP + p) * 64 + lane] = S::plane(f, p);
 }
 
 __device__ __forceinline__ Bf3 load_frag(const u32x4* __restrict__ pk, int frag, int lane) {
@@ -117,10 +117,90 @@ __device__ __forceinline__ void stage4(char* base, int plane_bytes, int off, flo
     *reinterpret_cast<uint2*>(base + 2 * plane_bytes + off) = make_uint2(l0, l1);
 }
 
+// ---- operand-split policies -------------------------------------------------------------------------------------------------
+// The kernels below are written once over the way an fp32 operand is cut into low-precision MFMA operands:
+//   SplitBf3  three bf16 planes, six MFMAs per product block (ffno_device.h "split-bf16"): any fp32 range;
+//   SplitHf2  two fp16 planes, three MFMAs ("split-fp16"): half the matrix work, two thirds of the LDS / register operand
+//             footprint, 6 instead of 11 vector instructions per split pair -- for data inside the half format's exponent range
+//             (2.4e-4 <= |x| < 65504 at full accuracy; gradients are brought there by a power-of-two scale, see ffno_ffh_*).
+// Frag = one MFMA operand fragment (NP planes of 16 B per lane).  A product chain runs on a main tile m (any fp32 start value)
+// and a correction tile c (zero at the start): mma(a, b, m, c) adds one product block, fold(m, c) leaves the result in m.
+struct SplitBf3 {
+    using Frag = Bf3;
+    static constexpr int NP = 3;
+    static constexpr bool SCALED = false;          // gradients need no range scale
+    static __device__ __forceinline__ Frag split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+        return split3_8(v0, v1, v2, v3, v4, v5, v6, v7);
+    }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& m, f32x16&) { m = mfma_x3(a, b, m); }
+    static __device__ __forceinline__ void fold(f32x16&, const f32x16&) {}
+    static __device__ __forceinline__ u32x4 plane(const Frag& f, int p) { return p == 0 ? f.hi : (p == 1 ? f.mid : f.lo); }
+    static __device__ __forceinline__ void set_plane(Frag& f, int p, u32x4 v) {
+        if (p == 0) f.hi = v;
+        if (p == 1) f.mid = v;
+        if (p == 2) f.lo = v;
+    }
+    // 4 consecutive values -> two words per plane
+    static __device__ __forceinline__ void split4(float x, float y, float z, float w, uint2* planes) {
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3_pair(x, y, h0, m0, l0);
+        split3_pair(z, w, h1, m1, l1);
+        planes[0] = make_uint2(h0, h1), planes[1] = make_uint2(m0, m1), planes[2] = make_uint2(l0, l1);
+    }
+};
+struct SplitHf2 {
+    using Frag = Hf2;
+    static constexpr int NP = 2;
+    static constexpr bool SCALED = true;
+    static __device__ __forceinline__ Frag split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+        return split2_8(v0, v1, v2, v3, v4, v5, v6, v7);
+    }
+    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& m, f32x16& c) { mfma_h2(a, b, m, c); }
+    static __device__ __forceinline__ void fold(f32x16& m, const f32x16& c) {
+        FFNO_UNROLL
+        for (int i = 0; i < 16; ++i) m[i] = __builtin_fmaf(c[i], kHf2Unscale, m[i]);
+    }
+    static __device__ __forceinline__ u32x4 plane(const Frag& f, int p) { return p == 0 ? f.hi : f.lo; }
+    static __device__ __forceinline__ void set_plane(Frag& f, int p, u32x4 v) {
+        if (p == 0) f.hi = v;
+        if (p == 1) f.lo = v;
+    }
+    static __device__ __forceinline__ void split4(float x, float y, float z, float w, uint2* planes) {
+        unsigned h0, l0, h1, l1;
+        split2_pair(x, y, h0, l0);
+        split2_pair(z, w, h1, l1);
+        planes[0] = make_uint2(h0, h1), planes[1] = make_uint2(l0, l1);
+    }
+};
+
+template <class S>
+__device__ __forceinline__ typename S::Frag load_frag_s(const u32x4* __restrict__ pk, int frag, int lane) {
+    typename S::Frag f;
+    FFNO_UNROLL
+    for (int p = 0; p < S::NP; ++p) S::set_plane(f, p, pk[(frag * S::NP + p) * 64 + lane]);
+    return f;
+}
+// NP planes at the same offset of an LDS tile
+template <class S>
+__device__ __forceinline__ typename S::Frag lds_frag_s(const char* base, int plane_bytes, int off) {
+    typename S::Frag f;
+    FFNO_UNROLL
+    for (int p = 0; p < S::NP; ++p) S::set_plane(f, p, *reinterpret_cast<const u32x4*>(base + p * plane_bytes + off));
+    return f;
+}
+// split 4 consecutive values and store them as 8 B per plane
+template <class S>
+__device__ __forceinline__ void stage4_s(char* base, int plane_bytes, int off, float x, float y, float z, float w) {
+    uint2 pl[S::NP];
+    S::split4(x, y, z, w, pl);
+    FFNO_UNROLL
+    for (int p = 0; p < S::NP; ++p) *reinterpret_cast<uint2*>(base + p * plane_bytes + off) = pl[p];
+}
+
 // ---- forward / backward-data -----------------------------------------------------------------------------------------
 //   forward : in = s,  A1 = pack1(W1),   A2 = pack2(W2)     h = relu(A1 in + b1), sign bits -> mask ; out = A2 h + b2 (+ resid)
 //   backward: in = db, A1 = pack1(W2^T), A2 = pack2(W1^T)   dh = mask ? A1 in : 0                    ; ds  = A2 dh
-template <int C, int H, bool BWD>
+template <int C, int H, bool BWD, class S>
 __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const float* __restrict__ in,
                                                                      const float* __restrict__ in2, float* sum_out,
                                                                      const float* resid,
@@ -128,10 +208,10 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2,
                                                                      const float* __restrict__ bias2, float* out,
-                                                                     uint32_t* mask, int P) {
+                                                                     uint32_t* mask, int P, const float* gscale_p) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, NV = F::NV, G = F::G, GPW = F::GPW, CPW = F::CPW;
-    __shared__ __attribute__((aligned(16))) char sp[2][3 * F::PPLANE];
+    __shared__ __attribute__((aligned(16))) char sp[2][S::NP * F::PPLANE];
     __shared__ __attribute__((aligned(16))) float part[2][NW * G * 64 * 4];
     __shared__ __attribute__((aligned(16))) float b1s[H];
     __shared__ float b2s[C];
@@ -139,17 +219,20 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int ntiles = (P + 31) >> 5;
+    const float gscale = (S::SCALED && gscale_p) ? *gscale_p : 1.f;     // (a power of two, device-resident)
+    const float rgscale = 1.f / gscale;
 
-    Bf3 A1[CPW][KS], A2[CPW][CTO][2];
+    using Frag = typename S::Frag;
+    Frag A1[CPW][KS], A2[CPW][CTO][2];
     FFNO_UNROLL
     for (int ch = 0; ch < CPW; ++ch) {
         const int q = wave * CPW + ch;
         FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) A1[ch][st] = load_frag(pk1, q * KS + st, lane);
+        for (int st = 0; st < KS; ++st) A1[ch][st] = load_frag_s<S>(pk1, q * KS + st, lane);
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
             FFNO_UNROLL
-            for (int s2 = 0; s2 < 2; ++s2) A2[ch][mt][s2] = load_frag(pk2, (q * CTO + mt) * 2 + s2, lane);
+            for (int s2 = 0; s2 < 2; ++s2) A2[ch][mt][s2] = load_frag_s<S>(pk2, (q * CTO + mt) * 2 + s2, lane);
         }
     }
     if (!BWD) {
@@ -188,13 +271,14 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                     if (px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = nS[v];
                 }
             }
+            if (BWD && S::SCALED) nS[v].x *= gscale, nS[v].y *= gscale, nS[v].z *= gscale, nS[v].w *= gscale;
         }
     };
     auto stage = [&](int buf) {
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
-            stage4(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
+            stage4_s<S>(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
         }
     };
     // reduce the NW partial tiles of `tile` (this wave owns float4 groups [wave*GPW, +GPW)) and store the output rows
@@ -230,6 +314,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                 acc.z += b2s[c0 + 2] + rres[u].z;
                 acc.w += b2s[c0 + 3] + rres[u].w;
             }
+            if (BWD && S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
             if (px < P) *reinterpret_cast<float4*>(out + px * C + c0) = acc;
         }
     };
@@ -268,19 +353,24 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
 
         // GEMM1: this wave's hidden chunks for the 32 pixels of the tile
         f32x16 d[CPW];
-        FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Bf3 b = lds_frag(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+        {
+            f32x16 dc[CPW];
             FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) d[ch] = mfma_x3(A1[ch][st], b, d[ch]);
+            for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16(), dc[ch] = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < KS; ++st) {
+                const Frag b = lds_frag_s<S>(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+                FFNO_UNROLL
+                for (int ch = 0; ch < CPW; ++ch) S::mma(A1[ch][st], b, d[ch], dc[ch]);
+            }
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) S::fold(d[ch], dc[ch]);
         }
         if (early && prev >= 0) reduce(prev, buf ^ 1);
         // epilogue + GEMM2 partial over the wave's hidden rows, k order = D-fragment order
-        f32x16 o[CTO];
+        f32x16 o[CTO], oc[CTO];
         FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16();
+        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16(), oc[mt] = zero16();
         FFNO_UNROLL
         for (int ch = 0; ch < CPW; ++ch) {
             if (BWD) {
@@ -299,15 +389,17 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                     }
                 }
             }
-            Bf3 hb[2];
-            hb[0] = split3_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
-            hb[1] = split3_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+            Frag hb[2];
+            hb[0] = S::split8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
+            hb[1] = S::split8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
             FFNO_UNROLL
             for (int mt = 0; mt < CTO; ++mt) {
-                o[mt] = mfma_x3(A2[ch][mt][0], hb[0], o[mt]);
-                o[mt] = mfma_x3(A2[ch][mt][1], hb[1], o[mt]);
+                S::mma(A2[ch][mt][0], hb[0], o[mt], oc[mt]);
+                S::mma(A2[ch][mt][1], hb[1], o[mt], oc[mt]);
             }
         }
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) S::fold(o[mt], oc[mt]);
         if (!BWD && mp) *mp = (uint16_t)bits;
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
@@ -772,7 +864,7 @@ __global__ __launch_bounds__(H / (32 * CPW) * 64) void ffx_chain_sp_kernel(const
 // so every slot pairs a matrix segment on one wave with a vector / LDS segment on its SIMD partner.  The first half
 // stages all input tiles, the second half reduces and stores all output tiles; the partial-output exchange needs ONE
 // buffer (reduce(t-1) is over before the first half writes part(t)), i.e. 64 KiB of LDS less.
-template <int C, int H, bool BWD>
+template <int C, int H, bool BWD, class S>
 __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const float* __restrict__ in,
                                                                         const float* __restrict__ in2, float* sum_out,
                                                                         const float* resid,
@@ -780,7 +872,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
                                                                         const float* __restrict__ bias1,
                                                                         const u32x4* __restrict__ pk2,
                                                                         const float* __restrict__ bias2, float* out,
-                                                                        uint32_t* mask, int P) {
+                                                                        uint32_t* mask, int P, const float* gscale_p) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, G = F::G;
     constexpr int NWA = NW / 2;                      // waves per role
@@ -788,7 +880,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
     constexpr int NVA = (32 * C / 4) / NTA;          // float4 per staging thread and tile
     constexpr int GPB = G / NWA;                     // float4 groups per reducing wave
     static_assert(NW >= 2 && NWA * 2 == NW && NVA * NTA * 4 == 32 * C && GPB * NWA == G, "role split");
-    __shared__ __attribute__((aligned(16))) char sp[2][3 * F::PPLANE];
+    __shared__ __attribute__((aligned(16))) char sp[2][S::NP * F::PPLANE];
     __shared__ __attribute__((aligned(16))) float part[NW * G * 64 * 4];
     __shared__ __attribute__((aligned(16))) float b1s[H];
     __shared__ float b2s[C];
@@ -796,16 +888,19 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int ntiles = (P + 31) >> 5;
+    const float gscale = (S::SCALED && gscale_p) ? *gscale_p : 1.f;     // (a power of two, device-resident)
+    const float rgscale = 1.f / gscale;
     const bool first = wave < NWA;                   // role: first half stages, second half reduces
     const int rw = wave - NWA;                       // index inside the reducing half
 
-    Bf3 A1[KS], A2[CTO][2];
+    using Frag = typename S::Frag;
+    Frag A1[KS], A2[CTO][2];
     FFNO_UNROLL
-    for (int st = 0; st < KS; ++st) A1[st] = load_frag(pk1, wave * KS + st, lane);
+    for (int st = 0; st < KS; ++st) A1[st] = load_frag_s<S>(pk1, wave * KS + st, lane);
     FFNO_UNROLL
     for (int mt = 0; mt < CTO; ++mt) {
         FFNO_UNROLL
-        for (int s2 = 0; s2 < 2; ++s2) A2[mt][s2] = load_frag(pk2, (wave * CTO + mt) * 2 + s2, lane);
+        for (int s2 = 0; s2 < 2; ++s2) A2[mt][s2] = load_frag_s<S>(pk2, (wave * CTO + mt) * 2 + s2, lane);
     }
     if (!BWD) {
         for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e];
@@ -837,13 +932,14 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
                 const long px = (long)tile * 32 + f / (C / 4);
                 if (sum_out && px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = pS[v];
             }
+            if (BWD && S::SCALED) pS[v].x *= gscale, pS[v].y *= gscale, pS[v].z *= gscale, pS[v].w *= gscale;
         }
     };
     auto stage = [&](int buf) {
         FFNO_UNROLL
         for (int v = 0; v < NVA; ++v) {
             const int f = tid + v * NTA;
-            stage4(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, pS[v].x, pS[v].y, pS[v].z, pS[v].w);
+            stage4_s<S>(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, pS[v].x, pS[v].y, pS[v].z, pS[v].w);
         }
     };
     // ---- reducing half: residual rows one tile ahead; reduce the NW partial tiles and store the output rows ----
@@ -879,21 +975,24 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
                 acc.z += b2s[c0 + 2] + rres[u].z;
                 acc.w += b2s[c0 + 3] + rres[u].w;
             }
+            if (BWD && S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
             if (px < P) *reinterpret_cast<float4*>(out + px * C + c0) = acc;
         }
     };
 
     // ---- the three compute segments of a wave (its hidden chunk of the current tile) ----
     f32x16 d;
-    Bf3 hb[2];
+    Frag hb[2];
     uint32_t bits = 0, bits_next = 0;
     auto gemm1 = [&](int buf) {
+        f32x16 dc = zero16();
         d = zero16();
         FFNO_UNROLL
         for (int st = 0; st < KS; ++st) {
-            const Bf3 b = lds_frag(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
-            d = mfma_x3(A1[st], b, d);
+            const Frag b = lds_frag_s<S>(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+            S::mma(A1[st], b, d, dc);
         }
+        S::fold(d, dc);
     };
     auto epilogue = [&](int tile) {
         uint16_t* mp = mask ? reinterpret_cast<uint16_t*>(mask) + ((long)tile * NW + wave) * 64 + lane : nullptr;
@@ -918,17 +1017,18 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
             }
             if (mp) *mp = (uint16_t)bits;
         }
-        hb[0] = split3_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
-        hb[1] = split3_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+        hb[0] = S::split8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+        hb[1] = S::split8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
     };
     auto gemm2 = [&]() {
         f32x16 o[CTO];
         FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16();
-        FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
-            o[mt] = mfma_x3(A2[mt][0], hb[0], o[mt]);
-            o[mt] = mfma_x3(A2[mt][1], hb[1], o[mt]);
+            f32x16 oc = zero16();
+            o[mt] = zero16();
+            S::mma(A2[mt][0], hb[0], o[mt], oc);
+            S::mma(A2[mt][1], hb[1], o[mt], oc);
+            S::fold(o[mt], oc);
         }
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
@@ -999,17 +1099,20 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
 // ---- weight gradients with recomputed hidden activations --------------------------------------------------------------
 // Per workgroup slice:  dW1^T[c][hid], dW2[c][hid], db1[hid], db2[c]  (dW1 is stored transposed; the reduce kernel
 // un-transposes).  pk1 = pack1(W1), pk2t = pack1(W2^T) -- the A1 operands of the forward and backward chain kernels.
-template <int C, int H>
+template <int C, int H, class S>
 __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const float* __restrict__ s,
                                                                      const float* __restrict__ db,
                                                                      const u32x4* __restrict__ pk1,
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2t,
-                                                                     float* __restrict__ partial, int P) {
+                                                                     float* __restrict__ partial, int P, const float* gscale_p) {
     using F = FxCfg<C, H>;
     constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV, CPW = F::CPW;
-    constexpr int BUF = 6 * F::PPLANE + 6 * F::TPLANE;   // [sP x3][dbP x3][sT x3][dbT x3]
-    constexpr int OFF_SP = 0, OFF_DP = 3 * F::PPLANE, OFF_ST = 6 * F::PPLANE, OFF_DT = 6 * F::PPLANE + 3 * F::TPLANE;
+    constexpr int NP = S::NP;
+    const float gscale = (S::SCALED && gscale_p) ? *gscale_p : 1.f;     // (a power of two, device-resident)
+    constexpr int BUF = 2 * NP * F::PPLANE + 2 * NP * F::TPLANE;   // [sP x NP][dbP x NP][sT x NP][dbT x NP]
+    constexpr int OFF_SP = 0, OFF_DP = NP * F::PPLANE, OFF_ST = 2 * NP * F::PPLANE, OFF_DT = 2 * NP * F::PPLANE + NP * F::TPLANE;
+    using Frag = typename S::Frag;
     __shared__ __attribute__((aligned(16))) char lds[2][BUF];
     __shared__ float red[F::NT];
 
@@ -1017,14 +1120,14 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
     const int j = lane & 31, half = lane >> 5;
     const int ntiles = (P + 31) >> 5;
 
-    Bf3 W1f[CPW][KS], W2f[CPW][KS];
+    Frag W1f[CPW][KS], W2f[CPW][KS];
     float b1v[CPW];
     FFNO_UNROLL
     for (int ch = 0; ch < CPW; ++ch) {
         FFNO_UNROLL
         for (int st = 0; st < KS; ++st) {
-            W1f[ch][st] = load_frag(pk1, (wave * CPW + ch) * KS + st, lane);
-            W2f[ch][st] = load_frag(pk2t, (wave * CPW + ch) * KS + st, lane);
+            W1f[ch][st] = load_frag_s<S>(pk1, (wave * CPW + ch) * KS + st, lane);
+            W2f[ch][st] = load_frag_s<S>(pk2t, (wave * CPW + ch) * KS + st, lane);
         }
         b1v[ch] = bias1[32 * (wave * CPW + ch) + j];
     }
@@ -1033,26 +1136,37 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
     const int tc = tid % C, tg = tid / C;
     float4 nSP[NV], nDP[NV], nST[NV], nDT[NV];
     float bs2 = 0.f;
+    // addresses = uniform tile base (scalar registers) + constant 32-bit lane offsets (pixel-major float4 f; channel-major
+    // gathers of 4 pixels with stride C: immediate offsets)
     auto gload = [&](int tile) {
+        const float* st = s + (long)tile * (32 * C);
+        const float* dt = db + (long)tile * (32 * C);
+        const int rows = P - tile * 32;            // pixels of this tile that exist (>= 32: all)
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
-            const long px = (long)tile * 32 + f / (C / 4);
+            const int row = f / (C / 4);
+            const unsigned offp = (unsigned)(row * C + 4 * (f % (C / 4)));
             nSP[v] = nDP[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (px < P) {
-                nSP[v] = *reinterpret_cast<const float4*>(s + px * C + 4 * (f % (C / 4)));
-                nDP[v] = *reinterpret_cast<const float4*>(db + px * C + 4 * (f % (C / 4)));
+            if (row < rows) {
+                nSP[v] = *reinterpret_cast<const float4*>(st + offp);
+                nDP[v] = *reinterpret_cast<const float4*>(dt + offp);
             }
-            const long p0 = (long)tile * 32 + 4 * (tg + v * (F::NT / C));
+            const int r0 = 4 * (tg + v * (F::NT / C));
+            const unsigned offt = (unsigned)(r0 * C + tc);
             float a[4], b[4];
             FFNO_UNROLL
             for (int i = 0; i < 4; ++i) {
-                const bool ok = p0 + i < P;
-                a[i] = ok ? s[(p0 + i) * C + tc] : 0.f;
-                b[i] = ok ? db[(p0 + i) * C + tc] : 0.f;
+                const bool ok = r0 + i < rows;
+                a[i] = ok ? st[offt + i * C] : 0.f;
+                b[i] = ok ? dt[offt + i * C] : 0.f;
             }
             nST[v] = make_float4(a[0], a[1], a[2], a[3]);
             nDT[v] = make_float4(b[0], b[1], b[2], b[3]);
+            if (S::SCALED) {
+                nDP[v].x *= gscale, nDP[v].y *= gscale, nDP[v].z *= gscale, nDP[v].w *= gscale;
+                nDT[v].x *= gscale, nDT[v].y *= gscale, nDT[v].z *= gscale, nDT[v].w *= gscale;
+            }
         }
     };
     auto stage = [&](int buf) {
@@ -1060,14 +1174,14 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
             const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
-            stage4(lds[buf] + OFF_SP, F::PPLANE, offp, nSP[v].x, nSP[v].y, nSP[v].z, nSP[v].w);
-            stage4(lds[buf] + OFF_DP, F::PPLANE, offp, nDP[v].x, nDP[v].y, nDP[v].z, nDP[v].w);
+            stage4_s<S>(lds[buf] + OFF_SP, F::PPLANE, offp, nSP[v].x, nSP[v].y, nSP[v].z, nSP[v].w);
+            stage4_s<S>(lds[buf] + OFF_DP, F::PPLANE, offp, nDP[v].x, nDP[v].y, nDP[v].z, nDP[v].w);
             // pixel group grp = (s2 << 2) | (q << 1) | half  <->  local pixels 16 s2 + 8 q + 4 half + i  <->  k slot 4 q + i
             const int grp = tg + v * (F::NT / C);
             const int pos = 16 * (grp & 1) + 8 * (grp >> 2) + 4 * ((grp >> 1) & 1);
             const int offt = tc * F::TROW + 2 * pos;
-            stage4(lds[buf] + OFF_ST, F::TPLANE, offt, nST[v].x, nST[v].y, nST[v].z, nST[v].w);
-            stage4(lds[buf] + OFF_DT, F::TPLANE, offt, nDT[v].x, nDT[v].y, nDT[v].z, nDT[v].w);
+            stage4_s<S>(lds[buf] + OFF_ST, F::TPLANE, offt, nST[v].x, nST[v].y, nST[v].z, nST[v].w);
+            stage4_s<S>(lds[buf] + OFF_DT, F::TPLANE, offt, nDT[v].x, nDT[v].y, nDT[v].z, nDT[v].w);
             bs2 += (nDT[v].x + nDT[v].y) + (nDT[v].z + nDT[v].w);
         }
     };
@@ -1105,15 +1219,20 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
         // h^T[px][hid] = relu(s W1^T + b1), pixels on the D rows
         f32x16 d[CPW];
         uint32_t bits = 0;
-        FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Bf3 a = lds_frag(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+        {
+            f32x16 dc[CPW];
             FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) d[ch] = mfma_x3(a, W1f[ch][st], d[ch]);
+            for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16(), dc[ch] = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < KS; ++st) {
+                const Frag a = lds_frag_s<S>(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+                FFNO_UNROLL
+                for (int ch = 0; ch < CPW; ++ch) S::mma(a, W1f[ch][st], d[ch], dc[ch]);
+            }
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) S::fold(d[ch], dc[ch]);
         }
-        Bf3 hb[CPW][2];
+        Frag hb[CPW][2];
         FFNO_UNROLL
         for (int ch = 0; ch < CPW; ++ch) {
             FFNO_UNROLL
@@ -1123,26 +1242,37 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
                 d[ch][r] = pos ? v : 0.f;
                 bits |= (pos ? 1u : 0u) << (16 * ch + r);
             }
-            hb[ch][0] = split3_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
-            hb[ch][1] = split3_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+            hb[ch][0] = S::split8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
+            hb[ch][1] = S::split8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
         }
+        // (the accumulators stay plain fp32 tiles between tiles: a product chain starts from them and is folded back)
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
+            f32x16 tc[CPW];
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) tc[ch] = zero16();
             FFNO_UNROLL
             for (int s2 = 0; s2 < 2; ++s2) {
-                const Bf3 a = lds_frag(L + OFF_DT, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
+                const Frag a = lds_frag_s<S>(L + OFF_DT, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
                 FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) acc2[ch][mt] = mfma_x3(a, hb[ch][s2], acc2[ch][mt]);
+                for (int ch = 0; ch < CPW; ++ch) S::mma(a, hb[ch][s2], acc2[ch][mt], tc[ch]);
             }
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) S::fold(acc2[ch][mt], tc[ch]);
         }
         // dh^T[px][hid] = (db W2) * [h > 0]
-        FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Bf3 a = lds_frag(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+        {
+            f32x16 dc[CPW];
             FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) d[ch] = mfma_x3(a, W2f[ch][st], d[ch]);
+            for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16(), dc[ch] = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < KS; ++st) {
+                const Frag a = lds_frag_s<S>(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
+                FFNO_UNROLL
+                for (int ch = 0; ch < CPW; ++ch) S::mma(a, W2f[ch][st], d[ch], dc[ch]);
+            }
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) S::fold(d[ch], dc[ch]);
         }
         FFNO_UNROLL
         for (int ch = 0; ch < CPW; ++ch) {
@@ -1151,22 +1281,28 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
                 d[ch][r] = ((bits >> (16 * ch + r)) & 1u) ? d[ch][r] : 0.f;
                 bs1[ch] += d[ch][r];
             }
-            hb[ch][0] = split3_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
-            hb[ch][1] = split3_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+            hb[ch][0] = S::split8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
+            hb[ch][1] = S::split8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
         }
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
+            f32x16 tc[CPW];
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) tc[ch] = zero16();
             FFNO_UNROLL
             for (int s2 = 0; s2 < 2; ++s2) {
-                const Bf3 a = lds_frag(L + OFF_ST, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
+                const Frag a = lds_frag_s<S>(L + OFF_ST, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
                 FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) acc1[ch][mt] = mfma_x3(a, hb[ch][s2], acc1[ch][mt]);
+                for (int ch = 0; ch < CPW; ++ch) S::mma(a, hb[ch][s2], acc1[ch][mt], tc[ch]);
             }
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) S::fold(acc1[ch][mt], tc[ch]);
         }
         if (!early && nt < ntiles) stage(buf ^ 1);
         __syncthreads();
     }
 
+    const float rg = S::SCALED ? 1.f / gscale : 1.f;     // (a power of two: exact)
     float* part = partial + (long)blockIdx.x * F::PART;
     float* pW1t = part;              // [c][hid]
     float* pW2 = part + H * C;       // [c][hid]
@@ -1180,19 +1316,19 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * mt + drow(r, half);
-                pW1t[c * H + hid] = acc1[ch][mt][r];
-                pW2[c * H + hid] = acc2[ch][mt][r];
+                pW1t[c * H + hid] = acc1[ch][mt][r] * rg;
+                pW2[c * H + hid] = acc2[ch][mt][r] * rg;
             }
         }
         const float v1 = bs1[ch] + __shfl_xor(bs1[ch], 32);
-        if (half == 0) pb1[hid] = v1;
+        if (half == 0) pb1[hid] = v1 * rg;
     }
     red[tid] = bs2;
     __syncthreads();
     if (tid < C) {
         float v = 0.f;
         for (int k = tid; k < F::NT; k += C) v += red[k];
-        pb2[tid] = v;
+        pb2[tid] = v * rg;
     }
 }
 
@@ -1562,39 +1698,37 @@ extern "C" int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, in
     return ffx_launch_status();
 }
 
-extern "C" int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
+// ---- host side, written once over the split policy --------------------------------------------------------------------------
+template <class S>
+static int fx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
     if (!descs_dev || n <= 0) return FFNO_EINVAL;
     if (!ffno_ffx_supported(C, H)) return FFNO_EUNSUPPORTED;
     static_assert(sizeof(ffno_fxpack_desc) == sizeof(FxPackDesc), "descriptor layout");
     const int threads = (C * H / 8);   // one thread per (fragment, lane): 8 weights each
-    FFNO_LAUNCH(ffx_pack_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+    FFNO_LAUNCH((ffx_pack_kernel<S>), dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
                 reinterpret_cast<const FxPackDesc*>(descs_dev), C, H);
     return ffx_launch_status();
 }
 
-extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
-                            const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
-    return ffno_ffx_fwd2(s, nullptr, nullptr, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
-}
-
-extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1,
-                             const float* b1, const void* pk2, const float* b2, float* out, void* mask, int P, int C,
-                             int H, void* stream) {
+template <class S>
+static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
+                   const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
     if (!s || !pk1 || !b1 || !pk2 || !b2 || !out || P <= 0 || (s_sum && !s2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
     const dim3 grid(min(kFxBlocks, ntiles));
     hipStream_t st = (hipStream_t)stream;
+    constexpr bool BF3 = S::NP == 3;      // the software-pipelined kernel exists for the split-bf16 operands only
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        if ((g_chain_schedule & 8) && CC == 64 && s2 && s_sum && resid && mask)                                                   \
-            FFNO_LAUNCH((ffx_chain_sp_kernel<64, HH, 1, false, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,     \
-                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                \
+        if (BF3 && (g_chain_schedule & 8) && CC == 64 && s2 && s_sum && resid && mask)                                \
+            FFNO_LAUNCH((ffx_chain_sp_kernel<64, HH, 1, false, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2,   \
+                        s_sum, resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);         \
         else if ((g_chain_schedule & 1) && HH >= 64)                                                                  \
-            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,     \
-                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                \
+            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, false, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,  \
+                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, (const float*)nullptr);           \
         else                                                                                                          \
-            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum, resid, \
-                        (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);                       \
+            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,     \
+                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, (const float*)nullptr);           \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -1602,31 +1736,28 @@ extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, cons
     return FFNO_EUNSUPPORTED;
 }
 
-extern "C" int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds, int P,
-                                 int C, int H, void* stream) {
-    return ffno_ffx_bwd_data2(db, nullptr, nullptr, mask, pk1b, pk2b, ds, P, C, H, stream);
-}
-
-extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
-                                  const void* pk2b, float* ds, int P, int C, int H, void* stream) {
+template <class S>
+static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
+                        const void* pk2b, float* ds, int P, int C, int H, const float* gscale, void* stream) {
     if (!db || !mask || !pk1b || !pk2b || !ds || P <= 0 || (db_sum && !db2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
     const dim3 grid(min(kFxBlocks, ntiles));
     hipStream_t st = (hipStream_t)stream;
+    constexpr bool BF3 = S::NP == 3;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        if ((g_chain_schedule & 16) && CC == 64 && db2 && db_sum)                                                                 \
-            FFNO_LAUNCH((ffx_chain_sp_kernel<64, HH, 1, true, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,   \
-                        nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
+        if (BF3 && (g_chain_schedule & 16) && CC == 64 && db2 && db_sum)                                              \
+            FFNO_LAUNCH((ffx_chain_sp_kernel<64, HH, 1, true, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2,  \
+                        db_sum, nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                \
                         (uint32_t*)const_cast<void*>(mask), P);                                                       \
         else if ((g_chain_schedule & 2) && HH >= 64)                                                                  \
-            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,   \
-                        nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
-                        (uint32_t*)const_cast<void*>(mask), P);                                                       \
+            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, true, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2,        \
+                        db_sum, nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                \
+                        (uint32_t*)const_cast<void*>(mask), P, gscale);                                               \
         else                                                                                                          \
-            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,      \
+            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,   \
                         nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
-                        (uint32_t*)const_cast<void*>(mask), P);                                                       \
+                        (uint32_t*)const_cast<void*>(mask), P, gscale);                                               \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -1634,24 +1765,97 @@ extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_s
     return FFNO_EUNSUPPORTED;
 }
 
-extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
-                                            const void* pk1b, float* partial, int P, int C, int H, int nsplit,
-                                            void* stream) {
+template <class S>
+static int fx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
+                                  float* partial, int P, int C, int H, int nsplit, const float* gscale, void* stream) {
     if (!s || !db || !pk1 || !b1 || !pk1b || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    constexpr bool BF3 = S::NP == 3;
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \
-        if (g_chain_schedule & 4)                                                                                  \
+        if (BF3 && (g_chain_schedule & 4))                                                                         \
             FFNO_LAUNCH((ffx_wgrad_rs_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
                         (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                    \
         else                                                                                                       \
-            FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,           \
-                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                    \
+            FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH, S>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
+                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, gscale);                            \
         return ffx_launch_status();                                                                                \
     }
     FFNO_FX_DISPATCH(CASE)
 #undef CASE
     return FFNO_EUNSUPPORTED;
+}
+
+// ---- split-bf16 entry points ----
+extern "C" int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
+    return fx_pack<SplitBf3>(descs_dev, n, C, H, stream);
+}
+extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
+                            const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
+    return fx_fwd2<SplitBf3>(s, nullptr, nullptr, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+}
+extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1,
+                             const float* b1, const void* pk2, const float* b2, float* out, void* mask, int P, int C,
+                             int H, void* stream) {
+    return fx_fwd2<SplitBf3>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+}
+extern "C" int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds, int P,
+                                 int C, int H, void* stream) {
+    return fx_bwd_data2<SplitBf3>(db, nullptr, nullptr, mask, pk1b, pk2b, ds, P, C, H, nullptr, stream);
+}
+extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
+                                  const void* pk2b, float* ds, int P, int C, int H, void* stream) {
+    return fx_bwd_data2<SplitBf3>(db, db2, db_sum, mask, pk1b, pk2b, ds, P, C, H, nullptr, stream);
+}
+extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
+                                            const void* pk1b, float* partial, int P, int C, int H, int nsplit,
+                                            void* stream) {
+    return fx_bwd_weights_partial<SplitBf3>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, nullptr, stream);
+}
+
+// power-of-two scale that brings max |g| to [32, 64]: 1000-fold growth through the backward layers stays below the half
+// format's 65504, elements down to 2^-18 of the maximum keep fp32-level relative accuracy
+__global__ __launch_bounds__(1024) void ffh_grad_scale_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+    __shared__ float red[1024];
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int sft = 512; sft >= 1; sft >>= 1) {
+        if ((int)threadIdx.x < sft) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + sft]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mx = red[0];
+        float sc = 1.f;
+        if (mx > 0.f && mx < 3.0e38f) sc = exp2f(6.f - ceilf(log2f(mx)));
+        out[0] = fminf(fmaxf(sc, 1.0e-30f), 1.0e30f);
+    }
+}
+extern "C" int ffno_ffh_grad_scale(const float* g, long n, float* scale_out, void* stream) {
+    if (!g || !scale_out || n <= 0) return FFNO_EINVAL;
+    FFNO_LAUNCH(ffh_grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, scale_out);
+    return ffx_launch_status();
+}
+
+// ---- split-fp16 entry points (same operators, masks, partial-slice layout and reduce kernels; own weight packs) ----
+extern "C" size_t ffno_ffh_pack_bytes(int C, int H) { return (size_t)C * H * 4; }
+extern "C" int ffno_ffh_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
+    return fx_pack<SplitHf2>(descs_dev, n, C, H, stream);
+}
+extern "C" int ffno_ffh_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1,
+                             const float* b1, const void* pk2, const float* b2, float* out, void* mask, int P, int C,
+                             int H, void* stream) {
+    return fx_fwd2<SplitHf2>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+}
+extern "C" int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
+                                  const void* pk2b, float* ds, int P, int C, int H, const float* grad_scale, void* stream) {
+    return fx_bwd_data2<SplitHf2>(db, db2, db_sum, mask, pk1b, pk2b, ds, P, C, H, grad_scale, stream);
+}
+extern "C" int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
+                                            const void* pk1b, float* partial, int P, int C, int H, int nsplit,
+                                            const float* grad_scale, void* stream) {
+    return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, grad_scale, stream);
 }
 
 extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,

@@ -353,6 +353,31 @@ int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_dev, int n,
                                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same feed-forward on the fp16 matrix cores at fp32 accuracy ("fp16x2": every fp32 operand x = hi + lo / 2^11 with
+ * hi = fp16(x), lo = fp16((x - hi) 2^11), both rounded to nearest, so |x - hi - lo / 2^11| <= 2^-24 |x|; three
+ * v_mfma_f32_32x32x16_f16 per product block -- hi hi into a main accumulator, hi lo + lo hi into a correction accumulator that
+ * is folded in with the factor 2^-11).  Half the matrix work and two thirds of the operand traffic of ffno_ffx_*, same
+ * operators, shapes (ffno_ffx_supported), sign-bit masks, partial-slice layout and reduce kernels
+ * (ffno_ffx_bwd_weights_reduce[_batched]); the weight packs are this family's own (ffno_ffh_pack, same descriptors).
+ * RANGE: the representation error of an element is max(2^-24 |x|, 2^-36): fp32-level relative accuracy for
+ * 2.4e-4 <= |x| < 65504, a fixed absolute error below (at or above 65504 fp16 overflows to infinity).  Activations and weights of an F-FNO layer are O(1) and need nothing; gradients
+ * can be arbitrarily small, so the backward entry points take `grad_scale`: a DEVICE pointer (or NULL = 1) to a positive power
+ * of two by which db is multiplied while it is staged (results are divided by it again, exactly).  ffno_ffh_grad_scale
+ * derives one from a gradient tensor without a host round trip (max |g| -> [32, 64]; one small launch per backward pass, on
+ * the loss gradient).  Without a scale the calls stay valid; accuracy then degrades gradually for |db| < 2.4e-4 (measured
+ * 9e-7 at 1e-5).
+ * --------------------------------------------------------------------------------------------- */
+size_t ffno_ffh_pack_bytes(int C, int H);
+int ffno_ffh_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
+int ffno_ffh_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
+                  const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
+                       const void* pk2b, float* ds, int P, int C, int H, const float* grad_scale, void* stream);
+int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
+                                 float* partial, int P, int C, int H, int nsplit, const float* grad_scale, void* stream);
+int ffno_ffh_grad_scale(const float* g, long n, float* scale_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),
  * eps 1e-5, biased variance, elementwise affine), fused with the layer's residual add (grid_2d.py:169):
  *   fwd:  out = (t - mean) * rstd * gamma + beta (+ resid);  stats[p] = {mean, rstd} (2 floats per pixel, kept for backward)

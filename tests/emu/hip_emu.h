@@ -202,6 +202,42 @@ inline f32x16 mfma_32x32x16_bf16(emu_u32x4 a, emu_u32x4 b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x16_f16: same fragment layout as the bf16 form with IEEE half elements.  Half products are exact in fp32.
+inline float emu_half_to_float(unsigned short h) {
+    _Float16 v;
+    memcpy(&v, &h, 2);
+    return (float)v;
+}
+inline unsigned short emu_float_to_half(float x) {      // round to nearest even, like v_cvt_pk_f16_f32
+    _Float16 v = (_Float16)x;
+    unsigned short h;
+    memcpy(&h, &v, 2);
+    return h;
+}
+inline f32x16 mfma_32x32x16_f16(emu_u32x4 a, emu_u32x4 b, f32x16 c) {
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int p = w.parity;
+    for (int i = 0; i < 4; ++i) {
+        w.xa[p][lane][i] = a[i];
+        w.xb[p][lane][i] = b[i];
+    }
+    wave_barrier(w);
+    int j = lane & 31, half = lane >> 5;
+    auto hf = [](unsigned word, int e) { return emu_half_to_float((unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu))); };
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float acc = c[r];
+        for (int kh = 0; kh < 2; ++kh)
+            for (int e = 0; e < 8; ++e)
+                acc = fmaf(hf(w.xa[p][i + 32 * kh][e >> 1], e), hf(w.xb[p][j + 32 * kh][e >> 1], e), acc);
+        d[r] = acc;
+    }
+    wave_exchange_done(p);
+    return d;
+}
+
 // v_mfma_f32_16x16x32_bf16: A[i = l&15][k = 8*(l>>4) + e], B[k = 8*(l>>4) + e][j = l&15], D as the fp32 16x16 form.
 inline f32x4 mfma_16x16x32_bf16(emu_u32x4 a, emu_u32x4 b, f32x4 c) {
     WaveX& w = my_wave();

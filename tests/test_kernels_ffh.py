@@ -1,0 +1,134 @@
+"""fp16x2 feed-forward kernels (ffno_ffh_*, fourierflow_amd/csrc/ffx.hip with the SplitHf2 policy) through the C ABI vs fp64
+numpy references -- on the CPU wave emulator (-m "not gpu") and on the MI355X (-m gpu).  Same operator, masks and tolerance as
+the bf16x3 family (test_kernels_ffx.py); what differs is the operand format, so the range behaviour is tested as well."""
+import numpy as np
+import pytest
+
+from backend_util import be, rel_l2  # noqa: F401
+from fourierflow_amd._capi import FxPackDesc
+from test_kernels_ff import ff_ref
+
+TOL = 1e-5
+
+
+def pack_weights_h(be, W1, W2):
+    lib, p = be.lib, be.ptr
+    H, C = W1.shape
+    nbytes = lib.ffno_ffh_pack_bytes(C, H)
+    assert nbytes == C * H * 4
+    dW1, dW2 = be.put(W1), be.put(W2)
+    bufs = [be.zeros(nbytes // 4, np.uint32) for _ in range(4)]
+    spec = [(dW1, C, 1, 1), (dW2, 1, H, 2), (dW2, 1, H, 1), (dW1, C, 1, 2)]
+    descs = (FxPackDesc * 4)(*[FxPackDesc(p(src), p(dst), sh, sc, ty, 0) for (src, sh, sc, ty), dst in zip(spec, bufs)])
+    table = be.put(np.frombuffer(bytes(descs), dtype=np.uint8))
+    assert lib.ffno_ffh_pack(p(table), 4, C, H, None) == 0
+    be.get(bufs[0])   # sync
+    return bufs, (dW1, dW2, table)
+
+
+def test_split2_pack_layout_and_accuracy(be):
+    """hi + lo / 2^11 of a packed weight reproduces the fp32 value to max(2^-24 |x|, 2^-36), at the documented
+    fragment positions (the bf16x3 layout with two planes)."""
+    C, H = 64, 256
+    rs = np.random.RandomState(0)
+    W1 = (rs.standard_normal((H, C)) * np.exp(rs.uniform(-6, 6, (H, C)))).astype(np.float32)     # 2.5e-3 .. 4e2
+    W2 = rs.standard_normal((C, H)).astype(np.float32)
+    bufs, _keep = pack_weights_h(be, W1, W2)
+    raw = be.get(bufs[0]).view(np.float16).reshape((H // 32) * (C // 16), 2, 64, 8)
+    val = raw[:, 0].astype(np.float64) + raw[:, 1].astype(np.float64) / 2048.0
+    lane = np.arange(64)
+    j, half, e = (lane & 31)[:, None], (lane >> 5)[:, None], np.arange(8)[None, :]
+    a1 = val.reshape(H // 32, C // 16, 64, 8)
+    for w in (0, 3, 7):
+        for st in range(C // 16):
+            ref = W1[32 * w + j, 16 * st + 8 * half + e].astype(np.float64)
+            err, big = np.abs(a1[w, st] - ref), np.abs(ref) >= 2.0 ** -12      # both planes are normal halves there
+            assert np.max(err[big] / np.abs(ref[big])) <= 2.0 ** -23
+            assert np.all(err[~big] <= 2.0 ** -35)
+
+
+@pytest.mark.parametrize("sched", [0, 1, 2, 3])
+@pytest.mark.parametrize("P,C,H", [(70, 64, 256), (33, 32, 128), (64, 64, 128), (40, 32, 64), (5000, 64, 256)])
+def test_ffh_fwd_bwd(be, P, C, H, sched):
+    if be.kind == "emu" and (P > 1000 or (sched and (C, H) != (64, 256))):
+        pytest.skip("large case / schedule sweep of the small shapes run on the GPU only")
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(P + C + H)
+    sa, sb = (rs.standard_normal((P, C)).astype(np.float32) for _ in range(2))
+    s = sa + sb
+    resid = rs.standard_normal((P, C)).astype(np.float32)
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = (rs.standard_normal(H) * 0.1).astype(np.float32)
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b2 = (rs.standard_normal(C) * 0.1).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
+    db1_, db2_ = be.put(b1), be.put(b2)
+    try:
+        assert lib.ffno_ffx_set_schedule(sched) == 0
+        out, ssum = be.put(resid), be.empty((P, C))              # out aliases the residual
+        mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+        assert lib.ffno_ffh_fwd2(p(be.put(sa)), p(be.put(sb)), p(ssum), p(out), p(a1), p(db1_), p(a2), p(db2_), p(out), p(mask),
+                                 P, C, H, None) == 0
+        ref_out, ref_h = ff_ref(s, resid, W1, b1, W2, b2)
+        assert rel_l2(be.get(out), ref_out) < TOL
+        np.testing.assert_array_equal(be.get(ssum), s)
+        # one addend, no residual, no mask
+        out2 = be.empty((P, C))
+        assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(out2), None, P, C, H, None) == 0
+        assert rel_l2(be.get(out2), ref_out - resid) < TOL
+
+        # backward: tiny gradients, brought into the half range by the power-of-two scale
+        ga, gb = ((rs.standard_normal((P, C)) * 4e-6).astype(np.float32) for _ in range(2))
+        db = ga + gb
+        scale = be.zeros(1)
+        assert lib.ffno_ffh_grad_scale(p(be.put(db)), db.size, p(scale), None) == 0
+        sc = float(be.get(scale)[0])
+        assert sc == 2.0 ** round(np.log2(sc)) and 32.0 <= sc * np.abs(db).max() <= 64.0
+        scale = p(scale)
+        gsum, ds = be.empty((P, C)), be.empty((P, C))
+        assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)), p(gsum), p(mask), p(a1b), p(a2b), p(ds), P, C, H, scale, None) == 0
+        np.testing.assert_array_equal(be.get(gsum), db)           # the stored sum is NOT scaled
+        ref_dh = (db.astype(np.float64) @ W2.astype(np.float64)) * (ref_h > 0)
+        ref_ds = ref_dh @ W1.astype(np.float64)
+        assert rel_l2(be.get(ds), ref_ds) < TOL
+        nsplit = 3 if P < 1000 else 64
+        partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
+        assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, scale, None) == 0
+        gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
+        assert lib.ffno_ffx_bwd_weights_reduce(p(partial), p(gW1), p(gW2), p(gb1), p(gb2), C, H, nsplit, 0, None) == 0
+        assert rel_l2(be.get(gW1), ref_dh.T @ s.astype(np.float64)) < TOL
+        assert rel_l2(be.get(gW2), db.astype(np.float64).T @ ref_h) < TOL
+        assert rel_l2(be.get(gb1), ref_dh.sum(0)) < TOL
+        assert rel_l2(be.get(gb2), db.astype(np.float64).sum(0)) < TOL
+        # without the scale the same call still works, only less accurately (documented: gradual below 6e-5)
+        assert lib.ffno_ffh_bwd_data2(p(be.put(db)), None, None, p(mask), p(a1b), p(a2b), p(ds), P, C, H, None, None) == 0
+        assert rel_l2(be.get(ds), ref_ds) < 3e-5
+    finally:
+        lib.ffno_ffx_set_schedule(1)
+
+
+def test_ffh_accuracy_over_the_half_range(be):
+    """Per-pixel relative error of the forward stays at fp32 level for activations from 1e-3 to 1e3 (hi is a normal half
+    throughout; the scaled lo plane carries the next 11 bits whatever the magnitude)."""
+    lib, p = be.lib, be.ptr
+    P, C, H = 96, 64, 256
+    rs = np.random.RandomState(5)
+    s = (rs.standard_normal((P, C)) * np.exp(rs.uniform(-7, 7, (P, 1)))).astype(np.float32)
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = np.zeros(H, np.float32)
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b2 = np.zeros(C, np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
+    out = be.empty((P, C))
+    assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, None, p(a1), p(be.put(b1)), p(a2), p(be.put(b2)), p(out), None, P, C, H, None) == 0
+    ref_out, _ = ff_ref(s, None, W1, b1, W2, b2)
+    err_rows = np.linalg.norm(be.get(out) - ref_out, axis=1) / np.linalg.norm(ref_out, axis=1)
+    assert err_rows.max() < 2e-6, err_rows.max()
+
+
+def test_ffh_rejects_bad_arguments(be):
+    z = be.zeros(64)
+    p = be.ptr
+    assert be.lib.ffno_ffh_fwd2(p(z), None, None, None, p(z), p(z), p(z), p(z), p(z), None, 1, 48, 192, None) == -2
+    assert be.lib.ffno_ffh_bwd_data2(None, None, None, p(z), p(z), p(z), p(z), 1, 64, 256, None, None) == -1
+    assert be.lib.ffno_ffh_grad_scale(p(z), 0, p(z), None) == -1
