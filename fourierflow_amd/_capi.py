@@ -36,14 +36,15 @@ class LayerFwdDesc(C.Structure):
     """Mirror of ``ffno_layer_fwd_desc`` (include/ffno.h)."""
     _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
                 ("pk1", P), ("b1", P), ("pk2", P), ("b2", P), ("s_sum", P), ("resid", P), ("out", P), ("mask", P),
-                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("pad_", C.c_int32)]
+                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("ff_kernel", C.c_int32)]
 
 
 class LayerBwdDesc(C.Structure):
     """Mirror of ``ffno_layer_bwd_desc`` (include/ffno.h)."""
     _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
                 ("g", P), ("g2", P), ("g_sum", P), ("mask", P), ("pk1b", P), ("pk2b", P), ("ds", P), ("s", P), ("pk1", P),
-                ("b1", P), ("partial", P), ("nsplit", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32)]
+                ("b1", P), ("partial", P), ("nsplit", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
+                ("ff_kernel", C.c_int32), ("pad_", C.c_int32), ("grad_scale", P)]
 
 
 class FxRedDesc(C.Structure):

@@ -20,6 +20,7 @@ fp32 buffer (``gflat``) so the trainer can run ONE fused AdamW and ONE RCCL all-
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -178,6 +179,10 @@ class FFNOEngine:
         # feed-forward on the bf16 matrix cores at fp32 accuracy (ffx.hip: split-bf16, no stored hidden activations)
         # when the library has the (C, H) instance; False = the fp32-MFMA kernels of ff.hip
         self.use_ffx = True
+        # operand split of those kernels: "fp16x2" (ffno_ffh_*: two fp16 planes, three MFMAs per product block -- half the matrix
+        # work; gradients are range-scaled by a device-resident power of two taken from the loss gradient) or "bf16x3"
+        # (ffno_ffx_*: three bf16 planes, six MFMAs, any fp32 range).  Both are fp32-grade (tests/test_kernels_ffh.py).
+        self.ff_split = os.environ.get("FFNO_FF_SPLIT", "fp16x2")
         # The first two spectral branches of a layer (and of its adjoint) run in ONE launch whose workgroups are co-resident
         # (ffno_spectral_fused_pair), each into its own buffer; the feed-forward kernels that consume them add the two
         # while staging (ffno_ffx_fwd2 / _bwd_data2).  Needs the split-bf16 feed-forward, no fork heads, and both axes on
@@ -256,6 +261,36 @@ class FFNOEngine:
     def _ffx(self) -> bool:
         return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
 
+    def _h2(self) -> bool:
+        if self.ff_split not in ("fp16x2", "bf16x3"):
+            raise ValueError("ff_split must be 'fp16x2' or 'bf16x3', got %r" % (self.ff_split,))
+        return self.ff_split == "fp16x2"
+
+    # ---- the split feed-forward kernels of either family (same operators; own weight packs) ----
+    def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st):
+        lib = _lib.get_lib()
+        fn = lib.ffno_ffh_fwd2 if self._h2() else lib.ffno_ffx_fwd2
+        self._k("ff_fwd", fn, _p(s), _p(s2), _p(s_sum), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out), _p(mask),
+                P, self.C, self.H, st)
+
+    def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st):
+        lib = _lib.get_lib()
+        if self._h2():
+            self._k("ff_bwd_data", lib.ffno_ffh_bwd_data2, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
+                    P, self.C, self.H, _p(self._gscale), st)
+        else:
+            self._k("ff_bwd_data", lib.ffno_ffx_bwd_data2, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
+                    P, self.C, self.H, st)
+
+    def _ffs_wgrad(self, s, g, l0, b0, part, P, nsplit, st):
+        lib = _lib.get_lib()
+        if self._h2():
+            self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0), _p(l0.fx[2]),
+                    _p(part), P, self.C, self.H, nsplit, _p(self._gscale), st)
+        else:
+            self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0), _p(l0.fx[2]),
+                    _p(part), P, self.C, self.H, nsplit, st)
+
     def _k(self, name, fn, *args):
         """Enqueue one C-ABI call; with a timer attached, bracket it with HIP events on the launch stream."""
         t = self.timer
@@ -326,7 +361,7 @@ class FFNOEngine:
         return self.gflat[o:o + int(np.prod(self.param_shapes[name]))].view(self.param_shapes[name])
 
     def _refresh_pointers(self):
-        sig = tuple(self.params[n].data_ptr() for n in self.param_names)
+        sig = tuple(self.params[n].data_ptr() for n in self.param_names) + (self.ff_split,)
         if sig == self._ptr_sig:
             return
         self._ptr_sig = sig
@@ -359,7 +394,7 @@ class FFNOEngine:
         blocks = list(dict.fromkeys(self.ff_prefix + self.fc_prefix))
         self._n_fx = 0
         if lib.ffno_ffx_supported(self.C, self.H):
-            words = int(lib.ffno_ffx_pack_bytes(self.C, self.H)) // 4
+            words = int((lib.ffno_ffh_pack_bytes if self._h2() else lib.ffno_ffx_pack_bytes)(self.C, self.H)) // 4
             if getattr(self, "_fx_flat", None) is None or self._fx_flat.numel() != 4 * words * len(blocks) \
                     or self._fx_flat.device != self.device:
                 self._fx_flat = torch.empty(4 * words * len(blocks), dtype=torch.int32, device=self.device)
@@ -511,7 +546,8 @@ class FFNOEngine:
         if self._desc_dev is not None:
             self._k("weightnorm_fwd", lib.ffno_weightnorm_fwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
         if self._ffx() and self._n_fx:
-            self._k("ffx_pack", lib.ffno_ffx_pack, _p(self._fx_dev), self._n_fx, self.C, self.H, st)
+            self._k("ffx_pack", lib.ffno_ffh_pack if self._h2() else lib.ffno_ffx_pack, _p(self._fx_dev), self._n_fx, self.C,
+                    self.H, st)
         for i, names in enumerate(self._fw_sets if self.spectral == "plus" else []):
             self._k("fw2d_pack", lib.ffno_fw2d_pack, _p(self.params[names[0]]), _p(self.params[names[1]]),
                     _p(self.planes[i][0][0]), _p(self.planes[i][0][1]), self.C, self.K, st)
@@ -556,8 +592,7 @@ class FFNOEngine:
     def _ff_fwd(self, s, resid, l0, l1, b0, b1, out, hbuf, mask, P, st):
         lib = _lib.get_lib()
         if self._ffx():
-            self._k("ff_fwd", lib.ffno_ffx_fwd, _p(s), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out),
-                    _p(mask), P, self.C, self.H, st)
+            self._ffs_fwd2(s, None, None, resid, l0, b0, b1, out, mask, P, st)
         else:
             self._k("ff_fwd", lib.ffno_ff_fwd, _p(s), _p(resid), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1), _p(out),
                     _p(hbuf), _p(mask), P, self.C, self.H, st)
@@ -565,8 +600,7 @@ class FFNOEngine:
     def _ff_bwd_data(self, g, mask, l0, l1, dh, ds, P, st):
         lib = _lib.get_lib()
         if self._ffx():
-            self._k("ff_bwd_data", lib.ffno_ffx_bwd_data, _p(g), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds), P,
-                    self.C, self.H, st)
+            self._ffs_bwd2(g, None, None, mask, l0, ds, P, st)
         else:
             self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(g), _p(mask), _p(l0.wt), _p(l1.wt), _p(dh), _p(ds), P,
                     self.C, self.H, st)
@@ -577,12 +611,10 @@ class FFNOEngine:
         if self._ffx() and ws.defer_reduce:
             assert not accumulate
             part = ws.ffparts[len(ws.red_jobs)]
-            self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0),
-                    _p(l0.fx[2]), _p(part), P, C, H, ws.nsplit_ff, st)
+            self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st)
             ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gb0.data_ptr(), gb1.data_ptr()))
         elif self._ffx():
-            self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0),
-                    _p(l0.fx[2]), _p(ws.ffpart), P, C, H, ws.nsplit_ff, st)
+            self._ffs_wgrad(s, g, l0, b0, ws.ffpart, P, ws.nsplit_ff, st)
             self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
                     _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
         else:
@@ -727,7 +759,7 @@ class FFNOEngine:
                             self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0),
                             int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
                             _p(s_l) if save_for_backward else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
-                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, 0)
+                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()))
                         self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
                         continue
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
@@ -738,9 +770,8 @@ class FFNOEngine:
             ff_out = ws.TL[sv] if self.layer_norm else (ws.Blast if last else ws.X)
             ff_res = None if (self.layer_norm or last) else ws.X
             if conc:
-                self._k("ff_fwd", lib.ffno_ffx_fwd2, _p(s_l), _p(ws.T), _p(s_l) if save_for_backward else None,
-                        _p(ff_res), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(ff_out),
-                        _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, st)
+                self._ffs_fwd2(s_l, ws.T, s_l if save_for_backward else None, ff_res, l0, b0, b1, ff_out,
+                               ws.MASK[sv] if save_for_backward else None, P, st)
             elif not (self.use_fork and last):    # with fork heads the last layer's backcast only feeds the dead x_L
                 self._ff_fwd(s_l, ff_res, l0, l1, b0, b1, ff_out,
                              ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st)
@@ -779,6 +810,12 @@ class FFNOEngine:
         C, H, L = self.C, self.H, self.L
         ws = self._workspace(B, S, True)
         st = _lib.current_stream(self.device)
+        if self._ffx() and self._h2():
+            # range scale of the fp16x2 backward kernels: one power of two for the whole pass, taken on the device from the
+            # loss gradient (max |gy| -> [32, 64]; the head and the layers change the magnitude by far less than the 2^10 left)
+            if getattr(self, "_gscale", None) is None or self._gscale.device != gy.device:
+                self._gscale = torch.ones(1, dtype=torch.float32, device=gy.device)
+            self._k("ff_grad_scale", lib.ffno_ffh_grad_scale, _p(gy), gy.numel(), _p(self._gscale), st)
         P = ws.P
         full = self.mode == "full"
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
@@ -864,7 +901,7 @@ class FFNOEngine:
                                  self._planes_for(si, b, 1, x3pair), 0),
                     int(x3pair), int(self.x3_interleave), _p(g_in), _p(ws.G1) if have_g1 else None, _p(g_in), _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
-                    _p(part), ws.nsplit_ff, P, C, H)
+                    _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, _p(self._gscale) if self._h2() else None)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
                 ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
                                     gv(fp + "layers.1.0.bias").data_ptr()))
@@ -884,8 +921,7 @@ class FFNOEngine:
             if conc:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
                 two = bool(have_g1 and not self.layer_norm)
-                self._k("ff_bwd_data", lib.ffno_ffx_bwd_data2, _p(g_ff), _p(ws.G1) if two else None,
-                        _p(g_ff) if two else None, _p(ws.MASK[l]), _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), P, C, H, st)
+                self._ffs_bwd2(g_ff, ws.G1 if two else None, g_ff if two else None, ws.MASK[l], l0, ws.DS, P, st)
             else:
                 self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
             if use_side:

@@ -197,10 +197,13 @@ int ffno_spectral_x3_staged_pair(const ffno_fused_branch* a, const ffno_fused_br
  *         a, b (a.in == b.in == ds; a.resid = the residual gradient), which also save the dY spectra for the Fourier-weight
  *         gradient through a.spec_save / b.spec_save.
  * branch_kernel selects the fused branch kernel: FFNO_BRANCH_X3 (planes = packed split-bf16 sets) or FFNO_BRANCH_FUSED
- * (planes = fp32 planes).  Weight packs as for ffno_ffx_*: pk1 / pk2 forward, pk1b / pk2b backward.
+ * (planes = fp32 planes).  ff_kernel selects the feed-forward family; weight packs as for ffno_ffx_* / ffno_ffh_*: pk1 / pk2
+ * forward, pk1b / pk2b backward.
  * --------------------------------------------------------------------------------------------- */
 #define FFNO_BRANCH_FUSED 0
 #define FFNO_BRANCH_X3 1
+#define FFNO_FF_BF16X3 0
+#define FFNO_FF_FP16X2 1
 typedef struct ffno_layer_fwd_desc {
     ffno_fused_branch a, b;
     int32_t branch_kernel, interleave;
@@ -212,7 +215,8 @@ typedef struct ffno_layer_fwd_desc {
     const float* resid;
     float* out;
     void* mask;
-    int32_t P, C, H, pad_;
+    int32_t P, C, H;
+    int32_t ff_kernel; /* FFNO_FF_BF16X3 (packs of ffno_ffx_pack) or FFNO_FF_FP16X2 (packs of ffno_ffh_pack) */
 } ffno_layer_fwd_desc;
 typedef struct ffno_layer_bwd_desc {
     ffno_fused_branch a, b;
@@ -229,6 +233,8 @@ typedef struct ffno_layer_bwd_desc {
     const float* b1;
     float* partial;
     int32_t nsplit, P, C, H;
+    int32_t ff_kernel, pad_;
+    const float* grad_scale; /* FFNO_FF_FP16X2: device-resident power of two (ffno_ffh_grad_scale), NULL = 1 */
 } ffno_layer_bwd_desc;
 int ffno_layer_fwd(const ffno_layer_fwd_desc* d, void* stream);
 int ffno_layer_bwd(const ffno_layer_bwd_desc* d, void* stream);

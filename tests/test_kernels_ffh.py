@@ -80,11 +80,11 @@ def test_ffh_fwd_bwd(be, P, C, H, sched):
         # backward: tiny gradients, brought into the half range by the power-of-two scale
         ga, gb = ((rs.standard_normal((P, C)) * 4e-6).astype(np.float32) for _ in range(2))
         db = ga + gb
-        scale = be.zeros(1)
-        assert lib.ffno_ffh_grad_scale(p(be.put(db)), db.size, p(scale), None) == 0
-        sc = float(be.get(scale)[0])
+        scale_buf = be.zeros(1)                                   # (kept alive: the kernels read it on the device)
+        assert lib.ffno_ffh_grad_scale(p(be.put(db)), db.size, p(scale_buf), None) == 0
+        sc = float(be.get(scale_buf)[0])
         assert sc == 2.0 ** round(np.log2(sc)) and 32.0 <= sc * np.abs(db).max() <= 64.0
-        scale = p(scale)
+        scale = p(scale_buf)
         gsum, ds = be.empty((P, C)), be.empty((P, C))
         assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)), p(gsum), p(mask), p(a1b), p(a2b), p(ds), P, C, H, scale, None) == 0
         np.testing.assert_array_equal(be.get(gsum), db)           # the stored sum is NOT scaled
