@@ -48,6 +48,8 @@ FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 # split-bf16 kernels: one fp32-accurate multiply-add = 6 bf16 MFMA multiply-adds, so their matrix-core ceiling in ALGORITHMIC
 # (fp32-equivalent) FLOP/s is the dense bf16 peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s) / 6
 BF16X3_PEAK_TFLOPS = 2500.0 / 6.0
+# split-fp16 kernels (ffno_ffh_*): three fp16 MFMA multiply-adds per fp32-accurate one; dense fp16 peak = the bf16 one
+FP16X2_PEAK_TFLOPS = 2500.0 / 3.0
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec peak
 REPLAYS = 200
 
@@ -168,7 +170,9 @@ def algorithmic_work(P, C, H, K, B, M, N, L, paired=True):
 def matrix_peak(name, engine):
     """Ceiling (fp32-equivalent TFLOP/s) of the matrix pipe a kernel runs on."""
     if name in ("ff_fwd", "ff_bwd_data", "ff_bwd_weights_partial"):
-        return BF16X3_PEAK_TFLOPS if engine._ffx() else FP32_MFMA_PEAK_TFLOPS
+        if not engine._ffx():
+            return FP32_MFMA_PEAK_TFLOPS
+        return FP16X2_PEAK_TFLOPS if engine.ff_split == "fp16x2" else BF16X3_PEAK_TFLOPS
     if name == "fw_grad_partial":
         return BF16X3_PEAK_TFLOPS
     if name.startswith("spectral_fused"):
@@ -317,6 +321,8 @@ def main():
     ap.add_argument("--modes", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline train steps (0 disables the CPU leg)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 256x256 and 64^3 secondary workloads")
+    ap.add_argument("--ff-split", choices=["fp16x2", "bf16x3"], default=None,
+                    help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--x3-interleave", type=int, default=1, help="bit 0: workgroup->branch interleave; bits 8..: start skew / 256 cycles")
     ap.add_argument("--ffx-schedule", type=int, default=1, help="bit mask: 1 forward, 2 backward-data, 4 weight gradients on the role-split schedule (default 1)")
@@ -346,6 +352,8 @@ def main():
     trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
     _fl.get_lib().ffno_ffx_set_schedule(args.ffx_schedule)
     trainer.engine.use_x3 = not args.no_x3
+    if args.ff_split:
+        trainer.engine.ff_split = args.ff_split
     trainer.engine.x3_interleave = args.x3_interleave
     B, G = args.batch, args.grid
     gen = torch.Generator().manual_seed(1000 + rank)  # rank r draws its own shard of the global batch
@@ -527,8 +535,15 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": "dp%d" % world,
                        "optimizer": "AdamW(lr 2.5e-3, wd 1e-4) + cosine warm-up, fused flat kernel",
                        "collective": "1 x all_reduce(flat fp32 grads, %d floats) / step" % trainer.pflat.numel(),
-                       "arithmetic": "fp32 results; matrix work as exact three-way bf16 splits on v_mfma_f32_32x32x16_bf16 "
-                                     "(feed-forward, spectral branches, Fourier-weight gradient)"},
+                       "arithmetic": "fp32 tensors and fp32-grade results throughout (forward <= 1e-5, gradients <= 5e-5 vs the fp64 "
+                                     "oracle at this geometry: tests/test_bench_geometry.py).  Matrix work on the low-precision "
+                                     "matrix cores through EXACT operand splits with fp32 accumulation: spectral branches and "
+                                     "Fourier-weight gradient as three bf16 planes / six v_mfma_f32_32x32x16_bf16 per product "
+                                     "block; feed-forward as " + (
+                                         "two fp16 planes (hi + lo / 2^11, both rounded to nearest: |error| <= 2^-24 |x|) / three "
+                                         "v_mfma_f32_32x32x16_f16 (measured 7.5e-8 rel-L2 vs fp64, fp32 MFMA: 1.5e-7)"
+                                         if trainer.engine.ff_split == "fp16x2" else "the same three-plane bf16 split"),
+                       "ff_split": trainer.engine.ff_split},
             "samples_per_s": round(steps_per_s * B, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5), "git_head": git_head(),

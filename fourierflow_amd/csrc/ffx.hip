@@ -22,6 +22,8 @@
 //     pixels of the workgroup -- no cross-wave reduction at all.
 //
 // Activation tiles are staged through LDS already split (each element is split once per workgroup, not once per wave).
+#include <algorithm>
+
 #include "ffno_device.h"
 #include "ffno.h"
 
@@ -1814,27 +1816,39 @@ extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, con
 }
 
 // power-of-two scale that brings max |g| to [32, 64]: 1000-fold growth through the backward layers stays below the half
-// format's 65504, elements down to 2^-18 of the maximum keep fp32-level relative accuracy
-__global__ __launch_bounds__(1024) void ffh_grad_scale_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
-    __shared__ float red[1024];
+// format's 65504, elements down to 2^-18 of the maximum keep fp32-level relative accuracy.  One launch: every workgroup folds
+// its maximum into g_gs_max (non-negative floats order like their bit patterns); the last one to arrive writes the scale and
+// resets the two words for the next call (calls on one device are stream-ordered by the caller).
+__device__ unsigned g_gs_max, g_gs_count;
+__global__ __launch_bounds__(256) void ffh_grad_scale_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+    __shared__ float red[256];
     float m = 0.f;
-    for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(g[i]));
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
     red[threadIdx.x] = m;
     __syncthreads();
-    for (int sft = 512; sft >= 1; sft >>= 1) {
+    for (int sft = 128; sft >= 1; sft >>= 1) {
         if ((int)threadIdx.x < sft) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + sft]);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float mx = red[0];
-        float sc = 1.f;
-        if (mx > 0.f && mx < 3.0e38f) sc = exp2f(6.f - ceilf(log2f(mx)));
-        out[0] = fminf(fmaxf(sc, 1.0e-30f), 1.0e30f);
+        float w = red[0];
+        if (!(w < 3.0e38f)) w = 3.0e38f;                      // inf / nan: saturate (the scale below then falls back to 1)
+        atomicMax(&g_gs_max, f2u(w));
+        __threadfence();
+        if (atomicAdd(&g_gs_count, 1u) == gridDim.x - 1) {
+            __threadfence();
+            const float mx = u2f(atomicExch(&g_gs_max, 0u));
+            g_gs_count = 0;
+            float sc = 1.f;
+            if (mx > 0.f && mx < 3.0e38f) sc = exp2f(6.f - ceilf(log2f(mx)));
+            out[0] = fminf(fmaxf(sc, 1.0e-30f), 1.0e30f);
+        }
     }
 }
 extern "C" int ffno_ffh_grad_scale(const float* g, long n, float* scale_out, void* stream) {
     if (!g || !scale_out || n <= 0) return FFNO_EINVAL;
-    FFNO_LAUNCH(ffh_grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, g, n, scale_out);
+    const int blocks = (int)std::min<long>(256, (n + 4095) / 4096);
+    FFNO_LAUNCH(ffh_grad_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, scale_out);
     return ffx_launch_status();
 }
 

@@ -361,7 +361,12 @@ static inline float __shfl_down(float v, int d) {
     return emu::shfl(v, l + d > 63 ? l : l + d);
 }
 static inline float __shfl(float v, int src) { return emu::shfl(v, src); }
+// (the emulator runs one workgroup at a time and its threads as cooperative fibres: plain read-modify-writes are atomic)
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; *p = o > v ? o : v; return o; }
+static inline unsigned atomicExch(unsigned* p, unsigned v) { unsigned o = *p; *p = v; return o; }
+static inline void __threadfence() {}
 static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -132,3 +132,22 @@ def test_ffh_rejects_bad_arguments(be):
     assert be.lib.ffno_ffh_fwd2(p(z), None, None, None, p(z), p(z), p(z), p(z), p(z), None, 1, 48, 192, None) == -2
     assert be.lib.ffno_ffh_bwd_data2(None, None, None, p(z), p(z), p(z), p(z), 1, 64, 256, None, None) == -1
     assert be.lib.ffno_ffh_grad_scale(p(z), 0, p(z), None) == -1
+
+
+@pytest.mark.parametrize("n,mag", [(100, 3e-7), (70000, 5.0), (1 << 20, 1e-3)])
+def test_ffh_grad_scale_is_a_power_of_two_and_reusable(be, n, mag):
+    """max |g| * scale lands in [32, 64] whatever the magnitude and the number of workgroups; the kernel's two words of
+    device state are reset by the call (second call with other data gives the other data's scale)."""
+    if be.kind == "emu" and n > 100000:
+        pytest.skip("large reduction runs on the GPU only")
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(n)
+    out = be.zeros(1)
+    for k in range(2):
+        g = (rs.standard_normal(n) * mag * (1 + 7 * k)).astype(np.float32)
+        assert lib.ffno_ffh_grad_scale(p(be.put(g)), n, p(out), None) == 0
+        sc = float(be.get(out)[0])
+        assert sc == 2.0 ** round(np.log2(sc))
+        assert 32.0 <= sc * np.abs(g).max() <= 64.0
+    assert lib.ffno_ffh_grad_scale(p(be.zeros(64)), 64, p(out), None) == 0      # all zeros: scale 1
+    assert float(be.get(out)[0]) == 1.0
