@@ -29,7 +29,8 @@ class FusedBranch(C.Structure):
     """Mirror of ``ffno_fused_branch`` (include/ffno.h)."""
     _fields_ = [("in_", P), ("out", P), ("resid", P), ("spec_save", P), ("planes", P), ("tw", P),
                 ("B", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
-                ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32)]
+                ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32),
+                ("planes_format", C.c_int32), ("pad_", C.c_int32), ("range_scale", P)]
 
 
 class LayerFwdDesc(C.Structure):
@@ -74,7 +75,7 @@ class FwPackDesc(C.Structure):
 
 class X3PackDesc(C.Structure):
     """Mirror of ``ffno_x3pack_desc`` (include/ffno.h)."""
-    _fields_ = [("planes", P), ("dst", P), ("K", C.c_int32), ("pad_", C.c_int32)]
+    _fields_ = [("planes", P), ("dst", P), ("K", C.c_int32), ("format", C.c_int32)]
 
 
 class TrDesc(C.Structure):

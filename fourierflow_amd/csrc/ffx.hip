@@ -119,62 +119,6 @@ __device__ __forceinline__ void stage4(char* base, int plane_bytes, int off, flo
     *reinterpret_cast<uint2*>(base + 2 * plane_bytes + off) = make_uint2(l0, l1);
 }
 
-// ---- operand-split policies -------------------------------------------------------------------------------------------------
-// The kernels below are written once over the way an fp32 operand is cut into low-precision MFMA operands:
-//   SplitBf3  three bf16 planes, six MFMAs per product block (ffno_device.h "split-bf16"): any fp32 range;
-//   SplitHf2  two fp16 planes, three MFMAs ("split-fp16"): half the matrix work, two thirds of the LDS / register operand
-//             footprint, 6 instead of 11 vector instructions per split pair -- for data inside the half format's exponent range
-//             (2.4e-4 <= |x| < 65504 at full accuracy; gradients are brought there by a power-of-two scale, see ffno_ffh_*).
-// Frag = one MFMA operand fragment (NP planes of 16 B per lane).  A product chain runs on a main tile m (any fp32 start value)
-// and a correction tile c (zero at the start): mma(a, b, m, c) adds one product block, fold(m, c) leaves the result in m.
-struct SplitBf3 {
-    using Frag = Bf3;
-    static constexpr int NP = 3;
-    static constexpr bool SCALED = false;          // gradients need no range scale
-    static __device__ __forceinline__ Frag split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-        return split3_8(v0, v1, v2, v3, v4, v5, v6, v7);
-    }
-    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& m, f32x16&) { m = mfma_x3(a, b, m); }
-    static __device__ __forceinline__ void fold(f32x16&, const f32x16&) {}
-    static __device__ __forceinline__ u32x4 plane(const Frag& f, int p) { return p == 0 ? f.hi : (p == 1 ? f.mid : f.lo); }
-    static __device__ __forceinline__ void set_plane(Frag& f, int p, u32x4 v) {
-        if (p == 0) f.hi = v;
-        if (p == 1) f.mid = v;
-        if (p == 2) f.lo = v;
-    }
-    // 4 consecutive values -> two words per plane
-    static __device__ __forceinline__ void split4(float x, float y, float z, float w, uint2* planes) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3_pair(x, y, h0, m0, l0);
-        split3_pair(z, w, h1, m1, l1);
-        planes[0] = make_uint2(h0, h1), planes[1] = make_uint2(m0, m1), planes[2] = make_uint2(l0, l1);
-    }
-};
-struct SplitHf2 {
-    using Frag = Hf2;
-    static constexpr int NP = 2;
-    static constexpr bool SCALED = true;
-    static __device__ __forceinline__ Frag split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-        return split2_8(v0, v1, v2, v3, v4, v5, v6, v7);
-    }
-    static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x16& m, f32x16& c) { mfma_h2(a, b, m, c); }
-    static __device__ __forceinline__ void fold(f32x16& m, const f32x16& c) {
-        FFNO_UNROLL
-        for (int i = 0; i < 16; ++i) m[i] = __builtin_fmaf(c[i], kHf2Unscale, m[i]);
-    }
-    static __device__ __forceinline__ u32x4 plane(const Frag& f, int p) { return p == 0 ? f.hi : f.lo; }
-    static __device__ __forceinline__ void set_plane(Frag& f, int p, u32x4 v) {
-        if (p == 0) f.hi = v;
-        if (p == 1) f.lo = v;
-    }
-    static __device__ __forceinline__ void split4(float x, float y, float z, float w, uint2* planes) {
-        unsigned h0, l0, h1, l1;
-        split2_pair(x, y, h0, l0);
-        split2_pair(z, w, h1, l1);
-        planes[0] = make_uint2(h0, h1), planes[1] = make_uint2(l0, l1);
-    }
-};
-
 template <class S>
 __device__ __forceinline__ typename S::Frag load_frag_s(const u32x4* __restrict__ pk, int frag, int lane) {
     typename S::Frag f;

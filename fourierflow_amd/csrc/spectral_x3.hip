@@ -23,6 +23,8 @@
 //   phase 3  wave w: zero-padded inverse DFT of lines 2w, 2w+1 with the accumulate / residual epilogue.
 // Column tile ct of every 32-column MFMA tile holds channels c = 2 j + ct (j = lane & 31), so a lane owns two adjacent
 // channels: 8-byte global loads / stores and LDS accesses throughout.
+#include <type_traits>
+
 #include "ffno_device.h"
 #include "ffno_lines.h"
 #include "ffno.h"
@@ -49,15 +51,18 @@ struct X3Args {
     int R, L, K;
     LineMap lm;
     int fwd_ck, inv_ck, conj_t, accumulate;
+    const float* rscale;  // device-resident power of two (or NULL = 1): the spectrum tile is held scaled by it (gradient passes)
 };
 
 // ---- weight packing --------------------------------------------------------------------------------------------------
 // planes[k][p][i][o] (p = re | im; ffno_fw_pack: forward planes, or the transposed planes for the adjoint) ->
 // fragment (k, st, p, t), lane (j, half), slot e  <-  planes[k][p][i = 16 st + 8 half + e][o = 2 j + t], split in three.
+// format 1 (FFNO_PLANES_FP16X2): two fp16 planes per fragment (SplitHf2), fragments of a mode ordered (p, t, st) instead of
+// (st, p, t) so that the k-steps of one output tile are consecutive (the mix then needs one correction accumulator at a time).
 struct X3PackDesc {
     const float* planes;
     u32x4* dst;
-    int K, pad;
+    int K, format;
 };
 
 __global__ __launch_bounds__(256) void x3_pack_kernel(const X3PackDesc* __restrict__ descs) {
@@ -73,6 +78,13 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const X3PackDesc* __restri
     float v[8];
     FFNO_UNROLL
     for (int e = 0; e < 8; ++e) v[e] = src[(long)e * C];
+    if (d.format == 1) {
+        const Hf2 f = split2_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        const int fo = (k * 4 + pt) * 4 + st;
+        d.dst[(fo * 2 + 0) * 64 + lane] = f.hi;
+        d.dst[(fo * 2 + 1) * 64 + lane] = f.lo;
+        return;
+    }
     const Bf3 f = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     d.dst[(frag * 3 + 0) * 64 + lane] = f.hi;
     d.dst[(frag * 3 + 1) * 64 + lane] = f.mid;
@@ -91,7 +103,7 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 // NL = lines per workgroup: 16 (two per wave; the per-mode mix fills its 32-row tile) or 8 (one per wave: launches with few
 // lines -- batch-1 rollout: 64 lines per axis -- spread over twice as many CUs; the mix then uses rows 0..15 of the tile,
 // rows 16..31 repeat them and are dropped).
-template <int NL>
+template <int NL, bool MIXH2>
 __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
@@ -104,6 +116,10 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     const float* __restrict__ in = A.in;
     const int R = A.R, L = A.L, K = A.K;
     const LineMap lm = A.lm;
+    // range scale of the spectrum tile (fp16x2 mix of a gradient pass): applied where phase 1 writes the tile, removed where
+    // phase 3 stores; the saved spectrum stays unscaled
+    const float rs = A.rscale ? *A.rscale : 1.f;
+    const float rrs = 1.f / rs;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -197,7 +213,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 const int row = drow(r, half);
                 if (row < 2 * K) {
                     const float2 v = make_float2(acc0[r], acc1[r]);
-                    *reinterpret_cast<float2*>(xs + row * RS) = v;
+                    *reinterpret_cast<float2*>(xs + row * RS) = make_float2(v.x * rs, v.y * rs);
                     if (A.spec_save && live)
                         *reinterpret_cast<float2*>(A.spec_save + (((long)(row >> 1) * R + line0 + ln) * 2 + (row & 1)) * C + 2 * j) = v;
                 }
@@ -209,10 +225,22 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     // sets its streaming rate (measured: the batch-1 launch, 16 workgroups, is paced by this stream, not by the MFMAs).  The
     // first RING fragments of the wave's first mode are requested on this side of the barrier.
     constexpr int RING = 8;
-    Bf3 ring[RING];
+    using MixFrag = typename std::conditional<MIXH2, Hf2, Bf3>::type;
+    constexpr int MNP = MIXH2 ? 2 : 3;                       // planes per packed weight fragment
+    auto load_w = [&](const u32x4* __restrict__ wk, int f) {
+        MixFrag w;
+        if constexpr (MIXH2) {
+            w.hi = wk[(f * 2 + 0) * 64 + lane];
+            w.lo = wk[(f * 2 + 1) * 64 + lane];
+        } else {
+            w = x3_load_frag(wk, f, lane);
+        }
+        return w;
+    };
+    MixFrag ring[RING];
     if (A.wpk && wave < K) {
         FFNO_UNROLL
-        for (int f = 0; f < RING; ++f) ring[f] = x3_load_frag(A.wpk + (long)wave * F::MODE_FRAGS * F::FRAG, f, lane);
+        for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
     }
     __syncthreads();
 
@@ -221,29 +249,48 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         // MFMA row j = (line (j mod 2 NL) >> 1, part j & 1); with 8 lines rows 16..31 repeat rows 0..15
         const float* arow = XS + ((j & (2 * NL - 1)) >> 1) * LSF + (j & 1) * RS + 8 * half;
         for (int k = wave; k < K; k += F::NW) {
-            const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * F::FRAG;
+            const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * 64 * MNP;
             if (k != wave) {
                 FFNO_UNROLL
-                for (int f = 0; f < RING; ++f) ring[f] = x3_load_frag(wk, f, lane);
+                for (int f = 0; f < RING; ++f) ring[f] = load_w(wk, f);
             }
-            Bf3 a[4];
+            MixFrag a[4];
             FFNO_UNROLL
             for (int st = 0; st < 4; ++st) {
                 const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st);
                 const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st + 4);
-                a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                if constexpr (MIXH2)
+                    a[st] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                else
+                    a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
             }
             f32x16 p[4];
             FFNO_UNROLL
             for (int pt = 0; pt < 4; ++pt) p[pt] = zero16();
-            FFNO_UNROLL
-            for (int st = 0; st < 4; ++st) {
+            if constexpr (MIXH2) {
+                // fragment order (pt, st): the four k-steps of an output tile run back to back on one correction accumulator
                 FFNO_UNROLL
                 for (int pt = 0; pt < 4; ++pt) {
-                    const int f = st * 4 + pt;                       // fragment f lives in ring slot f mod RING
-                    const Bf3 b = ring[f % RING];
-                    if (f + RING < F::MODE_FRAGS) ring[f % RING] = x3_load_frag(wk, f + RING, lane);
-                    p[pt] = mfma_x3(a[st], b, p[pt]);
+                    f32x16 pc = zero16();
+                    FFNO_UNROLL
+                    for (int st = 0; st < 4; ++st) {
+                        const int f = pt * 4 + st;
+                        const Hf2 b = ring[f % RING];
+                        if (f + RING < F::MODE_FRAGS) ring[f % RING] = load_w(wk, f + RING);
+                        mfma_h2(a[st], b, p[pt], pc);
+                    }
+                    SplitHf2::fold(p[pt], pc);
+                }
+            } else {
+                FFNO_UNROLL
+                for (int st = 0; st < 4; ++st) {
+                    FFNO_UNROLL
+                    for (int pt = 0; pt < 4; ++pt) {
+                        const int f = st * 4 + pt;                       // fragment f lives in ring slot f mod RING
+                        const Bf3 b = ring[f % RING];
+                        if (f + RING < F::MODE_FRAGS) ring[f % RING] = load_w(wk, f + RING);
+                        p[pt] = mfma_x3(a[st], b, p[pt]);
+                    }
                 }
             }
             // D rows 2q, 2q+1 of this lane = (re, im) of line (q & 1) + 4 (q >> 1) + 2 half
@@ -344,7 +391,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                         const int nu = 32 * (rt0 + q) + (r & 3) + 8 * (r >> 2);     // uniform part of the output sample index
                         if (nu + 4 * half < L) {
                             const long uo = (long)nu * es * 4;
-                            float2 o = make_float2(o0[r], o1[r]);
+                            float2 o = make_float2(o0[r] * rrs, o1[r] * rrs);
                             if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
                             if (A.accumulate && A.resid) {      // both at once (rare): the second addend is read in place
                                 const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lo);
@@ -359,15 +406,15 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     }
 }
 
-template <int NL>
+template <int NL, bool MIXH2>
 __global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
-    spectral_x3_body<NL>(a, blockIdx.x, 0);
+    spectral_x3_body<NL, MIXH2>(a, blockIdx.x, 0);
 }
 
 // Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
 // workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
 // weights of ONE branch only; otherwise [0, n0) run a and the rest b.
-template <int NL>
+template <int NL, bool MIXH2>
 __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
     const bool second = interleave ? (w & 1) : (w >= n0);
@@ -390,7 +437,8 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
     s.fwd_ck = a.fwd_ck, s.inv_ck = a.inv_ck, s.conj_t = a.conj_t;      // common to both branches
     s.accumulate = second ? b.accumulate : a.accumulate;
-    spectral_x3_body<NL>(s, idx, (idx & 1) ? skew : 0);
+    s.rscale = a.rscale;                                                // (one gradient pass: one scale)
+    spectral_x3_body<NL, MIXH2>(s, idx, (idx & 1) ? skew : 0);
 }
 
 // ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
@@ -706,8 +754,10 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     const int R = b->axis == 0 ? b->B * b->M : b->B * b->N;
     if (b->K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_x3_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
+    if (b->planes_format != FFNO_PLANES_BF16X3 && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EINVAL;
     a = X3Args{b->in, b->out, b->resid, b->spec_save, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
-               make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate};
+               make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate,
+               b->range_scale};
     return FFNO_OK;
 }
 
@@ -717,10 +767,20 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     const int rc = x3_args(a, br, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
     if (rc) return rc;
     // 8-line tiles when they still fit one round of workgroups (one per CU), else 16-line tiles
-    if (x3_small_tiles(a.R, 0))
-        FFNO_LAUNCH(spectral_x3_kernel<8>, dim3((a.R + 7) / 8), dim3(512), sizeof(float) * 2 * a.L, (hipStream_t)stream, a);
-    else
-        FFNO_LAUNCH(spectral_x3_kernel<16>, dim3((a.R + 15) / 16), dim3(512), sizeof(float) * 2 * a.L, (hipStream_t)stream, a);
+    const bool h2 = br->planes && br->planes_format == FFNO_PLANES_FP16X2;
+    const size_t smem = sizeof(float) * 2 * a.L;
+    hipStream_t st = (hipStream_t)stream;
+    if (x3_small_tiles(a.R, 0)) {
+        if (h2)
+            FFNO_LAUNCH((spectral_x3_kernel<8, true>), dim3((a.R + 7) / 8), dim3(512), smem, st, a);
+        else
+            FFNO_LAUNCH((spectral_x3_kernel<8, false>), dim3((a.R + 7) / 8), dim3(512), smem, st, a);
+    } else {
+        if (h2)
+            FFNO_LAUNCH((spectral_x3_kernel<16, true>), dim3((a.R + 15) / 16), dim3(512), smem, st, a);
+        else
+            FFNO_LAUNCH((spectral_x3_kernel<16, false>), dim3((a.R + 15) / 16), dim3(512), smem, st, a);
+    }
     return x3_status();
 }
 
@@ -734,15 +794,26 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     rc = x3_args(b, bb, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
     if (rc) return rc;
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
+    // both branches of a pair carry the same kind of planes (or none) and the same range scale
+    if ((ba->planes == nullptr) != (bb->planes == nullptr) || ba->planes_format != bb->planes_format ||
+        ba->range_scale != bb->range_scale)
+        return FFNO_EINVAL;
+    const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
+    hipStream_t st = (hipStream_t)stream;
     // interleave: bit 0 = workgroup -> branch map; bits 8.. = start skew of every other workgroup in units of 256 cycles
+    const int skew = (interleave >> 8) * 256;
     if (x3_small_tiles(a.R, b.R)) {
-        const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8;
-        FFNO_LAUNCH(spectral_x3_pair_kernel<8>, dim3(n0 + n1), dim3(512), smem, (hipStream_t)stream, a, b, n0,
-                    ((interleave & 1) && n0 == n1) ? 1 : 0, (interleave >> 8) * 256);
+        const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = ((interleave & 1) && n0 == n1) ? 1 : 0;
+        if (h2)
+            FFNO_LAUNCH((spectral_x3_pair_kernel<8, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+        else
+            FFNO_LAUNCH((spectral_x3_pair_kernel<8, false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
     } else {
-        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16;
-        FFNO_LAUNCH(spectral_x3_pair_kernel<16>, dim3(n0 + n1), dim3(512), smem, (hipStream_t)stream, a, b, n0,
-                    ((interleave & 1) && n0 == n1) ? 1 : 0, (interleave >> 8) * 256);
+        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = ((interleave & 1) && n0 == n1) ? 1 : 0;
+        if (h2)
+            FFNO_LAUNCH((spectral_x3_pair_kernel<16, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+        else
+            FFNO_LAUNCH((spectral_x3_pair_kernel<16, false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
     }
     return x3_status();
 }
@@ -756,6 +827,7 @@ static int x3_stage_args(X3Stage& s, const ffno_fused_branch* b, int C) {
     const int R = b->axis == 0 ? b->B * b->M : b->B * b->N;
     if (b->K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_x3_staged_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
+    if (b->planes && b->planes_format != FFNO_PLANES_BF16X3) return FFNO_EUNSUPPORTED;     // the stage kernels read bf16x3 packs
     s = X3Stage{b->in, b->out, b->resid, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
                 make_linemap(b->axis, b->B, b->M, b->N, C), b->accumulate};
     return FFNO_OK;

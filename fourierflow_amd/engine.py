@@ -192,6 +192,10 @@ class FFNOEngine:
         # picks 8 while the launch still fits one round of workgroups -- packed pre-split weights) for the axes the library
         # takes (C = 64, K <= 16); 17..32 modes go through the split-bf16 stage kernels
         self.use_x3 = True
+        # the per-mode channel mix of the fused x3 kernel on "fp16x2" (three fp16 MFMAs per product block, weight packs two thirds
+        # the size; gradient passes hold the spectrum tile range-scaled like the feed-forward) or "bf16x3"
+        self.x3_mix_split = os.environ.get("FFNO_X3_MIX_SPLIT", "fp16x2")
+        self._x3_fmt = None
         self.x3_min_lines = 1
         self.x3_interleave = 1       # paired launch: even workgroups branch a, odd ones branch b (one branch's weights per XCD)
         # one C call per layer and direction (ffno_layer_fwd / ffno_layer_bwd: paired branches + feed-forward) instead of two /
@@ -244,19 +248,33 @@ class FFNOEngine:
             self._k("spectral_staged_pair" + ("" if fwd else "(adj)"), fn, ctypes.byref(ba),
                     ctypes.byref(bb), _p(ws.SY), _p(ws.SY2), self.C, ck_f, ck_i, conj, st)
             return
+        fmt, rsc = self._x3_branch_extra(x3 and planes0 is not None, fwd)
         ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)),
-                               v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
+                               v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0, fmt, 0, rsc)
         bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)),
-                               v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0)
+                               v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0, fmt, 0, rsc)
         if x3:       # planes0 / planes1 are the packed split-bf16 sets
             self._k(name, lib.ffno_spectral_x3_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj,
                     int(self.x3_interleave), st)
             return
         self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
 
-    def _branch(self, v, src, dst, resid, save, planes, acc):
+    def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True):
+        fmt, rsc = self._x3_branch_extra(x3 and planes is not None, fwd)
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc)
+                                 v.a01, acc, fmt, 0, rsc)
+
+    def _x3_h2(self) -> bool:
+        if self.x3_mix_split not in ("fp16x2", "bf16x3"):
+            raise ValueError("x3_mix_split must be 'fp16x2' or 'bf16x3', got %r" % (self.x3_mix_split,))
+        return self.x3_mix_split == "fp16x2"
+
+    def _x3_branch_extra(self, packed_fused: bool, fwd: bool):
+        """(planes_format, range_scale) of a fused x3 branch: fp16x2 packs when the mix runs on them; gradient passes then keep
+        the spectrum tile scaled by the pass's power of two."""
+        if not (packed_fused and self._x3_h2()):
+            return 0, None
+        return 1, (None if fwd else _p(self._gscale))
 
     def _ffx(self) -> bool:
         return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
@@ -563,10 +581,11 @@ class FFNOEngine:
                 self._fwpack_sig, self._fwpack_n = sig, len(descs)
             self._k("fw_pack", lib.ffno_fw_pack_batched, _p(self._fwpack_dev), self._fwpack_n, self.C, max(self.Ks), st)
             if self.use_x3 and any(x is not None for row in self.xplanes for x in row):
-                sig = tuple((self.planes[i][w][d].data_ptr(), xp[d].data_ptr()) for i, row in enumerate(self.xplanes)
+                fmt = self._x3_fmt or [0] * len(self.Ks)
+                sig = tuple((self.planes[i][w][d].data_ptr(), xp[d].data_ptr(), fmt[w]) for i, row in enumerate(self.xplanes)
                             for w, xp in enumerate(row) if xp is not None for d in range(2))
                 if sig != self._x3pack_sig:
-                    descs = [_capi.X3PackDesc(self.planes[i][w][d].data_ptr(), xp[d].data_ptr(), self.Ks[w], 0)
+                    descs = [_capi.X3PackDesc(self.planes[i][w][d].data_ptr(), xp[d].data_ptr(), self.Ks[w], fmt[w])
                              for i, row in enumerate(self.xplanes) for w, xp in enumerate(row) if xp is not None
                              for d in range(2)]
                     arr = (_capi.X3PackDesc * len(descs))(*descs)
@@ -675,7 +694,9 @@ class FFNOEngine:
                     _p(planes), _p(self._twiddle(2 * v.L)), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, conj, accumulate, st)
             return
         if fused and x3:     # ``planes`` is the packed split-bf16 set
-            br = _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(tw), v.Bv, v.Mv, v.Nv, v.K, v.a01, accumulate)
+            fmt, rsc = self._x3_branch_extra(planes is not None, fwd)
+            br = _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(tw), v.Bv, v.Mv, v.Nv, v.K, v.a01, accumulate,
+                                   fmt, 0, rsc)
             self._k(name, lib.ffno_spectral_x3, ctypes.byref(br), C, ck_f, ck_i, conj, st)
             return
         if fused:
@@ -712,9 +733,12 @@ class FFNOEngine:
                                      f"(the reference raises an einsum size error)")
         st = _lib.current_stream(self.device)
         P = ws.P
-        self._prepare_weights(st)
         fused = self._can_fuse(ws.views)
         x3 = self._use_x3(ws.views, fused)
+        # format of the packed x3 weight sets per axis: fp16x2 where the FUSED x3 kernel mixes with them (the stage kernels of
+        # the 17..32-mode axes read bf16x3 packs)
+        self._x3_fmt = [int(self._x3_h2() and fused[w] and x3[w]) for w in range(len(ws.views))]
+        self._prepare_weights(st)
         full = self.mode == "full"
         singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)
         conc = pair is not None
@@ -755,8 +779,9 @@ class FFNOEngine:
                     if layer_calls:
                         l0, l1, b0, b1 = self._ff_weights(l)
                         d = _capi.LayerFwdDesc(
-                            self._branch(ws.views[a], ws.X, s_l, None, keep[0], self._planes_for(si, a, 0, x3pair), int(nwrit > 0)),
-                            self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0),
+                            self._branch(ws.views[a], ws.X, s_l, None, keep[0], self._planes_for(si, a, 0, x3pair), int(nwrit > 0),
+                                         x3pair, True),
+                            self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0, x3pair, True),
                             int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
                             _p(s_l) if save_for_backward else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
                             _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()))
@@ -810,7 +835,7 @@ class FFNOEngine:
         C, H, L = self.C, self.H, self.L
         ws = self._workspace(B, S, True)
         st = _lib.current_stream(self.device)
-        if self._ffx() and self._h2():
+        if (self._ffx() and self._h2()) or (self.use_x3 and self._x3_h2()):
             # range scale of the fp16x2 backward kernels: one power of two for the whole pass, taken on the device from the
             # loss gradient (max |gy| -> [32, 64]; the head and the layers change the magnitude by far less than the 2^10 left)
             if getattr(self, "_gscale", None) is None or self._gscale.device != gy.device:
@@ -896,9 +921,9 @@ class FFNOEngine:
                 part = ws.ffparts[len(ws.red_jobs)]
                 d = _capi.LayerBwdDesc(
                     self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
-                                 self._planes_for(si, a, 1, x3pair), 0),
+                                 self._planes_for(si, a, 1, x3pair), 0, x3pair, False),
                     self._branch(ws.views[b], ws.DS, ws.G1, None, ws.SDall[b][l] if full else None,
-                                 self._planes_for(si, b, 1, x3pair), 0),
+                                 self._planes_for(si, b, 1, x3pair), 0, x3pair, False),
                     int(x3pair), int(self.x3_interleave), _p(g_in), _p(ws.G1) if have_g1 else None, _p(g_in), _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
                     _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, _p(self._gscale) if self._h2() else None)

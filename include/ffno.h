@@ -147,7 +147,14 @@ typedef struct ffno_fused_branch {
     const float* tw;        /* twiddle table of this branch's axis length */
     int32_t B, M, N;        /* view of this branch */
     int32_t K, axis, accumulate;
+    /* ffno_spectral_x3* only (the fp32 kernels ignore them; zero = the previous behaviour): */
+    int32_t planes_format;  /* FFNO_PLANES_BF16X3 / FFNO_PLANES_FP16X2: how ffno_spectral_x3_pack wrote `planes` */
+    int32_t pad_;
+    const float* range_scale; /* optional DEVICE pointer to a power of two: the spectrum tile is held multiplied by it and the
+                                 outputs divided again (gradient passes with fp16x2 planes: ffno_ffh_grad_scale) */
 } ffno_fused_branch;
+#define FFNO_PLANES_BF16X3 0
+#define FFNO_PLANES_FP16X2 1
 int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                              int apply_ck_inv, int conj_transpose, void* stream);
 /* ---------------------------------------------------------------------------------------------
@@ -165,7 +172,9 @@ typedef struct ffno_x3pack_desc {
     const float* planes; /* [K][2][C][C] */
     void* dst;           /* ffno_spectral_x3_pack_bytes(C, K) bytes, 16-B aligned */
     int32_t K;
-    int32_t pad_;
+    int32_t format;      /* FFNO_PLANES_BF16X3, or FFNO_PLANES_FP16X2: the per-mode channel mix of the fused kernel (K <= 16) then
+                            runs on three fp16 MFMAs per product block instead of six bf16 ones (ffno_ffh_* has the number
+                            format; the DFT phases keep the bf16 split).  The staged kernels take BF16X3 packs only. */
 } ffno_x3pack_desc;
 int ffno_spectral_x3_supported(int C, int K, int L);
 /* Tile choice of the fused x3 kernels: 8-line workgroups while ceil(Ra/8) + ceil(Rb/8) <= `workgroups` (default 256 = one

@@ -356,8 +356,9 @@ def _branch_reference(x, w, K, axis, direction):
     return ref.numpy(), torch.stack([fs.real, fs.imag], dim=2).numpy()
 
 
-def _x3_pack(be, w, K, C=64):
-    """(forward pack, adjoint pack) of a [C, C, K, 2] Fourier weight through ffno_fw_pack + ffno_spectral_x3_pack."""
+def _x3_pack(be, w, K, C=64, fmt=0):
+    """(forward pack, adjoint pack) of a [C, C, K, 2] Fourier weight through ffno_fw_pack + ffno_spectral_x3_pack
+    (fmt 1: fp16x2 planes for the mix of the fused kernel)."""
     from fourierflow_amd._capi import X3PackDesc
     lib, p = be.lib, be.ptr
     wp, wpt = be.zeros((K, 2, C, C)), be.zeros((K, 2, C, C))
@@ -365,7 +366,7 @@ def _x3_pack(be, w, K, C=64):
     nbytes = int(lib.ffno_spectral_x3_pack_bytes(C, K))
     assert nbytes == K * 16 * 3 * 64 * 16
     pk = [be.zeros((nbytes // 4,), np.uint32) for _ in range(2)]
-    descs = (X3PackDesc * 2)(X3PackDesc(p(wp), p(pk[0]), K, 0), X3PackDesc(p(wpt), p(pk[1]), K, 0))
+    descs = (X3PackDesc * 2)(X3PackDesc(p(wp), p(pk[0]), K, fmt), X3PackDesc(p(wpt), p(pk[1]), K, fmt))
     dtab = be.put(np.frombuffer(bytes(descs), dtype=np.uint8).copy())
     assert lib.ffno_spectral_x3_pack(p(dtab), 2, C, K, None) == 0
     return pk[0], pk[1], (wp, wpt, dtab)
@@ -421,6 +422,48 @@ def test_spectral_x3_branch(be, x3_tile, B, M, N, K, axis, direction):
     br = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1)
     assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
     assert rel_l2(be.get(out), 2 * ref + resid) < TOL
+
+
+@pytest.mark.parametrize("B,M,N,K,axis", [(1, 8, 12, 3, 0), (1, 20, 64, 16, 0), (2, 16, 32, 8, 1), (32, 64, 64, 16, 1)])
+@pytest.mark.parametrize("direction", ["fwd", "adj"])
+def test_spectral_x3_branch_fp16x2_mix(be, x3_tile, B, M, N, K, axis, direction):
+    """The same branch with the per-mode channel mix on fp16x2 packs (FFNO_PLANES_FP16X2): fp32 tolerance for O(1) data, and
+    for a tiny gradient (1e-6) in the adjoint pass once the device-side range scale is attached -- the saved spectrum and the
+    outputs come back unscaled."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and (B > 2 or (x3_tile == 8 and K == 8)):
+        pytest.skip("emulator time budget (the GPU run covers all)")
+    C = 64
+    L = N if axis == 0 else M
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + 10 * M + 100 * N + K + axis)
+    mag = 1.0 if direction == "fwd" else 1e-6
+    x = (rs.standard_normal((B, M, N, C)) * mag).astype(np.float32)
+    w = (rs.standard_normal((C, C, K, 2)) * 0.02).astype(np.float32)         # the magnitude of xavier-initialised weights
+    R = B * M if axis == 0 else B * N
+    ref, ref_spec_ = _branch_reference(x, w, K, axis, direction)
+    dx, tw = be.put(x), be.twiddle(L)
+    pk_f, pk_a, keep = _x3_pack(be, w, K, fmt=1)
+    out, spec = be.empty(x.shape), be.empty((K, R, 2, C))
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    scale = None
+    if direction == "adj":
+        scale = be.zeros(1)
+        assert lib.ffno_ffh_grad_scale(p(dx), x.size, p(scale), None) == 0
+    br = FusedBranch(p(dx), p(out), None, p(spec), p(pk_a if direction == "adj" else pk_f), p(tw), B, M, N, K, axis, 0,
+                     1, 0, p(scale) if scale is not None else None)
+    assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
+    assert rel_l2(be.get(out), ref) < TOL
+    assert rel_l2(be.get(spec), ref_spec_) < TOL
+    resid = (rs.standard_normal(x.shape) * mag).astype(np.float32)
+    dres = be.put(resid)
+    br = FusedBranch(p(dx), p(out), p(dres), None, p(pk_a if direction == "adj" else pk_f), p(tw), B, M, N, K, axis, 1,
+                     1, 0, p(scale) if scale is not None else None)
+    assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
+    assert rel_l2(be.get(out), 2 * ref + resid) < TOL
+    # the staged kernels refuse fp16x2 packs; a pair must agree on the format
+    bad = FusedBranch(p(dx), p(out), None, p(spec), p(pk_f), p(tw), B, M, N, K, axis, 0, 2, 0, None)
+    assert lib.ffno_spectral_x3(ctypes.byref(bad), C, 0, 1, 0, None) == -1
 
 
 @pytest.mark.parametrize("B,M,N,K", [(2, 10, 12, 5), (1, 16, 16, 8), (1, 40, 34, 16)])
