@@ -27,11 +27,16 @@ TAGS = ["c64_2l_shared", "c64_3l_unshared", "c64_sharefork", "c64_lowpass", "c64
 GPU_ONLY = {"c64_4l_markov", "c64_24l_markov", "c64_3l_unshared"}  # too slow for the CPU emulator
 
 
-@pytest.mark.parametrize("fused", ["x3", True, False, "x3staged"], ids=["x3", "fused", "staged", "x3staged"])
+@pytest.mark.parametrize("fused", ["x3", True, False, "x3staged", "x3bf16"], ids=["x3", "fused", "staged", "x3staged", "x3bf16"])
 @pytest.mark.parametrize("tag", TAGS)
 def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     if host_device == "cpu" and tag in GPU_ONLY:
         pytest.skip("emulator too slow for this size; runs with -m gpu")
+    bf16_only = fused == "x3bf16"       # the pre-fp16x2 arithmetic: bf16x3 feed-forward and bf16x3 channel mix (still shipped)
+    if bf16_only:
+        if tag not in ("c64_2l_shared", "c64_sharefork_fork", "c64_4l_markov"):
+            pytest.skip("bf16x3-only variant: three representative configs")
+        fused = "x3"
     x3 = fused in ("x3", "x3staged")    # the split-bf16 branch kernels (forced on for the small golden grids) / the fp32-MFMA ones
     fused = fused in ("x3", True)         # "x3staged": the three split-bf16 STAGE kernels (the 17..32-mode path)
     if x3 and (tag in ("c32_nown", "c64_nofourier")):
@@ -47,6 +52,8 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
     blk.engine().use_fused = fused   # fused A->B->C branch kernel vs the three stage kernels
     blk.engine().use_x3 = x3
     blk.engine().x3_min_lines = 1
+    if bf16_only:
+        blk.engine().ff_split = blk.engine().x3_mix_split = "bf16x3"
     if not fused and host_device == "cpu" and tag not in ("c64_2l_shared", "c64_lowpass"):
         pytest.skip("staged path on the emulator: two representative configs are enough")
     x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
