@@ -99,12 +99,12 @@ PY
       # HBM traffic counters, one PMC pass each (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2), kernel-trace only
       for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf gpurun_out/pmc_$c
-        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/gpurun_out/pmc_$c" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 > "$OLDPWD/gpurun_out/pmc_$c.log" 2>&1)
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/gpurun_out/pmc_$c" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 --no-secondary > "$OLDPWD/gpurun_out/pmc_$c.log" 2>&1)
         echo "[session] pmc $c rc=$?"
       done
       f=$(find gpurun_out/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find gpurun_out/pmc_WRITE_SIZE -name "*.db" | head -1)
       python tools/rocpd_pmc.py "$f" > gpurun_out/pmc_FETCH_SIZE.md; python tools/rocpd_pmc.py "$w" > gpurun_out/pmc_WRITE_SIZE.md
-      (cd tools && python make_pmc_traffic.py "../$f" "../$w") > gpurun_out/pmc_traffic.json; head -c 600 gpurun_out/pmc_traffic.json
+      (cd tools && python make_pmc_traffic.py "../$f" "../$w" "7e95f5975582") > gpurun_out/pmc_traffic.json; head -c 600 gpurun_out/pmc_traffic.json
       find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.db" -size +20M -delete ;;
   esac
 done

@@ -8,11 +8,11 @@ import sys
 
 from rocpd_pmc import per_kernel
 
-NAMES = [("spectral_x3_pair_kernel<16", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false>", "ff_fwd"),
-         ("ffx_chain_rs_kernel<64, 256, true>", "ff_bwd_data"), ("ffx_wgrad_rs_kernel", "ff_bwd_weights_partial"),
+NAMES = [("spectral_x3_pair_kernel<16", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false", "ff_fwd"),
+         ("ffx_chain_rs_kernel<64, 256, true", "ff_bwd_data"), ("ffx_wgrad_rs_kernel", "ff_bwd_weights_partial"),
          ("fw_grad_x3_kernel", "fw_grad_partial"),
-         ("spectral_fused_pair_kernel", "spectral_fused"), ("spectral_fused_kernel", "spectral_fused"), ("ffx_chain_kernel<64, 256, false>", "ff_fwd"),
-         ("ffx_chain_kernel<64, 256, true>", "ff_bwd_data"), ("ffx_wgrad_kernel", "ff_bwd_weights_partial"),
+         ("spectral_fused_pair_kernel", "spectral_fused"), ("spectral_fused_kernel", "spectral_fused"), ("ffx_chain_kernel<64, 256, false", "ff_fwd"),
+         ("ffx_chain_kernel<64, 256, true", "ff_bwd_data"), ("ffx_wgrad_kernel", "ff_bwd_weights_partial"),
          ("ffx_wgrad_reduce_kernel", "ff_bwd_weights_reduce"), ("ff_chain_kernel<64, 256, 8, false>", "ff_fwd"),
          ("ff_chain_kernel<64, 256, 8, true>", "ff_bwd_data"), ("ff_bwd_weights_partial_kernel", "ff_bwd_weights_partial"),
          ("fw_grad_partial_kernel", "fw_grad_partial"), ("fw_grad_reduce_kernel", "fw_grad_reduce"),
