@@ -495,6 +495,27 @@ def main():
                                  f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE), "
                                  f"taken at the git head named in traffic_source")
         steps_per_s = world * args.steps / elapsed
+        # the same step on the all-bf16x3 arithmetic (three bf16 planes, six MFMAs per product block everywhere: the round-1 /
+        # early round-2 numerics), timed the same way right here, so that the line carries both
+        variants = None
+        if world == 1 and headline and not args.no_x3:
+            eng = trainer.engine
+            keep = (eng.ff_split, eng.x3_mix_split)
+            try:
+                eng.ff_split = eng.x3_mix_split = "bf16x3"
+                for _ in range(3):
+                    trainer.train_step(x, y)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    trainer.train_step(x, y)
+                sync()
+                alt = args.steps / (time.perf_counter() - t1)
+                variants = {"ff %s + mix %s (timed region, `value`)" % keep: round(steps_per_s, 3),
+                            "ff bf16x3 + mix bf16x3": round(alt, 3)}
+                log(f"all-bf16x3 arithmetic: {alt:.2f} steps/s")
+            finally:
+                eng.ff_split, eng.x3_mix_split = keep
         cpu = cpu19 = None
         if world == 1 and args.cpu_steps > 0 and not args.plus:
             cpu = cpu_baseline(B, G, kw, warm=2, timed=args.cpu_steps)
@@ -547,7 +568,8 @@ def main():
             "samples_per_s": round(steps_per_s * B, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5), "git_head": git_head(),
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "secondary": secondary, "distributed": dist_info,
+            "roofline": roofline, "kernels": kernels, "arithmetic_variants_steps_per_s": variants, "cpu_baseline": cpu,
+            "secondary": secondary, "distributed": dist_info,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)

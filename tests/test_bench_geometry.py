@@ -23,7 +23,7 @@ from backend_util import rel_l2
 MARKOV24 = dict(modes=16, width=64, input_dim=3, n_layers=24, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
 
 
-def _run_hip(kw, seed, B, M, N):
+def _run_hip(kw, seed, B, M, N, split=None):
     from fourierflow_amd.modules import FNOFactorized2DBlock
     from fourierflow_amd.trainer import FFNOTrainer
     blk = FNOFactorized2DBlock(**kw)
@@ -33,6 +33,8 @@ def _run_hip(kw, seed, B, M, N):
     x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
     x, t = torch.from_numpy(x_np).cuda(), torch.from_numpy(t_np).cuda()
     eng = tr.engine
+    if split is not None:
+        eng.ff_split = eng.x3_mix_split = split
     pred = eng.forward(blk.prepare_input(x), True)
     loss, gy = tr.loss_and_grad(pred, t)
     loss = float(loss.item())
@@ -44,15 +46,17 @@ def _run_hip(kw, seed, B, M, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [32, 19])
-def test_markov24_bench_geometry_forward_backward_vs_oracle(B):
+@pytest.mark.parametrize("B,split", [(32, None), (19, None), (19, "bf16x3")], ids=["B32", "B19", "B19-bf16x3"])
+def test_markov24_bench_geometry_forward_backward_vs_oracle(B, split):
+    """split None = the engine's defaults (fp16x2 feed-forward and channel mix: what bench.py times); "bf16x3" = the all-bf16x3
+    arithmetic that stays shipped beside it."""
     kw, seed, M, N = MARKOV24, 2024, 64, 64
-    pred, loss, grads, masks, io, _ = _run_hip(kw, seed, B, M, N)
+    pred, loss, grads, masks, io, _ = _run_hip(kw, seed, B, M, N, split)
     # the paired launch really ran (2 x 256 workgroups at B = 32): the test must not pass on a fallback schedule
     ref_out, ref_loss, ref_grads = ou.oracle_block_run(kw, seed, B, M, N, relu_masks=masks, io=io)
     e_fwd = rel_l2(pred, ref_out["forecast"].detach().numpy())
     e_loss = abs(loss - ref_loss.item())
-    print(f"[bench-geometry B={B}] forward rel-L2 {e_fwd:.2e}, |loss diff| {e_loss:.2e}")
+    print(f"[bench-geometry B={B} {split or 'fp16x2 defaults'}] forward rel-L2 {e_fwd:.2e}, |loss diff| {e_loss:.2e}")
     assert e_fwd < 1e-5
     assert e_loss < 1e-5
     first = {torch.float32: ref_grads}     # the fp32 run above is re-used
