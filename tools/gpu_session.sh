@@ -91,7 +91,7 @@ PY
       echo "[session] traincli rc=$?"; tail -n 3 gpurun_out/train_cli.log ;;
     sq)
       rm -rf gpurun_out/pmc_SQ
-      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_SQ" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 > "$OLDPWD/gpurun_out/pmc_SQ.log" 2>&1)
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_SQ" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 --no-secondary > "$OLDPWD/gpurun_out/pmc_SQ.log" 2>&1)
       echo "[session] pmc SQ rc=$?"; tail -n 2 gpurun_out/pmc_SQ.log | cut -c1-200
       db=$(find gpurun_out/pmc_SQ -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_SQ.md 2>&1; head -n 12 gpurun_out/pmc_SQ.md | cut -c1-230
       find gpurun_out/pmc_SQ -name "*.db" -size +20M -delete ;;
