@@ -324,7 +324,7 @@ def main():
     ap.add_argument("--ff-split", choices=["fp16x2", "bf16x3"], default=None,
                     help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
-    ap.add_argument("--x3-interleave", type=int, default=1, help="bit 0: workgroup->branch interleave; bits 8..: start skew / 256 cycles")
+    ap.add_argument("--x3-interleave", type=int, default=3, help="bit 0: even/odd workgroup->branch map; bit 1: image-local (XCD-aware) map where the shapes allow; bits 8..: start skew / 256 cycles")
     ap.add_argument("--ffx-schedule", type=int, default=1, help="bit mask: 1 forward, 2 backward-data, 4 weight gradients on the role-split schedule (default 1)")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")

@@ -417,8 +417,22 @@ __global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
 template <int NL, bool MIXH2>
 __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
-    const bool second = interleave ? (w & 1) : (w >= n0);
-    const int idx = interleave ? (w >> 1) : (second ? w - n0 : w);
+    bool second;
+    int idx;
+    if ((interleave & 3) == 2) {
+        // image-local map (square images, batch a multiple of 8, whole tiles per image; T = interleave >> 8 tiles per image and
+        // branch): workgroup w lands on XCD w % 8, so the 2 T workgroups that read one image -- T row tiles of one branch, T
+        // column tiles of the other -- are given the same XCD and consecutive slots: the image crosses HBM once and the second
+        // branch finds it in that XCD's L2.
+        const int T = interleave >> 8, G = 2 * T, per_xcd = n0 / (8 * T);
+        const int xcd = w & 7, slot = w >> 3;
+        const int image = xcd * per_xcd + slot / G, t = slot % G;
+        second = t >= T;
+        idx = image * T + (second ? t - T : t);
+    } else {
+        second = interleave ? (w & 1) : (w >= n0);
+        idx = interleave ? (w >> 1) : (second ? w - n0 : w);
+    }
     // skew > 0: every other workgroup of each branch starts `skew` cycles late, so that its HBM-bound phases (line loads,
     // output stores) fall on the L2 / matrix phase of its neighbours instead of all 256 CUs hitting HBM in lockstep
     X3Args s;
@@ -800,16 +814,23 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         return FFNO_EINVAL;
     const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
     hipStream_t st = (hipStream_t)stream;
-    // interleave: bit 0 = workgroup -> branch map; bits 8.. = start skew of every other workgroup in units of 256 cycles
+    // interleave: bit 0 = even / odd workgroup -> branch map; bit 1 = image-local map where the shapes allow it (else bit 0
+    // decides); bits 8.. = start skew of every other workgroup in units of 256 cycles
     const int skew = (interleave >> 8) * 256;
+    auto wg_map = [&](int NL, int n0, int n1) {
+        if (n0 != n1) return 0;
+        const bool square = ba->B == bb->B && ba->M == bb->M && ba->N == bb->N && ba->M == ba->N && ba->axis != bb->axis;
+        if ((interleave & 2) && square && ba->B % 8 == 0 && ba->M % NL == 0) return 2 | ((ba->M / NL) << 8);
+        return (interleave & 1) ? 1 : 0;
+    };
     if (x3_small_tiles(a.R, b.R)) {
-        const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = ((interleave & 1) && n0 == n1) ? 1 : 0;
+        const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
         if (h2)
             FFNO_LAUNCH((spectral_x3_pair_kernel<8, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         else
             FFNO_LAUNCH((spectral_x3_pair_kernel<8, false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
     } else {
-        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = ((interleave & 1) && n0 == n1) ? 1 : 0;
+        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = wg_map(16, n0, n1);
         if (h2)
             FFNO_LAUNCH((spectral_x3_pair_kernel<16, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         else

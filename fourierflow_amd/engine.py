@@ -197,7 +197,9 @@ class FFNOEngine:
         self.x3_mix_split = os.environ.get("FFNO_X3_MIX_SPLIT", "fp16x2")
         self._x3_fmt = None
         self.x3_min_lines = 1
-        self.x3_interleave = 1       # paired launch: even workgroups branch a, odd ones branch b (one branch's weights per XCD)
+        # paired launch, workgroup -> (branch, tile) map: bit 1 = image-local where the shapes allow it (the workgroups that read
+        # one image share an XCD: the image crosses HBM once), else bit 0 = even workgroups branch a, odd ones branch b
+        self.x3_interleave = 3
         # one C call per layer and direction (ffno_layer_fwd / ffno_layer_bwd: paired branches + feed-forward) instead of two /
         # three; per-kernel timing (a timer attached) needs the individual calls
         self.use_layer_calls = True

@@ -166,7 +166,9 @@ int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch
  *   ffno_spectral_x3_pack_bytes(C, K) bytes per packed set.  descs is a DEVICE array, one launch for all sets.
  * Supported by the fused kernel: C = 64, K <= 16, L <= 2048 (ffno_spectral_x3_supported); packs exist for K <= 32 (the
  * staged variant below); the fp32-MFMA kernels above cover the rest.
- * interleave != 0 (pair, equal workgroup counts): even workgroups run branch a, odd ones branch b.
+ * interleave (pair, equal workgroup counts): bit 0 = even workgroups run branch a, odd ones branch b; bit 1 = image-local map
+ * where the shapes allow it (both branches are the two axes of the same square images, batch a multiple of 8, whole tiles per
+ * image): the workgroups that read one image run on one XCD, so the second branch finds the image in that XCD's L2.
  * --------------------------------------------------------------------------------------------- */
 typedef struct ffno_x3pack_desc {
     const float* planes; /* [K][2][C][C] */

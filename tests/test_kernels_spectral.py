@@ -466,11 +466,16 @@ def test_spectral_x3_branch_fp16x2_mix(be, x3_tile, B, M, N, K, axis, direction)
     assert lib.ffno_spectral_x3(ctypes.byref(bad), C, 0, 1, 0, None) == -1
 
 
-@pytest.mark.parametrize("B,M,N,K", [(2, 10, 12, 5), (1, 16, 16, 8), (1, 40, 34, 16)])
+@pytest.mark.parametrize("B,M,N,K,interleave", [(2, 10, 12, 5, 0), (2, 10, 12, 5, 1), (1, 16, 16, 8, 0), (1, 16, 16, 8, 1),
+                                                (1, 40, 34, 16, 0), (1, 40, 34, 16, 1), (8, 16, 16, 8, 3), (16, 32, 32, 4, 2),
+                                                (8, 24, 24, 4, 3)])
 @pytest.mark.parametrize("direction", ["fwd", "adj"])
-@pytest.mark.parametrize("interleave", [0, 1])
 def test_spectral_x3_pair_equals_single_branches(be, x3_tile, B, M, N, K, direction, interleave):
-    """Both axes of a layer in one launch (either workgroup -> branch map): bit-identical to the single-branch launches."""
+    """Both axes of a layer in one launch (any workgroup -> branch map: contiguous, even / odd, image-local where the shapes allow
+    it -- batch a multiple of 8, square images of whole tiles; (8, 24, 24) falls back with 16-line tiles): bit-identical to the
+    single-branch launches."""
+    if be.kind == "emu" and (B >= 16 or (B == 8 and (direction == "adj" or M == 24))):
+        pytest.skip("emulator time budget (the GPU run covers it)")
     from fourierflow_amd._capi import FusedBranch
     C = 64
     lib, p = be.lib, be.ptr
