@@ -8,7 +8,11 @@ import sys
 
 from rocpd_pmc import per_kernel
 
-NAMES = [("spectral_x3_pair_kernel<16", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false", "ff_fwd"),
+# first match wins, so the instantiations of the default arithmetic (fp16x2) come before the generic patterns: bench.py also runs
+# the all-bf16x3 variant, whose kernels are in the same trace
+NAMES = [("spectral_x3_pair_kernel<16, true", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false, ffno::SplitHf2", "ff_fwd"),
+         ("ffx_chain_kernel<64, 256, true, ffno::SplitHf2", "ff_bwd_data"), ("ffx_wgrad_kernel<64, 256, ffno::SplitHf2", "ff_bwd_weights_partial"),
+         ("spectral_x3_pair_kernel<16", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false", "ff_fwd"),
          ("ffx_chain_rs_kernel<64, 256, true", "ff_bwd_data"), ("ffx_wgrad_rs_kernel", "ff_bwd_weights_partial"),
          ("fw_grad_x3_kernel", "fw_grad_partial"),
          ("spectral_fused_pair_kernel", "spectral_fused"), ("spectral_fused_kernel", "spectral_fused"), ("ffx_chain_kernel<64, 256, false", "ff_fwd"),
@@ -29,7 +33,8 @@ def short(kernel):
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 GIT_HEAD = sys.argv[3] if len(sys.argv) > 3 else None
 out = {}
-for k, (_, n, avg, _, _) in fetch.items():
+order = sorted(fetch.items(), key=lambda kv: next((i for i, (pat, _) in enumerate(NAMES) if pat in kv[0]), len(NAMES)))
+for k, (_, n, avg, _, _) in order:
     name = short(k)
     if name is None or k not in write or name in out:
         continue
