@@ -4,7 +4,7 @@
 // compiler (against tests/emu/ffno_platform.h) and executed lane-by-lane on the CPU so that index math, MFMA fragment
 // layouts, LDS addressing and barrier placement can be checked against the oracle without a GPU.
 //
-// Execution model: workgroups run one after another; every thread of a workgroup is a ucontext
+// Execution model: workgroups run one after another; every thread of a workgroup is a fibre (own stack, hand-written context switch)
 // fiber; __syncthreads() and the wave-level exchange ops (MFMA, shuffles) are rendezvous points
 // at which a fiber yields to a round-robin scheduler.  Fibers are resumed in a rotating order so
 // missing barriers have a chance to show up as wrong results.
@@ -15,7 +15,6 @@
 //   v_mfma_f32_16x16x4_f32 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D col=l&15, row=4*(l>>4)+r
 // A GPU self-test (tests/test_gpu_mfma_layout.py) checks the hardware against the same maps.
 #pragma once
-#include <ucontext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -61,8 +60,22 @@ typedef unsigned emu_u32x4 __attribute__((ext_vector_type(4)));
 
 namespace emu {
 
+// Context switch of the fibres: callee-saved registers + stack pointer only (x86-64 System V).  glibc's swapcontext also saves
+// the signal mask -- one system call per switch, and an MFMA of the emulated wave is 128 switches.
+#if !defined(__x86_64__)
+#error "tests/emu: the fibre switch is written for x86-64 (the build container and the GPU boxes)"
+#endif
+__attribute__((naked, noinline)) static void fiber_switch(void** /*save_sp*/, void* /*load_sp*/) {
+    asm volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq %rsi, %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret\n\t");
+}
+
 struct Fiber {
-    ucontext_t ctx;
+    void* sp;
     dim3 tid;
     unsigned linear;
     bool done;
@@ -79,7 +92,7 @@ struct WaveX {  // per-wave exchange state (double-buffered by parity)
 struct State {
     dim3 blockIdx_, blockDim_, gridDim_;
     Fiber* cur = nullptr;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     std::vector<Fiber> fibers;
     std::vector<char> stacks;
     std::vector<WaveX> waves;
@@ -101,14 +114,15 @@ static const size_t kStack = 128 * 1024;
 inline void yield() {
     State& s = S();
     s.n_switch++;
-    swapcontext(&s.cur->ctx, &s.sched);
+    fiber_switch(&s.cur->sp, s.sched_sp);
 }
 
 inline void trampoline() {
     State& s = S();
     s.body();
     s.cur->done = true;
-    swapcontext(&s.cur->ctx, &s.sched);
+    fiber_switch(&s.cur->sp, s.sched_sp);      // never resumed
+    abort();
 }
 
 inline void wg_barrier() {
@@ -318,11 +332,14 @@ inline void run_grid(dim3 grid, dim3 block, size_t smem, F&& body) {
                     f.linear = t;
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                     f.done = false;
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = s.stacks.data() + kStack * t;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                    // initial frame: six zeroed callee-saved slots, then the address fiber_switch "returns" to; the stack pointer at
+                    // the trampoline's first instruction is 8 (mod 16), as after a call
+                    uintptr_t top = ((uintptr_t)(s.stacks.data() + kStack * (t + 1))) & ~(uintptr_t)15;
+                    void** fr = reinterpret_cast<void**>(top - 16 - 6 * sizeof(void*));
+                    for (int q = 0; q < 6; ++q) fr[q] = nullptr;
+                    fr[6] = reinterpret_cast<void*>(&trampoline);
+                    fr[7] = nullptr;
+                    f.sp = fr;
                 }
                 unsigned remaining = s.nthreads;
                 while (remaining) {
@@ -336,7 +353,7 @@ inline void run_grid(dim3 grid, dim3 block, size_t smem, F&& body) {
                             Fiber& f = s.fibers[wv * 64 + l];
                             if (f.done) continue;
                             s.cur = &f;
-                            swapcontext(&s.sched, &f.ctx);
+                            fiber_switch(&s.sched_sp, f.sp);
                             progressed++;
                             if (f.done) remaining--;
                         }
