@@ -514,6 +514,8 @@ def main():
                 variants = {"ff %s + mix %s (timed region, `value`)" % keep: round(steps_per_s, 3),
                             "ff bf16x3 + mix bf16x3": round(alt, 3)}
                 log(f"all-bf16x3 arithmetic: {alt:.2f} steps/s")
+            except Exception as e:  # noqa: BLE001 - never lose the headline line to the variant leg
+                variants = dict(error=repr(e))
             finally:
                 eng.ff_split, eng.x3_mix_split = keep
         cpu = cpu19 = None
