@@ -325,7 +325,6 @@ def main():
                     help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--x3-interleave", type=int, default=3, help="bit 0: even/odd workgroup->branch map; bit 1: image-local (XCD-aware) map where the shapes allow; bits 8..: start skew / 256 cycles")
-    ap.add_argument("--ffx-schedule", type=int, default=1, help="bit mask: 1 forward, 2 backward-data, 4 weight gradients on the role-split schedule (default 1)")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()
@@ -350,7 +349,6 @@ def main():
     torch.manual_seed(0)  # same initial weights on every rank (and broadcast from rank 0 anyway)
     block = (FNOPlus2DBlock if args.plus else FNOFactorized2DBlock)(**kw).to(dev)
     trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
-    _fl.get_lib().ffno_ffx_set_schedule(args.ffx_schedule)
     trainer.engine.use_x3 = not args.no_x3
     if args.ff_split:
         trainer.engine.ff_split = args.ff_split

@@ -30,14 +30,19 @@ class FusedBranch(C.Structure):
     _fields_ = [("in_", P), ("out", P), ("resid", P), ("spec_save", P), ("planes", P), ("tw", P),
                 ("B", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32),
-                ("planes_format", C.c_int32), ("pad_", C.c_int32), ("range_scale", P)]
+                ("planes_format", C.c_int32), ("tile_lines", C.c_int32), ("in_amax", P), ("out_amax", P)]
+
+
+class FfOpts(C.Structure):
+    """Mirror of ``ffno_ff_opts`` (include/ffno.h)."""
+    _fields_ = [("in_amax", P), ("out_amax", P), ("max_workgroups", C.c_int32), ("schedule", C.c_int32)]
 
 
 class LayerFwdDesc(C.Structure):
     """Mirror of ``ffno_layer_fwd_desc`` (include/ffno.h)."""
     _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
                 ("pk1", P), ("b1", P), ("pk2", P), ("b2", P), ("s_sum", P), ("resid", P), ("out", P), ("mask", P),
-                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("ff_kernel", C.c_int32)]
+                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("ff_kernel", C.c_int32), ("out_amax", P)]
 
 
 class LayerBwdDesc(C.Structure):
@@ -45,7 +50,7 @@ class LayerBwdDesc(C.Structure):
     _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
                 ("g", P), ("g2", P), ("g_sum", P), ("mask", P), ("pk1b", P), ("pk2b", P), ("ds", P), ("s", P), ("pk1", P),
                 ("b1", P), ("partial", P), ("nsplit", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
-                ("ff_kernel", C.c_int32), ("pad_", C.c_int32), ("grad_scale", P)]
+                ("ff_kernel", C.c_int32), ("pad_", C.c_int32), ("g_amax", P), ("s_amax", P), ("ds_amax", P)]
 
 
 class FxRedDesc(C.Structure):
@@ -86,6 +91,7 @@ class TrDesc(C.Structure):
 SIGNATURES = {
     "ffno_build_target": (C.c_char_p, []),
     "ffno_abi_version": (I, []),
+    "ffno_amax": (I, [P, SZ, P, P]),
     "ffno_twiddle_fill_host": (I, [P, I]),
     "ffno_dft_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "ffno_fw_pack": (I, [P, P, P, I, I, P]),
@@ -98,7 +104,6 @@ SIGNATURES = {
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_x3_supported": (I, [I, I, I]),
-    "ffno_spectral_x3_set_round": (I, [I]),
     "ffno_spectral_x3_pack_bytes": (SZ, [I, I]),
     "ffno_spectral_x3_pack": (I, [P, I, I, I, P]),
     "ffno_spectral_x3": (I, [P, I, I, I, I, P]),
@@ -120,24 +125,21 @@ SIGNATURES = {
     "ffno_ff_bwd_weights_partial": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ff_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_supported": (I, [I, I]),
-    "ffno_ffx_set_schedule": (I, [I]),
-    "ffno_ffx_set_max_workgroups": (I, [I]),
     "ffno_ffx_pack_bytes": (SZ, [I, I]),
     "ffno_ffx_pack": (I, [P, I, I, I, P]),
     "ffno_ffx_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),
     "ffno_ffx_mask_unpack": (I, [P, P, I, I, I, P]),
     "ffno_ffx_bwd_data": (I, [P, P, P, P, P, I, I, I, P]),
-    "ffno_ffx_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
-    "ffno_ffx_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ffx_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    "ffno_ffx_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffx_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce": (I, [P, P, P, P, P, I, I, I, I, P]),
     "ffno_ffx_bwd_weights_reduce_batched": (I, [P, I, I, I, I, P]),
     "ffno_ffh_pack_bytes": (SZ, [I, I]),
     "ffno_ffh_pack": (I, [P, I, I, I, P]),
-    "ffno_ffh_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P]),
+    "ffno_ffh_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffh_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
-    "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
-    "ffno_ffh_grad_scale": (I, [P, L, P, P]),
+    "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P, P]),
     "ffno_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ffno_layernorm_nsplit": (I, [L]),
     "ffno_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),

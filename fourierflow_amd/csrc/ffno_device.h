@@ -23,6 +23,8 @@ namespace ffno {
 
 static constexpr int kWave = 64;
 
+static inline int device_cu_count() { return plat::cu_count(); }
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return plat::mfma_f32_32x32x2(a, b, c);
 }
@@ -200,6 +202,41 @@ struct SplitHf2 {
         planes[0] = make_uint2(h0, h1), planes[1] = make_uint2(l0, l1);
     }
 };
+
+// ---- range words: how the fp16x2 kernels stay inside the half format's exponent range ---------------------------------------
+// A RANGE WORD is a caller-owned 32-bit device word holding the bit pattern of max |x| over a tensor (non-negative floats order
+// like their bit patterns, so producers fold their maxima with one atomicMax per workgroup; zero it before the first producer).
+// A kernel that cuts an operand into fp16 planes reads the range word of that operand and derives, on the device, the power of
+// two that brings the operand's magnitude BOUND to 2^target: the data is multiplied by it while it is staged and the results are
+// divided by it again -- both exact.  No host round trip, no assumption about the data: any finite fp32 input is in range.
+//   bound = max|x| * 2^extra_log2   (extra_log2: what the kernel may add before the split -- e.g. +1 for a sum of two tensors,
+//                                    + log2(2 sqrt(L)) for an orthonormal DFT of length L with the c_k = 2 weights)
+//   scale * bound in (2^(target-1), 2^target]
+// A zero word (all-zero tensor) or a non-finite maximum gives scale 1 (non-finite data stays non-finite, as in fp32 arithmetic).
+__device__ __forceinline__ float range_scale(unsigned amax_bits, int extra_log2, int target) {
+    const int e = (int)((amax_bits >> 23) & 0xffu);          // max|x| < 2^(e - 126)
+    if (amax_bits == 0u || e == 255) return 1.f;
+    int sexp = target - (e - 126) - extra_log2;
+    sexp = sexp < -120 ? -120 : (sexp > 120 ? 120 : sexp);   // the scale and its reciprocal stay normal floats
+    return u2f((unsigned)(sexp + 127) << 23);
+}
+__device__ __forceinline__ int ceil_log2_int(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+// fold a per-lane maximum (>= 0) of a workgroup of NWAVES waves into a range word: wave butterflies, one LDS word per wave, one
+// atomic per workgroup.  Every thread of the workgroup must call it (it contains a barrier); `red` = NWAVES floats of LDS.
+__device__ __forceinline__ void range_fold(float m, float* red, int nwaves, unsigned* word) {
+    FFNO_UNROLL
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nwaves; ++w) m = fmaxf(m, red[w]);
+        atomicMax(word, f2u(m));
+    }
+}
 
 // row of the 32x32 D tile held in accumulator register r by a lane in half `half` (= lane >> 5)
 __device__ __forceinline__ int drow(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }

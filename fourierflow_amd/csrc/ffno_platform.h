@@ -84,6 +84,20 @@ __device__ __forceinline__ void sleep_cycles(int n) {
 // sin / cos of pi * x
 __device__ __forceinline__ void sincos_pi(float x, float& s, float& c) { sincospif(x, &s, &c); }
 
+// compute units of the current device: an immutable fact per device ordinal, queried once (the only state the library keeps
+// besides its constant tables)
+static inline int cu_count() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev];
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return n;
+}
+
 }  // namespace plat
 
 // dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel

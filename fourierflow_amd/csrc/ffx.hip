@@ -29,6 +29,10 @@
 
 namespace ffno {
 
+// magnitude bound (2^kFfRangeTarget) the split-fp16 kernels bring their staged rows to: 2^12 of head-room up to the half
+// format's 65504 for the growth through the first linear map of the chain (|h| <= ||W row||_1 |s| + |b|)
+constexpr int kFfRangeTarget = 4;
+
 template <int C, int H>
 struct FxCfg {
     static constexpr int CPW = 1;                 // hidden chunks (of 32 rows) per wave
@@ -154,7 +158,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2,
                                                                      const float* __restrict__ bias2, float* out,
-                                                                     uint32_t* mask, int P, const float* gscale_p) {
+                                                                     uint32_t* mask, int P, const unsigned* in_amax, unsigned* out_amax) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, NV = F::NV, G = F::G, GPW = F::GPW, CPW = F::CPW;
     __shared__ __attribute__((aligned(16))) char sp[2][S::NP * F::PPLANE];
@@ -165,8 +169,13 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int ntiles = (P + 31) >> 5;
-    const float gscale = (S::SCALED && gscale_p) ? *gscale_p : 1.f;     // (a power of two, device-resident)
+    // range scale of the split-fp16 operands (ffno_device.h "range words"): the staged rows are multiplied by a power of two
+    // derived on the device from the range word of the input (bound = 2 max|in|: the sum of two addends -> 2^kFfRangeTarget,
+    // which leaves 2^(16 - kFfRangeTarget) for the growth through the first product chain), the outputs divided again (exact)
+    const float gscale = (S::SCALED && in_amax) ? range_scale(*in_amax, 1, kFfRangeTarget) : 1.f;
     const float rgscale = 1.f / gscale;
+    float omax = 0.f;                                   // max |out| over the rows this thread stores (-> out_amax)
+    __shared__ float rfold[NW];
 
     using Frag = typename S::Frag;
     Frag A1[CPW][KS], A2[CPW][CTO][2];
@@ -182,7 +191,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
         }
     }
     if (!BWD) {
-        for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e];
+        for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e] * gscale;
         for (int e = tid; e < C; e += F::NT) b2s[e] = bias2[e];
     }
 
@@ -217,7 +226,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                     if (px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = nS[v];
                 }
             }
-            if (BWD && S::SCALED) nS[v].x *= gscale, nS[v].y *= gscale, nS[v].z *= gscale, nS[v].w *= gscale;
+            if (S::SCALED) nS[v].x *= gscale, nS[v].y *= gscale, nS[v].z *= gscale, nS[v].w *= gscale;
         }
     };
     auto stage = [&](int buf) {
@@ -254,14 +263,17 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
                 acc.w += t.w;
             }
             const int c0 = 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half;
+            if (S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
             if (!BWD) {
                 acc.x += b2s[c0] + rres[u].x;
                 acc.y += b2s[c0 + 1] + rres[u].y;
                 acc.z += b2s[c0 + 2] + rres[u].z;
                 acc.w += b2s[c0 + 3] + rres[u].w;
             }
-            if (BWD && S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
-            if (px < P) *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+            if (px < P) {
+                *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+                omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+            }
         }
     };
 
@@ -362,437 +374,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
         __syncthreads();
     }
     if (prev >= 0) reduce(prev, buf ^ 1);
-}
-
-// profiling hook of tools/scratch (cycle stamps around the iterations of ffx_chain_sp_kernel); empty in the product
-#ifndef FFX_STAMP
-#define FFX_STAMP(i)
-#endif
-// ablation mask of the same harness (0 in the product): 1 no GEMM1, 2 no epilogue / split, 4 no GEMM2, 8 no reduction,
-// 16 no sum / split / staging of tile t + 2, 32 no global loads, 64 no partial exchange, 128 no scheduling pattern
-#ifndef FFX_ABL
-#define FFX_ABL 0
-#endif
-
-template <bool V>
-struct FlagTag {
-    static constexpr bool value = V;
-};
-template <int V>
-struct IntTag {
-    static constexpr int value = V;
-};
-
-// Stores of tiles that do not exist (pipeline prologue / epilogue of ffx_chain_sp_kernel) are redirected here instead of being
-// predicated: a predicate is a branch, and a branch would cut the basic block the instruction scheduler interleaves.
-__device__ float4 g_fx_sink[512];
-
-// ---- forward / backward-data, software-pipelined schedule ---------------------------------------------------------------
-// Same arithmetic as ffx_chain_kernel (bit-identical with one hidden chunk per wave, CPW = 1).
-//
-// Why another schedule -- measured on one SIMD (tools/ubench/mfma_valu_overlap.hip, mfma_interleave.hip, profiles/r02_ffx_sp.md):
-//   * a wave whose next instruction is an MFMA that has to wait for the busy matrix pipe BLOCKS the vector issue of the other
-//     wave on its SIMD (the partner gets ~1 VALU per 32-cycle MFMA slot): back-to-back MFMAs never overlap with a partner's
-//     vector work, whatever the priorities or the accumulator register class;
-//   * inside ONE instruction stream {1 MFMA, k independent VALU} costs max(32, ~5k) cycles (two such streams per SIMD:
-//     max(64, ~2.3 * 2k)): the overlap is perfect when the vector work sits BETWEEN the wave's own MFMAs.
-// ffx_chain_kernel / _rs_kernel issue 24 MFMAs back to back, so their matrix and vector phases add up (~8400 cycles per tile
-// for 3072 cycles of MFMA).  Here the dependent chain GEMM1 -> epilogue -> GEMM2 is cut across tiles so that every MFMA group
-// has independent vector work of OTHER tiles next to it in the same wave.  An iteration is a sequence of SLOTS, one
-// mfma_x3 group (6 MFMAs per hidden chunk) plus one quantum of vector / memory work, fenced so that the order is the written one:
-//
-//     GEMM1(t+1), k-step 0     bias + ReLU + sign bits + split of rows 0-7 of tile t      (-> B operand of GEMM2, k-step 0)
-//     GEMM1(t+1), k-step 1     ... rows 8-15                                              (-> k-step 1)
-//     GEMM1(t+1), k-step 2     reduction of the partial outputs of tile t-1 + residual + store
-//     GEMM1(t+1), k-step 3     sum, store and split of the raw rows of tile t+2 into the staging buffer
-//     GEMM2(t), ...            row requests for tile t+3, residual rows of t+1, sign words; partial outputs to LDS
-//
-// One barrier per tile; values that cross iterations live in two register sets selected by the iteration parity (the loop is
-// unrolled by two) so nothing is copied at the back-edge; the steady-state iteration has no predicates (loads of tiles past the
-// end are clamped, their stores go to g_fx_sink); ragged pixel counts take the predicated flavour.
-template <int C, int H, int CPW, bool BWD, bool FULL>
-__global__ __launch_bounds__(H / (32 * CPW) * 64) void ffx_chain_sp_kernel(const float* __restrict__ in,
-                                                                          const float* __restrict__ in2, float* sum_out,
-                                                                          const float* resid,
-                                                                          const u32x4* __restrict__ pk1,
-                                                                          const float* __restrict__ bias1,
-                                                                          const u32x4* __restrict__ pk2,
-                                                                          const float* __restrict__ bias2, float* out,
-                                                                          uint32_t* mask, int P) {
-    using F = FxCfg<C, H>;
-    constexpr int NCH = H / 32, NW = NCH / CPW, NT = NW * 64, KS = F::KS, CTO = F::CTO, G = F::G;
-    constexpr int NV = (32 * C / 4) / NT, GPW = G / NW;
-    static_assert(NW * CPW == NCH && NV >= 1 && NV * NT * 4 == 32 * C && GPW >= 1 && GPW * NW == G && NT <= 512, "maps");
-    __shared__ __attribute__((aligned(16))) char sp[2][3 * F::PPLANE];
-    __shared__ __attribute__((aligned(16))) float part[2][NW * G * 64 * 4];
-    __shared__ __attribute__((aligned(16))) float b1s[H];
-    __shared__ __attribute__((aligned(16))) float b2s[C];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, half = lane >> 5;
-    const int ntiles = (P + 31) >> 5;
-    FFX_STAMP(10);
-
-    Bf3 A1[CPW][KS], A2[CPW][CTO][2];
-    FFNO_UNROLL
-    for (int ch = 0; ch < CPW; ++ch) {
-        const int q = wave * CPW + ch;
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) A1[ch][st] = load_frag(pk1, q * KS + st, lane);
-        FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) {
-            FFNO_UNROLL
-            for (int s2 = 0; s2 < 2; ++s2) A2[ch][mt][s2] = load_frag(pk2, (q * CTO + mt) * 2 + s2, lane);
-        }
-    }
-    if (!BWD) {
-        for (int e = tid; e < H; e += NT) b1s[e] = bias1[e];
-        for (int e = tid; e < C; e += NT) b2s[e] = bias2[e];
-    }
-    using Safe = FlagTag<true>;
-    using Pred = FlagTag<false>;
-    const int last_tile = ntiles - 1;
-    float* const sink = reinterpret_cast<float*>(g_fx_sink);   // 2048 floats: any lane offset of a [32][C <= 64] tile fits
-
-    // Addresses = uniform tile base (scalar registers) + a 32-bit lane offset that never changes (one VGPR, no 64-bit vector
-    // arithmetic in the loop).  soff: float4 number f = tid + v * NT of a staged [32 px][C] tile; ooff: this lane's 4 channels
-    // of output group u (D-fragment rows 8 (gi & 3) + 4 half .. + 3 of channel tile gi >> 2, pixel j).
-    constexpr long TILE = 32 * C;
-    auto soff = [&](int v) { return (unsigned)(((tid + v * NT) / (C / 4)) * C + 4 * ((tid + v * NT) % (C / 4))); };
-    auto ooff = [&](int u) {
-        const int gi = wave * GPW + u;
-        return (unsigned)(j * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
-    };
-    // Helpers in two flavours: SAFE = no per-lane predicate (P % 32 == 0; tile indices are clamped by the caller, stores of
-    // non-existent tiles are redirected to the sink by a uniform select); !SAFE = predicated on the pixel index.
-    float4 nS[NV], pA[NV], pB[NV];
-    auto gload_raw = [&](auto safe, int tile) {
-        const float* a = in + tile * TILE;
-        const float* b = (FULL || in2) ? in2 + tile * TILE : nullptr;
-        FFNO_UNROLL
-        for (int v = 0; v < NV; ++v) {
-            const long px = (long)tile * 32 + (tid + v * NT) / (C / 4);
-            if constexpr (decltype(safe)::value) {
-                pA[v] = *reinterpret_cast<const float4*>(a + soff(v));
-                if (FULL || in2) pB[v] = *reinterpret_cast<const float4*>(b + soff(v));
-            } else {
-                pA[v] = pB[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (px < P) {
-                    pA[v] = *reinterpret_cast<const float4*>(a + soff(v));
-                    if (FULL || in2) pB[v] = *reinterpret_cast<const float4*>(b + soff(v));
-                }
-            }
-        }
-    };
-    // exists: (uniform) the tile is a real one -- only looked at by the SAFE flavour
-    auto consume = [&](auto safe, int tile, bool exists) {
-        float* dst = (decltype(safe)::value && !exists) ? sink : sum_out + tile * TILE;
-        FFNO_UNROLL
-        for (int v = 0; v < NV; ++v) {
-            nS[v] = pA[v];
-            if (FULL || in2) {
-                nS[v].x += pB[v].x, nS[v].y += pB[v].y, nS[v].z += pB[v].z, nS[v].w += pB[v].w;
-                if (FULL || sum_out) {
-                    const long px = (long)tile * 32 + (tid + v * NT) / (C / 4);
-                    if (decltype(safe)::value || px < P) *reinterpret_cast<float4*>(dst + soff(v)) = nS[v];
-                }
-            }
-        }
-    };
-    auto stage = [&](int buf) {
-        FFNO_UNROLL
-        for (int v = 0; v < NV; ++v) {
-            const int f = tid + v * NT;
-            stage4(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
-        }
-    };
-    // Values that live across iterations come in two register sets selected by the (compile-time) parity of the iteration -- the
-    // loop below is unrolled by two -- so that nothing is copied at the loop back-edge: a copy of a just-requested row would
-    // make the wave wait for HBM every iteration.
-    //   rr      residual rows of a tile: requested late in its own iteration, added early in the next one (one set is enough)
-    //   dd[q]   hidden pre-activations: GEMM1 result written in an iteration of parity 1 - q, consumed in the next one
-    //   bw[q]   (backward) sign words of the tile of an iteration of parity q, requested one iteration earlier
-    float4 rr[GPW];
-    auto rload = [&](auto safe, int tile) {
-        const long px = (long)tile * 32 + j;
-        const float* r = resid + tile * TILE;
-        FFNO_UNROLL
-        for (int u = 0; u < GPW; ++u) {
-            rr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!BWD && (FULL || resid) && (decltype(safe)::value || px < P)) rr[u] = *reinterpret_cast<const float4*>(r + ooff(u));
-        }
-    };
-    auto reduce = [&](auto safe, auto par, int tile, bool exists) {
-        constexpr int q = decltype(par)::value;      // parity of the iteration that reduces: partials in part[q ^ 1]
-        const long px = (long)tile * 32 + j;
-        float* dst = (decltype(safe)::value && !exists) ? sink : out + tile * TILE;
-        FFNO_UNROLL
-        for (int u = 0; u < GPW; ++u) {
-            const int gi = wave * GPW + u;
-            float4 acc = *reinterpret_cast<const float4*>(&part[q ^ 1][((0 * G + gi) * 64 + lane) * 4]);
-            FFNO_UNROLL
-            for (int w = 1; w < NW; ++w) {
-                const float4 t = *reinterpret_cast<const float4*>(&part[q ^ 1][((w * G + gi) * 64 + lane) * 4]);
-                acc.x += t.x;
-                acc.y += t.y;
-                acc.z += t.z;
-                acc.w += t.w;
-            }
-            if (!BWD) {
-                const float4 bv = *reinterpret_cast<const float4*>(&b2s[32 * (gi >> 2) + 8 * (gi & 3) + 4 * half]);
-                acc.x += bv.x + rr[u].x;
-                acc.y += bv.y + rr[u].y;
-                acc.z += bv.z + rr[u].z;
-                acc.w += bv.w + rr[u].w;
-            }
-            if (decltype(safe)::value || (px >= 0 && px < P)) *reinterpret_cast<float4*>(dst + ooff(u)) = acc;
-        }
-    };
-    struct Hid {
-        f32x16 v[CPW];
-    };
-    auto gemm1 = [&](int buf) {
-        Hid d;
-        FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) d.v[ch] = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Bf3 b = lds_frag(sp[buf], F::PPLANE, j * F::PROW + 32 * st + 16 * half);
-            FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) d.v[ch] = mfma_x3(A1[ch][st], b, d.v[ch]);
-        }
-        return d;
-    };
-    auto mask_word = [&](int tile, int ch) {
-        return reinterpret_cast<uint16_t*>(mask) + (long)tile * (NCH * 64) + (unsigned)((wave * CPW + ch) * 64 + lane);
-    };
-    using Even = IntTag<0>;
-    using Odd = IntTag<1>;
-
-    const int t0 = blockIdx.x, gs = gridDim.x;
-    uint32_t bw[2][CPW];
-    Hid dd[2];
-    FFNO_UNROLL
-    for (int ch = 0; ch < CPW; ++ch) bw[0][ch] = bw[1][ch] = 0, dd[0].v[ch] = dd[1].v[ch] = zero16();
-    FFNO_UNROLL
-    for (int u = 0; u < GPW; ++u) rr[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t0 < ntiles) {
-        gload_raw(Pred{}, t0);
-        consume(Pred{}, t0, true);
-        stage(0);
-        if (t0 + gs < ntiles) {
-            gload_raw(Pred{}, t0 + gs);
-            consume(Pred{}, t0 + gs, true);
-            stage(1);
-        }
-        gload_raw(Pred{}, t0 + 2 * gs);
-        if (BWD) {
-            FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) bw[0][ch] = *mask_word(t0, ch);
-        }
-    }
-    __syncthreads();
-    if (t0 < ntiles) dd[0] = gemm1(0);
-    FFNO_DRAIN_MEMORY();
-
-    // one iteration of parity q: tile in sp[q] (its GEMM1 result in dd[q]), previous tile's partials in part[q ^ 1]
-    auto iteration = [&](auto safe, auto par, int tile, int prev) {
-        constexpr bool SAFE = decltype(safe)::value;
-        constexpr int q = decltype(par)::value;
-        constexpr int NSLOT = KS + 2 * CTO;          // mfma_x3 groups (per hidden chunk) of an iteration
-        static_assert(KS >= 4, "quanta E0 R S E1 ride on four GEMM1 slots");
-        int nt = tile + gs, nt2 = nt + gs, nt3 = nt2 + gs;
-        const bool have2 = nt2 < ntiles;
-        if (SAFE) nt = min(nt, last_tile), nt2 = min(nt2, last_tile), nt3 = min(nt3, last_tile);
-        uint32_t bits[CPW];
-        Bf3 hb[CPW][2];
-        // quantum E(s2): rows 8 s2 .. 8 s2 + 7 of the hidden tile -> activation (+ sign bits) -> B operand of GEMM2's k-step s2
-        auto quantum_e = [&](int s2, int ch0, int ch1) {
-            FFNO_UNROLL
-            for (int ch = ch0; ch < ch1; ++ch) {
-                f32x16& dv = dd[q].v[ch];
-                if (FFX_ABL & 2) {
-                    hb[ch][s2].hi = u32x4{f2u(dv[8 * s2]), f2u(dv[8 * s2 + 3]), f2u(dv[8 * s2 + 6]), f2u(dv[8 * s2 + 7])};
-                    hb[ch][s2].mid = u32x4{f2u(dv[8 * s2 + 1]), f2u(dv[8 * s2 + 4]), f2u(dv[8 * s2 + 6]), f2u(dv[8 * s2 + 7])};
-                    hb[ch][s2].lo = u32x4{f2u(dv[8 * s2 + 2]), f2u(dv[8 * s2 + 5]), f2u(dv[8 * s2 + 6]), f2u(dv[8 * s2 + 7])};
-                    continue;
-                }
-                if (BWD) {
-                    FFNO_UNROLL
-                    for (int r = 8 * s2; r < 8 * s2 + 8; ++r) dv[r] = u2f(f2u(dv[r]) & bit_mask(bits[ch], 15 - r));
-                } else {
-                    FFNO_UNROLL
-                    for (int g = 2 * s2; g < 2 * s2 + 2; ++g) {
-                        const float4 bv = *reinterpret_cast<const float4*>(&b1s[32 * (wave * CPW + ch) + 8 * g + 4 * half]);
-                        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-                        FFNO_UNROLL
-                        for (int i = 0; i < 4; ++i) {
-                            const float v = fmaxf(dv[4 * g + i] + bb[i], 0.f);
-                            dv[4 * g + i] = v;
-                            bits[ch] = push_sign(bits[ch], 0u - f2u(v));   // msb(-bits(v)) = [v > 0]; element r ends up at bit 15 - r
-                        }
-                    }
-                }
-                hb[ch][s2] = split3_8(dv[8 * s2], dv[8 * s2 + 1], dv[8 * s2 + 2], dv[8 * s2 + 3], dv[8 * s2 + 4], dv[8 * s2 + 5],
-                                      dv[8 * s2 + 6], dv[8 * s2 + 7]);
-                FFNO_PIN(hb[ch][s2].hi);
-                FFNO_PIN(hb[ch][s2].mid);
-                FFNO_PIN(hb[ch][s2].lo);
-            }
-        };
-        f32x16 o[CTO];
-        auto write_partial = [&](int mt) {
-            FFNO_UNROLL
-            for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(&part[q][(((wave * G) + mt * 4 + g) * 64 + lane) * 4]) =
-                    make_float4(o[mt][4 * g], o[mt][4 * g + 1], o[mt][4 * g + 2], o[mt][4 * g + 3]);
-        };
-        // pins the inputs of quantum i in FRONT of the slot's MFMAs (its outputs are pinned behind its code): the quantum's
-        // instructions then sit between the two pins, free to be interleaved with the MFMAs of the slot
-        // Slot -> quantum.  One chunk per wave (two waves per SIMD): E0 R S E1 L; two chunks per wave (one wave per SIMD, where a
-        // vector instruction costs ~5 cycles): the E quanta are cut per chunk and spread, ~80 instructions per 12 MFMAs:
-        // E0[0] E0[1] R S E1[0] E1[1] L.  E(s2) must precede slot KS + s2 * CTO, which both orders respect for KS = 4.
-        constexpr int QE0 = 0, QE0B = CPW == 2 ? 1 : -1, QR = CPW == 2 ? 2 : 1, QS = QR + 1, QE1 = QS + 1,
-                      QE1B = CPW == 2 ? QE1 + 1 : -1, QL = CPW == 2 ? 6 : 4, NQ = QL + 1;
-        static_assert(CPW <= 2, "quanta are laid out for one or two hidden chunks per wave");
-        // pins the inputs of quantum i in FRONT of the slot's MFMAs (its outputs are pinned behind its code): the quantum's
-        // instructions then sit between the two pins, free to be interleaved with the MFMAs of the slot
-        auto quantum_inputs = [&](int i) {
-            auto& hid = dd;                 // (an asm operand alone does not capture)
-            auto& rows = pA;
-            if (i == QE0 || i == QE1) FFNO_PIN(hid[q].v[0]);
-            if (i == QE0B || i == QE1B) FFNO_PIN(hid[q].v[CPW - 1]);
-            if (i == QS) {
-                FFNO_UNROLL
-                for (int v = 0; v < NV; ++v) FFNO_PIN(rows[v].x);
-            }
-        };
-        auto quantum = [&](int i) {
-            if (i == QE0) quantum_e(0, 0, CPW == 2 ? 1 : CPW);
-            if (i == QE0B) quantum_e(0, 1, 2);
-            if (i == QE1) quantum_e(1, 0, CPW == 2 ? 1 : CPW);
-            if (i == QE1B) quantum_e(1, 1, 2);
-            if (i == QR && !(FFX_ABL & 8)) reduce(safe, par, prev, prev >= 0);
-            if (i == QS && !(FFX_ABL & 16)) {
-                consume(safe, nt2, have2);
-                stage(q);                   // sp[q] held this tile: its GEMM1 ran one iteration ago
-            }
-            if (i == QL) {
-                if (!(FFX_ABL & 32)) {
-                    rload(safe, tile);      // added by the reduction early in the next iteration
-                    gload_raw(safe, nt3);
-                }
-                if (!BWD && (FULL || mask)) {
-                    FFNO_UNROLL
-                    for (int ch = 0; ch < CPW; ++ch) *mask_word(tile, ch) = (uint16_t)bits[ch];
-                }
-            }
-        };
-        // inside a slot: each MFMA followed by its share of the quantum (the groups that cannot be filled are skipped)
-        auto slot_pattern = [&]() {
-            if (FFX_ABL & 128) return;
-            FFNO_UNROLL
-            for (int i = 0; i < 6 * CPW; ++i) {
-                FFNO_SCHED_GROUP(0x008, 1);
-                FFNO_SCHED_GROUP(0x002, CPW == 2 ? 7 : 14);
-                FFNO_SCHED_GROUP(0x080, 2);
-                FFNO_SCHED_GROUP(0x010, 1);
-            }
-        };
-        FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) {
-            bits[ch] = BWD ? bw[q][ch] : 0;
-            if (BWD) bw[q ^ 1][ch] = *mask_word(min(nt, last_tile), ch);
-            dd[q ^ 1].v[ch] = zero16();
-        }
-        // ---- GEMM1 of the NEXT tile (whatever sp[q ^ 1] holds when there is none): its B operands are read one slot ahead ----
-        Bf3 bcur = lds_frag(sp[q ^ 1], F::PPLANE, j * F::PROW + 16 * half);
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            FFNO_SCHED_FENCE();
-            Bf3 bnext = bcur;
-            if (st + 1 < KS) bnext = lds_frag(sp[q ^ 1], F::PPLANE, j * F::PROW + 32 * (st + 1) + 16 * half);
-            quantum_inputs(st);
-            if (!(FFX_ABL & 1)) {
-                FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) dd[q ^ 1].v[ch] = mfma_x3(A1[ch][st], bcur, dd[q ^ 1].v[ch]);
-            }
-            quantum(st);
-            FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) FFNO_PIN(dd[q ^ 1].v[ch]);
-            slot_pattern();
-            bcur = bnext;
-        }
-        // ---- GEMM2 of this tile: k-step s2 needs the B operand of quantum E(s2) ----
-        FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16();
-        FFNO_UNROLL
-        for (int s2 = 0; s2 < 2; ++s2) {
-            FFNO_UNROLL
-            for (int mt = 0; mt < CTO; ++mt) {
-                const int slot = KS + s2 * CTO + mt;
-                FFNO_SCHED_FENCE();
-                quantum_inputs(slot);
-                FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) {
-                    if (FFX_ABL & 4) {
-                        FFNO_UNROLL
-                        for (int r = 0; r < 4; ++r)
-                            o[mt][4 * ch + r] += u2f(hb[ch][s2].hi[r] ^ hb[ch][s2].mid[r] ^ hb[ch][s2].lo[r]);
-                        continue;
-                    }
-                    o[mt] = mfma_x3(A2[ch][mt][s2], hb[ch][s2], o[mt]);
-                }
-                if (slot < NSLOT - 1) {
-                    quantum(slot);
-                    FFNO_PIN(o[mt]);
-                    slot_pattern();
-                } else {
-                    FFNO_UNROLL
-                    for (int i = NSLOT - 1; i < NQ; ++i) quantum(i);
-                    if (!(FFX_ABL & 64)) {
-                        FFNO_UNROLL
-                        for (int m2 = 0; m2 < CTO - 1; ++m2) write_partial(m2);   // complete since the slot before
-                    }
-                }
-            }
-        }
-        FFNO_SCHED_FENCE();
-        if (!(FFX_ABL & 64)) write_partial(CTO - 1);
-    };
-    // two iterations per trip (parities 0, 1); `last` = parity of the last iteration run
-    int last = 1, prev = -1, tile = t0;
-    auto run = [&](auto safe) {
-        for (; tile < ntiles; tile += 2 * gs) {
-            FFX_STAMP(0);
-            iteration(safe, Even{}, tile, prev);
-            FFX_STAMP(1);
-            __syncthreads();
-            FFX_STAMP(2);
-            prev = tile;
-            last = 0;
-            if (tile + gs >= ntiles) break;
-            iteration(safe, Odd{}, tile + gs, prev);
-            FFX_STAMP(1);
-            __syncthreads();
-            FFX_STAMP(2);
-            prev = tile + gs;
-            last = 1;
-        }
-    };
-    if ((P & 31) == 0)
-        run(Safe{});
-    else
-        run(Pred{});
-    FFX_STAMP(11);
-    // partials of the last tile: written by an iteration of parity `last`, reduced with the rows of the opposite set
-    if (prev >= 0) {
-        if (last == 0)
-            reduce(Pred{}, Odd{}, prev, true);
-        else
-            reduce(Pred{}, Even{}, prev, true);
-    }
-    FFX_STAMP(12);
+    if (out_amax) range_fold(omax, rfold, NW, out_amax);
 }
 
 // ---- forward / backward-data, role-split schedule ---------------------------------------------------------------------
@@ -818,7 +400,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
                                                                         const float* __restrict__ bias1,
                                                                         const u32x4* __restrict__ pk2,
                                                                         const float* __restrict__ bias2, float* out,
-                                                                        uint32_t* mask, int P, const float* gscale_p) {
+                                                                        uint32_t* mask, int P, const unsigned* in_amax, unsigned* out_amax) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, G = F::G;
     constexpr int NWA = NW / 2;                      // waves per role
@@ -834,8 +416,13 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int ntiles = (P + 31) >> 5;
-    const float gscale = (S::SCALED && gscale_p) ? *gscale_p : 1.f;     // (a power of two, device-resident)
+    // range scale of the split-fp16 operands (ffno_device.h "range words"): the staged rows are multiplied by a power of two
+    // derived on the device from the range word of the input (bound = 2 max|in|: the sum of two addends -> 2^kFfRangeTarget,
+    // which leaves 2^(16 - kFfRangeTarget) for the growth through the first product chain), the outputs divided again (exact)
+    const float gscale = (S::SCALED && in_amax) ? range_scale(*in_amax, 1, kFfRangeTarget) : 1.f;
     const float rgscale = 1.f / gscale;
+    float omax = 0.f;                                   // max |out| over the rows this thread stores (-> out_amax)
+    __shared__ float rfold[NW];
     const bool first = wave < NWA;                   // role: first half stages, second half reduces
     const int rw = wave - NWA;                       // index inside the reducing half
 
@@ -849,7 +436,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
         for (int s2 = 0; s2 < 2; ++s2) A2[mt][s2] = load_frag_s<S>(pk2, (wave * CTO + mt) * 2 + s2, lane);
     }
     if (!BWD) {
-        for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e];
+        for (int e = tid; e < H; e += F::NT) b1s[e] = bias1[e] * gscale;
         for (int e = tid; e < C; e += F::NT) b2s[e] = bias2[e];
     }
 
@@ -878,7 +465,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
                 const long px = (long)tile * 32 + f / (C / 4);
                 if (sum_out && px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = pS[v];
             }
-            if (BWD && S::SCALED) pS[v].x *= gscale, pS[v].y *= gscale, pS[v].z *= gscale, pS[v].w *= gscale;
+            if (S::SCALED) pS[v].x *= gscale, pS[v].y *= gscale, pS[v].z *= gscale, pS[v].w *= gscale;
         }
     };
     auto stage = [&](int buf) {
@@ -915,14 +502,17 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
                 acc.w += t.w;
             }
             const int c0 = 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half;
+            if (S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
             if (!BWD) {
                 acc.x += b2s[c0] + rres[u].x;
                 acc.y += b2s[c0 + 1] + rres[u].y;
                 acc.z += b2s[c0 + 2] + rres[u].z;
                 acc.w += b2s[c0 + 3] + rres[u].w;
             }
-            if (BWD && S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
-            if (px < P) *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+            if (px < P) {
+                *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+                omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+            }
         }
     };
 
@@ -1040,6 +630,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
         __syncthreads();
     }
     if (!first && prev >= 0) reduce(prev);
+    if (out_amax) range_fold(omax, rfold, NW, out_amax);
 }
 
 // ---- weight gradients with recomputed hidden activations --------------------------------------------------------------
@@ -1051,11 +642,15 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
                                                                      const u32x4* __restrict__ pk1,
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2t,
-                                                                     float* __restrict__ partial, int P, const float* gscale_p) {
+                                                                     float* __restrict__ partial, int P, const unsigned* s_amax,
+                                                                     const unsigned* db_amax) {
     using F = FxCfg<C, H>;
     constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV, CPW = F::CPW;
     constexpr int NP = S::NP;
-    const float gscale = (S::SCALED && gscale_p) ? *gscale_p : 1.f;     // (a power of two, device-resident)
+    // range scales of the two staged tensors (ffno_device.h "range words"): s like the forward chain kernel (the recomputed h
+    // then carries fscale), db like the backward one (dh carries gscale); every output is divided by the scales of its factors
+    const float fscale = (S::SCALED && s_amax) ? range_scale(*s_amax, 1, kFfRangeTarget) : 1.f;
+    const float gscale = (S::SCALED && db_amax) ? range_scale(*db_amax, 1, kFfRangeTarget) : 1.f;
     constexpr int BUF = 2 * NP * F::PPLANE + 2 * NP * F::TPLANE;   // [sP x NP][dbP x NP][sT x NP][dbT x NP]
     constexpr int OFF_SP = 0, OFF_DP = NP * F::PPLANE, OFF_ST = 2 * NP * F::PPLANE, OFF_DT = 2 * NP * F::PPLANE + NP * F::TPLANE;
     using Frag = typename S::Frag;
@@ -1075,7 +670,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
             W1f[ch][st] = load_frag_s<S>(pk1, (wave * CPW + ch) * KS + st, lane);
             W2f[ch][st] = load_frag_s<S>(pk2t, (wave * CPW + ch) * KS + st, lane);
         }
-        b1v[ch] = bias1[32 * (wave * CPW + ch) + j];
+        b1v[ch] = bias1[32 * (wave * CPW + ch) + j] * fscale;
     }
 
     // staging: pixel-major map as in the chain kernel; channel-major map: channel tc, pixel group tg (+ v * NT/C)
@@ -1110,6 +705,8 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
             nST[v] = make_float4(a[0], a[1], a[2], a[3]);
             nDT[v] = make_float4(b[0], b[1], b[2], b[3]);
             if (S::SCALED) {
+                nSP[v].x *= fscale, nSP[v].y *= fscale, nSP[v].z *= fscale, nSP[v].w *= fscale;
+                nST[v].x *= fscale, nST[v].y *= fscale, nST[v].z *= fscale, nST[v].w *= fscale;
                 nDP[v].x *= gscale, nDP[v].y *= gscale, nDP[v].z *= gscale, nDP[v].w *= gscale;
                 nDT[v].x *= gscale, nDT[v].y *= gscale, nDT[v].z *= gscale, nDT[v].w *= gscale;
             }
@@ -1248,7 +845,8 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
         __syncthreads();
     }
 
-    const float rg = S::SCALED ? 1.f / gscale : 1.f;     // (a power of two: exact)
+    const float rg = S::SCALED ? 1.f / gscale : 1.f;     // (powers of two: exact; applied one after the other so that their
+    const float rf = S::SCALED ? 1.f / fscale : 1.f;     //  product never leaves the float range)
     float* part = partial + (long)blockIdx.x * F::PART;
     float* pW1t = part;              // [c][hid]
     float* pW2 = part + H * C;       // [c][hid]
@@ -1262,8 +860,8 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int c = 32 * mt + drow(r, half);
-                pW1t[c * H + hid] = acc1[ch][mt][r] * rg;
-                pW2[c * H + hid] = acc2[ch][mt][r] * rg;
+                pW1t[c * H + hid] = acc1[ch][mt][r] * rf * rg;
+                pW2[c * H + hid] = acc2[ch][mt][r] * rf * rg;
             }
         }
         const float v1 = bs1[ch] + __shfl_xor(bs1[ch], 32);
@@ -1275,230 +873,6 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
         float v = 0.f;
         for (int k = tid; k < F::NT; k += C) v += red[k];
         pb2[tid] = v * rg;
-    }
-}
-
-// ---- weight gradients, role-split schedule --------------------------------------------------------------------------------
-// Same arithmetic and results as ffx_wgrad_kernel (bit-identical partial slices), scheduled like ffx_chain_rs_kernel: the
-// two waves of a SIMD (w and w + NW/2) stay one slot apart, a barrier after every slot, so that a matrix segment on one of
-// them always runs beside a vector / LDS segment on the other:
-//
-//     slot            1          2          3                   4                   5          6
-//     waves 0..NW/2   h^T GEMM   ReLU+split dW2 += , dh^T GEMM  mask+split          dW1 +=     stage tile t+1
-//     waves NW/2..    (idle)     h^T GEMM   ReLU+split          dW2 += , dh^T GEMM  mask+split dW1 +=
-//
-// The first half stages the whole next tile (both layouts of s and db); its rows are requested in slot 1, five slots
-// before they are split into LDS.
-template <int C, int H>
-__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_rs_kernel(const float* __restrict__ s,
-                                                                        const float* __restrict__ db,
-                                                                        const u32x4* __restrict__ pk1,
-                                                                        const float* __restrict__ bias1,
-                                                                        const u32x4* __restrict__ pk2t,
-                                                                        float* __restrict__ partial, int P) {
-    using F = FxCfg<C, H>;
-    constexpr int KS = F::KS, CTO = F::CTO, NW = F::NW;
-    constexpr int NWA = NW / 2, NTA = NWA * 64, NVA = (32 * C / 4) / NTA;
-    static_assert(NW >= 2 && NWA * 2 == NW && NVA * NTA * 4 == 32 * C && NTA % C == 0 && (NTA / C) * NVA == 8, "role split");
-    constexpr int BUF = 6 * F::PPLANE + 6 * F::TPLANE;   // [sP x3][dbP x3][sT x3][dbT x3]
-    constexpr int OFF_SP = 0, OFF_DP = 3 * F::PPLANE, OFF_ST = 6 * F::PPLANE, OFF_DT = 6 * F::PPLANE + 3 * F::TPLANE;
-    __shared__ __attribute__((aligned(16))) char lds[2][BUF];
-    __shared__ float red[F::NT];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, half = lane >> 5;
-    const int ntiles = (P + 31) >> 5;
-    const bool first = wave < NWA;
-
-    Bf3 W1f[KS], W2f[KS];
-    FFNO_UNROLL
-    for (int st = 0; st < KS; ++st) {
-        W1f[st] = load_frag(pk1, wave * KS + st, lane);
-        W2f[st] = load_frag(pk2t, wave * KS + st, lane);
-    }
-    const float b1v = bias1[32 * wave + j];
-
-    // staging, split by role so that no wave holds more than 2 * NVA rows in registers:
-    //   first half : pixel-major planes (sP, dbP; map f = tid + v * NTA), requested in slot 1, split into LDS in slot 6
-    //   second half: channel-major planes (sT, dbT; channel tc, pixel group tg + v * NTA / C), requested in slot 2 of the
-    //                previous tile, split into LDS in slot 1 -- two slots before the first reader (slot 3)
-    const int rt = first ? tid : tid - NTA;
-    const int tc = rt % C, tg = rt / C;
-    float4 nS[NVA], nD[NVA];
-    float bs2 = 0.f;
-    auto gload = [&](int tile) {
-        FFNO_UNROLL
-        for (int v = 0; v < NVA; ++v) {
-            if (first) {
-                const int f = rt + v * NTA;
-                const long px = (long)tile * 32 + f / (C / 4);
-                nS[v] = nD[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (px < P) {
-                    nS[v] = *reinterpret_cast<const float4*>(s + px * C + 4 * (f % (C / 4)));
-                    nD[v] = *reinterpret_cast<const float4*>(db + px * C + 4 * (f % (C / 4)));
-                }
-            } else {
-                const long p0 = (long)tile * 32 + 4 * (tg + v * (NTA / C));
-                float a[4], b[4];
-                FFNO_UNROLL
-                for (int i = 0; i < 4; ++i) {
-                    const bool ok = p0 + i < P;
-                    a[i] = ok ? s[(p0 + i) * C + tc] : 0.f;
-                    b[i] = ok ? db[(p0 + i) * C + tc] : 0.f;
-                }
-                nS[v] = make_float4(a[0], a[1], a[2], a[3]);
-                nD[v] = make_float4(b[0], b[1], b[2], b[3]);
-            }
-        }
-    };
-    auto stage = [&](int buf) {
-        FFNO_UNROLL
-        for (int v = 0; v < NVA; ++v) {
-            if (first) {
-                const int f = rt + v * NTA;
-                const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
-                stage4(lds[buf] + OFF_SP, F::PPLANE, offp, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
-                stage4(lds[buf] + OFF_DP, F::PPLANE, offp, nD[v].x, nD[v].y, nD[v].z, nD[v].w);
-            } else {
-                // pixel group grp = (s2 << 2) | (q << 1) | half  <->  local pixels 16 s2 + 8 q + 4 half + i  <->  k slot 4 q + i
-                const int grp = tg + v * (NTA / C);
-                const int pos = 16 * (grp & 1) + 8 * (grp >> 2) + 4 * ((grp >> 1) & 1);
-                const int offt = tc * F::TROW + 2 * pos;
-                stage4(lds[buf] + OFF_ST, F::TPLANE, offt, nS[v].x, nS[v].y, nS[v].z, nS[v].w);
-                stage4(lds[buf] + OFF_DT, F::TPLANE, offt, nD[v].x, nD[v].y, nD[v].z, nD[v].w);
-                bs2 += (nD[v].x + nD[v].y) + (nD[v].z + nD[v].w);
-            }
-        }
-    };
-
-    f32x16 acc1[CTO], acc2[CTO], d;
-    Bf3 hb[2];
-    float bs1 = 0.f;
-    uint32_t bits = 0;
-    FFNO_UNROLL
-    for (int mt = 0; mt < CTO; ++mt) acc1[mt] = zero16(), acc2[mt] = zero16();
-
-    auto seg_h = [&](const char* L) {          // h^T[px][hid] = s W1^T, pixels on the D rows
-        d = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Bf3 a = lds_frag(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
-            d = mfma_x3(a, W1f[st], d);
-        }
-    };
-    auto seg_relu = [&]() {
-        bits = 0;
-        FFNO_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            const float v = d[r] + b1v;
-            const bool pos = v > 0.f;
-            d[r] = pos ? v : 0.f;
-            bits |= (pos ? 1u : 0u) << r;
-        }
-        hb[0] = split3_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
-        hb[1] = split3_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
-    };
-    auto seg_w2_dh = [&](const char* L) {      // dW2 += db^T h ; then dh^T[px][hid] = db W2
-        FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) {
-            FFNO_UNROLL
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const Bf3 a = lds_frag(L + OFF_DT, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
-                acc2[mt] = mfma_x3(a, hb[s2], acc2[mt]);
-            }
-        }
-        FFNO_SCHED_FENCE();
-        d = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Bf3 a = lds_frag(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * st + 16 * half);
-            d = mfma_x3(a, W2f[st], d);
-        }
-    };
-    auto seg_mask = [&]() {
-        FFNO_UNROLL
-        for (int r = 0; r < 16; ++r) {
-            d[r] = ((bits >> r) & 1u) ? d[r] : 0.f;
-            bs1 += d[r];
-        }
-        hb[0] = split3_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
-        hb[1] = split3_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
-    };
-    auto seg_w1 = [&](const char* L) {         // dW1^T += s^T dh
-        FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) {
-            FFNO_UNROLL
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const Bf3 a = lds_frag(L + OFF_ST, F::TPLANE, (32 * mt + j) * F::TROW + 32 * half + 16 * s2);
-                acc1[mt] = mfma_x3(a, hb[s2], acc1[mt]);
-            }
-        }
-    };
-
-    const int t0 = blockIdx.x, gs = gridDim.x;
-    if (t0 < ntiles) {
-        gload(t0);
-        stage(0);
-        if (!first && t0 + gs < ntiles) gload(t0 + gs);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int tile = t0; tile < ntiles; tile += gs, buf ^= 1) {
-        const int nt = tile + gs;
-        const char* L = lds[buf];
-        if (first) {                      // slot 1
-            if (nt < ntiles) gload(nt);
-            seg_h(L);
-        } else if (tile != t0) {
-            stage(buf);                   // this tile's channel-major planes (first read in slot 3)
-        }
-        __syncthreads();
-        if (first) {                      // slot 2
-            seg_relu();
-        } else {
-            if (tile != t0 && nt < ntiles) gload(nt);
-            seg_h(L);
-        }
-        __syncthreads();
-        if (first) seg_w2_dh(L); else seg_relu();          // slot 3
-        __syncthreads();
-        if (first) seg_mask(); else seg_w2_dh(L);          // slot 4
-        __syncthreads();
-        if (first) seg_w1(L); else seg_mask();             // slot 5
-        __syncthreads();
-        if (first) {                      // slot 6
-            if (nt < ntiles) stage(buf ^ 1);
-        } else {
-            seg_w1(L);
-        }
-        __syncthreads();
-    }
-
-    float* part = partial + (long)blockIdx.x * F::PART;
-    float* pW1t = part;              // [c][hid]
-    float* pW2 = part + H * C;       // [c][hid]
-    float* pb1 = part + 2 * H * C;
-    float* pb2 = pb1 + H;
-    {
-        const int hid = 32 * wave + j;
-        FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) {
-            FFNO_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                const int c = 32 * mt + drow(r, half);
-                pW1t[c * H + hid] = acc1[mt][r];
-                pW2[c * H + hid] = acc2[mt][r];
-            }
-        }
-        const float v1 = bs1 + __shfl_xor(bs1, 32);
-        if (half == 0) pb1[hid] = v1;
-    }
-    red[tid] = bs2;
-    __syncthreads();
-    if (tid < C) {
-        float v = 0.f;
-        for (int k = tid; k < F::NT; k += C) v += red[k];
-        pb2[tid] = v;
     }
 }
 
@@ -1599,11 +973,12 @@ static inline int ffx_launch_status() {
     return e == hipSuccess ? FFNO_OK : (int)e;
 }
 
-static int kFxBlocks = 256;         // persistent workgroups: one per CU (ffno_ffx_set_max_workgroups)
-// which kernels run the role-split schedule (bit 0: forward, bit 1: backward-data, bit 2: weight gradients); the others run
-// the in-phase kernels.  Default = forward only: measured on MI355X at markov/24 batch 32 (profiles/r02_ffx_schedules.md)
-// forward 53 vs 57 us, backward-data 56 vs 50 us, weight gradients 108 vs 89 us.
-static int g_chain_schedule = 1;
+// persistent workgroups of the chain kernels: one per compute unit of the current device unless the caller says otherwise
+// (max_workgroups > 0).  The CU count is an immutable per-device fact, cached after the first query.
+static inline int fx_workgroups(int max_workgroups, int ntiles) {
+    const int n = max_workgroups > 0 ? max_workgroups : device_cu_count();
+    return n < ntiles ? n : ntiles;
+}
 
 }  // namespace ffno
 
@@ -1625,18 +1000,6 @@ extern "C" int ffno_ffx_supported(int C, int H) {
 
 extern "C" size_t ffno_ffx_pack_bytes(int C, int H) { return (size_t)C * H * 6; }
 
-extern "C" int ffno_ffx_set_max_workgroups(int n) {
-    if (n <= 0 || n > 65535) return FFNO_EINVAL;
-    kFxBlocks = n;
-    return FFNO_OK;
-}
-
-extern "C" int ffno_ffx_set_schedule(int schedule) {
-    if (schedule < 0 || schedule > 31) return FFNO_EINVAL;
-    g_chain_schedule = schedule;
-    return FFNO_OK;
-}
-
 extern "C" int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, int C, int H, void* stream) {
     if (!mask || !active || P <= 0) return FFNO_EINVAL;
     if (!ffno_ffx_supported(C, H)) return FFNO_EUNSUPPORTED;
@@ -1645,6 +1008,9 @@ extern "C" int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, in
 }
 
 // ---- host side, written once over the split policy --------------------------------------------------------------------------
+// Schedules (measured on MI355X at markov/24, batch 32, profiles/r02_ffx_schedules.md): the forward runs the role-split kernel
+// (53 vs 57 us), backward-data and the weight gradients the in-phase kernels (50 vs 56 us, 89 vs 108 us).  The schedules that
+// lost are in tools/experiments/ffx_negative_results.hip, not in this library.
 template <class S>
 static int fx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
     if (!descs_dev || n <= 0) return FFNO_EINVAL;
@@ -1658,23 +1024,23 @@ static int fx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void*
 
 template <class S>
 static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
-                   const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
+                   const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, const ffno_ff_opts* o,
+                   void* stream) {
     if (!s || !pk1 || !b1 || !pk2 || !b2 || !out || P <= 0 || (s_sum && !s2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
-    const dim3 grid(min(kFxBlocks, ntiles));
+    const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles));
+    const unsigned* ia = o ? o->in_amax : nullptr;
+    unsigned* oa = o ? o->out_amax : nullptr;
+    const bool in_phase = o && (o->schedule & FFNO_FF_SCHED_IN_PHASE);
     hipStream_t st = (hipStream_t)stream;
-    constexpr bool BF3 = S::NP == 3;      // the software-pipelined kernel exists for the split-bf16 operands only
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        if (BF3 && (g_chain_schedule & 8) && CC == 64 && s2 && s_sum && resid && mask)                                \
-            FFNO_LAUNCH((ffx_chain_sp_kernel<64, HH, 1, false, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2,   \
-                        s_sum, resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P);         \
-        else if ((g_chain_schedule & 1) && HH >= 64)                                                                  \
+        if (!in_phase && HH >= 64)                                                                                    \
             FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, false, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,  \
-                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, (const float*)nullptr);           \
+                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, ia, oa);        \
         else                                                                                                          \
             FFNO_LAUNCH((ffx_chain_kernel<CC, HH, false, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, s, s2, s_sum,     \
-                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, (const float*)nullptr);           \
+                        resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, out, (uint32_t*)mask, P, ia, oa);        \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -1684,26 +1050,18 @@ static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* r
 
 template <class S>
 static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
-                        const void* pk2b, float* ds, int P, int C, int H, const float* gscale, void* stream) {
+                        const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* o, void* stream) {
     if (!db || !mask || !pk1b || !pk2b || !ds || P <= 0 || (db_sum && !db2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
-    const dim3 grid(min(kFxBlocks, ntiles));
+    const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles));
+    const unsigned* ia = o ? o->in_amax : nullptr;
+    unsigned* oa = o ? o->out_amax : nullptr;
     hipStream_t st = (hipStream_t)stream;
-    constexpr bool BF3 = S::NP == 3;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
-        if (BF3 && (g_chain_schedule & 16) && CC == 64 && db2 && db_sum)                                              \
-            FFNO_LAUNCH((ffx_chain_sp_kernel<64, HH, 1, true, true>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2,  \
-                        db_sum, nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                \
-                        (uint32_t*)const_cast<void*>(mask), P);                                                       \
-        else if ((g_chain_schedule & 2) && HH >= 64)                                                                  \
-            FFNO_LAUNCH((ffx_chain_rs_kernel<CC, HH, true, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2,        \
-                        db_sum, nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                \
-                        (uint32_t*)const_cast<void*>(mask), P, gscale);                                               \
-        else                                                                                                          \
-            FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,   \
-                        nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                        \
-                        (uint32_t*)const_cast<void*>(mask), P, gscale);                                               \
+        FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,       \
+                    nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, ds,                            \
+                    (uint32_t*)const_cast<void*>(mask), P, ia, oa);                                                   \
         return ffx_launch_status();                                                                                   \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -1713,18 +1071,14 @@ static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const 
 
 template <class S>
 static int fx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
-                                  float* partial, int P, int C, int H, int nsplit, const float* gscale, void* stream) {
+                                  float* partial, int P, int C, int H, int nsplit, const unsigned* s_amax,
+                                  const unsigned* db_amax, void* stream) {
     if (!s || !db || !pk1 || !b1 || !pk1b || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    constexpr bool BF3 = S::NP == 3;
 #define CASE(CC, HH)                                                                                               \
     if (C == CC && H == HH) {                                                                                      \
-        if (BF3 && (g_chain_schedule & 4))                                                                         \
-            FFNO_LAUNCH((ffx_wgrad_rs_kernel<CC, HH>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
-                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P);                                    \
-        else                                                                                                       \
-            FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH, S>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
-                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, gscale);                            \
+        FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH, S>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,            \
+                    (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);                       \
         return ffx_launch_status();                                                                                \
     }
     FFNO_FX_DISPATCH(CASE)
@@ -1732,68 +1086,31 @@ static int fx_bwd_weights_partial(const float* s, const float* db, const void* p
     return FFNO_EUNSUPPORTED;
 }
 
-// ---- split-bf16 entry points ----
+// ---- split-bf16 entry points (any fp32 range: the range words of `opts` are only PRODUCED, never needed) ----
 extern "C" int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream) {
     return fx_pack<SplitBf3>(descs_dev, n, C, H, stream);
 }
 extern "C" int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
                             const float* b2, float* out, void* mask, int P, int C, int H, void* stream) {
-    return fx_fwd2<SplitBf3>(s, nullptr, nullptr, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+    return fx_fwd2<SplitBf3>(s, nullptr, nullptr, resid, pk1, b1, pk2, b2, out, mask, P, C, H, nullptr, stream);
 }
 extern "C" int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1,
                              const float* b1, const void* pk2, const float* b2, float* out, void* mask, int P, int C,
-                             int H, void* stream) {
-    return fx_fwd2<SplitBf3>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+                             int H, const ffno_ff_opts* opts, void* stream) {
+    return fx_fwd2<SplitBf3>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, C, H, opts, stream);
 }
 extern "C" int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds, int P,
                                  int C, int H, void* stream) {
     return fx_bwd_data2<SplitBf3>(db, nullptr, nullptr, mask, pk1b, pk2b, ds, P, C, H, nullptr, stream);
 }
 extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
-                                  const void* pk2b, float* ds, int P, int C, int H, void* stream) {
-    return fx_bwd_data2<SplitBf3>(db, db2, db_sum, mask, pk1b, pk2b, ds, P, C, H, nullptr, stream);
+                                  const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* opts, void* stream) {
+    return fx_bwd_data2<SplitBf3>(db, db2, db_sum, mask, pk1b, pk2b, ds, P, C, H, opts, stream);
 }
 extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
                                             const void* pk1b, float* partial, int P, int C, int H, int nsplit,
                                             void* stream) {
-    return fx_bwd_weights_partial<SplitBf3>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, nullptr, stream);
-}
-
-// power-of-two scale that brings max |g| to [32, 64]: 1000-fold growth through the backward layers stays below the half
-// format's 65504, elements down to 2^-18 of the maximum keep fp32-level relative accuracy.  One launch: every workgroup folds
-// its maximum into g_gs_max (non-negative floats order like their bit patterns); the last one to arrive writes the scale and
-// resets the two words for the next call (calls on one device are stream-ordered by the caller).
-__device__ unsigned g_gs_max, g_gs_count;
-__global__ __launch_bounds__(256) void ffh_grad_scale_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
-    __shared__ float red[256];
-    float m = 0.f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = fmaxf(m, fabsf(g[i]));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int sft = 128; sft >= 1; sft >>= 1) {
-        if ((int)threadIdx.x < sft) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + sft]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        float w = red[0];
-        if (!(w < 3.0e38f)) w = 3.0e38f;                      // inf / nan: saturate (the scale below then falls back to 1)
-        atomicMax(&g_gs_max, f2u(w));
-        __threadfence();
-        if (atomicAdd(&g_gs_count, 1u) == gridDim.x - 1) {
-            __threadfence();
-            const float mx = u2f(atomicExch(&g_gs_max, 0u));
-            g_gs_count = 0;
-            float sc = 1.f;
-            if (mx > 0.f && mx < 3.0e38f) sc = exp2f(6.f - ceilf(log2f(mx)));
-            out[0] = fminf(fmaxf(sc, 1.0e-30f), 1.0e30f);
-        }
-    }
-}
-extern "C" int ffno_ffh_grad_scale(const float* g, long n, float* scale_out, void* stream) {
-    if (!g || !scale_out || n <= 0) return FFNO_EINVAL;
-    const int blocks = (int)std::min<long>(256, (n + 4095) / 4096);
-    FFNO_LAUNCH(ffh_grad_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, scale_out);
-    return ffx_launch_status();
+    return fx_bwd_weights_partial<SplitBf3>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, nullptr, nullptr, stream);
 }
 
 // ---- split-fp16 entry points (same operators, masks, partial-slice layout and reduce kernels; own weight packs) ----
@@ -1803,17 +1120,17 @@ extern "C" int ffno_ffh_pack(const ffno_fxpack_desc* descs_dev, int n, int C, in
 }
 extern "C" int ffno_ffh_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1,
                              const float* b1, const void* pk2, const float* b2, float* out, void* mask, int P, int C,
-                             int H, void* stream) {
-    return fx_fwd2<SplitHf2>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, C, H, stream);
+                             int H, const ffno_ff_opts* opts, void* stream) {
+    return fx_fwd2<SplitHf2>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, C, H, opts, stream);
 }
 extern "C" int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
-                                  const void* pk2b, float* ds, int P, int C, int H, const float* grad_scale, void* stream) {
-    return fx_bwd_data2<SplitHf2>(db, db2, db_sum, mask, pk1b, pk2b, ds, P, C, H, grad_scale, stream);
+                                  const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* opts, void* stream) {
+    return fx_bwd_data2<SplitHf2>(db, db2, db_sum, mask, pk1b, pk2b, ds, P, C, H, opts, stream);
 }
 extern "C" int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
                                             const void* pk1b, float* partial, int P, int C, int H, int nsplit,
-                                            const float* grad_scale, void* stream) {
-    return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, grad_scale, stream);
+                                            const uint32_t* s_amax, const uint32_t* db_amax, void* stream) {
+    return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, s_amax, db_amax, stream);
 }
 
 extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,

@@ -526,6 +526,26 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
 
 using namespace ffno;
 
+// one tensor -> its range word (ffno_device.h "range words"): grid-stride maximum, one atomic per workgroup
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, size_t n, unsigned* word) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    range_fold(m, red, 4, word);
+}
+extern "C" int ffno_amax(const float* x, size_t n, uint32_t* word, void* stream) {
+    if (!x || !word || n == 0 || (reinterpret_cast<uintptr_t>(x) & 15u)) return FFNO_EINVAL;
+    const int blocks = (int)std::min<size_t>((size_t)4 * device_cu_count(), (n / 4 + 255) / 256 + 1);
+    FFNO_LAUNCH(amax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, word);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
 extern "C" const char* ffno_build_target(void) {
     return FFNO_BUILD_TARGET;
 }

@@ -51,7 +51,10 @@ struct X3Args {
     int R, L, K;
     LineMap lm;
     int fwd_ck, inv_ck, conj_t, accumulate;
-    const float* rscale;  // device-resident power of two (or NULL = 1): the spectrum tile is held scaled by it (gradient passes)
+    // range words (ffno_device.h): in_amax = max |in| (NULL: the data is known to fit the half format unscaled) -- with fp16x2
+    // packs the spectrum tile is held multiplied by the power of two derived from it; out_amax (optional) receives max |out|
+    const unsigned* in_amax;
+    unsigned* out_amax;
 };
 
 // ---- weight packing --------------------------------------------------------------------------------------------------
@@ -116,10 +119,13 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     const float* __restrict__ in = A.in;
     const int R = A.R, L = A.L, K = A.K;
     const LineMap lm = A.lm;
-    // range scale of the spectrum tile (fp16x2 mix of a gradient pass): applied where phase 1 writes the tile, removed where
-    // phase 3 stores; the saved spectrum stays unscaled
-    const float rs = A.rscale ? *A.rscale : 1.f;
+    // range scale of the spectrum tile (fp16x2 mix): applied where phase 1 writes the tile, removed where phase 3 stores; the
+    // saved spectrum stays unscaled.  |X[k]| <= 2 sqrt(L) max|x| (orthonormal DFT, c_k <= 2): that bound goes to 2^15, so no
+    // finite input can push a split operand of the mix past the half format's 65504.
+    const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
     const float rrs = 1.f / rs;
+    float omax = 0.f;                  // max |out| over what this thread stores
+    __shared__ float rfold[F::NW];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -398,12 +404,14 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                                 o.x += pv.x, o.y += pv.y;
                             }
                             *reinterpret_cast<float2*>(reinterpret_cast<char*>(A.out) + uo + lo) = o;
+                            omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
                         }
                     }
                 }
             }
         }
     }
+    if (A.out_amax) range_fold(omax, rfold, F::NW, A.out_amax);
 }
 
 template <int NL, bool MIXH2>
@@ -451,7 +459,8 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
     s.fwd_ck = a.fwd_ck, s.inv_ck = a.inv_ck, s.conj_t = a.conj_t;      // common to both branches
     s.accumulate = second ? b.accumulate : a.accumulate;
-    s.rscale = a.rscale;                                                // (one gradient pass: one scale)
+    s.in_amax = second ? b.in_amax : a.in_amax;
+    s.out_amax = second ? b.out_amax : a.out_amax;
     spectral_x3_body<NL, MIXH2>(s, idx, (idx & 1) ? skew : 0);
 }
 
@@ -470,6 +479,7 @@ struct X3Stage {
     int R, L, K;
     LineMap lm;
     int accumulate;
+    unsigned* out_amax;   // optional range word of `out` (stage C only)
 };
 
 __device__ __forceinline__ void x3_dft_fwd_body(const X3Stage S, int scale_ck, int bidx, int nblk) {
@@ -620,6 +630,8 @@ __device__ __forceinline__ void x3_dft_inv_body(const X3Stage S, int apply_ck, i
     const int RTtot = (L + 31) >> 5, NP = (RTtot + 1) >> 1;
     const unsigned hoff = (unsigned)(4 * half * es * 4);
     const int nitems = R * NP;
+    float omax = 0.f;
+    __shared__ float rfold[4];
     for (int item = bidx * 4 + wave; item < nitems; item += nblk * 4) {
         const int line = item / NP, rt0 = 2 * (item - line * NP);
         const unsigned lo = (unsigned)((S.lm.base(line) + 2 * j) * 4) + hoff;
@@ -682,10 +694,12 @@ __device__ __forceinline__ void x3_dft_inv_body(const X3Stage S, int apply_ck, i
                         ov.x += pv.x, ov.y += pv.y;
                     }
                     *reinterpret_cast<float2*>(reinterpret_cast<char*>(S.out) + uo + lo) = ov;
+                    omax = fmaxf(omax, fmaxf(fabsf(ov.x), fabsf(ov.y)));
                 }
             }
         }
     }
+    if (S.out_amax) range_fold(omax, rfold, 4, S.out_amax);
 }
 
 // one of two kernel-argument structs, selected field by field (a reference to `second ? b : a` would force an addressable
@@ -705,6 +719,7 @@ __device__ __forceinline__ X3Stage x3_pick(const X3Stage& a, const X3Stage& b, b
     s.lm.line_stride = second ? b.lm.line_stride : a.lm.line_stride;
     s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
     s.accumulate = second ? b.accumulate : a.accumulate;
+    s.out_amax = second ? b.out_amax : a.out_amax;
     return s;
 }
 
@@ -722,9 +737,13 @@ __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage
     x3_dft_inv_body(x3_pick(a, b, second), apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 
-static int g_x3_tile_wgs = 256;      // workgroups of one round (one per CU of an MI355X); ffno_spectral_x3_set_round
-// 8-line tiles while the launch still fits one round of workgroups: more CUs busy, same weight stream per workgroup
-static inline bool x3_small_tiles(int Ra, int Rb) { return (Ra + 7) / 8 + (Rb + 7) / 8 <= g_x3_tile_wgs; }
+// 8-line tiles while the launch still fits one round of workgroups (one per CU of the device): more CUs busy, same weight
+// stream per workgroup; a branch descriptor may force either (tile_lines = 8 / 16; results are bit-identical)
+static inline bool x3_small_tiles(int Ra, int Rb, int tile_lines) {
+    if (tile_lines == 8) return true;
+    if (tile_lines == 16) return false;
+    return (Ra + 7) / 8 + (Rb + 7) / 8 <= device_cu_count();
+}
 
 static inline int x3_status() {
     hipError_t e = hipGetLastError();
@@ -736,12 +755,6 @@ static inline int x3_status() {
 using namespace ffno;
 
 extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && 2 * K <= X3Cfg::KK && L >= 2 && L <= 2048) ? 1 : 0; }
-
-extern "C" int ffno_spectral_x3_set_round(int workgroups) {
-    if (workgroups < 0) return FFNO_EINVAL;
-    g_x3_tile_wgs = workgroups;        // 0: always 16-line tiles
-    return FFNO_OK;
-}
 
 extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
     return (C == X3Cfg::C && K >= 1 && K <= 32 && L >= 2 && L <= 2048) ? 1 : 0;
@@ -769,9 +782,10 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     if (b->K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_x3_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
     if (b->planes_format != FFNO_PLANES_BF16X3 && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EINVAL;
+    if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16) return FFNO_EINVAL;
     a = X3Args{b->in, b->out, b->resid, b->spec_save, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
                make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate,
-               b->range_scale};
+               b->in_amax, b->out_amax};
     return FFNO_OK;
 }
 
@@ -784,7 +798,7 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     const bool h2 = br->planes && br->planes_format == FFNO_PLANES_FP16X2;
     const size_t smem = sizeof(float) * 2 * a.L;
     hipStream_t st = (hipStream_t)stream;
-    if (x3_small_tiles(a.R, 0)) {
+    if (x3_small_tiles(a.R, 0, br->tile_lines)) {
         if (h2)
             FFNO_LAUNCH((spectral_x3_kernel<8, true>), dim3((a.R + 7) / 8), dim3(512), smem, st, a);
         else
@@ -808,9 +822,9 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     rc = x3_args(b, bb, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
     if (rc) return rc;
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
-    // both branches of a pair carry the same kind of planes (or none) and the same range scale
+    // both branches of a pair carry the same kind of planes (or none) and the same tile choice
     if ((ba->planes == nullptr) != (bb->planes == nullptr) || ba->planes_format != bb->planes_format ||
-        ba->range_scale != bb->range_scale)
+        ba->tile_lines != bb->tile_lines)
         return FFNO_EINVAL;
     const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
     hipStream_t st = (hipStream_t)stream;
@@ -823,7 +837,7 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         if ((interleave & 2) && square && ba->B % 8 == 0 && ba->M % NL == 0) return 2 | ((ba->M / NL) << 8);
         return (interleave & 1) ? 1 : 0;
     };
-    if (x3_small_tiles(a.R, b.R)) {
+    if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
         const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
         if (h2)
             FFNO_LAUNCH((spectral_x3_pair_kernel<8, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
@@ -850,7 +864,7 @@ static int x3_stage_args(X3Stage& s, const ffno_fused_branch* b, int C) {
     if (!ffno_spectral_x3_staged_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
     if (b->planes && b->planes_format != FFNO_PLANES_BF16X3) return FFNO_EUNSUPPORTED;     // the stage kernels read bf16x3 packs
     s = X3Stage{b->in, b->out, b->resid, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
-                make_linemap(b->axis, b->B, b->M, b->N, C), b->accumulate};
+                make_linemap(b->axis, b->B, b->M, b->N, C), b->accumulate, nullptr};
     return FFNO_OK;
 }
 
@@ -884,6 +898,7 @@ extern "C" int ffno_spectral_x3_staged_pair(const ffno_fused_branch* ba, const f
     // stage C: spectra -> activations (+ accumulate / residual)
     X3Stage ia = a, ib = b;
     ia.in = ya, ib.in = yb;
+    ia.out_amax = ba->out_amax, ib.out_amax = bb->out_amax;
     const int npa = (((a.L + 31) / 32) + 1) / 2, npb = (((b.L + 31) / 32) + 1) / 2;
     n0 = (int)(((long)a.R * npa + 3) / 4), n1 = (int)(((long)b.R * npb + 3) / 4);
     FFNO_LAUNCH(x3_dft_inv_pair_kernel, dim3(n0 + n1), dim3(256), smem, st, ia, ib, n0, apply_ck_inv);

@@ -197,6 +197,8 @@ class FFNOEngine:
         self.x3_mix_split = os.environ.get("FFNO_X3_MIX_SPLIT", "fp16x2")
         self._x3_fmt = None
         self.x3_min_lines = 1
+        self.x3_tile_lines = 0      # lines per workgroup of the fused x3 kernel: 0 = the library chooses, 8 / 16 = forced (tests)
+        self.ff_max_workgroups = 0  # persistent workgroups of the feed-forward chain kernels: 0 = one per CU
         # paired launch, workgroup -> (branch, tile) map: bit 1 = image-local where the shapes allow it (the workgroups that read
         # one image share an XCD: the image crosses HBM once), else bit 0 = even workgroups branch a, odd ones branch b
         self.x3_interleave = 3
@@ -234,49 +236,63 @@ class FFNOEngine:
         return [w for w in range(n) if w not in pair], pair
 
     def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st, acc0: int = 0,
-              fused: bool = True, x3: bool = False):
+              fused: bool = True, x3: bool = False, rin=None, rout=None):
         """Branches of views v0 and v1 side by side -- ONE launch when both are fused, three paired stage launches else:
-        dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = branch1(src)."""
+        dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = branch1(src).
+        rin / rout: range words of src / of the two outputs (both branches fold into ``rout``)."""
         lib = _lib.get_lib()
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
         if not fused:
             sv0 = save0 if save0 is not None else ws.SD
             sv1 = save1 if save1 is not None else ws.SD2
             ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(sv0), _p(planes0), _p(self._twiddle(v0.L)),
-                                   v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0)
+                                   v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0, 0, 0, None, rout if x3 else None)
             bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(sv1), _p(planes1), _p(self._twiddle(v1.L)),
-                                   v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0)
+                                   v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0, 0, 0, None, rout if x3 else None)
             fn = lib.ffno_spectral_x3_staged_pair if x3 else lib.ffno_spectral_staged_pair      # x3: planes are the packed sets
             self._k("spectral_staged_pair" + ("" if fwd else "(adj)"), fn, ctypes.byref(ba),
                     ctypes.byref(bb), _p(ws.SY), _p(ws.SY2), self.C, ck_f, ck_i, conj, st)
+            if not x3:      # the fp32 stage kernels do not fold their output maxima
+                self._fold(dst0, rout, st)
+                self._fold(dst1, rout, st)
             return
-        fmt, rsc = self._x3_branch_extra(x3 and planes0 is not None, fwd)
-        ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(save0), _p(planes0), _p(self._twiddle(v0.L)),
-                               v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0, fmt, 0, rsc)
-        bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(save1), _p(planes1), _p(self._twiddle(v1.L)),
-                               v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0, fmt, 0, rsc)
+        ba = self._branch(v0, src, dst0, resid0, save0, planes0, acc0, x3, fwd, rin, rout)
+        bb = self._branch(v1, src, dst1, None, save1, planes1, 0, x3, fwd, rin, rout)
         if x3:       # planes0 / planes1 are the packed split-bf16 sets
             self._k(name, lib.ffno_spectral_x3_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj,
                     int(self.x3_interleave), st)
             return
         self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
+        self._fold(dst0, rout, st)
+        self._fold(dst1, rout, st)
 
-    def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True):
-        fmt, rsc = self._x3_branch_extra(x3 and planes is not None, fwd)
+    def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True, rin=None, rout=None):
+        """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
+        fmt = int(bool(x3 and planes is not None and self._x3_h2()))
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc, fmt, 0, rsc)
+                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout if x3 else None)
+
+    # ---- range words (include/ffno.h "Range words"): one uint32 per (tensor kind, layer) in ws.RW ---------------------
+    def _ranged(self) -> bool:
+        """True when some kernel of this configuration cuts operands into fp16 planes (then every producer on the path
+        records its output maximum and every fp16x2 consumer scales from it -- on the device)."""
+        return bool((self._ffx() and self._h2()) or (self.use_x3 and self.spectral == "factorized" and self._x3_h2()))
+
+    def _rw(self, ws, kind: str, l: int):
+        if not self._ranged():
+            return None
+        return ctypes.c_void_p(ws.RW.data_ptr() + 4 * (ws.rw_kinds[kind] * (self.L + 1) + l))
+
+    def _fold(self, t, word, st):
+        """Producers that do not record their output maximum themselves: one more pass over the tensor."""
+        if word is None or t is None:
+            return
+        self._k("amax", _lib.get_lib().ffno_amax, _p(t), t.numel(), word, st)
 
     def _x3_h2(self) -> bool:
         if self.x3_mix_split not in ("fp16x2", "bf16x3"):
             raise ValueError("x3_mix_split must be 'fp16x2' or 'bf16x3', got %r" % (self.x3_mix_split,))
         return self.x3_mix_split == "fp16x2"
-
-    def _x3_branch_extra(self, packed_fused: bool, fwd: bool):
-        """(planes_format, range_scale) of a fused x3 branch: fp16x2 packs when the mix runs on them; gradient passes then keep
-        the spectrum tile scaled by the pass's power of two."""
-        if not (packed_fused and self._x3_h2()):
-            return 0, None
-        return 1, (None if fwd else _p(self._gscale))
 
     def _ffx(self) -> bool:
         return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
@@ -287,26 +303,25 @@ class FFNOEngine:
         return self.ff_split == "fp16x2"
 
     # ---- the split feed-forward kernels of either family (same operators; own weight packs) ----
-    def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st):
+    def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_fwd2 if self._h2() else lib.ffno_ffx_fwd2
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0)
         self._k("ff_fwd", fn, _p(s), _p(s2), _p(s_sum), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out), _p(mask),
-                P, self.C, self.H, st)
+                P, self.C, self.H, ctypes.byref(o), st)
 
-    def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st):
+    def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
-        if self._h2():
-            self._k("ff_bwd_data", lib.ffno_ffh_bwd_data2, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
-                    P, self.C, self.H, _p(self._gscale), st)
-        else:
-            self._k("ff_bwd_data", lib.ffno_ffx_bwd_data2, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
-                    P, self.C, self.H, st)
+        fn = lib.ffno_ffh_bwd_data2 if self._h2() else lib.ffno_ffx_bwd_data2
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0)
+        self._k("ff_bwd_data", fn, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
+                P, self.C, self.H, ctypes.byref(o), st)
 
-    def _ffs_wgrad(self, s, g, l0, b0, part, P, nsplit, st):
+    def _ffs_wgrad(self, s, g, l0, b0, part, P, nsplit, st, rs=None, rg=None):
         lib = _lib.get_lib()
         if self._h2():
             self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0), _p(l0.fx[2]),
-                    _p(part), P, self.C, self.H, nsplit, _p(self._gscale), st)
+                    _p(part), P, self.C, self.H, nsplit, rs, rg, st)
         else:
             self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0), _p(l0.fx[2]),
                     _p(part), P, self.C, self.H, nsplit, st)
@@ -512,6 +527,10 @@ class FFNOEngine:
             ws.SYb = torch.empty(ws.views[0].spec_y, **f32)
             ws.CW = torch.empty(int(lib.ffno_cdft_rows_ws_floats(B, C, self.K, self.K)), **f32)   # first-axis DFT scratch
         ws.mask_words = int(lib.ffno_ff_mask_words(P, H))
+        # range words, one per (tensor kind, layer): x = layer inputs, s = spectral-branch outputs (feed-forward inputs),
+        # g = running gradient (both buffers), d = feed-forward data gradients, t / f = LayerNorm / fork-head gradients
+        ws.rw_kinds = {"x": 0, "s": 1, "g": 2, "d": 3, "t": 4, "f": 5}
+        ws.RW = torch.zeros(len(ws.rw_kinds) * (L + 1), dtype=torch.int32, device=dev)
         if self.layer_norm:
             ws.TL = torch.empty(ns, P, C, **f32)                     # feed-forward outputs before the LayerNorm
             ws.LNS = torch.empty(ns, P, 2, **f32)                    # {mean, rstd} per pixel
@@ -610,32 +629,34 @@ class FFNOEngine:
         return l0, l1, self.params[fc + "layers.0.0.bias"], self.params[fc + "layers.1.0.bias"]
 
     # ---- feed-forward dispatch: split-bf16 kernels (ffx.hip) or the fp32-MFMA kernels (ff.hip) ---------------------
-    def _ff_fwd(self, s, resid, l0, l1, b0, b1, out, hbuf, mask, P, st):
+    def _ff_fwd(self, s, resid, l0, l1, b0, b1, out, hbuf, mask, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         if self._ffx():
-            self._ffs_fwd2(s, None, None, resid, l0, b0, b1, out, mask, P, st)
+            self._ffs_fwd2(s, None, None, resid, l0, b0, b1, out, mask, P, st, rin, rout)
         else:
             self._k("ff_fwd", lib.ffno_ff_fwd, _p(s), _p(resid), _p(l0.weff), _p(b0), _p(l1.weff), _p(b1), _p(out),
                     _p(hbuf), _p(mask), P, self.C, self.H, st)
+            self._fold(out, rout, st)
 
-    def _ff_bwd_data(self, g, mask, l0, l1, dh, ds, P, st):
+    def _ff_bwd_data(self, g, mask, l0, l1, dh, ds, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         if self._ffx():
-            self._ffs_bwd2(g, None, None, mask, l0, ds, P, st)
+            self._ffs_bwd2(g, None, None, mask, l0, ds, P, st, rin, rout)
         else:
             self._k("ff_bwd_data", lib.ffno_ff_bwd_data, _p(g), _p(mask), _p(l0.wt), _p(l1.wt), _p(dh), _p(ds), P,
                     self.C, self.H, st)
+            self._fold(ds, rout, st)
 
-    def _ff_bwd_weights(self, ws, s, g, hbuf, dh, l0, l1, b0, gb0, gb1, accumulate, P, st):
+    def _ff_bwd_weights(self, ws, s, g, hbuf, dh, l0, l1, b0, gb0, gb1, accumulate, P, st, rs=None, rg=None):
         lib = _lib.get_lib()
         C, H = self.C, self.H
         if self._ffx() and ws.defer_reduce:
             assert not accumulate
             part = ws.ffparts[len(ws.red_jobs)]
-            self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st)
+            self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st, rs, rg)
             ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gb0.data_ptr(), gb1.data_ptr()))
         elif self._ffx():
-            self._ffs_wgrad(s, g, l0, b0, ws.ffpart, P, ws.nsplit_ff, st)
+            self._ffs_wgrad(s, g, l0, b0, ws.ffpart, P, ws.nsplit_ff, st, rs, rg)
             self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
                     _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
         else:
@@ -670,8 +691,18 @@ class FFNOEngine:
                      and (self.mode != "full" or self.xplanes[0][w] is not None)) for w, v in enumerate(views)]
 
     def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st,
-                  x3: bool = False):
-        """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint)."""
+                  x3: bool = False, rin=None, rout=None):
+        """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint);
+        rin / rout = range words of src / dst."""
+        if not (fused and x3):
+            self._spectral_plain(name, ws, v, src, dst, resid, save, planes, fwd, accumulate, fused, st)
+            self._fold(dst, rout, st)       # only the x3 kernels record their output maximum themselves
+            return
+        br = self._branch(v, src, dst, resid, save, planes, accumulate, True, fwd, rin, rout)
+        ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
+        self._k(name, _lib.get_lib().ffno_spectral_x3, ctypes.byref(br), self.C, ck_f, ck_i, conj, st)
+
+    def _spectral_plain(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st):
         lib = _lib.get_lib()
         C = self.C
         tw = self._twiddle(v.L)
@@ -694,12 +725,6 @@ class FFNOEngine:
             spec = save if save is not None else ws.SD
             self._k("dct_branch" + ("" if fwd else "(adj)"), lib.ffno_dct_branch, _p(src), _p(dst), resid, _p(spec), _p(ws.SY),
                     _p(planes), _p(self._twiddle(2 * v.L)), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, conj, accumulate, st)
-            return
-        if fused and x3:     # ``planes`` is the packed split-bf16 set
-            fmt, rsc = self._x3_branch_extra(planes is not None, fwd)
-            br = _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(tw), v.Bv, v.Mv, v.Nv, v.K, v.a01, accumulate,
-                                   fmt, 0, rsc)
-            self._k(name, lib.ffno_spectral_x3, ctypes.byref(br), C, ck_f, ck_i, conj, st)
             return
         if fused:
             self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
@@ -750,20 +775,27 @@ class FFNOEngine:
                 lib.ffno_spectral_x3_staged_supported(C, ws.views[w].K, ws.views[w].L)
                 and (not full or self.xplanes[0][w] is not None) for w in pair)
                 and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
+        # (the fp32 pair kernel does not record its output maximum: ranged configurations then take the separate calls)
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
-                           and not self.layer_norm)
+                           and not self.layer_norm and (x3pair or not self._ranged()))
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
             ws.X.zero_()     # F.pad(..., 0) of the lifted features (mesh_3d.py:165)
         self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
                 self.Cin, C, pm, st)
+        rw = self._rw
+        if self._ranged():
+            ws.RW[:2 * (L + 1)].zero_()       # the forward's words: layer inputs (x) and branch outputs (s)
+            self._fold(ws.X, rw(ws, "x", 0), st)
         for l in range(L):
             sv = l if save_for_backward else 0
             last = l == L - 1
             s_l = ws.S[sv]
+            rx, rs_, rxn = rw(ws, "x", l), rw(ws, "s", l), rw(ws, "x", l + 1)
             if self.mode == "no-fourier":
                 s_l.copy_(ws.X)
+                self._fold(s_l, rs_, st)
             else:
                 si = self._fw_sets.index(self.fw_names[l]) if full else 0
                 nwrit = 0
@@ -773,7 +805,8 @@ class FFNOEngine:
                     if fused[w] and not save_for_backward:
                         keep = None
                     self._spectral("spectral_fused", ws, v, ws.X, s_l, None, keep,
-                                   self._planes_for(si, w, 0, x3[w]), True, int(nwrit > 0), fused[w], st, x3=x3[w])
+                                   self._planes_for(si, w, 0, x3[w]), True, int(nwrit > 0), fused[w], st, x3=x3[w],
+                                   rin=rx, rout=rs_)
                     nwrit += 1
                 if conc:
                     a, b = pair
@@ -782,35 +815,40 @@ class FFNOEngine:
                         l0, l1, b0, b1 = self._ff_weights(l)
                         d = _capi.LayerFwdDesc(
                             self._branch(ws.views[a], ws.X, s_l, None, keep[0], self._planes_for(si, a, 0, x3pair), int(nwrit > 0),
-                                         x3pair, True),
-                            self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0, x3pair, True),
+                                         x3pair, True, rx, rs_),
+                            self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0, x3pair, True,
+                                         rx, rs_),
                             int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
                             _p(s_l) if save_for_backward else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
-                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()))
+                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()), rxn)
                         self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
                         continue
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
                                self._planes_for(si, a, 0, x3pair), self._planes_for(si, b, 0, x3pair), True, st,
-                               acc0=int(nwrit > 0), fused=fused[a], x3=x3pair)
+                               acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rx, rout=rs_)
             l0, l1, b0, b1 = self._ff_weights(l)
             # FeedForward(layer_norm=True): the feed-forward writes its raw output, the LayerNorm kernel adds the residual
             ff_out = ws.TL[sv] if self.layer_norm else (ws.Blast if last else ws.X)
             ff_res = None if (self.layer_norm or last) else ws.X
+            ff_rout = None if self.layer_norm else rxn     # (LayerNorm: the next layer's input is the normalised tensor)
             if conc:
                 self._ffs_fwd2(s_l, ws.T, s_l if save_for_backward else None, ff_res, l0, b0, b1, ff_out,
-                               ws.MASK[sv] if save_for_backward else None, P, st)
+                               ws.MASK[sv] if save_for_backward else None, P, st, rs_, ff_rout)
             elif not (self.use_fork and last):    # with fork heads the last layer's backcast only feeds the dead x_L
                 self._ff_fwd(s_l, ff_res, l0, l1, b0, b1, ff_out,
-                             ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st)
+                             ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st,
+                             rs_, ff_rout)
             if self.layer_norm:
                 ln = self.ff_prefix[l] + "layers.1.3."
                 self._k("layernorm_fwd", lib.ffno_layernorm_fwd, _p(ws.TL[sv]), _p(self.params[ln + "weight"]),
                         _p(self.params[ln + "bias"]), None if last else _p(ws.X), _p(ws.Blast if last else ws.X), _p(ws.LNS[sv]),
                         P, C, 1e-5, st)
+                if not last:
+                    self._fold(ws.X, rxn, st)
             if self.use_fork:
                 c0, c1, cb0, cb1 = self._fc_weights(l)
                 self._ff_fwd(s_l, None, c0, c1, cb0, cb1, ws.F[sv], ws.HF[sv] if save_for_backward else None,
-                             ws.MASKF[sv] if save_for_backward else None, P, st)
+                             ws.MASKF[sv] if save_for_backward else None, P, st, rs_, None)
                 self._k("head_fwd", lib.ffno_head_fwd, _p(ws.F[sv]), _p(self.fold), _p(ws.YL[l]), ws.P_in, C, self.O, 0, pm, st)
         if self.use_fork:
             torch.sum(ws.YL, dim=0, out=ws.Y)     # forecast = sum of the per-layer head outputs
@@ -837,12 +875,12 @@ class FFNOEngine:
         C, H, L = self.C, self.H, self.L
         ws = self._workspace(B, S, True)
         st = _lib.current_stream(self.device)
-        if (self._ffx() and self._h2()) or (self.use_x3 and self._x3_h2()):
-            # range scale of the fp16x2 backward kernels: one power of two for the whole pass, taken on the device from the
-            # loss gradient (max |gy| -> [32, 64]; the head and the layers change the magnitude by far less than the 2^10 left)
-            if getattr(self, "_gscale", None) is None or self._gscale.device != gy.device:
-                self._gscale = torch.ones(1, dtype=torch.float32, device=gy.device)
-            self._k("ff_grad_scale", lib.ffno_ffh_grad_scale, _p(gy), gy.numel(), _p(self._gscale), st)
+        rw = self._rw
+        if self._ranged():
+            # the backward's range words (g: running gradient, d: feed-forward data gradients, t / f: LayerNorm / fork heads):
+            # every fp16x2 kernel of the pass scales its operands from the maximum its producer recorded -- per layer, on the
+            # device, so no growth or decay of the gradient through the layers can leave the half format's range
+            ws.RW[2 * (L + 1):].zero_()
         P = ws.P
         full = self.mode == "full"
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
@@ -873,9 +911,11 @@ class FFNOEngine:
                         _p(ws.headpart), _p(ws.red if l == 0 else ws.redl), ws.P_in, C, self.O, ws.nsplit_head, pm, st)
                 if l > 0:
                     self._k("axpy", lib.ffno_axpy, _p(ws.red), _p(ws.redl), 1.0, self.O * (C + 1), st)
+            self._fold(ws.GF, rw(ws, "f", 0), st)
         else:
             self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red),
                     ws.P_in, C, self.O, ws.nsplit_head, pm, st)
+            self._fold(ws.G[cur], rw(ws, "g", L - 1), st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
                 _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
         if not self._ffx():
@@ -884,19 +924,22 @@ class FFNOEngine:
         ws.red_jobs = []
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
                            and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
-                           and self.mode != "no-fourier" and not self.layer_norm)
+                           and self.mode != "no-fourier" and not self.layer_norm and (x3pair or not self._ranged()))
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
             g_in, g_out, dh = ws.G[cur], ws.G[1 - cur], ws.DH[l & 1]
+            # words: gradient entering this layer, its feed-forward input, the data gradient, the gradient it hands on
+            rg, rs_, rd, rgo = rw(ws, "g", l), rw(ws, "s", l), rw(ws, "d", l), (rw(ws, "g", l - 1) if l > 0 else rw(ws, "g", L))
             if self.use_fork:
                 c0, c1, _, _ = self._fc_weights(l)
                 fc = self.fc_prefix[l]
                 ds_f = ws.DS if last else ws.DSF     # last layer: the forecast path is the only contribution to ds
-                self._ff_bwd_data(ws.GF, ws.MASKF[l], c0, c1, dh, ds_f, P, st)
+                rf = rw(ws, "f", 0)
+                self._ff_bwd_data(ws.GF, ws.MASKF[l], c0, c1, dh, ds_f, P, st, rf, rd)
                 self._ff_bwd_weights(ws, ws.S[l], ws.GF, ws.HF[l], dh, c0, c1, self.params[fc + "layers.0.0.bias"],
-                                     gv(fc + "layers.0.0.bias"), gv(fc + "layers.1.0.bias"), int(fc in ff_seen), P, st)
+                                     gv(fc + "layers.0.0.bias"), gv(fc + "layers.1.0.bias"), int(fc in ff_seen), P, st, rs_, rf)
                 ff_seen.add(fc)
             if self.use_fork and last:
                 # x_L is never used with fork heads: the last backcast_ff gets a zero gradient
@@ -908,12 +951,14 @@ class FFNOEngine:
                     ff_seen.add(fp)
                 if self.mode == "no-fourier":
                     g_out.copy_(ws.DS)
+                    self._fold(g_out, rgo, st)
                 else:
                     si = self._fw_sets.index(self.fw_names[l]) if full else 0
                     for w, v in enumerate(ws.views):
                         keep = ws.SDall[w][l] if full else None
                         self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, None, keep,
-                                       self._planes_for(si, w, 1, x3[w]), False, int(w > 0), fused[w], st, x3=x3[w])
+                                       self._planes_for(si, w, 1, x3[w]), False, int(w > 0), fused[w], st, x3=x3[w],
+                                       rin=rd, rout=rgo)
                 cur = 1 - cur
                 continue
             if layer_calls:
@@ -923,12 +968,12 @@ class FFNOEngine:
                 part = ws.ffparts[len(ws.red_jobs)]
                 d = _capi.LayerBwdDesc(
                     self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
-                                 self._planes_for(si, a, 1, x3pair), 0, x3pair, False),
+                                 self._planes_for(si, a, 1, x3pair), 0, x3pair, False, rd, rgo),
                     self._branch(ws.views[b], ws.DS, ws.G1, None, ws.SDall[b][l] if full else None,
-                                 self._planes_for(si, b, 1, x3pair), 0, x3pair, False),
+                                 self._planes_for(si, b, 1, x3pair), 0, x3pair, False, rd, rgo),
                     int(x3pair), int(self.x3_interleave), _p(g_in), _p(ws.G1) if have_g1 else None, _p(g_in), _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
-                    _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, _p(self._gscale) if self._h2() else None)
+                    _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, rg, rs_, rd)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
                 ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
                                     gv(fp + "layers.1.0.bias").data_ptr()))
@@ -945,21 +990,24 @@ class FFNOEngine:
                         _p(g_in), _p(ws.G1) if two else None, _p(g_in) if two else None, _p(ws.DT), _p(ws.lnpart),
                         _p(gv(ln + "weight")), _p(gv(ln + "bias")), P, C, int(fp in ff_seen), st)
                 g_ff = ws.DT
+                rg = rw(ws, "t", l)
+                self._fold(ws.DT, rg, st)
             if conc:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
                 two = bool(have_g1 and not self.layer_norm)
-                self._ffs_bwd2(g_ff, ws.G1 if two else None, g_ff if two else None, ws.MASK[l], l0, ws.DS, P, st)
+                self._ffs_bwd2(g_ff, ws.G1 if two else None, g_ff if two else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
             else:
-                self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st)
+                self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st, rg, rd)
             if use_side:
                 ev_a.record(main_obj)
                 side.wait_event(ev_a)
                 self._issue_stream = side
             self._ff_bwd_weights(ws, ws.S[l], g_ff, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
-                                 gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side)
+                                 gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side, rs_, rg)
             ff_seen.add(fp)
             if self.use_fork:
                 self._k("axpy", lib.ffno_axpy, _p(ws.DS), _p(ws.DSF), 1.0, P * C, st)     # ds = ds(backcast) + ds(forecast)
+                self._fold(ws.DS, rd, st)     # (the word already holds both addends' maxima; the sum may exceed either)
             if use_side:
                 self._issue_stream = None
                 ev_b[l & 1].record(side)
@@ -971,6 +1019,7 @@ class FFNOEngine:
                     g_out.copy_(ws.DS)
                 else:
                     torch.add(g_in, ws.DS, out=g_out)
+                self._fold(g_out, rgo, st)
                 cur = 1 - cur
                 continue
             si = self._fw_sets.index(self.fw_names[l]) if full else 0
@@ -980,14 +1029,14 @@ class FFNOEngine:
                 v = ws.views[w]
                 keep = ws.SDall[w][l] if full else None   # dY of every layer is kept for the dW launch
                 self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, resid if nwrit == 0 else None, keep,
-                               self._planes_for(si, w, 1, x3[w]), False, int(nwrit > 0), fused[w], st, x3=x3[w])
+                               self._planes_for(si, w, 1, x3[w]), False, int(nwrit > 0), fused[w], st, x3=x3[w], rin=rd, rout=rgo)
                 nwrit += 1
             if conc:
                 a, b = pair
                 self._pair("spectral_fused(adj)", ws, ws.views[a], ws.views[b], ws.DS, g_out, ws.G1,
                            resid if nwrit == 0 else None, ws.SDall[a][l] if full else None, ws.SDall[b][l] if full else None,
                            self._planes_for(si, a, 1, x3pair), self._planes_for(si, b, 1, x3pair), False, st,
-                           acc0=int(nwrit > 0), fused=fused[a], x3=x3pair)
+                           acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rd, rout=rgo)
             have_g1 = conc
             cur = 1 - cur
         if conc and have_g1:

@@ -14,6 +14,19 @@
  *     shapes, or a positive hipError_t if a launch failed.  Nothing throws across the ABI.
  *   - activations are channels-last fp32: x[B][M][N][C]; "pixels" P = B*M*N.
  *   - supported widths: C in {32, 64}; hidden H = factor*C in {64, 128, 256} (H % 64 == 0).
+ *   - re-entrant: the library keeps no mutable state (only per-device constants such as the CU count, cached
+ *     after the first query).  Everything that tunes a launch is an argument of that call; everything a
+ *     kernel needs from an earlier kernel travels through caller-owned device memory.
+ *
+ * Range words (the fp16x2 kernels, ffno_ffh_* and FFNO_PLANES_FP16X2)
+ *   A range word is a caller-owned uint32 in DEVICE memory holding the bit pattern of max|x| over a tensor
+ *   (non-negative floats order like their bit patterns).  Producers fold their output maximum into the word
+ *   they are given (`out_amax`: atomic max, one per workgroup) -- the caller zeroes it before the first
+ *   producer of that tensor.  A kernel that cuts an operand into fp16 planes takes the operand's word
+ *   (`in_amax`) and derives, on the device, the power of two that brings the operand into the half format's
+ *   range; its results are divided by it again (exact).  So any finite fp32 tensor is a valid operand -- no
+ *   host round trip, no assumption about magnitudes.  NULL in_amax = "the data is known to lie in
+ *   [2^-12, 2^15]" (no scaling); NULL out_amax = nothing is recorded.  ffno_amax() folds any tensor.
  *
  * Spectrum layout (internal but part of the ABI because callers own the workspaces):
  *   spec[k][r][ri][c]   k = mode (0..K-1), r = line index, ri = 0 real / 1 imag, c = channel
@@ -42,6 +55,9 @@ extern "C" {
 /* library / build identification ("gfx950", or "emu" for the CPU test build) */
 const char* ffno_build_target(void);
 int ffno_abi_version(void);
+
+/* word[0] = max(word[0], bits(max |x[i]|)): folds a tensor into a range word (see "Range words" above) */
+int ffno_amax(const float* x, size_t n, uint32_t* word, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Twiddle table for a transform of length L (host helper, double precision -> fp32):
@@ -149,9 +165,11 @@ typedef struct ffno_fused_branch {
     int32_t K, axis, accumulate;
     /* ffno_spectral_x3* only (the fp32 kernels ignore them; zero = the previous behaviour): */
     int32_t planes_format;  /* FFNO_PLANES_BF16X3 / FFNO_PLANES_FP16X2: how ffno_spectral_x3_pack wrote `planes` */
-    int32_t pad_;
-    const float* range_scale; /* optional DEVICE pointer to a power of two: the spectrum tile is held multiplied by it and the
-                                 outputs divided again (gradient passes with fp16x2 planes: ffno_ffh_grad_scale) */
+    int32_t tile_lines;     /* lines per workgroup of the fused x3 kernel: 0 = the library chooses (8 while the launch fits one
+                               round of workgroups -- one per CU -- else 16), or 8 / 16; results are bit-identical */
+    const uint32_t* in_amax; /* range word of `in` (FP16X2 planes: the spectrum tile is held scaled by the power of two derived
+                                from it -- |X| <= 2 sqrt(L) max|in| goes to 2^15 -- and the outputs are divided again); NULL = 1 */
+    uint32_t* out_amax;      /* optional: receives max |out| of what this branch stores (x3 kernels, fused and staged) */
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
@@ -179,10 +197,6 @@ typedef struct ffno_x3pack_desc {
                             format; the DFT phases keep the bf16 split).  The staged kernels take BF16X3 packs only. */
 } ffno_x3pack_desc;
 int ffno_spectral_x3_supported(int C, int K, int L);
-/* Tile choice of the fused x3 kernels: 8-line workgroups while ceil(Ra/8) + ceil(Rb/8) <= `workgroups` (default 256 = one
- * round on an MI355X: small launches such as a batch-1 rollout step reach twice as many CUs), 16-line workgroups otherwise;
- * 0 = always 16.  Results are bit-identical either way.  Process-wide. */
-int ffno_spectral_x3_set_round(int workgroups);
 size_t ffno_spectral_x3_pack_bytes(int C, int K);
 int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream);
 int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
@@ -228,6 +242,9 @@ typedef struct ffno_layer_fwd_desc {
     void* mask;
     int32_t P, C, H;
     int32_t ff_kernel; /* FFNO_FF_BF16X3 (packs of ffno_ffx_pack) or FFNO_FF_FP16X2 (packs of ffno_ffh_pack) */
+    /* range words: a.in_amax = b.in_amax = word of x; a.out_amax = b.out_amax = word of the branch outputs, which the
+     * feed-forward then reads as its in_amax; out_amax receives max |out| (the next layer's x word).  All optional. */
+    uint32_t* out_amax;
 } ffno_layer_fwd_desc;
 typedef struct ffno_layer_bwd_desc {
     ffno_fused_branch a, b;
@@ -245,7 +262,13 @@ typedef struct ffno_layer_bwd_desc {
     float* partial;
     int32_t nsplit, P, C, H;
     int32_t ff_kernel, pad_;
-    const float* grad_scale; /* FFNO_FF_FP16X2: device-resident power of two (ffno_ffh_grad_scale), NULL = 1 */
+    /* range words (all optional): g_amax = word of g / g2 (both folded into it by their producers) -- read by the data- and
+     * the weight-gradient kernel; s_amax = word of the addends of s (the forward's a.out_amax); ds_amax receives max |ds| and
+     * is what the caller also passes as a.in_amax / b.in_amax of the adjoint branches; a.out_amax / b.out_amax receive the
+     * maxima of the two gradient buffers: the earlier layer's g_amax. */
+    const uint32_t* g_amax;
+    const uint32_t* s_amax;
+    uint32_t* ds_amax;
 } ffno_layer_bwd_desc;
 int ffno_layer_fwd(const ffno_layer_fwd_desc* d, void* stream);
 int ffno_layer_bwd(const ffno_layer_bwd_desc* d, void* stream);
@@ -324,16 +347,16 @@ typedef struct ffno_fxpack_desc {
     int32_t pad_;
 } ffno_fxpack_desc;
 int ffno_ffx_supported(int C, int H);
-/* Schedule of the three feed-forward kernels (process-wide; results identical up to the summation order of db2): bit 0 =
- * forward, bit 1 = backward-data, bit 2 = weight gradients run "role-split" (the two halves of a workgroup one slot apart:
- * a matrix segment on one wave of a SIMD beside a vector / LDS segment on the other); a clear bit = both halves in phase.
- * Bit 3 = forward, bit 4 = backward-data run the software-pipelined kernel instead (GEMM1 one tile ahead, every MFMA group
- * beside vector work of other tiles in the same wave; C = 64 with both addends, the stored sum, residual and sign words
- * present, otherwise the bit is ignored) -- bit-identical results.  Default 1 (forward role-split), from measurements on
- * MI355X (profiles/r02_ffx_sp.md: the pipelined kernels are within noise of the default inside a training step). */
-int ffno_ffx_set_schedule(int schedule);
-/* Persistent workgroups of the forward / backward-data kernel (default 256 = one per CU of an MI355X; process-wide). */
-int ffno_ffx_set_max_workgroups(int n);
+/* Per-call options of the chain kernels (forward / backward-data) of both split families; NULL = all defaults. */
+typedef struct ffno_ff_opts {
+    const uint32_t* in_amax; /* range word of the addends of the input (s / s2, db / db2); used by ffno_ffh_* only */
+    uint32_t* out_amax;      /* optional: receives max |out| (forward: out; backward-data: ds) */
+    int32_t max_workgroups;  /* persistent workgroups; 0 = one per compute unit of the device */
+    int32_t schedule;        /* 0 = the measured default (forward: role-split halves -- a matrix segment on one wave of a SIMD
+                                beside a vector / LDS segment on the other; backward-data: both halves in phase), or
+                                FFNO_FF_SCHED_IN_PHASE for the forward; results are bit-identical */
+} ffno_ff_opts;
+#define FFNO_FF_SCHED_IN_PHASE 1
 size_t ffno_ffx_pack_bytes(int C, int H);
 int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
 int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
@@ -345,9 +368,10 @@ int ffno_ffx_mask_unpack(const void* mask, uint8_t* active, int P, int C, int H,
  * side by side by concurrent launches); with s_sum / db_sum the sum is also stored for the kernels that follow
  * (s_sum may alias s). */
 int ffno_ffx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
-                  const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+                  const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, const ffno_ff_opts* opts,
+                  void* stream);
 int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
-                       const void* pk2b, float* ds, int P, int C, int H, void* stream);
+                       const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* opts, void* stream);
 /* ds = ((db W2) * relu'(.)) W1 ; pk1b / pk2b = the backward packs */
 int ffno_ffx_bwd_data(const float* db, const void* mask, const void* pk1b, const void* pk2b, float* ds,
                       int P, int C, int H, void* stream);
@@ -376,23 +400,26 @@ int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_dev, int n,
  * is folded in with the factor 2^-11).  Half the matrix work and two thirds of the operand traffic of ffno_ffx_*, same
  * operators, shapes (ffno_ffx_supported), sign-bit masks, partial-slice layout and reduce kernels
  * (ffno_ffx_bwd_weights_reduce[_batched]); the weight packs are this family's own (ffno_ffh_pack, same descriptors).
- * RANGE: the representation error of an element is max(2^-24 |x|, 2^-36): fp32-level relative accuracy for
- * 2.4e-4 <= |x| < 65504, a fixed absolute error below (at or above 65504 fp16 overflows to infinity).  Activations and weights of an F-FNO layer are O(1) and need nothing; gradients
- * can be arbitrarily small, so the backward entry points take `grad_scale`: a DEVICE pointer (or NULL = 1) to a positive power
- * of two by which db is multiplied while it is staged (results are divided by it again, exactly).  ffno_ffh_grad_scale
- * derives one from a gradient tensor without a host round trip (max |g| -> [32, 64]; one small launch per backward pass, on
- * the loss gradient).  Without a scale the calls stay valid; accuracy then degrades gradually for |db| < 2.4e-4 (measured
- * 9e-7 at 1e-5).
+ * RANGE: the representation error of an element is max(2^-24 |x|, 2^-36) and the half format ends at 65504, so the kernels
+ * scale what they split: every entry point takes the RANGE WORD of its input (see "Range words" at the top: `opts->in_amax`,
+ * `s_amax`, `db_amax` -- the word bounds EACH addend; the kernels allow for the sum) and multiplies the rows by
+ * 2^e, e chosen on the device so that the bound lands on 2^4, while they are staged; biases are scaled alike, outputs divided
+ * again -- exact, no host round trip.  2^12 of head-room remain for the growth through the first linear map (|h| <= ||W
+ * row||_1 |s| + |b1|); elements down to 2^-16 of the bound keep fp32-level relative accuracy, smaller ones an absolute error of
+ * 2^-40 of the bound.  So activations of 1e6 and gradients of 1e-12 are as good as O(1) data.  The WEIGHTS are split unscaled:
+ * |W| must be below 65504 (they are O(1) in any trainable network).  With a NULL word the data is taken as is (in range:
+ * 2^-12 <= |x| < 2^15 for full accuracy).
  * --------------------------------------------------------------------------------------------- */
 size_t ffno_ffh_pack_bytes(int C, int H);
 int ffno_ffh_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
 int ffno_ffh_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
-                  const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, void* stream);
+                  const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, const ffno_ff_opts* opts,
+                  void* stream);
 int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_sum, const void* mask, const void* pk1b,
-                       const void* pk2b, float* ds, int P, int C, int H, const float* grad_scale, void* stream);
+                       const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* opts, void* stream);
 int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
-                                 float* partial, int P, int C, int H, int nsplit, const float* grad_scale, void* stream);
-int ffno_ffh_grad_scale(const float* g, long n, float* scale_out, void* stream);
+                                 float* partial, int P, int C, int H, int nsplit, const uint32_t* s_amax,
+                                 const uint32_t* db_amax, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),

@@ -39,6 +39,8 @@ inline void sincos_pi(float x, float& s, float& c) {
     s = (float)sin(a), c = (float)cos(a);
 }
 
+static inline int cu_count() { return 256; }      // (the emulator plays an MI355X)
+
 }  // namespace plat
 
 template <class K>

@@ -36,9 +36,9 @@ def engine_relu_masks(engine):
     return {k: [v.cpu().bool()] for k, v in engine.relu_active_sets().items()}
 
 
-def oracle_block_run(kw, seed, B, M, N, dtype=torch.float32, relu_masks=None, io=None):
+def oracle_block_run(kw, seed, B, M, N, dtype=torch.float32, relu_masks=None, io=None, sd_np=None):
     kwf = gu.full_kwargs(kw)
-    sd_np = gu.make_block_state_dict(kw, seed)
+    sd_np = gu.make_block_state_dict(kw, seed) if sd_np is None else sd_np
     x_np, t_np = io if io is not None else gu.make_block_io(kw, seed, B, M, N)
     sd, uniq = torch_state_dict(sd_np, dtype)
     out = orc.ffno2d_block(sd, torch.tensor(x_np, dtype=dtype), modes=kwf["modes"], n_layers=kwf["n_layers"],

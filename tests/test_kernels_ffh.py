@@ -1,12 +1,16 @@
 """fp16x2 feed-forward kernels (ffno_ffh_*, fourierflow_amd/csrc/ffx.hip with the SplitHf2 policy) through the C ABI vs fp64
 numpy references -- on the CPU wave emulator (-m "not gpu") and on the MI355X (-m gpu).  Same operator, masks and tolerance as
 the bf16x3 family (test_kernels_ffx.py); what differs is the operand format, so the range behaviour is tested as well."""
+import ctypes
+
 import numpy as np
 import pytest
 
 from backend_util import be, rel_l2  # noqa: F401
-from fourierflow_amd._capi import FxPackDesc
+from fourierflow_amd._capi import FfOpts, FxPackDesc
 from test_kernels_ff import ff_ref
+
+FFNO_FF_SCHED_IN_PHASE = 1
 
 TOL = 1e-5
 
@@ -47,10 +51,41 @@ def test_split2_pack_layout_and_accuracy(be):
             assert np.all(err[~big] <= 2.0 ** -35)
 
 
-@pytest.mark.parametrize("sched", [0, 1, 2, 3])
+def amax_word(be, *tensors):
+    """A range word holding max |x| over the given host tensors, folded on the device by ffno_amax."""
+    w = be.zeros(1, np.uint32)
+    for t in tensors:
+        assert be.lib.ffno_amax(be.ptr(be.put(t)), t.size, be.ptr(w), None) == 0
+    got = np.asarray(be.get(w)).view(np.uint32)[0]
+    assert got == np.float32(max(np.abs(t).max() for t in tensors)).view(np.uint32)
+    return w
+
+
+def opts(be, in_amax=None, out_amax=None, max_workgroups=0, schedule=0):
+    return FfOpts(be.ptr(in_amax), be.ptr(out_amax), max_workgroups, schedule)
+
+
+def word_value(be, w):
+    return float(np.asarray(be.get(w)).view(np.float32)[0])
+
+
+def test_amax_folds_and_accumulates(be):
+    """ffno_amax: word = max(word, bits(max |x|)) for any length / alignment tail; a second call only raises it."""
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(3)
+    w = be.zeros(1, np.uint32)
+    for n, mag in ((7, 1.0), (4099, 0.5), (20000, 3.0)):
+        x = (rs.standard_normal(n) * mag).astype(np.float32)
+        before = word_value(be, w)
+        assert lib.ffno_amax(p(be.put(x)), n, p(w), None) == 0
+        assert word_value(be, w) == max(before, float(np.abs(x).max()))
+    assert lib.ffno_amax(None, 4, p(w), None) == -1 and lib.ffno_amax(p(w), 0, p(w), None) == -1
+
+
+@pytest.mark.parametrize("sched", [0, FFNO_FF_SCHED_IN_PHASE])
 @pytest.mark.parametrize("P,C,H", [(70, 64, 256), (33, 32, 128), (64, 64, 128), (40, 32, 64), (5000, 64, 256)])
 def test_ffh_fwd_bwd(be, P, C, H, sched):
-    if be.kind == "emu" and (P > 1000 or (sched and (C, H) != (64, 256)) or sched > 1):
+    if be.kind == "emu" and (P > 1000 or (sched and (C, H) != (64, 256))):
         pytest.skip("large case / most of the schedule sweep run on the GPU only")
     lib, p = be.lib, be.ptr
     rs = np.random.RandomState(P + C + H)
@@ -63,48 +98,90 @@ def test_ffh_fwd_bwd(be, P, C, H, sched):
     b2 = (rs.standard_normal(C) * 0.1).astype(np.float32)
     (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
     db1_, db2_ = be.put(b1), be.put(b2)
-    try:
-        assert lib.ffno_ffx_set_schedule(sched) == 0
-        out, ssum = be.put(resid), be.empty((P, C))              # out aliases the residual
-        mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
-        assert lib.ffno_ffh_fwd2(p(be.put(sa)), p(be.put(sb)), p(ssum), p(out), p(a1), p(db1_), p(a2), p(db2_), p(out), p(mask),
-                                 P, C, H, None) == 0
-        ref_out, ref_h = ff_ref(s, resid, W1, b1, W2, b2)
-        assert rel_l2(be.get(out), ref_out) < TOL
-        np.testing.assert_array_equal(be.get(ssum), s)
-        # one addend, no residual, no mask
-        out2 = be.empty((P, C))
-        assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(out2), None, P, C, H, None) == 0
-        assert rel_l2(be.get(out2), ref_out - resid) < TOL
+    out, ssum = be.put(resid), be.empty((P, C))              # out aliases the residual
+    mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+    s_word, out_word = amax_word(be, sa, sb), be.zeros(1, np.uint32)
+    o = opts(be, s_word, out_word, schedule=sched)
+    assert lib.ffno_ffh_fwd2(p(be.put(sa)), p(be.put(sb)), p(ssum), p(out), p(a1), p(db1_), p(a2), p(db2_), p(out), p(mask),
+                             P, C, H, ctypes.byref(o), None) == 0
+    ref_out, ref_h = ff_ref(s, resid, W1, b1, W2, b2)
+    assert rel_l2(be.get(out), ref_out) < TOL
+    np.testing.assert_array_equal(be.get(ssum), s)
+    assert word_value(be, out_word) == float(np.abs(be.get(out)).max())     # the producer recorded its output maximum
+    # one addend, no residual, no mask, no range word (the data is O(1): in range as it is)
+    out2 = be.empty((P, C))
+    assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(out2), None, P, C, H, None, None) == 0
+    assert rel_l2(be.get(out2), ref_out - resid) < TOL
 
-        # backward: tiny gradients, brought into the half range by the power-of-two scale
-        ga, gb = ((rs.standard_normal((P, C)) * 4e-6).astype(np.float32) for _ in range(2))
-        db = ga + gb
-        scale_buf = be.zeros(1)                                   # (kept alive: the kernels read it on the device)
-        assert lib.ffno_ffh_grad_scale(p(be.put(db)), db.size, p(scale_buf), None) == 0
-        sc = float(be.get(scale_buf)[0])
-        assert sc == 2.0 ** round(np.log2(sc)) and 32.0 <= sc * np.abs(db).max() <= 64.0
-        scale = p(scale_buf)
-        gsum, ds = be.empty((P, C)), be.empty((P, C))
-        assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)), p(gsum), p(mask), p(a1b), p(a2b), p(ds), P, C, H, scale, None) == 0
-        np.testing.assert_array_equal(be.get(gsum), db)           # the stored sum is NOT scaled
-        ref_dh = (db.astype(np.float64) @ W2.astype(np.float64)) * (ref_h > 0)
-        ref_ds = ref_dh @ W1.astype(np.float64)
-        assert rel_l2(be.get(ds), ref_ds) < TOL
-        nsplit = 3 if P < 1000 else 64
-        partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
-        assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, scale, None) == 0
-        gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
-        assert lib.ffno_ffx_bwd_weights_reduce(p(partial), p(gW1), p(gW2), p(gb1), p(gb2), C, H, nsplit, 0, None) == 0
-        assert rel_l2(be.get(gW1), ref_dh.T @ s.astype(np.float64)) < TOL
-        assert rel_l2(be.get(gW2), db.astype(np.float64).T @ ref_h) < TOL
-        assert rel_l2(be.get(gb1), ref_dh.sum(0)) < TOL
-        assert rel_l2(be.get(gb2), db.astype(np.float64).sum(0)) < TOL
-        # without the scale the same call still works, only less accurately (documented: gradual below 6e-5)
-        assert lib.ffno_ffh_bwd_data2(p(be.put(db)), None, None, p(mask), p(a1b), p(a2b), p(ds), P, C, H, None, None) == 0
-        assert rel_l2(be.get(ds), ref_ds) < 3e-5
-    finally:
-        lib.ffno_ffx_set_schedule(1)
+    # backward: tiny gradients, brought into the half range through the range word of their producer
+    ga, gb = ((rs.standard_normal((P, C)) * 4e-6).astype(np.float32) for _ in range(2))
+    db = ga + gb
+    g_word, ds_word = amax_word(be, ga, gb), be.zeros(1, np.uint32)
+    o = opts(be, g_word, ds_word)
+    gsum, ds = be.empty((P, C)), be.empty((P, C))
+    assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)), p(gsum), p(mask), p(a1b), p(a2b), p(ds), P, C, H, ctypes.byref(o), None) == 0
+    np.testing.assert_array_equal(be.get(gsum), db)           # the stored sum is NOT scaled
+    ref_dh = (db.astype(np.float64) @ W2.astype(np.float64)) * (ref_h > 0)
+    ref_ds = ref_dh @ W1.astype(np.float64)
+    assert rel_l2(be.get(ds), ref_ds) < TOL
+    assert word_value(be, ds_word) == float(np.abs(be.get(ds)).max())
+    nsplit = 3 if P < 1000 else 64
+    partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
+    assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, p(s_word), p(g_word), None) == 0
+    gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
+    assert lib.ffno_ffx_bwd_weights_reduce(p(partial), p(gW1), p(gW2), p(gb1), p(gb2), C, H, nsplit, 0, None) == 0
+    assert rel_l2(be.get(gW1), ref_dh.T @ s.astype(np.float64)) < TOL
+    assert rel_l2(be.get(gW2), db.astype(np.float64).T @ ref_h) < TOL
+    assert rel_l2(be.get(gb1), ref_dh.sum(0)) < TOL
+    assert rel_l2(be.get(gb2), db.astype(np.float64).sum(0)) < TOL
+    # without a range word the same call still works, only less accurately (documented: gradual below 6e-5)
+    assert lib.ffno_ffh_bwd_data2(p(be.put(db)), None, None, p(mask), p(a1b), p(a2b), p(ds), P, C, H, None, None) == 0
+    assert rel_l2(be.get(ds), ref_ds) < 3e-5
+
+
+@pytest.mark.parametrize("act,grad", [(1e5, 1e4), (1e6, 1e-12), (3e-9, 7e7), (1.0, 1.0)])
+def test_ffh_any_fp32_magnitude_is_in_range(be, act, grad):
+    """activations of 1e5 / 1e6 (>= 65504 used to become inf in the fp16 planes) and gradients of any
+    magnitude -- forward, data gradient and weight gradients stay at the 1e-5 bar of the O(1) case, nothing is inf / nan,
+    because every kernel scales its staged rows from the range word of its input (a power of two derived on the device)."""
+    lib, p = be.lib, be.ptr
+    P, C, H = 70, 64, 256
+    rs = np.random.RandomState(11)
+    sa, sb = ((rs.standard_normal((P, C)) * act).astype(np.float32) for _ in range(2))
+    s = sa + sb
+    resid = (rs.standard_normal((P, C)) * act).astype(np.float32)
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = (rs.standard_normal(H) * 0.1 * act).astype(np.float32)       # a bias that matters at this magnitude
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b2 = (rs.standard_normal(C) * 0.1 * act).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
+    db1_, db2_ = be.put(b1), be.put(b2)
+    out, ssum = be.empty((P, C)), be.empty((P, C))
+    mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+    s_word = amax_word(be, sa, sb)
+    o = opts(be, s_word, None)
+    assert lib.ffno_ffh_fwd2(p(be.put(sa)), p(be.put(sb)), p(ssum), p(be.put(resid)), p(a1), p(db1_), p(a2), p(db2_), p(out), p(mask),
+                             P, C, H, ctypes.byref(o), None) == 0
+    ref_out, ref_h = ff_ref(s, resid, W1, b1, W2, b2)
+    got = be.get(out)
+    assert np.all(np.isfinite(got)) and rel_l2(got, ref_out) < TOL
+    ga, gb = ((rs.standard_normal((P, C)) * grad).astype(np.float32) for _ in range(2))
+    db = ga + gb
+    g_word = amax_word(be, ga, gb)
+    o = opts(be, g_word, None)
+    gsum, ds = be.empty((P, C)), be.empty((P, C))
+    assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)), p(gsum), p(mask), p(a1b), p(a2b), p(ds), P, C, H, ctypes.byref(o), None) == 0
+    ref_dh = (db.astype(np.float64) @ W2.astype(np.float64)) * (ref_h > 0)
+    got = be.get(ds)
+    assert np.all(np.isfinite(got)) and rel_l2(got, ref_dh @ W1.astype(np.float64)) < TOL
+    partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, 3))
+    assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, 3, p(s_word), p(g_word), None) == 0
+    gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
+    assert lib.ffno_ffx_bwd_weights_reduce(p(partial), p(gW1), p(gW2), p(gb1), p(gb2), C, H, 3, 0, None) == 0
+    for got, ref in ((gW1, ref_dh.T @ s.astype(np.float64)), (gW2, db.astype(np.float64).T @ ref_h), (gb1, ref_dh.sum(0)),
+                     (gb2, db.astype(np.float64).sum(0))):
+        g = be.get(got)
+        assert np.all(np.isfinite(g)) and rel_l2(g, ref) < TOL
 
 
 def test_ffh_accuracy_over_the_half_range(be):
@@ -120,7 +197,7 @@ def test_ffh_accuracy_over_the_half_range(be):
     b2 = np.zeros(C, np.float32)
     (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
     out = be.empty((P, C))
-    assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, None, p(a1), p(be.put(b1)), p(a2), p(be.put(b2)), p(out), None, P, C, H, None) == 0
+    assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, None, p(a1), p(be.put(b1)), p(a2), p(be.put(b2)), p(out), None, P, C, H, None, None) == 0
     ref_out, _ = ff_ref(s, None, W1, b1, W2, b2)
     err_rows = np.linalg.norm(be.get(out) - ref_out, axis=1) / np.linalg.norm(ref_out, axis=1)
     assert err_rows.max() < 2e-6, err_rows.max()
@@ -129,25 +206,5 @@ def test_ffh_accuracy_over_the_half_range(be):
 def test_ffh_rejects_bad_arguments(be):
     z = be.zeros(64)
     p = be.ptr
-    assert be.lib.ffno_ffh_fwd2(p(z), None, None, None, p(z), p(z), p(z), p(z), p(z), None, 1, 48, 192, None) == -2
+    assert be.lib.ffno_ffh_fwd2(p(z), None, None, None, p(z), p(z), p(z), p(z), p(z), None, 1, 48, 192, None, None) == -2
     assert be.lib.ffno_ffh_bwd_data2(None, None, None, p(z), p(z), p(z), p(z), 1, 64, 256, None, None) == -1
-    assert be.lib.ffno_ffh_grad_scale(p(z), 0, p(z), None) == -1
-
-
-@pytest.mark.parametrize("n,mag", [(100, 3e-7), (70000, 5.0), (1 << 20, 1e-3)])
-def test_ffh_grad_scale_is_a_power_of_two_and_reusable(be, n, mag):
-    """max |g| * scale lands in [32, 64] whatever the magnitude and the number of workgroups; the kernel's two words of
-    device state are reset by the call (second call with other data gives the other data's scale)."""
-    if be.kind == "emu" and n > 100000:
-        pytest.skip("large reduction runs on the GPU only")
-    lib, p = be.lib, be.ptr
-    rs = np.random.RandomState(n)
-    out = be.zeros(1)
-    for k in range(2):
-        g = (rs.standard_normal(n) * mag * (1 + 7 * k)).astype(np.float32)
-        assert lib.ffno_ffh_grad_scale(p(be.put(g)), n, p(out), None) == 0
-        sc = float(be.get(out)[0])
-        assert sc == 2.0 ** round(np.log2(sc))
-        assert 32.0 <= sc * np.abs(g).max() <= 64.0
-    assert lib.ffno_ffh_grad_scale(p(be.zeros(64)), 64, p(out), None) == 0      # all zeros: scale 1
-    assert float(be.get(out)[0]) == 1.0

@@ -45,7 +45,7 @@ def test_layer_fwd_bwd_equal_the_kernel_level_sequence(be, kernel):
             fn = lib.ffno_spectral_x3_pair if kernel == "x3" else lib.ffno_spectral_fused_pair
             extra = (1,) if kernel == "x3" else ()
             assert fn(ctypes.byref(br[0]), ctypes.byref(br[1]), C, 0, 1, 0, *extra, None) == 0
-            assert lib.ffno_ffx_fwd2(p(s), p(t), p(s), p(dx), p(a1), p(db1), p(a2), p(db2), p(out), p(mask), P, C, H, None) == 0
+            assert lib.ffno_ffx_fwd2(p(s), p(t), p(s), p(dx), p(a1), p(db1), p(a2), p(db2), p(out), p(mask), P, C, H, None, None) == 0
         else:
             d = LayerFwdDesc(br[0], br[1], int(kernel == "x3"), 1, p(a1), p(db1), p(a2), p(db2), p(s), p(dx), p(out), p(mask), P, C, H, 0)
             assert lib.ffno_layer_fwd(ctypes.byref(d), None) == 0
@@ -56,7 +56,7 @@ def test_layer_fwd_bwd_equal_the_kernel_level_sequence(be, kernel):
         ab = [FusedBranch(p(ds), p(gout if i == 0 else g1), p(dg) if i == 0 else None, p(sd[i]), p(planes[i][1]), p(tw[i]), B, M, N, K,
                           i, 0) for i in range(2)]
         if mode == "kernels":
-            assert lib.ffno_ffx_bwd_data2(p(dg), p(dg2), p(dg), p(mask), p(a1b), p(a2b), p(ds), P, C, H, None) == 0
+            assert lib.ffno_ffx_bwd_data2(p(dg), p(dg2), p(dg), p(mask), p(a1b), p(a2b), p(ds), P, C, H, None, None) == 0
             assert lib.ffno_ffx_bwd_weights_partial(p(s), p(dg), p(a1), p(db1), p(a1b), p(part), P, C, H, nsplit, None) == 0
             fn = lib.ffno_spectral_x3_pair if kernel == "x3" else lib.ffno_spectral_fused_pair
             extra = (1,) if kernel == "x3" else ()
