@@ -187,11 +187,12 @@ def git_head():
         return None
 
 
-def cpu_baseline(batch, grid, kw, warm=2, timed=5, threads=None):
+def cpu_baseline(batch, grid, kw, warm=2, timed=5, threads=None, micro=None):
     """The oracle (op-for-op CPU torch restatement of the reference, certified against its golden vectors) timed on this
     box's host cores: same model, batch and synthetic data distribution, whole TRAIN steps (2 warm-up + 5 timed).
     The intra-op thread count is calibrated on the train step at the timed batch (all cores is not the fastest on a
-    256-core box)."""
+    256-core box).  ``micro``: run the step as batch / micro gradient-accumulation chunks (same optimiser step; torch's CPU
+    kernels fall off a cliff above some batch size -- VERDICT r02 weak #9 -- so the baseline is also timed in halves)."""
     from oracle import ffno_oracle as orc
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     sd = orc.init_block_state_dict(modes=kw["modes"], width=kw["width"], input_dim=kw["input_dim"],
@@ -211,9 +212,11 @@ def cpu_baseline(batch, grid, kw, warm=2, timed=5, threads=None):
     def step():
         t0 = time.perf_counter()
         opt.zero_grad()
-        out = orc.ffno2d_block(sd, x, modes=kw["modes"], n_layers=kw["n_layers"])["forecast"]
-        loss = orc.lp_rel_loss(out, y)
-        loss.backward()
+        mb = micro or batch
+        for i in range(0, batch, mb):
+            out = orc.ffno2d_block(sd, x[i:i + mb], modes=kw["modes"], n_layers=kw["n_layers"])["forecast"]
+            loss = orc.lp_rel_loss(out, y[i:i + mb]) * (min(mb, batch - i) / batch)
+            loss.backward()
         opt.step()
         sch.step()
         return time.perf_counter() - t0
@@ -245,7 +248,8 @@ def cpu_baseline(batch, grid, kw, warm=2, timed=5, threads=None):
                 s_per_step=round(dt, 3), samples_per_s=round(batch / dt, 2), ms_per_forward=round(1e3 * f, 1),
                 thread_calibration_s_per_step=calib,
                 sample=f"oracle (CPU torch restatement of the reference op sequence, pinned to its golden vectors) "
-                       f"train step, same model / batch ({batch}, {grid}x{grid}, fp32): {warm} warm-up + {timed} timed steps on "
+                       f"train step, same model / batch ({batch}{' as chunks of %d' % micro if micro else ''}, {grid}x{grid}, fp32): "
+                       f"{warm} warm-up + {timed} timed steps on "
                        f"{threads} threads (best of a thread-count calibration on the train step itself)")
 
 
@@ -315,7 +319,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (weak scaling: the global batch is batch x gpus)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fix the GLOBAL batch (e.g. 256 = BASELINE config 2) and give every rank global/gpus samples")
     ap.add_argument("--grid", type=int, default=64)
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--modes", type=int, default=16)
@@ -329,16 +335,39 @@ def main():
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as ONE command: re-launch ourselves as N ranks (one process per GPU) under
+        # torch.distributed.run on this node -- the same command line the driver would type -- and hand its output through.
+        # (The counterpart of Lightning spawning its DDP ranks: fourierflow/commands/train.py:83-84.)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on these hosts
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("self-launch: " + " ".join(cmd))
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
+    if args.global_batch:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of --gpus {world}")
+        args.batch = args.global_batch // world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rccl_world = 1
     if world > 1:
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        probe_t = torch.ones(1, device=dev)                    # the world size as RCCL itself counts it: a sum of ones
+        torch.distributed.all_reduce(probe_t)
+        rccl_world = int(probe_t.item())
+        assert rccl_world == world, (rccl_world, world)
 
     from fourierflow_amd import _lib as _fl
     from fourierflow_amd.modules import FNOFactorized2DBlock, FNOPlus2DBlock
@@ -492,7 +521,11 @@ def main():
                                  f"launches per step), nothing subtracted; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from "
                                  f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE), "
                                  f"taken at the git head named in traffic_source")
-        steps_per_s = world * args.steps / elapsed
+        strong = bool(args.global_batch)
+        opt_steps_per_s = args.steps / elapsed                    # optimiser steps of the GLOBAL batch (B x world samples each)
+        # weak scaling: per-GPU-batch steps summed over ranks (= N x optimiser steps/s: what the driver divides by N x the
+        # one-GPU value); strong scaling (--global-batch): the global batch is fixed, so optimiser steps/s is the figure
+        steps_per_s = opt_steps_per_s if strong else world * args.steps / elapsed
         # the same step on the all-bf16x3 arithmetic (three bf16 planes, six MFMAs per product block everywhere: the round-1 /
         # early round-2 numerics), timed the same way right here, so that the line carries both
         variants = None
@@ -524,6 +557,22 @@ def main():
                 cpu19 = cpu_baseline(19, G, kw, warm=1, timed=2, threads=cpu["cores"])
                 cpu["batch19"] = dict(value=cpu19["value"], s_per_step=cpu19["s_per_step"], samples_per_s=cpu19["samples_per_s"],
                                       sample="same oracle, batch 19 (the reference config's batch size), 1 warm-up + 2 timed steps")
+            if B >= 32 and B % 2 == 0:   # the same batch as two half-batch passes + one optimiser step (no large-batch cliff)
+                half = cpu_baseline(B, G, kw, warm=1, timed=2, threads=cpu["cores"], micro=B // 2)
+                cpu["as_two_half_batches"] = dict(value=half["value"], s_per_step=half["s_per_step"],
+                                                  samples_per_s=half["samples_per_s"], sample=half["sample"])
+            # the figure the GPU is compared with: the BEST samples/s the CPU restatement reached in any of these forms
+            forms = {"batch %d in one pass" % B: cpu["samples_per_s"]}
+            if cpu19:
+                forms["batch 19 (the reference's)"] = cpu19["samples_per_s"]
+            if "as_two_half_batches" in cpu:
+                forms["batch %d as two halves" % B] = cpu["as_two_half_batches"]["samples_per_s"]
+            best = max(forms, key=forms.get)
+            cpu["samples_per_s_by_form"] = forms
+            cpu["best_form"], cpu["best_samples_per_s"] = best, forms[best]
+            cpu["one_pass_steps_per_s"] = cpu["value"]
+            cpu["value"] = round(forms[best] / B, 4)          # steps/s-equivalent at this batch, from the best form
+            cpu["unit"] = "steps/s at batch %d (best CPU form: %s)" % (B, best)
         secondary = None
         if headline and world == 1 and not args.no_secondary:
             log("secondary workloads (256x256 and 64^3)")
@@ -537,16 +586,21 @@ def main():
                 ver = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception:  # noqa: BLE001
                 ver = None
-            dist_info = dict(world_size=world, backend=torch.distributed.get_backend(), rccl_version=ver,
-                             hip=torch.version.hip)
+            dist_info = dict(world_size=torch.distributed.get_world_size(), world_size_counted_by_all_reduce=rccl_world,
+                             backend=torch.distributed.get_backend(), rccl_version=ver, hip=torch.version.hip,
+                             launch="one process per GPU (torch.distributed.run; `python bench.py --gpus N` spawns them itself)")
         out = {
             "metric": ("training-steps/sec (whole node), FNOPlus2DBlock %dL %dx%d modes %d" % (args.layers, G, G, K) if args.plus else
                        "training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)"
                        if (G, args.layers, K) == (64, 24, 16) else
                        "training-steps/sec (whole node), F-FNO %dL %dx%d modes %d" % (args.layers, G, G, K)),
-            "value": round(steps_per_s, 3), "unit": "steps/s (per-GPU batch %d, summed over ranks)" % B,
+            "value": round(steps_per_s, 3),
+            "unit": ("optimiser steps/s at global batch %d" % (B * world)) if strong else
+                    ("steps/s (per-GPU batch %d, summed over ranks)" % B),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
+            "optimizer_steps_per_s": round(opt_steps_per_s, 3),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic N(0,1) inputs/targets, reference-init weights",
             "config": {"workload": "%s train step: FNOFactorized2DBlock(modes=%d,width=64,"
                                    "n_layers=%d,input_dim=3,share_weight,factor=4,weight_norm) %dx%d, fp32"
@@ -565,14 +619,15 @@ def main():
                                          "v_mfma_f32_32x32x16_f16 (measured 7.5e-8 rel-L2 vs fp64, fp32 MFMA: 1.5e-7)"
                                          if trainer.engine.ff_split == "fp16x2" else "the same three-plane bf16 split"),
                        "ff_split": trainer.engine.ff_split},
-            "samples_per_s": round(steps_per_s * B, 1), "ms_per_forward": round(ms_fwd, 3),
+            "samples_per_s": round(opt_steps_per_s * B * world, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5), "git_head": git_head(),
             "roofline": roofline, "kernels": kernels, "arithmetic_variants_steps_per_s": variants, "cpu_baseline": cpu,
             "secondary": secondary, "distributed": dist_info,
         }
         if cpu:
-            out["speedup_vs_cpu_baseline"] = round(steps_per_s / cpu["value"], 1)
+            # samples/s against the best CPU form (not against the large-batch one-pass figure, which a torch-CPU cliff depresses)
+            out["speedup_vs_cpu_baseline"] = round(opt_steps_per_s * B * world / cpu["best_samples_per_s"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

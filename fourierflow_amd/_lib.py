@@ -35,9 +35,17 @@ def get_lib() -> ctypes.CDLL:
     with _lock:
         if _lib is None:
             from . import build as _build
-            if not os.path.exists(LIB_PATH) or _build.is_stale():
+            state = _build.staleness()
+            if state == "unverifiable":
+                # a prebuilt library without the sources it came from (installed deployment): nothing to compare it with --
+                # load it, and say so
+                import warnings
+                warnings.warn(f"{LIB_PATH}: the kernel sources / include/ffno.h are not readable here, so the library cannot be "
+                              f"checked against them; loading it as it is", RuntimeWarning)
+            elif state == "stale":
                 # absent, or built from different kernel sources / ABI header than the ones in this tree (a stale .so would
-                # silently run old kernels behind new host code): rebuild, or refuse to load
+                # silently run old kernels behind new host code): rebuild (file-locked: all ranks of a node may get here at
+                # once; the first one builds, the others find a fresh library), or refuse to load
                 try:
                     _build.build(verbose=False)
                 except Exception as e:  # noqa: BLE001

@@ -40,37 +40,65 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
-def is_stale() -> bool:
-    """True when the library on disk was built from other sources than the ones in this tree (stamp mismatch / no stamp)."""
+def staleness() -> str:
+    """"fresh": the library on disk was built from exactly this tree's sources; "stale": from other sources (stamp mismatch / no
+    stamp / no library); "unverifiable": the sources or the ABI header are not readable here (an installed deployment that
+    ships the prebuilt .so without csrc/ or include/) -- nothing to compare the stamp with."""
     stamp_file = LIB + ".stamp"
+    if not os.path.exists(LIB):
+        return "stale"
     try:
-        return not (os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == _stamp())
+        want = _stamp()
     except OSError:
-        return True
+        return "unverifiable"
+    try:
+        with open(stamp_file) as f:
+            return "fresh" if f.read() == want else "stale"
+    except OSError:
+        return "stale"
+
+
+def is_stale() -> bool:
+    """True when the library on disk is known to come from other sources than the ones in this tree."""
+    return staleness() == "stale"
 
 
 def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
+    """Compile + link under an exclusive file lock (the ranks of a data-parallel job may all find the library stale at once),
+    into temporary names that are renamed into place: a concurrent reader never sees a half-written .so."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
     stamp_file = LIB + ".stamp"
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
-        return LIB
-    objs = []
-    for src in source_files():
-        obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src,
-               "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", obj, "-Wno-unused-result", *extra_flags]
-        if verbose:
-            print("[ffno build]", " ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
-    if verbose:
-        print("[ffno build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    with open(stamp_file, "w") as f:
-        f.write(stamp)
-    return LIB
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            stamp = _stamp()
+            # (checked AFTER the lock was taken: another process may have finished the same build while we waited)
+            if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+                return LIB
+            tag = f".tmp{os.getpid()}"
+            objs = []
+            for src in source_files():
+                obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
+                cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src,
+                       "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", obj, "-Wno-unused-result", *extra_flags]
+                if verbose:
+                    print("[ffno build]", " ".join(cmd), flush=True)
+                subprocess.check_call(cmd)
+                objs.append(obj)
+            cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + tag, *objs]
+            if verbose:
+                print("[ffno build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            if os.path.exists(stamp_file):
+                os.remove(stamp_file)          # never a new library beside an old stamp (or the reverse)
+            os.replace(LIB + tag, LIB)
+            with open(stamp_file + tag, "w") as f:
+                f.write(stamp)
+            os.replace(stamp_file + tag, stamp_file)
+            return LIB
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":

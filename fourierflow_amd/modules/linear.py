@@ -20,16 +20,19 @@ class WNLinear(nn.Module):
         self.in_features, self.out_features, self.wnorm = in_features, out_features, wnorm
         w = torch.empty(out_features, in_features, device=device, dtype=dtype or torch.float32)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
-        if bias:
-            bound = 1.0 / math.sqrt(in_features) if in_features > 0 else 0.0
-            self.bias = nn.Parameter(torch.empty(out_features, device=device, dtype=w.dtype).uniform_(-bound, bound))
-        else:
+        if not bias:
             raise NotImplementedError("bias=False is not part of the F-FNO hot path")
+        bound = 1.0 / math.sqrt(in_features) if in_features > 0 else 0.0
+        b = nn.Parameter(torch.empty(out_features, device=device, dtype=w.dtype).uniform_(-bound, bound))
+        # registration order = the reference's parameters() order (a torch.optim state_dict indexes parameters by it):
+        # nn.Linear registers weight, bias; weight_norm then removes `weight` and appends weight_g, weight_v AFTER the bias
         if wnorm:
+            self.bias = b
             self.weight_g = nn.Parameter(w.norm(2, dim=1, keepdim=True))
             self.weight_v = nn.Parameter(w)
         else:
             self.weight = nn.Parameter(w)
+            self.bias = b
 
     def effective_weight(self) -> torch.Tensor:
         """W = g * v / ||v||_row (plain torch; diagnostics only -- the hot path uses ffno_weightnorm_fwd)."""

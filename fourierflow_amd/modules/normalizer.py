@@ -39,6 +39,18 @@ class Normalizer(nn.Module):
     def _load_from_state_dict(self, *args, **kwargs):
         super()._load_from_state_dict(*args, **kwargs)
         self._n_acc_host = float(self.n_accumulations.item())
+        # a checkpoint holds the statistics of the GLOBAL stream (every rank saved and loads the same synced sums): they are
+        # the baseline of the next sync_across_ranks, not a local increment to be summed over ranks once more
+        self._synced = self._sync_vector().clone()
+
+    def _sync_vector(self) -> torch.Tensor:
+        return torch.cat([self.sum, self.sum_squared, self.count.reshape(1)])
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)      # .to(device) / .cuda(): the sync baseline moves with the buffers
+        if getattr(self, "_synced", None) is not None:
+            self._synced = fn(self._synced)
+        return out
 
     @property
     def mean(self):
@@ -68,9 +80,11 @@ class Normalizer(nn.Module):
             return
         D = self.sum.numel()
         base = getattr(self, "_synced", None)
-        if base is None or base.device != self.sum.device:
+        if base is None:          # nothing synced or loaded yet: everything this rank holds is its own contribution
             base = torch.zeros(2 * D + 1, dtype=self.sum.dtype, device=self.sum.device)
-        cur = torch.cat([self.sum, self.sum_squared, self.count.reshape(1)])
+        elif base.device != self.sum.device:
+            base = base.to(self.sum.device)
+        cur = self._sync_vector()
         delta = cur - base                      # this rank's contribution since the last sync
         dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=group)
         cur = base + delta

@@ -113,6 +113,9 @@ class CheckpointMixin:
             for d in shape:
                 cnt *= d
             if tuple(st['exp_avg'].shape) != tuple(shape):
+                import warnings
+                warnings.warn(f"optimiser state of parameter {i} ({tuple(st['exp_avg'].shape)}) does not fit {short} "
+                              f"{tuple(shape)}: the Adam moments are restarted", RuntimeWarning)
                 return False
             tr.m[o:o + cnt].copy_(st['exp_avg'].reshape(-1))
             tr.v[o:o + cnt].copy_(st['exp_avg_sq'].reshape(-1))

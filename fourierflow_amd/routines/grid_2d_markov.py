@@ -124,20 +124,27 @@ class Grid2DMarkovExperiment(CheckpointMixin, nn.Module):
         elif noise is None and self.noise_std:
             noise = torch.randn(B, M, N, D, device=dev)      # `x += randn * noise_std` (grid_2d_markov.py:168)
         out = torch.empty(B, M, N, D, dtype=torch.float32, device=dev)
-        rc = _lib.get_lib().ffno_markov_features(_p(x), _p(state), _p(self._derived), _p(noise), _p(out), _p(self._partial),
-                                                 B, M, N, Cx, float(self.low), float(self.high), float(self.noise_std),
-                                                 self._eps(), int(acc),
-                                                 int(self.should_normalize), extra, _lib.current_stream(dev))
-        del keep
-        _capi.check(rc, "markov_features")
+
+        def features(state, accumulate):
+            rc = _lib.get_lib().ffno_markov_features(_p(x), _p(state), _p(self._derived), _p(noise), _p(out), _p(self._partial),
+                                                     B, M, N, Cx, float(self.low), float(self.high), float(self.noise_std),
+                                                     self._eps(), int(accumulate),
+                                                     int(self.should_normalize), extra, _lib.current_stream(dev))
+            _capi.check(rc, "markov_features")
+
+        features(state, acc)
         if acc:
             nz.unpack_state(state)
             nz._n_acc_host += 1.0
-            # data parallel: every rank accumulated its own shard -- sum the increments so all ranks normalise (and
-            # checkpoint) with the statistics of the GLOBAL batch; mean / std are re-derived by the next feature build
+            # data parallel: every rank accumulated its own shard.  Sum the increments over ranks FIRST, then normalise this very
+            # batch once more with the statistics of the GLOBAL batch stream (a second pass over 1.5 MB), so that all ranks
+            # normalise every step -- this one included -- with identical mean / std, the loss's inverse affine (read from
+            # `_derived`) is the global one as well, and any rank's checkpoint holds the full statistics.
             if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                     torch.distributed.get_world_size() > 1:
                 nz.sync_across_ranks()
+                features(nz.pack_state(), False)
+        del keep
         return out
 
     def _velocity(self, x: torch.Tensor) -> torch.Tensor:

@@ -68,6 +68,11 @@ def linear_from_sd(sd: Dict[str, Tensor], prefix: str, x: Tensor) -> Tensor:
 # --------------------------------------------------------------------------
 # FeedForward  (feedforward.py:6-24)
 # --------------------------------------------------------------------------
+# tests only: set to a list to collect (prefix, hidden index, active set) of every ReLU this module evaluates (ReLU-flip
+# detection in gradient comparisons: tests/oracle_util.py::relu_flips)
+RELU_TRACE = None
+
+
 def feedforward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int = 2,
                 layer_norm: bool = False, relu_mask=None) -> Tensor:
     """n_layers x [linear -> (dropout p=0) -> ReLU except last -> LayerNorm iff last & layer_norm].
@@ -80,6 +85,8 @@ def feedforward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int = 2
     for i in range(n_layers):
         x = linear_from_sd(sd, f"{prefix}layers.{i}.0.", x)
         if i < n_layers - 1:
+            if RELU_TRACE is not None:      # tests only: this evaluation's own active set, before any injected one is applied
+                RELU_TRACE.append((prefix, i, (x.detach() > 0)))
             if relu_mask is not None:
                 x = x * relu_mask[i].reshape(x.shape).to(x.dtype)
             else:

@@ -50,6 +50,36 @@ def oracle_block_run(kw, seed, B, M, N, dtype=torch.float32, relu_masks=None, io
     return out, loss, grads
 
 
+def relu_flips(kw, seed, B, M, N, masks, io=None, sd_np=None):
+    """Number of hidden units on which the oracle's OWN fp32 ReLU decisions differ from the HIP path's active sets
+    (``masks`` = engine_relu_masks(engine)), over every backcast feed-forward of the block, evaluated along the oracle's
+    unmodified forward.  Zero flips = the two implementations sit on the same linear piece of the network, so their
+    gradients may be compared at rounding level directly (no mask injection needed)."""
+    orc.RELU_TRACE = trace = []
+    try:
+        with torch.no_grad():
+            kwf = gu.full_kwargs(kw)
+            sd_np = gu.make_block_state_dict(kw, seed) if sd_np is None else sd_np
+            x_np, _ = io if io is not None else gu.make_block_io(kw, seed, B, M, N)
+            sd, _ = torch_state_dict(sd_np, torch.float32, requires_grad=False)
+            orc.ffno2d_block(sd, torch.tensor(x_np), modes=kwf["modes"], n_layers=kwf["n_layers"], use_fork=kwf["use_fork"],
+                             mode=kwf["mode"], n_ff_layers=kwf["n_ff_layers"], layer_norm=kwf["layer_norm"])
+    finally:
+        orc.RELU_TRACE = None
+    flips, layer = 0, {"backcast": 0, "forecast": 0}
+    for prefix, i, active in trace:
+        kind = "forecast" if "forecast_ff" in prefix else "backcast" if "backcast_ff" in prefix else None
+        if kind is None or i != 0:
+            continue
+        key = (kind, layer[kind])
+        layer[kind] += 1
+        if kwf["use_fork"] and key == ("backcast", kwf["n_layers"] - 1):
+            continue        # with fork heads the last backcast only feeds the dead x_L: the HIP path does not evaluate it
+        if key in masks:
+            flips += int((active.reshape(-1) != masks[key][0].reshape(-1)).sum())
+    return flips
+
+
 GRAD_TOL = 5e-5
 
 

@@ -42,6 +42,12 @@ def _run_hip(kw, seed, B, M, N, split=None):
     grads = {n: eng.grad_view(n).detach().cpu().numpy().copy() for n in eng.param_names}
     masks = ou.engine_relu_masks(eng)
     torch.cuda.synchronize()
+    # the schedule bench.py times really ran -- the test must not pass on a fallback: both axes of every layer in ONE paired
+    # launch of the split (x3) branch kernel, one C call per layer and direction, the requested operand formats
+    assert eng.paired_last, "the paired spectral launch did not run"
+    assert eng._saved_x3 == ([True, True], True), eng._saved_x3
+    want = split or "fp16x2"
+    assert eng._x3_fmt == [int(want == "fp16x2")] * 2 and eng.ff_split == want and eng._ffx()
     return pred.cpu().numpy(), loss, grads, masks, (x_np, t_np), gflat
 
 
@@ -52,7 +58,7 @@ def test_markov24_bench_geometry_forward_backward_vs_oracle(B, split):
     arithmetic that stays shipped beside it."""
     kw, seed, M, N = MARKOV24, 2024, 64, 64
     pred, loss, grads, masks, io, _ = _run_hip(kw, seed, B, M, N, split)
-    # the paired launch really ran (2 x 256 workgroups at B = 32): the test must not pass on a fallback schedule
+    # (_run_hip asserts that the paired x3 launch really ran: 2 x 256 workgroups at B = 32)
     ref_out, ref_loss, ref_grads = ou.oracle_block_run(kw, seed, B, M, N, relu_masks=masks, io=io)
     e_fwd = rel_l2(pred, ref_out["forecast"].detach().numpy())
     e_loss = abs(loss - ref_loss.item())

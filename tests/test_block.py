@@ -74,17 +74,32 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
         p = named[n[5:]]
         assert p.grad is not None, n
         errs[n] = gu.compare_packed(g, n, p.grad.cpu().numpy(), 1e-5)
-    # Gradients are DIScontinuous in fp32 rounding: a pre-activation within an ulp of 0 flips its ReLU bit
-    # between any two correct implementations (observed: one flipped bit of 262144 moves the gradients of
-    # that layer and of the layers below by ~1e-3 rel. on a 1024-pixel batch).  So: every parameter within
-    # 3e-3 and the median below 3e-4 (a flip perturbs only the layers below it, and by ~1/sqrt(pixels)).  The kernels themselves are held to 1e-5 against fp64
-    # in tests/test_kernels_*.py, where no such discontinuity exists.
+    # Gradients are DIScontinuous in fp32 rounding: a pre-activation within an ulp of 0 flips its ReLU bit between any two
+    # correct implementations (observed: one flipped bit of 262144 moves the gradients of that layer and of the layers below
+    # by ~1e-3 rel. on a 1024-pixel batch).  So the bar against the reference's golden gradients depends on whether a flip
+    # happened, which is DETECTED (the oracle, pinned to the same goldens, re-evaluates its own ReLU decisions and they are
+    # compared with the HIP path's active sets):
+    #   no flip   -> every gradient at rounding level: 5e-5 (observed 5e-7 .. 8e-6; 1.2e-6 on the 24-layer golden);
+    #   flip(s)   -> the wide band: every parameter within 3e-3, median below 3e-4 (a flip perturbs only the layers below
+    #                it, and by ~1/sqrt(pixels)).
+    import oracle_util as ou
+    flips = ou.relu_flips(kw, seed, B, M, N, ou.engine_relu_masks(blk.engine())) if blk.engine()._ffx() else None
     worst = max(errs, key=errs.get)
-    assert errs[worst] < 3e-3, (worst, errs[worst])
-    assert float(np.median(list(errs.values()))) < 3e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    if flips == 0:
+        g64 = None
+        for n, e in errs.items():
+            if e >= ou.GRAD_TOL:      # sums with heavy cancellation (head / fork biases of the small fixtures): see oracle_util
+                g64 = g64 or ou.oracle_block_run(kw, seed, B, M, N, dtype=torch.float64)[2]
+                g32 = ou.oracle_block_run(kw, seed, B, M, N)[2]
+                noise = ou._rel(g32[n[5:]], g64[n[5:]])
+                assert ou._rel(named[n[5:]].grad.cpu().numpy(), g64[n[5:]]) < max(ou.GRAD_TOL, 4 * noise), (n, e, noise)
+    else:
+        assert errs[worst] < 3e-3, (worst, errs[worst], flips)
+        assert float(np.median(list(errs.values()))) < 3e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f"[block {tag}] ReLU flips vs the oracle's own decisions: {flips}; worst gradient vs reference golden "
+          f"{errs[worst]:.2e} ({worst})")
     # ... and WITHOUT the discontinuity: the oracle (pinned to the same reference goldens) evaluated on the HIP path's
     # ReLU active sets must agree with every gradient at rounding level.
-    import oracle_util as ou
     eng = blk.engine()
     masks = ou.engine_relu_masks(eng)
     label = f"block {tag} {('x3' if fused else 'x3staged') if x3 else 'fused' if fused else 'staged'} {host_device}"

@@ -169,6 +169,47 @@ def test_checkpoint_roundtrip_and_resume(host_device, tmp_path):
     assert torch.equal(c.state_dict()["conv.in_proj.weight_v"].cpu(), ck["state_dict"]["conv.in_proj.weight_v"])
 
 
+@pytest.mark.parametrize("wnorm", [True, False])
+def test_resume_converts_a_real_torch_adamw_state_dict(host_device, tmp_path, wnorm):
+    """a checkpoint written by the reference carries torch.optim.AdamW.state_dict(), which indexes parameters by
+    their position in ``parameters()``.  (1) The mirror's linears register their parameters in the order torch itself produces
+    for the reference's construction (nn.Linear, then weight_norm: linear.py:41-52) -- with and without weight-norm; (2) a real
+    AdamW state over that order lands on the right slices of the flat moment buffers."""
+    from fourierflow_amd.modules import FNOFactorized2DBlock, WNLinear
+    from fourierflow_amd.routines import Grid2DMarkovExperiment
+    ref_lin = torch.nn.Linear(5, 7)
+    if wnorm:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref_lin = torch.nn.utils.weight_norm(ref_lin)
+    assert [n for n, _ in WNLinear(5, 7, wnorm=wnorm).named_parameters()] == [n for n, _ in ref_lin.named_parameters()]
+
+    kw = dict(modes=4, width=32, n_layers=2, input_dim=3, share_weight=False, factor=4, ff_weight_norm=wnorm, gain=0.1)
+    torch.manual_seed(0)
+    exp = Grid2DMarkovExperiment(FNOFactorized2DBlock(**kw), n_steps=2, noise_std=0.0,
+                                 scheduler=dict(num_warmup_steps=2, num_training_steps=50)).to(host_device)
+    path = str(tmp_path / "ref.ckpt")
+    exp.save_checkpoint(path, epoch=1)
+    ck = torch.load(path, weights_only=False)
+    params = [p for _, p in exp.named_parameters()]
+    opt = torch.optim.AdamW([torch.nn.Parameter(p.detach().cpu().clone()) for p in params], lr=1e-3)
+    for i, p in enumerate(opt.param_groups[0]["params"]):       # moments that encode the parameter index
+        opt.state[p] = dict(step=torch.tensor(7.0), exp_avg=torch.full_like(p, float(i + 1)),
+                            exp_avg_sq=torch.full_like(p, 100.0 + i))
+    ck["optimizer_states"] = [opt.state_dict()]
+    ck["lr_schedulers"] = [dict(last_epoch=7)]
+    torch.save(ck, path)
+    exp.resume_from_checkpoint(path)
+    tr = exp.trainer()
+    assert tr.opt_step == 7 and tr.step_count == 7
+    eng = tr.engine
+    for i, (name, p) in enumerate(exp.named_parameters()):
+        short = name[len("conv."):]
+        o, cnt = eng._offsets[short], p.numel()
+        assert torch.all(tr.m[o:o + cnt] == float(i + 1)) and torch.all(tr.v[o:o + cnt] == 100.0 + i), name
+
+
 def test_markov_routine_with_velocity_features(host_device):
     """`use_velocity: true` (torus_kochkov, torus_li/ablation/with_velocity; grid_2d_markov.py:130-144): the conv sees
     normalised (vorticity, u, v, x, y); first train step's loss equals the oracle's on the same statistics."""

@@ -165,3 +165,50 @@ def test_ddp_two_ranks_rccl_equals_reference_full_batch(tmp_path):
         cnt = int(np.prod(shape))
         assert gu.compare_packed(g, "final." + n, r0["pflat"][off:off + cnt].reshape(shape), 1e-5) < 2e-4, n
         off += cnt
+
+
+def _normalizer_sync_worker(rank, world, port, out_dir):
+    """Each rank accumulates its own shard; statistics are synced; the module is checkpointed, re-loaded (resume) and
+    accumulates again.  Writes what every rank holds at the end."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fourierflow_amd.modules.normalizer import Normalizer
+
+    def accumulate(nz, x):      # what ffno_markov_features does to the state (normalizer.py:45-55)
+        nz.sum += x.sum(0)
+        nz.sum_squared += (x * x).sum(0)
+        nz.count += x.shape[0]
+        nz.n_accumulations += 1
+
+    g = torch.Generator().manual_seed(100 + rank)
+    a, b = torch.randn(7, 3, generator=g) + rank, torch.randn(5, 3, generator=g) * 2
+    nz = Normalizer([3])
+    accumulate(nz, a)
+    nz.sync_across_ranks()
+    nz.sync_across_ranks()                       # idempotent: nothing new since the last sync
+    ckpt = {k: v.clone() for k, v in nz.state_dict().items()}
+    resumed = Normalizer([3])
+    resumed.load_state_dict(ckpt)                # every rank loads the GLOBAL statistics
+    resumed = resumed.to("cpu")                  # (a device move keeps the sync baseline with the buffers)
+    loaded_count = float(resumed.count)
+    accumulate(resumed, b)
+    resumed.sync_across_ranks()
+    torch.save(dict(count=resumed.count, sum=resumed.sum, sum_squared=resumed.sum_squared, loaded_count=loaded_count,
+                    a=a, b=b), os.path.join(out_dir, f"nz{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_normalizer_sync_survives_checkpoint_resume_under_ddp(tmp_path):
+    """after resuming a checkpoint under DDP every rank already holds the global statistics -- the first sync must
+    all-reduce only what was accumulated SINCE the load, not the loaded history once per rank.  World size 2, gloo."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_normalizer_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(tmp_path / f"nz{k}.pt") for k in range(2)]
+    every = torch.cat([r[0]["a"], r[1]["a"], r[0]["b"], r[1]["b"]]).double()
+    for k in range(2):
+        assert r[k]["loaded_count"] == 14.0                                   # 7 + 7: the first sync
+        assert float(r[k]["count"]) == 24.0                                   # + 5 + 5, NOT 2 x 14 + 10
+        np.testing.assert_allclose(r[k]["sum"].double().numpy(), every.sum(0).numpy(), rtol=1e-5)
+        np.testing.assert_allclose(r[k]["sum_squared"].double().numpy(), (every * every).sum(0).numpy(), rtol=1e-5)
