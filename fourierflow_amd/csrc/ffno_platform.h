@@ -21,6 +21,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // scheduling hint: the next `size` instructions of class `mask` (0x8 MFMA, 0x2 VALU, 0x100 DS read, ...) form one group; a
 // sequence of such groups asks the scheduler to emit that pattern (llvm.amdgcn.sched.group.barrier)
 #define FFNO_SCHED_GROUP(mask, size) __builtin_amdgcn_sched_group_barrier(mask, size, 0)
+// scheduling barriers that only ONE class of instruction may not cross (llvm.amdgcn.sched.barrier mask = the classes that MAY:
+// 0x1 other ALU, 0x2 VALU, 0x4 SALU, 0x8 MFMA, 0x10 / 0x20 / 0x40 VMEM all / read / write, 0x80 / 0x100 / 0x200 DS all / read /
+// write): keeps a prefetch where it was written without fencing the arithmetic around it
+#define FFNO_SCHED_PIN_VMEM() __builtin_amdgcn_sched_barrier(0x38F)
+#define FFNO_SCHED_PIN_DSREAD() __builtin_amdgcn_sched_barrier(0x27F)
 // pins a register value to this point of the instruction stream: whatever computes x is emitted before, whatever uses it after
 // (an empty volatile asm; FFNO_SCHED_FENCE alone orders memory operations but not pure arithmetic, which instruction selection
 // is free to emit anywhere in the basic block)
@@ -70,6 +75,12 @@ __device__ __forceinline__ float f16_lo(unsigned w) {
 __device__ __forceinline__ float f16_hi(unsigned w) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     return (float)__builtin_bit_cast(f16x2, w)[1];
+}
+// both halves of a packed-fp16 word times k (a power of two here: exact): v_pk_mul_f16
+__device__ __forceinline__ unsigned pk_mul_f16(unsigned w, float k) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 v = __builtin_bit_cast(f16x2, w) * (_Float16)k;
+    return __builtin_bit_cast(unsigned, v);
 }
 // upper halves of two words -> one word (u0's in the low half): v_perm_b32
 __device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }

@@ -14,6 +14,8 @@ typedef emu_u32x4 u32x4;
 #define FFNO_UNROLL
 #define FFNO_NOUNROLL
 #define FFNO_SCHED_FENCE() ((void)0)
+#define FFNO_SCHED_PIN_VMEM() ((void)0)
+#define FFNO_SCHED_PIN_DSREAD() ((void)0)
 #define FFNO_SCHED_GROUP(mask, size) ((void)0)
 #define FFNO_DRAIN_MEMORY() ((void)0)
 #define FFNO_PIN(x) ((void)0)
@@ -30,6 +32,7 @@ inline f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_3
 inline unsigned pack_f16(float x0, float x1) { return (unsigned)emu::emu_float_to_half(x0) | ((unsigned)emu::emu_float_to_half(x1) << 16); }
 inline float f16_lo(unsigned w) { return emu::emu_half_to_float((unsigned short)(w & 0xffffu)); }
 inline float f16_hi(unsigned w) { return emu::emu_half_to_float((unsigned short)(w >> 16)); }
+inline unsigned pk_mul_f16(unsigned w, float k) { return pack_f16(f16_lo(w) * k, f16_hi(w) * k); }
 inline unsigned pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xffff0000u); }
 inline uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return (acc << 1) | (x >> 31); }
 inline uint32_t bit_to_mask(uint32_t x, int b) { return 0u - ((x >> b) & 1u); }

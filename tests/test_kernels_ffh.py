@@ -83,7 +83,7 @@ def test_amax_folds_and_accumulates(be):
 
 
 @pytest.mark.parametrize("sched", [0, FFNO_FF_SCHED_IN_PHASE])
-@pytest.mark.parametrize("P,C,H", [(70, 64, 256), (33, 32, 128), (64, 64, 128), (40, 32, 64), (5000, 64, 256)])
+@pytest.mark.parametrize("P,C,H", [(70, 64, 256), (33, 32, 128), (64, 64, 128), (40, 32, 64), (5000, 64, 256), (200, 64, 256)])
 def test_ffh_fwd_bwd(be, P, C, H, sched):
     if be.kind == "emu" and (P > 1000 or (sched and (C, H) != (64, 256))):
         pytest.skip("large case / most of the schedule sweep run on the GPU only")
@@ -125,7 +125,7 @@ def test_ffh_fwd_bwd(be, P, C, H, sched):
     ref_ds = ref_dh @ W1.astype(np.float64)
     assert rel_l2(be.get(ds), ref_ds) < TOL
     assert word_value(be, ds_word) == float(np.abs(be.get(ds)).max())
-    nsplit = 3 if P < 1000 else 64
+    nsplit = 2 if P == 200 else 3 if P < 1000 else 64      # (200 pixels on 2 workgroups: 4 + 3 tiles each, ragged last tile)
     partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
     assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, p(s_word), p(g_word), None) == 0
     gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
