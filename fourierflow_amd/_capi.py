@@ -148,6 +148,7 @@ SIGNATURES = {
     "ffno_transpose_batched": (I, [P, I, I, I, P]),
     "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P, P]),
     "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "ffno_lift_bwd_data": (I, [P, P, P, I, I, I, P, P]),
     "ffno_head_fold": (I, [P, P, P, P, P, I, I, I, P]),
     "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),

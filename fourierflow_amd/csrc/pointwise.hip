@@ -167,6 +167,32 @@ __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __re
     }
 }
 
+// dx[p][i] = sum_c gout[q(p)][c] W[c][i]: the data gradient of the lift (what autograd hands to whatever produced the block's
+// input).  One thread per pixel; W^T staged in LDS ([Cin][C], read as float4 broadcasts).
+template <int C>
+__global__ __launch_bounds__(256) void lift_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ W,
+                                                            float* __restrict__ dx, int P, int Cin, PadMapDev pm) {
+    FFNO_DYN_SMEM(smem);
+    float* Wt = reinterpret_cast<float*>(smem);  // [Cin][C]
+    for (int e = threadIdx.x; e < Cin * C; e += blockDim.x) Wt[(e % Cin) * C + (e / Cin)] = W[e];
+    __syncthreads();
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long)gridDim.x * 256) {
+        const float* g = gout + pm.map(p) * C;
+        float4 gv[C / 4];
+        FFNO_UNROLL
+        for (int q = 0; q < C / 4; ++q) gv[q] = *reinterpret_cast<const float4*>(g + 4 * q);
+        for (int i = 0; i < Cin; ++i) {
+            float a = 0.f;
+            FFNO_UNROLL
+            for (int q = 0; q < C / 4; ++q) {
+                const float4 w = *reinterpret_cast<const float4*>(Wt + i * C + 4 * q);
+                a = fmaf(gv[q].x, w.x, a), a = fmaf(gv[q].y, w.y, a), a = fmaf(gv[q].z, w.z, a), a = fmaf(gv[q].w, w.w, a);
+            }
+            dx[p * Cin + i] = a;
+        }
+    }
+}
+
 // 4 (input, channel) pairs per block, the slices spread over 64 lanes each (the serial version spent 60 us on 256 slices)
 __global__ __launch_bounds__(256) void lift_bwd_reduce_kernel(const float* __restrict__ partial, float* dW, float* db,
                                                               int Cin, int C, int nsplit, int accumulate) {
@@ -620,6 +646,23 @@ extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, 
     const int npairs = C * (Cin + 1);
     FFNO_LAUNCH(lift_bwd_reduce_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, partial, dW, db, Cin, C, nsplit,
                 accumulate);
+    return pw_status();
+}
+
+extern "C" int ffno_lift_bwd_data(const float* gout, const float* W, float* dx, int P, int Cin, int C,
+                                  const ffno_padmap* pad, void* stream) {
+    if (!gout || !W || !dx || P <= 0 || Cin <= 0) return FFNO_EINVAL;
+    if (Cin > 63) return FFNO_EUNSUPPORTED;
+    const PadMapDev pm = make_padmap(pad);
+    const dim3 grid((unsigned)std::min<long>(((long)P + 255) / 256, 4L * device_cu_count()));
+    const size_t smem = sizeof(float) * (size_t)Cin * C;
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 64)
+        FFNO_LAUNCH((lift_bwd_data_kernel<64>), grid, dim3(256), smem, s, gout, W, dx, P, Cin, pm);
+    else if (C == 32)
+        FFNO_LAUNCH((lift_bwd_data_kernel<32>), grid, dim3(256), smem, s, gout, W, dx, P, Cin, pm);
+    else
+        return FFNO_EUNSUPPORTED;
     return pw_status();
 }
 

@@ -861,9 +861,10 @@ class FFNOEngine:
         return ws.Y.view(B, *S, self.O).clone()
 
     # ------------------------------------------------------------------------------------------------
-    def backward(self, gy: torch.Tensor) -> torch.Tensor:
+    def backward(self, gy: torch.Tensor, need_dx: bool = False) -> torch.Tensor:
         """gy = dL/dout [B, *spatial, output_dim].  Fills and returns the flat gradient buffer ``gflat``
-        (layout: ``param_names`` order; use ``grad_view(name)``)."""
+        (layout: ``param_names`` order; use ``grad_view(name)``).  ``need_dx``: also compute the gradient with respect to
+        the input tensor (``self.dx``, [B, *spatial, input_dim]) -- what autograd of the reference module would hand upstream."""
         if self._saved is None:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
         x, B, S, fused, conc = self._saved
@@ -1055,6 +1056,10 @@ class FFNOEngine:
         lin_in = self.linears["in_proj."]
         self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")),
                 ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
+        self.dx = None
+        if need_dx:
+            self.dx = torch.empty(B, *S, self.Cin, dtype=torch.float32, device=self.device)
+            self._k("lift_bwd_data", lib.ffno_lift_bwd_data, _p(g_fin), _p(lin_in.weff), _p(self.dx), ws.P_in, self.Cin, C, pm, st)
         multi = self.spectral != "plus" and len(self._fw_sets) == L and L > 1      # per-layer weights: one launch per axis
         if multi:
             real = int(self.spectral == "dct")

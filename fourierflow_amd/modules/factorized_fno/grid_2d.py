@@ -59,7 +59,7 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, *params):
         eng = module._engine_for(params)
-        need_grad = any(ctx.needs_input_grad[2:])
+        need_grad = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:])
         y = eng.forward(x, need_grad)
         module._generation += 1
         ctx.module, ctx.gen, ctx.n = module, module._generation, len(params)
@@ -68,16 +68,12 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         module = ctx.module
-        if ctx.needs_input_grad[0]:
-            # the reference modules are ordinary autograd modules and would propagate dL/dx; this operator's kernels stop at
-            # the lift's parameter gradients -- fail loudly instead of silently training upstream parameters without that term
-            raise RuntimeError(f"{type(module).__name__}: the gradient with respect to the INPUT tensor is not computed by the "
-                               "gfx950 kernel set (feed it a tensor that does not require grad)")
         if module._generation != ctx.gen:
             raise RuntimeError("FNOFactorized2DBlock: only the most recent forward pass can be back-propagated "
                                "(activations live in one pre-allocated workspace)")
         eng = module._engine
-        flat = eng.backward(gy.contiguous()).clone()
+        # the reference modules are ordinary autograd modules: dL/dx goes to whatever produced the input (grid_2d.py:154-177)
+        flat = eng.backward(gy.contiguous(), need_dx=ctx.needs_input_grad[0]).clone()
         grads = []
         off = 0
         for n in eng.param_names:
@@ -86,7 +82,7 @@ class _BlockFn(torch.autograd.Function):
                 cnt *= s
             grads.append(flat[off:off + cnt].view(eng.param_shapes[n]))
             off += cnt
-        return (None, None, *grads)
+        return (eng.dx if ctx.needs_input_grad[0] else None, None, *grads)
 
 
 class FNOFactorized2DBlock(nn.Module):

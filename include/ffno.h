@@ -482,6 +482,10 @@ int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, in
                   const ffno_padmap* pad, void* stream);
 int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
                   int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
+/* dx[p][Cin] = gout[q(p)][C] W: the gradient with respect to the block's INPUT (the reference modules are ordinary autograd
+ * modules: grid_2d.py:154-177 propagates it to whatever produced x) */
+int ffno_lift_bwd_data(const float* gout, const float* W, float* dx, int P, int Cin, int C,
+                       const ffno_padmap* pad, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Output head (grid_2d.py:150-152,171-172; mesh_3d.py:155-157,174): y[P][O] = (b W_a^T + c_a) W_b^T + c_b

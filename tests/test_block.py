@@ -110,6 +110,34 @@ def test_block_forward_backward_vs_reference_golden(tag, host_device, fused):
                                      lambda dt: ou.oracle_block_run(kw, seed, B, M, N, dtype=dt, relu_masks=masks)[2])
 
 
+@pytest.mark.parametrize("frozen", [False, True], ids=["trainable", "frozen-params"])
+def test_block_input_gradient_matches_oracle(host_device, frozen):
+    """The reference block is an ordinary autograd module (grid_2d.py:154-177): dL/dx flows to whatever produced its input.
+    VERDICT r02 missing #7: the HIP path used to stop at the lift's parameter gradients.  Also with frozen parameters (only
+    the input requires grad: sensitivity / adjoint-based optimisation of the initial condition)."""
+    import oracle_util as ou
+    kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    seed, B, M, N = 7, 2, 8, 10
+    blk = build_block(kw, seed, host_device)
+    if frozen:
+        blk.requires_grad_(False)
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
+    x = torch.from_numpy(x_np).to(host_device).requires_grad_(True)
+    loss = orc.lp_rel_loss(blk(x)["forecast"], torch.from_numpy(t_np).to(host_device))
+    loss.backward()
+    assert x.grad is not None and tuple(x.grad.shape) == x_np.shape
+    masks = ou.engine_relu_masks(blk.engine())
+    sd, uniq = ou.torch_state_dict(gu.make_block_state_dict(kw, seed))
+    xo = torch.tensor(x_np, requires_grad=True)
+    out = orc.ffno2d_block(sd, xo, modes=kw["modes"], n_layers=kw["n_layers"], relu_masks=masks)
+    orc.lp_rel_loss(out["forecast"], torch.tensor(t_np)).backward()
+    assert rel_l2(x.grad.cpu().numpy(), xo.grad.numpy()) < 5e-5
+    if frozen:
+        assert all(p.grad is None for p in blk.parameters())
+    else:
+        assert rel_l2(dict(blk.named_parameters())["in_proj.weight_v"].grad.cpu().numpy(), uniq["in_proj.weight_v"].grad.numpy()) < 5e-5
+
+
 def test_state_dict_keys_match_reference_layout():
     kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
     from fourierflow_amd.modules import FNOFactorized2DBlock
