@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the 256x256 and 64^3 secondary workloads")
     ap.add_argument("--ff-split", choices=["fp16x2", "bf16x3"], default=None,
                     help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
+    ap.add_argument("--staged", action="store_true", help="spectral branches through the three stage kernels (HBM spectra) instead of the fused tile")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--x3-interleave", type=int, default=3, help="bit 0: even/odd workgroup->branch map; bit 1: image-local (XCD-aware) map where the shapes allow; bits 8..: start skew / 256 cycles")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
@@ -379,6 +380,8 @@ def main():
     block = (FNOPlus2DBlock if args.plus else FNOFactorized2DBlock)(**kw).to(dev)
     trainer = FFNOTrainer(block, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
     trainer.engine.use_x3 = not args.no_x3
+    if args.staged:
+        trainer.engine.use_fused = False
     if args.ff_split:
         trainer.engine.ff_split = args.ff_split
     trainer.engine.x3_interleave = args.x3_interleave

@@ -737,6 +737,338 @@ __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage
     x3_dft_inv_body(x3_pick(a, b, second), apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 
+// ---- the fused branch for 17..64 modes (256 x 256 grids: torus_kochkov runs 32 and 64 modes) ----------------------------------
+// Same operator as spectral_x3_body with the spectrum tile in LDS, re-tiled for many modes per line: KKT = 64 or 128 (mode,
+// re/im) rows per line, FOUR lines per workgroup, two waves per line.  Why four: at 256 x 256 and batch 2 an axis has 512
+// lines of 64 KiB -- an 8-line tile would leave half of the CUs idle, and a CU streams HBM at ~10 B/clk whatever it does (DESIGN
+// section 4), so the bytes must be spread over all 256 CUs: 4 lines = 256 KiB in and 256 KiB out per CU, exactly the 64 x 64 /
+// batch-32 case.  The three stage kernels above moved the spectra through HBM (69.5 us per paired launch, three launches).
+//   phase 1  wave (line, sub): row tiles sub, sub + 2, .. of the truncated DFT of its line (the line is read once from HBM; the
+//            partner wave's copy and later row tiles come from L2); writes the LDS tile (and the saved spectrum)
+//   phase 2  wave w: modes w, w + 8, ..: per-mode channel mix, rows = (line, re/im) of the four lines (8 live rows of the 32-row
+//            MFMA tile -- the mix is 5 % of the launch's MFMA budget here, the weight stream from L2 is what it costs)
+//   phase 3  wave (line, sub): pairs of 32-sample output tiles sub, sub + 2, .. of the zero-padded inverse DFT, k-step outer /
+//            tile inner as in x3_dft_inv_body, with the accumulate / residual epilogue.
+template <int KKT, bool MIXH2>
+__device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
+    using F = X3Cfg;
+    constexpr int C = F::C, RS = F::RS, NL = 4, LSF = KKT * RS + 8, RT = KKT / 32, NST = KKT / 16;
+    __shared__ __attribute__((aligned(16))) float XS[NL * LSF];
+    __shared__ float rfold[F::NW];
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+
+    const int R = A.R, L = A.L, K = A.K;
+    const LineMap lm = A.lm;
+    const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
+    const float rrs = 1.f / rs;
+    float omax = 0.f;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int lw = wave >> 1, sub = wave & 1;        // this wave's line inside the tile / which half of the line's items
+    const int line = bidx * NL + lw;
+    const bool live = line < R;
+    const long es = lm.elem_stride;
+    const unsigned esb = (unsigned)(es * 4);
+    // lines past the end of the axis read (and transform) line R - 1 again; nothing of a dead line is ever stored
+    const unsigned lo = (unsigned)((lm.base(min(line, R - 1)) + 2 * j) * 4);
+    const int nchunks = (L + 63) >> 6;
+
+    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+    __syncthreads();
+
+    // ---------------- phase 1 ----------------
+    for (int rt = sub; rt < RT; rt += 2) {
+        if (32 * rt >= 2 * K) break;
+        const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
+        const bool rowok = kk < 2 * K;
+        const float ck = (A.fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
+        const int km = rowok ? k : 0;
+        const int k8 = (km * 8) % L;
+        float2 raw[4][8];
+        auto load_rows = [&](int chunk, int u) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
+                raw[u][e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.in) + (lo + (unsigned)n * esb));
+            }
+        };
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u);
+        f32x16 acc0 = zero16(), acc1 = zero16();
+        FFNO_NOUNROLL
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            Bf3 Ff[4];
+            int idx = (int)(((long)km * (64 * chunk + 8 * half)) % L);
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * (4 * chunk + u) + 8 * half + e;
+                    f[e] = n < L ? amul * tws[tbase + idx] : 0.f;
+                    idx += km;
+                    if (idx >= L) idx -= L;
+                }
+                idx += k8;
+                if (idx >= L) idx -= L;
+                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+            }
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
+                                        raw[u][6].x, raw[u][7].x);
+                const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
+                                        raw[u][6].y, raw[u][7].y);
+                if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
+                acc0 = mfma_x3(Ff[u], b0, acc0);
+                acc1 = mfma_x3(Ff[u], b1, acc1);
+            }
+        }
+        float* xs = XS + lw * LSF + 2 * j;
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * rt + drow(r, half);
+            if (row < 2 * K) {
+                *reinterpret_cast<float2*>(xs + row * RS) = make_float2(acc0[r] * rs, acc1[r] * rs);
+                if (A.spec_save && live)
+                    *reinterpret_cast<float2*>(A.spec_save + (((long)(row >> 1) * R + line) * 2 + (row & 1)) * C + 2 * j) =
+                        make_float2(acc0[r], acc1[r]);
+            }
+        }
+    }
+    // The weight fragments of ALL this wave's modes are one stream through a ring: the slots a mode's last products free are
+    // refilled with the first fragments of the wave's next mode (an L2 round trip per mode would be exposed otherwise), and the
+    // first fragments of its first mode are requested on this side of the barrier.
+    constexpr int RING = 8;
+    using MixFrag = typename std::conditional<MIXH2, Hf2, Bf3>::type;
+    constexpr int MNP = MIXH2 ? 2 : 3;
+    auto load_w = [&](const u32x4* __restrict__ wk, int f) {
+        MixFrag w;
+        if constexpr (MIXH2) {
+            w.hi = wk[(f * 2 + 0) * 64 + lane];
+            w.lo = wk[(f * 2 + 1) * 64 + lane];
+        } else {
+            w = x3_load_frag(wk, f, lane);
+        }
+        return w;
+    };
+    MixFrag ring[RING];
+    if (A.wpk && wave < K) {
+        FFNO_UNROLL
+        for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: per-mode channel mix of the four lines, in place ----------------
+    if (A.wpk) {
+        // MFMA row j = (line (j mod 8) >> 1, part j & 1); rows 8..31 repeat rows 0..7 and are dropped
+        const float* arow = XS + ((j & (2 * NL - 1)) >> 1) * LSF + (j & 1) * RS + 8 * half;
+        for (int k = wave; k < K; k += F::NW) {
+            const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * 64 * MNP;
+            const bool more = k + F::NW < K;
+            const u32x4* __restrict__ wn = A.wpk + (long)(more ? k + F::NW : k) * F::MODE_FRAGS * 64 * MNP;
+            MixFrag a[4];
+            FFNO_UNROLL
+            for (int st = 0; st < 4; ++st) {
+                const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st);
+                const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st + 4);
+                if constexpr (MIXH2)
+                    a[st] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                else
+                    a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+            }
+            f32x16 p[4];
+            FFNO_UNROLL
+            for (int pt = 0; pt < 4; ++pt) p[pt] = zero16();
+            if constexpr (MIXH2) {
+                FFNO_UNROLL
+                for (int pt = 0; pt < 4; ++pt) {
+                    f32x16 pc = zero16();
+                    FFNO_UNROLL
+                    for (int st = 0; st < 4; ++st) {
+                        const int f = pt * 4 + st;
+                        const Hf2 b = ring[f % RING];
+                        if (f + RING < F::MODE_FRAGS)
+                            ring[f % RING] = load_w(wk, f + RING);
+                        else if (more)
+                            ring[f % RING] = load_w(wn, f + RING - F::MODE_FRAGS);
+                        mfma_h2(a[st], b, p[pt], pc);
+                    }
+                    SplitHf2::fold(p[pt], pc);
+                }
+            } else {
+                FFNO_UNROLL
+                for (int st = 0; st < 4; ++st) {
+                    FFNO_UNROLL
+                    for (int pt = 0; pt < 4; ++pt) {
+                        const int f = st * 4 + pt;
+                        const Bf3 b = ring[f % RING];
+                        if (f + RING < F::MODE_FRAGS)
+                            ring[f % RING] = load_w(wk, f + RING);
+                        else if (more)
+                            ring[f % RING] = load_w(wn, f + RING - F::MODE_FRAGS);
+                        p[pt] = mfma_x3(a[st], b, p[pt]);
+                    }
+                }
+            }
+            // D rows 2q, 2q+1 of this lane = (re, im) of line (q & 1) + 2 half  (accumulator registers 0..3 hold the 8 live rows)
+            FFNO_UNROLL
+            for (int q = 0; q < NL / 2; ++q) {
+                const int ln = (q & 1) + 2 * half;
+                float yr[2], yi[2];
+                FFNO_UNROLL
+                for (int t = 0; t < 2; ++t) {
+                    const float p1r = p[t][2 * q], p1i = p[t][2 * q + 1];
+                    const float p2r = p[2 + t][2 * q], p2i = p[2 + t][2 * q + 1];
+                    if (A.conj_t == 0) {
+                        yr[t] = p1r - p2i;
+                        yi[t] = p2r + p1i;
+                    } else {
+                        yr[t] = p1r + p2i;
+                        yi[t] = p1i - p2r;
+                    }
+                }
+                float* dst = XS + ln * LSF + 2 * k * RS + 2 * j;
+                *reinterpret_cast<float2*>(dst) = make_float2(yr[0], yr[1]);
+                *reinterpret_cast<float2*>(dst + RS) = make_float2(yi[0], yi[1]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 3 ----------------
+    {
+        const int RTtot = (L + 31) >> 5, NPR = (RTtot + 1) >> 1;
+        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const unsigned lob = lo + hoff;
+        const float* xs = XS + lw * LSF + 2 * j;
+        const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
+                                     : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
+        for (int np = sub; np < NPR && live; np += 2) {
+            const int rt0 = 2 * np;
+            f32x16 o[2][2];
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) o[q][0] = zero16(), o[q][1] = zero16();
+            // rows the epilogue adds (residual / accumulate) are requested ahead of the products: the first tile's before the
+            // k-step loop, the second tile's while the first is stored
+            float2 pre[16];
+            auto request_rows = [&](int rt) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int nu = min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
+                    pre[r] = *reinterpret_cast<const float2*>(addsrc + lo + (unsigned)nu * esb);
+                }
+            };
+            if (addsrc) request_rows(rt0);
+            const int nst = min(NST, (2 * K + 15) >> 4);
+            FFNO_NOUNROLL
+            for (int st = 0; st < nst; ++st) {      // (a real loop: only the four accumulators cross its iterations)
+                float2 v[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 16 * st + 8 * half + e;
+                    v[e] = make_float2(0.f, 0.f);
+                    if (kk < 2 * K) v[e] = *reinterpret_cast<const float2*>(xs + kk * RS);
+                }
+                const Bf3 y0 = split3_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+                const Bf3 y1 = split3_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+                FFNO_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    const int n = 32 * (rt0 + q) + j;
+                    const int nm = n < L ? n : 0;
+                    float g[8];
+                    int idx = (int)(((long)nm * (8 * st + 4 * half)) % L);
+                    FFNO_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+                        const float ck = (A.inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                        g[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tws[(part ? L : 0) + idx] : 0.f;
+                        if (part) {
+                            idx += nm;
+                            if (idx >= L) idx -= L;
+                        }
+                    }
+                    const Bf3 G = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                    o[q][0] = mfma_x3(G, y0, o[q][0]);
+                    o[q][1] = mfma_x3(G, y1, o[q][1]);
+                }
+            }
+            FFNO_UNROLL
+            for (int q = 0; q < 2; ++q) {
+                const int rt = rt0 + q;
+                if (rt >= RTtot) continue;
+                float2 cur[16];
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) cur[r] = pre[r];
+                if (addsrc && q == 0 && rt + 1 < RTtot) request_rows(rt + 1);
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
+                    if (nu + 4 * half < L) {
+                        const long uo = (long)nu * es * 4;
+                        float2 ov = make_float2(o[q][0][r] * rrs, o[q][1][r] * rrs);
+                        if (addsrc) ov.x += cur[r].x, ov.y += cur[r].y;
+                        if (A.accumulate && A.resid) {
+                            const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lob);
+                            ov.x += pv.x, ov.y += pv.y;
+                        }
+                        *reinterpret_cast<float2*>(reinterpret_cast<char*>(A.out) + uo + lob) = ov;
+                        omax = fmaxf(omax, fmaxf(fabsf(ov.x), fabsf(ov.y)));
+                    }
+                }
+            }
+        }
+    }
+    if (A.out_amax) range_fold(omax, rfold, F::NW, A.out_amax);
+}
+
+__device__ __forceinline__ X3Args x3_pick_args(const X3Args& a, const X3Args& b, bool second) {
+    X3Args s;
+    s.in = second ? b.in : a.in;
+    s.out = second ? b.out : a.out;
+    s.resid = second ? b.resid : a.resid;
+    s.spec_save = second ? b.spec_save : a.spec_save;
+    s.wpk = second ? b.wpk : a.wpk;
+    s.tw = second ? b.tw : a.tw;
+    s.R = second ? b.R : a.R;
+    s.L = second ? b.L : a.L;
+    s.K = second ? b.K : a.K;
+    s.lm.lines_per_group = second ? b.lm.lines_per_group : a.lm.lines_per_group;
+    s.lm.group_stride = second ? b.lm.group_stride : a.lm.group_stride;
+    s.lm.line_stride = second ? b.lm.line_stride : a.lm.line_stride;
+    s.lm.elem_stride = second ? b.lm.elem_stride : a.lm.elem_stride;
+    s.fwd_ck = a.fwd_ck, s.inv_ck = a.inv_ck, s.conj_t = a.conj_t;      // common to both branches
+    s.accumulate = second ? b.accumulate : a.accumulate;
+    s.in_amax = second ? b.in_amax : a.in_amax;
+    s.out_amax = second ? b.out_amax : a.out_amax;
+    return s;
+}
+
+template <int KKT, bool MIXH2>
+__global__ __launch_bounds__(512) void spectral_x3k_kernel(X3Args a) {
+    spectral_x3k_body<KKT, MIXH2>(a, blockIdx.x);
+}
+// two branches in one launch: even workgroups run branch a, odd ones branch b while both have tiles left (workgroup w lands on
+// XCD w % 8: every XCD's L2 then holds the packed weights of ONE branch), the rest in order
+template <int KKT, bool MIXH2>
+__global__ __launch_bounds__(512) void spectral_x3k_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
+    const int w = blockIdx.x, nmin = min(n0, n1);
+    bool second;
+    int idx;
+    if (w < 2 * nmin) {
+        second = w & 1;
+        idx = w >> 1;
+    } else {
+        second = n1 > n0;
+        idx = w - nmin;
+    }
+    spectral_x3k_body<KKT, MIXH2>(x3_pick_args(a, b, second), idx);
+}
+
 // 8-line tiles while the launch still fits one round of workgroups (one per CU of the device): more CUs busy, same weight
 // stream per workgroup; a branch descriptor may force either (tile_lines = 8 / 16; results are bit-identical)
 static inline bool x3_small_tiles(int Ra, int Rb, int tile_lines) {
@@ -754,19 +1086,21 @@ static inline int x3_status() {
 
 using namespace ffno;
 
-extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && 2 * K <= X3Cfg::KK && L >= 2 && L <= 2048) ? 1 : 0; }
+// fused x3 kernels: K <= 16 on the 16 / 8-line tile (spectral_x3_body), 17..64 modes on the 4-line tile (spectral_x3k_body)
+extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && K <= 64 && L >= 2 && L <= 2048) ? 1 : 0; }
+static inline bool x3_many_modes(int K) { return 2 * K > X3Cfg::KK; }
 
 extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
     return (C == X3Cfg::C && K >= 1 && K <= 32 && L >= 2 && L <= 2048) ? 1 : 0;
 }
 
 extern "C" size_t ffno_spectral_x3_pack_bytes(int C, int K) {
-    return (C == X3Cfg::C && K >= 1 && K <= 32) ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
+    return (C == X3Cfg::C && K >= 1 && K <= 64) ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
 }
 
 extern "C" int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream) {
     if (!descs_dev || n <= 0 || max_K <= 0) return FFNO_EINVAL;
-    if (C != X3Cfg::C || max_K > 32) return FFNO_EUNSUPPORTED;
+    if (C != X3Cfg::C || max_K > 64) return FFNO_EUNSUPPORTED;
     static_assert(sizeof(ffno_x3pack_desc) == sizeof(X3PackDesc), "descriptor layout");
     const int threads = max_K * X3Cfg::MODE_FRAGS * 64;
     FFNO_LAUNCH(x3_pack_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
@@ -798,6 +1132,22 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     const bool h2 = br->planes && br->planes_format == FFNO_PLANES_FP16X2;
     const size_t smem = sizeof(float) * 2 * a.L;
     hipStream_t st = (hipStream_t)stream;
+    if (x3_many_modes(a.K)) {      // 17..64 modes: the 4-line tile
+        const dim3 grid((a.R + 3) / 4);
+#define X3K_LAUNCH(KKT, H2)                                                                              \
+    do {                                                                                                 \
+        const int rc_ = allow_dynamic_lds(spectral_x3k_kernel<KKT, H2>, smem);                           \
+        if (rc_) return rc_;                                                                             \
+        FFNO_LAUNCH((spectral_x3k_kernel<KKT, H2>), grid, dim3(512), smem, st, a);                       \
+    } while (0)
+        if (a.K <= 32) {
+            if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
+        } else {
+            if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
+        }
+#undef X3K_LAUNCH
+        return x3_status();
+    }
     if (x3_small_tiles(a.R, 0, br->tile_lines)) {
         if (h2)
             FFNO_LAUNCH((spectral_x3_kernel<8, true>), dim3((a.R + 7) / 8), dim3(512), smem, st, a);
@@ -828,6 +1178,23 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         return FFNO_EINVAL;
     const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
     hipStream_t st = (hipStream_t)stream;
+    if (x3_many_modes(a.K) || x3_many_modes(b.K)) {      // 17..64 modes on either axis: both on the 4-line tile
+        const int n0 = (a.R + 3) / 4, n1 = (b.R + 3) / 4;
+        const dim3 grid(n0 + n1);
+#define X3K_LAUNCH(KKT, H2)                                                                              \
+    do {                                                                                                 \
+        const int rc_ = allow_dynamic_lds(spectral_x3k_pair_kernel<KKT, H2>, smem);                      \
+        if (rc_) return rc_;                                                                             \
+        FFNO_LAUNCH((spectral_x3k_pair_kernel<KKT, H2>), grid, dim3(512), smem, st, a, b, n0, n1);       \
+    } while (0)
+        if (max(a.K, b.K) <= 32) {
+            if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
+        } else {
+            if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
+        }
+#undef X3K_LAUNCH
+        return x3_status();
+    }
     // interleave: bit 0 = even / odd workgroup -> branch map; bit 1 = image-local map where the shapes allow it (else bit 0
     // decides); bits 8.. = start skew of every other workgroup in units of 256 cycles
     const int skew = (interleave >> 8) * 256;

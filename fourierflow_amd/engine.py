@@ -383,7 +383,7 @@ class FFNOEngine:
         if self.spectral == "factorized" and self.mode == "full":
             for si in range(len(self.planes)):
                 for w, K in enumerate(plane_modes):
-                    nb = int(lib.ffno_spectral_x3_pack_bytes(self.C, K)) if lib.ffno_spectral_x3_staged_supported(self.C, K, 2 * K) else 0
+                    nb = int(lib.ffno_spectral_x3_pack_bytes(self.C, K))      # 0 = no split kernel for (C, K)
                     if nb:
                         self.xplanes[si][w] = tuple(torch.empty(nb // 4, dtype=torch.int32, device=dev) for _ in range(2))
         self._x3pack_sig = None
@@ -678,17 +678,23 @@ class FFNOEngine:
             return [False]
         if self.spectral == "dct":
             return [False] * len(views)
-        return [bool(self.use_fused and self.mode != "no-fourier" and lib.ffno_spectral_fused_supported(self.C, v.K, v.L))
-                for v in views]
+        # fused = the fp32-MFMA fused kernel takes the shape, or the split (x3) fused kernels do (K <= 16 on the 16-line tile,
+        # 17..64 modes on the 4-line tile of spectral_x3k: 256 x 256 grids)
+        return [bool(self.use_fused and self.mode != "no-fourier"
+                     and (lib.ffno_spectral_fused_supported(self.C, v.K, v.L) or self._x3_ok(w, v, views)))
+                for w, v in enumerate(views)]
+
+    def _x3_ok(self, w, v, views) -> bool:
+        lib = _lib.get_lib()
+        if not (self.use_x3 and self.spectral == "factorized" and self.mode != "no-fourier"):
+            return False
+        P4 = 4 * self.C * max(u.Bv * u.Mv * u.Nv for u in views)       # 32-bit byte offsets inside the kernel
+        return bool(v.R >= self.x3_min_lines and P4 < 2 ** 32 and lib.ffno_spectral_x3_supported(self.C, v.K, v.L)
+                    and (self.mode != "full" or self.xplanes[0][w] is not None))
 
     def _use_x3(self, views, fused):
         """Per axis: the split-bf16 fused branch instead of the fp32-MFMA one (same operator, same flags)."""
-        lib = _lib.get_lib()
-        if not (self.use_x3 and self.spectral == "factorized" and self.mode != "no-fourier"):
-            return [False] * len(views)
-        P4 = 4 * self.C * max(v.Bv * v.Mv * v.Nv for v in views)       # 32-bit byte offsets inside the kernel
-        return [bool(fused[w] and v.R >= self.x3_min_lines and P4 < 2 ** 32 and lib.ffno_spectral_x3_supported(self.C, v.K, v.L)
-                     and (self.mode != "full" or self.xplanes[0][w] is not None)) for w, v in enumerate(views)]
+        return [bool(fused[w] and self._x3_ok(w, v, views)) for w, v in enumerate(views)]
 
     def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st,
                   x3: bool = False, rin=None, rout=None):

@@ -138,6 +138,36 @@ def test_block_input_gradient_matches_oracle(host_device, frozen):
         assert rel_l2(dict(blk.named_parameters())["in_proj.weight_v"].grad.cpu().numpy(), uniq["in_proj.weight_v"].grad.numpy()) < 5e-5
 
 
+@pytest.mark.parametrize("modes,grid", [(20, (40, 44)), (34, (72, 68))])
+def test_block_with_more_than_16_modes_runs_the_fused_split_kernel(host_device, modes, grid):
+    """17..64 modes (torus_kochkov: 32; its reference config: 64): both axes of every layer in ONE paired launch of the fused
+    4-line split kernel (spectral_x3k), spectra in LDS -- forward and gradients against the oracle, and the engine really takes
+    that path (not the three stage launches through HBM spectra it used up to round 2)."""
+    import oracle_util as ou
+    if host_device == "cpu" and modes > 20:
+        pytest.skip("emulator time budget (the GPU run covers it)")
+    kw = dict(modes=modes, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    seed, B = 9, 1
+    M, N = grid
+    blk = build_block(kw, seed, host_device)
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
+    pred = blk(torch.from_numpy(x_np).to(host_device))["forecast"]
+    orc.lp_rel_loss(pred, torch.from_numpy(t_np).to(host_device)).backward()
+    eng = blk.engine()
+    assert eng.paired_last and eng._saved_x3 == ([True, True], True) and eng._x3_fmt == [1, 1]
+    seen = []
+    orig = eng._k
+    eng._k = lambda name, fn, *a, _o=orig: (seen.append(name), _o(name, fn, *a))[1]
+    blk(torch.from_numpy(x_np).to(host_device))
+    assert "layer_fwd" in seen and not any("staged" in n for n in seen), seen
+    masks = ou.engine_relu_masks(eng)
+    ref_out, _, _ = ou.oracle_block_run(kw, seed, B, M, N)
+    assert rel_l2(pred.detach().cpu().numpy(), ref_out["forecast"].detach().numpy()) < 1e-5
+    named = dict(blk.named_parameters())
+    ou.check_grads_at_rounding_level(f"block modes {modes} {host_device}", {n: named[n].grad.cpu().numpy() for n in eng.param_names},
+                                     lambda dt: ou.oracle_block_run(kw, seed, B, M, N, dtype=dt, relu_masks=masks)[2])
+
+
 def test_state_dict_keys_match_reference_layout():
     kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
     from fourierflow_amd.modules import FNOFactorized2DBlock

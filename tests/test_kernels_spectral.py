@@ -517,10 +517,94 @@ def test_spectral_x3_pair_equals_single_branches(be, x3_tile, B, M, N, K, direct
     assert lib.ffno_spectral_x3_pair(ctypes.byref(a2[0]), ctypes.byref(a2[0]), C, fwd_ck, inv_ck, conj, 0, None) == -1   # shared output
 
 
+@pytest.mark.parametrize("B,M,N,K,axis", [(1, 40, 48, 20, 0), (1, 40, 48, 20, 1), (1, 70, 8, 34, 1), (2, 66, 70, 32, 0), (2, 66, 70, 32, 1),
+                                          (1, 130, 136, 64, 0), (2, 256, 256, 32, 1)])
+@pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
+@pytest.mark.parametrize("fmt", [0, 1], ids=["bf16x3", "fp16x2"])
+def test_spectral_x3_fused_many_modes(be, B, M, N, K, axis, direction, fmt):
+    """17..64 modes per axis on the FUSED split kernel (spectral_x3k: four lines per workgroup, the spectrum tile in LDS) -- the
+    256 x 256 regime of torus_kochkov (32 modes; the reference's own config runs 64) that used to go through three stage
+    launches and HBM spectra.  Against the fp64 reference at the fp32 tolerance: forward / adjoint / low-pass, the saved
+    spectrum, ragged line counts (R % 4 != 0), lengths that are not multiples of 32 or 64, both pack formats (with the range
+    word for fp16x2), accumulate + residual epilogue, and the recorded output maximum."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and (K > 34 or B > 1 or (direction == "lowpass" and fmt) or (K == 20 and fmt and direction == "adj")):
+        pytest.skip("emulator time budget (the GPU run covers all)")
+    C = 64
+    L = N if axis == 0 else M
+    lib, p = be.lib, be.ptr
+    assert lib.ffno_spectral_x3_supported(C, K, L) == 1
+    rs = np.random.RandomState(B + 10 * M + 100 * N + K + axis)
+    mag = 1.0 if fmt == 0 else 3e4          # fp16x2: a spectrum of 3e4 * sqrt(L) needs the device-side range scale
+    x = (rs.standard_normal((B, M, N, C)) * mag).astype(np.float32)
+    w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+    R = B * M if axis == 0 else B * N
+    ref, ref_spec_ = _branch_reference(x, w, K, axis, direction)
+    dx, tw = be.put(x), be.twiddle(L)
+    pk_f, pk_a, keep = _x3_pack(be, w, K, fmt=fmt)
+    out, spec = be.empty(x.shape), be.empty((K, R, 2, C))
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    planes = None if direction == "lowpass" else (pk_a if direction == "adj" else pk_f)
+    xw, ow = be.zeros(1, np.uint32), be.zeros(1, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(xw), None) == 0
+    br = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, 0, p(xw), p(ow))
+    assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
+    got = be.get(out)
+    assert np.all(np.isfinite(got)) and rel_l2(got, ref) < TOL
+    assert rel_l2(be.get(spec), ref_spec_) < TOL
+    assert np.asarray(be.get(ow)).view(np.float32)[0] == np.abs(got).max()
+    resid = (rs.standard_normal(x.shape) * mag).astype(np.float32)       # accumulate + residual epilogue, no spectrum save
+    dres = be.put(resid)          # (kept alive across the call: the descriptor holds a raw pointer)
+    br = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1, fmt, 0, p(xw), None)
+    assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
+    assert rel_l2(be.get(out), 2 * ref + resid) < TOL
+
+
+@pytest.mark.parametrize("B,M,N,Ka,Kb", [(1, 40, 48, 20, 18), (1, 70, 36, 12, 34), (2, 256, 256, 32, 32), (1, 130, 136, 64, 40)])
+@pytest.mark.parametrize("direction", ["fwd", "adj"])
+def test_spectral_x3_fused_many_modes_pair_equals_single_branches(be, B, M, N, Ka, Kb, direction):
+    """Both axes in ONE launch of the 4-line kernel (also when only one axis has more than 16 modes, and with unequal tile
+    counts): bit-identical to the single-branch launches."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and (B > 1 or M > 100 or direction == "adj"):
+        pytest.skip("emulator time budget (the GPU run covers all)")
+    C = 64
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + Ka)
+    x, resid, base = (rs.standard_normal((B, M, N, C)).astype(np.float32) for _ in range(3))
+    dx, dres = be.put(x), be.put(resid)
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br, keep = [], []
+    for axis, K in ((0, Ka), (1, Kb)):
+        L = N if axis == 0 else M
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        pk_f, pk_a, kp = _x3_pack(be, w, K)
+        keep.append(kp)
+        br.append(dict(axis=axis, K=K, R=B * M if axis == 0 else B * N, tw=be.twiddle(L), planes=pk_a if direction == "adj" else pk_f))
+
+    def branches(outs, sv):
+        return [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"]), p(b["tw"]), B, M, N, b["K"],
+                            b["axis"], int(i == 0)) for i, b in enumerate(br)]
+
+    outs1, sv1 = [be.put(base), be.empty(x.shape)], [be.empty((b["K"], b["R"], 2, C)) for b in br]
+    for a in branches(outs1, sv1):
+        assert lib.ffno_spectral_x3(ctypes.byref(a), C, fwd_ck, inv_ck, conj, None) == 0
+    outs2, sv2 = [be.put(base), be.empty(x.shape)], [be.empty((b["K"], b["R"], 2, C)) for b in br]
+    a2 = branches(outs2, sv2)
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(a2[0]), ctypes.byref(a2[1]), C, fwd_ck, inv_ck, conj, 1, None) == 0
+    for i in range(2):
+        if br[i]["K"] > 16 or max(Ka, Kb) <= 16:      # (an axis with <= 16 modes runs on another tile shape when launched alone)
+            np.testing.assert_array_equal(be.get(outs2[i]), be.get(outs1[i]))
+            np.testing.assert_array_equal(be.get(sv2[i]), be.get(sv1[i]))
+        else:
+            assert rel_l2(be.get(outs2[i]), be.get(outs1[i])) < 1e-6 and rel_l2(be.get(sv2[i]), be.get(sv1[i])) < 1e-6
+
+
 def test_spectral_x3_support_matrix(be):
     lib = be.lib
     assert lib.ffno_spectral_x3_supported(64, 16, 64) == 1
-    assert lib.ffno_spectral_x3_supported(64, 17, 64) == 0
+    assert lib.ffno_spectral_x3_supported(64, 17, 64) == 1 and lib.ffno_spectral_x3_supported(64, 64, 256) == 1   # the 4-line tile
+    assert lib.ffno_spectral_x3_supported(64, 65, 256) == 0
     assert lib.ffno_spectral_x3_supported(32, 8, 64) == 0
     assert lib.ffno_spectral_x3_pack_bytes(32, 8) == 0
 
