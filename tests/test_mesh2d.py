@@ -105,9 +105,11 @@ def test_mesh2d_structured_mesh_routine(host_device):
     assert l1 < l0
 
 
-def test_mesh2d_mixed_fused_and_staged_axes(host_device):
-    """modes_x = 20 exceeds the fused kernel's tile (K <= 16 at width 64) while modes_y = 5 fits: the engine picks the
-    kernel per axis; forward and gradients vs the oracle's autograd."""
+@pytest.mark.parametrize("x3", [True, False], ids=["x3", "fp32"])
+def test_mesh2d_mixed_fused_and_staged_axes(host_device, x3):
+    """modes_x = 20, modes_y = 5.  On the fp32-MFMA kernels 20 modes exceed the fused tile (K <= 16 at width 64) while 5 fit:
+    the engine picks the kernel per axis (staged + fused).  On the split kernels both axes are fused -- the 20-mode axis on the
+    4-line tile of spectral_x3k -- and share one paired launch.  Forward and gradients vs the oracle's autograd."""
     import oracle_util as ou
     from fourierflow_amd.modules import FNOFactorizedMesh2D
     kw = dict(modes_x=20, modes_y=5, width=64, input_dim=4, n_layers=2, share_weight=False, factor=4, ff_weight_norm=True,
@@ -117,10 +119,12 @@ def test_mesh2d_mixed_fused_and_staged_axes(host_device):
     blk = FNOFactorizedMesh2D(**kw)
     blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
     blk = blk.to(host_device)
+    blk.engine().use_x3 = x3
     x_np, t_np = gu.make_mesh2d_io(kw, seed, B, S)
     out = blk(torch.from_numpy(x_np).to(host_device))
     eng = blk.engine()
-    assert eng._can_fuse(eng._ws.views) == [False, True]
+    assert eng._can_fuse(eng._ws.views) == ([True, True] if x3 else [False, True])
+    assert eng._saved_x3 == (([True, True], True) if x3 else ([False, False], False))
     loss = ((out - torch.from_numpy(t_np).to(host_device)) ** 2).mean()
     loss.backward()
     ref_out, ref_loss, ref_grads = oracle_run(kw, seed, B, S, torch.float64)
