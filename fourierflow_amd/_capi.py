@@ -114,7 +114,7 @@ SIGNATURES = {
     "ffno_layer_bwd": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
-    "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),
     "ffno_spectral2d_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_spectral2d_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
@@ -146,12 +146,12 @@ SIGNATURES = {
     "ffno_weightnorm_fwd": (I, [P, I, I, P]),
     "ffno_weightnorm_bwd": (I, [P, I, I, P]),
     "ffno_transpose_batched": (I, [P, I, I, I, P]),
-    "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P, P]),
+    "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P, P, P]),
     "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "ffno_lift_bwd_data": (I, [P, P, P, I, I, I, P, P]),
     "ffno_head_fold": (I, [P, P, P, P, P, I, I, I, P]),
     "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
-    "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P]),
+    "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P, P]),
     "ffno_head_param_grads": (I, [P, P, P, P, P, P, P, P, I, I, I, I, P]),
     "ffno_cdft_rows": (I, [P, P, I, I, I, I, I, P]),
     "ffno_fw2d_pack": (I, [P, P, P, P, I, I, P]),

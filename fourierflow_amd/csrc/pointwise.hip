@@ -101,8 +101,10 @@ static inline PadMapDev make_padmap(const ffno_padmap* pm) {
 template <int C>
 __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ b, float* __restrict__ out, int P,
-                                                       int Cin, PadMapDev pm) {
+                                                       int Cin, PadMapDev pm, unsigned* out_amax) {
     FFNO_DYN_SMEM(smem);
+    __shared__ float rfold[4];
+    float omax = 0.f;
     float* Wt = reinterpret_cast<float*>(smem);  // [Cin + 1][C], last row = bias
     for (int e = threadIdx.x; e < Cin * C; e += blockDim.x) Wt[(e % Cin) * C + (e / Cin)] = W[e];
     for (int e = threadIdx.x; e < C; e += blockDim.x) Wt[Cin * C + e] = b[e];
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__
             acc.w = fmaf(xv, w.w, acc.w);
         }
         *reinterpret_cast<float4*>(out + pm.map(p) * C + c4) = acc;
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
     }
+    if (out_amax) range_fold(omax, rfold, 4, out_amax);      // (optional range word of the lifted features)
 }
 
 // partial[split][i][c] = sum_{p in slice} gout[q(p)][c] * (i < Cin ? x[p][i] : 1)
@@ -257,9 +261,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 template <int C>
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ b, const float* __restrict__ gy,
                                                        const float* __restrict__ fold, float* __restrict__ gb,
-                                                       float* __restrict__ partial, int P, int O, PadMapDev pm) {
+                                                       float* __restrict__ partial, int P, int O, PadMapDev pm,
+                                                       unsigned* gb_amax) {
     constexpr int LPP = C / 4, PPB = 256 / LPP;
     __shared__ float red[PPB * (C + 4)];
+    __shared__ float rfold[4];
+    float omax = 0.f;
     const int l = threadIdx.x % LPP, c4 = l * 4, pl = threadIdx.x / LPP;
     float4 acc[kHeadMaxOut];
     float sg[kHeadMaxOut];
@@ -289,7 +296,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             }
         }
         if (gb) *reinterpret_cast<float4*>(gb + q * C + c4) = gsum;
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(gsum.x), fabsf(gsum.y))), fmaxf(fabsf(gsum.z), fabsf(gsum.w)));
     }
+    if (gb && gb_amax) range_fold(omax, rfold, 4, gb_amax);      // (optional range word of the gradient handed to the layers)
     for (int o = 0; o < O; ++o) {
         __syncthreads();
         float* r = red + pl * (C + 4);
@@ -611,7 +620,7 @@ extern "C" int ffno_transpose_batched(const ffno_tr_desc* descs_dev, int n, int 
 }
 
 extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
-                             const ffno_padmap* pad, void* stream) {
+                             const ffno_padmap* pad, uint32_t* out_amax, void* stream) {
     if (!x || !W || !b || !out || P <= 0 || Cin <= 0) return FFNO_EINVAL;
     if (Cin > 63) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
@@ -620,9 +629,9 @@ extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, flo
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin, pm);
+        FFNO_LAUNCH((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
     else if (C == 32)
-        FFNO_LAUNCH((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin, pm);
+        FFNO_LAUNCH((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
@@ -693,15 +702,16 @@ extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P,
 }
 
 extern "C" int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
-                             float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, void* stream) {
+                             float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, uint32_t* gb_amax,
+                             void* stream) {
     if (!b || !gy || !fold || !partial || !red || P <= 0 || nsplit <= 0 || O <= 0) return FFNO_EINVAL;
     if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm);
+        FFNO_LAUNCH((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
     else if (C == 32)
-        FFNO_LAUNCH((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm);
+        FFNO_LAUNCH((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();

@@ -450,6 +450,7 @@ struct FusedArgs {
     int R, L, K;
     LineMap lm;
     int fwd_ck, inv_ck, conj_t, accumulate;
+    unsigned* out_amax;      // optional range word of `out` (ffno_device.h "range words")
 };
 
 template <int C>
@@ -641,6 +642,8 @@ __device__ __forceinline__ void spectral_fused_body(const FusedArgs& A, int bidx
     }
 
     // ---------------- phase 3: zero-padded inverse DFT of this wave's line ----------------
+    float omax = 0.f;            // max |out| over what this thread stores (-> A.out_amax)
+    __shared__ float rfold[8];
     if (live) {
         const float sgn = half ? -1.f : 1.f;
         const int tbase = half ? L : 0;
@@ -695,11 +698,14 @@ __device__ __forceinline__ void spectral_fused_body(const FusedArgs& A, int bidx
                             for (int ct = 0; ct < CT; ++ct) o.v[ct] += p.v[ct];
                         }
                         o.store(out + a);
+                        FFNO_UNROLL
+                        for (int ct = 0; ct < CT; ++ct) omax = fmaxf(omax, fabsf(o.v[ct]));
                     }
                 }
             }
         }
     }
+    if (A.out_amax) range_fold(omax, rfold, 8, A.out_amax);
 }
 
 template <int C>
@@ -1174,24 +1180,24 @@ extern "C" int ffno_spectral_fused_supported(int C, int K, int L) {
 
 static int fused_args(FusedArgs& a, const float* in, float* out, const float* resid, float* spec_save, const float* planes,
                       const float* tw, int B, int M, int N, int C, int K, int axis, int scale_ck_fwd, int apply_ck_inv,
-                      int conj_transpose, int accumulate) {
+                      int conj_transpose, int accumulate, uint32_t* out_amax) {
     if (!in || !out || !tw || B <= 0 || M <= 0 || N <= 0 || K <= 0 || (axis != 0 && axis != 1)) return FFNO_EINVAL;
     const int L = axis == 0 ? N : M;
     const int R = axis == 0 ? B * M : B * N;
     if (K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_fused_supported(C, K, L)) return FFNO_EUNSUPPORTED;
     a = FusedArgs{in, out, resid, spec_save, planes, tw, R, L, K, make_linemap(axis, B, M, N, C), scale_ck_fwd, apply_ck_inv,
-                  conj_transpose, accumulate};
+                  conj_transpose, accumulate, out_amax};
     return FFNO_OK;
 }
 
 extern "C" int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
                                    const float* planes, const float* tw, int B, int M, int N, int C, int K, int axis,
                                    int scale_ck_fwd, int apply_ck_inv, int conj_transpose, int accumulate,
-                                   void* stream) {
+                                   uint32_t* out_amax, void* stream) {
     FusedArgs a;
     const int rc = fused_args(a, in, out, resid, spec_save, planes, tw, B, M, N, C, K, axis, scale_ck_fwd, apply_ck_inv,
-                              conj_transpose, accumulate);
+                              conj_transpose, accumulate, out_amax);
     if (rc) return rc;
     const dim3 grid((a.R + 7) / 8), block(512);
     const size_t smem = sizeof(float) * 2 * a.L;
@@ -1208,10 +1214,10 @@ extern "C" int ffno_spectral_fused_pair(const ffno_fused_branch* ba, const ffno_
     if (ba->out == bb->out) return FFNO_EINVAL;      // concurrent workgroups: the branches may not share an output
     FusedArgs a, b;
     int rc = fused_args(a, ba->in, ba->out, ba->resid, ba->spec_save, ba->planes, ba->tw, ba->B, ba->M, ba->N, C, ba->K,
-                        ba->axis, scale_ck_fwd, apply_ck_inv, conj_transpose, ba->accumulate);
+                        ba->axis, scale_ck_fwd, apply_ck_inv, conj_transpose, ba->accumulate, ba->out_amax);
     if (rc) return rc;
     rc = fused_args(b, bb->in, bb->out, bb->resid, bb->spec_save, bb->planes, bb->tw, bb->B, bb->M, bb->N, C, bb->K,
-                    bb->axis, scale_ck_fwd, apply_ck_inv, conj_transpose, bb->accumulate);
+                    bb->axis, scale_ck_fwd, apply_ck_inv, conj_transpose, bb->accumulate, bb->out_amax);
     if (rc) return rc;
     const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8;
     const dim3 grid(n0 + n1), block(512);

@@ -263,14 +263,12 @@ class FFNOEngine:
                     int(self.x3_interleave), st)
             return
         self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
-        self._fold(dst0, rout, st)
-        self._fold(dst1, rout, st)
 
     def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True, rin=None, rout=None):
         """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
         fmt = int(bool(x3 and planes is not None and self._x3_h2()))
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout if x3 else None)
+                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout)
 
     # ---- range words (include/ffno.h "Range words"): one uint32 per (tensor kind, layer) in ws.RW ---------------------
     def _ranged(self) -> bool:
@@ -701,14 +699,17 @@ class FFNOEngine:
         """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint);
         rin / rout = range words of src / dst."""
         if not (fused and x3):
-            self._spectral_plain(name, ws, v, src, dst, resid, save, planes, fwd, accumulate, fused, st)
-            self._fold(dst, rout, st)       # only the x3 kernels record their output maximum themselves
+            folded = self._spectral_plain(name, ws, v, src, dst, resid, save, planes, fwd, accumulate, fused, st, rout)
+            if not folded:
+                self._fold(dst, rout, st)       # the stage / DCT / 2-D kernels do not record their output maximum themselves
             return
         br = self._branch(v, src, dst, resid, save, planes, accumulate, True, fwd, rin, rout)
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
         self._k(name, _lib.get_lib().ffno_spectral_x3, ctypes.byref(br), self.C, ck_f, ck_i, conj, st)
 
-    def _spectral_plain(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st):
+    def _spectral_plain(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st,
+                        rout=None) -> bool:
+        """-> True when the kernel that ran folded max |dst| into ``rout`` itself."""
         lib = _lib.get_lib()
         C = self.C
         tw = self._twiddle(v.L)
@@ -734,8 +735,8 @@ class FFNOEngine:
             return
         if fused:
             self._k(name, lib.ffno_spectral_fused, _p(src), _p(dst), resid, _p(save), _p(planes), _p(tw),
-                    v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, ck_i, conj, accumulate, st)
-            return
+                    v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, ck_i, conj, accumulate, rout, st)
+            return True
         SD, SY = ws.SD, ws.SY
         spec = save if save is not None else SD
         self._k("dft_fwd", lib.ffno_dft_fwd, _p(src), _p(spec), _p(tw), v.Bv, v.Mv, v.Nv, C, v.K, v.a01, ck_f, st)
@@ -781,19 +782,20 @@ class FFNOEngine:
                 lib.ffno_spectral_x3_staged_supported(C, ws.views[w].K, ws.views[w].L)
                 and (not full or self.xplanes[0][w] is not None) for w in pair)
                 and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
-        # (the fp32 pair kernel does not record its output maximum: ranged configurations then take the separate calls)
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
-                           and not self.layer_norm and (x3pair or not self._ranged()))
+                           and not self.layer_norm)
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
             ws.X.zero_()     # F.pad(..., 0) of the lifted features (mesh_3d.py:165)
-        self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
-                self.Cin, C, pm, st)
         rw = self._rw
         if self._ranged():
-            ws.RW[:2 * (L + 1)].zero_()       # the forward's words: layer inputs (x) and branch outputs (s)
-            self._fold(ws.X, rw(ws, "x", 0), st)
+            # the forward's words: layer inputs (x) and branch outputs (s) -- and, in the same launch, the words of the backward
+            # pass that will follow this forward
+            ws.RW.zero_()
+            ws.rw_bwd_clean = True
+        self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
+                self.Cin, C, pm, rw(ws, "x", 0), st)
         for l in range(L):
             sv = l if save_for_backward else 0
             last = l == L - 1
@@ -887,7 +889,9 @@ class FFNOEngine:
             # the backward's range words (g: running gradient, d: feed-forward data gradients, t / f: LayerNorm / fork heads):
             # every fp16x2 kernel of the pass scales its operands from the maximum its producer recorded -- per layer, on the
             # device, so no growth or decay of the gradient through the layers can leave the half format's range
-            ws.RW[2 * (L + 1):].zero_()
+            if not getattr(ws, "rw_bwd_clean", False):      # (a second backward pass over the same forward)
+                ws.RW[2 * (L + 1):].zero_()
+            ws.rw_bwd_clean = False
         P = ws.P
         full = self.mode == "full"
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
@@ -915,14 +919,13 @@ class FFNOEngine:
             # head-parameter reduction sums over layers
             for l in range(L):
                 self._k("head_bwd", lib.ffno_head_bwd, _p(ws.F[l]), _p(gy), _p(self.fold), _p(ws.GF) if l == 0 else None,
-                        _p(ws.headpart), _p(ws.red if l == 0 else ws.redl), ws.P_in, C, self.O, ws.nsplit_head, pm, st)
+                        _p(ws.headpart), _p(ws.red if l == 0 else ws.redl), ws.P_in, C, self.O, ws.nsplit_head, pm,
+                        rw(ws, "f", 0) if l == 0 else None, st)
                 if l > 0:
                     self._k("axpy", lib.ffno_axpy, _p(ws.red), _p(ws.redl), 1.0, self.O * (C + 1), st)
-            self._fold(ws.GF, rw(ws, "f", 0), st)
         else:
             self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red),
-                    ws.P_in, C, self.O, ws.nsplit_head, pm, st)
-            self._fold(ws.G[cur], rw(ws, "g", L - 1), st)
+                    ws.P_in, C, self.O, ws.nsplit_head, pm, rw(ws, "g", L - 1), st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
                 _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
         if not self._ffx():
@@ -931,7 +934,7 @@ class FFNOEngine:
         ws.red_jobs = []
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
                            and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
-                           and self.mode != "no-fourier" and not self.layer_norm and (x3pair or not self._ranged()))
+                           and self.mode != "no-fourier" and not self.layer_norm)
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)

@@ -217,7 +217,7 @@ class GeoFNO2DEngine(ZongyiEngine):
         pp = self._pp
         pm = ctypes.byref(ws.padmap)
         ws.x.copy_(x.reshape(P_in, Cin))
-        self._k("fc0", lib.ffno_lift_fwd, _p(ws.x), _p(pp("fc0.weight")), _p(pp("fc0.bias")), _p(ws.X[0]), P_in, Cin, C, pm, st)
+        self._k("fc0", lib.ffno_lift_fwd, _p(ws.x), _p(pp("fc0.weight")), _p(pp("fc0.bias")), _p(ws.X[0]), P_in, Cin, C, pm, None, st)
         for l in range(L):
             last = l == L - 1
             self._spectral(ws, ws.X[l], ws.Sb, ws.SX[l], self.planes[l][0], True, 0, st)

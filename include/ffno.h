@@ -149,7 +149,7 @@ int ffno_spectral_fused_supported(int C, int K, int L);
 int ffno_spectral_fused(const float* in, float* out, const float* resid, float* spec_save,
                         const float* planes, const float* tw, int B, int M, int N, int C, int K,
                         int axis, int scale_ck_fwd, int apply_ck_inv, int conj_transpose,
-                        int accumulate, void* stream);
+                        int accumulate, uint32_t* out_amax /* optional range word of out */, void* stream);
 /* Two branches in one launch (e.g. the two axes of a layer, or two of the three views of the 3-D operator -- each branch
  * carries its own [B][M][N] view of the buffers): the workgroups of both are resident together (two per CU) and hide each
  * other's memory phases.  The branches must write different `out` buffers (accumulate / resid are per branch); scale /
@@ -169,7 +169,8 @@ typedef struct ffno_fused_branch {
                                round of workgroups -- one per CU -- else 16), or 8 / 16; results are bit-identical */
     const uint32_t* in_amax; /* range word of `in` (FP16X2 planes: the spectrum tile is held scaled by the power of two derived
                                 from it -- |X| <= 2 sqrt(L) max|in| goes to 2^15 -- and the outputs are divided again); NULL = 1 */
-    uint32_t* out_amax;      /* optional: receives max |out| of what this branch stores (x3 kernels, fused and staged) */
+    uint32_t* out_amax;      /* optional: receives max |out| of what this branch stores (the fused kernels of both families and
+                                the x3 stage kernels; the fp32 stage kernels ignore it: fold their output with ffno_amax) */
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
@@ -479,7 +480,7 @@ typedef struct ffno_padmap {
  * gradients (deterministic two-step reduction; partial needs nsplit*C*(Cin+1) floats).
  * --------------------------------------------------------------------------------------------- */
 int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
-                  const ffno_padmap* pad, void* stream);
+                  const ffno_padmap* pad, uint32_t* out_amax /* optional range word of out */, void* stream);
 int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
                   int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
 /* dx[p][Cin] = gout[q(p)][C] W: the gradient with respect to the block's INPUT (the reference modules are ordinary autograd
@@ -501,7 +502,8 @@ int ffno_head_fold(const float* Wa, const float* ca, const float* Wb, const floa
 int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int O, int accumulate,
                   const ffno_padmap* pad, void* stream);
 int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
-                  float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, void* stream);
+                  float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad,
+                  uint32_t* gb_amax /* optional range word of gb */, void* stream);
 int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,
                           float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int O,
                           int accumulate, void* stream);

@@ -138,7 +138,7 @@ def test_lift(be, P, Cin, C):
     W = rs.standard_normal((C, Cin)).astype(np.float32)
     b = rs.standard_normal(C).astype(np.float32)
     dx, dW_, db_, out = be.put(x), be.put(W), be.put(b), be.empty((P, C))
-    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, None, None) == 0
+    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, None, None, None) == 0
     assert rel_l2(be.get(out), x.astype(np.float64) @ W.T + b) < TOL
     g = rs.standard_normal((P, C)).astype(np.float32)
     nsplit = 3
@@ -160,7 +160,7 @@ def test_lift_and_head_through_pad_map(be):
     W = rs.standard_normal((C, Cin)).astype(np.float32)
     b = rs.standard_normal(C).astype(np.float32)
     dx, dW_, db_, out = be.put(x), be.put(W), be.put(b), be.zeros((Pp, C))
-    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, ctypes.byref(pm), None) == 0
+    assert lib.ffno_lift_fwd(p(dx), p(dW_), p(db_), p(out), P, Cin, C, ctypes.byref(pm), None, None) == 0
     ref = np.zeros((Pp, C))
     ref[q] = x.astype(np.float64) @ W.T + b
     assert rel_l2(be.get(out), ref) < TOL            # pad region untouched (stays zero)
@@ -183,7 +183,7 @@ def test_lift_and_head_through_pad_map(be):
     gy = rs.standard_normal((P, O)).astype(np.float32)
     nsplit = 3
     dgy, gbuf, part, red = be.put(gy), be.zeros((Pp, C)), be.zeros(nsplit * O * (C + 1)), be.zeros(O * (C + 1))
-    assert lib.ffno_head_bwd(p(dft), p(dgy), p(fold), p(gbuf), p(part), p(red), P, C, O, nsplit, ctypes.byref(pm), None) == 0
+    assert lib.ffno_head_bwd(p(dft), p(dgy), p(fold), p(gbuf), p(part), p(red), P, C, O, nsplit, ctypes.byref(pm), None, None) == 0
     weff = Wb.astype(np.float64) @ Wa
     refg = np.zeros((Pp, C))
     refg[q] = gy.astype(np.float64) @ weff
@@ -218,7 +218,7 @@ def test_head(be, P, C):
     gy = rs.standard_normal(P).astype(np.float32)
     nsplit = 4
     dgy, gb, partial, red = be.put(gy), be.empty((P, C)), be.zeros(nsplit * (C + 1)), be.zeros(C + 1)
-    assert lib.ffno_head_bwd(p(dbf), p(dgy), p(fold), p(gb), p(partial), p(red), P, C, 1, nsplit, None, None) == 0
+    assert lib.ffno_head_bwd(p(dbf), p(dgy), p(fold), p(gb), p(partial), p(red), P, C, 1, nsplit, None, None, None) == 0
     weff = (Wb.astype(np.float64) @ Wa)[0]
     assert rel_l2(be.get(gb), gy[:, None] * weff[None]) < TOL
     G = gy.astype(np.float64) @ bfeat

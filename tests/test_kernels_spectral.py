@@ -212,8 +212,10 @@ def test_spectral_fused_branch_equals_three_stage_path(be, B, M, N, K, C, axis, 
     out, spec = be.empty(x.shape), be.empty((K, R, 2, C))
     fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
     planes = None if direction == "lowpass" else (wpt if direction == "adj" else wp)
+    word = be.zeros(1, np.uint32)
     assert lib.ffno_spectral_fused(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, C, K, axis,
-                                   fwd_ck, inv_ck, conj, 0, None) == 0
+                                   fwd_ck, inv_ck, conj, 0, p(word), None) == 0
+    assert np.asarray(be.get(word)).view(np.float32)[0] == np.abs(be.get(out)).max()     # the kernel recorded its output maximum
     # fp64 reference
     xt = torch.tensor(x, dtype=torch.float64)
     dim = 2 if axis == 0 else 1
@@ -251,7 +253,7 @@ def test_spectral_fused_branch_equals_three_stage_path(be, B, M, N, K, C, axis, 
     resid = rs.standard_normal(x.shape).astype(np.float32)
     dres = be.put(resid)
     assert lib.ffno_spectral_fused(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, C, K, axis,
-                                   fwd_ck, inv_ck, conj, 1, None) == 0
+                                   fwd_ck, inv_ck, conj, 1, None, None) == 0
     assert rel_l2(be.get(out), 2 * ref.numpy() + resid) < TOL
 
 
@@ -262,7 +264,7 @@ def test_spectral_fused_support_matrix(be):
     assert be.lib.ffno_spectral_fused_supported(32, 17, 64) == 0
     assert be.lib.ffno_spectral_fused_supported(48, 8, 64) == 0
     x, tw = be.zeros((1, 4, 64, 64)), be.twiddle(64)
-    assert be.lib.ffno_spectral_fused(be.ptr(x), be.ptr(x), None, None, None, be.ptr(tw), 1, 4, 64, 64, 17, 0, 0, 1, 0, 0, None) == -2
+    assert be.lib.ffno_spectral_fused(be.ptr(x), be.ptr(x), None, None, None, be.ptr(tw), 1, 4, 64, 64, 17, 0, 0, 1, 0, 0, None, None) == -2
 
 
 @pytest.mark.parametrize("B,M,N,K,C", [(2, 10, 12, 5, 64), (1, 40, 48, 20, 64), (2, 9, 14, 4, 32), (1, 34, 36, 17, 32)])

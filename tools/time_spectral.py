@@ -33,5 +33,5 @@ def timeit(name, fn, n=30):
 
 for axis in (0, 1):
     for acc in (0, 1):
-        timeit(f"fused axis={axis} fwd save acc={acc}", lambda: lib.ffno_spectral_fused(p(x), p(out), None, p(spec), p(planes), p(tw), B, M, N, C, K, axis, 0, 1, 0, acc, None))
-timeit("fused axis=0 inference (no save)", lambda: lib.ffno_spectral_fused(p(x), p(out), None, None, p(planes), p(tw), B, M, N, C, K, 0, 0, 1, 0, 0, None))
+        timeit(f"fused axis={axis} fwd save acc={acc}", lambda: lib.ffno_spectral_fused(p(x), p(out), None, p(spec), p(planes), p(tw), B, M, N, C, K, axis, 0, 1, 0, acc, None, None))
+timeit("fused axis=0 inference (no save)", lambda: lib.ffno_spectral_fused(p(x), p(out), None, None, p(planes), p(tw), B, M, N, C, K, 0, 0, 1, 0, 0, None, None))
