@@ -385,6 +385,7 @@ class FFNOEngine:
                     if nb:
                         self.xplanes[si][w] = tuple(torch.empty(nb // 4, dtype=torch.int32, device=dev) for _ in range(2))
         self._x3pack_sig = None
+        self._prep_sig = None
         self._ws_key = None
         self._ws_cache = {}
         self._tw = {}
@@ -577,9 +578,23 @@ class FFNOEngine:
             cache.pop(next(iter(cache)))
         return ws
 
+    def weights_changed(self):
+        """Tell the engine that parameter memory was written behind PyTorch's back (a raw-pointer kernel such as the fused
+        AdamW of FFNOTrainer): the derived operands (weight-norm products, packed fragments, folded head) are rebuilt by the
+        next forward.  In-place torch ops (optimizer.step(), load_state_dict, broadcast) are seen through the tensors'
+        version counters and need no call."""
+        self._prep_sig = None
+
     def _prepare_weights(self, st):
         lib = _lib.get_lib()
         self._refresh_pointers()
+        # derived operands only depend on the parameters and the arithmetic choices: an inference loop (rollout: 10-100 forwards
+        # on the same weights) prepares them once -- five launches less per forward
+        sig = (tuple((t.data_ptr(), t._version) for t in self.params.values()), self.ff_split, self.x3_mix_split,
+               tuple(self._x3_fmt or ()), self.use_x3, self.use_ffx, getattr(st, "value", st))
+        if sig == getattr(self, "_prep_sig", None):
+            return
+        self._prep_sig = sig
         if self._desc_dev is not None:
             self._k("weightnorm_fwd", lib.ffno_weightnorm_fwd, _p(self._desc_dev), self._n_desc, self._max_rows, st)
         if self._ffx() and self._n_fx:

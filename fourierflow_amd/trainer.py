@@ -118,6 +118,8 @@ class FFNOTrainer:
         _capi.check(fn(_p(self.pflat), _p(gflat), _p(self.m), _p(self.v), self.pflat.numel(), lr_t, self.betas[0],
                        self.betas[1], self.eps, self.wd, self.opt_step, 1.0 / self.world,
                        _lib.current_stream(self.device)), "adamw" if self.decoupled else "adam")
+        if hasattr(self.engine, "weights_changed"):
+            self.engine.weights_changed()      # (the kernel wrote the parameters through a raw pointer)
         return loss_out
 
     @torch.no_grad()
