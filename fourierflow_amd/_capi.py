@@ -173,6 +173,14 @@ SIGNATURES = {
     "ffno_plin_wgrad_nsplit": (I, [L]),
     "ffno_plin_wgrad_partial_floats": (SZ, [L, I, I]),
     "ffno_plin_bwd_weights": (I, [P, I, P, P, I, P, P, P, L, I, I, I, I, P]),
+    "ffno_glin_supported": (I, [I, I]),
+    "ffno_glin_fwd": (I, [P, P, P, P, P, L, I, I, I, F, C.c_uint32, P]),
+    "ffno_glin_bwd_data": (I, [P, P, P, P, L, I, I, F, C.c_uint32, I, P]),
+    "ffno_glin_wgrad_nsplit": (I, [L]),
+    "ffno_glin_wgrad_partial_floats": (SZ, [L, I, I]),
+    "ffno_glin_bwd_weights": (I, [P, P, P, P, P, P, L, I, I, F, C.c_uint32, I, P]),
+    "ffno_dropout": (I, [P, SZ, F, C.c_uint32, P]),
+    "ffno_dropout_mask": (I, [P, SZ, F, C.c_uint32, P]),
     "ffno_pad_copy": (I, [P, I, I, P]),
     "ffno_velocity_ws_floats": (SZ, [I, I, I]),
     "ffno_velocity_features": (I, [P, P, P, I, I, I, F, F, P]),

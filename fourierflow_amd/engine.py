@@ -73,7 +73,8 @@ class FFNOEngine:
     def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
                  share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
                  padding: int = 0, output_dim: int = 1, use_fork: bool = False, first_axis_first: bool = False,
-                 spectral: str = "factorized", layer_norm: bool = False):
+                 spectral: str = "factorized", layer_norm: bool = False, n_ff_layers: int = 2, dropout: float = 0.0,
+                 in_dropout: float = 0.0):
         if mode not in MODES:
             raise ValueError(f"mode must be one of {list(MODES)}, got {mode!r}")
         if spatial_dims not in (2, 3):
@@ -87,6 +88,16 @@ class FFNOEngine:
             raise ValueError("output_dim must be in 1..8")
         if layer_norm and use_fork:
             raise NotImplementedError("layer_norm together with use_fork (per-layer forecast heads) is not built")
+        if n_ff_layers < 2:
+            raise NotImplementedError("n_ff_layers = 1 (a single width -> width linear) is not built")
+        if not (0.0 <= dropout < 1.0 and 0.0 <= in_dropout < 1.0):
+            raise ValueError("dropout / in_dropout must lie in [0, 1)")
+        # FeedForward beyond the fused kernels' shape (n_layers = 2, dropout = 0; feedforward.py:13-23): the GENERAL path, one
+        # glin kernel per linear layer with kept hidden activations and regenerated dropout masks (csrc/glin.hip)
+        self.n_ff, self.dropout, self.in_dropout = int(n_ff_layers), float(dropout), float(in_dropout)
+        self.general_ff = self.n_ff != 2 or self.dropout > 0.0
+        self.drop_seed = int(torch.initial_seed()) & 0x7FFFFFFF      # base seed of the dropout masks (tests may set it)
+        self._drop_calls = 0                                          # training forwards so far: every one draws new masks
         # FeedForward(layer_norm=True): nn.LayerNorm(width) after the last linear of every feed-forward (feedforward.py:18-19)
         self.layer_norm = bool(layer_norm)
         if spectral not in ("factorized", "plus", "dct"):
@@ -124,7 +135,7 @@ class FFNOEngine:
             else:
                 self.param_shapes[prefix + "weight"] = (rows, cols)
             self.param_shapes[prefix + "bias"] = (rows,)
-            if layer_norm and prefix.endswith("_ff.layers.1.0."):       # the Sequential slot of the reference: layers.1.3
+            if layer_norm and prefix.endswith(f"_ff.layers.{self.n_ff - 1}.0."):   # the Sequential slot of the reference: layers.<last>.3
                 self.param_shapes[prefix[:-2] + "3.weight"] = (rows,)
                 self.param_shapes[prefix[:-2] + "3.bias"] = (rows,)
 
@@ -132,22 +143,22 @@ class FFNOEngine:
         self.ff_prefix: List[str] = []
         self.fc_prefix: List[str] = []     # forecast feed-forwards (use_fork)
         self.fw_names: List[Tuple[str, ...]] = []
+        def add_ff(prefix):             # FeedForward(dim, factor, ..., n_layers): dims C -> H (-> H)* -> C (feedforward.py:13-16)
+            for k in range(self.n_ff):
+                add_linear(prefix + f"layers.{k}.0.", C if k == self.n_ff - 1 else H, C if k == 0 else H)
+
         if share_fork:                      # registration order of the reference: forecast_ff, backcast_ff (grid_2d.py:116-122)
             if use_fork:
-                add_linear("forecast_ff.layers.0.0.", H, C)
-                add_linear("forecast_ff.layers.1.0.", C, H)
-            add_linear("backcast_ff.layers.0.0.", H, C)
-            add_linear("backcast_ff.layers.1.0.", C, H)
+                add_ff("forecast_ff.")
+            add_ff("backcast_ff.")
         for l in range(n_layers):
             if use_fork:
                 fc = "forecast_ff." if share_fork else f"spectral_layers.{l}.forecast_ff."
                 self.fc_prefix.append(fc)
-                add_linear(fc + "layers.0.0.", H, C)
-                add_linear(fc + "layers.1.0.", C, H)
+                add_ff(fc)
             fp = "backcast_ff." if share_fork else f"spectral_layers.{l}.backcast_ff."
             self.ff_prefix.append(fp)
-            add_linear(fp + "layers.0.0.", H, C)
-            add_linear(fp + "layers.1.0.", C, H)
+            add_ff(fp)
             if mode == "full":
                 base = "fourier_weight." if share_weight else f"spectral_layers.{l}.fourier_weight."
                 names = tuple(base + str(w) for w in range(self.nd))
@@ -175,6 +186,7 @@ class FFNOEngine:
         self._ws_key = None
         self._tw: Dict[int, torch.Tensor] = {}
         self._saved = None
+        self._training = False
         self.use_fused = True   # fused A->B->C branch kernel when (C, K, L) fits its LDS tile; else 3 stage kernels
         # feed-forward on the bf16 matrix cores at fp32 accuracy (ffx.hip: split-bf16, no stored hidden activations)
         # when the library has the (C, H) instance; False = the fp32-MFMA kernels of ff.hip
@@ -293,7 +305,7 @@ class FFNOEngine:
         return self.x3_mix_split == "fp16x2"
 
     def _ffx(self) -> bool:
-        return bool(self.use_ffx and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
+        return bool(self.use_ffx and not self.general_ff and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
 
     def _h2(self) -> bool:
         if self.ff_split not in ("fp16x2", "bf16x3"):
@@ -417,7 +429,7 @@ class FFNOEngine:
         self._n_desc = len(descs)
         toff, tdescs = 0, []
         for pfx, lin in self.linears.items():
-            if "_ff." not in pfx:
+            if "_ff." not in pfx or self.general_ff:      # (the fp32 fused feed-forward's backward reads transposed weights)
                 continue
             n = lin.rows * lin.cols
             lin.wt = self.wt_flat[toff:toff + n].view(lin.cols, lin.rows)
@@ -427,7 +439,7 @@ class FFNOEngine:
         lib = _lib.get_lib()
         blocks = list(dict.fromkeys(self.ff_prefix + self.fc_prefix))
         self._n_fx = 0
-        if lib.ffno_ffx_supported(self.C, self.H):
+        if lib.ffno_ffx_supported(self.C, self.H) and not self.general_ff:
             words = int((lib.ffno_ffh_pack_bytes if self._h2() else lib.ffno_ffx_pack_bytes)(self.C, self.H)) // 4
             if getattr(self, "_fx_flat", None) is None or self._fx_flat.numel() != 4 * words * len(blocks) \
                     or self._fx_flat.device != self.device:
@@ -485,7 +497,7 @@ class FFNOEngine:
                 _View(B, X * Y, Z, 0, self.Ks[2], C)]       # z: contiguous lines (b, x, y)
 
     def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
-        key = (B, tuple(S), bool(save), self._ffx(), self._conc())
+        key = (B, tuple(S), bool(save), self._ffx(), self._conc(), self.general_ff)
         if self._ws_key == key:
             return self._ws
         cache = self.__dict__.setdefault("_ws_cache", {})   # a few recent geometries (train batch / validation batch /
@@ -539,16 +551,24 @@ class FFNOEngine:
         if self.use_fork:
             ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
             ws.YL = torch.empty(L, P_in * O, **f32)             # per-layer head outputs (forecast_list)
+        if self.general_ff:
+            # kept hidden activations of the general feed-forward path, per block kind / saved layer / hidden layer
+            kinds = ["backcast"] + (["forecast"] if self.use_fork else [])
+            ws.HG = {kind: [[torch.empty(P, H, **f32) for _ in range(self.n_ff - 1)] for _ in range(ns)] for kind in kinds}
+            if save:
+                ws.DA = [torch.empty(P, H, **f32) for _ in range(2)]
+                ws.glpart = torch.empty(int(lib.ffno_glin_wgrad_partial_floats(P, H, H)), **f32)
+        fp32_ff = not self._ffx() and not self.general_ff      # the fp32 fused feed-forward keeps h / dh in HBM
         if save and self.use_fork:
-            ws.HF = torch.empty(ns, P, H, **f32) if not self._ffx() else [None] * ns
+            ws.HF = torch.empty(ns, P, H, **f32) if fp32_ff else [None] * ns
             ws.MASKF = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
             ws.DSF = torch.empty(P, C, **f32)
             ws.GF = torch.empty(P, C, **f32)
             ws.redl = torch.empty(O * (C + 1), **f32)
         if save:
-            ws.Hbuf = torch.empty(ns, P, H, **f32) if not self._ffx() else [None] * ns
+            ws.Hbuf = torch.empty(ns, P, H, **f32) if fp32_ff else [None] * ns
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
-            ws.DH = [torch.empty(P, H, **f32) if not self._ffx() else None for _ in range(2)]   # ping-pong (side-stream option)
+            ws.DH = [torch.empty(P, H, **f32) if fp32_ff else None for _ in range(2)]   # ping-pong (side-stream option)
             ws.DS = torch.empty(P, C, **f32)
             ws.G = [torch.empty(P, C, **f32) for _ in range(2)]    # running gradient, ping-pong per layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
@@ -678,6 +698,48 @@ class FFNOEngine:
             self._k("ff_bwd_weights_reduce", lib.ffno_ff_bwd_weights_reduce, _p(ws.ffpart), _p(l0.gweff), _p(l1.gweff),
                     _p(gb0), _p(gb1), C, H, ws.nsplit_ff, accumulate, st)
 
+    # ---- the GENERAL feed-forward path (n_ff_layers != 2 or dropout > 0): one glin kernel per linear layer ------------------
+    def _drop_args(self, layer: int, kind: str, k: int):
+        """(p, seed) of the dropout site behind linear k of a feed-forward block in this pass: a new mask per training forward,
+        layer, block kind and site; the backward pass regenerates it from the same pair."""
+        if not (self.dropout > 0.0 and self._training):
+            return 0.0, 0
+        h = (self.drop_seed * 0x9E3779B1 + self._drop_calls * 0x85EBCA6B + layer * 0xC2B2AE35 + (k + 1) * 0x27D4EB2F
+             + (0x165667B1 if kind == "forecast" else 0)) & 0xFFFFFFFF
+        return self.dropout, h
+
+    def _ffg_fwd(self, ws, prefix, kind, layer, sv, s, resid, out, P, st, rout=None):
+        lib = _lib.get_lib()
+        a = s
+        for k in range(self.n_ff):
+            last = k == self.n_ff - 1
+            lin = self.linears[prefix + f"layers.{k}.0."]
+            dst = out if last else ws.HG[kind][sv][k]
+            p, seed = self._drop_args(layer, kind, k)
+            self._k("ff_fwd", lib.ffno_glin_fwd, _p(a), _p(lin.weff), _p(self.params[prefix + f"layers.{k}.0.bias"]),
+                    _p(resid) if last else None, _p(dst), P, lin.cols, lin.rows, int(not last), p, seed, st)
+            a = dst
+        self._fold(out, rout, st)
+
+    def _ffg_bwd(self, ws, prefix, kind, layer, s, g, ds, accumulate, P, st, rout=None):
+        """g = dL/d(feed-forward output) -> ds = dL/ds, and the parameter gradients of every linear of the block."""
+        lib = _lib.get_lib()
+        gv = self.grad_view
+        g_cur = g
+        for k in reversed(range(self.n_ff)):
+            last = k == self.n_ff - 1
+            lin = self.linears[prefix + f"layers.{k}.0."]
+            x_in = s if k == 0 else ws.HG[kind][layer][k - 1]
+            y = None if last else ws.HG[kind][layer][k]
+            p, seed = self._drop_args(layer, kind, k)
+            self._k("ff_bwd_weights_partial", lib.ffno_glin_bwd_weights, _p(g_cur), _p(y), _p(x_in), _p(ws.glpart), _p(lin.gweff),
+                    _p(gv(prefix + f"layers.{k}.0.bias")), P, lin.cols, lin.rows, p, seed, int(accumulate), st)
+            dx = ds if k == 0 else ws.DA[k & 1]
+            self._k("ff_bwd_data", lib.ffno_glin_bwd_data, _p(g_cur), _p(y), _p(lin.weff), _p(dx), P, lin.cols, lin.rows, p, seed,
+                    0, st)
+            g_cur = dx
+        self._fold(ds, rout, st)
+
     def _planes_for(self, si, w, adj: int, x3: bool):
         if self.mode != "full":
             return None
@@ -763,8 +825,9 @@ class FFNOEngine:
                 accumulate, st)
 
     # ------------------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, save_for_backward: bool) -> torch.Tensor:
-        """x [B, *spatial, input_dim] fp32 on the device -> [B, *spatial, output_dim] (a fresh tensor)."""
+    def forward(self, x: torch.Tensor, save_for_backward: bool, training: Optional[bool] = None) -> torch.Tensor:
+        """x [B, *spatial, input_dim] fp32 on the device -> [B, *spatial, output_dim] (a fresh tensor).
+        ``training`` (default: save_for_backward) switches the dropout masks on (nn.Module.training of the reference)."""
         if not self.params:
             raise RuntimeError("bind() parameters first")
         _lib.require_device_tensor(x, "x")
@@ -782,6 +845,9 @@ class FFNOEngine:
                                      f"(the reference raises an einsum size error)")
         st = _lib.current_stream(self.device)
         P = ws.P
+        self._training = bool(save_for_backward if training is None else training)
+        if self._training and (self.dropout > 0.0 or self.in_dropout > 0.0):
+            self._drop_calls += 1
         fused = self._can_fuse(ws.views)
         x3 = self._use_x3(ws.views, fused)
         # format of the packed x3 weight sets per axis: fp16x2 where the FUSED x3 kernel mixes with them (the stage kernels of
@@ -809,8 +875,13 @@ class FFNOEngine:
             # pass that will follow this forward
             ws.RW.zero_()
             ws.rw_bwd_clean = True
+        in_drop = self._training and self.in_dropout > 0.0
         self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
-                self.Cin, C, pm, rw(ws, "x", 0), st)
+                self.Cin, C, pm, None if in_drop else rw(ws, "x", 0), st)
+        if in_drop:      # x = self.drop(x) after in_proj (grid_2d.py:158): a regenerated mask over the lifted features
+            self._in_drop_seed = (self.drop_seed * 0x9E3779B1 + self._drop_calls * 0x85EBCA6B + 0x632BE5AB) & 0xFFFFFFFF
+            self._k("in_dropout", lib.ffno_dropout, _p(ws.X), ws.X.numel(), self.in_dropout, self._in_drop_seed, st)
+            self._fold(ws.X, rw(ws, "x", 0), st)
         for l in range(L):
             sv = l if save_for_backward else 0
             last = l == L - 1
@@ -857,12 +928,16 @@ class FFNOEngine:
             if conc:
                 self._ffs_fwd2(s_l, ws.T, s_l if save_for_backward else None, ff_res, l0, b0, b1, ff_out,
                                ws.MASK[sv] if save_for_backward else None, P, st, rs_, ff_rout)
-            elif not (self.use_fork and last):    # with fork heads the last layer's backcast only feeds the dead x_L
+            elif self.use_fork and last:          # with fork heads the last layer's backcast only feeds the dead x_L
+                pass
+            elif self.general_ff:
+                self._ffg_fwd(ws, self.ff_prefix[l], "backcast", l, sv, s_l, ff_res, ff_out, P, st, ff_rout)
+            else:
                 self._ff_fwd(s_l, ff_res, l0, l1, b0, b1, ff_out,
                              ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st,
                              rs_, ff_rout)
             if self.layer_norm:
-                ln = self.ff_prefix[l] + "layers.1.3."
+                ln = self.ff_prefix[l] + f"layers.{self.n_ff - 1}.3."
                 self._k("layernorm_fwd", lib.ffno_layernorm_fwd, _p(ws.TL[sv]), _p(self.params[ln + "weight"]),
                         _p(self.params[ln + "bias"]), None if last else _p(ws.X), _p(ws.Blast if last else ws.X), _p(ws.LNS[sv]),
                         P, C, 1e-5, st)
@@ -870,8 +945,11 @@ class FFNOEngine:
                     self._fold(ws.X, rxn, st)
             if self.use_fork:
                 c0, c1, cb0, cb1 = self._fc_weights(l)
-                self._ff_fwd(s_l, None, c0, c1, cb0, cb1, ws.F[sv], ws.HF[sv] if save_for_backward else None,
-                             ws.MASKF[sv] if save_for_backward else None, P, st, rs_, None)
+                if self.general_ff:
+                    self._ffg_fwd(ws, self.fc_prefix[l], "forecast", l, sv, s_l, None, ws.F[sv], P, st)
+                else:
+                    self._ff_fwd(s_l, None, c0, c1, cb0, cb1, ws.F[sv], ws.HF[sv] if save_for_backward else None,
+                                 ws.MASKF[sv] if save_for_backward else None, P, st, rs_, None)
                 self._k("head_fwd", lib.ffno_head_fwd, _p(ws.F[sv]), _p(self.fold), _p(ws.YL[l]), ws.P_in, C, self.O, 0, pm, st)
         if self.use_fork:
             torch.sum(ws.YL, dim=0, out=ws.Y)     # forecast = sum of the per-layer head outputs
@@ -943,7 +1021,7 @@ class FFNOEngine:
                     ws.P_in, C, self.O, ws.nsplit_head, pm, rw(ws, "g", L - 1), st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
                 _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
-        if not self._ffx():
+        if not self._ffx() and self._n_tr:
             self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
         ws.red_jobs = []
@@ -962,17 +1040,19 @@ class FFNOEngine:
                 fc = self.fc_prefix[l]
                 ds_f = ws.DS if last else ws.DSF     # last layer: the forecast path is the only contribution to ds
                 rf = rw(ws, "f", 0)
-                self._ff_bwd_data(ws.GF, ws.MASKF[l], c0, c1, dh, ds_f, P, st, rf, rd)
-                self._ff_bwd_weights(ws, ws.S[l], ws.GF, ws.HF[l], dh, c0, c1, self.params[fc + "layers.0.0.bias"],
-                                     gv(fc + "layers.0.0.bias"), gv(fc + "layers.1.0.bias"), int(fc in ff_seen), P, st, rs_, rf)
+                if self.general_ff:
+                    self._ffg_bwd(ws, fc, "forecast", l, ws.S[l], ws.GF, ds_f, int(fc in ff_seen), P, st, rd)
+                else:
+                    self._ff_bwd_data(ws.GF, ws.MASKF[l], c0, c1, dh, ds_f, P, st, rf, rd)
+                    self._ff_bwd_weights(ws, ws.S[l], ws.GF, ws.HF[l], dh, c0, c1, self.params[fc + "layers.0.0.bias"],
+                                         gv(fc + "layers.0.0.bias"), gv(fc + "layers.1.0.bias"), int(fc in ff_seen), P, st, rs_, rf)
                 ff_seen.add(fc)
             if self.use_fork and last:
                 # x_L is never used with fork heads: the last backcast_ff gets a zero gradient
                 if fp not in ff_seen:
-                    for nm in (fp + "layers.0.0.bias", fp + "layers.1.0.bias"):
-                        gv(nm).zero_()
-                    l0.gweff.zero_()
-                    l1.gweff.zero_()
+                    for k in range(self.n_ff):
+                        gv(fp + f"layers.{k}.0.bias").zero_()
+                        self.linears[fp + f"layers.{k}.0."].gweff.zero_()
                     ff_seen.add(fp)
                 if self.mode == "no-fourier":
                     g_out.copy_(ws.DS)
@@ -1009,7 +1089,7 @@ class FFNOEngine:
             g_ff = g_in       # gradient w.r.t. the feed-forward output
             if self.layer_norm:
                 # through the LayerNorm first (it also folds in the second gradient buffer of a paired adjoint launch)
-                ln = fp + "layers.1.3."
+                ln = fp + f"layers.{self.n_ff - 1}.3."
                 two = bool(conc and have_g1)
                 self._k("layernorm_bwd", lib.ffno_layernorm_bwd, _p(ws.TL[l]), _p(ws.LNS[l]), _p(self.params[ln + "weight"]),
                         _p(g_in), _p(ws.G1) if two else None, _p(g_in) if two else None, _p(ws.DT), _p(ws.lnpart),
@@ -1021,14 +1101,17 @@ class FFNOEngine:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
                 two = bool(have_g1 and not self.layer_norm)
                 self._ffs_bwd2(g_ff, ws.G1 if two else None, g_ff if two else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
+            elif self.general_ff:
+                self._ffg_bwd(ws, fp, "backcast", l, ws.S[l], g_ff, ws.DS, int(fp in ff_seen), P, st, rd)
             else:
                 self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st, rg, rd)
             if use_side:
                 ev_a.record(main_obj)
                 side.wait_event(ev_a)
                 self._issue_stream = side
-            self._ff_bwd_weights(ws, ws.S[l], g_ff, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
-                                 gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side, rs_, rg)
+            if not self.general_ff:
+                self._ff_bwd_weights(ws, ws.S[l], g_ff, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
+                                     gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side, rs_, rg)
             ff_seen.add(fp)
             if self.use_fork:
                 self._k("axpy", lib.ffno_axpy, _p(ws.DS), _p(ws.DSF), 1.0, P * C, st)     # ds = ds(backcast) + ds(forecast)
@@ -1078,6 +1161,8 @@ class FFNOEngine:
                     ws.nsplit_ff, st)     # main stream: it has already waited for the side stream's partial kernels
         g_fin = ws.G[cur]
         lin_in = self.linears["in_proj."]
+        if self._training and self.in_dropout > 0.0:      # backward of x = self.drop(in_proj(x)): the same mask, regenerated
+            self._k("in_dropout", lib.ffno_dropout, _p(g_fin), g_fin.numel(), self.in_dropout, self._in_drop_seed, st)
         self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")),
                 ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
         self.dx = None
@@ -1129,6 +1214,12 @@ class FFNOEngine:
         """Diagnostics / parity tests: the ReLU active sets of the last ``forward(save_for_backward=True)``,
         {("backcast" | "forecast", layer): uint8 [pixels of the (padded) activation buffer, hidden]} -- what
         ``threshold_backward`` of feedforward.py:17 would see.  Split-bf16 feed-forward only."""
+        if self._saved is not None and self.general_ff:
+            _, B, S, _, _ = self._saved
+            ws = self._workspace(B, S, True)
+            # a LIST per block: one active set per hidden activation; with dropout a dropped unit counts as inactive
+            return {(kind, l): [(h > 0).to(torch.uint8) for h in ws.HG[kind][l]] for kind in ws.HG for l in range(self.L)
+                    if not (kind == "backcast" and self.use_fork and l == self.L - 1)}
         if self._saved is None or not self._ffx():
             raise RuntimeError("relu_active_sets() needs a preceding forward(save_for_backward=True) on the ffx path")
         _, B, S, _, _ = self._saved
@@ -1146,11 +1237,40 @@ class FFNOEngine:
         return out
 
 
+    def dropout_keep_sets(self):
+        """Diagnostics / parity tests: the dropout masks of the last training forward, regenerated from their seeds:
+        {("backcast" | "forecast", layer): [keep mask (uint8 [pixels, features]) behind every linear of the block]} and
+        {"in": keep mask of the lifted features} -- what nn.Dropout drew in the reference (feedforward.py:16, grid_2d.py:158)."""
+        if self._saved is None:
+            raise RuntimeError("dropout_keep_sets() needs a preceding forward(save_for_backward=True)")
+        _, B, S, _, _ = self._saved
+        ws = self._workspace(B, S, True)
+        lib = _lib.get_lib()
+        st = _lib.current_stream(self.device)
+        out = {}
+
+        def mask(n_rows, n_cols, p, seed):
+            m = torch.zeros(n_rows, n_cols, dtype=torch.uint8, device=self.device)
+            self._k("dropout_mask", lib.ffno_dropout_mask, _p(m), m.numel(), p, seed, st)
+            return m
+
+        if self._training and self.in_dropout > 0.0:
+            out["in"] = mask(ws.P, self.C, self.in_dropout, self._in_drop_seed)
+        if self._training and self.dropout > 0.0:
+            for kind in (["backcast"] + (["forecast"] if self.use_fork else [])):
+                for l in range(self.L):
+                    out[(kind, l)] = [mask(ws.P, self.C if k == self.n_ff - 1 else self.H, *self._drop_args(l, kind, k))
+                                      for k in range(self.n_ff)]
+        return out
+
+
 class FFNO2DEngine(FFNOEngine):
     """FNOFactorized2DBlock geometry (the 2-D entry point used by the module mirror and the tests)."""
 
     def __init__(self, *, modes: int, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
-                 share_fork: bool, ff_weight_norm: bool, mode: str = "full", use_fork: bool = False, layer_norm: bool = False):
+                 share_fork: bool, ff_weight_norm: bool, mode: str = "full", use_fork: bool = False, layer_norm: bool = False,
+                 n_ff_layers: int = 2, dropout: float = 0.0, in_dropout: float = 0.0):
         super().__init__(modes=modes, width=width, input_dim=input_dim, n_layers=n_layers, factor=factor,
                          share_weight=share_weight, share_fork=share_fork, ff_weight_norm=ff_weight_norm, mode=mode,
-                         spatial_dims=2, padding=0, output_dim=1, use_fork=use_fork, layer_norm=layer_norm)
+                         spatial_dims=2, padding=0, output_dim=1, use_fork=use_fork, layer_norm=layer_norm,
+                         n_ff_layers=n_ff_layers, dropout=dropout, in_dropout=in_dropout)

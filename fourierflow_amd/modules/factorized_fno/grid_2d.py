@@ -38,10 +38,10 @@ class SpectralConv2d(nn.Module):
         if use_fork:
             self.forecast_ff = forecast_ff
             if not self.forecast_ff:
-                self.forecast_ff = FeedForward(out_dim, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
+                self.forecast_ff = FeedForward(out_dim, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout, general_ok=True)
         self.backcast_ff = backcast_ff
         if not self.backcast_ff:
-            self.backcast_ff = FeedForward(out_dim, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
+            self.backcast_ff = FeedForward(out_dim, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout, general_ok=True)
 
     def forward_fourier(self, x):
         from ...ops import spectral_conv2d
@@ -60,7 +60,7 @@ class _BlockFn(torch.autograd.Function):
     def forward(ctx, x, module, *params):
         eng = module._engine_for(params)
         need_grad = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:])
-        y = eng.forward(x, need_grad)
+        y = eng.forward(x, need_grad, training=module.training)      # (dropout follows nn.Module.training like the reference)
         module._generation += 1
         ctx.module, ctx.gen, ctx.n = module, module._generation, len(params)
         return y
@@ -90,22 +90,21 @@ class FNOFactorized2DBlock(nn.Module):
                  share_weight: bool = False, share_fork=False, factor=2, ff_weight_norm=False, n_ff_layers=2,
                  gain=1, layer_norm=False, use_fork=False, mode='full'):
         super().__init__()
-        if in_dropout:
-            raise NotImplementedError("in_dropout > 0 is not implemented by the gfx950 kernel set (no config uses it)")
         if layer_norm and use_fork:
             raise NotImplementedError("layer_norm together with use_fork is not implemented by the gfx950 kernel set")
         self.modes, self.width, self.input_dim = modes, width, input_dim
         self.n_layers, self.use_fork, self.mode = n_layers, use_fork, mode
         self.share_weight, self.share_fork = share_weight, share_fork
         self.factor, self.ff_weight_norm, self.layer_norm = factor, ff_weight_norm, bool(layer_norm)
+        self.n_ff_layers, self.dropout, self.in_dropout = n_ff_layers, float(dropout), float(in_dropout)
         self.in_proj = WNLinear(input_dim, width, wnorm=ff_weight_norm)
-        self.drop = nn.Identity()  # nn.Dropout(in_dropout=0)
+        self.drop = nn.Dropout(in_dropout)      # (no parameters; the mask is drawn inside the engine: ffno_dropout)
 
         self.forecast_ff = self.backcast_ff = None
         if share_fork:
             if use_fork:
-                self.forecast_ff = FeedForward(width, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
-            self.backcast_ff = FeedForward(width, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
+                self.forecast_ff = FeedForward(width, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout, general_ok=True)
+            self.backcast_ff = FeedForward(width, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout, general_ok=True)
 
         self.fourier_weight = None
         if share_weight:
@@ -129,7 +128,8 @@ class FNOFactorized2DBlock(nn.Module):
             self._engine = FFNO2DEngine(modes=self.modes, width=self.width, input_dim=self.input_dim,
                                         n_layers=self.n_layers, factor=self.factor, share_weight=self.share_weight,
                                         share_fork=self.share_fork, ff_weight_norm=self.ff_weight_norm, mode=self.mode,
-                                        use_fork=self.use_fork, layer_norm=self.layer_norm)
+                                        use_fork=self.use_fork, layer_norm=self.layer_norm, n_ff_layers=self.n_ff_layers,
+                                        dropout=self.dropout, in_dropout=self.in_dropout)
         return self._engine
 
     def engine_parameters(self):

@@ -35,7 +35,7 @@ class SpectralConv2d(nn.Module):
                 self.fourier_weight.append(param)
         self.backcast_ff = backcast_ff
         if not self.backcast_ff:
-            self.backcast_ff = FeedForward(out_dim, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout)
+            self.backcast_ff = FeedForward(out_dim, factor, ff_weight_norm, n_ff_layers, layer_norm, dropout, general_ok=True)
 
 
 class _Mesh3DFn(torch.autograd.Function):
@@ -88,6 +88,7 @@ class FNOFactorizedMesh3D(nn.Module):
         self.out = nn.Sequential(WNLinear(self.width, 128, wnorm=ff_weight_norm),
                                  WNLinear(128, output_dim, wnorm=ff_weight_norm))
         self.layer_norm = bool(layer_norm)
+        self.n_ff_layers = n_ff_layers
         self._engine = None
         self._generation = 0
 
@@ -97,7 +98,7 @@ class FNOFactorizedMesh3D(nn.Module):
                                       input_dim=self.input_dim, n_layers=self.n_layers, factor=self.factor,
                                       share_weight=self.share_weight, share_fork=False,
                                       ff_weight_norm=self.ff_weight_norm, mode="full", spatial_dims=3,
-                                      padding=self.padding, output_dim=self.output_dim, layer_norm=self.layer_norm)
+                                      padding=self.padding, output_dim=self.output_dim, layer_norm=self.layer_norm, n_ff_layers=self.n_ff_layers)
         return self._engine
 
     def engine_parameters(self):

@@ -657,6 +657,32 @@ int ffno_plin_bwd_weights(const float* g, int ldg, const float* act, const float
                           float* dW, float* db, long P, int Cin, int Cout, int accumulate, int act_mode,
                           void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The GENERAL feed-forward path (fourierflow/modules/feedforward.py:6-24 beyond the fused kernels' n_layers = 2 / dropout = 0,
+ * and nn.Dropout(in_dropout) of grid_2d.py:113,158): one linear layer per call, any Cin, Cout <= 256, exact fp32 on the matrix
+ * cores, hidden activations kept by the caller.  Dropout is a counter-based mask: element idx of the [P][Cout] output is kept
+ * iff hash(seed, idx) >= p * 2^32 and scaled by 1 / (1 - p); the backward calls REGENERATE it from (p, seed) -- nothing is stored.
+ *   fwd:         out[p][o] = drop(act(b[o] + sum_i W[o][i] x[p][i])) (+ resid[p][o]);  relu = 1: ReLU  (Linear -> Dropout -> ReLU
+ *                of the reference: the positive dropout scale commutes with the ReLU)
+ *   bwd_data:    dpre = g * (y ? [y > 0] : keep) / (1 - p);  dx[p][i] (+)= sum_o dpre[p][o] W[o][i]
+ *                (y = the kept OUTPUT of a ReLU layer -- its zeros already contain the dropped units; y = NULL: the last layer)
+ *   bwd_weights: dW[o][i] (+)= sum_p dpre[p][o] x[p][i],  db[o] (+)= sum_p dpre[p][o]  (deterministic two-stage reduction through
+ *                `partial`, ffno_glin_wgrad_partial_floats() floats)
+ *   ffno_dropout: x[i] <- keep(seed, i) ? x[i] / (1 - p) : 0 in place (in_dropout; the same call on the gradient is its
+ *                backward); ffno_dropout_mask writes the keep bits (diagnostics / parity tests).
+ * --------------------------------------------------------------------------------------------- */
+int ffno_glin_supported(int Cin, int Cout);
+int ffno_glin_fwd(const float* x, const float* W, const float* b, const float* resid, float* out, long P, int Cin, int Cout,
+                  int relu, float drop_p, uint32_t drop_seed, void* stream);
+int ffno_glin_bwd_data(const float* g, const float* y, const float* W, float* dx, long P, int Cin, int Cout, float drop_p,
+                       uint32_t drop_seed, int accumulate, void* stream);
+int ffno_glin_wgrad_nsplit(long P);
+size_t ffno_glin_wgrad_partial_floats(long P, int Cin, int Cout);
+int ffno_glin_bwd_weights(const float* g, const float* y, const float* x, float* partial, float* dW, float* db, long P, int Cin,
+                          int Cout, float drop_p, uint32_t drop_seed, int accumulate, void* stream);
+int ffno_dropout(float* x, size_t n, float p, uint32_t seed, void* stream);
+int ffno_dropout_mask(uint8_t* keep, size_t n, float p, uint32_t seed, void* stream);
+
 /* One launch copying n parameter tensors between their reference shapes and channel-padded twins:
  * plain [R][Cc][inner] <-> rows r < R, columns c < Cc of padded [.][Cp][inner]; to_padded = 0 copies back
  * (gradients).  descs is a DEVICE array. */

@@ -74,8 +74,12 @@ RELU_TRACE = None
 
 
 def feedforward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int = 2,
-                layer_norm: bool = False, relu_mask=None) -> Tensor:
-    """n_layers x [linear -> (dropout p=0) -> ReLU except last -> LayerNorm iff last & layer_norm].
+                layer_norm: bool = False, relu_mask=None, dropout: float = 0.0, dropout_keep=None) -> Tensor:
+    """n_layers x [linear -> dropout(p) -> ReLU except last -> LayerNorm iff last & layer_norm]  (feedforward.py:13-23).
+
+    ``dropout`` > 0: nn.Dropout in training mode.  With ``dropout_keep`` (tests only: one keep mask per linear layer,
+    [pixels, features] -- the masks another implementation drew) the dropout is ``x * keep / (1 - p)``; without it the masks come
+    from torch's generator like the reference's.
 
     ``relu_mask`` (tests only): a list with one boolean tensor per hidden activation, [pixels, hidden] -- the ACTIVE SET
     another implementation chose.  The ReLU is then evaluated as ``pre * mask``: identical to relu(pre) wherever the two
@@ -84,6 +88,11 @@ def feedforward(sd: Dict[str, Tensor], prefix: str, x: Tensor, n_layers: int = 2
     compared at rounding level."""
     for i in range(n_layers):
         x = linear_from_sd(sd, f"{prefix}layers.{i}.0.", x)
+        if dropout > 0.0:
+            if dropout_keep is not None:
+                x = x * dropout_keep[i].reshape(x.shape).to(x.dtype) / (1.0 - dropout)
+            else:
+                x = F.dropout(x, dropout, training=True)
         if i < n_layers - 1:
             if RELU_TRACE is not None:      # tests only: this evaluation's own active set, before any injected one is applied
                 RELU_TRACE.append((prefix, i, (x.detach() > 0)))
@@ -178,7 +187,7 @@ def forward_fourier_plus(x: Tensor, w0: Tensor, w1: Tensor, modes: int) -> Tenso
 def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
                  use_fork: bool = False, mode: str = "full", n_ff_layers: int = 2,
                  layer_norm: bool = False, return_intermediates: bool = False, spectral: str = "factorized",
-                 relu_masks=None):
+                 relu_masks=None, dropout: float = 0.0, in_dropout: float = 0.0, dropout_keeps=None):
     """Forward of the whole block over a reference-layout state_dict.
 
     Returns {'forecast', 'forecast_list'} like the reference; with
@@ -186,10 +195,13 @@ def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
     ``relu_masks`` (tests only): {("backcast" | "forecast", layer): [mask per hidden activation]}, see ``feedforward``.
     """
     rm = relu_masks or {}
+    dk = dropout_keeps or {}      # tests only: {("backcast" | "forecast", layer): [keep mask per linear], "in": keep mask}
     def head(t: Tensor) -> Tensor:
         return linear_from_sd(sd, "out.1.", linear_from_sd(sd, "out.0.", t))
 
     x = linear_from_sd(sd, "in_proj.", x)
+    if in_dropout > 0.0:          # x = self.drop(x)  (grid_2d.py:113,158), training mode
+        x = x * dk["in"].reshape(x.shape).to(x.dtype) / (1.0 - in_dropout) if "in" in dk else F.dropout(x, in_dropout, training=True)
     forecast = 0
     forecast_list: List[Tensor] = []
     inter = [x]
@@ -202,9 +214,11 @@ def ffno2d_block(sd: Dict[str, Tensor], x: Tensor, *, modes: int, n_layers: int,
         elif mode != "no-fourier":
             s = forward_fourier(x, sd.get(pre + "fourier_weight.0"), sd.get(pre + "fourier_weight.1"),
                                 modes, mode)
-        b = feedforward(sd, pre + "backcast_ff.", s, n_ff_layers, layer_norm, rm.get(("backcast", i)))
+        b = feedforward(sd, pre + "backcast_ff.", s, n_ff_layers, layer_norm, rm.get(("backcast", i)), dropout,
+                        dk.get(("backcast", i)))
         if use_fork:
-            f_out = head(feedforward(sd, pre + "forecast_ff.", s, n_ff_layers, layer_norm, rm.get(("forecast", i))))
+            f_out = head(feedforward(sd, pre + "forecast_ff.", s, n_ff_layers, layer_norm, rm.get(("forecast", i)), dropout,
+                                     dk.get(("forecast", i))))
             forecast = forecast + f_out
             forecast_list.append(f_out)
         x = x + b

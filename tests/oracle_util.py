@@ -33,17 +33,19 @@ def torch_state_dict(sd_np, dtype=torch.float32, requires_grad=True):
 def engine_relu_masks(engine):
     """The HIP path's ReLU active sets in the form ``orc.feedforward(relu_mask=...)`` takes: {(kind, layer): [bool tensor]}
     on the CPU.  Feeding them to the oracle removes the ReLU bit-flip discontinuity from a gradient comparison."""
-    return {k: [v.cpu().bool()] for k, v in engine.relu_active_sets().items()}
+    return {k: ([t.cpu().bool() for t in v] if isinstance(v, (list, tuple)) else [v.cpu().bool()])
+            for k, v in engine.relu_active_sets().items()}
 
 
-def oracle_block_run(kw, seed, B, M, N, dtype=torch.float32, relu_masks=None, io=None, sd_np=None):
+def oracle_block_run(kw, seed, B, M, N, dtype=torch.float32, relu_masks=None, io=None, sd_np=None, dropout_keeps=None):
     kwf = gu.full_kwargs(kw)
     sd_np = gu.make_block_state_dict(kw, seed) if sd_np is None else sd_np
     x_np, t_np = io if io is not None else gu.make_block_io(kw, seed, B, M, N)
     sd, uniq = torch_state_dict(sd_np, dtype)
     out = orc.ffno2d_block(sd, torch.tensor(x_np, dtype=dtype), modes=kwf["modes"], n_layers=kwf["n_layers"],
                            use_fork=kwf["use_fork"], mode=kwf["mode"], n_ff_layers=kwf["n_ff_layers"],
-                           layer_norm=kwf["layer_norm"], relu_masks=relu_masks)
+                           layer_norm=kwf["layer_norm"], relu_masks=relu_masks, dropout=kwf.get("dropout", 0.0),
+                           in_dropout=kwf.get("in_dropout", 0.0), dropout_keeps=dropout_keeps)
     loss = orc.lp_rel_loss(out["forecast"], torch.tensor(t_np, dtype=dtype))
     loss.backward()
     grads = {k: (p.grad.detach().numpy() if p.grad is not None else None) for k, p in uniq.items()}
