@@ -86,8 +86,6 @@ class FFNOEngine:
             raise ValueError("input_dim must be in 1..63")
         if not (1 <= output_dim <= 8):
             raise ValueError("output_dim must be in 1..8")
-        if layer_norm and use_fork:
-            raise NotImplementedError("layer_norm together with use_fork (per-layer forecast heads) is not built")
         if n_ff_layers < 2:
             raise NotImplementedError("n_ff_layers = 1 (a single width -> width linear) is not built")
         if not (0.0 <= dropout < 1.0 and 0.0 <= in_dropout < 1.0):
@@ -545,9 +543,14 @@ class FFNOEngine:
         if self.layer_norm:
             ws.TL = torch.empty(ns, P, C, **f32)                     # feed-forward outputs before the LayerNorm
             ws.LNS = torch.empty(ns, P, 2, **f32)                    # {mean, rstd} per pixel
+            if self.use_fork:            # the forecast feed-forwards end in their own LayerNorm (feedforward.py:18-19)
+                ws.TLF = torch.empty(ns, P, C, **f32)
+                ws.LNSF = torch.empty(ns, P, 2, **f32)
             if save:
                 ws.DT = torch.empty(P, C, **f32)
                 ws.lnpart = torch.empty(2 * C * int(lib.ffno_layernorm_nsplit(P)), **f32)
+                if self.use_fork:
+                    ws.DTF = torch.empty(P, C, **f32)
         if self.use_fork:
             ws.F = torch.empty(ns, P, C, **f32)                 # forecast_ff outputs f_l (inputs of the shared head)
             ws.YL = torch.empty(L, P_in * O, **f32)             # per-layer head outputs (forecast_list)
@@ -936,7 +939,7 @@ class FFNOEngine:
                 self._ff_fwd(s_l, ff_res, l0, l1, b0, b1, ff_out,
                              ws.Hbuf[sv] if save_for_backward else None, ws.MASK[sv] if save_for_backward else None, P, st,
                              rs_, ff_rout)
-            if self.layer_norm:
+            if self.layer_norm and not (self.use_fork and last):
                 ln = self.ff_prefix[l] + f"layers.{self.n_ff - 1}.3."
                 self._k("layernorm_fwd", lib.ffno_layernorm_fwd, _p(ws.TL[sv]), _p(self.params[ln + "weight"]),
                         _p(self.params[ln + "bias"]), None if last else _p(ws.X), _p(ws.Blast if last else ws.X), _p(ws.LNS[sv]),
@@ -945,11 +948,16 @@ class FFNOEngine:
                     self._fold(ws.X, rxn, st)
             if self.use_fork:
                 c0, c1, cb0, cb1 = self._fc_weights(l)
+                f_raw = ws.TLF[sv] if self.layer_norm else ws.F[sv]
                 if self.general_ff:
-                    self._ffg_fwd(ws, self.fc_prefix[l], "forecast", l, sv, s_l, None, ws.F[sv], P, st)
+                    self._ffg_fwd(ws, self.fc_prefix[l], "forecast", l, sv, s_l, None, f_raw, P, st)
                 else:
-                    self._ff_fwd(s_l, None, c0, c1, cb0, cb1, ws.F[sv], ws.HF[sv] if save_for_backward else None,
+                    self._ff_fwd(s_l, None, c0, c1, cb0, cb1, f_raw, ws.HF[sv] if save_for_backward else None,
                                  ws.MASKF[sv] if save_for_backward else None, P, st, rs_, None)
+                if self.layer_norm:
+                    ln = self.fc_prefix[l] + f"layers.{self.n_ff - 1}.3."
+                    self._k("layernorm_fwd", lib.ffno_layernorm_fwd, _p(f_raw), _p(self.params[ln + "weight"]),
+                            _p(self.params[ln + "bias"]), None, _p(ws.F[sv]), _p(ws.LNSF[sv]), P, C, 1e-5, st)
                 self._k("head_fwd", lib.ffno_head_fwd, _p(ws.F[sv]), _p(self.fold), _p(ws.YL[l]), ws.P_in, C, self.O, 0, pm, st)
         if self.use_fork:
             torch.sum(ws.YL, dim=0, out=ws.Y)     # forecast = sum of the per-layer head outputs
@@ -1040,11 +1048,19 @@ class FFNOEngine:
                 fc = self.fc_prefix[l]
                 ds_f = ws.DS if last else ws.DSF     # last layer: the forecast path is the only contribution to ds
                 rf = rw(ws, "f", 0)
+                g_fc = ws.GF
+                if self.layer_norm:      # through the forecast block's LayerNorm first
+                    ln = fc + f"layers.{self.n_ff - 1}.3."
+                    self._k("layernorm_bwd", lib.ffno_layernorm_bwd, _p(ws.TLF[l]), _p(ws.LNSF[l]), _p(self.params[ln + "weight"]),
+                            _p(ws.GF), None, None, _p(ws.DTF), _p(ws.lnpart), _p(gv(ln + "weight")), _p(gv(ln + "bias")), P, C,
+                            int(fc in ff_seen), st)
+                    g_fc, rf = ws.DTF, rw(ws, "f", 1)
+                    self._fold(ws.DTF, rf, st)
                 if self.general_ff:
-                    self._ffg_bwd(ws, fc, "forecast", l, ws.S[l], ws.GF, ds_f, int(fc in ff_seen), P, st, rd)
+                    self._ffg_bwd(ws, fc, "forecast", l, ws.S[l], g_fc, ds_f, int(fc in ff_seen), P, st, rd)
                 else:
-                    self._ff_bwd_data(ws.GF, ws.MASKF[l], c0, c1, dh, ds_f, P, st, rf, rd)
-                    self._ff_bwd_weights(ws, ws.S[l], ws.GF, ws.HF[l], dh, c0, c1, self.params[fc + "layers.0.0.bias"],
+                    self._ff_bwd_data(g_fc, ws.MASKF[l], c0, c1, dh, ds_f, P, st, rf, rd)
+                    self._ff_bwd_weights(ws, ws.S[l], g_fc, ws.HF[l], dh, c0, c1, self.params[fc + "layers.0.0.bias"],
                                          gv(fc + "layers.0.0.bias"), gv(fc + "layers.1.0.bias"), int(fc in ff_seen), P, st, rs_, rf)
                 ff_seen.add(fc)
             if self.use_fork and last:
@@ -1053,6 +1069,9 @@ class FFNOEngine:
                     for k in range(self.n_ff):
                         gv(fp + f"layers.{k}.0.bias").zero_()
                         self.linears[fp + f"layers.{k}.0."].gweff.zero_()
+                    if self.layer_norm:
+                        gv(fp + f"layers.{self.n_ff - 1}.3.weight").zero_()
+                        gv(fp + f"layers.{self.n_ff - 1}.3.bias").zero_()
                     ff_seen.add(fp)
                 if self.mode == "no-fourier":
                     g_out.copy_(ws.DS)

@@ -90,8 +90,6 @@ class FNOFactorized2DBlock(nn.Module):
                  share_weight: bool = False, share_fork=False, factor=2, ff_weight_norm=False, n_ff_layers=2,
                  gain=1, layer_norm=False, use_fork=False, mode='full'):
         super().__init__()
-        if layer_norm and use_fork:
-            raise NotImplementedError("layer_norm together with use_fork is not implemented by the gfx950 kernel set")
         self.modes, self.width, self.input_dim = modes, width, input_dim
         self.n_layers, self.use_fork, self.mode = n_layers, use_fork, mode
         self.share_weight, self.share_fork = share_weight, share_fork

@@ -212,6 +212,30 @@ def test_block_with_dropout_matches_oracle_on_the_same_masks(host_device, extra)
     assert rel_l2(e1.cpu().numpy(), ref_eval["forecast"].detach().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("extra", [dict(), dict(share_fork=True), dict(n_ff_layers=3, factor=2)], ids=["plain", "sharefork", "ff3"])
+def test_block_with_layer_norm_and_fork_heads(host_device, extra):
+    """FeedForward(layer_norm=True) together with use_fork: the per-layer forecast feed-forwards end in their own LayerNorm
+    (feedforward.py:18-19, grid_2d.py:164-167) -- the last combination of constructor flags that used to raise.  Forward
+    (forecast and forecast_list) and every gradient vs the oracle on the same ReLU active sets."""
+    import oracle_util as ou
+    kw = {**dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1,
+                 layer_norm=True, use_fork=True), **extra}
+    seed, B, M, N = 17, 1, 8, 8
+    blk = build_block(kw, seed, host_device)
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
+    out = blk(torch.from_numpy(x_np).to(host_device))
+    orc.lp_rel_loss(out["forecast"], torch.from_numpy(t_np).to(host_device)).backward()
+    eng = blk.engine()
+    masks = ou.engine_relu_masks(eng)
+    ref_out, _, _ = ou.oracle_block_run(kw, seed, B, M, N, relu_masks=masks)
+    assert rel_l2(out["forecast"].detach().cpu().numpy(), ref_out["forecast"].detach().numpy()) < 1e-5
+    for a, b in zip(out["forecast_list"], ref_out["forecast_list"]):
+        assert rel_l2(a.detach().cpu().numpy(), b.detach().numpy()) < 1e-5
+    named = dict(blk.named_parameters())
+    ou.check_grads_at_rounding_level(f"layer_norm + fork {extra} {host_device}", {n: named[n].grad.cpu().numpy() for n in eng.param_names},
+                                     lambda dt: ou.oracle_block_run(kw, seed, B, M, N, dtype=dt, relu_masks=masks)[2])
+
+
 def test_state_dict_keys_match_reference_layout():
     kw = dict(modes=4, width=64, input_dim=3, n_layers=2, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
     from fourierflow_amd.modules import FNOFactorized2DBlock
@@ -232,7 +256,7 @@ def test_state_dict_keys_match_reference_layout():
 def test_unsupported_options_fail_loudly():
     from fourierflow_amd.modules import FNOFactorized2DBlock
     base = dict(modes=4, width=64, input_dim=3, n_layers=2, factor=4)
-    for bad in (dict(n_ff_layers=1), dict(layer_norm=True, use_fork=True)):
+    for bad in (dict(n_ff_layers=1),):
         with pytest.raises(NotImplementedError):
             FNOFactorized2DBlock(**{**base, **bad}).engine()
     for bad in (dict(dropout=1.0), dict(in_dropout=-0.1)):
