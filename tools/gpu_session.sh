@@ -104,7 +104,7 @@ PY
       done
       f=$(find gpurun_out/pmc_FETCH_SIZE -name "*.db" | head -1); w=$(find gpurun_out/pmc_WRITE_SIZE -name "*.db" | head -1)
       python tools/rocpd_pmc.py "$f" > gpurun_out/pmc_FETCH_SIZE.md; python tools/rocpd_pmc.py "$w" > gpurun_out/pmc_WRITE_SIZE.md
-      (cd tools && python make_pmc_traffic.py "../$f" "../$w" "8ae8522feeb7") > gpurun_out/pmc_traffic.json; head -c 600 gpurun_out/pmc_traffic.json
+      (cd tools && python make_pmc_traffic.py "../$f" "../$w" "${FFNO_GIT_HEAD:-unknown}") > gpurun_out/pmc_traffic.json; head -c 600 gpurun_out/pmc_traffic.json
       find gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE -name "*.db" -size +20M -delete ;;
   esac
 done

@@ -10,7 +10,7 @@ from rocpd_pmc import per_kernel
 
 # first match wins, so the instantiations of the default arithmetic (fp16x2) come before the generic patterns: bench.py also runs
 # the all-bf16x3 variant, whose kernels are in the same trace
-NAMES = [("spectral_x3_pair_kernel<16, true", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false, ffno::SplitHf2", "ff_fwd"),
+NAMES = [("ffh_wgrad_m_kernel<64, 256", "ff_bwd_weights_partial"), ("spectral_x3_pair_kernel<16, true", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false, ffno::SplitHf2", "ff_fwd"),
          ("ffx_chain_kernel<64, 256, true, ffno::SplitHf2", "ff_bwd_data"), ("ffx_wgrad_kernel<64, 256, ffno::SplitHf2", "ff_bwd_weights_partial"),
          ("spectral_x3_pair_kernel<16", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false", "ff_fwd"),
          ("ffx_chain_rs_kernel<64, 256, true", "ff_bwd_data"), ("ffx_wgrad_rs_kernel", "ff_bwd_weights_partial"),
