@@ -414,6 +414,317 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     if (A.out_amax) range_fold(omax, rfold, F::NW, A.out_amax);
 }
 
+// ---- width 32 (the 3-D mesh operators of the reference run width 32: mesh_3d.py / BASELINE config 5) -------------------------
+// The same three phases for C = 32 channels.  A wave still owns two lines, but transforms them TOGETHER: the two 32-column MFMA
+// tiles that were the even / odd channels of one 64-channel line are now the 32 channels of line 2w and of line 2w + 1 (the DFT
+// acts on every column independently, so nothing else changes in phases 1 and 3 -- a lane reads / writes one float of each
+// line instead of a float2 of one).  The per-mode channel mix has rows = (line, re/im) of the 16 lines (a full 32-row tile), 32
+// input channels (two k16 steps) and 32 output channels (one column tile): four weight fragments per mode.
+struct X3Cfg32 {
+    static constexpr int C = 32;
+    static constexpr int NW = 8;
+    static constexpr int NL = 16;              // lines per workgroup (two per wave)
+    static constexpr int KK = 32;              // (mode, re/im) rows per line: K <= 16
+    static constexpr int RS = 36;              // row stride (floats): +4 shifts the re / im rows of a line by 4 banks
+    static constexpr int LSF = KK * RS + 8;    // line stride (floats)
+    static constexpr int MODE_FRAGS = 4;       // per mode: 2 k-steps x 2 planes (re, im)
+};
+
+// planes[k][p][i][o] (C = 32) -> fragment (k, st, p), lane (j, half), slot e  <-  planes[k][p][i = 16 st + 8 half + e][o = j];
+// format 1: two fp16 planes per fragment, fragments of a mode ordered (p, st)
+__global__ __launch_bounds__(256) void x3_pack32_kernel(const X3PackDesc* __restrict__ descs) {
+    constexpr int C = X3Cfg32::C;
+    const X3PackDesc d = descs[blockIdx.y];
+    const int nfrag = d.K * X3Cfg32::MODE_FRAGS;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nfrag * 64) return;
+    const int frag = t >> 6, lane = t & 63, j = lane & 31, half = lane >> 5;
+    const int p = frag & 1, st = (frag >> 1) & 1, k = frag >> 2;
+    const float* src = d.planes + ((long)(k * 2 + p) * C + (16 * st + 8 * half)) * C + j;
+    float v[8];
+    FFNO_UNROLL
+    for (int e = 0; e < 8; ++e) v[e] = src[(long)e * C];
+    if (d.format == 1) {
+        const Hf2 f = split2_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        const int fo = (k * 2 + p) * 2 + st;
+        d.dst[(fo * 2 + 0) * 64 + lane] = f.hi;
+        d.dst[(fo * 2 + 1) * 64 + lane] = f.lo;
+        return;
+    }
+    const Bf3 f = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+    d.dst[(frag * 3 + 0) * 64 + lane] = f.hi;
+    d.dst[(frag * 3 + 1) * 64 + lane] = f.mid;
+    d.dst[(frag * 3 + 2) * 64 + lane] = f.lo;
+}
+
+template <bool MIXH2>
+__device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
+    using F = X3Cfg32;
+    constexpr int C = F::C, RS = F::RS, LSF = F::LSF, NL = F::NL;
+    __shared__ __attribute__((aligned(16))) float XS[NL * LSF];
+    __shared__ float rfold[F::NW];
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+
+    const float* __restrict__ in = A.in;
+    const int R = A.R, L = A.L, K = A.K;
+    const LineMap lm = A.lm;
+    const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
+    const float rrs = 1.f / rs;
+    float omax = 0.f;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int lw = 2 * wave;                       // this wave's two lines inside the tile: lw (column tile 0), lw + 1 (tile 1)
+    const int line0 = bidx * NL + lw;
+    const bool live0 = line0 < R, live1 = line0 + 1 < R;
+    const long es = lm.elem_stride;
+    const unsigned esb = (unsigned)(es * 4);
+    // lines past the end of the axis read (and transform) line R - 1 again; nothing of a dead line is ever stored
+    const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + j) * 4);
+    const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + j) * 4);
+
+    // ---------------- phase 1: truncated forward DFT of the wave's two lines, side by side ----------------
+    {
+        const int kk = j, k = kk >> 1, ri = kk & 1;
+        const bool rowok = kk < 2 * K;
+        const float ck = (A.fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
+        const int km = rowok ? k : 0;
+        float2 raw[4][8];      // .x = line lw, .y = line lw + 1
+        auto load_rows = [&](int chunk, int u) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const unsigned no = (unsigned)min(16 * (4 * chunk + u) + 8 * half + e, L - 1) * esb;
+                raw[u][e].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (lo0 + no));
+                raw[u][e].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (lo1 + no));
+            }
+        };
+        const int nchunks = (L + 63) >> 6;
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u);
+        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+        __syncthreads();
+        const int k8 = (km * 8) % L;
+        f32x16 acc0 = zero16(), acc1 = zero16();
+        FFNO_NOUNROLL
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            Bf3 Ff[4];
+            int idx = (km * (64 * chunk + 8 * half)) % L;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * (4 * chunk + u) + 8 * half + e;
+                    f[e] = n < L ? amul * tws[tbase + idx] : 0.f;
+                    idx += km;
+                    if (idx >= L) idx -= L;
+                }
+                idx += k8;
+                if (idx >= L) idx -= L;
+                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+            }
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
+                                        raw[u][6].x, raw[u][7].x);
+                const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
+                                        raw[u][6].y, raw[u][7].y);
+                if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
+                acc0 = mfma_x3(Ff[u], b0, acc0);
+                acc1 = mfma_x3(Ff[u], b1, acc1);
+            }
+        }
+        float* xs0 = XS + lw * LSF + j;
+        float* xs1 = xs0 + LSF;
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = drow(r, half);
+            if (row < 2 * K) {
+                xs0[row * RS] = acc0[r] * rs;
+                xs1[row * RS] = acc1[r] * rs;
+                if (A.spec_save) {
+                    float* sp = A.spec_save + (((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + j;
+                    if (live0) sp[0] = acc0[r];
+                    if (live1) sp[2 * C] = acc1[r];
+                }
+            }
+        }
+    }
+    // weight fragments of phase 2 through a ring (the fragments of all this wave's modes are one stream)
+    constexpr int RING = 4;
+    using MixFrag = typename std::conditional<MIXH2, Hf2, Bf3>::type;
+    constexpr int MNP = MIXH2 ? 2 : 3;
+    auto load_w = [&](const u32x4* __restrict__ wk, int f) {
+        MixFrag w;
+        if constexpr (MIXH2) {
+            w.hi = wk[(f * 2 + 0) * 64 + lane];
+            w.lo = wk[(f * 2 + 1) * 64 + lane];
+        } else {
+            w = x3_load_frag(wk, f, lane);
+        }
+        return w;
+    };
+    MixFrag ring[RING];
+    if (A.wpk && wave < K) {
+        FFNO_UNROLL
+        for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: per-mode channel mix of the 16 lines, in place ----------------
+    if (A.wpk) {
+        // MFMA row j = (line j >> 1, part j & 1)
+        const float* arow = XS + (j >> 1) * LSF + (j & 1) * RS + 8 * half;
+        for (int k = wave; k < K; k += F::NW) {
+            const bool more = k + F::NW < K;
+            const u32x4* __restrict__ wn = A.wpk + (long)(more ? k + F::NW : k) * F::MODE_FRAGS * 64 * MNP;
+            MixFrag a[2];
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st);
+                const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st + 4);
+                if constexpr (MIXH2)
+                    a[st] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                else
+                    a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+            }
+            f32x16 p[2];
+            p[0] = zero16(), p[1] = zero16();
+            if constexpr (MIXH2) {      // fragment order (p, st)
+                FFNO_UNROLL
+                for (int pp = 0; pp < 2; ++pp) {
+                    f32x16 pc = zero16();
+                    FFNO_UNROLL
+                    for (int st = 0; st < 2; ++st) {
+                        const int f = pp * 2 + st;
+                        const Hf2 b = ring[f];
+                        if (more) ring[f] = load_w(wn, f);
+                        mfma_h2(a[st], b, p[pp], pc);
+                    }
+                    SplitHf2::fold(p[pp], pc);
+                }
+            } else {                    // fragment order (st, p)
+                FFNO_UNROLL
+                for (int st = 0; st < 2; ++st) {
+                    FFNO_UNROLL
+                    for (int pp = 0; pp < 2; ++pp) {
+                        const int f = st * 2 + pp;
+                        const Bf3 b = ring[f];
+                        if (more) ring[f] = load_w(wn, f);
+                        p[pp] = mfma_x3(a[st], b, p[pp]);
+                    }
+                }
+            }
+            // D rows 2q, 2q+1 of this lane = (re, im) of line (q & 1) + 4 (q >> 1) + 2 half;  P1 = X Wr (p[0]), P2 = X Wi (p[1])
+            FFNO_UNROLL
+            for (int q = 0; q < 8; ++q) {
+                const int ln = (q & 1) + 4 * (q >> 1) + 2 * half;
+                const float p1r = p[0][2 * q], p1i = p[0][2 * q + 1];
+                const float p2r = p[1][2 * q], p2i = p[1][2 * q + 1];
+                float yr, yi;
+                if (A.conj_t == 0) {
+                    yr = p1r - p2i;
+                    yi = p2r + p1i;
+                } else {
+                    yr = p1r + p2i;
+                    yi = p1i - p2r;
+                }
+                float* dst = XS + ln * LSF + 2 * k * RS + j;
+                dst[0] = yr;
+                dst[RS] = yi;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 3: zero-padded inverse DFT of the wave's two lines, side by side ----------------
+    {
+        const int RTtot = (L + 31) >> 5;
+        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const float* xs0 = XS + lw * LSF + j;
+        const float* xs1 = xs0 + LSF;
+        // B operands: the two lines' spectra (tile 0 = line lw, tile 1 = line lw + 1): slot e of k-step st <-> row 16 st + 8 half + e
+        Bf3 y[2][2];
+        FFNO_UNROLL
+        for (int st = 0; st < 2; ++st) {
+            float v0[8], v1[8];
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * st + 8 * half + e;
+                v0[e] = v1[e] = 0.f;
+                if (kk < 2 * K) v0[e] = xs0[kk * RS], v1[e] = xs1[kk * RS];
+            }
+            y[st][0] = split3_8(v0[0], v0[1], v0[2], v0[3], v0[4], v0[5], v0[6], v0[7]);
+            y[st][1] = split3_8(v1[0], v1[1], v1[2], v1[3], v1[4], v1[5], v1[6], v1[7]);
+        }
+        const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
+                                     : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
+        FFNO_NOUNROLL
+        for (int rt = 0; rt < RTtot; ++rt) {
+            const int n = 32 * rt + j;
+            Bf3 G[2];
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                float g[8];
+                const int nm = n < L ? n : 0;
+                int idx = (nm * (8 * st + 4 * half)) % L;
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+                    const float ck = (A.inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                    g[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tws[(part ? L : 0) + idx] : 0.f;
+                    if (part) {
+                        idx += nm;
+                        if (idx >= L) idx -= L;
+                    }
+                }
+                G[st] = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+            }
+            float2 pre[16];
+            if (addsrc) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned no = (unsigned)min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1) * esb;
+                    pre[r].x = *reinterpret_cast<const float*>(addsrc + (lo0 + no));
+                    pre[r].y = *reinterpret_cast<const float*>(addsrc + (lo1 + no));
+                }
+            }
+            f32x16 o0 = zero16(), o1 = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                o0 = mfma_x3(G[st], y[st][0], o0);
+                o1 = mfma_x3(G[st], y[st][1], o1);
+            }
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
+                if (nu + 4 * half < L) {
+                    const unsigned uo = (unsigned)nu * esb + hoff;
+                    float2 o = make_float2(o0[r] * rrs, o1[r] * rrs);
+                    if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
+                    char* ob = reinterpret_cast<char*>(A.out);
+                    if (A.accumulate && A.resid) {
+                        o.x += *reinterpret_cast<const float*>(ob + (lo0 + uo));
+                        o.y += *reinterpret_cast<const float*>(ob + (lo1 + uo));
+                    }
+                    if (live0) {
+                        *reinterpret_cast<float*>(ob + (lo0 + uo)) = o.x;
+                        omax = fmaxf(omax, fabsf(o.x));
+                    }
+                    if (live1) {
+                        *reinterpret_cast<float*>(ob + (lo1 + uo)) = o.y;
+                        omax = fmaxf(omax, fabsf(o.y));
+                    }
+                }
+            }
+        }
+    }
+    if (A.out_amax) range_fold(omax, rfold, F::NW, A.out_amax);
+}
+
 template <int NL, bool MIXH2>
 __global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
     spectral_x3_body<NL, MIXH2>(a, blockIdx.x, 0);
@@ -1069,6 +1380,25 @@ __global__ __launch_bounds__(512) void spectral_x3k_pair_kernel(X3Args a, X3Args
     spectral_x3k_body<KKT, MIXH2>(x3_pick_args(a, b, second), idx);
 }
 
+template <bool MIXH2>
+__global__ __launch_bounds__(512) void spectral_x3c32_kernel(X3Args a) {
+    spectral_x3c32_body<MIXH2>(a, blockIdx.x);
+}
+template <bool MIXH2>
+__global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
+    const int w = blockIdx.x, nmin = min(n0, n1);
+    bool second;
+    int idx;
+    if (w < 2 * nmin) {
+        second = w & 1;
+        idx = w >> 1;
+    } else {
+        second = n1 > n0;
+        idx = w - nmin;
+    }
+    spectral_x3c32_body<MIXH2>(x3_pick_args(a, b, second), idx);
+}
+
 // 8-line tiles while the launch still fits one round of workgroups (one per CU of the device): more CUs busy, same weight
 // stream per workgroup; a branch descriptor may force either (tile_lines = 8 / 16; results are bit-identical)
 static inline bool x3_small_tiles(int Ra, int Rb, int tile_lines) {
@@ -1087,7 +1417,10 @@ static inline int x3_status() {
 using namespace ffno;
 
 // fused x3 kernels: K <= 16 on the 16 / 8-line tile (spectral_x3_body), 17..64 modes on the 4-line tile (spectral_x3k_body)
-extern "C" int ffno_spectral_x3_supported(int C, int K, int L) { return (C == X3Cfg::C && K >= 1 && K <= 64 && L >= 2 && L <= 2048) ? 1 : 0; }
+extern "C" int ffno_spectral_x3_supported(int C, int K, int L) {
+    if (C == X3Cfg32::C) return (K >= 1 && 2 * K <= X3Cfg32::KK && L >= 2 && L <= 2048) ? 1 : 0;      // width 32: K <= 16
+    return (C == X3Cfg::C && K >= 1 && K <= 64 && L >= 2 && L <= 2048) ? 1 : 0;
+}
 static inline bool x3_many_modes(int K) { return 2 * K > X3Cfg::KK; }
 
 extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
@@ -1095,13 +1428,21 @@ extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
 }
 
 extern "C" size_t ffno_spectral_x3_pack_bytes(int C, int K) {
+    if (C == X3Cfg32::C) return (K >= 1 && K <= 16) ? (size_t)K * X3Cfg32::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
     return (C == X3Cfg::C && K >= 1 && K <= 64) ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
 }
 
 extern "C" int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream) {
     if (!descs_dev || n <= 0 || max_K <= 0) return FFNO_EINVAL;
-    if (C != X3Cfg::C || max_K > 64) return FFNO_EUNSUPPORTED;
     static_assert(sizeof(ffno_x3pack_desc) == sizeof(X3PackDesc), "descriptor layout");
+    if (C == X3Cfg32::C) {
+        if (max_K > 16) return FFNO_EUNSUPPORTED;
+        const int threads = max_K * X3Cfg32::MODE_FRAGS * 64;
+        FFNO_LAUNCH(x3_pack32_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
+                    reinterpret_cast<const X3PackDesc*>(descs_dev));
+        return x3_status();
+    }
+    if (C != X3Cfg::C || max_K > 64) return FFNO_EUNSUPPORTED;
     const int threads = max_K * X3Cfg::MODE_FRAGS * 64;
     FFNO_LAUNCH(x3_pack_kernel, dim3((threads + 255) / 256, n), dim3(256), 0, (hipStream_t)stream,
                 reinterpret_cast<const X3PackDesc*>(descs_dev));
@@ -1132,6 +1473,14 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     const bool h2 = br->planes && br->planes_format == FFNO_PLANES_FP16X2;
     const size_t smem = sizeof(float) * 2 * a.L;
     hipStream_t st = (hipStream_t)stream;
+    if (C == X3Cfg32::C) {          // width 32: 16 lines per workgroup, two per wave side by side
+        const dim3 grid((a.R + 15) / 16);
+        if (h2)
+            FFNO_LAUNCH((spectral_x3c32_kernel<true>), grid, dim3(512), smem, st, a);
+        else
+            FFNO_LAUNCH((spectral_x3c32_kernel<false>), grid, dim3(512), smem, st, a);
+        return x3_status();
+    }
     if (x3_many_modes(a.K)) {      // 17..64 modes: the 4-line tile
         const dim3 grid((a.R + 3) / 4);
 #define X3K_LAUNCH(KKT, H2)                                                                              \
@@ -1178,6 +1527,14 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         return FFNO_EINVAL;
     const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
     hipStream_t st = (hipStream_t)stream;
+    if (C == X3Cfg32::C) {
+        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16;
+        if (h2)
+            FFNO_LAUNCH((spectral_x3c32_pair_kernel<true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else
+            FFNO_LAUNCH((spectral_x3c32_pair_kernel<false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        return x3_status();
+    }
     if (x3_many_modes(a.K) || x3_many_modes(b.K)) {      // 17..64 modes on either axis: both on the 4-line tile
         const int n0 = (a.R + 3) / 4, n1 = (b.R + 3) / 4;
         const dim3 grid(n0 + n1);
