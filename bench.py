@@ -65,7 +65,8 @@ class KernelProbe:
     """engine.timer hook: (a) raw HIP-event brackets around every `every`-th launch of the named kernels, on the stream they
     are enqueued on; (b) capture of (entry point, arguments) of every named launch of ONE step, for the replay timing."""
 
-    def __init__(self, names, every=7):
+    def __init__(self, names, every=7, every_of=None):
+        self.every_of = dict(every_of or {})
         self.names = set(names)
         self.pairs = {n: [] for n in names}
         self.calls = {n: [] for n in names}
@@ -83,7 +84,7 @@ class KernelProbe:
         if not self.sample or name not in self.names:
             return False
         self.count[name] += 1
-        return self.count[name] % self.every == 0
+        return self.count[name] % self.every_of.get(name, self.every) == 0
 
     def start(self, name, stream=None):
         ev = torch.cuda.Event(enable_timing=True)
@@ -402,7 +403,11 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         log("warm-up done; timing")
-    probe = KernelProbe(HOT, every=7) if rank == 0 else None   # sample 1 launch in 7 (odd: fwd / adj, all layers get sampled)
+    # HIP-event brackets inside the timed region: 1 launch in 13 of the spectral entry point (the roofline's kernel), 1 in 37 of
+    # the others (odd, coprime with the layer count: every layer gets sampled over the run) -- about six brackets per step.  A
+    # bracket costs the device ~5 us of pipeline drain (rocprofv3: `tools/rocpd_idle.py`); at 1 in 7 of everything (rounds 1-2)
+    # that was 3 % of the step this line reports.
+    probe = KernelProbe(HOT, every=37, every_of={"spectral_fused": 13, "spectral_fused(adj)": 13}) if rank == 0 else None
     trainer.engine.timer = probe
     if probe:
         probe.sample = True
