@@ -328,6 +328,9 @@ def main():
     ap.add_argument("--modes", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=5, help="timed CPU-baseline train steps (0 disables the CPU leg)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 256x256 and 64^3 secondary workloads")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
+                    help="activation storage of the timed region (bf16: the storage twins -- a variant, not the parity path; the "
+                         "default run reports it beside the fp32 headline as `bf16_storage_variant`)")
     ap.add_argument("--ff-split", choices=["fp16x2", "bf16x3"], default=None,
                     help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
     ap.add_argument("--staged", action="store_true", help="spectral branches through the three stage kernels (HBM spectra) instead of the fused tile")
@@ -386,6 +389,7 @@ def main():
     if args.ff_split:
         trainer.engine.ff_split = args.ff_split
     trainer.engine.x3_interleave = args.x3_interleave
+    trainer.engine.storage = args.storage
     B, G = args.batch, args.grid
     gen = torch.Generator().manual_seed(1000 + rank)  # rank r draws its own shard of the global batch
     x = torch.randn(B, G, G, kw["input_dim"], generator=gen).to(dev)
@@ -557,6 +561,44 @@ def main():
                 variants = dict(error=repr(e))
             finally:
                 eng.ff_split, eng.x3_mix_split = keep
+        # ... and on the bf16 STORAGE twins of the hot kernels (include/ffno.h "Storage formats": activations in HBM as bf16, every
+        # product still fp32-grade): BASELINE.json quotes this config as "bf16"; the reference itself is precision 32, so this is a
+        # throughput variant with its own measured tolerance, never `value`
+        bf16_variant = None
+        if world == 1 and headline and not args.no_x3 and trainer.engine.storage == "fp32":
+            eng = trainer.engine
+            try:
+                p32 = trainer.predict(x).float().clone()
+                eng.storage = "bf16"
+                p16 = trainer.predict(x).float()
+                ferr = float((torch.linalg.norm(p16 - p32) / torch.linalg.norm(p32)).item())
+                for _ in range(3):
+                    trainer.train_step(x, y)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    trainer.train_step(x, y)
+                sync()
+                alt = args.steps / (time.perf_counter() - t1)
+                pr = KernelProbe(HOT)
+                eng.timer = pr
+                pr.capture = True
+                trainer.train_step(x, y)
+                pr.capture = False
+                sync()
+                rep_us = {n: round(v, 2) for n, v in pr.replay().items()}
+                eng.timer = None
+                bf16_variant = dict(steps_per_s=round(alt, 3), ms_per_step=round(1e3 / alt, 3),
+                                    forward_rel_l2_vs_fp32_storage=float("%.3g" % ferr), kernel_us_replay=rep_us,
+                                    what="activation tensors (layer inputs / outputs, branch outputs, saved feed-forward inputs and "
+                                         "their gradients) stored as bf16; weights, spectra, accumulation, optimiser state fp32; "
+                                         "each twin == bf16(fp32 kernel) bit for bit (tests/test_storage_bf16.py)")
+                log(f"bf16 storage twins: {alt:.2f} steps/s, forward rel-L2 vs fp32 storage {ferr:.2e}")
+            except Exception as e:  # noqa: BLE001 - never lose the headline line to the variant leg
+                bf16_variant = dict(error=repr(e))
+            finally:
+                eng.storage = "fp32"
+                eng.timer = None
         cpu = cpu19 = None
         if world == 1 and args.cpu_steps > 0 and not args.plus:
             cpu = cpu_baseline(B, G, kw, warm=2, timed=args.cpu_steps)
@@ -609,7 +651,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "optimizer_steps_per_s": round(opt_steps_per_s, 3),
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic N(0,1) inputs/targets, reference-init weights",
+            "vs_baseline": None, "dtype": "f32" if args.storage == "fp32" else "bf16 storage, f32 arithmetic", "data": "synthetic N(0,1) inputs/targets, reference-init weights",
             "config": {"workload": "%s train step: FNOFactorized2DBlock(modes=%d,width=64,"
                                    "n_layers=%d,input_dim=3,share_weight,factor=4,weight_norm) %dx%d, fp32"
                                    % ("FNOPlus2DBlock (non-factorized ablation)" if args.plus else
@@ -630,7 +672,8 @@ def main():
             "samples_per_s": round(opt_steps_per_s * B * world, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5), "git_head": git_head(),
-            "roofline": roofline, "kernels": kernels, "arithmetic_variants_steps_per_s": variants, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "arithmetic_variants_steps_per_s": variants,
+            "bf16_storage_variant": bf16_variant, "cpu_baseline": cpu,
             "secondary": secondary, "distributed": dist_info,
         }
         if cpu:

@@ -30,12 +30,14 @@ class FusedBranch(C.Structure):
     _fields_ = [("in_", P), ("out", P), ("resid", P), ("spec_save", P), ("planes", P), ("tw", P),
                 ("B", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32),
-                ("planes_format", C.c_int32), ("tile_lines", C.c_int32), ("in_amax", P), ("out_amax", P)]
+                ("planes_format", C.c_int32), ("tile_lines", C.c_int32), ("in_amax", P), ("out_amax", P),
+                ("storage", C.c_int32)]
 
 
 class FfOpts(C.Structure):
     """Mirror of ``ffno_ff_opts`` (include/ffno.h)."""
-    _fields_ = [("in_amax", P), ("out_amax", P), ("max_workgroups", C.c_int32), ("schedule", C.c_int32)]
+    _fields_ = [("in_amax", P), ("out_amax", P), ("max_workgroups", C.c_int32), ("schedule", C.c_int32),
+                ("storage", C.c_int32)]
 
 
 class LayerFwdDesc(C.Structure):
@@ -139,7 +141,7 @@ SIGNATURES = {
     "ffno_ffh_pack": (I, [P, I, I, I, P]),
     "ffno_ffh_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffh_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
-    "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P, P]),
+    "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P, I, P]),
     "ffno_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ffno_layernorm_nsplit": (I, [L]),
     "ffno_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),
@@ -149,6 +151,10 @@ SIGNATURES = {
     "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P, P, P]),
     "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
     "ffno_lift_bwd_data": (I, [P, P, P, I, I, I, P, P]),
+    "ffno_lift_fwd_bf16": (I, [P, P, P, P, I, I, I, P, P, P]),
+    "ffno_lift_bwd_bf16": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "ffno_head_fwd_bf16": (I, [P, P, P, I, I, I, I, P, P]),
+    "ffno_head_bwd_bf16": (I, [P, P, P, P, P, P, I, I, I, I, P, P, P]),
     "ffno_head_fold": (I, [P, P, P, P, P, I, I, I, P]),
     "ffno_head_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "ffno_head_bwd": (I, [P, P, P, P, P, P, I, I, I, I, P, P, P]),

@@ -63,6 +63,15 @@ __device__ __forceinline__ f32x16 mfma_x3(const Bf3& a, const Bf3& b, f32x16 c) 
     return c;
 }
 
+// the same product when b is ONE bf16 plane (data stored as bf16): the three products of mfma_x3 that are not with a zero plane,
+// in its order -- bit for bit what mfma_x3(a, {b, 0, 0}, c) gives
+__device__ __forceinline__ f32x16 mfma_x3_plane(const Bf3& a, u32x4 b, f32x16 c) {
+    c = mfma_bf16(a.lo, b, c);
+    c = mfma_bf16(a.mid, b, c);
+    c = mfma_bf16(a.hi, b, c);
+    return c;
+}
+
 __device__ __forceinline__ unsigned f2u(float x) {
     unsigned u;
     __builtin_memcpy(&u, &x, 4);
@@ -236,6 +245,71 @@ __device__ __forceinline__ void range_fold(float m, float* red, int nwaves, unsi
         for (int w = 1; w < nwaves; ++w) m = fmaxf(m, red[w]);
         atomicMax(word, f2u(m));
     }
+}
+
+// ---- activation storage formats ------------------------------------------------------------------------------------------
+// The hot kernels are written once over the format their ACTIVATION tensors have in HBM (layer inputs / outputs, branch outputs,
+// saved feed-forward inputs, gradients of those): StF32 (the parity path: the reference is `precision: 32`) or StBf16 (the
+// "bf16 storage twins": half the activation bytes; values are widened as they are loaded and rounded to nearest even where they
+// are stored, everything between -- operand splits, accumulation, spectra, weights, reductions -- is the fp32-grade arithmetic
+// of the fp32 path).  A bf16 kernel run on inputs x gives bit for bit bf16(fp32 kernel run on float(x)).
+// Loads that are requested long before their use keep the RAW words (ldr* -> Raw*) and widen them (w*) where they are consumed:
+// arithmetic placed next to a load makes the wave wait for it there (s_waitcnt vmcnt), i.e. turns the prefetch into a stall.
+struct StF32 {
+    using T = float;
+    using Raw4 = float4;
+    using Raw2 = float2;
+    using Raw1 = float;
+    static constexpr bool BF16 = false;
+    static constexpr int BYTES = 4;
+    static __device__ __forceinline__ Raw4 ldr4(const T* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ Raw2 ldr2(const void* p) { return *reinterpret_cast<const float2*>(p); }
+    static __device__ __forceinline__ Raw1 ldr1(const T* p) { return *p; }
+    static __device__ __forceinline__ Raw4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    static __device__ __forceinline__ float4 w4(Raw4 r) { return r; }
+    static __device__ __forceinline__ float2 w2(Raw2 r) { return r; }
+    static __device__ __forceinline__ float w1(Raw1 r) { return r; }
+    static __device__ __forceinline__ float4 ld4(const T* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ float2 ld2(const void* p) { return *reinterpret_cast<const float2*>(p); }
+    static __device__ __forceinline__ float ld1(const T* p) { return *p; }
+    static __device__ __forceinline__ void st4(T* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ void st2(void* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+    static __device__ __forceinline__ float rnd(float x) { return x; }      // what a stored value reads back as
+};
+struct StBf16 {
+    using T = uint16_t;
+    using Raw4 = uint2;
+    using Raw2 = unsigned;
+    using Raw1 = uint16_t;
+    static constexpr bool BF16 = true;
+    static constexpr int BYTES = 2;
+    static __device__ __forceinline__ Raw4 ldr4(const T* p) { return *reinterpret_cast<const uint2*>(p); }
+    static __device__ __forceinline__ Raw2 ldr2(const void* p) { return *reinterpret_cast<const unsigned*>(p); }
+    static __device__ __forceinline__ Raw1 ldr1(const T* p) { return *p; }
+    static __device__ __forceinline__ Raw4 zero4() { return make_uint2(0u, 0u); }
+    static __device__ __forceinline__ float4 w4(Raw4 w) {
+        return make_float4(u2f(w.x << 16), u2f(w.x & 0xffff0000u), u2f(w.y << 16), u2f(w.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ float2 w2(Raw2 w) { return make_float2(u2f(w << 16), u2f(w & 0xffff0000u)); }
+    static __device__ __forceinline__ float w1(Raw1 r) { return u2f((unsigned)r << 16); }
+    static __device__ __forceinline__ float4 ld4(const T* p) {
+        const uint2 w = *reinterpret_cast<const uint2*>(p);
+        return make_float4(u2f(w.x << 16), u2f(w.x & 0xffff0000u), u2f(w.y << 16), u2f(w.y & 0xffff0000u));
+    }
+    static __device__ __forceinline__ float2 ld2(const void* p) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(p);
+        return make_float2(u2f(w << 16), u2f(w & 0xffff0000u));
+    }
+    static __device__ __forceinline__ float ld1(const T* p) { return u2f((unsigned)*p << 16); }
+    static __device__ __forceinline__ void st4(T* p, float4 v) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(plat::pack_bf16(v.x, v.y), plat::pack_bf16(v.z, v.w));
+    }
+    static __device__ __forceinline__ void st2(void* p, float2 v) { *reinterpret_cast<unsigned*>(p) = plat::pack_bf16(v.x, v.y); }
+    static __device__ __forceinline__ float rnd(float x) { return u2f(plat::pack_bf16(x, 0.f) << 16); }
+};
+template <class ST>
+__device__ __forceinline__ float4 st_rnd4(float4 v) {
+    return make_float4(ST::rnd(v.x), ST::rnd(v.y), ST::rnd(v.z), ST::rnd(v.w));
 }
 
 // row of the 32x32 D tile held in accumulator register r by a lane in half `half` (= lane >> 5)

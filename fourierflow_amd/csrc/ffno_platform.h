@@ -82,8 +82,22 @@ __device__ __forceinline__ unsigned pk_mul_f16(unsigned w, float k) {
     const f16x2 v = __builtin_bit_cast(f16x2, w) * (_Float16)k;
     return __builtin_bit_cast(unsigned, v);
 }
+// two floats -> one word of bf16, round to nearest even (x0 in the low half): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float x0, float x1) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = {(__bf16)x0, (__bf16)x1};
+    return __builtin_bit_cast(unsigned, v);
+}
 // upper halves of two words -> one word (u0's in the low half): v_perm_b32
 __device__ __forceinline__ unsigned pack_hi16(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x07060302u); }
+// lower halves of two words -> one word (u0's in the low half): v_perm_b32
+__device__ __forceinline__ unsigned pack_lo16(unsigned u0, unsigned u1) { return __builtin_amdgcn_perm(u1, u0, 0x05040100u); }
+// lanes 32..63 of a <-> lanes 0..31 of b (v_permlane32_swap): afterwards a lane of the lower half holds (its a, its partner's a),
+// a lane of the upper half (its partner's b, its b) -- every lane of the wave must execute it
+__device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0], b = r[1];
+}
 // (acc << 1) | msb(x): v_alignbit_b32
 __device__ __forceinline__ uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return __builtin_amdgcn_alignbit(acc, x, 31); }
 // all-ones if bit b of x is set, else 0: v_bfe_i32

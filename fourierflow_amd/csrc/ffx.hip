@@ -150,14 +150,17 @@ __device__ __forceinline__ void stage4_s(char* base, int plane_bytes, int off, f
 // ---- forward / backward-data -----------------------------------------------------------------------------------------
 //   forward : in = s,  A1 = pack1(W1),   A2 = pack2(W2)     h = relu(A1 in + b1), sign bits -> mask ; out = A2 h + b2 (+ resid)
 //   backward: in = db, A1 = pack1(W2^T), A2 = pack2(W1^T)   dh = mask ? A1 in : 0                    ; ds  = A2 dh
-template <int C, int H, bool BWD, class S>
-__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const float* __restrict__ in,
-                                                                     const float* __restrict__ in2, float* sum_out,
-                                                                     const float* resid,
+// ST = storage format of in / in2 / sum_out / resid / out (ffno_device.h "activation storage formats"); with StBf16 the input
+// sum is rounded to the stored format BEFORE it is used, so the kernels that read sum_out later see the operand of this one.
+template <int C, int H, bool BWD, class S, class ST = StF32>
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const typename ST::T* __restrict__ in,
+                                                                     const typename ST::T* __restrict__ in2,
+                                                                     typename ST::T* sum_out,
+                                                                     const typename ST::T* resid,
                                                                      const u32x4* __restrict__ pk1,
                                                                      const float* __restrict__ bias1,
                                                                      const u32x4* __restrict__ pk2,
-                                                                     const float* __restrict__ bias2, float* out,
+                                                                     const float* __restrict__ bias2, typename ST::T* out,
                                                                      uint32_t* mask, int P, const unsigned* in_amax, unsigned* out_amax) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, NV = F::NV, G = F::G, GPW = F::GPW, CPW = F::CPW;
@@ -200,30 +203,33 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
     // (nS) at the top of iteration t + 1, and split into LDS at its end -- a full iteration (~3 us) between request and use,
     // so an HBM round trip under load (~2 us) is never on the critical path of a tile (profiles/r01_v4_ablation.md: 8.5 of
     // 51 us were exposed staging latency with one tile of distance).
-    float4 nS[NV], pA[NV], pB[NV];
+    float4 nS[NV];
+    typename ST::Raw4 pA[NV], pB[NV];      // (raw words: widened in consume(), an iteration after the request)
     auto gload_raw = [&](int tile) {
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
             const long px = (long)tile * 32 + f / (C / 4);
-            pA[v] = pB[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pA[v] = pB[v] = ST::zero4();
             if (px < P) {
                 const long off = px * C + 4 * (f % (C / 4));
-                pA[v] = *reinterpret_cast<const float4*>(in + off);
-                if (in2) pB[v] = *reinterpret_cast<const float4*>(in2 + off);
+                pA[v] = ST::ldr4(in + off);
+                if (in2) pB[v] = ST::ldr4(in2 + off);
             }
         }
     };
     auto consume = [&](int tile) {       // raw rows -> staging registers (the input may be the sum of two tensors: the two
         FFNO_UNROLL                      // spectral branches ran side by side; the sum is optionally written back)
         for (int v = 0; v < NV; ++v) {
-            nS[v] = pA[v];
+            nS[v] = ST::w4(pA[v]);
             if (in2) {
-                nS[v].x += pB[v].x, nS[v].y += pB[v].y, nS[v].z += pB[v].z, nS[v].w += pB[v].w;
+                const float4 b = ST::w4(pB[v]);
+                nS[v].x += b.x, nS[v].y += b.y, nS[v].z += b.z, nS[v].w += b.w;
+                nS[v] = st_rnd4<ST>(nS[v]);
                 if (sum_out) {
                     const int f = tid + v * F::NT;
                     const long px = (long)tile * 32 + f / (C / 4);
-                    if (px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = nS[v];
+                    if (px < P) ST::st4(sum_out + px * C + 4 * (f % (C / 4)), nS[v]);
                 }
             }
             if (S::SCALED) nS[v].x *= gscale, nS[v].y *= gscale, nS[v].z *= gscale, nS[v].w *= gscale;
@@ -237,15 +243,15 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
         }
     };
     // reduce the NW partial tiles of `tile` (this wave owns float4 groups [wave*GPW, +GPW)) and store the output rows
-    float4 rres[GPW], rnext[GPW];
+    typename ST::Raw4 rres[GPW], rnext[GPW];
     auto rload = [&](int tile) {   // residual rows of the tile, requested a whole iteration before its reduction
         const long px = (long)tile * 32 + j;
         FFNO_UNROLL
         for (int u = 0; u < GPW; ++u) {
             const int gi = wave * GPW + u;
-            rnext[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rnext[u] = ST::zero4();
             if (!BWD && resid && px < P)
-                rnext[u] = *reinterpret_cast<const float4*>(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
+                rnext[u] = ST::ldr4(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
         }
     };
     auto reduce = [&](int tile, int buf) {
@@ -265,13 +271,15 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
             const int c0 = 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half;
             if (S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
             if (!BWD) {
-                acc.x += b2s[c0] + rres[u].x;
-                acc.y += b2s[c0 + 1] + rres[u].y;
-                acc.z += b2s[c0 + 2] + rres[u].z;
-                acc.w += b2s[c0 + 3] + rres[u].w;
+                const float4 rr = ST::w4(rres[u]);
+                acc.x += b2s[c0] + rr.x;
+                acc.y += b2s[c0 + 1] + rr.y;
+                acc.z += b2s[c0 + 2] + rr.z;
+                acc.w += b2s[c0 + 3] + rr.w;
             }
             if (px < P) {
-                *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+                ST::st4(out + px * C + c0, acc);
+                acc = st_rnd4<ST>(acc);
                 omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
             }
         }
@@ -392,14 +400,15 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const floa
 // so every slot pairs a matrix segment on one wave with a vector / LDS segment on its SIMD partner.  The first half
 // stages all input tiles, the second half reduces and stores all output tiles; the partial-output exchange needs ONE
 // buffer (reduce(t-1) is over before the first half writes part(t)), i.e. 64 KiB of LDS less.
-template <int C, int H, bool BWD, class S>
-__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const float* __restrict__ in,
-                                                                        const float* __restrict__ in2, float* sum_out,
-                                                                        const float* resid,
+template <int C, int H, bool BWD, class S, class ST = StF32>
+__global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const typename ST::T* __restrict__ in,
+                                                                        const typename ST::T* __restrict__ in2,
+                                                                        typename ST::T* sum_out,
+                                                                        const typename ST::T* resid,
                                                                         const u32x4* __restrict__ pk1,
                                                                         const float* __restrict__ bias1,
                                                                         const u32x4* __restrict__ pk2,
-                                                                        const float* __restrict__ bias2, float* out,
+                                                                        const float* __restrict__ bias2, typename ST::T* out,
                                                                         uint32_t* mask, int P, const unsigned* in_amax, unsigned* out_amax) {
     using F = FxCfg<C, H>;
     constexpr int NW = F::NW, KS = F::KS, CTO = F::CTO, G = F::G;
@@ -441,54 +450,107 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
     }
 
     // ---- staging half: raw rows requested two tiles ahead (qA / qB), summed into pS one tile ahead, split into LDS in slot 4 ----
-    float4 pS[NVA], qA[NVA], qB[NVA];
+    float4 pS[NVA];
+    typename ST::Raw4 qA[NVA], qB[NVA];      // (raw words: widened in consume(), an iteration after the request)
+    // float4 number (within the [32][C] tile) of this thread's staging slot v.  bf16 storage: the two slots are neighbours, so
+    // that one 16-byte access covers both (8-byte accesses run at 0.5-0.7 of the 16-byte rate, MI355X_MICROARCH.md)
+    static_assert(!ST::BF16 || (NVA == 2 && GPB == 2), "bf16 storage: 16-byte accesses pair two float4 groups");
+    auto fmap = [&](int v) { return ST::BF16 ? (tid / (C / 8)) * (C / 4) + 2 * (tid % (C / 8)) + v : tid + v * NTA; };
     auto gload_raw = [&](int tile) {
-        FFNO_UNROLL
-        for (int v = 0; v < NVA; ++v) {
-            const int f = tid + v * NTA;
+        if constexpr (ST::BF16) {
+            const int f = fmap(0);
             const long px = (long)tile * 32 + f / (C / 4);
-            qA[v] = qB[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            qA[0] = qA[1] = qB[0] = qB[1] = ST::zero4();
             if (px < P) {
                 const long off = px * C + 4 * (f % (C / 4));
-                qA[v] = *reinterpret_cast<const float4*>(in + off);
-                if (in2) qB[v] = *reinterpret_cast<const float4*>(in2 + off);
+                const u32x4 a = *reinterpret_cast<const u32x4*>(in + off);
+                qA[0] = make_uint2(a[0], a[1]), qA[1] = make_uint2(a[2], a[3]);
+                if (in2) {
+                    const u32x4 b = *reinterpret_cast<const u32x4*>(in2 + off);
+                    qB[0] = make_uint2(b[0], b[1]), qB[1] = make_uint2(b[2], b[3]);
+                }
+            }
+        } else {
+            FFNO_UNROLL
+            for (int v = 0; v < NVA; ++v) {
+                const int f = fmap(v);
+                const long px = (long)tile * 32 + f / (C / 4);
+                qA[v] = qB[v] = ST::zero4();
+                if (px < P) {
+                    const long off = px * C + 4 * (f % (C / 4));
+                    qA[v] = ST::ldr4(in + off);
+                    if (in2) qB[v] = ST::ldr4(in2 + off);
+                }
             }
         }
     };
     auto consume = [&](int tile) {      // raw rows -> pS (the input may be the sum of two tensors; the sum is optionally stored)
         FFNO_UNROLL
         for (int v = 0; v < NVA; ++v) {
-            pS[v] = qA[v];
+            pS[v] = ST::w4(qA[v]);
             if (in2) {
-                pS[v].x += qB[v].x, pS[v].y += qB[v].y, pS[v].z += qB[v].z, pS[v].w += qB[v].w;
-                const int f = tid + v * NTA;
+                const float4 b = ST::w4(qB[v]);
+                pS[v].x += b.x, pS[v].y += b.y, pS[v].z += b.z, pS[v].w += b.w;
+                pS[v] = st_rnd4<ST>(pS[v]);
+                const int f = fmap(v);
                 const long px = (long)tile * 32 + f / (C / 4);
-                if (sum_out && px < P) *reinterpret_cast<float4*>(sum_out + px * C + 4 * (f % (C / 4))) = pS[v];
+                if constexpr (!ST::BF16)
+                    if (sum_out && px < P) ST::st4(sum_out + px * C + 4 * (f % (C / 4)), pS[v]);
             }
-            if (S::SCALED) pS[v].x *= gscale, pS[v].y *= gscale, pS[v].z *= gscale, pS[v].w *= gscale;
+        }
+        if constexpr (ST::BF16) {
+            const int f = fmap(0);
+            const long px = (long)tile * 32 + f / (C / 4);
+            if (in2 && sum_out && px < P) {
+                u32x4 w;
+                w[0] = plat::pack_bf16(pS[0].x, pS[0].y), w[1] = plat::pack_bf16(pS[0].z, pS[0].w);
+                w[2] = plat::pack_bf16(pS[1].x, pS[1].y), w[3] = plat::pack_bf16(pS[1].z, pS[1].w);
+                *reinterpret_cast<u32x4*>(sum_out + px * C + 4 * (f % (C / 4))) = w;
+            }
+        }
+        if (S::SCALED) {
+            FFNO_UNROLL
+            for (int v = 0; v < NVA; ++v) pS[v].x *= gscale, pS[v].y *= gscale, pS[v].z *= gscale, pS[v].w *= gscale;
         }
     };
     auto stage = [&](int buf) {
         FFNO_UNROLL
         for (int v = 0; v < NVA; ++v) {
-            const int f = tid + v * NTA;
+            const int f = fmap(v);
             stage4_s<S>(sp[buf], F::PPLANE, (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8, pS[v].x, pS[v].y, pS[v].z, pS[v].w);
         }
     };
     // ---- reducing half: residual rows one tile ahead; reduce the NW partial tiles and store the output rows ----
-    float4 rres[GPB], rnext[GPB];
+    typename ST::Raw4 rres[GPB], rnext[GPB];
+    // bf16 storage: the wave's two float4 groups are the halves of two 8-channel blocks; a lane of the lower half-wave reads and
+    // writes the WHOLE first block of its pixel (16 bytes), a lane of the upper half the second, and the two halves exchange
+    // the quads they own through v_permlane32_swap (rres / rnext then hold the raw 16 bytes: [0] = words 0, 1, [1] = words 2, 3)
+    const int c16 = 32 * ((rw * GPB) >> 2) + 8 * (((rw * GPB) & 3) + half);
     auto rload = [&](int tile) {
         const long px = (long)tile * 32 + j;
+        if constexpr (ST::BF16) {
+            rnext[0] = rnext[1] = ST::zero4();
+            if (!BWD && resid && px < P) {
+                const u32x4 a = *reinterpret_cast<const u32x4*>(resid + px * C + c16);
+                rnext[0] = make_uint2(a[0], a[1]), rnext[1] = make_uint2(a[2], a[3]);
+            }
+            return;
+        }
         FFNO_UNROLL
         for (int u = 0; u < GPB; ++u) {
             const int gi = rw * GPB + u;
-            rnext[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rnext[u] = ST::zero4();
             if (!BWD && resid && px < P)
-                rnext[u] = *reinterpret_cast<const float4*>(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
+                rnext[u] = ST::ldr4(resid + px * C + 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half);
         }
     };
     auto reduce = [&](int tile) {
         const long px = (long)tile * 32 + j;
+        if constexpr (ST::BF16) {      // words 0, 1 of both halves -> the lower quads' owners; words 2, 3 -> the upper quads'
+            plat::swap_halves(rres[0].x, rres[1].x);
+            plat::swap_halves(rres[0].y, rres[1].y);
+        }
+        uint2 pk16[2];
         FFNO_UNROLL
         for (int u = 0; u < GPB; ++u) {
             const int gi = rw * GPB + u;
@@ -504,14 +566,26 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_rs_kernel(const f
             const int c0 = 32 * (gi >> 2) + 8 * (gi & 3) + 4 * half;
             if (S::SCALED) acc.x *= rgscale, acc.y *= rgscale, acc.z *= rgscale, acc.w *= rgscale;
             if (!BWD) {
-                acc.x += b2s[c0] + rres[u].x;
-                acc.y += b2s[c0 + 1] + rres[u].y;
-                acc.z += b2s[c0 + 2] + rres[u].z;
-                acc.w += b2s[c0 + 3] + rres[u].w;
+                const float4 rr = ST::w4(rres[u]);
+                acc.x += b2s[c0] + rr.x;
+                acc.y += b2s[c0 + 1] + rr.y;
+                acc.z += b2s[c0 + 2] + rr.z;
+                acc.w += b2s[c0 + 3] + rr.w;
             }
+            if constexpr (ST::BF16) pk16[u & 1] = make_uint2(plat::pack_bf16(acc.x, acc.y), plat::pack_bf16(acc.z, acc.w));
             if (px < P) {
-                *reinterpret_cast<float4*>(out + px * C + c0) = acc;
+                if constexpr (!ST::BF16) ST::st4(out + px * C + c0, acc);
+                acc = st_rnd4<ST>(acc);
                 omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+            }
+        }
+        if constexpr (ST::BF16) {
+            plat::swap_halves(pk16[0].x, pk16[1].x);
+            plat::swap_halves(pk16[0].y, pk16[1].y);
+            if (px < P) {
+                u32x4 w;
+                w[0] = pk16[0].x, w[1] = pk16[0].y, w[2] = pk16[1].x, w[3] = pk16[1].y;
+                *reinterpret_cast<u32x4*>(out + px * C + c16) = w;
             }
         }
     };
@@ -894,8 +968,9 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //     independent instruction streams) -- measured 64 us against 56: a lone wave per SIMD exposes every LDS / HBM round trip
 //     that its partner hides in the eight-wave form (round 3, DESIGN.md "Negative results"), so it is not compiled in;
 //   * branch-free tile loop (one basic block: the scheduler interleaves staging / epilogue vector work with the MFMAs).
-template <int C, int H, int NWV>
-__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const float* __restrict__ s, const float* __restrict__ db,
+template <int C, int H, int NWV, class ST = StF32>
+__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST::T* __restrict__ s,
+                                                               const typename ST::T* __restrict__ db,
                                                                const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
                                                                const u32x4* __restrict__ pk2t, float* __restrict__ partial,
                                                                int P, const unsigned* s_amax, const unsigned* db_amax) {
@@ -940,28 +1015,30 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const float* __re
     // last tile re-read its last valid row and are zeroed -- by stage(), an iteration later: a select placed next to the load
     // would make the wave wait for every load where it is issued.
     const int tc = tid % C, tg = tid / C;
-    float4 nSP[NV], nDP[NV], nST[NV], nDT[NV];
+    // (raw words of the next tile: widened in stage(), an iteration after the request)
+    struct Raw1x4 {
+        typename ST::Raw1 v[4];
+    };
+    typename ST::Raw4 nSP[NV], nDP[NV];
+    Raw1x4 nST[NV], nDT[NV];
     float bs2 = 0.f;
     auto gload = [&](int tile_) {
         const int tile = min(tile_, ntiles - 1);
-        const float* st = s + (long)tile * (32 * C);
-        const float* dt = db + (long)tile * (32 * C);
+        const typename ST::T* st = s + (long)tile * (32 * C);
+        const typename ST::T* dt = db + (long)tile * (32 * C);
         const int rows = min(P - tile * 32, 32);
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
             const unsigned offp = (unsigned)(min(f / (C / 4), rows - 1) * C + 4 * (f % (C / 4)));
-            nSP[v] = *reinterpret_cast<const float4*>(st + offp);
-            nDP[v] = *reinterpret_cast<const float4*>(dt + offp);
+            nSP[v] = ST::ldr4(st + offp);
+            nDP[v] = ST::ldr4(dt + offp);
             const int r0 = 4 * (tg + v * (F::NT / C));
-            float a[4], b[4];
             FFNO_UNROLL
             for (int i = 0; i < 4; ++i) {
                 const unsigned offt = (unsigned)(min(r0 + i, rows - 1) * C + tc);
-                a[i] = st[offt], b[i] = dt[offt];
+                nST[v].v[i] = ST::ldr1(st + offt), nDT[v].v[i] = ST::ldr1(dt + offt);
             }
-            nST[v] = make_float4(a[0], a[1], a[2], a[3]);
-            nDT[v] = make_float4(b[0], b[1], b[2], b[3]);
         }
     };
     // tile_ = the tile whose rows are in the staging registers (may lie past the end: its copy is staged but never used and
@@ -973,23 +1050,26 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const float* __re
             const int f = tid + v * F::NT;
             const float mp = (f / (C / 4)) < rows ? 1.f : 0.f;
             const float fs = fscale * mp, gs = gscale * mp;
-            nSP[v].x *= fs, nSP[v].y *= fs, nSP[v].z *= fs, nSP[v].w *= fs;
-            nDP[v].x *= gs, nDP[v].y *= gs, nDP[v].z *= gs, nDP[v].w *= gs;
+            float4 sp = ST::w4(nSP[v]), dp = ST::w4(nDP[v]);
+            sp.x *= fs, sp.y *= fs, sp.z *= fs, sp.w *= fs;
+            dp.x *= gs, dp.y *= gs, dp.z *= gs, dp.w *= gs;
             const int r0 = 4 * (tg + v * (F::NT / C));
             const float m0 = r0 < rows ? 1.f : 0.f, m1 = r0 + 1 < rows ? 1.f : 0.f, m2 = r0 + 2 < rows ? 1.f : 0.f,
                         m3 = r0 + 3 < rows ? 1.f : 0.f;
-            nST[v].x *= fscale * m0, nST[v].y *= fscale * m1, nST[v].z *= fscale * m2, nST[v].w *= fscale * m3;
-            nDT[v].x *= gscale * m0, nDT[v].y *= gscale * m1, nDT[v].z *= gscale * m2, nDT[v].w *= gscale * m3;
+            float4 tS = make_float4(ST::w1(nST[v].v[0]), ST::w1(nST[v].v[1]), ST::w1(nST[v].v[2]), ST::w1(nST[v].v[3]));
+            float4 tD = make_float4(ST::w1(nDT[v].v[0]), ST::w1(nDT[v].v[1]), ST::w1(nDT[v].v[2]), ST::w1(nDT[v].v[3]));
+            tS.x *= fscale * m0, tS.y *= fscale * m1, tS.z *= fscale * m2, tS.w *= fscale * m3;
+            tD.x *= gscale * m0, tD.y *= gscale * m1, tD.z *= gscale * m2, tD.w *= gscale * m3;
             const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
-            stage4_s<SplitHf2>(lds[buf] + OFF_SP, F::PPLANE, offp, nSP[v].x, nSP[v].y, nSP[v].z, nSP[v].w);
-            stage4_s<SplitHf2>(lds[buf] + OFF_DP, F::PPLANE, offp, nDP[v].x, nDP[v].y, nDP[v].z, nDP[v].w);
+            stage4_s<SplitHf2>(lds[buf] + OFF_SP, F::PPLANE, offp, sp.x, sp.y, sp.z, sp.w);
+            stage4_s<SplitHf2>(lds[buf] + OFF_DP, F::PPLANE, offp, dp.x, dp.y, dp.z, dp.w);
             // pixel group grp = (s2 << 2) | (q << 1) | half  <->  local pixels 16 s2 + 8 q + 4 half + i  <->  k slot 4 q + i
             const int grp = tg + v * (F::NT / C);
             const int pos = 16 * (grp & 1) + 8 * (grp >> 2) + 4 * ((grp >> 1) & 1);
             const int offt = tc * F::TROW + 2 * pos;
-            stage4_s<SplitHf2>(lds[buf] + OFF_ST, F::TPLANE, offt, nST[v].x, nST[v].y, nST[v].z, nST[v].w);
-            stage4_s<SplitHf2>(lds[buf] + OFF_DT, F::TPLANE, offt, nDT[v].x, nDT[v].y, nDT[v].z, nDT[v].w);
-            bs2 += (nDT[v].x + nDT[v].y) + (nDT[v].z + nDT[v].w);
+            stage4_s<SplitHf2>(lds[buf] + OFF_ST, F::TPLANE, offt, tS.x, tS.y, tS.z, tS.w);
+            stage4_s<SplitHf2>(lds[buf] + OFF_DT, F::TPLANE, offt, tD.x, tD.y, tD.z, tD.w);
+            bs2 += (tD.x + tD.y) + (tD.z + tD.w);
         }
     };
 
@@ -1304,6 +1384,15 @@ static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* r
     unsigned* oa = o ? o->out_amax : nullptr;
     const bool in_phase = o && (o->schedule & FFNO_FF_SCHED_IN_PHASE);
     hipStream_t st = (hipStream_t)stream;
+    if (o && o->storage == FFNO_STORE_BF16) {      // bf16 storage twin: the split-fp16 kernel of the headline shape
+        typedef const uint16_t* cp;
+        if (S::NP != 2 || C != 64 || H != 256) return FFNO_EUNSUPPORTED;
+        FFNO_LAUNCH((ffx_chain_rs_kernel<64, 256, false, SplitHf2, StBf16>), grid, dim3(FxCfg<64, 256>::NT), 0, st, (cp)s, (cp)s2,
+                    (uint16_t*)s_sum, (cp)resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, (uint16_t*)out, (uint32_t*)mask, P,
+                    ia, oa);
+        return ffx_launch_status();
+    }
+    if (o && o->storage != FFNO_STORE_F32) return FFNO_EINVAL;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
         if (!in_phase && HH >= 64)                                                                                    \
@@ -1328,6 +1417,15 @@ static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const 
     const unsigned* ia = o ? o->in_amax : nullptr;
     unsigned* oa = o ? o->out_amax : nullptr;
     hipStream_t st = (hipStream_t)stream;
+    if (o && o->storage == FFNO_STORE_BF16) {
+        typedef const uint16_t* cp;
+        if (S::NP != 2 || C != 64 || H != 256) return FFNO_EUNSUPPORTED;
+        FFNO_LAUNCH((ffx_chain_kernel<64, 256, true, SplitHf2, StBf16>), grid, dim3(FxCfg<64, 256>::NT), 0, st, (cp)db, (cp)db2,
+                    (uint16_t*)db_sum, (cp) nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, (uint16_t*)ds,
+                    (uint32_t*)const_cast<void*>(mask), P, ia, oa);
+        return ffx_launch_status();
+    }
+    if (o && o->storage != FFNO_STORE_F32) return FFNO_EINVAL;
 #define CASE(CC, HH)                                                                                                  \
     if (C == CC && H == HH) {                                                                                         \
         FFNO_LAUNCH((ffx_chain_kernel<CC, HH, true, S>), grid, dim3(FxCfg<CC, HH>::NT), 0, st, db, db2, db_sum,       \
@@ -1343,9 +1441,17 @@ static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const 
 template <class S>
 static int fx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
                                   float* partial, int P, int C, int H, int nsplit, const unsigned* s_amax,
-                                  const unsigned* db_amax, void* stream) {
+                                  const unsigned* db_amax, int storage, void* stream) {
     if (!s || !db || !pk1 || !b1 || !pk1b || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (storage == FFNO_STORE_BF16) {      // bf16 storage twin: the single-accumulator kernel (needs both range words)
+        if (S::NP != 2 || C != 64 || H != 256) return FFNO_EUNSUPPORTED;
+        if (!s_amax || !db_amax) return FFNO_EINVAL;
+        FFNO_LAUNCH((ffh_wgrad_m_kernel<64, 256, 8, StBf16>), dim3(nsplit), dim3(512), 0, st, (const uint16_t*)s,
+                    (const uint16_t*)db, (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);
+        return ffx_launch_status();
+    }
+    if (storage != FFNO_STORE_F32) return FFNO_EINVAL;
     // split-fp16 with range words at the headline shape: the single-accumulator kernel (measured 56 vs 66 us per layer)
     const bool merged = S::NP == 2 && s_amax && db_amax;
 #define CASE(CC, HH)                                                                                               \
@@ -1387,7 +1493,8 @@ extern "C" int ffno_ffx_bwd_data2(const float* db, const float* db2, float* db_s
 extern "C" int ffno_ffx_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
                                             const void* pk1b, float* partial, int P, int C, int H, int nsplit,
                                             void* stream) {
-    return fx_bwd_weights_partial<SplitBf3>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, nullptr, nullptr, stream);
+    return fx_bwd_weights_partial<SplitBf3>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, nullptr, nullptr, FFNO_STORE_F32,
+                                            stream);
 }
 
 // ---- split-fp16 entry points (same operators, masks, partial-slice layout and reduce kernels; own weight packs) ----
@@ -1406,8 +1513,8 @@ extern "C" int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_s
 }
 extern "C" int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1,
                                             const void* pk1b, float* partial, int P, int C, int H, int nsplit,
-                                            const uint32_t* s_amax, const uint32_t* db_amax, void* stream) {
-    return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, s_amax, db_amax, stream);
+                                            const uint32_t* s_amax, const uint32_t* db_amax, int storage, void* stream) {
+    return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, s_amax, db_amax, storage, stream);
 }
 
 extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,

@@ -98,9 +98,10 @@ static inline PadMapDev make_padmap(const ffno_padmap* pm) {
 }
 
 // ---- lift (in_proj) -----------------------------------------------------------------------------------
-template <int C>
+// (ST: storage format of the activation tensor -- `out` here; ffno_device.h)
+template <int C, class ST = StF32>
 __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                       const float* __restrict__ b, float* __restrict__ out, int P,
+                                                       const float* __restrict__ b, typename ST::T* __restrict__ out, int P,
                                                        int Cin, PadMapDev pm, unsigned* out_amax) {
     FFNO_DYN_SMEM(smem);
     __shared__ float rfold[4];
@@ -123,16 +124,17 @@ __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__
             acc.z = fmaf(xv, w.z, acc.z);
             acc.w = fmaf(xv, w.w, acc.w);
         }
-        *reinterpret_cast<float4*>(out + pm.map(p) * C + c4) = acc;
+        ST::st4(out + pm.map(p) * C + c4, acc);
+        acc = st_rnd4<ST>(acc);
         omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
     }
     if (out_amax) range_fold(omax, rfold, 4, out_amax);      // (optional range word of the lifted features)
 }
 
 // partial[split][i][c] = sum_{p in slice} gout[q(p)][c] * (i < Cin ? x[p][i] : 1)
-template <int C>
+template <int C, class ST = StF32>
 __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __restrict__ x,
-                                                               const float* __restrict__ gout,
+                                                               const typename ST::T* __restrict__ gout,
                                                                float* __restrict__ partial, int P, int Cin,
                                                                int chunk, PadMapDev pm) {
     constexpr int TP = 32;                     // pixels staged per pass
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __re
     for (long p0 = pbeg; p0 < pend; p0 += TP) {
         const int np = (int)min((long)TP, pend - p0);
         __syncthreads();
-        for (int e = threadIdx.x; e < TP * C; e += 256) gs[e] = (e / C) < np ? gout[pm.map(p0 + e / C) * C + (e % C)] : 0.f;
+        for (int e = threadIdx.x; e < TP * C; e += 256) gs[e] = (e / C) < np ? ST::ld1(gout + pm.map(p0 + e / C) * C + (e % C)) : 0.f;
         for (int e = threadIdx.x; e < TP * (Cin + 1); e += 256) {
             const int pp = e / (Cin + 1), i = e % (Cin + 1);
             xs[pp * 64 + i] = (pp < np) ? (i < Cin ? x[(p0 + pp) * Cin + i] : 1.f) : 0.f;
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict_
     if (lane == 0) fold[e] = s + ((c == C) ? cb[o] : 0.f);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ b, const float* __restrict__ fold,
+template <int C, class ST = StF32>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const typename ST::T* __restrict__ b, const float* __restrict__ fold,
                                                        float* y, int P, int O, int accumulate, PadMapDev pm) {
     constexpr int LPP = C / 4, PPB = 256 / LPP;
     const int c4 = (threadIdx.x % LPP) * 4, pl = threadIdx.x / LPP;
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     for (long pass = blockIdx.x; pass < npass; pass += gridDim.x) {  // uniform trip count per wave (shuffles)
         const long p = pass * PPB + pl;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < P) v = *reinterpret_cast<const float4*>(b + pm.map(p) * C + c4);
+        if (p < P) v = ST::ld4(b + pm.map(p) * C + c4);
         for (int o = 0; o < O; ++o) {
             const float4 w = *reinterpret_cast<const float4*>(fold + o * (C + 1) + c4);
             float d = v.x * w.x + v.y * w.y + v.z * w.z + v.w * w.w;
@@ -258,9 +260,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // gb[q(p)][:] = sum_o gy[p][o] * weff[o] ;  partial[block][o][0..C) = sum_p gy[p][o] b[q(p)][:],  [o][C] = sum_p gy[p][o]
-template <int C>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ b, const float* __restrict__ gy,
-                                                       const float* __restrict__ fold, float* __restrict__ gb,
+template <int C, class ST = StF32>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const typename ST::T* __restrict__ b, const float* __restrict__ gy,
+                                                       const float* __restrict__ fold, typename ST::T* __restrict__ gb,
                                                        float* __restrict__ partial, int P, int O, PadMapDev pm,
                                                        unsigned* gb_amax) {
     constexpr int LPP = C / 4, PPB = 256 / LPP;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
     for (long p = (long)blockIdx.x * PPB + pl; p < P; p += (long)gridDim.x * PPB) {
         const long q = pm.map(p);
-        const float4 v = *reinterpret_cast<const float4*>(b + q * C + c4);
+        const float4 v = ST::ld4(b + q * C + c4);
         float4 gsum = make_float4(0.f, 0.f, 0.f, 0.f);
         FFNO_UNROLL
         for (int o = 0; o < kHeadMaxOut; ++o) {
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                 gsum.w = fmaf(g, w.w, gsum.w);
             }
         }
-        if (gb) *reinterpret_cast<float4*>(gb + q * C + c4) = gsum;
+        if (gb) ST::st4(gb + q * C + c4, gsum);
+        gsum = st_rnd4<ST>(gsum);
         omax = fmaxf(fmaxf(omax, fmaxf(fabsf(gsum.x), fabsf(gsum.y))), fmaxf(fabsf(gsum.z), fabsf(gsum.w)));
     }
     if (gb && gb_amax) range_fold(omax, rfold, 4, gb_amax);      // (optional range word of the gradient handed to the layers)
@@ -619,8 +622,9 @@ extern "C" int ffno_transpose_batched(const ffno_tr_desc* descs_dev, int n, int 
     return pw_status();
 }
 
-extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
-                             const ffno_padmap* pad, uint32_t* out_amax, void* stream) {
+template <class ST>
+static int lift_fwd_impl(const float* x, const float* W, const float* b, typename ST::T* out, int P, int Cin, int C,
+                         const ffno_padmap* pad, uint32_t* out_amax, void* stream) {
     if (!x || !W || !b || !out || P <= 0 || Cin <= 0) return FFNO_EINVAL;
     if (Cin > 63) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
@@ -629,25 +633,37 @@ extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, flo
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((lift_fwd_kernel<64>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
-    else if (C == 32)
-        FFNO_LAUNCH((lift_fwd_kernel<32>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
+        FFNO_LAUNCH((lift_fwd_kernel<64, ST>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
+    else if (C == 32 && !ST::BF16)
+        FFNO_LAUNCH((lift_fwd_kernel<32, StF32>), grid, block, smem, s, x, W, b, (float*)out, P, Cin, pm, out_amax);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
 }
+extern "C" int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, int P, int Cin, int C,
+                             const ffno_padmap* pad, uint32_t* out_amax, void* stream) {
+    return lift_fwd_impl<StF32>(x, W, b, out, P, Cin, C, pad, out_amax, stream);
+}
+// bf16 storage twins of the four pointwise kernels that touch the layer stack's activations (C = 64): `out` / `gout` / `b` / `gb`
+// are bf16, everything else (inputs, targets, parameters and their gradients) stays fp32
+extern "C" int ffno_lift_fwd_bf16(const float* x, const float* W, const float* b, uint16_t* out, int P, int Cin, int C,
+                                  const ffno_padmap* pad, uint32_t* out_amax, void* stream) {
+    return lift_fwd_impl<StBf16>(x, W, b, out, P, Cin, C, pad, out_amax, stream);
+}
 
-extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
-                             int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
+template <class ST>
+static int lift_bwd_impl(const float* x, const typename ST::T* gout, float* partial, float* dW, float* db, int P,
+                         int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
     if (!x || !gout || !partial || !dW || !db || P <= 0 || Cin <= 0 || nsplit <= 0) return FFNO_EINVAL;
     if (Cin > 63) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
     const int chunk = (P + nsplit - 1) / nsplit;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<64>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
-    else if (C == 32)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<32>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
+    else if (C == 32 && !ST::BF16)
+        FFNO_LAUNCH((lift_bwd_partial_kernel<32, StF32>), dim3(nsplit), dim3(256), 0, s, x, (const float*)gout, partial, P, Cin,
+                    chunk, pm);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
@@ -656,6 +672,14 @@ extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, 
     FFNO_LAUNCH(lift_bwd_reduce_kernel, dim3((npairs + 3) / 4), dim3(256), 0, s, partial, dW, db, Cin, C, nsplit,
                 accumulate);
     return pw_status();
+}
+extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
+                             int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
+    return lift_bwd_impl<StF32>(x, gout, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
+}
+extern "C" int ffno_lift_bwd_bf16(const float* x, const uint16_t* gout, float* partial, float* dW, float* db, int P,
+                                  int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
+    return lift_bwd_impl<StBf16>(x, gout, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
 }
 
 extern "C" int ffno_lift_bwd_data(const float* gout, const float* W, float* dx, int P, int Cin, int C,
@@ -684,8 +708,9 @@ extern "C" int ffno_head_fold(const float* Wa, const float* ca, const float* Wb,
     return pw_status();
 }
 
-extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int O, int accumulate,
-                             const ffno_padmap* pad, void* stream) {
+template <class ST>
+static int head_fwd_impl(const typename ST::T* b, const float* fold, float* y, int P, int C, int O, int accumulate,
+                         const ffno_padmap* pad, void* stream) {
     if (!b || !fold || !y || P <= 0 || O <= 0) return FFNO_EINVAL;
     if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
@@ -693,31 +718,51 @@ extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P,
     const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((head_fwd_kernel<64>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
-    else if (C == 32)
-        FFNO_LAUNCH((head_fwd_kernel<32>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
+        FFNO_LAUNCH((head_fwd_kernel<64, ST>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
+    else if (C == 32 && !ST::BF16)
+        FFNO_LAUNCH((head_fwd_kernel<32, StF32>), grid, block, 0, s, (const float*)b, fold, y, P, O, accumulate, pm);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
 }
+extern "C" int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int O, int accumulate,
+                             const ffno_padmap* pad, void* stream) {
+    return head_fwd_impl<StF32>(b, fold, y, P, C, O, accumulate, pad, stream);
+}
+extern "C" int ffno_head_fwd_bf16(const uint16_t* b, const float* fold, float* y, int P, int C, int O, int accumulate,
+                                  const ffno_padmap* pad, void* stream) {
+    return head_fwd_impl<StBf16>(b, fold, y, P, C, O, accumulate, pad, stream);
+}
 
-extern "C" int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
-                             float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, uint32_t* gb_amax,
-                             void* stream) {
+template <class ST>
+static int head_bwd_impl(const typename ST::T* b, const float* gy, const float* fold, typename ST::T* gb, float* partial,
+                         float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, uint32_t* gb_amax,
+                         void* stream) {
     if (!b || !gy || !fold || !partial || !red || P <= 0 || nsplit <= 0 || O <= 0) return FFNO_EINVAL;
     if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((head_bwd_kernel<64>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
-    else if (C == 32)
-        FFNO_LAUNCH((head_bwd_kernel<32>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
+        FFNO_LAUNCH((head_bwd_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
+    else if (C == 32 && !ST::BF16)
+        FFNO_LAUNCH((head_bwd_kernel<32, StF32>), dim3(nsplit), dim3(256), 0, s, (const float*)b, gy, fold, (float*)gb, partial, P,
+                    O, pm, gb_amax);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
     if (rc) return rc;
     FFNO_LAUNCH(head_bwd_reduce_kernel, dim3((O * (C + 1) + 3) / 4), dim3(256), 0, s, partial, red, C, O, nsplit);
     return pw_status();
+}
+extern "C" int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
+                             float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, uint32_t* gb_amax,
+                             void* stream) {
+    return head_bwd_impl<StF32>(b, gy, fold, gb, partial, red, P, C, O, nsplit, pad, gb_amax, stream);
+}
+extern "C" int ffno_head_bwd_bf16(const uint16_t* b, const float* gy, const float* fold, uint16_t* gb, float* partial,
+                                  float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, uint32_t* gb_amax,
+                                  void* stream) {
+    return head_bwd_impl<StBf16>(b, gy, fold, gb, partial, red, P, C, O, nsplit, pad, gb_amax, stream);
 }
 
 extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,

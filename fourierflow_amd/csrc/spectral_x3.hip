@@ -106,7 +106,9 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 // NL = lines per workgroup: 16 (two per wave; the per-mode mix fills its 32-row tile) or 8 (one per wave: launches with few
 // lines -- batch-1 rollout: 64 lines per axis -- spread over twice as many CUs; the mix then uses rows 0..15 of the tile,
 // rows 16..31 repeat them and are dropped).
-template <int NL, bool MIXH2>
+// ST = storage format of the activation tensors in / out / resid (ffno_device.h): with StBf16 a loaded sample IS one bf16 plane,
+// so the forward DFT needs three MFMAs per product block instead of six; the saved spectra stay fp32.
+template <int NL, bool MIXH2, class ST = StF32>
 __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
@@ -138,8 +140,8 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     const long es = lm.elem_stride;
     // Lines past the end of the axis read (and transform) line R - 1 again: rows of the tile are independent, and nothing of
     // a dead line is ever stored.
-    const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + 2 * j) * 4);
-    const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + 2 * j) * 4);
+    const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + 2 * j) * ST::BYTES);
+    const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + 2 * j) * ST::BYTES);
     if (skew_cycles > 0) plat::sleep_cycles(skew_cycles);      // optional start skew (see spectral_x3_pair_kernel)
 
     // ---------------- phase 1: truncated forward DFT of the wave's two lines ----------------
@@ -151,14 +153,17 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         const int tbase = ri ? L : 0;
         const int km = rowok ? k : 0;
 
-        float2 raw[4][8];      // one 64-sample chunk of one line: k-step u, slot e -> sample 16 (4 chunk + u) + 8 half + e
+        // one 64-sample chunk of one line: k-step u, slot e -> sample 16 (4 chunk + u) + 8 half + e (bf16 storage: the word
+        // holding the lane's two channels, as it came)
+        using Raw = typename std::conditional<ST::BF16, unsigned, float2>::type;
+        Raw raw[4][8];
         // samples past the end of the line (L not a multiple of 16) re-read sample L - 1: finite data under a zero of F
-        const unsigned esb = (unsigned)(es * 4);
+        const unsigned esb = (unsigned)(es * ST::BYTES);
         auto load_rows = [&](int chunk, int u, unsigned lo) {
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
                 const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
-                raw[u][e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(in) + (lo + (unsigned)n * esb));
+                raw[u][e] = *reinterpret_cast<const Raw*>(reinterpret_cast<const char*>(in) + (lo + (unsigned)n * esb));
             }
         };
         // DFT-matrix fragments of one chunk (exact three-way splits; built while the loads are in flight).  The table index
@@ -200,16 +205,32 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 const bool more = chunk + 1 < nchunks;
                 FFNO_UNROLL
                 for (int u = 0; u < 4; ++u) {
-                    const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
-                                            raw[u][6].x, raw[u][7].x);
-                    const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
-                                            raw[u][6].y, raw[u][7].y);
-                    if (more)
-                        load_rows(chunk + 1, u, ln ? lo1 : lo0);
-                    else if (ln == 0 && NLW > 1)
-                        load_rows(0, u, lo1);
-                    acc0 = mfma_x3(Ff[u], b0, acc0);
-                    acc1 = mfma_x3(Ff[u], b1, acc1);
+                    if constexpr (ST::BF16) {
+                        // the samples are bf16: one operand plane (low halves = even channel, high halves = odd channel)
+                        u32x4 b0, b1;
+                        FFNO_UNROLL
+                        for (int q = 0; q < 4; ++q) {
+                            b0[q] = plat::pack_lo16(raw[u][2 * q], raw[u][2 * q + 1]);
+                            b1[q] = plat::pack_hi16(raw[u][2 * q], raw[u][2 * q + 1]);
+                        }
+                        if (more)
+                            load_rows(chunk + 1, u, ln ? lo1 : lo0);
+                        else if (ln == 0 && NLW > 1)
+                            load_rows(0, u, lo1);
+                        acc0 = mfma_x3_plane(Ff[u], b0, acc0);
+                        acc1 = mfma_x3_plane(Ff[u], b1, acc1);
+                    } else {
+                        const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
+                                                raw[u][6].x, raw[u][7].x);
+                        const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
+                                                raw[u][6].y, raw[u][7].y);
+                        if (more)
+                            load_rows(chunk + 1, u, ln ? lo1 : lo0);
+                        else if (ln == 0 && NLW > 1)
+                            load_rows(0, u, lo1);
+                        acc0 = mfma_x3(Ff[u], b0, acc0);
+                        acc1 = mfma_x3(Ff[u], b1, acc1);
+                    }
                 }
             }
             float* xs = XS + (lw + ln) * LSF + 2 * j;
@@ -327,7 +348,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     // ---------------- phase 3: zero-padded inverse DFT of the wave's two lines ----------------
     {
         const int RTtot = (L + 31) >> 5;
-        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const unsigned hoff = (unsigned)(4 * half * es * ST::BYTES);
         FFNO_NOUNROLL
         for (int rt0 = 0; rt0 < RTtot; rt0 += 2) {
             // inverse-DFT matrix fragments of two 32-row output tiles: row n, slot e of k-step st <-> kk = (mode t, part)
@@ -376,14 +397,14 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 for (int q = 0; q < 2; ++q) {
                     if (rt0 + q >= RTtot) continue;
                     // rows the epilogue adds (residual / accumulate) are requested before the tile's products
-                    float2 pre[16];
+                    typename ST::Raw2 pre[16];      // (raw words: widened in the epilogue, after the tile's products)
                     const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
                                                  : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
                     if (addsrc) {
                         FFNO_UNROLL
                         for (int r = 0; r < 16; ++r) {
                             const int nu = min(32 * (rt0 + q) + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
-                            pre[r] = *reinterpret_cast<const float2*>(addsrc + (lo - hoff) + (unsigned)nu * (unsigned)(es * 4));
+                            pre[r] = ST::ldr2(addsrc + (lo - hoff) + (unsigned)nu * (unsigned)(es * ST::BYTES));
                         }
                     }
                     f32x16 o0 = zero16(), o1 = zero16();
@@ -396,15 +417,18 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                     for (int r = 0; r < 16; ++r) {
                         const int nu = 32 * (rt0 + q) + (r & 3) + 8 * (r >> 2);     // uniform part of the output sample index
                         if (nu + 4 * half < L) {
-                            const long uo = (long)nu * es * 4;
+                            const long uo = (long)nu * es * ST::BYTES;
                             float2 o = make_float2(o0[r] * rrs, o1[r] * rrs);
-                            if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
+                            if (addsrc) {
+                                const float2 pw = ST::w2(pre[r]);
+                                o.x += pw.x, o.y += pw.y;
+                            }
                             if (A.accumulate && A.resid) {      // both at once (rare): the second addend is read in place
-                                const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lo);
+                                const float2 pv = ST::ld2(reinterpret_cast<const char*>(A.out) + uo + lo);
                                 o.x += pv.x, o.y += pv.y;
                             }
-                            *reinterpret_cast<float2*>(reinterpret_cast<char*>(A.out) + uo + lo) = o;
-                            omax = fmaxf(omax, fmaxf(fabsf(o.x), fabsf(o.y)));
+                            ST::st2(reinterpret_cast<char*>(A.out) + uo + lo, o);
+                            omax = fmaxf(omax, fmaxf(fabsf(ST::rnd(o.x)), fabsf(ST::rnd(o.y))));
                         }
                     }
                 }
@@ -725,15 +749,15 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
     if (A.out_amax) range_fold(omax, rfold, F::NW, A.out_amax);
 }
 
-template <int NL, bool MIXH2>
+template <int NL, bool MIXH2, class ST = StF32>
 __global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
-    spectral_x3_body<NL, MIXH2>(a, blockIdx.x, 0);
+    spectral_x3_body<NL, MIXH2, ST>(a, blockIdx.x, 0);
 }
 
 // Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
 // workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
 // weights of ONE branch only; otherwise [0, n0) run a and the rest b.
-template <int NL, bool MIXH2>
+template <int NL, bool MIXH2, class ST = StF32>
 __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
     bool second;
@@ -772,7 +796,7 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.accumulate = second ? b.accumulate : a.accumulate;
     s.in_amax = second ? b.in_amax : a.in_amax;
     s.out_amax = second ? b.out_amax : a.out_amax;
-    spectral_x3_body<NL, MIXH2>(s, idx, (idx & 1) ? skew : 0);
+    spectral_x3_body<NL, MIXH2, ST>(s, idx, (idx & 1) ? skew : 0);
 }
 
 // ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
@@ -1407,6 +1431,8 @@ static inline bool x3_small_tiles(int Ra, int Rb, int tile_lines) {
     return (Ra + 7) / 8 + (Rb + 7) / 8 <= device_cu_count();
 }
 
+static inline bool x3_many_modes(int K) { return 2 * K > X3Cfg::KK; }
+
 static inline int x3_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? FFNO_OK : (int)e;
@@ -1421,8 +1447,6 @@ extern "C" int ffno_spectral_x3_supported(int C, int K, int L) {
     if (C == X3Cfg32::C) return (K >= 1 && 2 * K <= X3Cfg32::KK && L >= 2 && L <= 2048) ? 1 : 0;      // width 32: K <= 16
     return (C == X3Cfg::C && K >= 1 && K <= 64 && L >= 2 && L <= 2048) ? 1 : 0;
 }
-static inline bool x3_many_modes(int K) { return 2 * K > X3Cfg::KK; }
-
 extern "C" int ffno_spectral_x3_staged_supported(int C, int K, int L) {
     return (C == X3Cfg::C && K >= 1 && K <= 32 && L >= 2 && L <= 2048) ? 1 : 0;
 }
@@ -1458,6 +1482,11 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     if (!ffno_spectral_x3_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
     if (b->planes_format != FFNO_PLANES_BF16X3 && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EINVAL;
     if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16) return FFNO_EINVAL;
+    if (b->storage != FFNO_STORE_F32 && b->storage != FFNO_STORE_BF16) return FFNO_EINVAL;
+    // bf16 storage twins: the K <= 16 kernel at width 64, with the fp16x2 mix (or none)
+    if (b->storage == FFNO_STORE_BF16 &&
+        (C != X3Cfg::C || x3_many_modes(b->K) || (b->planes && b->planes_format != FFNO_PLANES_FP16X2)))
+        return FFNO_EUNSUPPORTED;
     a = X3Args{b->in, b->out, b->resid, b->spec_save, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
                make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate,
                b->in_amax, b->out_amax};
@@ -1497,6 +1526,13 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
 #undef X3K_LAUNCH
         return x3_status();
     }
+    if (br->storage == FFNO_STORE_BF16) {
+        if (x3_small_tiles(a.R, 0, br->tile_lines))
+            FFNO_LAUNCH((spectral_x3_kernel<8, true, StBf16>), dim3((a.R + 7) / 8), dim3(512), smem, st, a);
+        else
+            FFNO_LAUNCH((spectral_x3_kernel<16, true, StBf16>), dim3((a.R + 15) / 16), dim3(512), smem, st, a);
+        return x3_status();
+    }
     if (x3_small_tiles(a.R, 0, br->tile_lines)) {
         if (h2)
             FFNO_LAUNCH((spectral_x3_kernel<8, true>), dim3((a.R + 7) / 8), dim3(512), smem, st, a);
@@ -1523,7 +1559,7 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
     // both branches of a pair carry the same kind of planes (or none) and the same tile choice
     if ((ba->planes == nullptr) != (bb->planes == nullptr) || ba->planes_format != bb->planes_format ||
-        ba->tile_lines != bb->tile_lines)
+        ba->tile_lines != bb->tile_lines || ba->storage != bb->storage)
         return FFNO_EINVAL;
     const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
     hipStream_t st = (hipStream_t)stream;
@@ -1561,6 +1597,16 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         if ((interleave & 2) && square && ba->B % 8 == 0 && ba->M % NL == 0) return 2 | ((ba->M / NL) << 8);
         return (interleave & 1) ? 1 : 0;
     };
+    if (ba->storage == FFNO_STORE_BF16) {
+        if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
+            const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
+            FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+        } else {
+            const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = wg_map(16, n0, n1);
+            FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+        }
+        return x3_status();
+    }
     if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
         const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
         if (h2)

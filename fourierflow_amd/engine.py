@@ -220,6 +220,19 @@ class FFNOEngine:
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
         self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
+        # storage format of the activation tensors in HBM (include/ffno.h "Storage formats"): "fp32" = the parity path (the
+        # reference is precision: 32); "bf16" = the bf16 storage twins of the hot kernels -- half the activation bytes, results
+        # rounded to bf16 wherever a tensor is stored (a throughput variant with its own tolerance).  Available for the paired
+        # split-kernel path (2-D operators, width 64, <= 16 modes, 2-layer feed-forward, no fork heads / LayerNorm / dropout).
+        self.storage = os.environ.get("FFNO_STORAGE", "fp32")
+
+    def _bf16(self) -> bool:
+        if self.storage not in ("fp32", "bf16"):
+            raise ValueError("storage must be 'fp32' or 'bf16', got %r" % (self.storage,))
+        return self.storage == "bf16"
+
+    def _st(self) -> int:
+        return 1 if self._bf16() else 0      # FFNO_STORE_F32 / FFNO_STORE_BF16
 
     def _conc(self) -> bool:
         return bool(self.concurrent_branches and self._ffx() and not self.use_fork and not self.overlap
@@ -278,7 +291,7 @@ class FFNOEngine:
         """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
         fmt = int(bool(x3 and planes is not None and self._x3_h2()))
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout)
+                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout, self._st())
 
     # ---- range words (include/ffno.h "Range words"): one uint32 per (tensor kind, layer) in ws.RW ---------------------
     def _ranged(self) -> bool:
@@ -314,14 +327,14 @@ class FFNOEngine:
     def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_fwd2 if self._h2() else lib.ffno_ffx_fwd2
-        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0)
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0, self._st())
         self._k("ff_fwd", fn, _p(s), _p(s2), _p(s_sum), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out), _p(mask),
                 P, self.C, self.H, ctypes.byref(o), st)
 
     def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_bwd_data2 if self._h2() else lib.ffno_ffx_bwd_data2
-        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0)
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0, self._st())
         self._k("ff_bwd_data", fn, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
                 P, self.C, self.H, ctypes.byref(o), st)
 
@@ -329,7 +342,7 @@ class FFNOEngine:
         lib = _lib.get_lib()
         if self._h2():
             self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0), _p(l0.fx[2]),
-                    _p(part), P, self.C, self.H, nsplit, rs, rg, st)
+                    _p(part), P, self.C, self.H, nsplit, rs, rg, self._st(), st)
         else:
             self._k("ff_bwd_weights_partial", lib.ffno_ffx_bwd_weights_partial, _p(s), _p(g), _p(l0.fx[0]), _p(b0), _p(l0.fx[2]),
                     _p(part), P, self.C, self.H, nsplit, st)
@@ -495,7 +508,7 @@ class FFNOEngine:
                 _View(B, X * Y, Z, 0, self.Ks[2], C)]       # z: contiguous lines (b, x, y)
 
     def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
-        key = (B, tuple(S), bool(save), self._ffx(), self._conc(), self.general_ff)
+        key = (B, tuple(S), bool(save), self._ffx(), self._conc(), self.general_ff, self._bf16())
         if self._ws_key == key:
             return self._ws
         cache = self.__dict__.setdefault("_ws_cache", {})   # a few recent geometries (train batch / validation batch /
@@ -508,6 +521,7 @@ class FFNOEngine:
         P_in = B * int(np.prod(S))            # unpadded pixels (inputs / outputs)
         P = B * int(np.prod(Sp))              # pixels of the activation buffers
         f32 = dict(dtype=torch.float32, device=dev)
+        act = dict(dtype=torch.bfloat16 if self._bf16() else torch.float32, device=dev)     # activation tensors of the layer stack
         ns = L if save else 1
         ws = type("WS", (), {})()
         ws.P, ws.P_in, ws.Sp = P, P_in, Sp
@@ -517,10 +531,10 @@ class FFNOEngine:
             s3 = (1,) * (3 - self.nd) + tuple(S)
             p3 = (1,) * (3 - self.nd) + tuple(Sp)
             ws.padmap = _capi.PadMap((ctypes.c_int32 * 3)(*s3), (ctypes.c_int32 * 3)(*p3))
-        ws.X = torch.empty(P, C, **f32)
-        ws.Blast = torch.empty(P, C, **f32)
+        ws.X = torch.empty(P, C, **act)
+        ws.Blast = torch.empty(P, C, **act)
         ws.Y = torch.empty(P_in * O, **f32)
-        ws.S = torch.empty(ns, P, C, **f32)
+        ws.S = torch.empty(ns, P, C, **act)
         nv = len(ws.views)
         ws.SXall = [torch.empty(ns, v.spec, **f32) for v in ws.views]      # forward spectra, per axis, layer-major
         ws.SY = torch.empty(max(v.spec for v in ws.views), **f32)
@@ -528,9 +542,9 @@ class FFNOEngine:
         if self._conc():
             ws.SD2 = torch.empty_like(ws.SD)                          # second branch of a paired STAGE launch
             ws.SY2 = torch.empty_like(ws.SY)
-            ws.T = torch.empty(P, C, **f32)                           # output of the second branch of a paired launch
+            ws.T = torch.empty(P, C, **act)                           # output of the second branch of a paired launch
             if save:
-                ws.G1 = torch.empty(P, C, **f32)                      # ... and of the second adjoint branch
+                ws.G1 = torch.empty(P, C, **act)                      # ... and of the second adjoint branch
         if self.spectral == "plus":
             ws.SYa = torch.empty(ws.views[0].spec_y, **f32)           # last-axis spectra on either side of the x transform
             ws.SYb = torch.empty(ws.views[0].spec_y, **f32)
@@ -572,8 +586,8 @@ class FFNOEngine:
             ws.Hbuf = torch.empty(ns, P, H, **f32) if fp32_ff else [None] * ns
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
             ws.DH = [torch.empty(P, H, **f32) if fp32_ff else None for _ in range(2)]   # ping-pong (side-stream option)
-            ws.DS = torch.empty(P, C, **f32)
-            ws.G = [torch.empty(P, C, **f32) for _ in range(2)]    # running gradient, ping-pong per layer
+            ws.DS = torch.empty(P, C, **act)
+            ws.G = [torch.empty(P, C, **act) for _ in range(2)]    # running gradient, ping-pong per layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
@@ -868,6 +882,14 @@ class FFNOEngine:
                 and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
                            and not self.layer_norm)
+        bf16 = self._bf16()
+        if bf16 and not (conc and not singles and fused[pair[0]] and x3pair and self._h2() and self._x3_h2() and self._ffx()
+                         and C == 64 and H == 256 and max(v.K for v in ws.views) <= 16 and full and not self.use_fork
+                         and not self.layer_norm and self.dropout == 0.0 and self.in_dropout == 0.0):
+            raise NotImplementedError(
+                "storage='bf16' covers the paired split-kernel path of the 2-D operator (width 64, factor 4, <= 16 modes, "
+                "mode='full', fp16x2 splits, 2-layer feed-forward without fork heads / LayerNorm / dropout); this configuration "
+                "runs with storage='fp32'")
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:
@@ -879,7 +901,8 @@ class FFNOEngine:
             ws.RW.zero_()
             ws.rw_bwd_clean = True
         in_drop = self._training and self.in_dropout > 0.0
-        self._k("lift_fwd", lib.ffno_lift_fwd, _p(x), _p(lin_in.weff), _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
+        self._k("lift_fwd", lib.ffno_lift_fwd_bf16 if bf16 else lib.ffno_lift_fwd, _p(x), _p(lin_in.weff),
+                _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
                 self.Cin, C, pm, None if in_drop else rw(ws, "x", 0), st)
         if in_drop:      # x = self.drop(x) after in_proj (grid_2d.py:158): a regenerated mask over the lifted features
             self._in_drop_seed = (self.drop_seed * 0x9E3779B1 + self._drop_calls * 0x85EBCA6B + 0x632BE5AB) & 0xFFFFFFFF
@@ -963,7 +986,8 @@ class FFNOEngine:
             torch.sum(ws.YL, dim=0, out=ws.Y)     # forecast = sum of the per-layer head outputs
             self.forecast_list = [ws.YL[l].view(B, *S, self.O).clone() for l in range(L)]
         else:
-            self._k("head_fwd", lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y), ws.P_in, C, self.O, 0, pm, st)
+            self._k("head_fwd", lib.ffno_head_fwd_bf16 if bf16 else lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y),
+                    ws.P_in, C, self.O, 0, pm, st)
         self._saved = (x, B, S, fused, conc) if save_for_backward else None
         self._saved_x3 = (x3, x3pair)
         self.paired_last = conc      # (bench.py: which algorithmic-work table applies)
@@ -1025,8 +1049,8 @@ class FFNOEngine:
                 if l > 0:
                     self._k("axpy", lib.ffno_axpy, _p(ws.red), _p(ws.redl), 1.0, self.O * (C + 1), st)
         else:
-            self._k("head_bwd", lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold), _p(ws.G[cur]), _p(ws.headpart), _p(ws.red),
-                    ws.P_in, C, self.O, ws.nsplit_head, pm, rw(ws, "g", L - 1), st)
+            self._k("head_bwd", lib.ffno_head_bwd_bf16 if self._bf16() else lib.ffno_head_bwd, _p(ws.Blast), _p(gy), _p(self.fold),
+                    _p(ws.G[cur]), _p(ws.headpart), _p(ws.red), ws.P_in, C, self.O, ws.nsplit_head, pm, rw(ws, "g", L - 1), st)
         self._k("head_param_grads", lib.ffno_head_param_grads, _p(ws.red), _p(o0.weff), _p(self.params["out.0.bias"]),
                 _p(o1.weff), _p(o0.gweff), _p(gv("out.0.bias")), _p(o1.gweff), _p(gv("out.1.bias")), C, HEAD_DIM, self.O, 0, st)
         if not self._ffx() and self._n_tr:
@@ -1166,8 +1190,11 @@ class FFNOEngine:
                            acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rd, rout=rgo)
             have_g1 = conc
             cur = 1 - cur
-        if conc and have_g1:
-            self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(ws.G1), 1.0, P * C, st)     # lift_bwd takes one input
+        if conc and have_g1:      # lift_bwd takes one input
+            if self._bf16():
+                ws.G[cur].add_(ws.G1)       # (a torch kernel on the same stream; rounds the sum to bf16 like every stored tensor)
+            else:
+                self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(ws.G1), 1.0, P * C, st)
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:
@@ -1182,12 +1209,13 @@ class FFNOEngine:
         lin_in = self.linears["in_proj."]
         if self._training and self.in_dropout > 0.0:      # backward of x = self.drop(in_proj(x)): the same mask, regenerated
             self._k("in_dropout", lib.ffno_dropout, _p(g_fin), g_fin.numel(), self.in_dropout, self._in_drop_seed, st)
-        self._k("lift_bwd", lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart), _p(lin_in.gweff), _p(gv("in_proj.bias")),
-                ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
+        self._k("lift_bwd", lib.ffno_lift_bwd_bf16 if self._bf16() else lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart),
+                _p(lin_in.gweff), _p(gv("in_proj.bias")), ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
         self.dx = None
         if need_dx:
             self.dx = torch.empty(B, *S, self.Cin, dtype=torch.float32, device=self.device)
-            self._k("lift_bwd_data", lib.ffno_lift_bwd_data, _p(g_fin), _p(lin_in.weff), _p(self.dx), ws.P_in, self.Cin, C, pm, st)
+            g_dx = g_fin.float() if self._bf16() else g_fin      # (the input gradient is an fp32 tensor of the caller)
+            self._k("lift_bwd_data", lib.ffno_lift_bwd_data, _p(g_dx), _p(lin_in.weff), _p(self.dx), ws.P_in, self.Cin, C, pm, st)
         multi = self.spectral != "plus" and len(self._fw_sets) == L and L > 1      # per-layer weights: one launch per axis
         if multi:
             real = int(self.spectral == "dct")

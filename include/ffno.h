@@ -28,6 +28,17 @@
  *   host round trip, no assumption about magnitudes.  NULL in_amax = "the data is known to lie in
  *   [2^-12, 2^15]" (no scaling); NULL out_amax = nothing is recorded.  ffno_amax() folds any tensor.
  *
+ * Storage formats (the "bf16 storage twins" of the hot path; SURVEY 8(b) level 1)
+ *   The reference is `precision: 32` and fp32 tensors are the parity path.  The entry points of the markov / torus hot path
+ *   (width 64, <= 16 modes, 2-layer feed-forward: ffno_spectral_x3[_pair], ffno_ffh_fwd2 / _bwd_data2 / _bwd_weights_partial,
+ *   ffno_layer_fwd / _bwd, ffno_lift_*_bf16, ffno_head_*_bf16) also take their ACTIVATION tensors -- layer inputs and
+ *   outputs, branch outputs, the saved feed-forward input, and the gradients of those -- as bf16 (FFNO_STORE_BF16 in the
+ *   descriptor / options of the call; the pointers are then read as uint16_t*, same element counts).  Values are widened as
+ *   they are loaded and rounded to nearest even where they are stored; weights, spectra, ReLU sign bits, reductions and every
+ *   product in between are the fp32-grade arithmetic of the fp32 path, so  twin(x) == bf16(fp32 path(float(x)))  bit for bit.
+ *   Half the activation bytes of a training step; the price is the bf16 rounding of the stored tensors (forward ~3e-3
+ *   relative against the fp32 path over 24 layers: a throughput variant with its own tolerance, never the parity path).
+ *
  * Spectrum layout (internal but part of the ABI because callers own the workspaces):
  *   spec[k][r][ri][c]   k = mode (0..K-1), r = line index, ri = 0 real / 1 imag, c = channel
  *   lines: axis 0 (transform along N, fourier_weight[0]): r = b*M + m  (R = B*M lines of length N)
@@ -47,6 +58,9 @@ extern "C" {
 #define FFNO_EINVAL (-1)       /* null pointer / non-positive size */
 #define FFNO_EUNSUPPORTED (-2) /* shape outside the compiled template set */
 #define FFNO_EMODES (-3)       /* modes > L/2+1 (the reference fails with an einsum size error here) */
+
+#define FFNO_STORE_F32 0       /* activation tensors are float            */
+#define FFNO_STORE_BF16 1      /* activation tensors are bf16 (uint16_t)  */
 
 #define FFNO_MODE_FULL 0       /* grid_2d.py:64-68  */
 #define FFNO_MODE_LOWPASS 1    /* grid_2d.py:69-70  */
@@ -171,6 +185,8 @@ typedef struct ffno_fused_branch {
                                 from it -- |X| <= 2 sqrt(L) max|in| goes to 2^15 -- and the outputs are divided again); NULL = 1 */
     uint32_t* out_amax;      /* optional: receives max |out| of what this branch stores (the fused kernels of both families and
                                 the x3 stage kernels; the fp32 stage kernels ignore it: fold their output with ffno_amax) */
+    int32_t storage;         /* FFNO_STORE_F32 (0) / FFNO_STORE_BF16: format of in / out / resid ("Storage formats" above;
+                                ffno_spectral_x3[_pair] with C = 64, K <= 16 and FP16X2 or no planes; spec_save stays fp32) */
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
@@ -230,6 +246,8 @@ int ffno_spectral_x3_staged_pair(const ffno_fused_branch* a, const ffno_fused_br
 #define FFNO_BRANCH_X3 1
 #define FFNO_FF_BF16X3 0
 #define FFNO_FF_FP16X2 1
+/* (a.storage == b.storage is the format of EVERY activation tensor of the layer call: the branches' in / out / resid and the
+ *  feed-forward's s_sum / resid / out, g / g2 / g_sum / ds / s) */
 typedef struct ffno_layer_fwd_desc {
     ffno_fused_branch a, b;
     int32_t branch_kernel, interleave;
@@ -356,6 +374,8 @@ typedef struct ffno_ff_opts {
     int32_t schedule;        /* 0 = the measured default (forward: role-split halves -- a matrix segment on one wave of a SIMD
                                 beside a vector / LDS segment on the other; backward-data: both halves in phase), or
                                 FFNO_FF_SCHED_IN_PHASE for the forward; results are bit-identical */
+    int32_t storage;         /* FFNO_STORE_F32 (0) / FFNO_STORE_BF16: format of every activation pointer of the call (s, s2,
+                                s_sum, resid, out / db, db2, db_sum, ds); bf16: ffno_ffh_* at C = 64, H = 256 */
 } ffno_ff_opts;
 #define FFNO_FF_SCHED_IN_PHASE 1
 size_t ffno_ffx_pack_bytes(int C, int H);
@@ -420,7 +440,7 @@ int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_sum, const v
                        const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* opts, void* stream);
 int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
                                  float* partial, int P, int C, int H, int nsplit, const uint32_t* s_amax,
-                                 const uint32_t* db_amax, void* stream);
+                                 const uint32_t* db_amax, int storage /* FFNO_STORE_*: format of s and db */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),
@@ -483,6 +503,11 @@ int ffno_lift_fwd(const float* x, const float* W, const float* b, float* out, in
                   const ffno_padmap* pad, uint32_t* out_amax /* optional range word of out */, void* stream);
 int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
                   int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
+/* bf16 storage twins ("Storage formats" at the top; C = 64): the lifted features `out` / their gradient `gout` are bf16 */
+int ffno_lift_fwd_bf16(const float* x, const float* W, const float* b, uint16_t* out, int P, int Cin, int C,
+                       const ffno_padmap* pad, uint32_t* out_amax, void* stream);
+int ffno_lift_bwd_bf16(const float* x, const uint16_t* gout, float* partial, float* dW, float* db, int P,
+                       int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
 /* dx[p][Cin] = gout[q(p)][C] W: the gradient with respect to the block's INPUT (the reference modules are ordinary autograd
  * modules: grid_2d.py:154-177 propagates it to whatever produced x) */
 int ffno_lift_bwd_data(const float* gout, const float* W, float* dx, int P, int Cin, int C,
@@ -504,6 +529,11 @@ int ffno_head_fwd(const float* b, const float* fold, float* y, int P, int C, int
 int ffno_head_bwd(const float* b, const float* gy, const float* fold, float* gb, float* partial,
                   float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad,
                   uint32_t* gb_amax /* optional range word of gb */, void* stream);
+/* bf16 storage twins (C = 64): the last layer's output `b` and its gradient `gb` are bf16; y, gy, red stay fp32 */
+int ffno_head_fwd_bf16(const uint16_t* b, const float* fold, float* y, int P, int C, int O, int accumulate,
+                       const ffno_padmap* pad, void* stream);
+int ffno_head_bwd_bf16(const uint16_t* b, const float* gy, const float* fold, uint16_t* gb, float* partial,
+                       float* red, int P, int C, int O, int nsplit, const ffno_padmap* pad, uint32_t* gb_amax, void* stream);
 int ffno_head_param_grads(const float* red, const float* Wa, const float* ca, const float* Wb,
                           float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int O,
                           int accumulate, void* stream);

@@ -6,6 +6,7 @@
 #include "hip_emu.h"
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 typedef emu_u32x4 u32x4;
 
@@ -34,6 +35,22 @@ inline float f16_lo(unsigned w) { return emu::emu_half_to_float((unsigned short)
 inline float f16_hi(unsigned w) { return emu::emu_half_to_float((unsigned short)(w >> 16)); }
 inline unsigned pk_mul_f16(unsigned w, float k) { return pack_f16(f16_lo(w) * k, f16_hi(w) * k); }
 inline unsigned pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xffff0000u); }
+inline unsigned pack_lo16(unsigned u0, unsigned u1) { return (u0 & 0xffffu) | (u1 << 16); }
+inline unsigned bf16_rne(float x) {      // IEEE round-to-nearest-even to bf16 (NaN stays NaN)
+    unsigned u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+inline unsigned pack_bf16(float x0, float x1) { return bf16_rne(x0) | (bf16_rne(x1) << 16); }
+inline void swap_halves(unsigned& a, unsigned& b) {
+    float fa, fb;
+    memcpy(&fa, &a, 4), memcpy(&fb, &b, 4);
+    const float ta = __shfl_xor(fa, 32), tb = __shfl_xor(fb, 32);     // (plain copies: bit patterns survive)
+    const bool hi = (emu::S().cur->linear & 63) >= 32;
+    const float na = hi ? tb : fa, nb = hi ? fb : ta;
+    memcpy(&a, &na, 4), memcpy(&b, &nb, 4);
+}
 inline uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return (acc << 1) | (x >> 31); }
 inline uint32_t bit_to_mask(uint32_t x, int b) { return 0u - ((x >> b) & 1u); }
 inline void sleep_cycles(int) {}

@@ -127,7 +127,7 @@ def test_ffh_fwd_bwd(be, P, C, H, sched):
     assert word_value(be, ds_word) == float(np.abs(be.get(ds)).max())
     nsplit = 2 if P == 200 else 3 if P < 1000 else 64      # (200 pixels on 2 workgroups: 4 + 3 tiles each, ragged last tile)
     partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
-    assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, p(s_word), p(g_word), None) == 0
+    assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, nsplit, p(s_word), p(g_word), 0, None) == 0
     gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
     assert lib.ffno_ffx_bwd_weights_reduce(p(partial), p(gW1), p(gW2), p(gb1), p(gb2), C, H, nsplit, 0, None) == 0
     assert rel_l2(be.get(gW1), ref_dh.T @ s.astype(np.float64)) < TOL
@@ -175,7 +175,7 @@ def test_ffh_any_fp32_magnitude_is_in_range(be, act, grad):
     got = be.get(ds)
     assert np.all(np.isfinite(got)) and rel_l2(got, ref_dh @ W1.astype(np.float64)) < TOL
     partial = be.zeros(lib.ffno_ff_wgrad_partial_floats(C, H, 3))
-    assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, 3, p(s_word), p(g_word), None) == 0
+    assert lib.ffno_ffh_bwd_weights_partial(p(ssum), p(gsum), p(a1), p(db1_), p(a1b), p(partial), P, C, H, 3, p(s_word), p(g_word), 0, None) == 0
     gW1, gW2, gb1, gb2 = be.zeros((H, C)), be.zeros((C, H)), be.zeros(H), be.zeros(C)
     assert lib.ffno_ffx_bwd_weights_reduce(p(partial), p(gW1), p(gW2), p(gb1), p(gb2), C, H, 3, 0, None) == 0
     for got, ref in ((gW1, ref_dh.T @ s.astype(np.float64)), (gW2, db.astype(np.float64).T @ ref_h), (gb1, ref_dh.sum(0)),

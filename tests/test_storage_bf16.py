@@ -1,0 +1,303 @@
+"""bf16 storage twins of the hot path (include/ffno.h "Storage formats", SURVEY 8b level 1 / VERDICT x2).
+
+The contract that makes them testable to the bit: a twin widens its activation operands as they are loaded and rounds to
+nearest even where it stores; everything in between is the arithmetic of the fp32 kernel.  So
+
+    twin(x)  ==  bf16( fp32 kernel( float(x) ) )        bit for bit
+
+for every kernel on the path (fused split spectral branch, the three feed-forward kernels, lift / head), on the CPU wave
+emulator (-m "not gpu") and on the MI355X (-m gpu).  The block-level tests then state what bf16 STORAGE costs against the fp32
+oracle (a throughput variant with its own tolerance -- never the parity path) and that a training step runs on it."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import oracle_util as ou
+from backend_util import be, host_device, rel_l2  # noqa: F401
+from fourierflow_amd._capi import FfOpts, FusedBranch
+from oracle import ffno_oracle as orc
+from test_kernels_ffh import amax_word, pack_weights_h
+from test_kernels_spectral import _x3_pack
+
+FFNO_STORE_BF16 = 1
+
+
+def to_bf16(x):
+    """float32 array -> uint16 array of bf16 bit patterns, round to nearest even."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def from_bf16(h):
+    return (np.asarray(h).view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def put16(be, h):
+    return be.put(np.ascontiguousarray(h).view(np.int16))
+
+
+def get16(be, t):
+    return np.asarray(be.get(t)).view(np.uint16)
+
+
+def bf16_data(rs, shape, scale=1.0):
+    """(bit patterns, their float values) of random bf16 data."""
+    h = to_bf16(rs.standard_normal(shape).astype(np.float32) * scale)
+    return h, from_bf16(h)
+
+
+def test_rounding_helper_is_round_to_nearest_even():
+    x = np.array([1.0, 1.00390625, 1.005859375, 1.001953125, -3.0e-39, 65504.0, 3.3895314e38], np.float32)
+    ref = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    np.testing.assert_array_equal(to_bf16(x), ref)
+
+
+# ---- feed-forward kernels ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("P", [70, 200])
+def test_ffh_twins_are_the_rounded_fp32_kernels(be, P):
+    lib, p = be.lib, be.ptr
+    C, H = 64, 256
+    rs = np.random.RandomState(P)
+    sa_h, sa = bf16_data(rs, (P, C))
+    sb_h, sb = bf16_data(rs, (P, C))
+    re_h, resid = bf16_data(rs, (P, C))
+    s_h = to_bf16(sa + sb)                  # what the twin uses (and stores) as the feed-forward input
+    s = from_bf16(s_h)
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = (rs.standard_normal(H) * 0.1).astype(np.float32)
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b2 = (rs.standard_normal(C) * 0.1).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
+    db1_, db2_ = be.put(b1), be.put(b2)
+    nmask = lib.ffno_ff_mask_words(P, H)
+    s_word = amax_word(be, sa, sb)          # the same range word for both runs: the same power-of-two scale
+    # fp32 kernel on the widened operands
+    out32, mask32, w32 = be.empty((P, C)), be.zeros(nmask, np.uint32), be.zeros(1, np.uint32)
+    o = FfOpts(p(s_word), p(w32), 0, 0, 0)
+    assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, p(be.put(resid)), p(a1), p(db1_), p(a2), p(db2_), p(out32), p(mask32),
+                             P, C, H, ctypes.byref(o), None) == 0
+    # the twin: two bf16 addends, bf16 residual, bf16 output and stored sum
+    out16, sum16 = put16(be, np.zeros((P, C), np.uint16)), put16(be, np.zeros((P, C), np.uint16))
+    mask16, w16 = be.zeros(nmask, np.uint32), be.zeros(1, np.uint32)
+    o = FfOpts(p(s_word), p(w16), 0, 0, FFNO_STORE_BF16)
+    assert lib.ffno_ffh_fwd2(p(put16(be, sa_h)), p(put16(be, sb_h)), p(sum16), p(put16(be, re_h)), p(a1), p(db1_), p(a2), p(db2_),
+                             p(out16), p(mask16), P, C, H, ctypes.byref(o), None) == 0
+    np.testing.assert_array_equal(get16(be, sum16), s_h)
+    np.testing.assert_array_equal(get16(be, out16), to_bf16(be.get(out32)))
+    np.testing.assert_array_equal(be.get(mask16), be.get(mask32))
+    # the recorded maximum is the maximum of what was STORED
+    assert np.asarray(be.get(w16)).view(np.float32)[0] == np.abs(from_bf16(get16(be, out16))).max()
+
+    # backward-data
+    ga_h, ga = bf16_data(rs, (P, C), 3e-4)
+    gb_h, gb = bf16_data(rs, (P, C), 3e-4)
+    g_h = to_bf16(ga + gb)
+    g = from_bf16(g_h)
+    g_word = amax_word(be, ga, gb)
+    ds32 = be.empty((P, C))
+    o = FfOpts(p(g_word), None, 0, 0, 0)
+    assert lib.ffno_ffh_bwd_data2(p(be.put(g)), None, None, p(mask32), p(a1b), p(a2b), p(ds32), P, C, H, ctypes.byref(o), None) == 0
+    ds16, gsum16 = put16(be, np.zeros((P, C), np.uint16)), put16(be, np.zeros((P, C), np.uint16))
+    o = FfOpts(p(g_word), None, 0, 0, FFNO_STORE_BF16)
+    assert lib.ffno_ffh_bwd_data2(p(put16(be, ga_h)), p(put16(be, gb_h)), p(gsum16), p(mask16), p(a1b), p(a2b), p(ds16), P, C, H,
+                                  ctypes.byref(o), None) == 0
+    np.testing.assert_array_equal(get16(be, gsum16), g_h)
+    np.testing.assert_array_equal(get16(be, ds16), to_bf16(be.get(ds32)))
+
+    # weight gradients: fp32 slices either way -- identical
+    nsplit = 2
+    n = lib.ffno_ff_wgrad_partial_floats(C, H, nsplit)
+    part32, part16 = be.zeros(n), be.zeros(n)
+    assert lib.ffno_ffh_bwd_weights_partial(p(be.put(s)), p(be.put(g)), p(a1), p(db1_), p(a1b), p(part32), P, C, H, nsplit,
+                                            p(s_word), p(g_word), 0, None) == 0
+    assert lib.ffno_ffh_bwd_weights_partial(p(sum16), p(gsum16), p(a1), p(db1_), p(a1b), p(part16), P, C, H, nsplit,
+                                            p(s_word), p(g_word), FFNO_STORE_BF16, None) == 0
+    np.testing.assert_array_equal(be.get(part16), be.get(part32))
+
+
+def test_twins_refuse_what_they_do_not_cover(be):
+    lib, p = be.lib, be.ptr
+    P, C, H = 40, 32, 128
+    rs = np.random.RandomState(0)
+    W1, W2 = rs.standard_normal((H, C)).astype(np.float32), rs.standard_normal((C, H)).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
+    b1, b2 = be.zeros(H), be.zeros(C)
+    x = put16(be, np.zeros((P, C), np.uint16))
+    o = FfOpts(None, None, 0, 0, FFNO_STORE_BF16)
+    assert lib.ffno_ffh_fwd2(p(x), None, None, None, p(a1), p(b1), p(a2), p(b2), p(x), None, P, C, H, ctypes.byref(o), None) == -2
+    assert lib.ffno_ffx_fwd2(p(x), None, None, None, p(a1), p(b1), p(a2), p(b2), p(x), None, P, 64, 256, ctypes.byref(o), None) == -2
+    o = FfOpts(None, None, 0, 0, 7)
+    assert lib.ffno_ffh_fwd2(p(x), None, None, None, p(a1), p(b1), p(a2), p(b2), p(x), None, P, 64, 256, ctypes.byref(o), None) == -1
+
+
+# ---- fused split spectral branch --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,M,N,K,tile", [(2, 12, 16, 5, 0), (1, 40, 8, 4, 16), (3, 9, 10, 5, 8)])
+def test_spectral_x3_twin_is_the_rounded_fp32_kernel(be, B, M, N, K, tile):
+    """Single launches of both axes (forward flags and adjoint flags, with and without a residual) and the paired launch."""
+    lib, p = be.lib, be.ptr
+    C = 64
+    rs = np.random.RandomState(B * 100 + M)
+    x_h, x = bf16_data(rs, (B, M, N, C))
+    r_h, r = bf16_data(rs, (B, M, N, C))
+    w = [(rs.standard_normal((C, C, K, 2)) / C).astype(np.float32) for _ in range(2)]
+    packs = [_x3_pack(be, w[a], K, C, fmt=1) for a in (0, 1)]      # fp16x2 packs
+    sets = [(pk[0], pk[1]) for pk in packs]                         # [axis][fwd / adj]
+    x_word = amax_word(be, x)
+    x32, r32, x16, r16 = be.put(x), be.put(r), put16(be, x_h), put16(be, r_h)      # (kept alive: the descriptors hold raw pointers)
+    outs = {}
+    for axis in (0, 1):
+        L, R = (N, B * M) if axis == 0 else (M, B * N)
+        tw = be.twiddle(L)
+        for adj in (0, 1):
+            for with_resid in (False, True):
+                ck_f, ck_i, conj = (1, 0, 1) if adj else (0, 1, 0)
+                o32, sp32 = be.empty((B, M, N, C)), be.empty(K * R * 2 * C)
+                br = FusedBranch(p(x32), p(o32), p(r32) if with_resid else None, p(sp32), p(sets[axis][adj]), p(tw),
+                                 B, M, N, K, axis, 0, 1, tile, p(x_word), None, 0)
+                assert lib.ffno_spectral_x3(ctypes.byref(br), C, ck_f, ck_i, conj, None) == 0
+                o16, sp16 = put16(be, np.zeros((B, M, N, C), np.uint16)), be.empty(K * R * 2 * C)
+                w16 = be.zeros(1, np.uint32)
+                br = FusedBranch(p(x16), p(o16), p(r16) if with_resid else None, p(sp16), p(sets[axis][adj]),
+                                 p(tw), B, M, N, K, axis, 0, 1, tile, p(x_word), p(w16), FFNO_STORE_BF16)
+                assert lib.ffno_spectral_x3(ctypes.byref(br), C, ck_f, ck_i, conj, None) == 0
+                np.testing.assert_array_equal(get16(be, o16), to_bf16(be.get(o32)))
+                np.testing.assert_array_equal(be.get(sp16), be.get(sp32))          # the saved spectrum stays fp32
+                assert np.asarray(be.get(w16)).view(np.float32)[0] == np.abs(from_bf16(get16(be, o16))).max()
+                if not adj and not with_resid:
+                    outs[axis] = get16(be, o16).copy()
+    # the paired launch gives the two single launches
+    tws = [be.twiddle(N), be.twiddle(M)]
+    oa, ob = (put16(be, np.zeros((B, M, N, C), np.uint16)) for _ in range(2))
+    xin = x16
+    ba = FusedBranch(p(xin), p(oa), None, None, p(sets[0][0]), p(tws[0]), B, M, N, K, 0, 0, 1, tile, p(x_word), None, FFNO_STORE_BF16)
+    bb = FusedBranch(p(xin), p(ob), None, None, p(sets[1][0]), p(tws[1]), B, M, N, K, 1, 0, 1, tile, p(x_word), None, FFNO_STORE_BF16)
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(ba), ctypes.byref(bb), C, 0, 1, 0, 3, None) == 0
+    np.testing.assert_array_equal(get16(be, oa), outs[0])
+    np.testing.assert_array_equal(get16(be, ob), outs[1])
+    # mixed formats in one pair, > 16 modes, bf16x3 planes: refused
+    bb.storage = 0
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(ba), ctypes.byref(bb), C, 0, 1, 0, 3, None) == -1
+    ba.planes_format = 0
+    assert lib.ffno_spectral_x3(ctypes.byref(ba), C, 0, 1, 0, None) == -2
+
+
+# ---- lift / head ---------------------------------------------------------------------------------------------------------------
+def test_lift_and_head_twins(be):
+    lib, p = be.lib, be.ptr
+    P, Cin, C, O = 300, 3, 64, 1
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((P, Cin)).astype(np.float32)
+    W, b = rs.standard_normal((C, Cin)).astype(np.float32), rs.standard_normal(C).astype(np.float32)
+    o32, o16 = be.empty((P, C)), put16(be, np.zeros((P, C), np.uint16))
+    w16 = be.zeros(1, np.uint32)
+    assert lib.ffno_lift_fwd(p(be.put(x)), p(be.put(W)), p(be.put(b)), p(o32), P, Cin, C, None, None, None) == 0
+    assert lib.ffno_lift_fwd_bf16(p(be.put(x)), p(be.put(W)), p(be.put(b)), p(o16), P, Cin, C, None, p(w16), None) == 0
+    np.testing.assert_array_equal(get16(be, o16), to_bf16(be.get(o32)))
+    assert np.asarray(be.get(w16)).view(np.float32)[0] == np.abs(from_bf16(get16(be, o16))).max()
+    assert lib.ffno_lift_fwd_bf16(p(be.put(x)), p(be.put(W[:32])), p(be.put(b[:32])), p(o16), P, Cin, 32, None, None, None) == -2
+    # head forward / backward on a bf16 activation
+    a_h, a = bf16_data(rs, (P, C))
+    fold = rs.standard_normal(O * (C + 1)).astype(np.float32)
+    y32, y16 = be.empty(P * O), be.empty(P * O)
+    assert lib.ffno_head_fwd(p(be.put(a)), p(be.put(fold)), p(y32), P, C, O, 0, None, None) == 0
+    assert lib.ffno_head_fwd_bf16(p(put16(be, a_h)), p(be.put(fold)), p(y16), P, C, O, 0, None, None) == 0
+    np.testing.assert_array_equal(be.get(y16), be.get(y32))
+    gy = rs.standard_normal(P * O).astype(np.float32)
+    nsplit = 2
+    g32, g16 = be.empty((P, C)), put16(be, np.zeros((P, C), np.uint16))
+    part, red32, red16 = be.zeros(nsplit * O * (C + 1)), be.zeros(O * (C + 1)), be.zeros(O * (C + 1))
+    assert lib.ffno_head_bwd(p(be.put(a)), p(be.put(gy)), p(be.put(fold)), p(g32), p(part), p(red32), P, C, O, nsplit, None, None, None) == 0
+    assert lib.ffno_head_bwd_bf16(p(put16(be, a_h)), p(be.put(gy)), p(be.put(fold)), p(g16), p(part), p(red16), P, C, O, nsplit, None,
+                                  None, None) == 0
+    np.testing.assert_array_equal(get16(be, g16), to_bf16(be.get(g32)))
+    np.testing.assert_array_equal(be.get(red16), be.get(red32))
+    # lift backward on a bf16 gradient
+    ns = 3
+    lp = be.zeros(ns * C * (Cin + 1))
+    dW32, db32, dW16, db16 = be.zeros((C, Cin)), be.zeros(C), be.zeros((C, Cin)), be.zeros(C)
+    assert lib.ffno_lift_bwd(p(be.put(x)), p(be.put(a)), p(lp), p(dW32), p(db32), P, Cin, C, ns, 0, None, None) == 0
+    assert lib.ffno_lift_bwd_bf16(p(be.put(x)), p(put16(be, a_h)), p(lp), p(dW16), p(db16), P, Cin, C, ns, 0, None, None) == 0
+    np.testing.assert_array_equal(be.get(dW16), be.get(dW32))
+    np.testing.assert_array_equal(be.get(db16), be.get(db32))
+
+
+# ---- the block on bf16 storage ----------------------------------------------------------------------------------------------------
+KW = dict(modes=4, width=64, input_dim=3, n_layers=4, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+
+
+def _block(kw, sd_np, device, storage):
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()}, strict=True)
+    blk = blk.to(device)
+    eng = blk.engine()
+    eng.use_x3, eng.x3_min_lines = True, 1
+    eng.storage = storage
+    return blk, eng
+
+
+# What bf16 STORAGE costs against the fp32 oracle (4 layers, O(1) data): every stored activation carries a relative rounding
+# error of 2^-9 = 2e-3; observed forward 2e-3, gradients 1e-2 (they pass through twice as many stored tensors).
+BF16_FWD_TOL, BF16_GRAD_TOL = 1e-2, 5e-2
+
+
+def test_block_on_bf16_storage_against_the_oracle(host_device):
+    seed, B, M, N = 2, 2, 8, 8
+    sd_np = gu.make_block_state_dict(KW, seed)
+    x_np, t_np = gu.make_block_io(KW, seed, B, M, N)
+    ref_out, _, ref_grads = ou.oracle_block_run(KW, 0, B, M, N, io=(x_np, t_np), sd_np=sd_np)
+    ref = ref_out["forecast"].detach().numpy()
+    res = {}
+    for storage in ("fp32", "bf16"):
+        blk, eng = _block(KW, sd_np, host_device, storage)
+        pred = blk(torch.from_numpy(x_np).to(host_device))["forecast"]
+        orc.lp_rel_loss(pred, torch.from_numpy(t_np).to(host_device)).backward()
+        named = dict(blk.named_parameters())
+        res[storage] = (pred.detach().cpu().numpy(), {n: named[n].grad.cpu().numpy() for n in eng.param_names})
+        ws = eng._workspace(B, (M, N), True)
+        assert ws.X.dtype == (torch.bfloat16 if storage == "bf16" else torch.float32)
+        assert ws.SXall[0].dtype == torch.float32            # spectra stay fp32 either way
+    e32, e16 = rel_l2(res["fp32"][0], ref), rel_l2(res["bf16"][0], ref)
+    print(f"forward rel-L2 vs oracle: fp32 storage {e32:.2e}, bf16 storage {e16:.2e}")
+    assert e32 < 1e-5 and 1e-5 < e16 < BF16_FWD_TOL
+    worst = 0.0
+    for n, g in res["bf16"][1].items():
+        r = np.asarray(ref_grads[n])
+        assert np.all(np.isfinite(g))
+        worst = max(worst, rel_l2(g, r))
+    print(f"worst parameter-gradient rel-L2 on bf16 storage vs oracle: {worst:.2e}")
+    assert worst < BF16_GRAD_TOL
+
+
+def test_bf16_storage_is_refused_outside_its_path(host_device):
+    kw = dict(KW, use_fork=True)
+    sd_np = gu.make_block_state_dict(kw, 1)
+    blk, eng = _block(kw, sd_np, host_device, "bf16")
+    x_np, _ = gu.make_block_io(kw, 1, 1, 8, 8)
+    with pytest.raises(NotImplementedError, match="storage='bf16'"):
+        blk(torch.from_numpy(x_np).to(host_device))
+    eng.storage = "fp8"
+    with pytest.raises(ValueError, match="storage"):
+        blk(torch.from_numpy(x_np).to(host_device))
+
+
+def test_training_steps_on_bf16_storage_follow_the_fp32_run(host_device):
+    """Five AdamW steps of FFNOTrainer: the loss of the bf16-storage run stays within 2 % of the fp32-storage run, step by step
+    (same seed, same data; masters, moments and the optimiser are fp32 in both)."""
+    from fourierflow_amd.trainer import FFNOTrainer
+    seed, B, M, N = 7, 2, 8, 8
+    sd_np = gu.make_block_state_dict(KW, seed)
+    x_np, t_np = gu.make_block_io(KW, seed, B, M, N)
+    losses = {}
+    for storage in ("fp32", "bf16"):
+        blk, eng = _block(KW, sd_np, host_device, storage)
+        tr = FFNOTrainer(blk, lr=1e-3, weight_decay=1e-4, num_warmup_steps=0, num_training_steps=100)
+        x, t = torch.from_numpy(x_np).to(host_device), torch.from_numpy(t_np).to(host_device)
+        losses[storage] = [float(tr.train_step(x, t).item()) for _ in range(5)]
+    print(losses)
+    a, b = np.array(losses["fp32"]), np.array(losses["bf16"])
+    assert a[-1] < a[0] and b[-1] < b[0]
+    assert np.max(np.abs(a - b) / a) < 2e-2
