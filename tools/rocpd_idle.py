@@ -27,25 +27,27 @@ def union_busy(s):
     return busy
 
 
+def dominant(s):
+    tot = {}
+    for st, en, name in s:
+        tot[name] = tot.get(name, 0) + en - st
+    return max(tot, key=tot.get)
+
+
 groups = {}
 for s in steps:
-    groups.setdefault(len(s), []).append(s)
+    groups.setdefault((len(s), dominant(s)), []).append(s)
 print(f"{len(steps)} optimiser steps in the trace; groups of steps with the same number of launches (>= 3 steps):\n")
 print("| launches per step | steps | dominant kernel | span ms | busy ms | idle ms | idle % | gaps > 1 us | largest gap us |")
 print("|---|---|---|---|---|---|---|---|---|")
 med = statistics.median
-for n, ss in sorted(groups.items(), key=lambda kv: -len(kv[1])):
+for (n, dom), ss in sorted(groups.items(), key=lambda kv: -len(kv[1])):
     if len(ss) < 3:
         continue
     ss = ss[1:]                       # the first step of a group follows a host-side pause (setup, synchronisation)
     span = [s[-1][1] - s[0][0] for s in ss]
     busy = [union_busy(s) for s in ss]
     gaps = [[b[0] - a[1] for a, b in zip(s, s[1:])] for s in ss]
-    tot = {}
-    for s in ss:
-        for st, en, name in s:
-            tot[name] = tot.get(name, 0) + en - st
-    dom = max(tot, key=tot.get)
     dom = subprocess.run(["c++filt", dom.replace(".kd", "")], capture_output=True, text=True).stdout.strip().replace("void ", "").split("(")[0][:60]
     idle = [a - b for a, b in zip(span, busy)]
     print(f"| {n} | {len(ss)} | {dom} | {med(span)/1e6:.3f} | {med(busy)/1e6:.3f} | {med(idle)/1e6:.3f} | {100*med(idle)/med(span):.1f} | "
