@@ -23,7 +23,7 @@ from backend_util import rel_l2
 MARKOV24 = dict(modes=16, width=64, input_dim=3, n_layers=24, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
 
 
-def _run_hip(kw, seed, B, M, N, split=None):
+def _run_hip(kw, seed, B, M, N, split=None, storage="fp32"):
     from fourierflow_amd.modules import FNOFactorized2DBlock
     from fourierflow_amd.trainer import FFNOTrainer
     blk = FNOFactorized2DBlock(**kw)
@@ -35,6 +35,7 @@ def _run_hip(kw, seed, B, M, N, split=None):
     eng = tr.engine
     if split is not None:
         eng.ff_split = eng.x3_mix_split = split
+    eng.storage = storage
     pred = eng.forward(blk.prepare_input(x), True)
     loss, gy = tr.loss_and_grad(pred, t)
     loss = float(loss.item())
@@ -84,3 +85,25 @@ def test_markov24_train_step_is_deterministic_and_replicated():
     b = _run_hip(kw, seed, B, M, N)
     assert torch.equal(a[5], b[5])
     assert a[1] == b[1]
+
+
+@pytest.mark.gpu
+def test_markov24_bench_geometry_on_bf16_storage():
+    """The bf16 storage twins (include/ffno.h "Storage formats") at the benchmarked geometry: what the format costs against the
+    fp32 oracle over 24 layers -- forward and every parameter gradient inside the stated band of a bf16-activation run --
+    and that the pass is deterministic.  (Kernel by kernel the twins are exact: tests/test_storage_bf16.py.)"""
+    kw, seed, B, M, N = MARKOV24, 2024, 32, 64, 64
+    pred, loss, grads, masks, io, gflat = _run_hip(kw, seed, B, M, N, storage="bf16")
+    ref_out, ref_loss, ref_grads = ou.oracle_block_run(kw, seed, B, M, N, io=io)
+    e_fwd = rel_l2(pred, ref_out["forecast"].detach().numpy())
+    errs = {n: rel_l2(g, np.asarray(ref_grads[n])) for n, g in grads.items()}
+    worst = max(errs, key=errs.get)
+    med = float(np.median(list(errs.values())))
+    print(f"[bench-geometry bf16 storage] forward rel-L2 {e_fwd:.2e}, |loss diff| {abs(loss - ref_loss.item()):.2e}, "
+          f"gradients: median {med:.2e}, worst {errs[worst]:.2e} ({worst})")
+    assert 1e-5 < e_fwd < 1e-2            # (not the parity path: the rounding of 24 stored residual streams is visible)
+    assert abs(loss - ref_loss.item()) < 1e-2
+    assert all(np.all(np.isfinite(g)) for g in grads.values())
+    assert med < 2e-2 and errs[worst] < 1.5e-1
+    again = _run_hip(kw, seed, B, M, N, storage="bf16")
+    assert torch.equal(gflat, again[5]) and loss == again[1]
