@@ -1423,12 +1423,300 @@ __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Ar
     spectral_x3c32_body<MIXH2>(x3_pick_args(a, b, second), idx);
 }
 
+// ---- the latency variant: FOUR lines per workgroup, two waves per line (rollout at batch 1: 128 lines per launch) --------------
+// With few workgroups a launch is one dependent chain per workgroup -- line load, DFT, barrier, per-mode mix against a weight
+// stream from L2, barrier, inverse DFT, store -- and nothing overlaps it (profiles/r02_x3_phase_timing.md, 8-line tiles at batch
+// 1: 5.8 + 7.6 + 6.4 us).  Same operator and the same products per output element as spectral_x3_body (bit-identical results);
+// the chain is cut three ways: twice as many workgroups (4-line tiles); every line gets TWO waves -- wave (line, t) loads,
+// transforms and stores column tile t of its line (the even or the odd channels: half of the operand splits and MFMAs of phases
+// 1 and 3); and the ring of weight fragments holds a WHOLE mode (16 fragments in flight per wave instead of 8, refilled with the
+// wave's next mode as they are consumed), which halves the L2 round trips the mix waits for.  256 registers per wave.
+template <bool MIXH2>
+__device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
+    using F = X3Cfg;
+    constexpr int C = F::C, RS = F::RS, LSF = F::LSF, NL = 4, NWS = 8;
+    __shared__ __attribute__((aligned(16))) float XS[NL * F::LSF];
+    __shared__ float rfold[NWS];
+    FFNO_DYN_SMEM(smem);
+    float* tws = reinterpret_cast<float*>(smem);
+
+    const float* __restrict__ in = A.in;
+    const int R = A.R, L = A.L, K = A.K;
+    const LineMap lm = A.lm;
+    const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
+    const float rrs = 1.f / rs;
+    float omax = 0.f;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int lw = wave >> 1, t = wave & 1;          // line inside the tile, column tile (channel parity) of this wave
+    const int line0 = bidx * NL + lw;
+    const bool live = line0 < R;
+    const long es = lm.elem_stride;
+    const unsigned esb = (unsigned)(es * 4);
+    const unsigned lo = (unsigned)((lm.base(min(line0, R - 1)) + 2 * j + t) * 4);      // this lane's channel 2 j + t
+
+    // ---------------- phase 1: column tile t of the truncated forward DFT of the wave's line ----------------
+    {
+        const int kk = j, k = kk >> 1, ri = kk & 1;
+        const bool rowok = kk < 2 * K;
+        const float ck = (A.fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int tbase = ri ? L : 0;
+        const int km = rowok ? k : 0;
+        float raw[4][8];
+        auto load_rows = [&](int chunk, int u) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
+                raw[u][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (lo + (unsigned)n * esb));
+            }
+        };
+        Bf3 Ff[4];
+        const int k8 = (km * 8) % L;
+        auto build_F = [&](int chunk) {
+            int idx = (km * (64 * chunk + 8 * half)) % L;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float f[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int n = 16 * (4 * chunk + u) + 8 * half + e;
+                    f[e] = n < L ? amul * tws[tbase + idx] : 0.f;
+                    idx += km;
+                    if (idx >= L) idx -= L;
+                }
+                idx += k8;
+                if (idx >= L) idx -= L;
+                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+            }
+        };
+        const int nchunks = (L + 63) >> 6;
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u);
+        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+        __syncthreads();
+        f32x16 acc = zero16();
+        FFNO_NOUNROLL
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            build_F(chunk);
+            const bool more = chunk + 1 < nchunks;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                const Bf3 b = split3_8(raw[u][0], raw[u][1], raw[u][2], raw[u][3], raw[u][4], raw[u][5], raw[u][6], raw[u][7]);
+                if (more) load_rows(chunk + 1, u);
+                acc = mfma_x3(Ff[u], b, acc);
+            }
+        }
+        float* xs = XS + lw * LSF + 2 * j + t;
+        FFNO_UNROLL
+        for (int r = 0; r < 16; ++r) {
+            const int row = drow(r, half);
+            if (row < 2 * K) {
+                xs[row * RS] = acc[r] * rs;
+                if (A.spec_save && live) A.spec_save[(((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + 2 * j + t] = acc[r];
+            }
+        }
+    }
+    // weight fragments: a ring over ALL this wave's modes (the slots a mode's last products free are refilled with the first
+    // fragments of the wave's next mode); with fp16x2 packs the ring holds a whole mode
+    constexpr int RING = MIXH2 ? F::MODE_FRAGS : 8;
+    using MixFrag = typename std::conditional<MIXH2, Hf2, Bf3>::type;
+    constexpr int MNP = MIXH2 ? 2 : 3;
+    auto load_w = [&](const u32x4* __restrict__ wk, int f) {
+        MixFrag w;
+        if constexpr (MIXH2) {
+            w.hi = wk[(f * 2 + 0) * 64 + lane];
+            w.lo = wk[(f * 2 + 1) * 64 + lane];
+        } else {
+            w = x3_load_frag(wk, f, lane);
+        }
+        return w;
+    };
+    MixFrag ring[RING];
+    if (A.wpk && wave < K) {
+        FFNO_UNROLL
+        for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: per-mode channel mix of the four lines (8 live rows of the 32-row tile; rows 8..31 repeat them) ----
+    if (A.wpk) {
+        const float* arow = XS + ((j & (2 * NL - 1)) >> 1) * LSF + (j & 1) * RS + 8 * half;
+        for (int k = wave; k < K; k += NWS) {
+            const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * 64 * MNP;
+            const bool more = k + NWS < K;
+            const u32x4* __restrict__ wn = A.wpk + (long)(more ? k + NWS : k) * F::MODE_FRAGS * 64 * MNP;
+            MixFrag a[4];
+            FFNO_UNROLL
+            for (int st = 0; st < 4; ++st) {
+                const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st);
+                const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st + 4);
+                if constexpr (MIXH2)
+                    a[st] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                else
+                    a[st] = split3_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+            }
+            f32x16 p[4];
+            FFNO_UNROLL
+            for (int pt = 0; pt < 4; ++pt) p[pt] = zero16();
+            auto refill = [&](int f) {      // slot f % RING is free: request what will be read from it next
+                if (f + RING < F::MODE_FRAGS)
+                    ring[f % RING] = load_w(wk, f + RING);
+                else if (more)
+                    ring[f % RING] = load_w(wn, f + RING - F::MODE_FRAGS);
+            };
+            if constexpr (MIXH2) {
+                FFNO_UNROLL
+                for (int pt = 0; pt < 4; ++pt) {
+                    f32x16 pc = zero16();
+                    FFNO_UNROLL
+                    for (int st = 0; st < 4; ++st) {
+                        const int f = pt * 4 + st;
+                        const Hf2 b = ring[f % RING];
+                        refill(f);
+                        mfma_h2(a[st], b, p[pt], pc);
+                    }
+                    SplitHf2::fold(p[pt], pc);
+                }
+            } else {
+                FFNO_UNROLL
+                for (int st = 0; st < 4; ++st) {
+                    FFNO_UNROLL
+                    for (int pt = 0; pt < 4; ++pt) {
+                        const int f = st * 4 + pt;
+                        const Bf3 b = ring[f % RING];
+                        refill(f);
+                        p[pt] = mfma_x3(a[st], b, p[pt]);
+                    }
+                }
+            }
+            // D rows 2q, 2q+1 of this lane = (re, im) of line (q & 1) + 2 half  (accumulator registers 0..3 hold the 8 live rows)
+            FFNO_UNROLL
+            for (int q = 0; q < NL / 2; ++q) {
+                const int line = (q & 1) + 2 * half;
+                float yr[2], yi[2];
+                FFNO_UNROLL
+                for (int tt = 0; tt < 2; ++tt) {
+                    const float p1r = p[tt][2 * q], p1i = p[tt][2 * q + 1];
+                    const float p2r = p[2 + tt][2 * q], p2i = p[2 + tt][2 * q + 1];
+                    if (A.conj_t == 0) {
+                        yr[tt] = p1r - p2i;
+                        yi[tt] = p2r + p1i;
+                    } else {
+                        yr[tt] = p1r + p2i;
+                        yi[tt] = p1i - p2r;
+                    }
+                }
+                float* dst = XS + line * LSF + 2 * k * RS + 2 * j;
+                *reinterpret_cast<float2*>(dst) = make_float2(yr[0], yr[1]);
+                *reinterpret_cast<float2*>(dst + RS) = make_float2(yi[0], yi[1]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 3: column tile t of the zero-padded inverse DFT of the wave's line ----------------
+    if (live) {
+        const int RTtot = (L + 31) >> 5;
+        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const unsigned lob = lo + hoff;
+        const float* xs = XS + lw * LSF + 2 * j + t;
+        const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
+                                     : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
+        // B operands: the line's spectrum, column tile t, split: slot e of k-step st <-> row kk = 16 st + 8 half + e
+        Bf3 y[2];
+        FFNO_UNROLL
+        for (int st = 0; st < 2; ++st) {
+            float v[8];
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int kk = 16 * st + 8 * half + e;
+                v[e] = kk < 2 * K ? xs[kk * RS] : 0.f;
+            }
+            y[st] = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+        FFNO_NOUNROLL
+        for (int rt = 0; rt < RTtot; ++rt) {
+            float pre[16];
+            if (addsrc) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) {
+                    const int nu = min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
+                    pre[r] = *reinterpret_cast<const float*>(addsrc + lo + (unsigned)nu * esb);
+                }
+            }
+            // inverse-DFT matrix fragments of this 32-row output tile: row n, slot e of k-step st <-> kk = (mode, part)
+            const int n = 32 * rt + j;
+            f32x16 o = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                float g[8];
+                const int nm = n < L ? n : 0;
+                int idx = (nm * (8 * st + 4 * half)) % L;
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 16 * st + 8 * half + e, tm = kk >> 1, part = kk & 1;
+                    const float ck = (A.inv_ck && !(tm == 0 || 2 * tm == L)) ? 2.f : 1.f;
+                    g[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tws[(part ? L : 0) + idx] : 0.f;
+                    if (part) {
+                        idx += nm;
+                        if (idx >= L) idx -= L;
+                    }
+                }
+                o = mfma_x3(split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]), y[st], o);
+            }
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
+                if (nu + 4 * half < L) {
+                    const long uo = (long)nu * es * 4;
+                    float ov = o[r] * rrs;
+                    if (addsrc) ov += pre[r];
+                    if (A.accumulate && A.resid) ov += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(A.out) + uo + lob);
+                    *reinterpret_cast<float*>(reinterpret_cast<char*>(A.out) + uo + lob) = ov;
+                    omax = fmaxf(omax, fabsf(ov));
+                }
+            }
+        }
+    }
+    if (A.out_amax) range_fold(omax, rfold, NWS, A.out_amax);
+}
+
+template <bool MIXH2>
+__global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_kernel(X3Args a) {
+    spectral_x3s_body<MIXH2>(a, blockIdx.x);
+}
+template <bool MIXH2>
+__global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
+    const int w = blockIdx.x, nmin = min(n0, n1);
+    bool second;
+    int idx;
+    if (w < 2 * nmin) {
+        second = w & 1;
+        idx = w >> 1;
+    } else {
+        second = n1 > n0;
+        idx = w - nmin;
+    }
+    spectral_x3s_body<MIXH2>(x3_pick_args(a, b, second), idx);
+}
+
 // 8-line tiles while the launch still fits one round of workgroups (one per CU of the device): more CUs busy, same weight
 // stream per workgroup; a branch descriptor may force either (tile_lines = 8 / 16; results are bit-identical)
 static inline bool x3_small_tiles(int Ra, int Rb, int tile_lines) {
     if (tile_lines == 8) return true;
     if (tile_lines == 16) return false;
     return (Ra + 7) / 8 + (Rb + 7) / 8 <= device_cu_count();
+}
+// ... and 4-line tiles with two waves per line (spectral_x3s_body) while THOSE fit one round of workgroups: such a launch is a
+// latency chain per workgroup, not a bandwidth problem (rollout at batch 1: 32 workgroups per axis; measured on MI355X, markov/24
+// forward at batch 1 / 2 / 4 / 8: 0.70 / 0.77 / 0.89 / 1.08 ms against 0.76 / 0.82 / 0.93 / 1.11 on 8-line tiles).  fp32 storage.
+static inline bool x3_latency_tiles(int Ra, int Rb, int tile_lines, int storage) {
+    if (storage != FFNO_STORE_F32) return false;
+    if (tile_lines == FFNO_X3_TILE_LATENCY) return true;
+    if (tile_lines != 0) return false;
+    return (Ra + 3) / 4 + (Rb + 3) / 4 <= device_cu_count();
 }
 
 static inline bool x3_many_modes(int K) { return 2 * K > X3Cfg::KK; }
@@ -1481,8 +1769,9 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     if (b->K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_x3_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
     if (b->planes_format != FFNO_PLANES_BF16X3 && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EINVAL;
-    if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16) return FFNO_EINVAL;
+    if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16 && b->tile_lines != FFNO_X3_TILE_LATENCY) return FFNO_EINVAL;
     if (b->storage != FFNO_STORE_F32 && b->storage != FFNO_STORE_BF16) return FFNO_EINVAL;
+    if (b->storage == FFNO_STORE_BF16 && b->tile_lines == FFNO_X3_TILE_LATENCY) return FFNO_EUNSUPPORTED;
     // bf16 storage twins: the K <= 16 kernel at width 64, with the fp16x2 mix (or none)
     if (b->storage == FFNO_STORE_BF16 &&
         (C != X3Cfg::C || x3_many_modes(b->K) || (b->planes && b->planes_format != FFNO_PLANES_FP16X2)))
@@ -1524,6 +1813,14 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
             if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
         }
 #undef X3K_LAUNCH
+        return x3_status();
+    }
+    if (x3_latency_tiles(a.R, 0, br->tile_lines, br->storage)) {
+        const dim3 grid((a.R + 3) / 4);
+        if (h2)
+            FFNO_LAUNCH((spectral_x3s_kernel<true>), grid, dim3(512), smem, st, a);
+        else
+            FFNO_LAUNCH((spectral_x3s_kernel<false>), grid, dim3(512), smem, st, a);
         return x3_status();
     }
     if (br->storage == FFNO_STORE_BF16) {
@@ -1597,6 +1894,14 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         if ((interleave & 2) && square && ba->B % 8 == 0 && ba->M % NL == 0) return 2 | ((ba->M / NL) << 8);
         return (interleave & 1) ? 1 : 0;
     };
+    if (x3_latency_tiles(a.R, b.R, ba->tile_lines, ba->storage)) {
+        const int n0 = (a.R + 3) / 4, n1 = (b.R + 3) / 4;
+        if (h2)
+            FFNO_LAUNCH((spectral_x3s_pair_kernel<true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else
+            FFNO_LAUNCH((spectral_x3s_pair_kernel<false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        return x3_status();
+    }
     if (ba->storage == FFNO_STORE_BF16) {
         if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
             const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);

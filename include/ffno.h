@@ -179,8 +179,10 @@ typedef struct ffno_fused_branch {
     int32_t K, axis, accumulate;
     /* ffno_spectral_x3* only (the fp32 kernels ignore them; zero = the previous behaviour): */
     int32_t planes_format;  /* FFNO_PLANES_BF16X3 / FFNO_PLANES_FP16X2: how ffno_spectral_x3_pack wrote `planes` */
-    int32_t tile_lines;     /* lines per workgroup of the fused x3 kernel: 0 = the library chooses (8 while the launch fits one
-                               round of workgroups -- one per CU -- else 16), or 8 / 16; results are bit-identical */
+    int32_t tile_lines;     /* lines per workgroup of the fused x3 kernel: 0 = the library chooses (16; 8 while the launch fits one
+                               round of workgroups -- one per CU; 4 lines with two waves per line, FFNO_X3_TILE_LATENCY, while those fit
+                               one round of workgroups: rollout at batch 1), or 8 / 16 / FFNO_X3_TILE_LATENCY; results are
+                               bit-identical */
     const uint32_t* in_amax; /* range word of `in` (FP16X2 planes: the spectrum tile is held scaled by the power of two derived
                                 from it -- |X| <= 2 sqrt(L) max|in| goes to 2^15 -- and the outputs are divided again); NULL = 1 */
     uint32_t* out_amax;      /* optional: receives max |out| of what this branch stores (the fused kernels of both families and
@@ -190,6 +192,7 @@ typedef struct ffno_fused_branch {
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
+#define FFNO_X3_TILE_LATENCY 1
 int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                              int apply_ck_inv, int conj_transpose, void* stream);
 /* ---------------------------------------------------------------------------------------------

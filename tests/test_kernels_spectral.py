@@ -562,6 +562,56 @@ def test_spectral_x3_fused_many_modes(be, B, M, N, K, axis, direction, fmt):
     assert rel_l2(be.get(out), 2 * ref + resid) < TOL
 
 
+@pytest.mark.parametrize("B,M,N,K", [(1, 8, 12, 3), (1, 64, 64, 16), (2, 6, 10, 5), (1, 3, 72, 16), (3, 5, 7, 2), (1, 13, 9, 4)])
+@pytest.mark.parametrize("direction,fmt", [("fwd", 1), ("adj", 1), ("fwd", 0), ("lowpass", 1)])
+def test_spectral_x3_latency_tiles_are_bit_identical(be, B, M, N, K, direction, fmt):
+    """FFNO_X3_TILE_LATENCY (4-line tiles, two waves per line, a whole mode of weight fragments in flight: the rollout's batch-1
+    launches) against the 8-line kernel: the same products in the same order per output element -- outputs, saved spectra and
+    range words are bit-identical; single launches of both axes (with the accumulate + residual epilogue) and the paired launch."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and (B, M, N, K) in ((1, 64, 64, 16), (2, 6, 10, 5)) and (direction, fmt) != ("fwd", 1):
+        pytest.skip("emulator time budget (the GPU run covers all)")
+    C = 64
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + 10 * M + 100 * N + K)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    resid = rs.standard_normal(x.shape).astype(np.float32)
+    dx, dres = be.put(x), be.put(resid)
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    word_in = be.zeros(1, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(word_in), None) == 0
+    keep, br = [], {}
+    for axis in (0, 1):
+        L = N if axis == 0 else M
+        if K > L // 2 + 1:
+            pytest.skip("modes exceed axis")
+        R = B * M if axis == 0 else B * N
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        pk_f, pk_a, k_ = _x3_pack(be, w, K, C, fmt)
+        planes = None if direction == "lowpass" else (pk_a if direction == "adj" else pk_f)
+        tw = be.twiddle(L)
+        keep += [k_, pk_f, pk_a, tw]
+        got = {}
+        for tile in (8, 1):
+            out, spec, word = be.empty(x.shape), be.empty((K, R, 2, C)), be.zeros(1, np.uint32)
+            d = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, tile, p(word_in), p(word))
+            assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
+            first = be.get(out).copy()
+            d = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1, fmt, tile, p(word_in), None)
+            assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
+            got[tile] = (first, be.get(spec).copy(), np.asarray(be.get(word)).copy(), be.get(out).copy())
+        assert not np.isnan(got[1][0]).any()
+        for a, b in zip(got[8], got[1]):
+            np.testing.assert_array_equal(a, b)
+        br[axis] = (planes, tw, got[1][0])
+    oa, ob = be.empty(x.shape), be.empty(x.shape)
+    da = FusedBranch(p(dx), p(oa), None, None, p(br[0][0]), p(br[0][1]), B, M, N, K, 0, 0, fmt, 1, p(word_in), None)
+    db = FusedBranch(p(dx), p(ob), None, None, p(br[1][0]), p(br[1][1]), B, M, N, K, 1, 0, fmt, 1, p(word_in), None)
+    assert lib.ffno_spectral_x3_pair(ctypes.byref(da), ctypes.byref(db), C, fwd_ck, inv_ck, conj, 3, None) == 0
+    np.testing.assert_array_equal(be.get(oa), br[0][2])
+    np.testing.assert_array_equal(be.get(ob), br[1][2])
+
+
 @pytest.mark.parametrize("B,M,N,Ka,Kb", [(1, 40, 48, 20, 18), (1, 70, 36, 12, 34), (2, 256, 256, 32, 32), (1, 130, 136, 64, 40)])
 @pytest.mark.parametrize("direction", ["fwd", "adj"])
 def test_spectral_x3_fused_many_modes_pair_equals_single_branches(be, B, M, N, Ka, Kb, direction):

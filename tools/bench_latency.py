@@ -1,0 +1,44 @@
+"""Forward latency of markov/24 at small batches, per tile choice of the fused split spectral kernel (8-line tiles, the
+4-line latency tiles, the library's own choice): the rollout's metric.  usage: python tools/bench_latency.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fourierflow_amd.modules import FNOFactorized2DBlock  # noqa: E402
+from fourierflow_amd.trainer import FFNOTrainer  # noqa: E402
+
+kw = dict(modes=16, width=64, input_dim=3, n_layers=24, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+torch.manual_seed(0)
+blk = FNOFactorized2DBlock(**kw).cuda()
+tr = FFNOTrainer(blk)      # (binds the flat parameter buffer; predict() = engine.forward without saving)
+eng = tr.engine
+for B in (1, 2, 4, 8):
+    x = torch.randn(B, 64, 64, 3, device="cuda")
+    for tile in (8, 1, 0):
+        eng.x3_tile_lines = tile
+        for _ in range(5):
+            tr.predict(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            tr.predict(x)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 100
+        print(f"batch {B} tile_lines {tile}: {1e3 * dt:.3f} ms / forward", flush=True)
+
+# the reference API path: nn.Module.__call__ under no_grad (host overhead of the module wrapper included)
+eng.x3_tile_lines = 0
+with torch.no_grad():
+    for B in (1, 8):
+        x = torch.randn(B, 64, 64, 3, device="cuda")
+        for _ in range(5):
+            blk(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            blk(x)
+        torch.cuda.synchronize()
+        print(f"batch {B} through FNOFactorized2DBlock.__call__: {1e3 * (time.perf_counter() - t0) / 100:.3f} ms / forward", flush=True)
