@@ -202,8 +202,9 @@ int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch
  * lines.  The branch descriptor is ffno_fused_branch with `planes` pointing at PACKED weights:
  *   ffno_spectral_x3_pack: planes[k][re|im][i][o] (forward: wp, adjoint: wpt of ffno_fw_pack) -> fragment order, split;
  *   ffno_spectral_x3_pack_bytes(C, K) bytes per packed set.  descs is a DEVICE array, one launch for all sets.
- * Supported by the fused kernel: C = 64, K <= 16, L <= 2048 (ffno_spectral_x3_supported); packs exist for K <= 32 (the
- * staged variant below); the fp32-MFMA kernels above cover the rest.
+ * Supported by the fused kernels (ffno_spectral_x3_supported, L <= 2048): C = 64 with K <= 16 (16- / 8-line tiles, or the 4-line
+ * latency tiles for small launches), C = 64 with 17..64 modes (4-line tiles), C = 32 with K <= 16 (16 lines, two side by side per
+ * wave); the staged variant below takes C = 64, K <= 32; the fp32-MFMA kernels above cover the rest.
  * interleave (pair, equal workgroup counts): bit 0 = even workgroups run branch a, odd ones branch b; bit 1 = image-local map
  * where the shapes allow it (both branches are the two axes of the same square images, batch a multiple of 8, whole tiles per
  * image): the workgroups that read one image run on one XCD, so the second branch finds the image in that XCD's L2.
@@ -212,7 +213,7 @@ typedef struct ffno_x3pack_desc {
     const float* planes; /* [K][2][C][C] */
     void* dst;           /* ffno_spectral_x3_pack_bytes(C, K) bytes, 16-B aligned */
     int32_t K;
-    int32_t format;      /* FFNO_PLANES_BF16X3, or FFNO_PLANES_FP16X2: the per-mode channel mix of the fused kernel (K <= 16) then
+    int32_t format;      /* FFNO_PLANES_BF16X3, or FFNO_PLANES_FP16X2: the per-mode channel mix of the fused kernels then
                             runs on three fp16 MFMAs per product block instead of six bf16 ones (ffno_ffh_* has the number
                             format; the DFT phases keep the bf16 split).  The staged kernels take BF16X3 packs only. */
 } ffno_x3pack_desc;
