@@ -511,7 +511,10 @@ def main():
             mpeak = kernels[members[0]]["mfma_peak_tflops"]
             bound = "hbm" if fl / by < mpeak * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"
             if bound == "hbm":
-                ach, peak, unit = by / us * 1e-3, HBM_PEAK_GBS, "GB/s"
+                # the contract's figure: SURVEY 8(d)'s algorithmic bytes (a fused layer reads x and writes s once) per launch /
+                # the measured launch time; what a TRAINING launch must move on top of that (second branch image, saved
+                # spectra, residual gradient) is reported beside it as achieved_training_bytes / frac_training_bytes
+                ach, peak, unit = fo / us * 1e-3, HBM_PEAK_GBS, "GB/s"
             else:
                 ach, peak, unit = fl / us * 1e-6, mpeak, "TFLOP/s"
             tr = pmc.get(dom, {})
@@ -519,16 +522,18 @@ def main():
                             frac=round(ach / peak, 4),
                             traffic=tr.get("hbm_bytes_per_launch"), traffic_source=pmc_meta,
                             avg_launch_us=round(us, 2), share_of_step=round(share[dom] / (1e3 * elapsed / args.steps), 3),
+                            achieved_training_bytes=round(by / us * 1e-3, 2), frac_training_bytes=round(by / us * 1e-3 / HBM_PEAK_GBS, 4),
                             frac_hbm=round(by / us * 1e-3 / HBM_PEAK_GBS, 4), frac_mfma=round(fl / us * 1e-6 / mpeak, 4),
                             frac_hbm_floor_8d=round(fo / us * 1e-3 / HBM_PEAK_GBS, 4),
                             mfma_peak_tflops=mpeak, intensity_flop_per_byte=round(fl / by, 1),
                             ridge_flop_per_byte=round(mpeak * 1e12 / (HBM_PEAK_GBS * 1e9), 1),
-                            algorithmic_bytes_per_launch=int(by), bytes_floor_8d_per_launch=int(fo),
+                            algorithmic_bytes_per_launch=int(fo), training_bytes_per_launch=int(by), bytes_floor_8d_per_launch=int(fo),
                             algorithmic_flops_per_launch=int(fl),
                             byte_formula={n: work[n]["formula"] for n in members},
                             floor_formula="SURVEY 8(d): a fused A+B+C layer reads x and writes s once = 2*P*C*4 bytes",
                             event_pair_us=round(pair_us, 2),
-                            note=f"achieved = algorithmic (training) bytes or FLOPs per launch / avg_launch_us; avg_launch_us = one HIP-event "
+                            note=f"achieved = SURVEY 8(d) algorithmic bytes (2*P*C*4: read x, write s) per launch / avg_launch_us (bound = hbm: the "
+                                 f"launch moves training_bytes_per_launch, intensity below the ridge); avg_launch_us = one HIP-event "
                                  f"pair around {REPLAYS} back-to-back replays of the middle layer's launch (forward and adjoint weighted by "
                                  f"launches per step), nothing subtracted; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch from "
                                  f"profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, gfx950 x2 correction on FETCH_SIZE), "
