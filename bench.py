@@ -267,41 +267,49 @@ def time_steps(fn, steps, warmup, sync):
 
 def secondary_workloads(dev, steps=10, warmup=3):
     """The other single-GPU BASELINE configs, in the same run so the driver's line carries them (north_star: 64x64 AND 256x256
-    in the same run): torus_kochkov 256 x 256 (12 layers, 32 modes, batch 2) and the 64^3 plasticity-shaped 3-D operator."""
+    in the same run): torus_kochkov 256 x 256 (12 layers / 32 modes and the reference's own 24 layers / 64 modes, batch 2) and
+    the 64^3 plasticity-shaped 3-D operator."""
     from fourierflow_amd.modules import FNOFactorized2DBlock, FNOFactorizedMesh3D
     from fourierflow_amd.routines import StructuredMeshExperiment
     from fourierflow_amd.trainer import FFNOTrainer
     out = []
     sync = torch.cuda.synchronize
-    # -- 256 x 256, 12 layers, 32 modes, batch 2 (BASELINE.json configs[3]) --
-    kw = dict(MARKOV24, n_layers=12, modes=32, input_dim=5)
-    torch.manual_seed(0)
-    blk = FNOFactorized2DBlock(**kw).to(dev)
-    tr = FFNOTrainer(blk, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
     g = torch.Generator().manual_seed(5)
-    x, y = torch.randn(2, 256, 256, 5, generator=g).to(dev), torch.randn(2, 256, 256, 1, generator=g).to(dev)
-    probe = KernelProbe(HOT)
-    tr.engine.timer = probe
-    dt, _ = time_steps(lambda: tr.train_step(x, y), steps, warmup, sync)
-    probe.capture = True
-    tr.train_step(x, y)
-    probe.capture = False
-    sync()
-    rep = probe.replay(50)
-    tr.engine.timer = None
-    df, _ = time_steps(lambda: tr.predict(x), steps, 2, sync)
-    P, C, H, K = 2 * 256 * 256, 64, 256, 32
-    work = algorithmic_work(P, C, H, K, 2, 256, 256, 12, True)
-    spectral = {}
-    for n, us in rep.items():
-        if n.startswith("spectral"):
-            w, mpeak = work[n], matrix_peak(n, tr.engine)
-            spectral[n] = dict(us_per_layer_direction=round(us, 1), frac_hbm_training_bytes=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3),
-                               frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3), mfma_peak_tflops=round(mpeak, 1))
-    out.append(dict(workload="torus_kochkov-shaped F-FNO train step: 256x256, 12 layers, 32 modes, width 64, batch 2, fp32",
-                    value=round(1.0 / dt, 2), unit="steps/s", ms_per_step=round(1e3 * dt, 3), ms_per_forward=round(1e3 * df, 3),
-                    spectral=spectral))
-    del tr, blk
+
+    def grid256(layers, modes, label):
+        kw = dict(MARKOV24, n_layers=layers, modes=modes, input_dim=5)
+        torch.manual_seed(0)
+        blk = FNOFactorized2DBlock(**kw).to(dev)
+        tr = FFNOTrainer(blk, lr=2.5e-3, weight_decay=1e-4, num_warmup_steps=500, num_training_steps=100000)
+        x, y = torch.randn(2, 256, 256, 5, generator=g).to(dev), torch.randn(2, 256, 256, 1, generator=g).to(dev)
+        probe = KernelProbe(HOT)
+        tr.engine.timer = probe
+        dt, _ = time_steps(lambda: tr.train_step(x, y), steps, warmup, sync)
+        probe.capture = True
+        tr.train_step(x, y)
+        probe.capture = False
+        sync()
+        rep = probe.replay(50)
+        tr.engine.timer = None
+        df, _ = time_steps(lambda: tr.predict(x), steps, 2, sync)
+        P, C, H = 2 * 256 * 256, 64, 256
+        work = algorithmic_work(P, C, H, modes, 2, 256, 256, layers, True)
+        spectral = {}
+        for n, us in rep.items():
+            if n.startswith("spectral"):
+                w, mpeak = work[n], matrix_peak(n, tr.engine)
+                spectral[n] = dict(us_per_layer_direction=round(us, 1),
+                                   frac_hbm_8d_bytes=round(w["floor"] / us * 1e-3 / HBM_PEAK_GBS, 3),
+                                   frac_hbm_training_bytes=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3),
+                                   frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3), mfma_peak_tflops=round(mpeak, 1))
+        out.append(dict(workload=label, value=round(1.0 / dt, 2), unit="steps/s", ms_per_step=round(1e3 * dt, 3),
+                        ms_per_forward=round(1e3 * df, 3), spectral=spectral))
+
+    # -- 256 x 256, 12 layers, 32 modes, batch 2 (BASELINE.json configs[3]) --
+    grid256(12, 32, "torus_kochkov-shaped F-FNO train step: 256x256, 12 layers, 32 modes, width 64, batch 2, fp32")
+    # -- the reference's own 256 x 256 experiment (experiments/torus_kochkov/ffno/grid_sizes/256/config.yaml:32-44: 24 layers, 64
+    #    modes, batch_size 2) --
+    grid256(24, 64, "torus_kochkov/ffno/grid_sizes/256 train step: 256x256, 24 layers, 64 modes, width 64, batch 2, fp32")
     # -- 64^3 -> 72^3 padded, modes 8, width 32, 12 layers, batch 1 (BASELINE.json configs[4]) --
     torch.manual_seed(0)
     model = FNOFactorizedMesh3D(**CUBE64).to(dev)
