@@ -249,6 +249,10 @@ class FFNOEngine:
         pair = None
         if len(fz) >= 2:
             pair = (fz[-2], fz[-1])
+            # a many-mode axis (4-line tiles, the whole weight set streamed per tile) does not share a launch with a <= 16-mode
+            # axis: the pair kernel would drag the short axis onto 4-line tiles too (airfoil, 32 x 16 modes: 91 vs 99 steps/s)
+            if (views[pair[0]].K > 16) != (views[pair[1]].K > 16):
+                pair = None
         elif len(sg) >= 2:
             a, b = sg[-2], sg[-1]
             rt = lambda v: (2 * v.K + 31) // 32      # noqa: E731
@@ -787,8 +791,10 @@ class FFNOEngine:
         if not (self.use_x3 and self.spectral == "factorized" and self.mode != "no-fourier"):
             return False
         P4 = 4 * self.C * max(u.Bv * u.Mv * u.Nv for u in views)       # 32-bit byte offsets inside the kernel
-        return bool(v.R >= self.x3_min_lines and P4 < 2 ** 32 and lib.ffno_spectral_x3_supported(self.C, v.K, v.L)
-                    and (self.mode != "full" or self.xplanes[0][w] is not None))
+        if not (v.R >= self.x3_min_lines and P4 < 2 ** 32 and lib.ffno_spectral_x3_supported(self.C, v.K, v.L)
+                and (self.mode != "full" or self.xplanes[0][w] is not None)):
+            return False
+        return True
 
     def _use_x3(self, views, fused):
         """Per axis: the split-bf16 fused branch instead of the fp32-MFMA one (same operator, same flags)."""

@@ -109,7 +109,9 @@ def test_mesh2d_structured_mesh_routine(host_device):
 def test_mesh2d_mixed_fused_and_staged_axes(host_device, x3):
     """modes_x = 20, modes_y = 5.  On the fp32-MFMA kernels 20 modes exceed the fused tile (K <= 16 at width 64) while 5 fit:
     the engine picks the kernel per axis (staged + fused).  On the split kernels both axes are fused -- the 20-mode axis on the
-    4-line tile of spectral_x3k -- and share one paired launch.  Forward and gradients vs the oracle's autograd."""
+    4-line tile of spectral_x3k, the 5-mode axis on the 16- / 8-line tile -- as two launches: a many-mode axis does not share a
+    paired launch with a <= 16-mode one (it would drag the short axis onto 4-line tiles: the airfoil mesh ran 91 instead of 104
+    steps/s that way).  Forward and gradients vs the oracle's autograd."""
     import oracle_util as ou
     from fourierflow_amd.modules import FNOFactorizedMesh2D
     kw = dict(modes_x=20, modes_y=5, width=64, input_dim=4, n_layers=2, share_weight=False, factor=4, ff_weight_norm=True,
@@ -124,7 +126,7 @@ def test_mesh2d_mixed_fused_and_staged_axes(host_device, x3):
     out = blk(torch.from_numpy(x_np).to(host_device))
     eng = blk.engine()
     assert eng._can_fuse(eng._ws.views) == ([True, True] if x3 else [False, True])
-    assert eng._saved_x3 == (([True, True], True) if x3 else ([False, False], False))
+    assert eng._saved_x3 == (([True, True], False) if x3 else ([False, False], False))
     loss = ((out - torch.from_numpy(t_np).to(host_device)) ** 2).mean()
     loss.backward()
     ref_out, ref_loss, ref_grads = oracle_run(kw, seed, B, S, torch.float64)
