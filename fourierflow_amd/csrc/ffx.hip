@@ -977,6 +977,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
     constexpr int CPW = H / (32 * NWV);            // hidden chunks per wave
     using F = FxCfg<C, H, CPW>;
     constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV;
+    constexpr int GS = KS;                         // operand fragments per staged tile and orientation (C / 16)
     static_assert(F::NW == NWV && F::NT == NWV * 64 && CPW >= 1 && F::NT % C == 0, "wave / chunk map");
     const float fscale = range_scale(*s_amax, 1, kFfRangeTarget);       // (the host side only takes this kernel WITH range words:
     const float gscale = range_scale(*db_amax, 1, kFfRangeTarget);      //  the 2^11 hi plane needs the 2^4 bound)
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         // scheduling barrier that only LDS reads may not cross) -- left alone the scheduler puts every read right in front of
         // its use and the wave waits out each LDS round trip.
         auto frag = [&](int i) {
-            const int g = i >> 2, q = i & 3;
+            const int g = i / GS, q = i % GS;
             if (g == 0) return lds_frag_s<SplitHf2>(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * q + 16 * half);
             if (g == 1) return lds_frag_s<SplitHf2>(L + OFF_DT, F::TPLANE, (32 * (q >> 1) + j) * F::TROW + 32 * half + 16 * (q & 1));
             if (g == 2) return lds_frag_s<SplitHf2>(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * q + 16 * half);
@@ -1116,11 +1117,11 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         uint32_t bits = 0;
         FFNO_UNROLL
         for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16(), dc[ch] = zero16();
-        static_assert(KS == 4 && CTO == 2, "fragment ring: four fragments per operand");
+        static_assert(2 * CTO == KS, "fragment ring: C / 16 fragments per operand, pixel-major and channel-major alike");
         FFNO_UNROLL
         for (int st = 0; st < KS; ++st) {
             const Hf2 a = ring[st & 1];
-            ring[st & 1] = frag(0 + st + 2);
+            ring[st & 1] = frag(0 * GS + st + 2);
             FFNO_SCHED_PIN_DSREAD();
             FFNO_UNROLL
             for (int ch = 0; ch < CPW; ++ch) mfma_h2(a, W1f[ch][st], d[ch], dc[ch]);
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int q = 2 * mt + s2;
                 const Hf2 a = ring[q & 1];
-                ring[q & 1] = frag(4 + q + 2);
+                ring[q & 1] = frag(1 * GS + q + 2);
                 FFNO_SCHED_PIN_DSREAD();
                 FFNO_UNROLL
                 for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2], acc2[ch][mt]);
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         FFNO_UNROLL
         for (int st = 0; st < KS; ++st) {
             const Hf2 a = ring[st & 1];
-            ring[st & 1] = frag(8 + st + 2);
+            ring[st & 1] = frag(2 * GS + st + 2);
             FFNO_SCHED_PIN_DSREAD();
             FFNO_UNROLL
             for (int ch = 0; ch < CPW; ++ch) mma3(a, W2f[ch][st], d[ch]);
@@ -1185,8 +1186,8 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int q = 2 * mt + s2;
                 const Hf2 a = ring[q & 1];
-                if (q < 2) {
-                    ring[q & 1] = frag(12 + q + 2);
+                if (q + 2 < GS) {
+                    ring[q & 1] = frag(3 * GS + q + 2);
                     FFNO_SCHED_PIN_DSREAD();
                 }
                 FFNO_UNROLL
@@ -1458,6 +1459,9 @@ static int fx_bwd_weights_partial(const float* s, const float* db, const void* p
     if (C == CC && H == HH) {                                                                                      \
         if (merged && CC == 64 && HH == 256)                                                                       \
             FFNO_LAUNCH((ffh_wgrad_m_kernel<64, 256, 8>), dim3(nsplit), dim3(512), 0, st, s, db,                   \
+                        (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);                   \
+        else if (merged && CC == 32 && HH == 128)      /* width 32 (3-D mesh operators): four waves */              \
+            FFNO_LAUNCH((ffh_wgrad_m_kernel<32, 128, 4>), dim3(nsplit), dim3(256), 0, st, s, db,                   \
                         (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);                   \
         else                                                                                                       \
             FFNO_LAUNCH((ffx_wgrad_kernel<CC, HH, S>), dim3(nsplit), dim3(FxCfg<CC, HH>::NT), 0, st, s, db,        \
