@@ -15,6 +15,7 @@ first axis = samples) or, without it, are synthetic N(0,1) fields of the configu
 from __future__ import annotations
 
 import json
+import math
 import time
 from pathlib import Path
 from typing import Dict, Iterator, List, Optional
@@ -196,7 +197,15 @@ def train(config_path: Path, overrides: Optional[List[str]] = Argument(None), fo
             elif hasattr(routine, "current_epoch"):
                 routine.current_epoch = epoch
         if step % max(1, steps // 5) == 0 or step == steps - 1:
-            print(json.dumps(dict(step=start["global_step"] + step, epoch=epoch, train_loss=round(float(loss.item()), 6),
+            lv = float(loss.item())
+            if not math.isfinite(lv):
+                # activations, spectra and gradients are range-safe by construction (include/ffno.h "Range words"); what is left is
+                # data that is non-finite already, a diverged run, or WEIGHTS beyond the half format's range in the split-fp16
+                # packs (|W| >= 65504) -- the any-range arithmetic is one switch away
+                raise FloatingPointError(
+                    f"non-finite training loss at step {start['global_step'] + step}: check the data and the learning rate; if the "
+                    f"weights have grown past 6.5e4, run with FFNO_FF_SPLIT=bf16x3 FFNO_X3_MIX_SPLIT=bf16x3 (any fp32 range)")
+            print(json.dumps(dict(step=start["global_step"] + step, epoch=epoch, train_loss=round(lv, 6),
                                   lr=routine.trainer().current_lr())), flush=True)
     if dev.type == "cuda":
         torch.cuda.synchronize()
