@@ -220,6 +220,7 @@ class FFNOEngine:
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
         self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
+        self.weight_range_check_every = 16   # fp16x2 packs: look at max |W| every n-th rebuild of the derived operands (0 = never)
         # storage format of the activation tensors in HBM (include/ffno.h "Storage formats"): "fp32" = the parity path (the
         # reference is precision: 32); "bf16" = the bf16 storage twins of the hot kernels -- half the activation bytes, results
         # rounded to bf16 wherever a tensor is stored (a throughput variant with its own tolerance).  Available for the paired
@@ -677,6 +678,57 @@ class FFNOEngine:
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         self._k("head_fold", lib.ffno_head_fold, _p(o0.weff), _p(self.params["out.0.bias"]), _p(o1.weff),
                 _p(self.params["out.1.bias"]), _p(self.fold), self.C, HEAD_DIM, self.O, st)
+        self._check_weight_range(st)
+
+    # ---- the one operand the range words do not cover: the WEIGHTS inside the fp16x2 packs ---------------------------------
+    def _check_weight_range(self, st):
+        """Activations, spectra and gradients are brought into the half format's range per launch (range words).  Weights are
+        packed as they are: one at or above 65504 would overflow its fp16 planes.  Every ``weight_range_check_every``-th time
+        the derived operands are rebuilt, max |W| of everything that goes into an fp16x2 pack is folded on the device
+        (ffno_amax) and copied to pinned host memory asynchronously; the value is looked at the next time round -- no
+        synchronisation, the error arrives a few steps late but it arrives (the loss is NaN by then, and says why)."""
+        every = int(self.weight_range_check_every)
+        fp16_ff, fp16_mix = self._ffx() and self._h2(), bool(self._x3_fmt and any(self._x3_fmt))
+        if every <= 0 or not (fp16_ff or fp16_mix):
+            return
+        pend = self.__dict__.get("_wr_pending")
+        if pend is not None:
+            host, ev = pend
+            if ev is None or ev.query():
+                self._wr_pending = None
+                wmax = float(host.view(torch.float32)[0])
+                if not wmax < 65504.0:
+                    raise FloatingPointError(
+                        f"a weight of magnitude {wmax:.3g} does not fit the split-fp16 packs (|W| < 65504): set "
+                        f"engine.ff_split = engine.x3_mix_split = 'bf16x3' (FFNO_FF_SPLIT / FFNO_X3_MIX_SPLIT) -- any fp32 range")
+        self._wr_count = self.__dict__.get("_wr_count", 0) + 1
+        if (self._wr_count - 1) % every or self.__dict__.get("_wr_pending") is not None:
+            return
+        lib = _lib.get_lib()
+        if self.__dict__.get("_wr_word") is None or self._wr_word.device != self.device:
+            self._wr_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._wr_host = torch.zeros(1, dtype=torch.int32)
+            if self.device.type == "cuda":
+                self._wr_host = self._wr_host.pin_memory()
+        self._wr_word.zero_()
+        srcs = []
+        if fp16_ff:
+            if self.wnorm:
+                srcs.append(self.weff_flat)       # every effective linear weight, one buffer
+            else:
+                srcs += [self.params[p + "weight"] for p in self.linears if "_ff." in p and p + "weight" in self.params]
+        if fp16_mix:
+            srcs += [self.params[n] for names in self._fw_sets for n in names]
+        for t in srcs:
+            self._k("amax", lib.ffno_amax, _p(t), t.numel(), _p(self._wr_word), st)
+        ev = None
+        if self.device.type == "cuda":
+            self._wr_host.copy_(self._wr_word, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            self._wr_host.copy_(self._wr_word)
+        self._wr_pending = (self._wr_host, ev)
 
     def _ff_weights(self, l):
         fp = self.ff_prefix[l]

@@ -85,3 +85,34 @@ def test_block_with_gradient_growth_through_the_layers(host_device):
     growth = g[eng.L] / g[eng.L - 1]           # word L: the gradient handed to the lift; word L - 1: the head's
     print(f"gradient maxima per layer (head -> lift): {g[:eng.L][::-1]} -> {g[eng.L]}; growth {growth:.3g}")
     assert growth > 1e4, growth
+
+
+def test_weights_beyond_the_half_range_are_reported(host_device):
+    """The one operand the range words do not scale: a weight >= 65504 overflows its fp16 planes.  The engine folds max |W| of
+    what it packs as fp16x2 on the device and looks at it one rebuild later (no synchronisation): the run stops with a message
+    that names the any-range arithmetic; with that arithmetic the same weights are fine."""
+    seed, B, M, N = 3, 1, 8, 8
+    sd_np = gu.make_block_state_dict(KW, seed)
+    key = next(k for k in sd_np if k.endswith("backcast_ff.layers.0.0.weight_g"))
+    sd_np[key] = (sd_np[key] * 0 + 3.0e5).astype(np.float32)          # effective rows of norm 3e5
+    x_np, _ = gu.make_block_io(KW, seed, B, M, N)
+    x = torch.from_numpy(x_np).to(host_device)
+    blk = _build(KW, sd_np, host_device)
+    eng = blk.engine()
+    eng.use_x3, eng.x3_min_lines, eng.weight_range_check_every = True, 1, 1
+    with torch.no_grad():
+        blk(x)                                                         # folds the maximum, asynchronously
+        if host_device != "cpu":
+            torch.cuda.synchronize()
+        eng.weights_changed()                                          # (a training step would have changed them)
+        with pytest.raises(FloatingPointError, match="bf16x3"):
+            blk(x)
+    blk = _build(KW, sd_np, host_device)
+    eng = blk.engine()
+    eng.use_x3, eng.x3_min_lines, eng.weight_range_check_every = True, 1, 1
+    eng.ff_split = eng.x3_mix_split = "bf16x3"
+    with torch.no_grad():
+        out = blk(x)["forecast"]
+        eng.weights_changed()
+        out = blk(x)["forecast"]
+    assert torch.isfinite(out).all()
