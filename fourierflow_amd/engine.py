@@ -697,6 +697,12 @@ class FFNOEngine:
             if ev is None or ev.query():
                 self._wr_pending = None
                 wmax = float(host.view(torch.float32)[0])
+                if 0.0 < wmax < 2.0 ** -9 and not self.__dict__.get("_wr_warned"):
+                    import warnings
+                    self._wr_warned = True
+                    warnings.warn(f"every weight that goes into the split-fp16 packs is below {wmax:.3g}: the packs keep a fixed "
+                                  f"absolute error of 2^-36 there, i.e. relative accuracy degrades as the weights shrink "
+                                  f"(1e-6 at 2e-5); ff_split / x3_mix_split = 'bf16x3' is exact at any magnitude", RuntimeWarning)
                 if not wmax < 65504.0:
                     raise FloatingPointError(
                         f"a weight of magnitude {wmax:.3g} does not fit the split-fp16 packs (|W| < 65504): set "
