@@ -372,11 +372,19 @@ def main():
         if args.global_batch % world:
             raise SystemExit(f"--global-batch {args.global_batch} is not a multiple of --gpus {world}")
         args.batch = args.global_batch // world
+    # FFNO_BENCH_ONE_DEVICE=1 (a dry run of the N > 1 control flow on a one-GPU box, NOT a measurement): every rank on device 0,
+    # gloo instead of RCCL (RCCL refuses two ranks on one device); the line then says backend "gloo"
+    one_device = world > 1 and os.environ.get("FFNO_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     rccl_world = 1
-    if world > 1:
+    if world > 1 and one_device:
+        torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if world > 1:
         probe_t = torch.ones(1, device=dev)                    # the world size as RCCL itself counts it: a sum of ones
         torch.distributed.all_reduce(probe_t)
         rccl_world = int(probe_t.item())
@@ -468,7 +476,11 @@ def main():
         # one more training step with the launches captured, then the replay timing of the middle layer's launches
         trainer.engine.timer = probe
         probe.capture = True
+        # (rank 0 only from here on: no collective may be issued -- the other ranks are done.  The captured step therefore runs
+        #  without its gradient all-reduce; nothing after this point compares ranks)
+        world_saved, trainer.world = trainer.world, 1
         trainer.train_step(x, y)
+        trainer.world = world_saved
         probe.capture = False
         torch.cuda.synchronize()
         paired = bool(getattr(trainer.engine, "paired_last", False))
