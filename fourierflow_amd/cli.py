@@ -27,6 +27,12 @@ from typer import Argument, Option, Typer
 from .config import build_routine, load_config
 
 app = Typer(add_completion=False, help=__doc__)
+_LAST: Dict[str, object] = {}
+
+
+def _last_routine():
+    """The routine object the last `train` command of this process built (for callers that drive the CLI in-process)."""
+    return _LAST.get("routine")
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -40,12 +46,33 @@ def _device(device: Optional[str]) -> torch.device:
     return torch.device(device or "cuda:0")
 
 
+def _init_distributed(device: Optional[str]):
+    """(rank, world, device).  Started as one process per GPU (`python -m torch.distributed.run --nproc-per-node N -m
+    fourierflow_amd train ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) the command joins the job --
+    the counterpart of the reference handing Lightning a DDPPlugin (commands/train.py:83-84): weights are broadcast from
+    rank 0, every rank draws its own shard of each global batch, the flat gradient buffer is all-reduced once per step
+    (FFNOTrainer) and the normaliser statistics are global (Normalizer.sync_across_ranks).  RCCL on GPUs, gloo on CPU tensors."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or "RANK" not in os.environ:
+        return 0, 1, _device(device)
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device(device) if device else torch.device("cuda", local)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    if not torch.distributed.is_initialized():
+        torch.distributed.init_process_group("nccl" if dev.type == "cuda" else "gloo", rank=rank, world_size=world)
+    return rank, world, dev
+
+
 class _Batches:
     """Batches of the routine's geometry: slices of an .npz file, or synthetic."""
 
     def __init__(self, routine, cfg, dev, data: Optional[Path], batch_size: Optional[int], grid: int, size: Optional[List[int]],
-                 seed: int):
+                 seed: int, rank: int = 0, world: int = 1):
         self.routine, self.dev, self.kind = routine, dev, _kind(routine)
+        self.rank, self.world = rank, world      # data parallel: rank r takes every world-th batch of a file / its own stream
+        seed = seed + 1000003 * rank
         self.B = batch_size or int(cfg.get("builder", {}).get("batch_size", 19))
         self.grid, self.size = grid, tuple(size) if size else None
         self.gen = torch.Generator().manual_seed(seed)
@@ -68,7 +95,8 @@ class _Batches:
     def epoch(self) -> Iterator[Dict[str, torch.Tensor]]:
         if self.arrays is not None:
             n = len(next(iter(self.arrays.values())))
-            for i in range(0, n - self.B + 1, self.B):
+            nb = (n // self.B) // self.world * self.world        # the same number of batches on every rank
+            for i in range(self.rank * self.B, nb * self.B, self.world * self.B):
                 b = {k: torch.from_numpy(v[i:i + self.B]).to(self.dev) for k, v in self.arrays.items()}
                 yield self._finish(b)
             return
@@ -162,20 +190,23 @@ def train(config_path: Path, overrides: Optional[List[str]] = Argument(None), fo
           device: Optional[str] = Option(None, hidden=True)):
     """Train: build the routine from CONFIG (+ `a.b=c` overrides) and run fused optimisation steps."""
     cfg = load_config(str(config_path), overrides or [])
-    dev = _device(device)
-    torch.manual_seed(int(cfg.get("seed", 7231 + trial)))      # commands/train.py:61-64
+    rank, world, dev = _init_distributed(device)
+    torch.manual_seed(int(cfg.get("seed", 7231 + trial)))      # commands/train.py:61-64 (the same initial weights on every rank)
     routine = build_routine(cfg).to(dev)
+    _LAST["routine"] = routine
     kind = _kind(routine)
-    batches = _Batches(routine, cfg, dev, data, batch_size, grid, size, seed=7231 + trial)
-    out_dir = None if no_logging else _trial_dir(config_path.parent, trial, checkpoint_id, create=True)
+    batches = _Batches(routine, cfg, dev, data, batch_size, grid, size, seed=7231 + trial, rank=rank, world=world)
+    # checkpoints and the log lines are rank 0's (every rank holds the same weights and the same global normaliser statistics)
+    trial_dir = None if no_logging else _trial_dir(config_path.parent, trial, checkpoint_id, create=rank == 0)
+    out_dir = trial_dir if rank == 0 else None      # (only rank 0 writes; every rank reads the checkpoint it resumes from)
     if out_dir is not None and force and not resume:
         for old in out_dir.glob("*.ckpt"):       # delete_old_results (commands/train.py:58)
             old.unlink()
     start = dict(epoch=0, global_step=0)
     if resume:
-        if out_dir is None or not (out_dir / "last.ckpt").exists():
+        if trial_dir is None or not (trial_dir / "last.ckpt").exists():
             raise FileNotFoundError("--resume needs checkpoints/trial-<trial>-*/last.ckpt (commands/train.py:74-80)")
-        start = routine.resume_from_checkpoint(str(out_dir / "last.ckpt"))
+        start = routine.resume_from_checkpoint(str(trial_dir / "last.ckpt"))
     it = iter(batches)
     epoch = start["epoch"]
     if kind == "markov" and not resume and routine.should_normalize:      # epoch 0: statistics only (:376-378)
@@ -205,12 +236,13 @@ def train(config_path: Path, overrides: Optional[List[str]] = Argument(None), fo
                 raise FloatingPointError(
                     f"non-finite training loss at step {start['global_step'] + step}: check the data and the learning rate; if the "
                     f"weights have grown past 6.5e4, run with FFNO_FF_SPLIT=bf16x3 FFNO_X3_MIX_SPLIT=bf16x3 (any fp32 range)")
-            print(json.dumps(dict(step=start["global_step"] + step, epoch=epoch, train_loss=round(lv, 6),
-                                  lr=routine.trainer().current_lr())), flush=True)
+            if rank == 0:
+                print(json.dumps(dict(step=start["global_step"] + step, epoch=epoch, train_loss=round(lv, 6),
+                                      lr=routine.trainer().current_lr())), flush=True)
     if dev.type == "cuda":
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    summary = dict(steps=steps, batch=batches.B, steps_per_s=round(steps / max(dt, 1e-9), 2),
+    summary = dict(steps=steps, batch=batches.B, world_size=world, steps_per_s=round(steps / max(dt, 1e-9), 2),
                    resumed_from_step=start["global_step"])
     if out_dir is not None:
         gs = start["global_step"] + steps
@@ -221,7 +253,10 @@ def train(config_path: Path, overrides: Optional[List[str]] = Argument(None), fo
         routine.save_checkpoint(str(best), epoch=epoch, global_step=gs)
         routine.save_checkpoint(str(out_dir / "last.ckpt"), epoch=epoch, global_step=gs)
         summary.update(valid_loss=round(vl, 6), checkpoint=str(best))
-    print(json.dumps(summary), flush=True)
+    if rank == 0:
+        print(json.dumps(summary), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
 
 
 @app.command()

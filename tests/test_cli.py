@@ -119,3 +119,46 @@ def test_cli_rollout_routine_with_data_file(tmp_path, host_device):
     from fourierflow_amd.cli import app
     res = CliRunner().invoke(app, ["train", str(cfg), "--data", str(bad), "--device", host_device])
     assert res.exit_code != 0 and isinstance(res.exception, ValueError)
+
+
+def _cli_ddp_worker(rank, world, port, cfg_path, data_path):
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world), FFNO_ALLOW_TEST_BACKEND="1")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    from backend_util import emu_lib
+    from fourierflow_amd import _lib
+    _lib._install_test_backend(emu_lib())
+    from fourierflow_amd.cli import app
+    res = CliRunner().invoke(app, ["train", cfg_path, "routine.noise_std=0.0", "--steps", "3", "--data", data_path,
+                                   "--accumulation-batches", "1", "--device", "cpu"])
+    assert res.exit_code == 0, (res.output, res.exception)
+    lines = [json.loads(l) for l in res.output.splitlines() if l.startswith("{")]
+    assert (len(lines) > 0) == (rank == 0)            # the log lines and the checkpoints are rank 0's
+    # every rank ends with the same weights and the same (global) normaliser statistics
+    from fourierflow_amd.cli import _last_routine
+    sd = {k: v.detach().cpu().numpy() for k, v in _last_routine().state_dict().items()}
+    np.savez(os.path.join(os.path.dirname(cfg_path), f"rank{rank}.npz"), **sd)
+    torch.distributed.destroy_process_group()
+
+
+def test_cli_train_joins_a_two_rank_job(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m fourierflow_amd train ...` (here: two spawned processes, gloo, the CPU
+    emulator): the command initialises the process group from RANK / WORLD_SIZE, rank r takes every second batch of the data
+    file, gradients are all-reduced per step, only rank 0 logs and writes checkpoints -- and both ranks end bit-identical.
+    (The reference's switch: Lightning's DDPPlugin, commands/train.py:83-84.)"""
+    import torch.multiprocessing as mp
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(MARKOV)
+    rs = np.random.RandomState(1)
+    np.savez(tmp_path / "data.npz", x=rs.standard_normal((8, 8, 8, 1)).astype(np.float32),
+             y=rs.standard_normal((8, 8, 8, 1)).astype(np.float32))
+    port = 29600 + (os.getpid() % 2000)
+    mp.spawn(_cli_ddp_worker, args=(2, port, str(cfg), str(tmp_path / "data.npz")), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert set(r0.files) == set(r1.files) and len(r0.files) > 10
+    for k in r0.files:
+        np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    tdirs = os.listdir(tmp_path / "checkpoints")
+    assert len(tdirs) == 1 and "last.ckpt" in os.listdir(tmp_path / "checkpoints" / tdirs[0])
