@@ -569,7 +569,7 @@ def test_spectral_x3_latency_tiles_are_bit_identical(be, B, M, N, K, direction, 
     launches) against the 8-line kernel: the same products in the same order per output element -- outputs, saved spectra and
     range words are bit-identical; single launches of both axes (with the accumulate + residual epilogue) and the paired launch."""
     from fourierflow_amd._capi import FusedBranch
-    if be.kind == "emu" and (B, M, N, K) in ((1, 64, 64, 16), (2, 6, 10, 5)) and (direction, fmt) != ("fwd", 1):
+    if be.kind == "emu" and ((B, M, N, K) == (1, 64, 64, 16) or ((B, M, N, K) == (2, 6, 10, 5) and (direction, fmt) != ("fwd", 1))):
         pytest.skip("emulator time budget (the GPU run covers all)")
     C = 64
     lib, p = be.lib, be.ptr

@@ -289,11 +289,12 @@ def test_training_steps_on_bf16_storage_follow_the_fp32_run(host_device):
     (same seed, same data; masters, moments and the optimiser are fp32 in both)."""
     from fourierflow_amd.trainer import FFNOTrainer
     seed, B, M, N = 7, 2, 8, 8
-    sd_np = gu.make_block_state_dict(KW, seed)
-    x_np, t_np = gu.make_block_io(KW, seed, B, M, N)
+    kw = dict(KW, n_layers=2) if host_device == "cpu" else KW          # (emulator time budget)
+    sd_np = gu.make_block_state_dict(kw, seed)
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
     losses = {}
     for storage in ("fp32", "bf16"):
-        blk, eng = _block(KW, sd_np, host_device, storage)
+        blk, eng = _block(kw, sd_np, host_device, storage)
         tr = FFNOTrainer(blk, lr=1e-3, weight_decay=1e-4, num_warmup_steps=0, num_training_steps=100)
         x, t = torch.from_numpy(x_np).to(host_device), torch.from_numpy(t_np).to(host_device)
         losses[storage] = [float(tr.train_step(x, t).item()) for _ in range(5)]
