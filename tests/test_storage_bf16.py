@@ -302,3 +302,22 @@ def test_training_steps_on_bf16_storage_follow_the_fp32_run(host_device):
     a, b = np.array(losses["fp32"]), np.array(losses["bf16"])
     assert a[-1] < a[0] and b[-1] < b[0]
     assert np.max(np.abs(a - b) / a) < 2e-2
+
+
+def test_switching_the_storage_of_one_engine_back_and_forth(host_device):
+    """fp32 -> bf16 -> fp32 on the SAME engine (what bench.py's variant leg does): each format has its own workspace, and the fp32
+    results after the round trip are the fp32 results from before it, bit for bit."""
+    seed, B, M, N = 4, 1, 8, 8
+    kw = dict(KW, n_layers=2)
+    sd_np = gu.make_block_state_dict(kw, seed)
+    x_np, _ = gu.make_block_io(kw, seed, B, M, N)
+    blk, eng = _block(kw, sd_np, host_device, "fp32")
+    x = torch.from_numpy(x_np).to(host_device)
+    with torch.no_grad():
+        a = blk(x)["forecast"].clone()
+        eng.storage = "bf16"
+        b = blk(x)["forecast"].clone()
+        eng.storage = "fp32"
+        c = blk(x)["forecast"].clone()
+    assert torch.equal(a, c)
+    assert not torch.equal(a, b) and rel_l2(b.cpu().numpy(), a.cpu().numpy()) < 1e-2
