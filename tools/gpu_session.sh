@@ -51,6 +51,13 @@ for st in $STAGES; do
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_zongyi" -o z -- python "$OLDPWD/tools/bench_zongyi.py" --steps 3 --warmup 1 --cpu 0 > "$OLDPWD/gpurun_out/prof_zongyi.log" 2>&1)
       db=$(find gpurun_out/prof_zongyi -name "*.db" | head -1); python tools/rocpd_stats.py "$db" > gpurun_out/zongyi_kernel_stats.md 2>&1; head -n 22 gpurun_out/zongyi_kernel_stats.md | cut -c1-180
       find gpurun_out/prof_zongyi -size +20M -delete ;;
+    latency)
+      timeout 300 python tools/bench_latency.py > gpurun_out/bench_latency.log 2>&1
+      echo "[session] latency rc=$?"; tail -n 14 gpurun_out/bench_latency.log ;;
+    dry2)
+      # the N > 1 control flow of bench.py on ONE device (both ranks on cuda:0 over gloo: a dry run, not a measurement)
+      FFNO_BENCH_ONE_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --cpu-steps 0 > gpurun_out/bench_dry2.log 2>&1
+      echo "[session] dry2 rc=$?"; tail -n 1 gpurun_out/bench_dry2.log | cut -c1-300 ;;
     bench19)
       timeout 600 python bench.py --steps 20 --warmup 5 --batch 19 --cpu-steps 0 > gpurun_out/bench_b19.log 2>&1
       echo "[session] bench19 rc=$?"; grep "timed region" gpurun_out/bench_b19.log ;;
