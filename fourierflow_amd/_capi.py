@@ -7,6 +7,10 @@ from __future__ import annotations
 
 import ctypes as C
 
+# generation of include/ffno.h these signatures and struct mirrors belong to (FFNO_ABI_VERSION there; _lib.check_abi compares
+# it with what the loaded library reports before anything is called)
+ABI_VERSION = 4
+
 P = C.c_void_p
 I = C.c_int
 F = C.c_float

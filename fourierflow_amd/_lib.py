@@ -65,8 +65,18 @@ def get_lib() -> ctypes.CDLL:
             _capi.bind(lib)
             if lib.ffno_build_target() != b"gfx950":
                 raise FFNOLibraryError(f"{LIB_PATH} is not a gfx950 build")
+            check_abi(lib, LIB_PATH)
             _lib = lib
     return _lib
+
+
+def check_abi(lib, path) -> None:
+    """The struct layouts and argument lists of _capi.py belong to ONE generation of include/ffno.h: a library of another
+    generation (a prebuilt .so loaded "unverifiable", an older build on the path) would read shifted arguments."""
+    got = int(lib.ffno_abi_version())
+    if got != _capi.ABI_VERSION:
+        raise FFNOLibraryError(f"{path} speaks ABI generation {got}, this host code expects {_capi.ABI_VERSION} "
+                               f"(include/ffno.h FFNO_ABI_VERSION): rebuild with `python -m fourierflow_amd.build --force`")
 
 
 def is_test_backend() -> bool:
@@ -79,6 +89,8 @@ def _install_test_backend(lib):
     if lib is not None and os.environ.get("FFNO_ALLOW_TEST_BACKEND") != "1":
         raise FFNOLibraryError("the emulator test backend can only be installed in a process started with "
                                "FFNO_ALLOW_TEST_BACKEND=1 (tests/conftest.py); product runs use libffno_hip.so only")
+    if lib is not None:
+        check_abi(lib, "the emulator test backend")
     _test_backend = lib
 
 

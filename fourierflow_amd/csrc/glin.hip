@@ -21,15 +21,19 @@
 
 namespace ffno {
 
-// keep(seed, idx): the dropout mask bit of element idx (a 32-bit finaliser over idx and the call's seed; uniform to ~2^-32)
-__host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr) {
-    uint32_t h = idx * 0x9E3779B1u + seed;
+// keep(seed, idx): the dropout mask bit of element idx: fmix32(idx ^ fmix32(seed)) (the 32-bit murmur3 finaliser, a bijection;
+// uniform to ~2^-32).  The seed goes through the finaliser BEFORE it meets the index: with `idx * G + seed` the masks of two
+// sites were one bit sequence shifted by (seed difference) / G mod 2^32 elements -- shifted copies, not independent draws.
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
     h ^= h >> 13;
     h *= 0xC2B2AE35u;
     h ^= h >> 16;
-    return h >= thr;
+    return h;
+}
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr) {
+    return fmix32(idx ^ fmix32(seed)) >= thr;
 }
 
 struct GlinDrop {

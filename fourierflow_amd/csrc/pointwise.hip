@@ -587,7 +587,7 @@ extern "C" int ffno_amax(const float* x, size_t n, uint32_t* word, void* stream)
 extern "C" const char* ffno_build_target(void) {
     return FFNO_BUILD_TARGET;
 }
-extern "C" int ffno_abi_version(void) { return 1; }
+extern "C" int ffno_abi_version(void) { return FFNO_ABI_VERSION; }
 
 extern "C" int ffno_twiddle_fill_host(float* tw_host, int L) {
     if (!tw_host || L <= 0) return FFNO_EINVAL;

@@ -33,6 +33,24 @@ HEAD_DIM = 128  # grid_2d.py:150-152 / mesh_3d.py:155-157: WNLinear(width, 128) 
 _SUPPORTED_CH = {(64, 256), (64, 128), (32, 128), (32, 64)}
 
 
+def _fmix32(h: int) -> int:
+    h &= 0xFFFFFFFF
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+    return h ^ (h >> 16)
+
+
+def _site_seed(*words: int) -> int:
+    """Seed of one dropout site: a hash CHAIN over (base seed, training call, layer, linear, block kind), not a linear
+    combination of them -- linear seeds made the masks of neighbouring sites shifted copies of one sequence."""
+    h = 0x9E3779B1
+    for w in words:
+        h = _fmix32(h ^ _fmix32((int(w) + 0x7F4A7C15) & 0xFFFFFFFF))
+    return h
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -220,7 +238,10 @@ class FFNOEngine:
         # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
         self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
-        self.weight_range_check_every = 16   # fp16x2 packs: look at max |W| every n-th rebuild of the derived operands (0 = never)
+        # fp16x2 packs: max |W| of what goes into them is folded at every n-th rebuild of the derived operands (0 = never) and
+        # looked at one rebuild later -- with 1 (the default since round 4: three 3-us launches per step) an overflowing weight
+        # is reported after at most one more optimiser step (include/ffno.h: |W| < 65504 is a hard precondition of the packs)
+        self.weight_range_check_every = 1
         # storage format of the activation tensors in HBM (include/ffno.h "Storage formats"): "fp32" = the parity path (the
         # reference is precision: 32); "bf16" = the bf16 storage twins of the hot kernels -- half the activation bytes, results
         # rounded to bf16 wherever a tensor is stored (a throughput variant with its own tolerance).  Available for the paired
@@ -629,8 +650,9 @@ class FFNOEngine:
     def weights_changed(self):
         """Tell the engine that parameter memory was written behind PyTorch's back (a raw-pointer kernel such as the fused
         AdamW of FFNOTrainer): the derived operands (weight-norm products, packed fragments, folded head) are rebuilt by the
-        next forward.  In-place torch ops (optimizer.step(), load_state_dict, broadcast) are seen through the tensors'
-        version counters and need no call."""
+        next forward.  In-place torch ops on the BOUND tensors or on anything that shares their version counter (the module
+        mirrors and FFNOTrainer bind ``parameter.detach()``: optimizer.step(), load_state_dict, p.copy_() are seen) need no
+        call; writes through another alias of the same memory (a view of a flat buffer, ``p.data``'s source) do."""
         self._prep_sig = None
 
     def _prepare_weights(self, st):
@@ -638,9 +660,12 @@ class FFNOEngine:
         self._refresh_pointers()
         # derived operands only depend on the parameters and the arithmetic choices: an inference loop (rollout: 10-100 forwards
         # on the same weights) prepares them once -- five launches less per forward
-        sig = (tuple((t.data_ptr(), t._version) for t in self.params.values()), self.ff_split, self.x3_mix_split,
-               tuple(self._x3_fmt or ()), self.use_x3, self.use_ffx, getattr(st, "value", st))
-        if sig == getattr(self, "_prep_sig", None):
+        try:
+            sig = (tuple((t.data_ptr(), t._version) for t in self.params.values()), self.ff_split, self.x3_mix_split,
+                   tuple(self._x3_fmt or ()), self.use_x3, self.use_ffx, getattr(st, "value", st))
+        except RuntimeError:      # inference tensors (created under torch.inference_mode()) have no version counter:
+            sig = None            # nothing to compare -- the operands are rebuilt by every forward, as before round 3
+        if sig is not None and sig == getattr(self, "_prep_sig", None):
             return
         self._prep_sig = sig
         if self._desc_dev is not None:
@@ -789,9 +814,7 @@ class FFNOEngine:
         layer, block kind and site; the backward pass regenerates it from the same pair."""
         if not (self.dropout > 0.0 and self._training):
             return 0.0, 0
-        h = (self.drop_seed * 0x9E3779B1 + self._drop_calls * 0x85EBCA6B + layer * 0xC2B2AE35 + (k + 1) * 0x27D4EB2F
-             + (0x165667B1 if kind == "forecast" else 0)) & 0xFFFFFFFF
-        return self.dropout, h
+        return self.dropout, _site_seed(self.drop_seed, self._drop_calls, layer, k + 1, int(kind == "forecast"))
 
     def _ffg_fwd(self, ws, prefix, kind, layer, sv, s, resid, out, P, st, rout=None):
         lib = _lib.get_lib()
@@ -943,6 +966,12 @@ class FFNOEngine:
         self._prepare_weights(st)
         full = self.mode == "full"
         singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)
+        if pair is not None and fused[pair[0]] and not (x3[pair[0]] and x3[pair[1]]):
+            # one fused launch for two axes needs ONE kernel family to take both shapes: either both on the split (x3) kernels
+            # or both on the fp32-MFMA fused kernel; an axis that is "fused" through the x3 kernels only next to one that the
+            # x3 kernels refuse (x3_min_lines, a missing pack) would be handed to a kernel that does not support it
+            if not all(lib.ffno_spectral_fused_supported(C, ws.views[w].K, ws.views[w].L) for w in pair):
+                singles, pair = list(range(len(ws.views))), None
         conc = pair is not None
         x3pair = bool(conc and x3[pair[0]] and x3[pair[1]])
         if conc and not fused[pair[0]]:      # both axes staged: the split-bf16 stage kernels when the library takes the shape
@@ -975,7 +1004,7 @@ class FFNOEngine:
                 _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
                 self.Cin, C, pm, None if in_drop else rw(ws, "x", 0), st)
         if in_drop:      # x = self.drop(x) after in_proj (grid_2d.py:158): a regenerated mask over the lifted features
-            self._in_drop_seed = (self.drop_seed * 0x9E3779B1 + self._drop_calls * 0x85EBCA6B + 0x632BE5AB) & 0xFFFFFFFF
+            self._in_drop_seed = _site_seed(self.drop_seed, self._drop_calls, 0xFFFF, 0, 2)
             self._k("in_dropout", lib.ffno_dropout, _p(ws.X), ws.X.numel(), self.in_dropout, self._in_drop_seed, st)
             self._fold(ws.X, rw(ws, "x", 0), st)
         for l in range(L):
@@ -1060,6 +1089,7 @@ class FFNOEngine:
                     ws.P_in, C, self.O, 0, pm, st)
         self._saved = (x, B, S, fused, conc) if save_for_backward else None
         self._saved_x3 = (x3, x3pair)
+        self._saved_sched = (singles, pair)
         self.paired_last = conc      # (bench.py: which algorithmic-work table applies)
         return ws.Y.view(B, *S, self.O).clone()
 
@@ -1072,7 +1102,7 @@ class FFNOEngine:
             raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
         x, B, S, fused, conc = self._saved
         x3, x3pair = self._saved_x3
-        singles, pair = self._schedule(fused, self._workspace(B, S, True).views) if conc else (list(range(len(fused))), None)
+        singles, pair = self._saved_sched
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()

@@ -63,11 +63,16 @@ class FFNOTrainer:
                 v = self.pflat[off:off + cnt].view(p.shape)
                 v.copy_(p)
                 p.data = v  # the module's parameters now alias the flat buffer
-                views[name] = v
+                # What the engine binds is ``p.detach()``, not ``v``: ``p.data = v`` keeps p's OWN version counter, so an
+                # in-place write through the Parameter (load_state_dict, p.copy_(), an external optimizer.step()) bumps
+                # p._version only -- a bound ``v`` would never see it and the engine would keep stale derived operands
+                # (weight-norm products, packed fragments, folded head).  detach() shares p's counter.
+                views[name] = p.detach()
                 off += cnt
         assert off == n
         if self.world > 1 and broadcast_from_rank0:
             torch.distributed.broadcast(self.pflat, src=0, group=process_group)
+            self.engine.weights_changed()      # (written through the flat buffer, whose counter the engine does not watch)
         self.engine.bind(views)
         self.m = torch.zeros_like(self.pflat)
         self.v = torch.zeros_like(self.pflat)

@@ -68,6 +68,12 @@ extern "C" {
 
 /* library / build identification ("gfx950", or "emu" for the CPU test build) */
 const char* ffno_build_target(void);
+/* ABI generation of this header: bumped whenever a struct layout or an argument list below changes incompatibly (round 3 changed
+ * ffno_fused_branch, the layer descriptors and inserted range-word arguments before `stream` without bumping it: an older
+ * library under newer host code would have read shifted arguments).  ffno_abi_version() returns the value the LIBRARY was built
+ * with; a caller compares it with the FFNO_ABI_VERSION it was compiled against before the first compute call (the Python host
+ * does: fourierflow_amd/_lib.py refuses a mismatch). */
+#define FFNO_ABI_VERSION 4
 int ffno_abi_version(void);
 
 /* word[0] = max(word[0], bits(max |x[i]|)): folds a tensor into a range word (see "Range words" above) */
@@ -432,8 +438,12 @@ int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_dev, int n,
  * again -- exact, no host round trip.  2^12 of head-room remain for the growth through the first linear map (|h| <= ||W
  * row||_1 |s| + |b1|); elements down to 2^-16 of the bound keep fp32-level relative accuracy, smaller ones an absolute error of
  * 2^-40 of the bound.  So activations of 1e6 and gradients of 1e-12 are as good as O(1) data.  The WEIGHTS are split unscaled:
- * |W| must be below 65504 (they are O(1) in any trainable network).  With a NULL word the data is taken as is (in range:
- * 2^-12 <= |x| < 2^15 for full accuracy).
+ * |W| < 65504 is a HARD PRECONDITION of every fp16x2 pack (ffno_ffh_pack, ffno_spectral_x3_pack with format 1) that the
+ * library does NOT check: a larger weight becomes +-inf in its hi plane and the products are non-finite from then on.  A
+ * caller that cannot rule it out folds max |W| of what it packs with ffno_amax (the Python host does so at EVERY rebuild of
+ * the packs, reads the word back without synchronising and raises FloatingPointError at the next rebuild -- at most one
+ * optimiser step late) or uses the split-bf16 twins (ffno_ffx_*, format 0), which take any fp32 range.  With a NULL range
+ * word the data is taken as is (in range: 2^-12 <= |x| < 2^15 for full accuracy).
  * --------------------------------------------------------------------------------------------- */
 size_t ffno_ffh_pack_bytes(int C, int H);
 int ffno_ffh_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);

@@ -101,9 +101,94 @@ def test_markov24_bench_geometry_on_bf16_storage():
     med = float(np.median(list(errs.values())))
     print(f"[bench-geometry bf16 storage] forward rel-L2 {e_fwd:.2e}, |loss diff| {abs(loss - ref_loss.item()):.2e}, "
           f"gradients: median {med:.2e}, worst {errs[worst]:.2e} ({worst})")
-    assert 1e-5 < e_fwd < 1e-2            # (not the parity path: the rounding of 24 stored residual streams is visible)
-    assert abs(loss - ref_loss.item()) < 1e-2
+    # bands = 3 x what was observed on MI355X in round 3 (forward 1.3e-3, |loss diff| 1e-3-level, gradients: median 1.4e-2, worst
+    # 3.0e-2): this is the ONLY oracle check of the storage variant -- the kernel-level twin tests compare against the rounded
+    # fp32 HIP kernels -- so the band is kept as tight as the format allows
+    assert 1e-5 < e_fwd < 4e-3            # (not the parity path: the rounding of 24 stored residual streams is visible)
+    assert abs(loss - ref_loss.item()) < 4e-3
     assert all(np.all(np.isfinite(g)) for g in grads.values())
-    assert med < 2e-2 and errs[worst] < 1.5e-1
+    assert med < 4e-2 and errs[worst] < 9e-2
     again = _run_hip(kw, seed, B, M, N, storage="bf16")
     assert torch.equal(gflat, again[5]) and loss == again[1]
+
+
+# ---- the SECONDARY benchmarked shapes at full depth (VERDICT r03 "next" #3): bench.py's `secondary` lines time exactly these --------
+KOCHKOV256 = dict(width=64, input_dim=5, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layers,modes", [(12, 32), (24, 64)], ids=["12L-K32", "24L-K64"])
+def test_kochkov256_full_depth_forward_backward_vs_oracle(layers, modes):
+    """BASELINE configs[3] (256 x 256, 12 layers, 32 modes, batch 2) and the reference's own 256 x 256 experiment
+    (experiments/torus_kochkov/ffno/grid_sizes/256/config.yaml:32-44: 24 layers, 64 modes, batch_size 2) at FULL depth and batch,
+    through FFNOTrainer's forward / loss / backward -- the fused many-mode split kernels (spectral_x3k) on both axes of every
+    layer -- against the oracle on the same inputs: forward <= 1e-5, every parameter gradient at rounding level on the HIP
+    path's ReLU active sets."""
+    kw = dict(KOCHKOV256, modes=modes, n_layers=layers)
+    seed, B, M, N = 256 + modes, 2, 256, 256
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    from fourierflow_amd.trainer import FFNOTrainer
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in gu.make_block_state_dict(kw, seed).items()}, strict=True)
+    tr = FFNOTrainer(blk.cuda())
+    io = gu.make_block_io(kw, seed, B, M, N)
+    x, t = torch.from_numpy(io[0]).cuda(), torch.from_numpy(io[1]).cuda()
+    eng = tr.engine
+    pred = eng.forward(blk.prepare_input(x), True)
+    loss, gy = tr.loss_and_grad(pred, t)
+    loss = float(loss.item())
+    eng.backward(gy)
+    grads = {n: eng.grad_view(n).detach().cpu().numpy().copy() for n in eng.param_names}
+    masks = ou.engine_relu_masks(eng)
+    torch.cuda.synchronize()
+    # what bench.py's secondary line times: both axes of every layer in one paired launch of the fused split kernels
+    assert eng.paired_last and eng._saved_x3 == ([True, True], True), (eng.paired_last, eng._saved_x3)
+    ref_out, ref_loss, ref_grads = ou.oracle_block_run(kw, seed, B, M, N, relu_masks=masks, io=io)
+    e_fwd = rel_l2(pred.cpu().numpy(), ref_out["forecast"].detach().numpy())
+    print(f"[kochkov 256x256 {layers}L K={modes} B={B}] forward rel-L2 {e_fwd:.2e}, |loss diff| {abs(loss - ref_loss.item()):.2e}")
+    assert e_fwd < 1e-5
+    assert abs(loss - ref_loss.item()) < 1e-5
+    first = {torch.float32: ref_grads}
+    ou.check_grads_at_rounding_level(
+        f"kochkov 256x256 {layers}L K={modes}", grads,
+        lambda dt: first.get(dt) or ou.oracle_block_run(kw, seed, B, M, N, dtype=dt, relu_masks=masks, io=io)[2])
+
+
+@pytest.mark.gpu
+def test_mesh3d_config5_full_depth_forward_backward_vs_oracle():
+    """BASELINE configs[4] at FULL depth: 64^3 -> 72^3 padded, modes 8, width 32, 12 layers (what bench.py's 64^3 secondary line
+    times: fourierflow/modules/factorized_fno/mesh_3d.py:154-177), forward + every parameter gradient against the oracle on the
+    HIP path's ReLU active sets."""
+    from fourierflow_amd.modules import FNOFactorizedMesh3D
+    from oracle import ffno_oracle as orc
+    kw = dict(modes_x=8, modes_y=8, modes_z=8, width=32, input_dim=4, output_dim=1, n_layers=12, share_weight=False, factor=4,
+              ff_weight_norm=True, n_ff_layers=2, layer_norm=False)
+    seed, B, S = 55, 1, (64, 64, 64)
+    sd_np = gu.make_mesh3d_state_dict(kw, seed)
+    blk = FNOFactorizedMesh3D(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    blk = blk.cuda()
+    x_np, t_np = gu.make_mesh3d_io(kw, seed, B, S)
+    out = blk(torch.from_numpy(x_np).cuda())
+    loss = orc.lp_rel_loss(out, torch.from_numpy(t_np).cuda())
+    loss.backward()
+    eng = blk.engine()
+    masks = ou.engine_relu_masks(eng)
+    assert all(eng._saved_x3[0]), eng._saved_x3      # all three axes on the width-32 split kernels
+
+    def oracle(dtype=torch.float32):
+        sd, uniq = ou.torch_state_dict(sd_np, dtype)
+        o = orc.ffno_mesh3d(sd, torch.tensor(x_np, dtype=dtype), modes=(8, 8, 8), n_layers=12, relu_masks=masks)
+        l = orc.lp_rel_loss(o, torch.tensor(t_np, dtype=dtype))
+        l.backward()
+        return o, l, {k: (p.grad.detach().numpy() if p.grad is not None else None) for k, p in uniq.items()}
+
+    ref_out, ref_loss, ref_grads = oracle()
+    e_fwd = rel_l2(out.detach().cpu().numpy(), ref_out.detach().numpy())
+    print(f"[mesh3d 64^3 12 layers] forward rel-L2 {e_fwd:.2e}, |loss diff| {abs(loss.item() - ref_loss.item()):.2e}")
+    assert e_fwd < 1e-5
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    named = dict(blk.named_parameters())
+    first = {torch.float32: ref_grads}
+    ou.check_grads_at_rounding_level("mesh3d 64^3 12 layers", {n: named[n].grad.cpu().numpy() for n in eng.param_names},
+                                     lambda dt: first.get(dt) or oracle(dt)[2])

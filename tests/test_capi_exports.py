@@ -23,7 +23,21 @@ def test_library_exports_every_declared_symbol():
     declared = header_functions()
     assert declared == bound, (declared - bound, bound - declared)
     assert lib.ffno_build_target() == b"gfx950"
-    assert lib.ffno_abi_version() == 1
+    m = re.search(r"#define\s+FFNO_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "ffno.h")).read())
+    assert lib.ffno_abi_version() == int(m.group(1)) == _capi.ABI_VERSION
+
+
+def test_loader_refuses_a_library_of_another_abi_generation():
+    import pytest
+    from fourierflow_amd import _capi, _lib
+
+    class Old:
+        @staticmethod
+        def ffno_abi_version():
+            return _capi.ABI_VERSION - 1
+
+    with pytest.raises(_lib.FFNOLibraryError, match="ABI generation"):
+        _lib.check_abi(Old, "old.so")
 
 
 def test_wn_desc_layout_matches_header():
