@@ -31,9 +31,10 @@ wandb / pytorch_lightning):
     file at generation time (tools/make_golden_velocity.py -> tests/golden/markov_velocity.npz); only the wavenumber meshes
     (jax_cfd ``Grid.rfft_mesh()``, an un-vendored dependency pinned at git rev eb4d723e) are restated from that
     function's published definition.  Also held to analytic known answers (tests/test_velocity.py).
-  * ``rollout_learning_step`` (routines/grid_2d_rollout.py:75-150): the loop is restated from the file and PARITY IS UNPINNED
-    by a reference run for the loop itself; every operator inside it (FNOZongyi2DBlock, LpLoss.rel) is pinned by golden
-    vectors.
+  * ``rollout_learning_step`` (routines/grid_2d_rollout.py:75-150): PINNED since round 4 by a run of the reference's own
+    `forward` / `_learning_step` bodies, lifted from the file at generation time and executed over the reference's real
+    FNOZongyi2DBlock and LpLoss (tools/make_golden_rollout.py -> tests/golden/rollout_step.npz: losses, predictions,
+    correlations, time_until and every parameter gradient for append_pos on / off and teacher forcing in train / eval mode).
 ``relu_mask`` / ``relu_masks`` arguments are a test device (gradient comparisons without the ReLU bit-flip
 discontinuity, see ``feedforward``); they change nothing when absent.
 """

@@ -39,6 +39,63 @@ def _oracle_step(sd_np, data, lr, teacher_forcing=False):
     return out, grads, {k: v.detach() for k, v in sd.items()}
 
 
+# ---- the loop of routines/grid_2d_rollout.py:38-50,75-150 pinned by a run of the reference's own method bodies --------------------
+# (tools/make_golden_rollout.py lifts `forward` / `_learning_step` from the reference file and runs them over the reference's
+#  real FNOZongyi2DBlock and LpLoss; the fixture holds inputs / outputs / parameter gradients only)
+ROLLOUT_CASES = ["pos", "nopos", "tf_train", "tf_eval"]
+
+
+def _golden_case(tag):
+    g = gu.load_golden("rollout_step")
+    ap, tf, training, wseed, _ = [int(v) for v in g[f"{tag}.flags"]]
+    sd_np, _ = gu.make_zongyi_state_dict(KW, wseed)
+    return g, bool(ap), bool(tf), bool(training), float(g[f"{tag}.step_size"]), sd_np, g[f"{tag}.data"]
+
+
+@pytest.mark.parametrize("tag", ROLLOUT_CASES)
+def test_oracle_rollout_matches_reference_golden(tag):
+    g, ap, tf, training, step_size, sd_np, data = _golden_case(tag)
+    assert [int(v) for v in g["meta"]] == [B, G, T]
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in sd_np.items()}
+    xx = torch.cat([torch.tensor(data[..., :10]), orc.rollout_positions(B, G, G)], dim=-1)
+    conv = lambda z: orc.fno_zongyi_2d(sd, z, modes=KW["modes1"], n_layers=KW["n_layers"])["forecast"]   # noqa: E731
+    loss, loss_full, pred, step_losses, p, time_until = orc.rollout_learning_step(
+        conv, xx, torch.tensor(data[..., 10:]), T, append_pos=ap, teacher_forcing=tf, training=training, step_size=step_size)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}.loss"])) < 2e-6 and abs(loss_full.item() - float(g[f"{tag}.loss_full"])) < 2e-6
+    assert rel_l2(pred.detach().numpy(), g[f"{tag}.pred"]) < 2e-6
+    np.testing.assert_allclose([l.item() for l in step_losses], g[f"{tag}.step_losses"], atol=2e-6)
+    np.testing.assert_allclose(p.detach().numpy(), g[f"{tag}.p"], atol=2e-6)
+    assert float(time_until) == float(g[f"{tag}.time_until"])
+    for k, v in sd.items():
+        assert rel_l2(v.grad.numpy(), g[f"{tag}.grad.{k}"]) < 2e-5, k
+
+
+@pytest.mark.parametrize("tag", ROLLOUT_CASES)
+def test_rollout_hip_path_matches_reference_golden(host_device, tag):
+    """The HIP routine (Grid2DRolloutExperiment.forward over the FNOZongyi2DBlock engine) against the reference run itself."""
+    from fourierflow_amd.modules import FNOZongyi2DBlock
+    from fourierflow_amd.routines import Grid2DRolloutExperiment
+    g, ap, tf, training, step_size, sd_np, data = _golden_case(tag)
+    conv = FNOZongyi2DBlock(**KW)
+    conv.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+    routine = Grid2DRolloutExperiment(conv, n_steps=T, append_pos=ap, teacher_forcing=tf, step_size=step_size).to(host_device)
+    routine.train(training)
+    eng = routine.trainer().engine
+    conv.fused_grad_accumulation = True          # what training_step sets: the n_steps passes add their gradients up in the engine
+    conv.max_live_passes = max(conv.max_live_passes, T)
+    eng.zero_grad()
+    loss, loss_full, pred, step_losses, p, time_until = routine.forward({'data': torch.from_numpy(data.copy()).to(host_device)})
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{tag}.loss"])) < 1e-5 and abs(loss_full.item() - float(g[f"{tag}.loss_full"])) < 1e-5
+    assert rel_l2(pred.detach().cpu().numpy(), g[f"{tag}.pred"]) < 1e-5
+    np.testing.assert_allclose([l.item() for l in step_losses], g[f"{tag}.step_losses"], atol=1e-5)
+    np.testing.assert_allclose(p.cpu().numpy(), g[f"{tag}.p"], atol=1e-5)
+    assert float(time_until) == float(g[f"{tag}.time_until"])
+    for n in eng.param_names:
+        assert rel_l2(eng.grad_view(n).cpu().numpy(), g[f"{tag}.grad.{n}"]) < 2e-4, n
+
+
 @pytest.mark.parametrize("teacher_forcing", [False, True])
 def test_rollout_training_step_matches_oracle(host_device, teacher_forcing):
     routine, sd_np, data = _setup(host_device, teacher_forcing=teacher_forcing)
