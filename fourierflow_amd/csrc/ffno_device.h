@@ -149,6 +149,30 @@ __device__ __forceinline__ void mfma_h2(const Hf2& a, const Hf2& b, f32x16& m, f
     m = plat::mfma_f16_32x32x16(a.hi, b.hi, m);
 }
 
+// ---- single-accumulator split-fp16 products against a BOUNDED operand ------------------------------------------------------
+// When one operand of a product block is known to be small (|a| < 2^4: DFT-matrix entries are <= 2 / sqrt(L)), a third plane
+// hs = hi * 2^11 (exact: one v_pk_mul_f16 per pair) makes every kept partial product carry the same factor:
+//     acc += a.lo b.hi + a.hi b.lo + a.hs b.hi  =  2^11 (a b)        (lo lo / 2^11 dropped: <= 2^-24 |a b|)
+// -- three MFMAs on ONE accumulator tile, no correction tile and no fold; the caller divides by 2^11 where it scales anyway.
+struct Hf3 {
+    u32x4 hi, lo, hs;
+};
+__device__ __forceinline__ Hf3 split2s_8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+    const Hf2 h = split2_8(v0, v1, v2, v3, v4, v5, v6, v7);
+    Hf3 f;
+    f.hi = h.hi, f.lo = h.lo;
+    FFNO_UNROLL
+    for (int w = 0; w < 4; ++w) f.hs[w] = plat::pk_mul_f16(h.hi[w], kHf2Scale);
+    return f;
+}
+// acc += 2^11 (a b), a bounded (Hf3), b any in-range split pair
+__device__ __forceinline__ f32x16 mfma_h2s(const Hf3& a, const Hf2& b, f32x16 c) {
+    c = plat::mfma_f16_32x32x16(a.lo, b.hi, c);
+    c = plat::mfma_f16_32x32x16(a.hi, b.lo, c);
+    c = plat::mfma_f16_32x32x16(a.hs, b.hi, c);
+    return c;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
     FFNO_UNROLL

@@ -108,11 +108,18 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 // rows 16..31 repeat them and are dropped).
 // ST = storage format of the activation tensors in / out / resid (ffno_device.h): with StBf16 a loaded sample IS one bf16 plane,
 // so the forward DFT needs three MFMAs per product block instead of six; the saved spectra stay fp32.
+// DFTH2 (= MIXH2: the launches whose operands carry range words): the two DFT phases on split-fp16 as well -- the DFT matrices
+// are the bounded operand of single-accumulator products (ffno_device.h: Hf3, three MFMAs per product block instead of the
+// six of the bf16 split, 6 instead of 11 vector instructions per split pair), the samples are multiplied by the power of two
+// that brings max |in| (range word) to 2^10 while they are split, and each line's mixed spectrum by one derived from ITS OWN
+// maximum (the wave reads the whole line from LDS anyway) -- both exact, both undone where the result is scaled anyway.
 template <int NL, bool MIXH2, class ST = StF32>
 __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
     constexpr int NLW = NL / F::NW;                 // lines per wave
+    constexpr bool DFTH2 = MIXH2;
+    using DftFrag = typename std::conditional<DFTH2, Hf3, Bf3>::type;      // DFT-matrix fragments
     static_assert(NL == 16 || NL == 8, "16 or 8 lines per workgroup");
     __shared__ __attribute__((aligned(16))) float XS[NL * F::LSF];
     FFNO_DYN_SMEM(smem);
@@ -126,6 +133,9 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     // finite input can push a split operand of the mix past the half format's 65504.
     const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
     const float rrs = 1.f / rs;
+    // fp16x2 DFT: samples x sx (max |in| -> 2^10); the accumulators then hold 2^11 sx X
+    const float sx = (DFTH2 && A.in_amax) ? range_scale(*A.in_amax, 0, 10) : 1.f;
+    const float unx = DFTH2 ? kHf2Unscale / sx : 1.f;      // accumulator -> spectrum
     float omax = 0.f;                  // max |out| over what this thread stores
     __shared__ float rfold[F::NW];
 
@@ -168,7 +178,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         };
         // DFT-matrix fragments of one chunk (exact three-way splits; built while the loads are in flight).  The table index
         // k n mod L advances incrementally: +k per sample, +8 k across the other half-wave's samples.
-        Bf3 Ff[4];
+        DftFrag Ff[4];
         const int k8 = (km * 8) % L;
         auto build_F = [&](int chunk) {
             int idx = (km * (64 * chunk + 8 * half)) % L;
@@ -184,7 +194,10 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 }
                 idx += k8;
                 if (idx >= L) idx -= L;
-                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                if constexpr (DFTH2)
+                    Ff[u] = split2s_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                else
+                    Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
             }
         };
         const int nchunks = (L + 63) >> 6;
@@ -205,7 +218,23 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 const bool more = chunk + 1 < nchunks;
                 FFNO_UNROLL
                 for (int u = 0; u < 4; ++u) {
-                    if constexpr (ST::BF16) {
+                    if constexpr (DFTH2) {
+                        // split-fp16 samples (bf16 storage: widened first -- the same arithmetic as the fp32 kernel on float(x))
+                        float2 w[8];
+                        FFNO_UNROLL
+                        for (int e = 0; e < 8; ++e) {
+                            w[e] = ST::w2(raw[u][e]);
+                            w[e].x *= sx, w[e].y *= sx;
+                        }
+                        const Hf2 b0 = split2_8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
+                        const Hf2 b1 = split2_8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
+                        if (more)
+                            load_rows(chunk + 1, u, ln ? lo1 : lo0);
+                        else if (ln == 0 && NLW > 1)
+                            load_rows(0, u, lo1);
+                        acc0 = mfma_h2s(Ff[u], b0, acc0);
+                        acc1 = mfma_h2s(Ff[u], b1, acc1);
+                    } else if constexpr (ST::BF16) {
                         // the samples are bf16: one operand plane (low halves = even channel, high halves = odd channel)
                         u32x4 b0, b1;
                         FFNO_UNROLL
@@ -239,7 +268,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
             for (int r = 0; r < 16; ++r) {
                 const int row = drow(r, half);
                 if (row < 2 * K) {
-                    const float2 v = make_float2(acc0[r], acc1[r]);
+                    const float2 v = make_float2(acc0[r] * unx, acc1[r] * unx);      // (unx = 1 on the bf16 split)
                     *reinterpret_cast<float2*>(xs + row * RS) = make_float2(v.x * rs, v.y * rs);
                     if (A.spec_save && live)
                         *reinterpret_cast<float2*>(A.spec_save + (((long)(row >> 1) * R + line0 + ln) * 2 + (row & 1)) * C + 2 * j) = v;
@@ -352,7 +381,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         FFNO_NOUNROLL
         for (int rt0 = 0; rt0 < RTtot; rt0 += 2) {
             // inverse-DFT matrix fragments of two 32-row output tiles: row n, slot e of k-step st <-> kk = (mode t, part)
-            Bf3 G[2][2];
+            DftFrag G[2][2];
             FFNO_UNROLL
             for (int q = 0; q < 2; ++q) {
                 const int n = 32 * (rt0 + q) + j;
@@ -371,7 +400,10 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                             if (idx >= L) idx -= L;
                         }
                     }
-                    G[q][st] = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                    if constexpr (DFTH2)
+                        G[q][st] = split2s_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                    else
+                        G[q][st] = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
                 }
             }
             FFNO_UNROLL
@@ -379,19 +411,50 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 if (!(ln ? live1 : live0)) continue;
                 const unsigned lo = (ln ? lo1 : lo0) + hoff;
                 // B operands: the line's spectrum, split: slot e of k-step st <-> row kk = 16 st + 8 half + e
-                Bf3 y[2][2];
+                using SpecFrag = typename std::conditional<DFTH2, Hf2, Bf3>::type;
+                SpecFrag y[2][2];
                 const float* xs = XS + (lw + ln) * LSF + 2 * j;
+                float2 v[2][8];
                 FFNO_UNROLL
                 for (int st = 0; st < 2; ++st) {
-                    float2 v[8];
                     FFNO_UNROLL
                     for (int e = 0; e < 8; ++e) {
                         const int kk = 16 * st + 8 * half + e;
-                        v[e] = make_float2(0.f, 0.f);
-                        if (kk < 2 * K) v[e] = *reinterpret_cast<const float2*>(xs + kk * RS);
+                        v[st][e] = make_float2(0.f, 0.f);
+                        if (kk < 2 * K) v[st][e] = *reinterpret_cast<const float2*>(xs + kk * RS);
                     }
-                    y[st][0] = split3_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
-                    y[st][1] = split3_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+                }
+                // fp16x2: the line's mixed spectrum (nobody bounds it: it went through the weights) is brought to 2^10 by the power
+                // of two of ITS OWN maximum -- the wave holds the whole line -- and the outputs are divided again (exact)
+                // (one scale per COLUMN TILE -- the even / the odd channels: what one wave of the latency kernel sees of a line, so
+                // that the two kernels stay bit-identical)
+                float osc0 = rrs, osc1 = rrs;                 // accumulator -> output, per column tile
+                if constexpr (DFTH2) {
+                    float ym0 = 0.f, ym1 = 0.f;
+                    FFNO_UNROLL
+                    for (int st = 0; st < 2; ++st) {
+                        FFNO_UNROLL
+                        for (int e = 0; e < 8; ++e) ym0 = fmaxf(ym0, fabsf(v[st][e].x)), ym1 = fmaxf(ym1, fabsf(v[st][e].y));
+                    }
+                    FFNO_UNROLL
+                    for (int sh = 32; sh >= 1; sh >>= 1) ym0 = fmaxf(ym0, __shfl_xor(ym0, sh)), ym1 = fmaxf(ym1, __shfl_xor(ym1, sh));
+                    const float sy0 = range_scale(f2u(ym0), 0, 10), sy1 = range_scale(f2u(ym1), 0, 10);
+                    osc0 = rrs * kHf2Unscale / sy0, osc1 = rrs * kHf2Unscale / sy1;
+                    FFNO_UNROLL
+                    for (int st = 0; st < 2; ++st) {
+                        FFNO_UNROLL
+                        for (int e = 0; e < 8; ++e) v[st][e].x *= sy0, v[st][e].y *= sy1;
+                    }
+                }
+                FFNO_UNROLL
+                for (int st = 0; st < 2; ++st) {
+                    if constexpr (DFTH2) {
+                        y[st][0] = split2_8(v[st][0].x, v[st][1].x, v[st][2].x, v[st][3].x, v[st][4].x, v[st][5].x, v[st][6].x, v[st][7].x);
+                        y[st][1] = split2_8(v[st][0].y, v[st][1].y, v[st][2].y, v[st][3].y, v[st][4].y, v[st][5].y, v[st][6].y, v[st][7].y);
+                    } else {
+                        y[st][0] = split3_8(v[st][0].x, v[st][1].x, v[st][2].x, v[st][3].x, v[st][4].x, v[st][5].x, v[st][6].x, v[st][7].x);
+                        y[st][1] = split3_8(v[st][0].y, v[st][1].y, v[st][2].y, v[st][3].y, v[st][4].y, v[st][5].y, v[st][6].y, v[st][7].y);
+                    }
                 }
                 FFNO_UNROLL
                 for (int q = 0; q < 2; ++q) {
@@ -410,15 +473,20 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                     f32x16 o0 = zero16(), o1 = zero16();
                     FFNO_UNROLL
                     for (int st = 0; st < 2; ++st) {
-                        o0 = mfma_x3(G[q][st], y[st][0], o0);
-                        o1 = mfma_x3(G[q][st], y[st][1], o1);
+                        if constexpr (DFTH2) {
+                            o0 = mfma_h2s(G[q][st], y[st][0], o0);
+                            o1 = mfma_h2s(G[q][st], y[st][1], o1);
+                        } else {
+                            o0 = mfma_x3(G[q][st], y[st][0], o0);
+                            o1 = mfma_x3(G[q][st], y[st][1], o1);
+                        }
                     }
                     FFNO_UNROLL
                     for (int r = 0; r < 16; ++r) {
                         const int nu = 32 * (rt0 + q) + (r & 3) + 8 * (r >> 2);     // uniform part of the output sample index
                         if (nu + 4 * half < L) {
                             const long uo = (long)nu * es * ST::BYTES;
-                            float2 o = make_float2(o0[r] * rrs, o1[r] * rrs);
+                            float2 o = make_float2(o0[r] * osc0, o1[r] * osc1);
                             if (addsrc) {
                                 const float2 pw = ST::w2(pre[r]);
                                 o.x += pw.x, o.y += pw.y;
@@ -495,6 +563,11 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
     const LineMap lm = A.lm;
     const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
     const float rrs = 1.f / rs;
+    // the DFT phases on split-fp16 with the fp16x2 packs (spectral_x3_body "DFTH2"); here a column tile IS a line
+    constexpr bool DFTH2 = MIXH2;
+    using DftFrag = typename std::conditional<DFTH2, Hf3, Bf3>::type;
+    const float sx = (DFTH2 && A.in_amax) ? range_scale(*A.in_amax, 0, 10) : 1.f;
+    const float unx = DFTH2 ? kHf2Unscale / sx : 1.f;
     float omax = 0.f;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -534,7 +607,7 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
         f32x16 acc0 = zero16(), acc1 = zero16();
         FFNO_NOUNROLL
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            Bf3 Ff[4];
+            DftFrag Ff[4];
             int idx = (km * (64 * chunk + 8 * half)) % L;
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
@@ -548,17 +621,31 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
                 }
                 idx += k8;
                 if (idx >= L) idx -= L;
-                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                if constexpr (DFTH2)
+                    Ff[u] = split2s_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                else
+                    Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
             }
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
-                const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
-                                        raw[u][6].x, raw[u][7].x);
-                const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
-                                        raw[u][6].y, raw[u][7].y);
-                if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
-                acc0 = mfma_x3(Ff[u], b0, acc0);
-                acc1 = mfma_x3(Ff[u], b1, acc1);
+                if constexpr (DFTH2) {
+                    float2 w[8];
+                    FFNO_UNROLL
+                    for (int e = 0; e < 8; ++e) w[e] = make_float2(raw[u][e].x * sx, raw[u][e].y * sx);
+                    const Hf2 b0 = split2_8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
+                    const Hf2 b1 = split2_8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
+                    if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
+                    acc0 = mfma_h2s(Ff[u], b0, acc0);
+                    acc1 = mfma_h2s(Ff[u], b1, acc1);
+                } else {
+                    const Bf3 b0 = split3_8(raw[u][0].x, raw[u][1].x, raw[u][2].x, raw[u][3].x, raw[u][4].x, raw[u][5].x,
+                                            raw[u][6].x, raw[u][7].x);
+                    const Bf3 b1 = split3_8(raw[u][0].y, raw[u][1].y, raw[u][2].y, raw[u][3].y, raw[u][4].y, raw[u][5].y,
+                                            raw[u][6].y, raw[u][7].y);
+                    if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
+                    acc0 = mfma_x3(Ff[u], b0, acc0);
+                    acc1 = mfma_x3(Ff[u], b1, acc1);
+                }
             }
         }
         float* xs0 = XS + lw * LSF + j;
@@ -567,12 +654,13 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
         for (int r = 0; r < 16; ++r) {
             const int row = drow(r, half);
             if (row < 2 * K) {
-                xs0[row * RS] = acc0[r] * rs;
-                xs1[row * RS] = acc1[r] * rs;
+                const float v0 = acc0[r] * unx, v1 = acc1[r] * unx;
+                xs0[row * RS] = v0 * rs;
+                xs1[row * RS] = v1 * rs;
                 if (A.spec_save) {
                     float* sp = A.spec_save + (((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + j;
-                    if (live0) sp[0] = acc0[r];
-                    if (live1) sp[2 * C] = acc1[r];
+                    if (live0) sp[0] = v0;
+                    if (live1) sp[2 * C] = v1;
                 }
             }
         }
@@ -671,25 +759,52 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
         const float* xs0 = XS + lw * LSF + j;
         const float* xs1 = xs0 + LSF;
         // B operands: the two lines' spectra (tile 0 = line lw, tile 1 = line lw + 1): slot e of k-step st <-> row 16 st + 8 half + e
-        Bf3 y[2][2];
+        using SpecFrag = typename std::conditional<DFTH2, Hf2, Bf3>::type;
+        SpecFrag y[2][2];
+        float v0[2][8], v1[2][8];
         FFNO_UNROLL
         for (int st = 0; st < 2; ++st) {
-            float v0[8], v1[8];
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
                 const int kk = 16 * st + 8 * half + e;
-                v0[e] = v1[e] = 0.f;
-                if (kk < 2 * K) v0[e] = xs0[kk * RS], v1[e] = xs1[kk * RS];
+                v0[st][e] = v1[st][e] = 0.f;
+                if (kk < 2 * K) v0[st][e] = xs0[kk * RS], v1[st][e] = xs1[kk * RS];
             }
-            y[st][0] = split3_8(v0[0], v0[1], v0[2], v0[3], v0[4], v0[5], v0[6], v0[7]);
-            y[st][1] = split3_8(v1[0], v1[1], v1[2], v1[3], v1[4], v1[5], v1[6], v1[7]);
+        }
+        float osc0 = rrs, osc1 = rrs;
+        if constexpr (DFTH2) {      // each line's mixed spectrum scaled from its own maximum (the wave holds both lines whole)
+            float ym0 = 0.f, ym1 = 0.f;
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) ym0 = fmaxf(ym0, fabsf(v0[st][e])), ym1 = fmaxf(ym1, fabsf(v1[st][e]));
+            }
+            FFNO_UNROLL
+            for (int sh = 32; sh >= 1; sh >>= 1) ym0 = fmaxf(ym0, __shfl_xor(ym0, sh)), ym1 = fmaxf(ym1, __shfl_xor(ym1, sh));
+            const float sy0 = range_scale(f2u(ym0), 0, 10), sy1 = range_scale(f2u(ym1), 0, 10);
+            osc0 = rrs * kHf2Unscale / sy0, osc1 = rrs * kHf2Unscale / sy1;
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) v0[st][e] *= sy0, v1[st][e] *= sy1;
+            }
+        }
+        FFNO_UNROLL
+        for (int st = 0; st < 2; ++st) {
+            if constexpr (DFTH2) {
+                y[st][0] = split2_8(v0[st][0], v0[st][1], v0[st][2], v0[st][3], v0[st][4], v0[st][5], v0[st][6], v0[st][7]);
+                y[st][1] = split2_8(v1[st][0], v1[st][1], v1[st][2], v1[st][3], v1[st][4], v1[st][5], v1[st][6], v1[st][7]);
+            } else {
+                y[st][0] = split3_8(v0[st][0], v0[st][1], v0[st][2], v0[st][3], v0[st][4], v0[st][5], v0[st][6], v0[st][7]);
+                y[st][1] = split3_8(v1[st][0], v1[st][1], v1[st][2], v1[st][3], v1[st][4], v1[st][5], v1[st][6], v1[st][7]);
+            }
         }
         const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
                                      : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
         FFNO_NOUNROLL
         for (int rt = 0; rt < RTtot; ++rt) {
             const int n = 32 * rt + j;
-            Bf3 G[2];
+            DftFrag G[2];
             FFNO_UNROLL
             for (int st = 0; st < 2; ++st) {
                 float g[8];
@@ -705,7 +820,10 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
                         if (idx >= L) idx -= L;
                     }
                 }
-                G[st] = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                if constexpr (DFTH2)
+                    G[st] = split2s_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                else
+                    G[st] = split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
             }
             float2 pre[16];
             if (addsrc) {
@@ -719,15 +837,20 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
             f32x16 o0 = zero16(), o1 = zero16();
             FFNO_UNROLL
             for (int st = 0; st < 2; ++st) {
-                o0 = mfma_x3(G[st], y[st][0], o0);
-                o1 = mfma_x3(G[st], y[st][1], o1);
+                if constexpr (DFTH2) {
+                    o0 = mfma_h2s(G[st], y[st][0], o0);
+                    o1 = mfma_h2s(G[st], y[st][1], o1);
+                } else {
+                    o0 = mfma_x3(G[st], y[st][0], o0);
+                    o1 = mfma_x3(G[st], y[st][1], o1);
+                }
             }
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
                 if (nu + 4 * half < L) {
                     const unsigned uo = (unsigned)nu * esb + hoff;
-                    float2 o = make_float2(o0[r] * rrs, o1[r] * rrs);
+                    float2 o = make_float2(o0[r] * osc0, o1[r] * osc1);
                     if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
                     char* ob = reinterpret_cast<char*>(A.out);
                     if (A.accumulate && A.resid) {
@@ -1097,6 +1220,11 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     const LineMap lm = A.lm;
     const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
     const float rrs = 1.f / rs;
+    // with the fp16x2 packs the DFT phases run on split-fp16 too (spectral_x3_body "DFTH2": DFT matrices as the bounded operand of
+    // single-accumulator products, samples scaled from the range word, each line's mixed spectrum from its own maximum)
+    constexpr bool DFTH2 = MIXH2;
+    const float sx = (DFTH2 && A.in_amax) ? range_scale(*A.in_amax, 0, 10) : 1.f;
+    const float unx = DFTH2 ? kHf2Unscale / sx : 1.f;
     float omax = 0.f;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1114,6 +1242,87 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     __syncthreads();
 
     // ---------------- phase 1 ----------------
+    if constexpr (DFTH2) {
+        // The line is requested and split ONCE per wave; every k-step's samples then meet the DFT-matrix fragments of ALL the
+        // wave's row tiles (rt = sub, sub + 2, ..: one at <= 32 modes, two at 33..64), which are built on the fly from the
+        // twiddle table with a table index that is carried from sample to sample and from chunk to chunk (no modulo in the loop).
+        constexpr int RTW = RT / 2;
+        float amul[RTW];
+        int tbase[RTW], km[RTW], k8[RTW], fidx[RTW];
+        bool act[RTW];
+        FFNO_UNROLL
+        for (int i = 0; i < RTW; ++i) {
+            const int rt = sub + 2 * i;
+            const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
+            const bool rowok = kk < 2 * K;
+            const float ck = (A.fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+            act[i] = 32 * rt < 2 * K;
+            amul[i] = rowok ? (ri ? -ck : ck) : 0.f;
+            tbase[i] = ri ? L : 0;
+            km[i] = rowok ? k : 0;
+            k8[i] = (km[i] * 8) % L;
+            fidx[i] = (km[i] * 8 * half) % L;
+        }
+        float2 raw[4][8];
+        auto load_rows = [&](int chunk, int u) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
+                raw[u][e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.in) + (lo + (unsigned)n * esb));
+            }
+        };
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u);
+        f32x16 acc[RTW][2];
+        FFNO_UNROLL
+        for (int i = 0; i < RTW; ++i) acc[i][0] = zero16(), acc[i][1] = zero16();
+        FFNO_NOUNROLL
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool more = chunk + 1 < nchunks;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float2 w[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) w[e] = make_float2(raw[u][e].x * sx, raw[u][e].y * sx);
+                const Hf2 b0 = split2_8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
+                const Hf2 b1 = split2_8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
+                if (more) load_rows(chunk + 1, u);
+                FFNO_UNROLL
+                for (int i = 0; i < RTW; ++i) {
+                    float f[8];
+                    FFNO_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        const int n = 16 * (4 * chunk + u) + 8 * half + e;
+                        f[e] = n < L ? amul[i] * tws[tbase[i] + fidx[i]] : 0.f;
+                        fidx[i] += km[i];
+                        if (fidx[i] >= L) fidx[i] -= L;
+                    }
+                    fidx[i] += k8[i];
+                    if (fidx[i] >= L) fidx[i] -= L;
+                    if (act[i]) {
+                        const Hf3 Ff = split2s_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                        acc[i][0] = mfma_h2s(Ff, b0, acc[i][0]);
+                        acc[i][1] = mfma_h2s(Ff, b1, acc[i][1]);
+                    }
+                }
+            }
+        }
+        float* xs = XS + lw * LSF + 2 * j;
+        FFNO_UNROLL
+        for (int i = 0; i < RTW; ++i) {
+            if (!act[i]) continue;
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * (sub + 2 * i) + drow(r, half);
+                if (row < 2 * K) {
+                    const float2 v = make_float2(acc[i][0][r] * unx, acc[i][1][r] * unx);
+                    *reinterpret_cast<float2*>(xs + row * RS) = make_float2(v.x * rs, v.y * rs);
+                    if (A.spec_save && live)
+                        *reinterpret_cast<float2*>(A.spec_save + (((long)(row >> 1) * R + line) * 2 + (row & 1)) * C + 2 * j) = v;
+                }
+            }
+        }
+    } else
     for (int rt = sub; rt < RT; rt += 2) {
         if (32 * rt >= 2 * K) break;
         const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
@@ -1283,6 +1492,24 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
         const float* xs = XS + lw * LSF + 2 * j;
         const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
                                      : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
+        // fp16x2: power-of-two scales of the line's mixed spectrum, one per column tile (even / odd channels), from its own maximum
+        float sy0 = 1.f, sy1 = 1.f, osc0 = rrs, osc1 = rrs;
+        if constexpr (DFTH2) {
+            float ym0 = 0.f, ym1 = 0.f;
+            for (int kk = 8 * half; kk < 2 * K; kk += 16) {
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    if (kk + e < 2 * K) {
+                        const float2 v = *reinterpret_cast<const float2*>(xs + (kk + e) * RS);
+                        ym0 = fmaxf(ym0, fabsf(v.x)), ym1 = fmaxf(ym1, fabsf(v.y));
+                    }
+                }
+            }
+            FFNO_UNROLL
+            for (int sh = 32; sh >= 1; sh >>= 1) ym0 = fmaxf(ym0, __shfl_xor(ym0, sh)), ym1 = fmaxf(ym1, __shfl_xor(ym1, sh));
+            sy0 = range_scale(f2u(ym0), 0, 10), sy1 = range_scale(f2u(ym1), 0, 10);
+            osc0 = rrs * kHf2Unscale / sy0, osc1 = rrs * kHf2Unscale / sy1;
+        }
         for (int np = sub; np < NPR && live; np += 2) {
             const int rt0 = 2 * np;
             f32x16 o[2][2];
@@ -1300,6 +1527,52 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
             };
             if (addsrc) request_rows(rt0);
             const int nst = min(NST, (2 * K + 15) >> 4);
+            if constexpr (DFTH2) {
+                // table index of the inverse-DFT matrix rows of the two output tiles: n t mod L, carried from mode to mode and from
+                // k-step to k-step (+ 8 n per k-step: four modes here, four in the other half-wave)
+                int nmq[2], nm4[2], gidx[2];
+                bool nok[2];
+                FFNO_UNROLL
+                for (int q = 0; q < 2; ++q) {
+                    const int n = 32 * (rt0 + q) + j;
+                    nok[q] = n < L;
+                    nmq[q] = nok[q] ? n : 0;
+                    nm4[q] = (int)(((long)nmq[q] * 4) % L);
+                    gidx[q] = half ? nm4[q] : 0;
+                }
+                FFNO_NOUNROLL
+                for (int st = 0; st < nst; ++st) {
+                    float2 v[8];
+                    FFNO_UNROLL
+                    for (int e = 0; e < 8; ++e) {
+                        const int kk = 16 * st + 8 * half + e;
+                        v[e] = make_float2(0.f, 0.f);
+                        if (kk < 2 * K) v[e] = *reinterpret_cast<const float2*>(xs + kk * RS);
+                        v[e].x *= sy0, v[e].y *= sy1;
+                    }
+                    const Hf2 y0 = split2_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
+                    const Hf2 y1 = split2_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+                    FFNO_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        float g[8];
+                        FFNO_UNROLL
+                        for (int e = 0; e < 8; ++e) {
+                            const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+                            const float ck = (A.inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+                            g[e] = (kk < 2 * K && nok[q]) ? (part ? -ck : ck) * tws[(part ? L : 0) + gidx[q]] : 0.f;
+                            if (part) {
+                                gidx[q] += nmq[q];
+                                if (gidx[q] >= L) gidx[q] -= L;
+                            }
+                        }
+                        gidx[q] += nm4[q];
+                        if (gidx[q] >= L) gidx[q] -= L;
+                        const Hf3 G = split2s_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+                        o[q][0] = mfma_h2s(G, y0, o[q][0]);
+                        o[q][1] = mfma_h2s(G, y1, o[q][1]);
+                    }
+                }
+            } else
             FFNO_NOUNROLL
             for (int st = 0; st < nst; ++st) {      // (a real loop: only the four accumulators cross its iterations)
                 float2 v[8];
@@ -1345,7 +1618,7 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                     const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
                     if (nu + 4 * half < L) {
                         const long uo = (long)nu * es * 4;
-                        float2 ov = make_float2(o[q][0][r] * rrs, o[q][1][r] * rrs);
+                        float2 ov = make_float2(o[q][0][r] * osc0, o[q][1][r] * osc1);
                         if (addsrc) ov.x += cur[r].x, ov.y += cur[r].y;
                         if (A.accumulate && A.resid) {
                             const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lob);
@@ -1445,6 +1718,11 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
     const LineMap lm = A.lm;
     const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
     const float rrs = 1.f / rs;
+    // the DFT phases on split-fp16 with the fp16x2 packs, exactly as spectral_x3_body does them (same products, same scales)
+    constexpr bool DFTH2 = MIXH2;
+    using DftFrag = typename std::conditional<DFTH2, Hf3, Bf3>::type;
+    const float sx = (DFTH2 && A.in_amax) ? range_scale(*A.in_amax, 0, 10) : 1.f;
+    const float unx = DFTH2 ? kHf2Unscale / sx : 1.f;
     float omax = 0.f;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1472,7 +1750,7 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
                 raw[u][e] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (lo + (unsigned)n * esb));
             }
         };
-        Bf3 Ff[4];
+        DftFrag Ff[4];
         const int k8 = (km * 8) % L;
         auto build_F = [&](int chunk) {
             int idx = (km * (64 * chunk + 8 * half)) % L;
@@ -1488,7 +1766,10 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
                 }
                 idx += k8;
                 if (idx >= L) idx -= L;
-                Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                if constexpr (DFTH2)
+                    Ff[u] = split2s_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+                else
+                    Ff[u] = split3_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
             }
         };
         const int nchunks = (L + 63) >> 6;
@@ -1503,9 +1784,16 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
             const bool more = chunk + 1 < nchunks;
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
-                const Bf3 b = split3_8(raw[u][0], raw[u][1], raw[u][2], raw[u][3], raw[u][4], raw[u][5], raw[u][6], raw[u][7]);
-                if (more) load_rows(chunk + 1, u);
-                acc = mfma_x3(Ff[u], b, acc);
+                if constexpr (DFTH2) {
+                    const Hf2 b = split2_8(raw[u][0] * sx, raw[u][1] * sx, raw[u][2] * sx, raw[u][3] * sx, raw[u][4] * sx,
+                                           raw[u][5] * sx, raw[u][6] * sx, raw[u][7] * sx);
+                    if (more) load_rows(chunk + 1, u);
+                    acc = mfma_h2s(Ff[u], b, acc);
+                } else {
+                    const Bf3 b = split3_8(raw[u][0], raw[u][1], raw[u][2], raw[u][3], raw[u][4], raw[u][5], raw[u][6], raw[u][7]);
+                    if (more) load_rows(chunk + 1, u);
+                    acc = mfma_x3(Ff[u], b, acc);
+                }
             }
         }
         float* xs = XS + lw * LSF + 2 * j + t;
@@ -1513,8 +1801,9 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
         for (int r = 0; r < 16; ++r) {
             const int row = drow(r, half);
             if (row < 2 * K) {
-                xs[row * RS] = acc[r] * rs;
-                if (A.spec_save && live) A.spec_save[(((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + 2 * j + t] = acc[r];
+                const float v = acc[r] * unx;
+                xs[row * RS] = v * rs;
+                if (A.spec_save && live) A.spec_save[(((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + 2 * j + t] = v;
             }
         }
     }
@@ -1625,16 +1914,41 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
         const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
                                      : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
         // B operands: the line's spectrum, column tile t, split: slot e of k-step st <-> row kk = 16 st + 8 half + e
-        Bf3 y[2];
+        using SpecFrag = typename std::conditional<DFTH2, Hf2, Bf3>::type;
+        SpecFrag y[2];
+        float v[2][8];
         FFNO_UNROLL
         for (int st = 0; st < 2; ++st) {
-            float v[8];
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
                 const int kk = 16 * st + 8 * half + e;
-                v[e] = kk < 2 * K ? xs[kk * RS] : 0.f;
+                v[st][e] = kk < 2 * K ? xs[kk * RS] : 0.f;
             }
-            y[st] = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+        }
+        float osc = rrs;
+        if constexpr (DFTH2) {      // the scale of this column tile of the line, from its own maximum (spectral_x3_body)
+            float ym = 0.f;
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) ym = fmaxf(ym, fabsf(v[st][e]));
+            }
+            FFNO_UNROLL
+            for (int sh = 32; sh >= 1; sh >>= 1) ym = fmaxf(ym, __shfl_xor(ym, sh));
+            const float sy = range_scale(f2u(ym), 0, 10);
+            osc = rrs * kHf2Unscale / sy;
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) v[st][e] *= sy;
+            }
+        }
+        FFNO_UNROLL
+        for (int st = 0; st < 2; ++st) {
+            if constexpr (DFTH2)
+                y[st] = split2_8(v[st][0], v[st][1], v[st][2], v[st][3], v[st][4], v[st][5], v[st][6], v[st][7]);
+            else
+                y[st] = split3_8(v[st][0], v[st][1], v[st][2], v[st][3], v[st][4], v[st][5], v[st][6], v[st][7]);
         }
         FFNO_NOUNROLL
         for (int rt = 0; rt < RTtot; ++rt) {
@@ -1664,14 +1978,17 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
                         if (idx >= L) idx -= L;
                     }
                 }
-                o = mfma_x3(split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]), y[st], o);
+                if constexpr (DFTH2)
+                    o = mfma_h2s(split2s_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]), y[st], o);
+                else
+                    o = mfma_x3(split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]), y[st], o);
             }
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
                 if (nu + 4 * half < L) {
                     const long uo = (long)nu * es * 4;
-                    float ov = o[r] * rrs;
+                    float ov = o[r] * osc;
                     if (addsrc) ov += pre[r];
                     if (A.accumulate && A.resid) ov += *reinterpret_cast<const float*>(reinterpret_cast<const char*>(A.out) + uo + lob);
                     *reinterpret_cast<float*>(reinterpret_cast<char*>(A.out) + uo + lob) = ov;

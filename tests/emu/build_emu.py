@@ -35,18 +35,35 @@ def build(verbose=False):
     sf = LIB + ".stamp"
     if os.path.exists(LIB) and os.path.exists(sf) and open(sf).read() == stamp:
         return LIB
-    objs = []
-    for src in srcs:
-        obj = os.path.join(OUT, os.path.basename(src) + ".o")
-        cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC,
-               "-I", os.path.join(ROOT, "include"), "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-psabi", "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
-    subprocess.check_call([_cxx(), "-shared", "-fPIC", "-o", LIB, *objs])
-    open(sf, "w").write(stamp)
-    return LIB
+    # pytest-xdist workers all get here at once after a source change: one builds (exclusive file lock, temporary names renamed
+    # into place), the others wait and find a fresh library -- nobody ever loads a half-linked .so
+    import fcntl
+    with open(os.path.join(OUT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if os.path.exists(LIB) and os.path.exists(sf) and open(sf).read() == stamp:
+                return LIB
+            tag = f".tmp{os.getpid()}"
+            objs = []
+            for src in srcs:
+                obj = os.path.join(OUT, os.path.basename(src) + ".o")
+                cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC,
+                       "-I", os.path.join(ROOT, "include"), "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-psabi", "-c", src,
+                       "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd)
+                objs.append(obj)
+            subprocess.check_call([_cxx(), "-shared", "-fPIC", "-o", LIB + tag, *objs])
+            if os.path.exists(sf):
+                os.remove(sf)
+            os.replace(LIB + tag, LIB)
+            with open(sf + tag, "w") as f:
+                f.write(stamp)
+            os.replace(sf + tag, sf)
+            return LIB
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 if __name__ == "__main__":
