@@ -302,6 +302,17 @@ def secondary_workloads(dev, steps=10, warmup=3):
     sync = torch.cuda.synchronize
     g = torch.Generator().manual_seed(5)
 
+    def bf16_leg(eng, step, n, sync_):
+        """steps/s of the same train step on the bf16 storage twins (a variant with its own tolerance, never `value`)."""
+        try:
+            eng.storage = "bf16"
+            dtb, _ = time_steps(step, n, 2, sync_)
+            return round(1.0 / dtb, 2)
+        except Exception as e:  # noqa: BLE001
+            return repr(e)
+        finally:
+            eng.storage = "fp32"
+
     def grid256(layers, modes, label):
         kw = dict(MARKOV24, n_layers=layers, modes=modes, input_dim=5)
         torch.manual_seed(0)
@@ -318,6 +329,7 @@ def secondary_workloads(dev, steps=10, warmup=3):
         rep = probe.replay(50)
         tr.engine.timer = None
         df, _ = time_steps(lambda: tr.predict(x), steps, 2, sync)
+        bf16 = bf16_leg(tr.engine, lambda: tr.train_step(x, y), steps, sync)
         P, C, H = 2 * 256 * 256, 64, 256
         work = algorithmic_work(P, C, H, modes, 2, 256, 256, layers, True)
         spectral = {}
@@ -329,7 +341,7 @@ def secondary_workloads(dev, steps=10, warmup=3):
                                    frac_hbm_training_bytes=round(w["bytes"] / us * 1e-3 / HBM_PEAK_GBS, 3),
                                    frac_mfma=round(w["flops"] / us * 1e-6 / mpeak, 3), mfma_peak_tflops=round(mpeak, 1))
         out.append(dict(workload=label, value=round(1.0 / dt, 2), unit="steps/s", ms_per_step=round(1e3 * dt, 3),
-                        ms_per_forward=round(1e3 * df, 3), spectral=spectral))
+                        ms_per_forward=round(1e3 * df, 3), spectral=spectral, bf16_storage_variant_steps_per_s=bf16))
 
     # -- 256 x 256, 12 layers, 32 modes, batch 2 (BASELINE.json configs[3]) --
     grid256(12, 32, "torus_kochkov-shaped F-FNO train step: 256x256, 12 layers, 32 modes, width 64, batch 2, fp32")
@@ -344,6 +356,7 @@ def secondary_workloads(dev, steps=10, warmup=3):
     batch = dict(x=torch.randn(1, 64, 64, 64, 1, generator=g).to(dev), y=torch.randn(1, 64, 64, 64, 1, generator=g).to(dev))
     dt, _ = time_steps(lambda: exp.training_step(batch), steps, warmup, sync)
     df, _ = time_steps(lambda: exp.trainer().predict(batch["x"]), steps, 2, sync)
+    bf16_3d = bf16_leg(exp.trainer().engine, lambda: exp.training_step(batch), steps, sync)
     # roofline of its spectral launches, the way the headline's is taken (replay of the middle layer's captured launches).  A 3-D
     # layer is one single-axis launch + one paired launch per direction; SURVEY 8(d)'s bytes for a fused layer are read x + write
     # s once = 2 * P * C * 4 with P = 72^3 padded pixels -- set against the SUM of the layer's spectral launches
@@ -371,7 +384,7 @@ def secondary_workloads(dev, steps=10, warmup=3):
                     roofline=dict(bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s", per_direction=roof,
                                   note="8(d) bytes of a fused layer (read x + write s once = 2 * 72^3 * 32 * 4 B) over the sum of the "
                                        "layer's spectral launches (one single-axis + one paired launch), replay-timed"),
-                    kernel_us_replay=launches))
+                    kernel_us_replay=launches, bf16_storage_variant_steps_per_s=bf16_3d))
     return out
 
 

@@ -35,7 +35,7 @@ class FusedBranch(C.Structure):
                 ("B", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32),
                 ("planes_format", C.c_int32), ("tile_lines", C.c_int32), ("in_amax", P), ("out_amax", P),
-                ("storage", C.c_int32)]
+                ("storage", C.c_int32), ("pad_", C.c_int32), ("dft_frags", P)]
 
 
 class FfOpts(C.Structure):
@@ -111,6 +111,8 @@ SIGNATURES = {
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_x3_supported": (I, [I, I, I]),
     "ffno_spectral_x3_pack_bytes": (SZ, [I, I]),
+    "ffno_spectral_x3_dft_frags_bytes": (SZ, [I, I]),
+    "ffno_spectral_x3_dft_frags": (I, [P, I, I, I, I, P, P]),
     "ffno_spectral_x3_pack": (I, [P, I, I, I, P]),
     "ffno_spectral_x3": (I, [P, I, I, I, I, P]),
     "ffno_spectral_x3_pair": (I, [P, P, I, I, I, I, I, P]),

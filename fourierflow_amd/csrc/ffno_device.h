@@ -298,6 +298,7 @@ struct StF32 {
     static __device__ __forceinline__ float ld1(const T* p) { return *p; }
     static __device__ __forceinline__ void st4(T* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
     static __device__ __forceinline__ void st2(void* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+    static __device__ __forceinline__ void st1(void* p, float v) { *reinterpret_cast<float*>(p) = v; }
     static __device__ __forceinline__ float rnd(float x) { return x; }      // what a stored value reads back as
 };
 struct StBf16 {
@@ -329,6 +330,7 @@ struct StBf16 {
         *reinterpret_cast<uint2*>(p) = make_uint2(plat::pack_bf16(v.x, v.y), plat::pack_bf16(v.z, v.w));
     }
     static __device__ __forceinline__ void st2(void* p, float2 v) { *reinterpret_cast<unsigned*>(p) = plat::pack_bf16(v.x, v.y); }
+    static __device__ __forceinline__ void st1(void* p, float v) { *reinterpret_cast<uint16_t*>(p) = (uint16_t)plat::pack_bf16(v, 0.f); }
     static __device__ __forceinline__ float rnd(float x) { return u2f(plat::pack_bf16(x, 0.f) << 16); }
 };
 template <class ST>

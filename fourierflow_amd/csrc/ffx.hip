@@ -1385,12 +1385,17 @@ static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* r
     unsigned* oa = o ? o->out_amax : nullptr;
     const bool in_phase = o && (o->schedule & FFNO_FF_SCHED_IN_PHASE);
     hipStream_t st = (hipStream_t)stream;
-    if (o && o->storage == FFNO_STORE_BF16) {      // bf16 storage twin: the split-fp16 kernel of the headline shape
+    if (o && o->storage == FFNO_STORE_BF16) {      // bf16 storage twins: the split-fp16 kernels of widths 64 and 32 (factor 4)
         typedef const uint16_t* cp;
-        if (S::NP != 2 || C != 64 || H != 256) return FFNO_EUNSUPPORTED;
-        FFNO_LAUNCH((ffx_chain_rs_kernel<64, 256, false, SplitHf2, StBf16>), grid, dim3(FxCfg<64, 256>::NT), 0, st, (cp)s, (cp)s2,
-                    (uint16_t*)s_sum, (cp)resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, (uint16_t*)out, (uint32_t*)mask, P,
-                    ia, oa);
+        if (S::NP != 2 || !((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
+        if (C == 64)
+            FFNO_LAUNCH((ffx_chain_rs_kernel<64, 256, false, SplitHf2, StBf16>), grid, dim3(FxCfg<64, 256>::NT), 0, st, (cp)s,
+                        (cp)s2, (uint16_t*)s_sum, (cp)resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, (uint16_t*)out,
+                        (uint32_t*)mask, P, ia, oa);
+        else
+            FFNO_LAUNCH((ffx_chain_rs_kernel<32, 128, false, SplitHf2, StBf16>), grid, dim3(FxCfg<32, 128>::NT), 0, st, (cp)s,
+                        (cp)s2, (uint16_t*)s_sum, (cp)resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, (uint16_t*)out,
+                        (uint32_t*)mask, P, ia, oa);
         return ffx_launch_status();
     }
     if (o && o->storage != FFNO_STORE_F32) return FFNO_EINVAL;
@@ -1420,10 +1425,15 @@ static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const 
     hipStream_t st = (hipStream_t)stream;
     if (o && o->storage == FFNO_STORE_BF16) {
         typedef const uint16_t* cp;
-        if (S::NP != 2 || C != 64 || H != 256) return FFNO_EUNSUPPORTED;
-        FFNO_LAUNCH((ffx_chain_kernel<64, 256, true, SplitHf2, StBf16>), grid, dim3(FxCfg<64, 256>::NT), 0, st, (cp)db, (cp)db2,
-                    (uint16_t*)db_sum, (cp) nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr, (uint16_t*)ds,
-                    (uint32_t*)const_cast<void*>(mask), P, ia, oa);
+        if (S::NP != 2 || !((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
+        if (C == 64)
+            FFNO_LAUNCH((ffx_chain_kernel<64, 256, true, SplitHf2, StBf16>), grid, dim3(FxCfg<64, 256>::NT), 0, st, (cp)db,
+                        (cp)db2, (uint16_t*)db_sum, (cp) nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr,
+                        (uint16_t*)ds, (uint32_t*)const_cast<void*>(mask), P, ia, oa);
+        else
+            FFNO_LAUNCH((ffx_chain_kernel<32, 128, true, SplitHf2, StBf16>), grid, dim3(FxCfg<32, 128>::NT), 0, st, (cp)db,
+                        (cp)db2, (uint16_t*)db_sum, (cp) nullptr, (const u32x4*)pk1b, nullptr, (const u32x4*)pk2b, nullptr,
+                        (uint16_t*)ds, (uint32_t*)const_cast<void*>(mask), P, ia, oa);
         return ffx_launch_status();
     }
     if (o && o->storage != FFNO_STORE_F32) return FFNO_EINVAL;
@@ -1446,10 +1456,14 @@ static int fx_bwd_weights_partial(const float* s, const float* db, const void* p
     if (!s || !db || !pk1 || !b1 || !pk1b || !partial || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (storage == FFNO_STORE_BF16) {      // bf16 storage twin: the single-accumulator kernel (needs both range words)
-        if (S::NP != 2 || C != 64 || H != 256) return FFNO_EUNSUPPORTED;
+        if (S::NP != 2 || !((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
         if (!s_amax || !db_amax) return FFNO_EINVAL;
-        FFNO_LAUNCH((ffh_wgrad_m_kernel<64, 256, 8, StBf16>), dim3(nsplit), dim3(512), 0, st, (const uint16_t*)s,
-                    (const uint16_t*)db, (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);
+        if (C == 64)
+            FFNO_LAUNCH((ffh_wgrad_m_kernel<64, 256, 8, StBf16>), dim3(nsplit), dim3(512), 0, st, (const uint16_t*)s,
+                        (const uint16_t*)db, (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);
+        else
+            FFNO_LAUNCH((ffh_wgrad_m_kernel<32, 128, 4, StBf16>), dim3(nsplit), dim3(256), 0, st, (const uint16_t*)s,
+                        (const uint16_t*)db, (const u32x4*)pk1, b1, (const u32x4*)pk1b, partial, P, s_amax, db_amax);
         return ffx_launch_status();
     }
     if (storage != FFNO_STORE_F32) return FFNO_EINVAL;

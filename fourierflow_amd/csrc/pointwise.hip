@@ -634,8 +634,8 @@ static int lift_fwd_impl(const float* x, const float* W, const float* b, typenam
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
         FFNO_LAUNCH((lift_fwd_kernel<64, ST>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
-    else if (C == 32 && !ST::BF16)
-        FFNO_LAUNCH((lift_fwd_kernel<32, StF32>), grid, block, smem, s, x, W, b, (float*)out, P, Cin, pm, out_amax);
+    else if (C == 32)
+        FFNO_LAUNCH((lift_fwd_kernel<32, ST>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
@@ -661,9 +661,8 @@ static int lift_bwd_impl(const float* x, const typename ST::T* gout, float* part
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
         FFNO_LAUNCH((lift_bwd_partial_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
-    else if (C == 32 && !ST::BF16)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<32, StF32>), dim3(nsplit), dim3(256), 0, s, x, (const float*)gout, partial, P, Cin,
-                    chunk, pm);
+    else if (C == 32)
+        FFNO_LAUNCH((lift_bwd_partial_kernel<32, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
@@ -719,8 +718,8 @@ static int head_fwd_impl(const typename ST::T* b, const float* fold, float* y, i
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
         FFNO_LAUNCH((head_fwd_kernel<64, ST>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
-    else if (C == 32 && !ST::BF16)
-        FFNO_LAUNCH((head_fwd_kernel<32, StF32>), grid, block, 0, s, (const float*)b, fold, y, P, O, accumulate, pm);
+    else if (C == 32)
+        FFNO_LAUNCH((head_fwd_kernel<32, ST>), grid, block, 0, s, b, fold, y, P, O, accumulate, pm);
     else
         return FFNO_EUNSUPPORTED;
     return pw_status();
@@ -744,9 +743,8 @@ static int head_bwd_impl(const typename ST::T* b, const float* gy, const float* 
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
         FFNO_LAUNCH((head_bwd_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
-    else if (C == 32 && !ST::BF16)
-        FFNO_LAUNCH((head_bwd_kernel<32, StF32>), dim3(nsplit), dim3(256), 0, s, (const float*)b, gy, fold, (float*)gb, partial, P,
-                    O, pm, gb_amax);
+    else if (C == 32)
+        FFNO_LAUNCH((head_bwd_kernel<32, ST>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();

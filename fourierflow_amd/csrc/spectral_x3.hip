@@ -55,6 +55,8 @@ struct X3Args {
     // packs the spectrum tile is held multiplied by the power of two derived from it; out_amax (optional) receives max |out|
     const unsigned* in_amax;
     unsigned* out_amax;
+    // many-mode kernel only: precomputed DFT-matrix fragments (x3k_dft_frags_kernel), NULL = built from the twiddle table
+    const u32x4* dft;
 };
 
 // ---- weight packing --------------------------------------------------------------------------------------------------
@@ -549,8 +551,9 @@ __global__ __launch_bounds__(256) void x3_pack32_kernel(const X3PackDesc* __rest
     d.dst[(frag * 3 + 2) * 64 + lane] = f.lo;
 }
 
-template <bool MIXH2>
+template <bool MIXH2, class ST = StF32>
 __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
+    static_assert(!ST::BF16 || MIXH2, "bf16 storage runs the split-fp16 path");
     using F = X3Cfg32;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF, NL = F::NL;
     __shared__ __attribute__((aligned(16))) float XS[NL * LSF];
@@ -576,10 +579,10 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
     const int line0 = bidx * NL + lw;
     const bool live0 = line0 < R, live1 = line0 + 1 < R;
     const long es = lm.elem_stride;
-    const unsigned esb = (unsigned)(es * 4);
+    const unsigned esb = (unsigned)(es * ST::BYTES);
     // lines past the end of the axis read (and transform) line R - 1 again; nothing of a dead line is ever stored
-    const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + j) * 4);
-    const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + j) * 4);
+    const unsigned lo0 = (unsigned)((lm.base(min(line0, R - 1)) + j) * ST::BYTES);
+    const unsigned lo1 = (unsigned)((lm.base(min(line0 + 1, R - 1)) + j) * ST::BYTES);
 
     // ---------------- phase 1: truncated forward DFT of the wave's two lines, side by side ----------------
     {
@@ -594,8 +597,8 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
                 const unsigned no = (unsigned)min(16 * (4 * chunk + u) + 8 * half + e, L - 1) * esb;
-                raw[u][e].x = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (lo0 + no));
-                raw[u][e].y = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (lo1 + no));
+                raw[u][e].x = ST::ld1(reinterpret_cast<const typename ST::T*>(reinterpret_cast<const char*>(in) + (lo0 + no)));
+                raw[u][e].y = ST::ld1(reinterpret_cast<const typename ST::T*>(reinterpret_cast<const char*>(in) + (lo1 + no)));
             }
         };
         const int nchunks = (L + 63) >> 6;
@@ -755,7 +758,7 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
     // ---------------- phase 3: zero-padded inverse DFT of the wave's two lines, side by side ----------------
     {
         const int RTtot = (L + 31) >> 5;
-        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const unsigned hoff = (unsigned)(4 * half * es * ST::BYTES);
         const float* xs0 = XS + lw * LSF + j;
         const float* xs1 = xs0 + LSF;
         // B operands: the two lines' spectra (tile 0 = line lw, tile 1 = line lw + 1): slot e of k-step st <-> row 16 st + 8 half + e
@@ -830,8 +833,8 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
                 FFNO_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const unsigned no = (unsigned)min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1) * esb;
-                    pre[r].x = *reinterpret_cast<const float*>(addsrc + (lo0 + no));
-                    pre[r].y = *reinterpret_cast<const float*>(addsrc + (lo1 + no));
+                    pre[r].x = ST::ld1(reinterpret_cast<const typename ST::T*>(addsrc + (lo0 + no)));
+                    pre[r].y = ST::ld1(reinterpret_cast<const typename ST::T*>(addsrc + (lo1 + no)));
                 }
             }
             f32x16 o0 = zero16(), o1 = zero16();
@@ -854,16 +857,16 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
                     if (addsrc) o.x += pre[r].x, o.y += pre[r].y;
                     char* ob = reinterpret_cast<char*>(A.out);
                     if (A.accumulate && A.resid) {
-                        o.x += *reinterpret_cast<const float*>(ob + (lo0 + uo));
-                        o.y += *reinterpret_cast<const float*>(ob + (lo1 + uo));
+                        o.x += ST::ld1(reinterpret_cast<const typename ST::T*>(ob + (lo0 + uo)));
+                        o.y += ST::ld1(reinterpret_cast<const typename ST::T*>(ob + (lo1 + uo)));
                     }
                     if (live0) {
-                        *reinterpret_cast<float*>(ob + (lo0 + uo)) = o.x;
-                        omax = fmaxf(omax, fabsf(o.x));
+                        ST::st1(ob + (lo0 + uo), o.x);
+                        omax = fmaxf(omax, fabsf(ST::rnd(o.x)));
                     }
                     if (live1) {
-                        *reinterpret_cast<float*>(ob + (lo1 + uo)) = o.y;
-                        omax = fmaxf(omax, fabsf(o.y));
+                        ST::st1(ob + (lo1 + uo), o.y);
+                        omax = fmaxf(omax, fabsf(ST::rnd(o.y)));
                     }
                 }
             }
@@ -919,6 +922,7 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.accumulate = second ? b.accumulate : a.accumulate;
     s.in_amax = second ? b.in_amax : a.in_amax;
     s.out_amax = second ? b.out_amax : a.out_amax;
+    s.dft = nullptr;
     spectral_x3_body<NL, MIXH2, ST>(s, idx, (idx & 1) ? skew : 0);
 }
 
@@ -1195,6 +1199,67 @@ __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage
     x3_dft_inv_body(x3_pick(a, b, second), apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 
+// ---- DFT-matrix fragment table of the many-mode kernel ------------------------------------------------------------------------
+// The many-mode kernel gives a wave ONE line, so nothing amortises the construction of its DFT-matrix fragments: per product
+// block ~90 vector instructions (table lookups, index bookkeeping, the fp16 split) against 6 MFMAs -- measured 20 vector
+// instructions per MFMA over the whole launch (profiles/r04_x3k_sq_counters.md).  The fragments only depend on (L, K, flags), so
+// they are built ONCE into a table in MFMA lane order (two fp16 planes per fragment: hi, lo; the 2^11 hi plane is one
+// v_pk_mul_f16 per word in the kernel) and every wave loads them (L1 / L2 hits: all waves of a CU walk the same table):
+//   forward  part: fragment ((rt * nchunks + chunk) * 4 + u)      rt < RT = KKT / 32, chunk < nchunks, u < 4
+//   inverse  part: fragment (nfwd + tile * NST + st)               tile < ceil(L / 32), st < NST = KKT / 16
+// Values = exactly the expressions of spectral_x3k_body's on-the-fly path (bit-identical results with and without a table).
+struct X3kDft {
+    int KKT, RT, NST, nchunks, ntiles, nfwd;
+};
+static inline X3kDft x3k_dft_layout(int L, int K) {
+    X3kDft d;
+    d.KKT = K <= 32 ? 64 : 128;
+    d.RT = d.KKT / 32, d.NST = d.KKT / 16;
+    d.nchunks = (L + 63) >> 6, d.ntiles = (L + 31) >> 5;
+    d.nfwd = d.RT * d.nchunks * 4;
+    return d;
+}
+
+__global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restrict__ tw, int L, int K, int fwd_ck, int inv_ck,
+                                                           X3kDft d, u32x4* __restrict__ out) {
+    const int frag = blockIdx.x, lane = threadIdx.x, j = lane & 31, half = lane >> 5;
+    float f[8];
+    if (frag < d.nfwd) {
+        const int u = frag & 3, chunk = (frag >> 2) % d.nchunks, rt = (frag >> 2) / d.nchunks;
+        const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
+        const bool rowok = kk < 2 * K;
+        const float ck = (fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int km = rowok ? k : 0;
+        FFNO_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const int n = 16 * (4 * chunk + u) + 8 * half + e;
+            f[e] = n < L ? amul * tw[(ri ? L : 0) + (int)(((long)km * n) % L)] : 0.f;
+        }
+    } else {
+        const int g = frag - d.nfwd, st = g % d.NST, tile = g / d.NST;
+        const int n = 32 * tile + j;
+        FFNO_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+            const float ck = (inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+            f[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tw[(part ? L : 0) + (int)(((long)n * t) % L)] : 0.f;
+        }
+    }
+    const Hf2 h = split2_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    out[(frag * 2 + 0) * 64 + lane] = h.hi;
+    out[(frag * 2 + 1) * 64 + lane] = h.lo;
+}
+// fragment `frag` of the table as the bounded operand of mfma_h2s
+__device__ __forceinline__ Hf3 x3k_load_dft(const u32x4* __restrict__ tab, int frag, int lane) {
+    Hf3 f;
+    f.hi = tab[(frag * 2 + 0) * 64 + lane];
+    f.lo = tab[(frag * 2 + 1) * 64 + lane];
+    FFNO_UNROLL
+    for (int w = 0; w < 4; ++w) f.hs[w] = plat::pk_mul_f16(f.hi[w], kHf2Scale);
+    return f;
+}
+
 // ---- the fused branch for 17..64 modes (256 x 256 grids: torus_kochkov runs 32 and 64 modes) ----------------------------------
 // Same operator as spectral_x3_body with the spectrum tile in LDS, re-tiled for many modes per line: KKT = 64 or 128 (mode,
 // re/im) rows per line, FOUR lines per workgroup, two waves per line.  Why four: at 256 x 256 and batch 2 an axis has 512
@@ -1207,8 +1272,12 @@ __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage
 //            MFMA tile -- the mix is 5 % of the launch's MFMA budget here, the weight stream from L2 is what it costs)
 //   phase 3  wave (line, sub): pairs of 32-sample output tiles sub, sub + 2, .. of the zero-padded inverse DFT, k-step outer /
 //            tile inner as in x3_dft_inv_body, with the accumulate / residual epilogue.
-template <int KKT, bool MIXH2>
+// ST = storage format of in / out / resid (ffno_device.h); the bf16 twin exists for the fp16x2 packs (the split-fp16 DFT path)
+// TAB: the DFT-matrix fragments come from the precomputed table A.dft (x3k_dft_frags_kernel) instead of the twiddle table
+template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false>
 __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
+    static_assert(!TAB || MIXH2, "the fragment table holds fp16 planes");
+    static_assert(!ST::BF16 || MIXH2, "bf16 storage runs the split-fp16 path");
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, NL = 4, LSF = KKT * RS + 8, RT = KKT / 32, NST = KKT / 16;
     __shared__ __attribute__((aligned(16))) float XS[NL * LSF];
@@ -1233,9 +1302,9 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     const int line = bidx * NL + lw;
     const bool live = line < R;
     const long es = lm.elem_stride;
-    const unsigned esb = (unsigned)(es * 4);
+    const unsigned esb = (unsigned)(es * ST::BYTES);
     // lines past the end of the axis read (and transform) line R - 1 again; nothing of a dead line is ever stored
-    const unsigned lo = (unsigned)((lm.base(min(line, R - 1)) + 2 * j) * 4);
+    const unsigned lo = (unsigned)((lm.base(min(line, R - 1)) + 2 * j) * ST::BYTES);
     const int nchunks = (L + 63) >> 6;
 
     for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
@@ -1263,12 +1332,12 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
             k8[i] = (km[i] * 8) % L;
             fidx[i] = (km[i] * 8 * half) % L;
         }
-        float2 raw[4][8];
+        typename ST::Raw2 raw[4][8];      // (raw words: widened where they are split)
         auto load_rows = [&](int chunk, int u) {
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
                 const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
-                raw[u][e] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.in) + (lo + (unsigned)n * esb));
+                raw[u][e] = ST::ldr2(reinterpret_cast<const char*>(A.in) + (lo + (unsigned)n * esb));
             }
         };
         FFNO_UNROLL
@@ -1276,6 +1345,11 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
         f32x16 acc[RTW][2];
         FFNO_UNROLL
         for (int i = 0; i < RTW; ++i) acc[i][0] = zero16(), acc[i][1] = zero16();
+        Hf3 Fn[RTW];
+        if constexpr (TAB) {
+            FFNO_UNROLL
+            for (int i = 0; i < RTW; ++i) Fn[i] = x3k_load_dft(A.dft, ((sub + 2 * i) * nchunks) * 4, lane);
+        }
         FFNO_NOUNROLL
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const bool more = chunk + 1 < nchunks;
@@ -1283,10 +1357,28 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
             for (int u = 0; u < 4; ++u) {
                 float2 w[8];
                 FFNO_UNROLL
-                for (int e = 0; e < 8; ++e) w[e] = make_float2(raw[u][e].x * sx, raw[u][e].y * sx);
+                for (int e = 0; e < 8; ++e) {
+                    w[e] = ST::w2(raw[u][e]);
+                    w[e].x *= sx, w[e].y *= sx;
+                }
                 const Hf2 b0 = split2_8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
                 const Hf2 b1 = split2_8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
                 if (more) load_rows(chunk + 1, u);
+                if constexpr (TAB) {      // fragments from the table, requested one k-step ahead (Fn), consumed here (Fc)
+                    Hf3 Fc[RTW];
+                    FFNO_UNROLL
+                    for (int i = 0; i < RTW; ++i) Fc[i] = Fn[i];
+                    const int nu = u == 3 ? 0 : u + 1, nc = u == 3 ? min(chunk + 1, nchunks - 1) : chunk;
+                    FFNO_UNROLL
+                    for (int i = 0; i < RTW; ++i) Fn[i] = x3k_load_dft(A.dft, ((sub + 2 * i) * nchunks + nc) * 4 + nu, lane);
+                    FFNO_UNROLL
+                    for (int i = 0; i < RTW; ++i) {
+                        if (act[i]) {
+                            acc[i][0] = mfma_h2s(Fc[i], b0, acc[i][0]);
+                            acc[i][1] = mfma_h2s(Fc[i], b1, acc[i][1]);
+                        }
+                    }
+                } else
                 FFNO_UNROLL
                 for (int i = 0; i < RTW; ++i) {
                     float f[8];
@@ -1322,7 +1414,7 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                 }
             }
         }
-    } else
+    } else if constexpr (!ST::BF16)
     for (int rt = sub; rt < RT; rt += 2) {
         if (32 * rt >= 2 * K) break;
         const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
@@ -1487,7 +1579,7 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     // ---------------- phase 3 ----------------
     {
         const int RTtot = (L + 31) >> 5, NPR = (RTtot + 1) >> 1;
-        const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const unsigned hoff = (unsigned)(4 * half * es * ST::BYTES);
         const unsigned lob = lo + hoff;
         const float* xs = XS + lw * LSF + 2 * j;
         const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
@@ -1517,12 +1609,12 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
             for (int q = 0; q < 2; ++q) o[q][0] = zero16(), o[q][1] = zero16();
             // rows the epilogue adds (residual / accumulate) are requested ahead of the products: the first tile's before the
             // k-step loop, the second tile's while the first is stored
-            float2 pre[16];
+            typename ST::Raw2 pre[16];
             auto request_rows = [&](int rt) {
                 FFNO_UNROLL
                 for (int r = 0; r < 16; ++r) {
                     const int nu = min(32 * rt + (r & 3) + 8 * (r >> 2) + 4 * half, L - 1);
-                    pre[r] = *reinterpret_cast<const float2*>(addsrc + lo + (unsigned)nu * esb);
+                    pre[r] = ST::ldr2(addsrc + lo + (unsigned)nu * esb);
                 }
             };
             if (addsrc) request_rows(rt0);
@@ -1540,6 +1632,12 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                     nm4[q] = (int)(((long)nmq[q] * 4) % L);
                     gidx[q] = half ? nm4[q] : 0;
                 }
+                const int dftl_nfwd = RT * nchunks * 4;
+                Hf3 Gn[2];
+                if constexpr (TAB) {
+                    FFNO_UNROLL
+                    for (int q = 0; q < 2; ++q) Gn[q] = x3k_load_dft(A.dft, dftl_nfwd + min(rt0 + q, RTtot - 1) * NST, lane);
+                }
                 FFNO_NOUNROLL
                 for (int st = 0; st < nst; ++st) {
                     float2 v[8];
@@ -1552,6 +1650,20 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                     }
                     const Hf2 y0 = split2_8(v[0].x, v[1].x, v[2].x, v[3].x, v[4].x, v[5].x, v[6].x, v[7].x);
                     const Hf2 y1 = split2_8(v[0].y, v[1].y, v[2].y, v[3].y, v[4].y, v[5].y, v[6].y, v[7].y);
+                    if constexpr (TAB) {      // inverse-DFT matrix fragments from the table, one k-step ahead
+                        Hf3 Gc[2];
+                        FFNO_UNROLL
+                        for (int q = 0; q < 2; ++q) Gc[q] = Gn[q];
+                        const int sn = min(st + 1, nst - 1);
+                        FFNO_UNROLL
+                        for (int q = 0; q < 2; ++q)
+                            Gn[q] = x3k_load_dft(A.dft, dftl_nfwd + min(rt0 + q, RTtot - 1) * NST + sn, lane);
+                        FFNO_UNROLL
+                        for (int q = 0; q < 2; ++q) {
+                            o[q][0] = mfma_h2s(Gc[q], y0, o[q][0]);
+                            o[q][1] = mfma_h2s(Gc[q], y1, o[q][1]);
+                        }
+                    } else
                     FFNO_UNROLL
                     for (int q = 0; q < 2; ++q) {
                         float g[8];
@@ -1572,7 +1684,7 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                         o[q][1] = mfma_h2s(G, y1, o[q][1]);
                     }
                 }
-            } else
+            } else if constexpr (!ST::BF16)
             FFNO_NOUNROLL
             for (int st = 0; st < nst; ++st) {      // (a real loop: only the four accumulators cross its iterations)
                 float2 v[8];
@@ -1609,7 +1721,7 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
             for (int q = 0; q < 2; ++q) {
                 const int rt = rt0 + q;
                 if (rt >= RTtot) continue;
-                float2 cur[16];
+                typename ST::Raw2 cur[16];
                 FFNO_UNROLL
                 for (int r = 0; r < 16; ++r) cur[r] = pre[r];
                 if (addsrc && q == 0 && rt + 1 < RTtot) request_rows(rt + 1);
@@ -1617,15 +1729,18 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                 for (int r = 0; r < 16; ++r) {
                     const int nu = 32 * rt + (r & 3) + 8 * (r >> 2);
                     if (nu + 4 * half < L) {
-                        const long uo = (long)nu * es * 4;
+                        const long uo = (long)nu * es * ST::BYTES;
                         float2 ov = make_float2(o[q][0][r] * osc0, o[q][1][r] * osc1);
-                        if (addsrc) ov.x += cur[r].x, ov.y += cur[r].y;
+                        if (addsrc) {
+                            const float2 cw = ST::w2(cur[r]);
+                            ov.x += cw.x, ov.y += cw.y;
+                        }
                         if (A.accumulate && A.resid) {
-                            const float2 pv = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(A.out) + uo + lob);
+                            const float2 pv = ST::ld2(reinterpret_cast<const char*>(A.out) + uo + lob);
                             ov.x += pv.x, ov.y += pv.y;
                         }
-                        *reinterpret_cast<float2*>(reinterpret_cast<char*>(A.out) + uo + lob) = ov;
-                        omax = fmaxf(omax, fmaxf(fabsf(ov.x), fabsf(ov.y)));
+                        ST::st2(reinterpret_cast<char*>(A.out) + uo + lob, ov);
+                        omax = fmaxf(omax, fmaxf(fabsf(ST::rnd(ov.x)), fabsf(ST::rnd(ov.y))));
                     }
                 }
             }
@@ -1653,16 +1768,17 @@ __device__ __forceinline__ X3Args x3_pick_args(const X3Args& a, const X3Args& b,
     s.accumulate = second ? b.accumulate : a.accumulate;
     s.in_amax = second ? b.in_amax : a.in_amax;
     s.out_amax = second ? b.out_amax : a.out_amax;
+    s.dft = second ? b.dft : a.dft;
     return s;
 }
 
-template <int KKT, bool MIXH2>
+template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false>
 __global__ __launch_bounds__(512) void spectral_x3k_kernel(X3Args a) {
-    spectral_x3k_body<KKT, MIXH2>(a, blockIdx.x);
+    spectral_x3k_body<KKT, MIXH2, ST, TAB>(a, blockIdx.x);
 }
 // two branches in one launch: even workgroups run branch a, odd ones branch b while both have tiles left (workgroup w lands on
 // XCD w % 8: every XCD's L2 then holds the packed weights of ONE branch), the rest in order
-template <int KKT, bool MIXH2>
+template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false>
 __global__ __launch_bounds__(512) void spectral_x3k_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
     const int w = blockIdx.x, nmin = min(n0, n1);
     bool second;
@@ -1674,14 +1790,14 @@ __global__ __launch_bounds__(512) void spectral_x3k_pair_kernel(X3Args a, X3Args
         second = n1 > n0;
         idx = w - nmin;
     }
-    spectral_x3k_body<KKT, MIXH2>(x3_pick_args(a, b, second), idx);
+    spectral_x3k_body<KKT, MIXH2, ST, TAB>(x3_pick_args(a, b, second), idx);
 }
 
-template <bool MIXH2>
+template <bool MIXH2, class ST = StF32>
 __global__ __launch_bounds__(512) void spectral_x3c32_kernel(X3Args a) {
-    spectral_x3c32_body<MIXH2>(a, blockIdx.x);
+    spectral_x3c32_body<MIXH2, ST>(a, blockIdx.x);
 }
-template <bool MIXH2>
+template <bool MIXH2, class ST = StF32>
 __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
     const int w = blockIdx.x, nmin = min(n0, n1);
     bool second;
@@ -1693,7 +1809,7 @@ __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Ar
         second = n1 > n0;
         idx = w - nmin;
     }
-    spectral_x3c32_body<MIXH2>(x3_pick_args(a, b, second), idx);
+    spectral_x3c32_body<MIXH2, ST>(x3_pick_args(a, b, second), idx);
 }
 
 // ---- the latency variant: FOUR lines per workgroup, two waves per line (rollout at batch 1: 128 lines per launch) --------------
@@ -2061,6 +2177,22 @@ extern "C" size_t ffno_spectral_x3_pack_bytes(int C, int K) {
     return (C == X3Cfg::C && K >= 1 && K <= 64) ? (size_t)K * X3Cfg::MODE_FRAGS * X3Cfg::FRAG * sizeof(u32x4) : 0;
 }
 
+extern "C" size_t ffno_spectral_x3_dft_frags_bytes(int L, int K) {
+    if (!x3_many_modes(K) || K > 64 || L < 2 || L > 2048) return 0;
+    const X3kDft d = x3k_dft_layout(L, K);
+    return (size_t)(d.nfwd + d.ntiles * d.NST) * 2 * 64 * sizeof(u32x4);
+}
+extern "C" int ffno_spectral_x3_dft_frags(const float* tw, int L, int K, int scale_ck_fwd, int apply_ck_inv, void* frags,
+                                          void* stream) {
+    if (!tw || !frags) return FFNO_EINVAL;
+    if (K > L / 2 + 1) return FFNO_EMODES;
+    if (!ffno_spectral_x3_dft_frags_bytes(L, K)) return FFNO_EUNSUPPORTED;
+    const X3kDft d = x3k_dft_layout(L, K);
+    FFNO_LAUNCH(x3k_dft_frags_kernel, dim3(d.nfwd + d.ntiles * d.NST), dim3(64), 0, (hipStream_t)stream, tw, L, K, scale_ck_fwd,
+                apply_ck_inv, d, reinterpret_cast<u32x4*>(frags));
+    return x3_status();
+}
+
 extern "C" int ffno_spectral_x3_pack(const ffno_x3pack_desc* descs_dev, int n, int C, int max_K, void* stream) {
     if (!descs_dev || n <= 0 || max_K <= 0) return FFNO_EINVAL;
     static_assert(sizeof(ffno_x3pack_desc) == sizeof(X3PackDesc), "descriptor layout");
@@ -2089,13 +2221,18 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16 && b->tile_lines != FFNO_X3_TILE_LATENCY) return FFNO_EINVAL;
     if (b->storage != FFNO_STORE_F32 && b->storage != FFNO_STORE_BF16) return FFNO_EINVAL;
     if (b->storage == FFNO_STORE_BF16 && b->tile_lines == FFNO_X3_TILE_LATENCY) return FFNO_EUNSUPPORTED;
-    // bf16 storage twins: the K <= 16 kernel at width 64, with the fp16x2 mix (or none)
-    if (b->storage == FFNO_STORE_BF16 &&
-        (C != X3Cfg::C || x3_many_modes(b->K) || (b->planes && b->planes_format != FFNO_PLANES_FP16X2)))
-        return FFNO_EUNSUPPORTED;
+    // bf16 storage twins: every fused split kernel (width 64 with <= 64 modes, width 32), on the split-fp16 path -- i.e. WITH
+    // fp16x2 packs (a launch without planes, mode 'low-pass', runs the bf16x3 DFT, which has twins only on the K <= 16 kernel)
+    if (b->storage == FFNO_STORE_BF16) {
+        if (b->planes && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EUNSUPPORTED;
+        if (!b->planes && (C != X3Cfg::C || x3_many_modes(b->K))) return FFNO_EUNSUPPORTED;
+    }
     a = X3Args{b->in, b->out, b->resid, b->spec_save, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
                make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate,
-               b->in_amax, b->out_amax};
+               b->in_amax, b->out_amax,
+               // (only the split-fp16 DFT path of the many-mode kernel reads the table)
+               (C == X3Cfg::C && x3_many_modes(b->K) && b->planes && b->planes_format == FFNO_PLANES_FP16X2)
+                   ? reinterpret_cast<const u32x4*>(b->dft_frags) : nullptr};
     return FFNO_OK;
 }
 
@@ -2108,9 +2245,12 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     const bool h2 = br->planes && br->planes_format == FFNO_PLANES_FP16X2;
     const size_t smem = sizeof(float) * 2 * a.L;
     hipStream_t st = (hipStream_t)stream;
+    const bool b16 = br->storage == FFNO_STORE_BF16;      // (x3_args: only with fp16x2 packs outside the K <= 16 kernel)
     if (C == X3Cfg32::C) {          // width 32: 16 lines per workgroup, two per wave side by side
         const dim3 grid((a.R + 15) / 16);
-        if (h2)
+        if (b16)
+            FFNO_LAUNCH((spectral_x3c32_kernel<true, StBf16>), grid, dim3(512), smem, st, a);
+        else if (h2)
             FFNO_LAUNCH((spectral_x3c32_kernel<true>), grid, dim3(512), smem, st, a);
         else
             FFNO_LAUNCH((spectral_x3c32_kernel<false>), grid, dim3(512), smem, st, a);
@@ -2118,16 +2258,19 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     }
     if (x3_many_modes(a.K)) {      // 17..64 modes: the 4-line tile
         const dim3 grid((a.R + 3) / 4);
-#define X3K_LAUNCH(KKT, H2)                                                                              \
+#define X3K_LAUNCH(...)                                                                                  \
     do {                                                                                                 \
-        const int rc_ = allow_dynamic_lds(spectral_x3k_kernel<KKT, H2>, smem);                           \
+        const int rc_ = allow_dynamic_lds(spectral_x3k_kernel<__VA_ARGS__>, smem);                       \
         if (rc_) return rc_;                                                                             \
-        FFNO_LAUNCH((spectral_x3k_kernel<KKT, H2>), grid, dim3(512), smem, st, a);                       \
+        FFNO_LAUNCH((spectral_x3k_kernel<__VA_ARGS__>), grid, dim3(512), smem, st, a);                   \
     } while (0)
+        const bool tab = a.dft != nullptr;       // (x3_args: only with fp16x2 planes)
         if (a.K <= 32) {
-            if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
+            if (b16 && tab) X3K_LAUNCH(64, true, StBf16, true); else if (b16) X3K_LAUNCH(64, true, StBf16);
+            else if (h2 && tab) X3K_LAUNCH(64, true, StF32, true); else if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
         } else {
-            if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
+            if (b16 && tab) X3K_LAUNCH(128, true, StBf16, true); else if (b16) X3K_LAUNCH(128, true, StBf16);
+            else if (h2 && tab) X3K_LAUNCH(128, true, StF32, true); else if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
         }
 #undef X3K_LAUNCH
         return x3_status();
@@ -2177,9 +2320,13 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         return FFNO_EINVAL;
     const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
     hipStream_t st = (hipStream_t)stream;
+    const bool b16 = ba->storage == FFNO_STORE_BF16;
+    if (b16 && !h2 && (C != X3Cfg::C || x3_many_modes(a.K) || x3_many_modes(b.K))) return FFNO_EUNSUPPORTED;
     if (C == X3Cfg32::C) {
         const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16;
-        if (h2)
+        if (b16)
+            FFNO_LAUNCH((spectral_x3c32_pair_kernel<true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else if (h2)
             FFNO_LAUNCH((spectral_x3c32_pair_kernel<true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
         else
             FFNO_LAUNCH((spectral_x3c32_pair_kernel<false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
@@ -2188,16 +2335,24 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     if (x3_many_modes(a.K) || x3_many_modes(b.K)) {      // 17..64 modes on either axis: both on the 4-line tile
         const int n0 = (a.R + 3) / 4, n1 = (b.R + 3) / 4;
         const dim3 grid(n0 + n1);
-#define X3K_LAUNCH(KKT, H2)                                                                              \
+#define X3K_LAUNCH(...)                                                                                  \
     do {                                                                                                 \
-        const int rc_ = allow_dynamic_lds(spectral_x3k_pair_kernel<KKT, H2>, smem);                      \
+        const int rc_ = allow_dynamic_lds(spectral_x3k_pair_kernel<__VA_ARGS__>, smem);                  \
         if (rc_) return rc_;                                                                             \
-        FFNO_LAUNCH((spectral_x3k_pair_kernel<KKT, H2>), grid, dim3(512), smem, st, a, b, n0, n1);       \
+        FFNO_LAUNCH((spectral_x3k_pair_kernel<__VA_ARGS__>), grid, dim3(512), smem, st, a, b, n0, n1);   \
     } while (0)
-        if (max(a.K, b.K) <= 32) {
-            if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
+        // the table kernel needs BOTH branches' tables, laid out for the launch's tile height (64 / 128 rows): a branch with
+        // <= 16 modes dragged onto this kernel, or <= 32 next to > 32, has none that fits -- then both build on the fly
+        const int kkt = max(a.K, b.K) <= 32 ? 64 : 128;
+        const bool tab = a.dft && b.dft && x3_many_modes(a.K) && x3_many_modes(b.K) && (a.K <= 32 ? 64 : 128) == kkt &&
+                         (b.K <= 32 ? 64 : 128) == kkt;
+        if (!tab) a.dft = b.dft = nullptr;
+        if (kkt == 64) {
+            if (b16 && tab) X3K_LAUNCH(64, true, StBf16, true); else if (b16) X3K_LAUNCH(64, true, StBf16);
+            else if (h2 && tab) X3K_LAUNCH(64, true, StF32, true); else if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
         } else {
-            if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
+            if (b16 && tab) X3K_LAUNCH(128, true, StBf16, true); else if (b16) X3K_LAUNCH(128, true, StBf16);
+            else if (h2 && tab) X3K_LAUNCH(128, true, StF32, true); else if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
         }
 #undef X3K_LAUNCH
         return x3_status();

@@ -224,6 +224,10 @@ class FFNOEngine:
         # the size; gradient passes hold the spectrum tile range-scaled like the feed-forward) or "bf16x3"
         self.x3_mix_split = os.environ.get("FFNO_X3_MIX_SPLIT", "fp16x2")
         self._x3_fmt = None
+        # 17..64 modes: the fused kernel loads its DFT-matrix fragments from a table built once per (L, K, direction) instead of
+        # rebuilding them from the twiddle table for every line (bit-identical results; False = rebuild: tests)
+        self.x3_dft_tables = True
+        self._dft_tabs = {}
         self.x3_min_lines = 1
         self.x3_tile_lines = 0      # lines per workgroup of the fused x3 kernel: 0 = the library chooses, 8 / 16 = forced (tests)
         self.ff_max_workgroups = 0  # persistent workgroups of the feed-forward chain kernels: 0 = one per CU
@@ -244,8 +248,9 @@ class FFNOEngine:
         self.weight_range_check_every = 1
         # storage format of the activation tensors in HBM (include/ffno.h "Storage formats"): "fp32" = the parity path (the
         # reference is precision: 32); "bf16" = the bf16 storage twins of the hot kernels -- half the activation bytes, results
-        # rounded to bf16 wherever a tensor is stored (a throughput variant with its own tolerance).  Available for the paired
-        # split-kernel path (2-D operators, width 64, <= 16 modes, 2-layer feed-forward, no fork heads / LayerNorm / dropout).
+        # rounded to bf16 wherever a tensor is stored (a throughput variant with its own tolerance).  Available on the fused split
+        # kernels of every BASELINE shape (2-D width 64 up to 64 modes, 3-D width 32), 2-layer feed-forward, no fork heads /
+        # LayerNorm / dropout.
         self.storage = os.environ.get("FFNO_STORAGE", "fp32")
 
     def _bf16(self) -> bool:
@@ -316,8 +321,27 @@ class FFNOEngine:
     def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True, rin=None, rout=None):
         """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
         fmt = int(bool(x3 and planes is not None and self._x3_h2()))
+        dft = self._dft_frags(v.L, v.K, fwd) if (fmt and self.x3_dft_tables) else None
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout, self._st())
+                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout, self._st(), 0, _p(dft))
+
+    def _dft_frags(self, L: int, K: int, fwd: bool):
+        """DFT-matrix fragment table of the many-mode fused kernel for (axis length, modes, direction): built once per engine and
+        device on the launch stream (ffno_spectral_x3_dft_frags), then shared by every line, layer and step."""
+        key = (L, K, bool(fwd))
+        tab = self._dft_tabs.get(key)
+        if tab is None:
+            lib = _lib.get_lib()
+            nb = int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) if self.C == 64 else 0      # 0: no table for this shape
+            if nb:
+                tab = torch.empty(nb // 4, dtype=torch.int32, device=self.device)
+                ck_f, ck_i = (0, 1) if fwd else (1, 0)
+                self._k("dft_frags", lib.ffno_spectral_x3_dft_frags, _p(self._twiddle(L)), L, K, ck_f, ck_i, _p(tab),
+                        _lib.current_stream(self.device))
+            else:
+                tab = False
+            self._dft_tabs[key] = tab
+        return tab if tab is not False else None
 
     # ---- range words (include/ffno.h "Range words"): one uint32 per (tensor kind, layer) in ws.RW ---------------------
     def _ranged(self) -> bool:
@@ -444,6 +468,7 @@ class FFNOEngine:
         self._ws_key = None
         self._ws_cache = {}
         self._tw = {}
+        self._dft_tabs = {}
 
     def grad_view(self, name: str) -> torch.Tensor:
         o = self._offsets[name]
@@ -982,13 +1007,13 @@ class FFNOEngine:
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
                            and not self.layer_norm)
         bf16 = self._bf16()
-        if bf16 and not (conc and not singles and fused[pair[0]] and x3pair and self._h2() and self._x3_h2() and self._ffx()
-                         and C == 64 and H == 256 and max(v.K for v in ws.views) <= 16 and full and not self.use_fork
-                         and not self.layer_norm and self.dropout == 0.0 and self.in_dropout == 0.0):
+        if bf16 and not (all(fused) and all(x3) and self._h2() and self._x3_h2() and self._ffx() and self.spectral == "factorized"
+                         and (C, H) in ((64, 256), (32, 128)) and full and not self.use_fork and not self.layer_norm
+                         and self.dropout == 0.0 and self.in_dropout == 0.0):
             raise NotImplementedError(
-                "storage='bf16' covers the paired split-kernel path of the 2-D operator (width 64, factor 4, <= 16 modes, "
-                "mode='full', fp16x2 splits, 2-layer feed-forward without fork heads / LayerNorm / dropout); this configuration "
-                "runs with storage='fp32'")
+                "storage='bf16' covers the fused split-kernel path of the factorized operators (2-D grids / meshes and the 3-D mesh: "
+                "width 64 with up to 64 modes or width 32 with up to 16, factor 4, mode='full', fp16x2 splits, 2-layer feed-forward "
+                "without fork heads / LayerNorm / dropout); this configuration runs with storage='fp32'")
         lin_in = self.linears["in_proj."]
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         if pm is not None:

@@ -194,11 +194,23 @@ typedef struct ffno_fused_branch {
     uint32_t* out_amax;      /* optional: receives max |out| of what this branch stores (the fused kernels of both families and
                                 the x3 stage kernels; the fp32 stage kernels ignore it: fold their output with ffno_amax) */
     int32_t storage;         /* FFNO_STORE_F32 (0) / FFNO_STORE_BF16: format of in / out / resid ("Storage formats" above;
-                                ffno_spectral_x3[_pair] with C = 64, K <= 16 and FP16X2 or no planes; spec_save stays fp32) */
+                                ffno_spectral_x3[_pair]: every fused split kernel with FP16X2 planes, the K <= 16 kernel also
+                                without planes; spec_save stays fp32) */
+    int32_t pad_;
+    const void* dft_frags;   /* optional (17..64 modes with FP16X2 planes): the DFT-matrix fragments of this branch's (L, K, flags)
+                                as ffno_spectral_x3_dft_frags wrote them -- the kernel then loads them instead of rebuilding them
+                                from the twiddle table for every line (bit-identical results); NULL = build on the fly */
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
 #define FFNO_X3_TILE_LATENCY 1
+/* DFT-matrix fragment table of the many-mode fused kernel (C = 64, 17..64 modes, FP16X2 planes) for one axis length L, mode
+ * count K and direction (scale_ck_fwd / apply_ck_inv as the launch will pass them): every (row tile, 64-sample chunk, k-step)
+ * fragment of the truncated forward DFT matrix and every (32-sample tile, k-step) fragment of the zero-padded inverse, already
+ * split into fp16 planes in MFMA lane order.  Built once per (L, K, direction) -- rfft / irfft twiddles do not change
+ * (grid_2d.py:58,72,76,90) -- and shared by all lines, layers and steps.  `tw` = the device twiddle table of length L. */
+size_t ffno_spectral_x3_dft_frags_bytes(int L, int K);
+int ffno_spectral_x3_dft_frags(const float* tw, int L, int K, int scale_ck_fwd, int apply_ck_inv, void* frags, void* stream);
 int ffno_spectral_fused_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int scale_ck_fwd,
                              int apply_ck_inv, int conj_transpose, void* stream);
 /* ---------------------------------------------------------------------------------------------

@@ -562,6 +562,59 @@ def test_spectral_x3_fused_many_modes(be, B, M, N, K, axis, direction, fmt):
     assert rel_l2(be.get(out), 2 * ref + resid) < TOL
 
 
+@pytest.mark.parametrize("B,M,N,Ka,Kb", [(1, 40, 48, 20, 18), (1, 36, 70, 34, 17), (2, 256, 256, 32, 32), (1, 130, 136, 64, 40), (1, 44, 40, 20, 12)])
+@pytest.mark.parametrize("direction", ["fwd", "adj"])
+def test_spectral_x3_many_modes_dft_table_is_bit_identical(be, B, M, N, Ka, Kb, direction):
+    """ffno_spectral_x3_dft_frags: the many-mode kernel with its DFT-matrix fragments LOADED from the table built once per (L, K,
+    direction) against the same kernel building them from the twiddle table for every line -- outputs, saved spectra and range
+    words bit for bit, single launches of both axes and the paired launch (also a pair whose axes need different tile heights,
+    or one axis with <= 16 modes: the library then falls back to building on the fly for both)."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and (B > 1 or M > 100 or (direction == "adj" and Ka > 30)):
+        pytest.skip("emulator time budget (the GPU run covers all)")
+    C = 64
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + Ka)
+    x, resid = (rs.standard_normal((B, M, N, C)).astype(np.float32) for _ in range(2))
+    dx, dres = be.put(x), be.put(resid)
+    xw = be.zeros(1, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(xw), None) == 0
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br, keep = [], []
+    for axis, K in ((0, Ka), (1, Kb)):
+        L = N if axis == 0 else M
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        pk_f, pk_a, kp = _x3_pack(be, w, K, fmt=1)
+        tw = be.twiddle(L)
+        nb = int(lib.ffno_spectral_x3_dft_frags_bytes(L, K))
+        assert (nb > 0) == (K > 16)
+        tab = None
+        if nb:
+            tab = be.zeros((nb // 4,), np.uint32)
+            assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
+        keep += [kp, tw, tab]
+        br.append(dict(axis=axis, K=K, R=B * M if axis == 0 else B * N, tw=tw, tab=tab, planes=pk_a if direction == "adj" else pk_f))
+    assert lib.ffno_spectral_x3_dft_frags(p(br[0]["tw"]), N, N // 2 + 2, 0, 1, p(keep[2] if keep[2] is not None else keep[1]), None) == -3
+
+    def run(with_tab, paired):
+        outs, sv = [be.empty(x.shape), be.empty(x.shape)], [be.empty((b["K"], b["R"], 2, C)) for b in br]
+        words = [be.zeros(1, np.uint32), be.zeros(1, np.uint32)]
+        ds = [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"]), p(b["tw"]), B, M, N, b["K"],
+                          b["axis"], 0, 1, 0, p(xw), p(words[i]), 0, 0, p(b["tab"]) if with_tab else None) for i, b in enumerate(br)]
+        if paired:
+            assert lib.ffno_spectral_x3_pair(ctypes.byref(ds[0]), ctypes.byref(ds[1]), C, fwd_ck, inv_ck, conj, 3, None) == 0
+        else:
+            for d in ds:
+                assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
+        return [be.get(t).copy() for t in outs + sv] + [np.asarray(be.get(t)).copy() for t in words]
+
+    ref = run(False, False)
+    assert all(np.all(np.isfinite(a)) for a in ref[:4])
+    for paired in (False, True):
+        for a, b in zip(run(True, paired), ref):
+            np.testing.assert_array_equal(a, b)
+
+
 @pytest.mark.parametrize("B,M,N,K", [(1, 8, 12, 3), (1, 64, 64, 16), (2, 6, 10, 5), (1, 3, 72, 16), (3, 5, 7, 2), (1, 13, 9, 4)])
 @pytest.mark.parametrize("direction,fmt", [("fwd", 1), ("adj", 1), ("fwd", 0), ("lowpass", 1)])
 def test_spectral_x3_latency_tiles_are_bit_identical(be, B, M, N, K, direction, fmt):

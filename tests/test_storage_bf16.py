@@ -56,10 +56,9 @@ def test_rounding_helper_is_round_to_nearest_even():
 
 
 # ---- feed-forward kernels ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("P", [70, 200])
-def test_ffh_twins_are_the_rounded_fp32_kernels(be, P):
+@pytest.mark.parametrize("P,C,H", [(70, 64, 256), (200, 64, 256), (90, 32, 128)])
+def test_ffh_twins_are_the_rounded_fp32_kernels(be, P, C, H):
     lib, p = be.lib, be.ptr
-    C, H = 64, 256
     rs = np.random.RandomState(P)
     sa_h, sa = bf16_data(rs, (P, C))
     sb_h, sb = bf16_data(rs, (P, C))
@@ -120,7 +119,7 @@ def test_ffh_twins_are_the_rounded_fp32_kernels(be, P):
 
 def test_twins_refuse_what_they_do_not_cover(be):
     lib, p = be.lib, be.ptr
-    P, C, H = 40, 32, 128
+    P, C, H = 40, 32, 64            # (width 32 with factor 2: an fp32-storage instance without a bf16 twin)
     rs = np.random.RandomState(0)
     W1, W2 = rs.standard_normal((H, C)).astype(np.float32), rs.standard_normal((C, H)).astype(np.float32)
     (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
@@ -134,11 +133,16 @@ def test_twins_refuse_what_they_do_not_cover(be):
 
 
 # ---- fused split spectral branch --------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,M,N,K,tile", [(2, 12, 16, 5, 0), (1, 40, 8, 4, 16), (3, 9, 10, 5, 8)])
-def test_spectral_x3_twin_is_the_rounded_fp32_kernel(be, B, M, N, K, tile):
-    """Single launches of both axes (forward flags and adjoint flags, with and without a residual) and the paired launch."""
+@pytest.mark.parametrize("B,M,N,K,tile,C", [(2, 12, 16, 5, 0, 64), (1, 40, 8, 4, 16, 64), (3, 9, 10, 5, 8, 64),
+                                            (1, 40, 44, 20, 0, 64), (1, 70, 72, 34, 0, 64),      # 17..64 modes: spectral_x3k
+                                            (2, 12, 16, 5, 0, 32), (1, 9, 40, 4, 0, 32)])        # width 32: spectral_x3c32
+def test_spectral_x3_twin_is_the_rounded_fp32_kernel(be, B, M, N, K, tile, C):
+    """Single launches of both axes (forward flags and adjoint flags, with and without a residual) and the paired launch --
+    on the K <= 16 kernel, the many-mode kernel (VERDICT r03 #5a: BASELINE configs[3] shapes) and the width-32 kernel
+    (configs[4])."""
     lib, p = be.lib, be.ptr
-    C = 64
+    if be.kind == "emu" and K > 30:
+        pytest.skip("emulator time budget (the GPU run covers it)")
     rs = np.random.RandomState(B * 100 + M)
     x_h, x = bf16_data(rs, (B, M, N, C))
     r_h, r = bf16_data(rs, (B, M, N, C))
@@ -177,7 +181,7 @@ def test_spectral_x3_twin_is_the_rounded_fp32_kernel(be, B, M, N, K, tile):
     assert lib.ffno_spectral_x3_pair(ctypes.byref(ba), ctypes.byref(bb), C, 0, 1, 0, 3, None) == 0
     np.testing.assert_array_equal(get16(be, oa), outs[0])
     np.testing.assert_array_equal(get16(be, ob), outs[1])
-    # mixed formats in one pair, > 16 modes, bf16x3 planes: refused
+    # mixed formats in one pair, bf16x3 planes: refused
     bb.storage = 0
     assert lib.ffno_spectral_x3_pair(ctypes.byref(ba), ctypes.byref(bb), C, 0, 1, 0, 3, None) == -1
     ba.planes_format = 0
@@ -185,9 +189,10 @@ def test_spectral_x3_twin_is_the_rounded_fp32_kernel(be, B, M, N, K, tile):
 
 
 # ---- lift / head ---------------------------------------------------------------------------------------------------------------
-def test_lift_and_head_twins(be):
+@pytest.mark.parametrize("C,O", [(64, 1), (32, 4)])
+def test_lift_and_head_twins(be, C, O):
     lib, p = be.lib, be.ptr
-    P, Cin, C, O = 300, 3, 64, 1
+    P, Cin = 300, 3
     rs = np.random.RandomState(4)
     x = rs.standard_normal((P, Cin)).astype(np.float32)
     W, b = rs.standard_normal((C, Cin)).astype(np.float32), rs.standard_normal(C).astype(np.float32)
@@ -197,7 +202,7 @@ def test_lift_and_head_twins(be):
     assert lib.ffno_lift_fwd_bf16(p(be.put(x)), p(be.put(W)), p(be.put(b)), p(o16), P, Cin, C, None, p(w16), None) == 0
     np.testing.assert_array_equal(get16(be, o16), to_bf16(be.get(o32)))
     assert np.asarray(be.get(w16)).view(np.float32)[0] == np.abs(from_bf16(get16(be, o16))).max()
-    assert lib.ffno_lift_fwd_bf16(p(be.put(x)), p(be.put(W[:32])), p(be.put(b[:32])), p(o16), P, Cin, 32, None, None, None) == -2
+    assert lib.ffno_lift_fwd_bf16(p(be.put(x)), p(be.put(W[:16])), p(be.put(b[:16])), p(o16), P, Cin, 16, None, None, None) == -2
     # head forward / backward on a bf16 activation
     a_h, a = bf16_data(rs, (P, C))
     fold = rs.standard_normal(O * (C + 1)).astype(np.float32)
@@ -270,6 +275,56 @@ def test_block_on_bf16_storage_against_the_oracle(host_device):
         worst = max(worst, rel_l2(g, r))
     print(f"worst parameter-gradient rel-L2 on bf16 storage vs oracle: {worst:.2e}")
     assert worst < BF16_GRAD_TOL
+
+
+def test_block_with_many_modes_on_bf16_storage(host_device):
+    """17..64 modes (the fused many-mode kernel: BASELINE configs[3] runs 32, the reference's 256 x 256 experiment 64) on bf16
+    storage against the fp32 oracle, forward and every parameter gradient inside the band of the format."""
+    kw = dict(KW, modes=18, n_layers=2)
+    seed, B, M, N = 5, 1, 36, 40
+    sd_np = gu.make_block_state_dict(kw, seed)
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
+    ref_out, _, ref_grads = ou.oracle_block_run(kw, 0, B, M, N, io=(x_np, t_np), sd_np=sd_np)
+    blk, eng = _block(kw, sd_np, host_device, "bf16")
+    pred = blk(torch.from_numpy(x_np).to(host_device))["forecast"]
+    orc.lp_rel_loss(pred, torch.from_numpy(t_np).to(host_device)).backward()
+    assert eng._saved_x3 == ([True, True], True) and eng._workspace(B, (M, N), True).X.dtype == torch.bfloat16
+    e = rel_l2(pred.detach().cpu().numpy(), ref_out["forecast"].detach().numpy())
+    named = dict(blk.named_parameters())
+    worst = max(rel_l2(named[n].grad.cpu().numpy(), np.asarray(ref_grads[n])) for n in eng.param_names)
+    print(f"many modes on bf16 storage: forward {e:.2e}, worst gradient {worst:.2e}")
+    assert 1e-5 < e < BF16_FWD_TOL and worst < BF16_GRAD_TOL
+
+
+def test_mesh3d_on_bf16_storage(host_device):
+    """The 3-D mesh operator (width 32: BASELINE configs[4]) on bf16 storage: one single-axis launch + one paired launch per
+    layer and direction on the width-32 split kernels, the width-32 feed-forward twins, padded lift / cropped head."""
+    from fourierflow_amd.modules import FNOFactorizedMesh3D
+    kw = dict(modes_x=3, modes_y=2, modes_z=2, width=32, input_dim=4, output_dim=2, n_layers=2, share_weight=False,
+              factor=4, ff_weight_norm=True, n_ff_layers=2, layer_norm=False)
+    seed, B, S = 9, 1, (5, 4, 6)
+    sd_np = gu.make_mesh3d_state_dict(kw, seed)
+    x_np, t_np = gu.make_mesh3d_io(kw, seed, B, S)
+    sd, uniq = ou.torch_state_dict(sd_np)
+    ref = orc.ffno_mesh3d(sd, torch.from_numpy(x_np), modes=(3, 2, 2), n_layers=2)
+    orc.lp_rel_loss(ref, torch.from_numpy(t_np)).backward()
+    res = {}
+    for storage in ("fp32", "bf16"):
+        blk = FNOFactorizedMesh3D(**kw)
+        blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+        blk = blk.to(host_device)
+        eng = blk.engine()
+        eng.use_x3, eng.x3_min_lines, eng.storage = True, 1, storage
+        out = blk(torch.from_numpy(x_np).to(host_device))
+        orc.lp_rel_loss(out, torch.from_numpy(t_np).to(host_device)).backward()
+        assert all(eng._saved_x3[0])
+        named = dict(blk.named_parameters())
+        res[storage] = (rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()),
+                        max(rel_l2(named[n].grad.cpu().numpy(), uniq[n].grad.numpy()) for n in eng.param_names))
+    print(f"mesh3d: fp32 storage forward {res['fp32'][0]:.2e} / worst gradient {res['fp32'][1]:.2e}; "
+          f"bf16 storage {res['bf16'][0]:.2e} / {res['bf16'][1]:.2e}")
+    assert res["fp32"][0] < 1e-5
+    assert 1e-5 < res["bf16"][0] < BF16_FWD_TOL and res["bf16"][1] < BF16_GRAD_TOL
 
 
 def test_bf16_storage_is_refused_outside_its_path(host_device):

@@ -11,6 +11,22 @@ for st in "$@"; do
     newtests)
       timeout 1500 python -m pytest tests/test_bench_geometry.py tests/test_trainer.py tests/test_rollout.py tests/test_capi_exports.py -m gpu -q -s --tb=short -p no:cacheprovider > gpurun_out/pytest_new.log 2>&1
       echo "[r4] new tests rc=$?"; grep -E "^\[|passed|failed|Error|error" gpurun_out/pytest_new.log | tail -40 ;;
+    spectests)
+      timeout 900 python -m pytest tests/test_kernels_spectral.py tests/test_storage_bf16.py -m gpu -q -x --tb=short -p no:cacheprovider > gpurun_out/pytest_spec.log 2>&1
+      echo "[r4] spectral tests rc=$?"; tail -n 4 gpurun_out/pytest_spec.log
+      timeout 900 python -m pytest tests/test_bench_geometry.py -m gpu -q -s --tb=short -p no:cacheprovider -k "B32 or 12L or mesh3d or bf16" > gpurun_out/pytest_geo.log 2>&1
+      echo "[r4] geometry tests rc=$?"; grep -E "^\[|passed|failed" gpurun_out/pytest_geo.log | tail -12 ;;
+    sq256)
+      # SQ counters of the 256 x 256 / 64-mode step (its own PMC pass: kernel-trace + pmc only)
+      rm -rf gpurun_out/pmc_SQ256
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_SQ256" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2 > "$OLDPWD/gpurun_out/pmc_SQ256.log" 2>&1)
+      echo "[r4] pmc SQ256 rc=$?"
+      db=$(find gpurun_out/pmc_SQ256 -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_SQ256.md 2>&1; head -n 14 gpurun_out/pmc_SQ256.md | cut -c1-260
+      rm -rf gpurun_out/pmc_SQ2
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d "$OLDPWD/gpurun_out/pmc_SQ2" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2 > "$OLDPWD/gpurun_out/pmc_SQ2.log" 2>&1)
+      echo "[r4] pmc SQ2 rc=$?"; tail -n 3 gpurun_out/pmc_SQ2.log | cut -c1-200
+      db=$(find gpurun_out/pmc_SQ2 -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_SQ2.md 2>&1; head -n 14 gpurun_out/pmc_SQ2.md | cut -c1-260
+      find gpurun_out/pmc_SQ256 gpurun_out/pmc_SQ2 -name "*.db" -size +20M -delete ;;
     benchfast)
       timeout 600 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/bench_fast.log 2> gpurun_out/bench_fast.err
       echo "[r4] benchfast rc=$?"; tail -n 12 gpurun_out/bench_fast.err; python - <<'PY'
