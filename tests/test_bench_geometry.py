@@ -249,5 +249,7 @@ def test_secondary_shapes_on_bf16_storage():
 
 
 # bands of test_secondary_shapes_on_bf16_storage (set from the first MI355X run of round 4, see the docstring)
-BF16_2D_FWD, BF16_2D_MED, BF16_2D_WORST = 1e-2, 5e-2, 3e-1
-BF16_3D_FWD, BF16_3D_MED, BF16_3D_WORST = 1e-2, 5e-2, 3e-1
+# observed on MI355X (round 4): 256 x 256 forward 2.36e-4, gradients median 8.5e-4 / worst 1.63e-2 (in_proj.weight_v);
+#                              64^3      forward 7.12e-4, gradients median 1.02e-3 / worst 2.03e-3
+BF16_2D_FWD, BF16_2D_MED, BF16_2D_WORST = 8e-4, 3e-3, 5e-2
+BF16_3D_FWD, BF16_3D_MED, BF16_3D_WORST = 2.2e-3, 3.1e-3, 6.1e-3
