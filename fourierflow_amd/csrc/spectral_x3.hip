@@ -1213,7 +1213,7 @@ struct X3kDft {
 };
 static inline X3kDft x3k_dft_layout(int L, int K) {
     X3kDft d;
-    d.KKT = K <= 32 ? 64 : 128;
+    d.KKT = K <= 16 ? 32 : (K <= 32 ? 64 : 128);      // (<= 16 modes: the latency kernel's tile height)
     d.RT = d.KKT / 32, d.NST = d.KKT / 16;
     d.nchunks = (L + 63) >> 6, d.ntiles = (L + 31) >> 5;
     d.nfwd = d.RT * d.nchunks * 4;
@@ -1311,7 +1311,62 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     __syncthreads();
 
     // ---------------- phase 1 ----------------
-    if constexpr (DFTH2) {
+    if constexpr (TAB) {
+        // With the fragments coming from the table a wave can afford ALL row tiles of its line, so the two waves of a line split
+        // its CHANNELS instead of its row tiles: wave (line, sub) requests, splits and transforms channels [32 sub, 32 sub + 32)
+        // only -- the line crosses the load path once (not once per wave), and each wave splits half the samples.
+        const unsigned loc = (unsigned)((lm.base(min(line, R - 1)) + 32 * sub + j) * ST::BYTES);
+        typename ST::Raw1 raw[4][8];
+        auto load_rows = [&](int chunk, int u) {
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                const int n = min(16 * (4 * chunk + u) + 8 * half + e, L - 1);
+                raw[u][e] = ST::ldr1(reinterpret_cast<const typename ST::T*>(reinterpret_cast<const char*>(A.in) + (loc + (unsigned)n * esb)));
+            }
+        };
+        FFNO_UNROLL
+        for (int u = 0; u < 4; ++u) load_rows(0, u);
+        f32x16 acc[RT];
+        Hf3 Fn[RT];
+        FFNO_UNROLL
+        for (int rt = 0; rt < RT; ++rt) {
+            acc[rt] = zero16();
+            Fn[rt] = x3k_load_dft(A.dft, (rt * nchunks) * 4, lane);
+        }
+        FFNO_NOUNROLL
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool more = chunk + 1 < nchunks;
+            FFNO_UNROLL
+            for (int u = 0; u < 4; ++u) {
+                float w[8];
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) w[e] = ST::w1(raw[u][e]) * sx;
+                const Hf2 b = split2_8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+                if (more) load_rows(chunk + 1, u);
+                const int nu = u == 3 ? 0 : u + 1, nc = u == 3 ? min(chunk + 1, nchunks - 1) : chunk;
+                FFNO_UNROLL
+                for (int rt = 0; rt < RT; ++rt) {
+                    const Hf3 Fc = Fn[rt];
+                    Fn[rt] = x3k_load_dft(A.dft, (rt * nchunks + nc) * 4 + nu, lane);      // one k-step ahead
+                    if (32 * rt < 2 * K) acc[rt] = mfma_h2s(Fc, b, acc[rt]);
+                }
+            }
+        }
+        float* xs = XS + lw * LSF + 32 * sub + j;
+        FFNO_UNROLL
+        for (int rt = 0; rt < RT; ++rt) {
+            if (32 * rt >= 2 * K) continue;
+            FFNO_UNROLL
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * rt + drow(r, half);
+                if (row < 2 * K) {
+                    const float v = acc[rt][r] * unx;
+                    xs[row * RS] = v * rs;
+                    if (A.spec_save && live) A.spec_save[(((long)(row >> 1) * R + line) * 2 + (row & 1)) * C + 32 * sub + j] = v;
+                }
+            }
+        }
+    } else if constexpr (DFTH2) {
         // The line is requested and split ONCE per wave; every k-step's samples then meet the DFT-matrix fragments of ALL the
         // wave's row tiles (rt = sub, sub + 2, ..: one at <= 32 modes, two at 33..64), which are built on the fly from the
         // twiddle table with a table index that is carried from sample to sample and from chunk to chunk (no modulo in the loop).
@@ -1345,11 +1400,6 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
         f32x16 acc[RTW][2];
         FFNO_UNROLL
         for (int i = 0; i < RTW; ++i) acc[i][0] = zero16(), acc[i][1] = zero16();
-        Hf3 Fn[RTW];
-        if constexpr (TAB) {
-            FFNO_UNROLL
-            for (int i = 0; i < RTW; ++i) Fn[i] = x3k_load_dft(A.dft, ((sub + 2 * i) * nchunks) * 4, lane);
-        }
         FFNO_NOUNROLL
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const bool more = chunk + 1 < nchunks;
@@ -1364,21 +1414,6 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
                 const Hf2 b0 = split2_8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
                 const Hf2 b1 = split2_8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
                 if (more) load_rows(chunk + 1, u);
-                if constexpr (TAB) {      // fragments from the table, requested one k-step ahead (Fn), consumed here (Fc)
-                    Hf3 Fc[RTW];
-                    FFNO_UNROLL
-                    for (int i = 0; i < RTW; ++i) Fc[i] = Fn[i];
-                    const int nu = u == 3 ? 0 : u + 1, nc = u == 3 ? min(chunk + 1, nchunks - 1) : chunk;
-                    FFNO_UNROLL
-                    for (int i = 0; i < RTW; ++i) Fn[i] = x3k_load_dft(A.dft, ((sub + 2 * i) * nchunks + nc) * 4 + nu, lane);
-                    FFNO_UNROLL
-                    for (int i = 0; i < RTW; ++i) {
-                        if (act[i]) {
-                            acc[i][0] = mfma_h2s(Fc[i], b0, acc[i][0]);
-                            acc[i][1] = mfma_h2s(Fc[i], b1, acc[i][1]);
-                        }
-                    }
-                } else
                 FFNO_UNROLL
                 for (int i = 0; i < RTW; ++i) {
                     float f[8];
@@ -1820,8 +1855,9 @@ __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Ar
 // transforms and stores column tile t of its line (the even or the odd channels: half of the operand splits and MFMAs of phases
 // 1 and 3); and the ring of weight fragments holds a WHOLE mode (16 fragments in flight per wave instead of 8, refilled with the
 // wave's next mode as they are consumed), which halves the L2 round trips the mix waits for.  256 registers per wave.
-template <bool MIXH2>
+template <bool MIXH2, bool TAB = false>
 __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
+    static_assert(!TAB || MIXH2, "the fragment table holds fp16 planes");
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF, NL = 4, NWS = 8;
     __shared__ __attribute__((aligned(16))) float XS[NL * F::LSF];
@@ -1896,7 +1932,12 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
         f32x16 acc = zero16();
         FFNO_NOUNROLL
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            build_F(chunk);
+            if constexpr (TAB) {      // the four fragments of the chunk from the table (built once per (L, K, direction))
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) Ff[u] = x3k_load_dft(A.dft, chunk * 4 + u, lane);
+            } else {
+                build_F(chunk);
+            }
             const bool more = chunk + 1 < nchunks;
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
@@ -2079,6 +2120,11 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
             // inverse-DFT matrix fragments of this 32-row output tile: row n, slot e of k-step st <-> kk = (mode, part)
             const int n = 32 * rt + j;
             f32x16 o = zero16();
+            Hf3 Gt[2];
+            if constexpr (TAB) {
+                FFNO_UNROLL
+                for (int st = 0; st < 2; ++st) Gt[st] = x3k_load_dft(A.dft, ((L + 63) >> 6) * 4 + rt * 2 + st, lane);
+            }
             FFNO_UNROLL
             for (int st = 0; st < 2; ++st) {
                 float g[8];
@@ -2094,7 +2140,9 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
                         if (idx >= L) idx -= L;
                     }
                 }
-                if constexpr (DFTH2)
+                if constexpr (TAB)
+                    o = mfma_h2s(Gt[st], y[st], o);
+                else if constexpr (DFTH2)
                     o = mfma_h2s(split2s_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]), y[st], o);
                 else
                     o = mfma_x3(split3_8(g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]), y[st], o);
@@ -2116,11 +2164,11 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
     if (A.out_amax) range_fold(omax, rfold, NWS, A.out_amax);
 }
 
-template <bool MIXH2>
+template <bool MIXH2, bool TAB = false>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_kernel(X3Args a) {
-    spectral_x3s_body<MIXH2>(a, blockIdx.x);
+    spectral_x3s_body<MIXH2, TAB>(a, blockIdx.x);
 }
-template <bool MIXH2>
+template <bool MIXH2, bool TAB = false>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
     const int w = blockIdx.x, nmin = min(n0, n1);
     bool second;
@@ -2132,7 +2180,7 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_pair_
         second = n1 > n0;
         idx = w - nmin;
     }
-    spectral_x3s_body<MIXH2>(x3_pick_args(a, b, second), idx);
+    spectral_x3s_body<MIXH2, TAB>(x3_pick_args(a, b, second), idx);
 }
 
 // 8-line tiles while the launch still fits one round of workgroups (one per CU of the device): more CUs busy, same weight
@@ -2178,7 +2226,7 @@ extern "C" size_t ffno_spectral_x3_pack_bytes(int C, int K) {
 }
 
 extern "C" size_t ffno_spectral_x3_dft_frags_bytes(int L, int K) {
-    if (!x3_many_modes(K) || K > 64 || L < 2 || L > 2048) return 0;
+    if (K < 1 || K > 64 || L < 2 || L > 2048) return 0;
     const X3kDft d = x3k_dft_layout(L, K);
     return (size_t)(d.nfwd + d.ntiles * d.NST) * 2 * 64 * sizeof(u32x4);
 }
@@ -2231,7 +2279,7 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
                make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate,
                b->in_amax, b->out_amax,
                // (only the split-fp16 DFT path of the many-mode kernel reads the table)
-               (C == X3Cfg::C && x3_many_modes(b->K) && b->planes && b->planes_format == FFNO_PLANES_FP16X2)
+               (C == X3Cfg::C && b->planes && b->planes_format == FFNO_PLANES_FP16X2)
                    ? reinterpret_cast<const u32x4*>(b->dft_frags) : nullptr};
     return FFNO_OK;
 }
@@ -2277,7 +2325,9 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     }
     if (x3_latency_tiles(a.R, 0, br->tile_lines, br->storage)) {
         const dim3 grid((a.R + 3) / 4);
-        if (h2)
+        if (h2 && a.dft)
+            FFNO_LAUNCH((spectral_x3s_kernel<true, true>), grid, dim3(512), smem, st, a);
+        else if (h2)
             FFNO_LAUNCH((spectral_x3s_kernel<true>), grid, dim3(512), smem, st, a);
         else
             FFNO_LAUNCH((spectral_x3s_kernel<false>), grid, dim3(512), smem, st, a);
@@ -2368,7 +2418,9 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     };
     if (x3_latency_tiles(a.R, b.R, ba->tile_lines, ba->storage)) {
         const int n0 = (a.R + 3) / 4, n1 = (b.R + 3) / 4;
-        if (h2)
+        if (h2 && a.dft && b.dft)
+            FFNO_LAUNCH((spectral_x3s_pair_kernel<true, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else if (h2)
             FFNO_LAUNCH((spectral_x3s_pair_kernel<true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
         else
             FFNO_LAUNCH((spectral_x3s_pair_kernel<false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);

@@ -197,14 +197,16 @@ typedef struct ffno_fused_branch {
                                 ffno_spectral_x3[_pair]: every fused split kernel with FP16X2 planes, the K <= 16 kernel also
                                 without planes; spec_save stays fp32) */
     int32_t pad_;
-    const void* dft_frags;   /* optional (17..64 modes with FP16X2 planes): the DFT-matrix fragments of this branch's (L, K, flags)
+    const void* dft_frags;   /* optional (FP16X2 planes; read by the many-mode kernel, 17..64 modes, and by the 4-line latency
+                                kernel of the <= 16-mode shapes): the DFT-matrix fragments of this branch's (L, K, flags)
                                 as ffno_spectral_x3_dft_frags wrote them -- the kernel then loads them instead of rebuilding them
                                 from the twiddle table for every line (bit-identical results); NULL = build on the fly */
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
 #define FFNO_X3_TILE_LATENCY 1
-/* DFT-matrix fragment table of the many-mode fused kernel (C = 64, 17..64 modes, FP16X2 planes) for one axis length L, mode
+/* DFT-matrix fragment table of the fused kernels that give a wave ONE line (C = 64, FP16X2 planes: the many-mode kernel, 17..64
+ * modes, and the latency kernel FFNO_X3_TILE_LATENCY of the <= 16-mode shapes) for one axis length L, mode
  * count K and direction (scale_ck_fwd / apply_ck_inv as the launch will pass them): every (row tile, 64-sample chunk, k-step)
  * fragment of the truncated forward DFT matrix and every (32-sample tile, k-step) fragment of the zero-padded inverse, already
  * split into fp16 planes in MFMA lane order.  Built once per (L, K, direction) -- rfft / irfft twiddles do not change

@@ -587,14 +587,12 @@ def test_spectral_x3_many_modes_dft_table_is_bit_identical(be, B, M, N, Ka, Kb, 
         pk_f, pk_a, kp = _x3_pack(be, w, K, fmt=1)
         tw = be.twiddle(L)
         nb = int(lib.ffno_spectral_x3_dft_frags_bytes(L, K))
-        assert (nb > 0) == (K > 16)
-        tab = None
-        if nb:
-            tab = be.zeros((nb // 4,), np.uint32)
-            assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
+        assert nb > 0
+        tab = be.zeros((nb // 4,), np.uint32)
+        assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
         keep += [kp, tw, tab]
         br.append(dict(axis=axis, K=K, R=B * M if axis == 0 else B * N, tw=tw, tab=tab, planes=pk_a if direction == "adj" else pk_f))
-    assert lib.ffno_spectral_x3_dft_frags(p(br[0]["tw"]), N, N // 2 + 2, 0, 1, p(keep[2] if keep[2] is not None else keep[1]), None) == -3
+    assert lib.ffno_spectral_x3_dft_frags(p(br[0]["tw"]), N, N // 2 + 2, 0, 1, p(keep[2]), None) == -3
 
     def run(with_tab, paired):
         outs, sv = [be.empty(x.shape), be.empty(x.shape)], [be.empty((b["K"], b["R"], 2, C)) for b in br]
@@ -644,25 +642,34 @@ def test_spectral_x3_latency_tiles_are_bit_identical(be, B, M, N, K, direction, 
         planes = None if direction == "lowpass" else (pk_a if direction == "adj" else pk_f)
         tw = be.twiddle(L)
         keep += [k_, pk_f, pk_a, tw]
+        # (tile "1t": the latency kernel loading its DFT-matrix fragments from the table of ffno_spectral_x3_dft_frags)
+        tab = be.zeros((int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) // 4,), np.uint32)
+        assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
+        keep.append(tab)
         got = {}
-        for tile in (8, 1):
+        for tag in (8, 1, "1t"):
+            tile, dft = (1, p(tab)) if tag == "1t" else (tag, None)
             out, spec, word = be.empty(x.shape), be.empty((K, R, 2, C)), be.zeros(1, np.uint32)
-            d = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, tile, p(word_in), p(word))
+            d = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, tile, p(word_in), p(word), 0, 0, dft)
             assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
             first = be.get(out).copy()
-            d = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1, fmt, tile, p(word_in), None)
+            d = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1, fmt, tile, p(word_in), None, 0, 0, dft)
             assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
-            got[tile] = (first, be.get(spec).copy(), np.asarray(be.get(word)).copy(), be.get(out).copy())
+            got[tag] = (first, be.get(spec).copy(), np.asarray(be.get(word)).copy(), be.get(out).copy())
         assert not np.isnan(got[1][0]).any()
-        for a, b in zip(got[8], got[1]):
-            np.testing.assert_array_equal(a, b)
-        br[axis] = (planes, tw, got[1][0])
+        for tag in (1, "1t"):
+            for a, b in zip(got[8], got[tag]):
+                np.testing.assert_array_equal(a, b)
+        br[axis] = (planes, tw, got[1][0], tab)
     oa, ob = be.empty(x.shape), be.empty(x.shape)
-    da = FusedBranch(p(dx), p(oa), None, None, p(br[0][0]), p(br[0][1]), B, M, N, K, 0, 0, fmt, 1, p(word_in), None)
-    db = FusedBranch(p(dx), p(ob), None, None, p(br[1][0]), p(br[1][1]), B, M, N, K, 1, 0, fmt, 1, p(word_in), None)
-    assert lib.ffno_spectral_x3_pair(ctypes.byref(da), ctypes.byref(db), C, fwd_ck, inv_ck, conj, 3, None) == 0
-    np.testing.assert_array_equal(be.get(oa), br[0][2])
-    np.testing.assert_array_equal(be.get(ob), br[1][2])
+    for with_tab in (False, True):
+        da = FusedBranch(p(dx), p(oa), None, None, p(br[0][0]), p(br[0][1]), B, M, N, K, 0, 0, fmt, 1, p(word_in), None, 0, 0,
+                         p(br[0][3]) if with_tab else None)
+        db = FusedBranch(p(dx), p(ob), None, None, p(br[1][0]), p(br[1][1]), B, M, N, K, 1, 0, fmt, 1, p(word_in), None, 0, 0,
+                         p(br[1][3]) if with_tab else None)
+        assert lib.ffno_spectral_x3_pair(ctypes.byref(da), ctypes.byref(db), C, fwd_ck, inv_ck, conj, 3, None) == 0
+        np.testing.assert_array_equal(be.get(oa), br[0][2])
+        np.testing.assert_array_equal(be.get(ob), br[1][2])
 
 
 @pytest.mark.parametrize("B,M,N,Ka,Kb", [(1, 40, 48, 20, 18), (1, 70, 36, 12, 34), (2, 256, 256, 32, 32), (1, 130, 136, 64, 40)])
