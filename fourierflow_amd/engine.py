@@ -262,7 +262,7 @@ class FFNOEngine:
         return 1 if self._bf16() else 0      # FFNO_STORE_F32 / FFNO_STORE_BF16
 
     def _conc(self) -> bool:
-        return bool(self.concurrent_branches and self._ffx() and not self.use_fork and not self.overlap
+        return bool(self.concurrent_branches and self._ffx() and not self.use_fork
                     and self.mode != "no-fourier" and self.spectral == "factorized")
 
     @staticmethod
