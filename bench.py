@@ -612,7 +612,22 @@ def main():
             else:
                 ach, peak, unit = fl / us * 1e-6, mpeak, "TFLOP/s"
             tr = pmc.get(dom, {})
+            # what the launch's own loads and stores cost without any arithmetic (a micro-benchmark of the same geometry, round 4):
+            # the bound that a one-round launch of this access pattern can reach, next to the contract's 8 TB/s figure
+            pattern = None
+            try:
+                if headline:
+                    sp = json.load(open(os.path.join(ROOT, "profiles", "stream_patterns.json")))
+                    fwd_us = kernels.get("spectral_fused", {}).get("avg_us")
+                    pattern = dict(forward_pair_us=sp["forward_pair_8byte"], source=sp["source"],
+                                   kernel_forward_us=fwd_us,
+                                   frac_of_pattern_bound=dict(warm=round(sp["forward_pair_8byte"]["warm_us"] / fwd_us, 3),
+                                                              cold=round(sp["forward_pair_8byte"]["cold_us"] / fwd_us, 3)) if fwd_us else None,
+                                   note="replay timing re-uses one buffer set (warm); the training step sits between the two")
+            except Exception:  # noqa: BLE001 - optional evidence
+                pattern = None
             roofline = dict(kernel=dom, symbol=tr.get("symbol"), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
+                            memory_pattern_bound=pattern,
                             frac=round(ach / peak, 4),
                             traffic=tr.get("hbm_bytes_per_launch"), traffic_source=pmc_meta,
                             avg_launch_us=round(us, 2), share_of_step=round(share[dom] / (1e3 * elapsed / args.steps), 3),

@@ -126,8 +126,7 @@ struct Hf2 {
 constexpr float kHf2Scale = 2048.f, kHf2Unscale = 1.f / 2048.f;
 
 __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
-    h = plat::pack_f16(x0, x1);
-    l = plat::pack_f16((x0 - plat::f16_lo(h)) * kHf2Scale, (x1 - plat::f16_hi(h)) * kHf2Scale);
+    plat::split2_pair(x0, x1, h, l);      // (h = fp16(x), l = fp16((x - h) 2^11): on the packed instructions)
 }
 __device__ __forceinline__ Hf2 split2_8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
     Hf2 f;

@@ -82,6 +82,19 @@ __device__ __forceinline__ unsigned pk_mul_f16(unsigned w, float k) {
     const f16x2 v = __builtin_bit_cast(f16x2, w) * (_Float16)k;
     return __builtin_bit_cast(unsigned, v);
 }
+// split-fp16 of a pair (ffno_device.h "split-fp16"): h = fp16(x), l = fp16((x - h) 2^11), both rounded to nearest, as packed
+// words.  Written over two-element vectors so that the pair stays on the packed instructions wherever it is inlined
+// (v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32: six instructions per pair; written element by element the same code came out as
+// twelve scalar ones inside the feed-forward epilogues -- and those kernels issue ten vector instructions per MFMA).
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 x = {x0, x1};
+    const f16x2 hv = __builtin_convertvector(x, f16x2);
+    const f32x2 r = (x - __builtin_convertvector(hv, f32x2)) * 2048.f;
+    h = __builtin_bit_cast(unsigned, hv);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
 // two floats -> one word of bf16, round to nearest even (x0 in the low half): v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float x0, float x1) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

@@ -1327,8 +1327,11 @@ static inline int ffx_launch_status() {
 
 // persistent workgroups of the chain kernels: one per compute unit of the current device unless the caller says otherwise
 // (max_workgroups > 0).  The CU count is an immutable per-device fact, cached after the first query.
-static inline int fx_workgroups(int max_workgroups, int ntiles) {
-    const int n = max_workgroups > 0 ? max_workgroups : device_cu_count();
+// persistent workgroups of a chain launch: one per CU at H = 256 (512 threads, 85-150 KiB of LDS: one fits); THREE per CU for the
+// 256-thread instances (H = 128: width 32 -- four waves and 27-43 KiB each, so a lone workgroup leaves three quarters of the
+// CU's wave slots empty; measured at 72^3 x 32, round 4: 157 -> 165 steps/s with 768 workgroups and 512 weight-gradient slices)
+static inline int fx_workgroups(int max_workgroups, int ntiles, int H = 256) {
+    const int n = max_workgroups > 0 ? max_workgroups : device_cu_count() * (H <= 128 ? 3 : 1);
     return n < ntiles ? n : ntiles;
 }
 
@@ -1380,7 +1383,7 @@ static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* r
                    void* stream) {
     if (!s || !pk1 || !b1 || !pk2 || !b2 || !out || P <= 0 || (s_sum && !s2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
-    const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles));
+    const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles, H));
     const unsigned* ia = o ? o->in_amax : nullptr;
     unsigned* oa = o ? o->out_amax : nullptr;
     const bool in_phase = o && (o->schedule & FFNO_FF_SCHED_IN_PHASE);
@@ -1419,7 +1422,7 @@ static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const 
                         const void* pk2b, float* ds, int P, int C, int H, const ffno_ff_opts* o, void* stream) {
     if (!db || !mask || !pk1b || !pk2b || !ds || P <= 0 || (db_sum && !db2)) return FFNO_EINVAL;
     const int ntiles = (P + 31) / 32;
-    const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles));
+    const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles, H));
     const unsigned* ia = o ? o->in_amax : nullptr;
     unsigned* oa = o ? o->out_amax : nullptr;
     hipStream_t st = (hipStream_t)stream;

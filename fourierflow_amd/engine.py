@@ -230,7 +230,10 @@ class FFNOEngine:
         self._dft_tabs = {}
         self.x3_min_lines = 1
         self.x3_tile_lines = 0      # lines per workgroup of the fused x3 kernel: 0 = the library chooses, 8 / 16 = forced (tests)
-        self.ff_max_workgroups = 0  # persistent workgroups of the feed-forward chain kernels: 0 = one per CU
+        self.ff_max_workgroups = int(os.environ.get("FFNO_FF_MAX_WG", "0"))  # persistent workgroups of the feed-forward chain kernels: 0 = one per CU
+        # workgroups (= partial slices) of the weight-gradient kernel: one per CU at width 64 (eight waves each), two per CU at
+        # width 32 (four waves each: measured 157 -> 165 steps/s at 72^3 x 32 together with three chain workgroups per CU)
+        self.ff_wgrad_slices = int(os.environ.get("FFNO_FF_WGRAD_SLICES", "512" if width == 32 else "256"))
         # paired launch, workgroup -> (branch, tile) map: bit 1 = image-local where the shapes allow it (the workgroups that read
         # one image share an XCD: the image crosses HBM once), else bit 0 = even workgroups branch a, odd ones branch b
         self.x3_interleave = 3
@@ -646,7 +649,7 @@ class FFNOEngine:
             ws.DS = torch.empty(P, C, **act)
             ws.G = [torch.empty(P, C, **act) for _ in range(2)]    # running gradient, ping-pong per layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
-            ws.nsplit_ff = max(1, min(256, (P + 127) // 128))
+            ws.nsplit_ff = max(1, min(int(self.ff_wgrad_slices), (P + 127) // 128))
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
             # split-bf16 path with per-layer feed-forwards: every layer keeps its own slices and ONE batched launch
             # reduces them all at the end of the backward pass (24 kernel boundaries less per step)

@@ -34,6 +34,10 @@ inline unsigned pack_f16(float x0, float x1) { return (unsigned)emu::emu_float_t
 inline float f16_lo(unsigned w) { return emu::emu_half_to_float((unsigned short)(w & 0xffffu)); }
 inline float f16_hi(unsigned w) { return emu::emu_half_to_float((unsigned short)(w >> 16)); }
 inline unsigned pk_mul_f16(unsigned w, float k) { return pack_f16(f16_lo(w) * k, f16_hi(w) * k); }
+inline void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+    h = pack_f16(x0, x1);
+    l = pack_f16((x0 - f16_lo(h)) * 2048.f, (x1 - f16_hi(h)) * 2048.f);
+}
 inline unsigned pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xffff0000u); }
 inline unsigned pack_lo16(unsigned u0, unsigned u1) { return (u0 & 0xffffu) | (u1 << 16); }
 inline unsigned bf16_rne(float x) {      // IEEE round-to-nearest-even to bf16 (NaN stays NaN)

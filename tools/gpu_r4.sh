@@ -27,6 +27,51 @@ for st in "$@"; do
       echo "[r4] pmc SQ2 rc=$?"; tail -n 3 gpurun_out/pmc_SQ2.log | cut -c1-200
       db=$(find gpurun_out/pmc_SQ2 -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_SQ2.md 2>&1; head -n 14 gpurun_out/pmc_SQ2.md | cut -c1-260
       find gpurun_out/pmc_SQ256 gpurun_out/pmc_SQ2 -name "*.db" -size +20M -delete ;;
+    profall)
+      # rocprofv3 kernel stats, one file per benchmarked configuration
+      prof() {  # tag, steps-in-run, command...
+        tag=$1; shift; n=$1; shift
+        rm -rf gpurun_out/prof_$tag
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_$tag" -o p -- "$@" > "$OLDPWD/gpurun_out/prof_$tag.log" 2>&1)
+        echo "[r4] rocprof $tag rc=$?"
+        db=$(find gpurun_out/prof_$tag -name "*.db" | head -1); python tools/rocpd_stats.py "$db" $n > gpurun_out/r04_${tag}_kernel_stats.md 2>&1
+        head -n 12 gpurun_out/r04_${tag}_kernel_stats.md | cut -c1-150
+        [ "$tag" = markov24 ] && python tools/rocpd_idle.py "$db" > gpurun_out/r04_markov24_step_idle.md 2>&1
+        find gpurun_out/prof_$tag -type f -size +1M -delete
+      }
+      R=$PWD
+      prof markov24 7 python $R/bench.py --steps 5 --warmup 2 --cpu-steps 0 --no-secondary
+      prof kochkov256_k32 7 python $R/bench.py --steps 5 --warmup 2 --cpu-steps 0 --no-secondary --grid 256 --layers 12 --modes 32 --batch 2
+      prof kochkov256_k64 7 python $R/bench.py --steps 5 --warmup 2 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2
+      prof cube64 7 python $R/tools/bench_mesh.py --preset cube64 --steps 5 --warmup 2
+      ;;
+    pmcall)
+      # HBM traffic counters, one PMC pass each, per configuration (kernel-trace + pmc only)
+      pmc() {  # tag, label, command...
+        tag=$1; shift; label=$1; shift
+        for c in FETCH_SIZE WRITE_SIZE; do
+          rm -rf gpurun_out/pmc_${tag}_$c
+          (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/gpurun_out/pmc_${tag}_$c" -o p -- "$@" > "$OLDPWD/gpurun_out/pmc_${tag}_$c.log" 2>&1)
+          echo "[r4] pmc $tag $c rc=$?"
+        done
+        f=$(find gpurun_out/pmc_${tag}_FETCH_SIZE -name "*.db" | head -1); w=$(find gpurun_out/pmc_${tag}_WRITE_SIZE -name "*.db" | head -1)
+        (cd tools && python make_pmc_traffic.py "../$f" "../$w" "${FFNO_GIT_HEAD:-unknown}" "$label") > gpurun_out/pmc_traffic_$tag.json
+        head -c 700 gpurun_out/pmc_traffic_$tag.json; echo
+        find gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE -type f -size +1M -delete
+      }
+      R=$PWD
+      pmc markov24 "markov/24 B=32 64x64 fp32 (bench.py defaults)" python $R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-secondary
+      pmc kochkov256_k32 "256x256 12L K=32 B=2 fp32" python $R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-secondary --grid 256 --layers 12 --modes 32 --batch 2
+      pmc kochkov256_k64 "256x256 24L K=64 B=2 fp32" python $R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2
+      pmc cube64 "64^3 (72^3 padded) width 32 12L B=1 fp32" python $R/tools/bench_mesh.py --preset cube64 --steps 3 --warmup 1
+      ;;
+    final)
+      timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
+      echo "[r4] smoke rc=$?"; tail -n 2 gpurun_out/smoke.log
+      timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err
+      echo "[r4] bench rc=$?"; tail -n 4 gpurun_out/bench.err
+      timeout 1700 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
+      echo "[r4] pytest -m gpu rc=$?"; tail -n 6 gpurun_out/pytest_gpu.log ;;
     benchfast)
       timeout 600 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/bench_fast.log 2> gpurun_out/bench_fast.err
       echo "[r4] benchfast rc=$?"; tail -n 12 gpurun_out/bench_fast.err; python - <<'PY'

@@ -10,7 +10,11 @@ from rocpd_pmc import per_kernel
 
 # first match wins, so the instantiations of the default arithmetic (fp16x2) come before the generic patterns: bench.py also runs
 # the all-bf16x3 variant, whose kernels are in the same trace
-NAMES = [("ffh_wgrad_m_kernel<64, 256", "ff_bwd_weights_partial"), ("spectral_x3_pair_kernel<16, true", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false, ffno::SplitHf2", "ff_fwd"),
+NAMES = [("ffh_wgrad_m_kernel<64, 256", "ff_bwd_weights_partial"), ("spectral_x3_pair_kernel<16, true", "spectral_fused"),
+         ("spectral_x3k_pair_kernel<64, true", "spectral_fused"), ("spectral_x3k_pair_kernel<128, true", "spectral_fused"),
+         ("spectral_x3c32_pair_kernel<true", "spectral_fused_pair"), ("spectral_x3c32_kernel<true", "spectral_fused_single"),
+         ("ffh_wgrad_m_kernel<32, 128", "ff_bwd_weights_partial"), ("ffx_chain_rs_kernel<32, 128, false, ffno::SplitHf2", "ff_fwd"),
+         ("ffx_chain_kernel<32, 128, true, ffno::SplitHf2", "ff_bwd_data"), ("ffx_chain_rs_kernel<64, 256, false, ffno::SplitHf2", "ff_fwd"),
          ("ffx_chain_kernel<64, 256, true, ffno::SplitHf2", "ff_bwd_data"), ("ffx_wgrad_kernel<64, 256, ffno::SplitHf2", "ff_bwd_weights_partial"),
          ("spectral_x3_pair_kernel<16", "spectral_fused"), ("ffx_chain_rs_kernel<64, 256, false", "ff_fwd"),
          ("ffx_chain_rs_kernel<64, 256, true", "ff_bwd_data"), ("ffx_wgrad_rs_kernel", "ff_bwd_weights_partial"),
@@ -41,7 +45,8 @@ for k, (_, n, avg, _, _) in order:
     w = write[k][2]
     out[name] = dict(fetch_kib_raw=round(avg, 1), write_kib=round(w, 1), hbm_bytes_per_launch=int((2 * avg + w) * 1024),
                      launches_sampled=n, symbol=k)
-print(json.dumps(dict(workload="markov/24 B=32 64x64 fp32 (bench.py defaults)", git_head=GIT_HEAD,
+WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "markov/24 B=32 64x64 fp32 (bench.py defaults)"
+print(json.dumps(dict(workload=WORKLOAD, git_head=GIT_HEAD,
                       method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
                              "(2*FETCH_SIZE + WRITE_SIZE)*1024; the x2 on FETCH_SIZE is the gfx950 correction of "
                              "MI355X_MICROARCH.md, confirmed on adamw_kernel; WRITE_SIZE reads exact",
