@@ -62,6 +62,11 @@ __device__ __forceinline__ f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b, f32x16 c) 
     typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_f16 (4 passes): A[i = l & 15][k = 8 (l >> 4) + e], B[k = 8 (l >> 4) + e][j = l & 15], D reg r = D[4 (l >> 4) + r][l & 15]
+__device__ __forceinline__ f32x4 mfma_f16_16x16x32(u32x4 a, u32x4 b, f32x4 c) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
 // two floats -> one word of IEEE halves, round to nearest even (x0 in the low half): v_cvt_pk_f16_f32
 __device__ __forceinline__ unsigned pack_f16(float x0, float x1) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));

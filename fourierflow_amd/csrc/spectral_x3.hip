@@ -90,6 +90,22 @@ __global__ __launch_bounds__(256) void x3_pack_kernel(const X3PackDesc* __restri
         d.dst[(fo * 2 + 1) * 64 + lane] = f.lo;
         return;
     }
+    if (d.format == 2) {
+        // format 2 (FFNO_PLANES_FP16X2_M16): B fragments of v_mfma_f32_16x16x32_f16 -- the mix of the 4-line tiles (8 live rows) runs
+        // 16-row products.  fragment (k, p, t16, s2): lane (j16 = lane & 15, g = lane >> 4), slot e  <-
+        //     planes[k][p][i = 32 s2 + 8 g + e][o = 4 j16 + t16]        (p = re | im; t16 = 0..3; s2 = 0..1: two k32 steps)
+        // two fp16 planes per fragment, fragments of a mode ordered ((p, t16), s2): 16 per mode, the size of format 1.
+        const int fm = frag & 15, s2 = fm & 1, t16 = (fm >> 1) & 3, pp = fm >> 3;
+        const int j16 = lane & 15, g = lane >> 4;
+        const float* src2 = d.planes + ((long)(k * 2 + pp) * C + (32 * s2 + 8 * g)) * C + 4 * j16 + t16;
+        float w[8];
+        FFNO_UNROLL
+        for (int e = 0; e < 8; ++e) w[e] = src2[(long)e * C];
+        const Hf2 f = split2_8(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+        d.dst[(frag * 2 + 0) * 64 + lane] = f.hi;
+        d.dst[(frag * 2 + 1) * 64 + lane] = f.lo;
+        return;
+    }
     const Bf3 f = split3_8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
     d.dst[(frag * 3 + 0) * 64 + lane] = f.hi;
     d.dst[(frag * 3 + 1) * 64 + lane] = f.mid;
@@ -101,6 +117,67 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
     f.hi = pk[(frag * 3 + 0) * 64 + lane];
     f.mid = pk[(frag * 3 + 1) * 64 + lane];
     f.lo = pk[(frag * 3 + 2) * 64 + lane];
+    return f;
+}
+
+// ---- DFT-matrix fragment table of the many-mode kernel ------------------------------------------------------------------------
+// The many-mode kernel gives a wave ONE line, so nothing amortises the construction of its DFT-matrix fragments: per product
+// block ~90 vector instructions (table lookups, index bookkeeping, the fp16 split) against 6 MFMAs -- measured 20 vector
+// instructions per MFMA over the whole launch (profiles/r04_x3k_sq_counters.md).  The fragments only depend on (L, K, flags), so
+// they are built ONCE into a table in MFMA lane order (two fp16 planes per fragment: hi, lo; the 2^11 hi plane is one
+// v_pk_mul_f16 per word in the kernel) and every wave loads them (L1 / L2 hits: all waves of a CU walk the same table):
+//   forward  part: fragment ((rt * nchunks + chunk) * 4 + u)      rt < RT = KKT / 32, chunk < nchunks, u < 4
+//   inverse  part: fragment (nfwd + tile * NST + st)               tile < ceil(L / 32), st < NST = KKT / 16
+// Values = exactly the expressions of spectral_x3k_body's on-the-fly path (bit-identical results with and without a table).
+struct X3kDft {
+    int KKT, RT, NST, nchunks, ntiles, nfwd;
+};
+static inline X3kDft x3k_dft_layout(int L, int K) {
+    X3kDft d;
+    d.KKT = K <= 16 ? 32 : (K <= 32 ? 64 : 128);      // (<= 16 modes: the latency kernel's tile height)
+    d.RT = d.KKT / 32, d.NST = d.KKT / 16;
+    d.nchunks = (L + 63) >> 6, d.ntiles = (L + 31) >> 5;
+    d.nfwd = d.RT * d.nchunks * 4;
+    return d;
+}
+
+__global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restrict__ tw, int L, int K, int fwd_ck, int inv_ck,
+                                                           X3kDft d, u32x4* __restrict__ out) {
+    const int frag = blockIdx.x, lane = threadIdx.x, j = lane & 31, half = lane >> 5;
+    float f[8];
+    if (frag < d.nfwd) {
+        const int u = frag & 3, chunk = (frag >> 2) % d.nchunks, rt = (frag >> 2) / d.nchunks;
+        const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
+        const bool rowok = kk < 2 * K;
+        const float ck = (fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
+        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
+        const int km = rowok ? k : 0;
+        FFNO_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const int n = 16 * (4 * chunk + u) + 8 * half + e;
+            f[e] = n < L ? amul * tw[(ri ? L : 0) + (int)(((long)km * n) % L)] : 0.f;
+        }
+    } else {
+        const int g = frag - d.nfwd, st = g % d.NST, tile = g / d.NST;
+        const int n = 32 * tile + j;
+        FFNO_UNROLL
+        for (int e = 0; e < 8; ++e) {
+            const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
+            const float ck = (inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
+            f[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tw[(part ? L : 0) + (int)(((long)n * t) % L)] : 0.f;
+        }
+    }
+    const Hf2 h = split2_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
+    out[(frag * 2 + 0) * 64 + lane] = h.hi;
+    out[(frag * 2 + 1) * 64 + lane] = h.lo;
+}
+// fragment `frag` of the table as the bounded operand of mfma_h2s
+__device__ __forceinline__ Hf3 x3k_load_dft(const u32x4* __restrict__ tab, int frag, int lane) {
+    Hf3 f;
+    f.hi = tab[(frag * 2 + 0) * 64 + lane];
+    f.lo = tab[(frag * 2 + 1) * 64 + lane];
+    FFNO_UNROLL
+    for (int w = 0; w < 4; ++w) f.hs[w] = plat::pk_mul_f16(f.hi[w], kHf2Scale);
     return f;
 }
 
@@ -551,9 +628,10 @@ __global__ __launch_bounds__(256) void x3_pack32_kernel(const X3PackDesc* __rest
     d.dst[(frag * 3 + 2) * 64 + lane] = f.lo;
 }
 
-template <bool MIXH2, class ST = StF32>
+template <bool MIXH2, class ST = StF32, bool TAB = false>
 __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
     static_assert(!ST::BF16 || MIXH2, "bf16 storage runs the split-fp16 path");
+    static_assert(!TAB || MIXH2, "the fragment table holds fp16 planes");
     using F = X3Cfg32;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF, NL = F::NL;
     __shared__ __attribute__((aligned(16))) float XS[NL * LSF];
@@ -612,6 +690,10 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             DftFrag Ff[4];
             int idx = (km * (64 * chunk + 8 * half)) % L;
+            if constexpr (TAB) {      // the chunk's fragments from the table (the table layout of <= 16 modes: one row tile)
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) Ff[u] = x3k_load_dft(A.dft, chunk * 4 + u, lane);
+            } else
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
                 float f[8];
@@ -808,6 +890,10 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
         for (int rt = 0; rt < RTtot; ++rt) {
             const int n = 32 * rt + j;
             DftFrag G[2];
+            if constexpr (TAB) {
+                FFNO_UNROLL
+                for (int st = 0; st < 2; ++st) G[st] = x3k_load_dft(A.dft, ((L + 63) >> 6) * 4 + rt * 2 + st, lane);
+            } else
             FFNO_UNROLL
             for (int st = 0; st < 2; ++st) {
                 float g[8];
@@ -1199,67 +1285,6 @@ __global__ __launch_bounds__(256) void x3_dft_inv_pair_kernel(X3Stage a, X3Stage
     x3_dft_inv_body(x3_pick(a, b, second), apply_ck, second ? blockIdx.x - n0 : blockIdx.x, second ? gridDim.x - n0 : n0);
 }
 
-// ---- DFT-matrix fragment table of the many-mode kernel ------------------------------------------------------------------------
-// The many-mode kernel gives a wave ONE line, so nothing amortises the construction of its DFT-matrix fragments: per product
-// block ~90 vector instructions (table lookups, index bookkeeping, the fp16 split) against 6 MFMAs -- measured 20 vector
-// instructions per MFMA over the whole launch (profiles/r04_x3k_sq_counters.md).  The fragments only depend on (L, K, flags), so
-// they are built ONCE into a table in MFMA lane order (two fp16 planes per fragment: hi, lo; the 2^11 hi plane is one
-// v_pk_mul_f16 per word in the kernel) and every wave loads them (L1 / L2 hits: all waves of a CU walk the same table):
-//   forward  part: fragment ((rt * nchunks + chunk) * 4 + u)      rt < RT = KKT / 32, chunk < nchunks, u < 4
-//   inverse  part: fragment (nfwd + tile * NST + st)               tile < ceil(L / 32), st < NST = KKT / 16
-// Values = exactly the expressions of spectral_x3k_body's on-the-fly path (bit-identical results with and without a table).
-struct X3kDft {
-    int KKT, RT, NST, nchunks, ntiles, nfwd;
-};
-static inline X3kDft x3k_dft_layout(int L, int K) {
-    X3kDft d;
-    d.KKT = K <= 16 ? 32 : (K <= 32 ? 64 : 128);      // (<= 16 modes: the latency kernel's tile height)
-    d.RT = d.KKT / 32, d.NST = d.KKT / 16;
-    d.nchunks = (L + 63) >> 6, d.ntiles = (L + 31) >> 5;
-    d.nfwd = d.RT * d.nchunks * 4;
-    return d;
-}
-
-__global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restrict__ tw, int L, int K, int fwd_ck, int inv_ck,
-                                                           X3kDft d, u32x4* __restrict__ out) {
-    const int frag = blockIdx.x, lane = threadIdx.x, j = lane & 31, half = lane >> 5;
-    float f[8];
-    if (frag < d.nfwd) {
-        const int u = frag & 3, chunk = (frag >> 2) % d.nchunks, rt = (frag >> 2) / d.nchunks;
-        const int kk = 32 * rt + j, k = kk >> 1, ri = kk & 1;
-        const bool rowok = kk < 2 * K;
-        const float ck = (fwd_ck && !(k == 0 || 2 * k == L)) ? 2.f : 1.f;
-        const float amul = rowok ? (ri ? -ck : ck) : 0.f;
-        const int km = rowok ? k : 0;
-        FFNO_UNROLL
-        for (int e = 0; e < 8; ++e) {
-            const int n = 16 * (4 * chunk + u) + 8 * half + e;
-            f[e] = n < L ? amul * tw[(ri ? L : 0) + (int)(((long)km * n) % L)] : 0.f;
-        }
-    } else {
-        const int g = frag - d.nfwd, st = g % d.NST, tile = g / d.NST;
-        const int n = 32 * tile + j;
-        FFNO_UNROLL
-        for (int e = 0; e < 8; ++e) {
-            const int kk = 16 * st + 8 * half + e, t = kk >> 1, part = kk & 1;
-            const float ck = (inv_ck && !(t == 0 || 2 * t == L)) ? 2.f : 1.f;
-            f[e] = (kk < 2 * K && n < L) ? (part ? -ck : ck) * tw[(part ? L : 0) + (int)(((long)n * t) % L)] : 0.f;
-        }
-    }
-    const Hf2 h = split2_8(f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7]);
-    out[(frag * 2 + 0) * 64 + lane] = h.hi;
-    out[(frag * 2 + 1) * 64 + lane] = h.lo;
-}
-// fragment `frag` of the table as the bounded operand of mfma_h2s
-__device__ __forceinline__ Hf3 x3k_load_dft(const u32x4* __restrict__ tab, int frag, int lane) {
-    Hf3 f;
-    f.hi = tab[(frag * 2 + 0) * 64 + lane];
-    f.lo = tab[(frag * 2 + 1) * 64 + lane];
-    FFNO_UNROLL
-    for (int w = 0; w < 4; ++w) f.hs[w] = plat::pk_mul_f16(f.hi[w], kHf2Scale);
-    return f;
-}
-
 // ---- the fused branch for 17..64 modes (256 x 256 grids: torus_kochkov runs 32 and 64 modes) ----------------------------------
 // Same operator as spectral_x3_body with the spectrum tile in LDS, re-tiled for many modes per line: KKT = 64 or 128 (mode,
 // re/im) rows per line, FOUR lines per workgroup, two waves per line.  Why four: at 256 x 256 and batch 2 an axis has 512
@@ -1274,9 +1299,12 @@ __device__ __forceinline__ Hf3 x3k_load_dft(const u32x4* __restrict__ tab, int f
 //            tile inner as in x3_dft_inv_body, with the accumulate / residual epilogue.
 // ST = storage format of in / out / resid (ffno_device.h); the bf16 twin exists for the fp16x2 packs (the split-fp16 DFT path)
 // TAB: the DFT-matrix fragments come from the precomputed table A.dft (x3k_dft_frags_kernel) instead of the twiddle table
-template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false>
+// M16: the per-mode mix on v_mfma_f32_16x16x32_f16 with format-2 packs (the tile has 8 live rows: half a 16-row tile instead of a
+// quarter of a 32-row one -- half the matrix time and a third of the vector work of the mix)
+template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false, bool M16 = false>
 __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     static_assert(!TAB || MIXH2, "the fragment table holds fp16 planes");
+    static_assert(!M16 || MIXH2, "the 16-row mix runs on fp16x2 packs");
     static_assert(!ST::BF16 || MIXH2, "bf16 storage runs the split-fp16 path");
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, NL = 4, LSF = KKT * RS + 8, RT = KKT / 32, NST = KKT / 16;
@@ -1535,6 +1563,68 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     __syncthreads();
 
     // ---------------- phase 2: per-mode channel mix of the four lines, in place ----------------
+    if constexpr (M16) {
+        if (A.wpk) {
+            // MFMA row r16 = (line (r16 mod 8) >> 1, part r16 & 1); rows 8..15 repeat rows 0..7 and are dropped.  k = input channel
+            // 32 s2 + 8 g + e; column j16 of tile t16 = output channel 4 j16 + t16 (a lane ends up with four consecutive channels).
+            const int r16 = lane & 15, g = lane >> 4;
+            const float* arow = XS + ((r16 & 7) >> 1) * LSF + (r16 & 1) * RS + 8 * g;
+            for (int k = wave; k < K; k += F::NW) {
+                const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * 64 * 2;
+                const bool more = k + F::NW < K;
+                const u32x4* __restrict__ wn = A.wpk + (long)(more ? k + F::NW : k) * F::MODE_FRAGS * 64 * 2;
+                Hf2 a[2];
+                FFNO_UNROLL
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 32 * s2);
+                    const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 32 * s2 + 4);
+                    a[s2] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                }
+                f32x4 p[8];
+                FFNO_UNROLL
+                for (int pt = 0; pt < 8; ++pt) {
+                    f32x4 pm = {0.f, 0.f, 0.f, 0.f}, pc = {0.f, 0.f, 0.f, 0.f};
+                    FFNO_UNROLL
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int f = pt * 2 + s2;
+                        const Hf2 b = ring[f % RING];
+                        if (f + RING < F::MODE_FRAGS)
+                            ring[f % RING] = load_w(wk, f + RING);
+                        else if (more)
+                            ring[f % RING] = load_w(wn, f + RING - F::MODE_FRAGS);
+                        pc = plat::mfma_f16_16x16x32(a[s2].lo, b.hi, pc);
+                        pc = plat::mfma_f16_16x16x32(a[s2].hi, b.lo, pc);
+                        pm = plat::mfma_f16_16x16x32(a[s2].hi, b.hi, pm);
+                    }
+                    FFNO_UNROLL
+                    for (int r = 0; r < 4; ++r) p[pt][r] = __builtin_fmaf(pc[r], kHf2Unscale, pm[r]);
+                }
+                // D rows 4 g + r of this lane: g = 0 -> lines 0, 1; g = 1 -> lines 2, 3 (r = 2 q + part); g >= 2: the repeated rows
+                if (g < 2) {
+                    FFNO_UNROLL
+                    for (int q = 0; q < 2; ++q) {
+                        float yr[4], yi[4];
+                        FFNO_UNROLL
+                        for (int t = 0; t < 4; ++t) {
+                            const float p1r = p[t][2 * q], p1i = p[t][2 * q + 1];
+                            const float p2r = p[4 + t][2 * q], p2i = p[4 + t][2 * q + 1];
+                            if (A.conj_t == 0) {
+                                yr[t] = p1r - p2i;
+                                yi[t] = p2r + p1i;
+                            } else {
+                                yr[t] = p1r + p2i;
+                                yi[t] = p1i - p2r;
+                            }
+                        }
+                        float* dst = XS + (2 * g + q) * LSF + 2 * k * RS + 4 * r16;
+                        *reinterpret_cast<float4*>(dst) = make_float4(yr[0], yr[1], yr[2], yr[3]);
+                        *reinterpret_cast<float4*>(dst + RS) = make_float4(yi[0], yi[1], yi[2], yi[3]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else
     if (A.wpk) {
         // MFMA row j = (line (j mod 8) >> 1, part j & 1); rows 8..31 repeat rows 0..7 and are dropped
         const float* arow = XS + ((j & (2 * NL - 1)) >> 1) * LSF + (j & 1) * RS + 8 * half;
@@ -1807,13 +1897,13 @@ __device__ __forceinline__ X3Args x3_pick_args(const X3Args& a, const X3Args& b,
     return s;
 }
 
-template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false>
+template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false, bool M16 = false>
 __global__ __launch_bounds__(512) void spectral_x3k_kernel(X3Args a) {
-    spectral_x3k_body<KKT, MIXH2, ST, TAB>(a, blockIdx.x);
+    spectral_x3k_body<KKT, MIXH2, ST, TAB, M16>(a, blockIdx.x);
 }
 // two branches in one launch: even workgroups run branch a, odd ones branch b while both have tiles left (workgroup w lands on
 // XCD w % 8: every XCD's L2 then holds the packed weights of ONE branch), the rest in order
-template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false>
+template <int KKT, bool MIXH2, class ST = StF32, bool TAB = false, bool M16 = false>
 __global__ __launch_bounds__(512) void spectral_x3k_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
     const int w = blockIdx.x, nmin = min(n0, n1);
     bool second;
@@ -1825,14 +1915,14 @@ __global__ __launch_bounds__(512) void spectral_x3k_pair_kernel(X3Args a, X3Args
         second = n1 > n0;
         idx = w - nmin;
     }
-    spectral_x3k_body<KKT, MIXH2, ST, TAB>(x3_pick_args(a, b, second), idx);
+    spectral_x3k_body<KKT, MIXH2, ST, TAB, M16>(x3_pick_args(a, b, second), idx);
 }
 
-template <bool MIXH2, class ST = StF32>
+template <bool MIXH2, class ST = StF32, bool TAB = false>
 __global__ __launch_bounds__(512) void spectral_x3c32_kernel(X3Args a) {
-    spectral_x3c32_body<MIXH2, ST>(a, blockIdx.x);
+    spectral_x3c32_body<MIXH2, ST, TAB>(a, blockIdx.x);
 }
-template <bool MIXH2, class ST = StF32>
+template <bool MIXH2, class ST = StF32, bool TAB = false>
 __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
     const int w = blockIdx.x, nmin = min(n0, n1);
     bool second;
@@ -1844,7 +1934,7 @@ __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Ar
         second = n1 > n0;
         idx = w - nmin;
     }
-    spectral_x3c32_body<MIXH2, ST>(x3_pick_args(a, b, second), idx);
+    spectral_x3c32_body<MIXH2, ST, TAB>(x3_pick_args(a, b, second), idx);
 }
 
 // ---- the latency variant: FOUR lines per workgroup, two waves per line (rollout at batch 1: 128 lines per launch) --------------
@@ -2265,22 +2355,25 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     const int R = b->axis == 0 ? b->B * b->M : b->B * b->N;
     if (b->K > L / 2 + 1) return FFNO_EMODES;
     if (!ffno_spectral_x3_supported(C, b->K, L)) return FFNO_EUNSUPPORTED;
-    if (b->planes_format != FFNO_PLANES_BF16X3 && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EINVAL;
+    if (b->planes_format != FFNO_PLANES_BF16X3 && b->planes_format != FFNO_PLANES_FP16X2 && b->planes_format != FFNO_PLANES_FP16X2_M16)
+        return FFNO_EINVAL;
+    // format 2 = the 16-row mix of the many-mode kernel (width 64, 17..64 modes), which also takes its DFT fragments from a table
+    if (b->planes && b->planes_format == FFNO_PLANES_FP16X2_M16 && (C != X3Cfg::C || !x3_many_modes(b->K) || !b->dft_frags))
+        return FFNO_EUNSUPPORTED;
     if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16 && b->tile_lines != FFNO_X3_TILE_LATENCY) return FFNO_EINVAL;
     if (b->storage != FFNO_STORE_F32 && b->storage != FFNO_STORE_BF16) return FFNO_EINVAL;
     if (b->storage == FFNO_STORE_BF16 && b->tile_lines == FFNO_X3_TILE_LATENCY) return FFNO_EUNSUPPORTED;
     // bf16 storage twins: every fused split kernel (width 64 with <= 64 modes, width 32), on the split-fp16 path -- i.e. WITH
     // fp16x2 packs (a launch without planes, mode 'low-pass', runs the bf16x3 DFT, which has twins only on the K <= 16 kernel)
     if (b->storage == FFNO_STORE_BF16) {
-        if (b->planes && b->planes_format != FFNO_PLANES_FP16X2) return FFNO_EUNSUPPORTED;
+        if (b->planes && b->planes_format == FFNO_PLANES_BF16X3) return FFNO_EUNSUPPORTED;
         if (!b->planes && (C != X3Cfg::C || x3_many_modes(b->K))) return FFNO_EUNSUPPORTED;
     }
     a = X3Args{b->in, b->out, b->resid, b->spec_save, reinterpret_cast<const u32x4*>(b->planes), b->tw, R, L, b->K,
                make_linemap(b->axis, b->B, b->M, b->N, C), scale_ck_fwd, apply_ck_inv, conj_transpose, b->accumulate,
                b->in_amax, b->out_amax,
                // (only the split-fp16 DFT path of the many-mode kernel reads the table)
-               (C == X3Cfg::C && b->planes && b->planes_format == FFNO_PLANES_FP16X2)
-                   ? reinterpret_cast<const u32x4*>(b->dft_frags) : nullptr};
+               (b->planes && b->planes_format != FFNO_PLANES_BF16X3) ? reinterpret_cast<const u32x4*>(b->dft_frags) : nullptr};
     return FFNO_OK;
 }
 
@@ -2290,14 +2383,19 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     const int rc = x3_args(a, br, C, scale_ck_fwd, apply_ck_inv, conj_transpose);
     if (rc) return rc;
     // 8-line tiles when they still fit one round of workgroups (one per CU), else 16-line tiles
-    const bool h2 = br->planes && br->planes_format == FFNO_PLANES_FP16X2;
+    const bool h2 = br->planes && br->planes_format != FFNO_PLANES_BF16X3;
+    const bool m16 = br->planes && br->planes_format == FFNO_PLANES_FP16X2_M16;      // (x3_args: many modes + table)
     const size_t smem = sizeof(float) * 2 * a.L;
     hipStream_t st = (hipStream_t)stream;
     const bool b16 = br->storage == FFNO_STORE_BF16;      // (x3_args: only with fp16x2 packs outside the K <= 16 kernel)
     if (C == X3Cfg32::C) {          // width 32: 16 lines per workgroup, two per wave side by side
         const dim3 grid((a.R + 15) / 16);
-        if (b16)
+        if (b16 && a.dft)
+            FFNO_LAUNCH((spectral_x3c32_kernel<true, StBf16, true>), grid, dim3(512), smem, st, a);
+        else if (b16)
             FFNO_LAUNCH((spectral_x3c32_kernel<true, StBf16>), grid, dim3(512), smem, st, a);
+        else if (h2 && a.dft)
+            FFNO_LAUNCH((spectral_x3c32_kernel<true, StF32, true>), grid, dim3(512), smem, st, a);
         else if (h2)
             FFNO_LAUNCH((spectral_x3c32_kernel<true>), grid, dim3(512), smem, st, a);
         else
@@ -2314,10 +2412,12 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
     } while (0)
         const bool tab = a.dft != nullptr;       // (x3_args: only with fp16x2 planes)
         if (a.K <= 32) {
-            if (b16 && tab) X3K_LAUNCH(64, true, StBf16, true); else if (b16) X3K_LAUNCH(64, true, StBf16);
+            if (m16 && b16) X3K_LAUNCH(64, true, StBf16, true, true); else if (m16) X3K_LAUNCH(64, true, StF32, true, true);
+            else if (b16 && tab) X3K_LAUNCH(64, true, StBf16, true); else if (b16) X3K_LAUNCH(64, true, StBf16);
             else if (h2 && tab) X3K_LAUNCH(64, true, StF32, true); else if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
         } else {
-            if (b16 && tab) X3K_LAUNCH(128, true, StBf16, true); else if (b16) X3K_LAUNCH(128, true, StBf16);
+            if (m16 && b16) X3K_LAUNCH(128, true, StBf16, true, true); else if (m16) X3K_LAUNCH(128, true, StF32, true, true);
+            else if (b16 && tab) X3K_LAUNCH(128, true, StBf16, true); else if (b16) X3K_LAUNCH(128, true, StBf16);
             else if (h2 && tab) X3K_LAUNCH(128, true, StF32, true); else if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
         }
 #undef X3K_LAUNCH
@@ -2368,14 +2468,20 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
     if ((ba->planes == nullptr) != (bb->planes == nullptr) || ba->planes_format != bb->planes_format ||
         ba->tile_lines != bb->tile_lines || ba->storage != bb->storage)
         return FFNO_EINVAL;
-    const bool h2 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2;
+    const bool h2 = ba->planes && ba->planes_format != FFNO_PLANES_BF16X3;
+    const bool m16 = ba->planes && ba->planes_format == FFNO_PLANES_FP16X2_M16;
     hipStream_t st = (hipStream_t)stream;
     const bool b16 = ba->storage == FFNO_STORE_BF16;
     if (b16 && !h2 && (C != X3Cfg::C || x3_many_modes(a.K) || x3_many_modes(b.K))) return FFNO_EUNSUPPORTED;
     if (C == X3Cfg32::C) {
         const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16;
-        if (b16)
+        const bool tab = a.dft && b.dft;
+        if (b16 && tab)
+            FFNO_LAUNCH((spectral_x3c32_pair_kernel<true, StBf16, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else if (b16)
             FFNO_LAUNCH((spectral_x3c32_pair_kernel<true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else if (h2 && tab)
+            FFNO_LAUNCH((spectral_x3c32_pair_kernel<true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
         else if (h2)
             FFNO_LAUNCH((spectral_x3c32_pair_kernel<true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
         else
@@ -2397,11 +2503,14 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         const bool tab = a.dft && b.dft && x3_many_modes(a.K) && x3_many_modes(b.K) && (a.K <= 32 ? 64 : 128) == kkt &&
                          (b.K <= 32 ? 64 : 128) == kkt;
         if (!tab) a.dft = b.dft = nullptr;
+        if (m16 && !tab) return FFNO_EUNSUPPORTED;      // (the 16-row mix ships with the table kernels only)
         if (kkt == 64) {
-            if (b16 && tab) X3K_LAUNCH(64, true, StBf16, true); else if (b16) X3K_LAUNCH(64, true, StBf16);
+            if (m16 && b16) X3K_LAUNCH(64, true, StBf16, true, true); else if (m16) X3K_LAUNCH(64, true, StF32, true, true);
+            else if (b16 && tab) X3K_LAUNCH(64, true, StBf16, true); else if (b16) X3K_LAUNCH(64, true, StBf16);
             else if (h2 && tab) X3K_LAUNCH(64, true, StF32, true); else if (h2) X3K_LAUNCH(64, true); else X3K_LAUNCH(64, false);
         } else {
-            if (b16 && tab) X3K_LAUNCH(128, true, StBf16, true); else if (b16) X3K_LAUNCH(128, true, StBf16);
+            if (m16 && b16) X3K_LAUNCH(128, true, StBf16, true, true); else if (m16) X3K_LAUNCH(128, true, StF32, true, true);
+            else if (b16 && tab) X3K_LAUNCH(128, true, StBf16, true); else if (b16) X3K_LAUNCH(128, true, StBf16);
             else if (h2 && tab) X3K_LAUNCH(128, true, StF32, true); else if (h2) X3K_LAUNCH(128, true); else X3K_LAUNCH(128, false);
         }
 #undef X3K_LAUNCH

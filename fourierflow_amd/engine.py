@@ -67,7 +67,7 @@ class _Linear:
 
 class _View:
     """One spatial axis as a [Bv, Mv, Nv, C] view: a01 = 0 transforms along Nv, 1 along Mv."""
-    __slots__ = ("Bv", "Mv", "Nv", "a01", "L", "K", "R", "spec", "K2", "spec_y")
+    __slots__ = ("Bv", "Mv", "Nv", "a01", "L", "K", "R", "spec", "K2", "spec_y", "x3fmt")
 
     def __init__(self, Bv, Mv, Nv, a01, K, C):
         self.Bv, self.Mv, self.Nv, self.a01, self.K = Bv, Mv, Nv, a01, K
@@ -228,6 +228,7 @@ class FFNOEngine:
         # rebuilding them from the twiddle table for every line (bit-identical results; False = rebuild: tests)
         self.x3_dft_tables = True
         self._dft_tabs = {}
+        self.x3_mix16 = os.environ.get("FFNO_X3_MIX16", "1") != "0"      # 16-row mix packs for the many-mode kernel (False: 32-row)
         self.x3_min_lines = 1
         self.x3_tile_lines = 0      # lines per workgroup of the fused x3 kernel: 0 = the library chooses, 8 / 16 = forced (tests)
         self.ff_max_workgroups = int(os.environ.get("FFNO_FF_MAX_WG", "0"))  # persistent workgroups of the feed-forward chain kernels: 0 = one per CU
@@ -323,7 +324,7 @@ class FFNOEngine:
 
     def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True, rin=None, rout=None):
         """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
-        fmt = int(bool(x3 and planes is not None and self._x3_h2()))
+        fmt = int(getattr(v, "x3fmt", 1)) if (x3 and planes is not None and self._x3_h2()) else 0      # ffno.h FFNO_PLANES_*
         dft = self._dft_frags(v.L, v.K, fwd) if (fmt and self.x3_dft_tables) else None
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
                                  v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout, self._st(), 0, _p(dft))
@@ -335,7 +336,7 @@ class FFNOEngine:
         tab = self._dft_tabs.get(key)
         if tab is None:
             lib = _lib.get_lib()
-            nb = int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) if self.C == 64 else 0      # 0: no table for this shape
+            nb = int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) if self.C in (32, 64) else 0      # 0: no table for this shape
             if nb:
                 tab = torch.empty(nb // 4, dtype=torch.int32, device=self.device)
                 ck_f, ck_i = (0, 1) if fwd else (1, 0)
@@ -990,7 +991,13 @@ class FFNOEngine:
         x3 = self._use_x3(ws.views, fused)
         # format of the packed x3 weight sets per axis: fp16x2 where the FUSED x3 kernel mixes with them (the stage kernels of
         # the 17..32-mode axes read bf16x3 packs)
-        self._x3_fmt = [int(self._x3_h2() and fused[w] and x3[w]) for w in range(len(ws.views))]
+        # ... and FFNO_PLANES_FP16X2_M16 (the 16-row mix) for the many-mode axes (width 64, 17..64 modes: 4-line tiles with 8 live mix
+        # rows) when their DFT-fragment tables are in use and all of them share a tile height (a paired launch needs one)
+        many = [v.K > 16 for v in ws.views]
+        m16 = bool(self.x3_mix16 and self.x3_dft_tables and C == 64 and len({v.K <= 32 for v, m in zip(ws.views, many) if m}) == 1)
+        self._x3_fmt = [(2 if (m16 and many[w]) else 1) if (self._x3_h2() and fused[w] and x3[w]) else 0 for w in range(len(ws.views))]
+        for w, v in enumerate(ws.views):
+            v.x3fmt = self._x3_fmt[w]
         self._prepare_weights(st)
         full = self.mode == "full"
         singles, pair = self._schedule(fused, ws.views) if self._conc() else (list(range(len(ws.views))), None)

@@ -197,13 +197,17 @@ typedef struct ffno_fused_branch {
                                 ffno_spectral_x3[_pair]: every fused split kernel with FP16X2 planes, the K <= 16 kernel also
                                 without planes; spec_save stays fp32) */
     int32_t pad_;
-    const void* dft_frags;   /* optional (FP16X2 planes; read by the many-mode kernel, 17..64 modes, and by the 4-line latency
-                                kernel of the <= 16-mode shapes): the DFT-matrix fragments of this branch's (L, K, flags)
+    const void* dft_frags;   /* optional (FP16X2 planes; read by the many-mode kernel, 17..64 modes, by the 4-line latency
+                                kernel of the <= 16-mode shapes and by the width-32 kernel): the DFT-matrix fragments of this
+                                branch's (L, K, flags)
                                 as ffno_spectral_x3_dft_frags wrote them -- the kernel then loads them instead of rebuilding them
                                 from the twiddle table for every line (bit-identical results); NULL = build on the fly */
 } ffno_fused_branch;
 #define FFNO_PLANES_BF16X3 0
 #define FFNO_PLANES_FP16X2 1
+#define FFNO_PLANES_FP16X2_M16 2   /* fp16x2 fragments in the order of v_mfma_f32_16x16x32_f16: the many-mode kernel (C = 64, 17..64
+                                      modes; its 4-line tile has 8 live mix rows) then runs 16-row products -- half the matrix time and a
+                                      third of the vector work of its mix.  Needs dft_frags; same bytes as FFNO_PLANES_FP16X2 */
 #define FFNO_X3_TILE_LATENCY 1
 /* DFT-matrix fragment table of the fused kernels that give a wave ONE line (C = 64, FP16X2 planes: the many-mode kernel, 17..64
  * modes, and the latency kernel FFNO_X3_TILE_LATENCY of the <= 16-mode shapes) for one axis length L, mode

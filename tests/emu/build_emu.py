@@ -29,7 +29,7 @@ def build(verbose=False):
     h = hashlib.sha256()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
               [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
-    for p in sorted(srcs + headers + [os.path.join(ROOT, "include", "ffno.h")]):
+    for p in sorted(srcs + headers + [os.path.join(ROOT, "include", "ffno.h"), os.path.abspath(__file__)]):      # (+ the flags)
         h.update(open(p, "rb").read())
     stamp = h.hexdigest()
     sf = LIB + ".stamp"
@@ -47,7 +47,7 @@ def build(verbose=False):
             objs = []
             for src in srcs:
                 obj = os.path.join(OUT, os.path.basename(src) + ".o")
-                cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-I", HERE, "-I", CSRC,
+                cmd = [_cxx(), "-x", "c++", "-std=c++17", "-O2", "-mf16c", "-fPIC", "-I", HERE, "-I", CSRC,
                        "-I", os.path.join(ROOT, "include"), "-Wno-unknown-pragmas", "-Wno-unknown-attributes", "-Wno-psabi", "-c", src,
                        "-o", obj]
                 if verbose:

@@ -30,6 +30,7 @@ inline f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) { return emu::mfma_16x1
 inline f32x16 mfma_bf16_32x32x16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_bf16(a, b, c); }
 inline f32x4 mfma_bf16_16x16x32(u32x4 a, u32x4 b, f32x4 c) { return emu::mfma_16x16x32_bf16(a, b, c); }
 inline f32x16 mfma_f16_32x32x16(u32x4 a, u32x4 b, f32x16 c) { return emu::mfma_32x32x16_f16(a, b, c); }
+inline f32x4 mfma_f16_16x16x32(u32x4 a, u32x4 b, f32x4 c) { return emu::mfma_16x16x32_f16(a, b, c); }
 inline unsigned pack_f16(float x0, float x1) { return (unsigned)emu::emu_float_to_half(x0) | ((unsigned)emu::emu_float_to_half(x1) << 16); }
 inline float f16_lo(unsigned w) { return emu::emu_half_to_float((unsigned short)(w & 0xffffu)); }
 inline float f16_hi(unsigned w) { return emu::emu_half_to_float((unsigned short)(w >> 16)); }

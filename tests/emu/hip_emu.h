@@ -253,6 +253,30 @@ inline f32x16 mfma_32x32x16_f16(emu_u32x4 a, emu_u32x4 b, f32x16 c) {
 }
 
 // v_mfma_f32_16x16x32_bf16: A[i = l&15][k = 8*(l>>4) + e], B[k = 8*(l>>4) + e][j = l&15], D as the fp32 16x16 form.
+inline f32x4 mfma_16x16x32_f16(emu_u32x4 a, emu_u32x4 b, f32x4 c) {
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int p = w.parity;
+    for (int i = 0; i < 4; ++i) {
+        w.xa[p][lane][i] = a[i];
+        w.xb[p][lane][i] = b[i];
+    }
+    wave_barrier(w);
+    int j = lane & 15, q = lane >> 4;
+    auto hf = [](unsigned word, int e) { return emu_half_to_float((unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu))); };
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * q + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g)
+            for (int e = 0; e < 8; ++e)
+                acc = fmaf(hf(w.xa[p][i + 16 * g][e >> 1], e), hf(w.xb[p][j + 16 * g][e >> 1], e), acc);
+        d[r] = acc;
+    }
+    wave_exchange_done(p);
+    return d;
+}
+
 inline f32x4 mfma_16x16x32_bf16(emu_u32x4 a, emu_u32x4 b, f32x4 c) {
     WaveX& w = my_wave();
     int lane = S().cur->linear & 63;

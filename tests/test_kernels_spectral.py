@@ -570,7 +570,7 @@ def test_spectral_x3_many_modes_dft_table_is_bit_identical(be, B, M, N, Ka, Kb, 
     words bit for bit, single launches of both axes and the paired launch (also a pair whose axes need different tile heights,
     or one axis with <= 16 modes: the library then falls back to building on the fly for both)."""
     from fourierflow_amd._capi import FusedBranch
-    if be.kind == "emu" and (B > 1 or M > 100 or (direction == "adj" and Ka > 30)):
+    if be.kind == "emu" and (B > 1 or M > 100 or Ka > 30 or (direction == "adj" and Kb > 16)):
         pytest.skip("emulator time budget (the GPU run covers all)")
     C = 64
     lib, p = be.lib, be.ptr
@@ -790,6 +790,53 @@ def test_spectral_x3_width32_pair_equals_single_branches(be, B, M, N, K, directi
     for i in range(2):
         np.testing.assert_array_equal(be.get(outs2[i]), be.get(outs1[i]))
         np.testing.assert_array_equal(be.get(sv2[i]), be.get(sv1[i]))
+
+
+@pytest.mark.parametrize("B,M,N,K", [(1, 12, 16, 5), (2, 72, 10, 4), (1, 14, 72, 8)])
+@pytest.mark.parametrize("direction", ["fwd", "adj"])
+def test_spectral_x3_width32_dft_table_is_bit_identical(be, B, M, N, K, direction):
+    """The width-32 kernel loading its DFT-matrix fragments from the table of ffno_spectral_x3_dft_frags (round 4: a wave owns two
+    lines there, so the on-the-fly construction is a quarter of its vector work) against the on-the-fly path: outputs, saved
+    spectra, range words bit for bit; single launches and the paired launch."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and B * M * N > 1100:
+        pytest.skip("emulator time budget (the GPU run covers it)")
+    C = 32
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + K)
+    x, resid = (rs.standard_normal((B, M, N, C)).astype(np.float32) for _ in range(2))
+    dx, dres = be.put(x), be.put(resid)
+    xw = be.zeros(1, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(xw), None) == 0
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br, keep = [], []
+    for axis in (0, 1):
+        L = N if axis == 0 else M
+        w = (rs.standard_normal((C, C, K, 2)) / 6).astype(np.float32)
+        pk_f, pk_a, kp = _x3_pack(be, w, K, C=32, fmt=1)
+        tw = be.twiddle(L)
+        tab = be.zeros((int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) // 4,), np.uint32)
+        assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
+        keep += [kp, tw, tab]
+        br.append(dict(axis=axis, R=B * M if axis == 0 else B * N, tw=tw, tab=tab, planes=pk_a if direction == "adj" else pk_f))
+
+    def run(with_tab, paired):
+        outs, sv = [be.empty(x.shape), be.empty(x.shape)], [be.empty((K, b["R"], 2, C)) for b in br]
+        words = [be.zeros(1, np.uint32), be.zeros(1, np.uint32)]
+        ds = [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"]), p(b["tw"]), B, M, N, K,
+                          b["axis"], 0, 1, 0, p(xw), p(words[i]), 0, 0, p(b["tab"]) if with_tab else None) for i, b in enumerate(br)]
+        if paired:
+            assert lib.ffno_spectral_x3_pair(ctypes.byref(ds[0]), ctypes.byref(ds[1]), C, fwd_ck, inv_ck, conj, 1, None) == 0
+        else:
+            for d in ds:
+                assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
+        return [be.get(t).copy() for t in outs + sv] + [np.asarray(be.get(t)).copy() for t in words]
+
+    ref = run(False, False)
+    assert all(np.all(np.isfinite(a)) for a in ref[:4])
+    for paired in (False, True):
+        for a, b in zip(run(True, paired), ref):
+            np.testing.assert_array_equal(a, b)
 
 
 def test_spectral_x3_support_matrix(be):

@@ -141,8 +141,9 @@ def test_spectral_x3_twin_is_the_rounded_fp32_kernel(be, B, M, N, K, tile, C):
     on the K <= 16 kernel, the many-mode kernel (VERDICT r03 #5a: BASELINE configs[3] shapes) and the width-32 kernel
     (configs[4])."""
     lib, p = be.lib, be.ptr
-    if be.kind == "emu" and K > 30:
-        pytest.skip("emulator time budget (the GPU run covers it)")
+    if be.kind == "emu" and K > 16:
+        pytest.skip("emulator time budget (the GPU run covers the many-mode twins; test_block_with_many_modes_on_bf16_storage runs "
+                    "the kernel on the emulator)")
     rs = np.random.RandomState(B * 100 + M)
     x_h, x = bf16_data(rs, (B, M, N, C))
     r_h, r = bf16_data(rs, (B, M, N, C))
