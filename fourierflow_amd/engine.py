@@ -992,9 +992,10 @@ class FFNOEngine:
         # format of the packed x3 weight sets per axis: fp16x2 where the FUSED x3 kernel mixes with them (the stage kernels of
         # the 17..32-mode axes read bf16x3 packs)
         # ... and FFNO_PLANES_FP16X2_M16 (the 16-row mix) for the many-mode axes (width 64, 17..64 modes: 4-line tiles with 8 live mix
-        # rows) when their DFT-fragment tables are in use and all of them share a tile height (a paired launch needs one)
+        # rows) when their DFT-fragment tables are in use and ALL axes are such and share a tile height (a paired launch carries one
+        # format and one tile height)
         many = [v.K > 16 for v in ws.views]
-        m16 = bool(self.x3_mix16 and self.x3_dft_tables and C == 64 and len({v.K <= 32 for v, m in zip(ws.views, many) if m}) == 1)
+        m16 = bool(self.x3_mix16 and self.x3_dft_tables and C == 64 and all(many) and len({v.K <= 32 for v in ws.views}) == 1)
         self._x3_fmt = [(2 if (m16 and many[w]) else 1) if (self._x3_h2() and fused[w] and x3[w]) else 0 for w in range(len(ws.views))]
         for w, v in enumerate(ws.views):
             v.x3fmt = self._x3_fmt[w]

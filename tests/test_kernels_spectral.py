@@ -522,15 +522,19 @@ def test_spectral_x3_pair_equals_single_branches(be, x3_tile, B, M, N, K, direct
 @pytest.mark.parametrize("B,M,N,K,axis", [(1, 40, 48, 20, 0), (1, 40, 48, 20, 1), (1, 70, 8, 34, 1), (2, 66, 70, 32, 0), (2, 66, 70, 32, 1),
                                           (1, 130, 136, 64, 0), (2, 256, 256, 32, 1)])
 @pytest.mark.parametrize("direction", ["fwd", "adj", "lowpass"])
-@pytest.mark.parametrize("fmt", [0, 1], ids=["bf16x3", "fp16x2"])
+@pytest.mark.parametrize("fmt", [0, 1, 2], ids=["bf16x3", "fp16x2", "fp16x2-mix16"])
 def test_spectral_x3_fused_many_modes(be, B, M, N, K, axis, direction, fmt):
     """17..64 modes per axis on the FUSED split kernel (spectral_x3k: four lines per workgroup, the spectrum tile in LDS) -- the
     256 x 256 regime of torus_kochkov (32 modes; the reference's own config runs 64) that used to go through three stage
     launches and HBM spectra.  Against the fp64 reference at the fp32 tolerance: forward / adjoint / low-pass, the saved
-    spectrum, ragged line counts (R % 4 != 0), lengths that are not multiples of 32 or 64, both pack formats (with the range
-    word for fp16x2), accumulate + residual epilogue, and the recorded output maximum."""
+    spectrum, ragged line counts (R % 4 != 0), lengths that are not multiples of 32 or 64, all pack formats (with the range
+    word for fp16x2; format 2 = the 16-row mix, which ships with the DFT-fragment table), accumulate + residual epilogue, and
+    the recorded output maximum."""
     from fourierflow_amd._capi import FusedBranch
-    if be.kind == "emu" and (K > 34 or B > 1 or (direction == "lowpass" and fmt) or (K == 20 and fmt and direction == "adj")):
+    if fmt == 2 and direction == "lowpass":
+        pytest.skip("no mix in the low-pass: the pack format does not enter")
+    if be.kind == "emu" and (K > 34 or B > 1 or (direction == "lowpass" and fmt) or (K == 20 and fmt == 1 and direction == "adj") or
+                             (fmt == 2 and K == 34)):
         pytest.skip("emulator time budget (the GPU run covers all)")
     C = 64
     L = N if axis == 0 else M
@@ -549,7 +553,13 @@ def test_spectral_x3_fused_many_modes(be, B, M, N, K, axis, direction, fmt):
     planes = None if direction == "lowpass" else (pk_a if direction == "adj" else pk_f)
     xw, ow = be.zeros(1, np.uint32), be.zeros(1, np.uint32)
     assert lib.ffno_amax(p(dx), x.size, p(xw), None) == 0
-    br = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, 0, p(xw), p(ow))
+    tab = None
+    if fmt == 2:
+        br = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, 0, p(xw), p(ow))
+        assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == -2      # FFNO_EUNSUPPORTED without the table
+        tab = be.zeros((int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) // 4,), np.uint32)
+        assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
+    br = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, 0, p(xw), p(ow), 0, 0, p(tab))
     assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
     got = be.get(out)
     assert np.all(np.isfinite(got)) and rel_l2(got, ref) < TOL
@@ -557,7 +567,7 @@ def test_spectral_x3_fused_many_modes(be, B, M, N, K, axis, direction, fmt):
     assert np.asarray(be.get(ow)).view(np.float32)[0] == np.abs(got).max()
     resid = (rs.standard_normal(x.shape) * mag).astype(np.float32)       # accumulate + residual epilogue, no spectrum save
     dres = be.put(resid)          # (kept alive across the call: the descriptor holds a raw pointer)
-    br = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1, fmt, 0, p(xw), None)
+    br = FusedBranch(p(dx), p(out), p(dres), None, p(planes), p(tw), B, M, N, K, axis, 1, fmt, 0, p(xw), None, 0, 0, p(tab))
     assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
     assert rel_l2(be.get(out), 2 * ref + resid) < TOL
 
@@ -611,6 +621,65 @@ def test_spectral_x3_many_modes_dft_table_is_bit_identical(be, B, M, N, Ka, Kb, 
     for paired in (False, True):
         for a, b in zip(run(True, paired), ref):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("B,M,N,Ka,Kb", [(1, 40, 48, 20, 18), (2, 256, 256, 32, 32), (1, 130, 136, 64, 40), (1, 36, 70, 34, 17)])
+@pytest.mark.parametrize("direction", ["fwd", "adj"])
+def test_spectral_x3_many_modes_mix16_pair(be, B, M, N, Ka, Kb, direction):
+    """FFNO_PLANES_FP16X2_M16 (the mix of a 4-line tile on 16-row MFMA tiles: 8 live rows of 16 instead of 8 of 32): the paired
+    launch equals the two single launches bit for bit (outputs, saved spectra, range words), and both stay within fp32 rounding
+    of the 32-row mix on the same inputs (the products are the same; only the accumulation order inside the MFMA differs).  A
+    pair whose axes need different tile heights has no common table layout: FFNO_EUNSUPPORTED, the engine keeps format 1 there."""
+    from fourierflow_amd._capi import FusedBranch
+    if be.kind == "emu" and (B > 1 or M > 100 or direction == "adj"):
+        pytest.skip("emulator time budget (the GPU run covers all)")
+    C = 64
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(B + M + N + Ka)
+    x, resid = (rs.standard_normal((B, M, N, C)).astype(np.float32) for _ in range(2))
+    dx, dres = be.put(x), be.put(resid)
+    xw = be.zeros(1, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(xw), None) == 0
+    fwd_ck, inv_ck, conj = (0, 1, 0) if direction != "adj" else (1, 0, 1)
+    br, keep = [], []
+    for axis, K in ((0, Ka), (1, Kb)):
+        L = N if axis == 0 else M
+        w = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+        packs = {fmt: _x3_pack(be, w, K, fmt=fmt) for fmt in (1, 2)}
+        tw = be.twiddle(L)
+        tab = be.zeros((int(lib.ffno_spectral_x3_dft_frags_bytes(L, K)) // 4,), np.uint32)
+        assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
+        keep += [packs, tw, tab]
+        br.append(dict(axis=axis, K=K, R=B * M if axis == 0 else B * N, tw=tw, tab=tab,
+                       planes={fmt: pk[1] if direction == "adj" else pk[0] for fmt, pk in packs.items()}))
+    same_tile = (Ka <= 32) == (Kb <= 32)
+
+    def run(fmt, paired):
+        outs, sv = [be.empty(x.shape), be.empty(x.shape)], [be.empty((b["K"], b["R"], 2, C)) for b in br]
+        words = [be.zeros(1, np.uint32), be.zeros(1, np.uint32)]
+        ds = [FusedBranch(p(dx), p(outs[i]), p(dres) if i == 0 else None, p(sv[i]), p(b["planes"][fmt]), p(b["tw"]), B, M, N, b["K"],
+                          b["axis"], 0, fmt, 0, p(xw), p(words[i]), 0, 0, p(b["tab"])) for i, b in enumerate(br)]
+        if paired:
+            rc = lib.ffno_spectral_x3_pair(ctypes.byref(ds[0]), ctypes.byref(ds[1]), C, fwd_ck, inv_ck, conj, 3, None)
+            if fmt == 2 and not same_tile:
+                assert rc == -2
+                return None
+            assert rc == 0
+        else:
+            for d in ds:
+                assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
+        return [be.get(t).copy() for t in outs + sv] + [np.asarray(be.get(t)).copy() for t in words]
+
+    single = run(2, False)
+    assert all(np.all(np.isfinite(a)) for a in single[:4])
+    pair = run(2, True)
+    if pair is not None:
+        for a, b in zip(pair, single):
+            np.testing.assert_array_equal(a, b)
+    for a, b in zip(single[:2], run(1, False)[:2]):
+        assert rel_l2(a, b) < 3e-7
+    for a, b in zip(single[2:4], run(1, False)[2:4]):      # saved spectra: before the mix -- the same bits
+        np.testing.assert_array_equal(a, b)
 
 
 @pytest.mark.parametrize("B,M,N,K", [(1, 8, 12, 3), (1, 64, 64, 16), (2, 6, 10, 5), (1, 3, 72, 16), (3, 5, 7, 2), (1, 13, 9, 4)])
