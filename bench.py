@@ -565,6 +565,11 @@ def main():
         P = B * G * G
         C, H, K = kw["width"], kw["width"] * kw["factor"], kw["modes"]
         work = algorithmic_work(P, C, H, K, B, G, G, args.layers, paired)
+        if len(probe.calls.get("ff_bwd_weights_partial", [])) == 1 and args.layers > 1:
+            # the weight-gradient slices of ALL layers from one launch after the backward loop (engine.ff_wgrad_deferred)
+            w = work["ff_bwd_weights_partial"]
+            w.update(flops=w["flops"] * args.layers, bytes=w["bytes"] * args.layers, floor=w["floor"] * args.layers, per_step=1,
+                     formula="read s + g of all %d layers (one launch)" % args.layers)
         pmc, pmc_meta = {}, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -717,6 +722,14 @@ def main():
             finally:
                 eng.storage = "fp32"
                 eng.timer = None
+        # (GPU legs first: the CPU baseline leaves a host thread pool behind, and the batch-1 64^3 step is sensitive to launch rate)
+        secondary = None
+        if headline and world == 1 and not args.no_secondary:
+            log("secondary workloads (256x256 and 64^3)")
+            try:
+                secondary = secondary_workloads(dev)
+            except Exception as e:  # noqa: BLE001 - never lose the headline line to a secondary workload
+                secondary = [dict(error=repr(e))]
         cpu = cpu19 = None
         if world == 1 and args.cpu_steps > 0 and not args.plus:
             cpu = cpu_baseline(B, G, kw, warm=2, timed=args.cpu_steps)
@@ -742,13 +755,6 @@ def main():
             # the GPU is compared with (`speedup_vs_cpu_baseline`) is samples/s against the best form, under its own name
             cpu["best_form_steps_per_s_equivalent"] = round(forms[best] / B, 4)
             cpu["unit"] = "steps/s"
-        secondary = None
-        if headline and world == 1 and not args.no_secondary:
-            log("secondary workloads (256x256 and 64^3)")
-            try:
-                secondary = secondary_workloads(dev)
-            except Exception as e:  # noqa: BLE001 - never lose the headline line to a secondary workload
-                secondary = [dict(error=repr(e))]
         dist_info = None
         if world > 1:
             try:

@@ -9,7 +9,7 @@ import ctypes as C
 
 # generation of include/ffno.h these signatures and struct mirrors belong to (FFNO_ABI_VERSION there; _lib.check_abi compares
 # it with what the loaded library reports before anything is called)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 P = C.c_void_p
 I = C.c_int
@@ -62,6 +62,11 @@ class LayerBwdDesc(C.Structure):
 class FxRedDesc(C.Structure):
     """Mirror of ``ffno_fxred_desc`` (include/ffno.h)."""
     _fields_ = [("partial", P), ("dW1", P), ("dW2", P), ("db1", P), ("db2", P)]
+
+
+class FfWgDesc(C.Structure):
+    """Mirror of ``ffno_ffwg_desc`` (include/ffno.h)."""
+    _fields_ = [("s", P), ("g", P), ("pk1", P), ("b1", P), ("pk1b", P), ("partial", P), ("s_amax", P), ("g_amax", P)]
 
 
 class MarkovExtra(C.Structure):
@@ -148,6 +153,7 @@ SIGNATURES = {
     "ffno_ffh_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffh_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P, I, P]),
+    "ffno_ffh_bwd_weights_partial_multi": (I, [P, I, I, I, I, I, I, P]),
     "ffno_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ffno_layernorm_nsplit": (I, [L]),
     "ffno_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),

@@ -968,12 +968,13 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //     independent instruction streams) -- measured 64 us against 56: a lone wave per SIMD exposes every LDS / HBM round trip
 //     that its partner hides in the eight-wave form (round 3, DESIGN.md "Negative results"), so it is not compiled in;
 //   * branch-free tile loop (one basic block: the scheduler interleaves staging / epilogue vector work with the MFMAs).
+//   * the body takes its slice index and slice count as arguments (bid of nb): the per-layer launch passes its block index and
+//     grid size, the all-layers launch (ffh_wgrad_m_multi_kernel below) the position inside its layer's slices.
 template <int C, int H, int NWV, class ST = StF32>
-__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST::T* __restrict__ s,
-                                                               const typename ST::T* __restrict__ db,
-                                                               const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
-                                                               const u32x4* __restrict__ pk2t, float* __restrict__ partial,
-                                                               int P, const unsigned* s_amax, const unsigned* db_amax) {
+__device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restrict__ s, const typename ST::T* __restrict__ db,
+                                                 const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
+                                                 const u32x4* __restrict__ pk2t, float* __restrict__ partial, int P,
+                                                 const unsigned* s_amax, const unsigned* db_amax, const int bid, const int nb) {
     constexpr int CPW = H / (32 * NWV);            // hidden chunks per wave
     using F = FxCfg<C, H, CPW>;
     constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV;
@@ -1083,13 +1084,13 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         for (int mt = 0; mt < CTO; ++mt) acc1[ch][mt] = zero16(), acc2[ch][mt] = zero16();
     }
 
-    gload(blockIdx.x);
-    stage(0, blockIdx.x);
-    gload(blockIdx.x + gridDim.x);
+    gload(bid);
+    stage(0, bid);
+    gload(bid + nb);
     __syncthreads();
     int buf = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        const int nt = tile + gridDim.x;
+    for (int tile = bid; tile < ntiles; tile += nb, buf ^= 1) {
+        const int nt = tile + nb;
         const char* L = lds[buf];
         // The 16 operand fragments of a tile, in the order the products consume them (s, db^T, db, s^T), come through a ring of
         // two: fragment i + 2 is requested when fragment i has been handed to its MFMAs, and the request is pinned there (a
@@ -1109,7 +1110,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         // places between the MFMAs of the h GEMM below
         stage(buf ^ 1, nt);
         if constexpr (NWV == 8) {     // two waves per SIMD hide each other's round trips; the registers are too few to hold the
-            gload(nt + gridDim.x);    // rows of the next tile across the whole iteration (the scheduler sinks the requests)
+            gload(nt + nb);    // rows of the next tile across the whole iteration (the scheduler sinks the requests)
             FFNO_SCHED_PIN_VMEM();
         }
         // h^T[px][hid] = relu(s W1^T + b1), pixels on the D rows: main + correction tile, as in the forward kernel
@@ -1130,7 +1131,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         // used.  The fence keeps the requests HERE: left alone the scheduler sinks them to the end of the iteration, next to
         // their use at the top of the next one, and the wave waits out every HBM round trip.
         if constexpr (NWV != 8) {
-            gload(nt + gridDim.x);
+            gload(nt + nb);
             FFNO_SCHED_FENCE();
         }
         Hf2 hb[CPW][2];
@@ -1199,7 +1200,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
 
     // (powers of two: exact; applied one after the other so that their product never leaves the float range)
     const float rg = 1.f / gscale, rf = 1.f / fscale;
-    float* part = partial + (long)blockIdx.x * F::PART;
+    float* part = partial + (long)bid * F::PART;
     float* pW1t = part;              // [c][hid]
     float* pW2 = part + H * C;       // [c][hid]
     float* pb1 = part + 2 * H * C;
@@ -1226,6 +1227,40 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST
         for (int k = tid; k < F::NT; k += C) v += red[k];
         pb2[tid] = v * rg;
     }
+}
+
+template <int C, int H, int NWV, class ST = StF32>
+__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_kernel(const typename ST::T* __restrict__ s,
+                                                               const typename ST::T* __restrict__ db,
+                                                               const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
+                                                               const u32x4* __restrict__ pk2t, float* __restrict__ partial,
+                                                               int P, const unsigned* s_amax, const unsigned* db_amax) {
+    ffh_wgrad_m_body<C, H, NWV, ST>(s, db, pk1, bias1, pk2t, partial, P, s_amax, db_amax, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The weight-gradient launches of ALL layers of a backward pass as one (ffno_ffh_bwd_weights_partial_multi).  Nothing downstream
+// of a layer's weight gradient is on the backward's critical path, so the engine keeps every layer's (s, summed gradient) and
+// runs this once at the end: `nsplit` workgroups per layer, each walking ntiles / nsplit tiles of its layer.  Measured on the
+// per-layer launch (MI355X, round 4, batch 8..128): 7.3 us + 1.5 us per image -- the constant is the fragment loads at the
+// start and the burst of 256 x 132 KB slices at the end, plus 7 us per layer in the reduce kernel that reads them back.  With
+// 3 x CUs / L slices per layer (768 workgroups for 24 layers, three full rounds) a workgroup walks 8 x as many tiles per slice.
+struct FfWgDesc {
+    const void* s;
+    const void* g;
+    const u32x4* pk1;
+    const float* b1;
+    const u32x4* pk2t;
+    float* partial;
+    const unsigned* s_amax;
+    const unsigned* g_amax;
+};
+
+template <int C, int H, int NWV, class ST = StF32>
+__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_multi_kernel(const FfWgDesc* __restrict__ descs, int P, int nsplit) {
+    const int layer = (int)blockIdx.x / nsplit;
+    const FfWgDesc d = descs[layer];
+    ffh_wgrad_m_body<C, H, NWV, ST>((const typename ST::T*)d.s, (const typename ST::T*)d.g, d.pk1, d.b1, d.pk2t, d.partial, P,
+                                    d.s_amax, d.g_amax, (int)blockIdx.x - layer * nsplit, nsplit);
 }
 
 // partial slices -> gradients; the dW1 block of a slice is [c][hid] (transposed)
@@ -1536,6 +1571,23 @@ extern "C" int ffno_ffh_bwd_weights_partial(const float* s, const float* db, con
                                             const void* pk1b, float* partial, int P, int C, int H, int nsplit,
                                             const uint32_t* s_amax, const uint32_t* db_amax, int storage, void* stream) {
     return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, s_amax, db_amax, storage, stream);
+}
+
+extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit,
+                                                  int storage, void* stream) {
+    static_assert(sizeof(ffno_ffwg_desc) == sizeof(FfWgDesc), "descriptor layout");
+    if (!descs_dev || n <= 0 || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    if (storage != FFNO_STORE_F32 && storage != FFNO_STORE_BF16) return FFNO_EINVAL;
+    if (!((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const FfWgDesc* d = reinterpret_cast<const FfWgDesc*>(descs_dev);
+    const dim3 grid((unsigned)n * (unsigned)nsplit);
+    const bool b16 = storage == FFNO_STORE_BF16;
+    if (C == 64 && b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16>), grid, dim3(512), 0, st, d, P, nsplit);
+    else if (C == 64) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8>), grid, dim3(512), 0, st, d, P, nsplit);
+    else if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<32, 128, 4, StBf16>), grid, dim3(256), 0, st, d, P, nsplit);
+    else FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<32, 128, 4>), grid, dim3(256), 0, st, d, P, nsplit);
+    return ffx_launch_status();
 }
 
 extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,

@@ -43,6 +43,7 @@ extern "C" int ffno_layer_bwd(const ffno_layer_bwd_desc* d, void* stream) {
     if (rc) return rc;
     // the weight-gradient kernel reads the summed gradient (g_sum when a second addend was given, else g)
     const float* gw = d->g2 ? d->g_sum : d->g;
+    if (!d->partial) return layer_branches(&d->a, &d->b, d->branch_kernel, d->interleave, d->C, 0, stream);      // (deferred)
     rc = h2 ? ffno_ffh_bwd_weights_partial(d->s, gw, d->pk1, d->b1, d->pk1b, d->partial, d->P, d->C, d->H, d->nsplit,
                                            d->s_amax, d->g_amax, d->a.storage, stream)
             : ffno_ffx_bwd_weights_partial(d->s, gw, d->pk1, d->b1, d->pk1b, d->partial, d->P, d->C, d->H, d->nsplit, stream);

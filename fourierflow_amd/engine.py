@@ -228,6 +228,11 @@ class FFNOEngine:
         # rebuilding them from the twiddle table for every line (bit-identical results; False = rebuild: tests)
         self.x3_dft_tables = True
         self._dft_tabs = {}
+        # feed-forward weight gradients of ALL layers as one launch after the backward loop (ffno_ffh_bwd_weights_partial_multi):
+        # every layer keeps its own gradient buffer instead of the ping-pong pair; `ff_wgrad_rounds` x resident workgroups / L
+        # slices per layer
+        self.ff_wgrad_deferred = os.environ.get("FFNO_FF_WGRAD_DEFERRED", "1") != "0"
+        self.ff_wgrad_rounds = int(os.environ.get("FFNO_FF_WGRAD_ROUNDS", "3"))
         self.x3_mix16 = os.environ.get("FFNO_X3_MIX16", "1") != "0"      # 16-row mix packs for the many-mode kernel (False: 32-row)
         self.x3_min_lines = 1
         self.x3_tile_lines = 0      # lines per workgroup of the fused x3 kernel: 0 = the library chooses, 8 / 16 = forced (tests)
@@ -648,9 +653,17 @@ class FFNOEngine:
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
             ws.DH = [torch.empty(P, H, **f32) if fp32_ff else None for _ in range(2)]   # ping-pong (side-stream option)
             ws.DS = torch.empty(P, C, **act)
-            ws.G = [torch.empty(P, C, **act) for _ in range(2)]    # running gradient, ping-pong per layer
+            # running gradient: a ping-pong pair -- or one buffer per layer when the weight-gradient launches are deferred to
+            # the end of the pass (they read every layer's summed gradient then)
+            ws.defer_wgrad = bool(self.ff_wgrad_deferred and self._ffx() and self._h2() and self._ranged() and not self.share_fork
+                                  and not self.use_fork and not self.layer_norm and not self.general_ff
+                                  and (C, H) in ((64, 256), (32, 128)) and self.mode != "no-fourier")
+            ws.G = [torch.empty(P, C, **act) for _ in range(L + 1 if ws.defer_wgrad else 2)]
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(int(self.ff_wgrad_slices), (P + 127) // 128))
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
+            ws.nsplit_ffm = max(1, min(ws.nsplit_ff, (int(self.ff_wgrad_rounds) * (3 if H <= 128 else 1) * cus) // L))
+            ws.wg_sig, ws.wg_table = None, None
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
             # split-bf16 path with per-layer feed-forwards: every layer keeps its own slices and ONE batched launch
             # reduces them all at the end of the backward pass (24 kernel boundaries less per step)
@@ -825,7 +838,11 @@ class FFNOEngine:
         if self._ffx() and ws.defer_reduce:
             assert not accumulate
             part = ws.ffparts[len(ws.red_jobs)]
-            self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st, rs, rg)
+            if getattr(ws, "wg_jobs", None) is not None:
+                ws.wg_jobs.append((s.data_ptr(), g.data_ptr(), l0.fx[0].data_ptr(), b0.data_ptr(), l0.fx[2].data_ptr(),
+                                   part.data_ptr(), rs.value, rg.value))
+            else:
+                self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st, rs, rg)
             ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gb0.data_ptr(), gb1.data_ptr()))
         elif self._ffx():
             self._ffs_wgrad(s, g, l0, b0, ws.ffpart, P, ws.nsplit_ff, st, rs, rg)
@@ -1193,6 +1210,9 @@ class FFNOEngine:
             self._k("transpose_batched", lib.ffno_transpose_batched, _p(self._tr_dev), self._n_tr, max(C, H), max(C, H), st)
         ff_seen = set()
         ws.red_jobs = []
+        nG = len(ws.G)
+        # deferred weight-gradient launch: (s, summed gradient, packs, words, slices) of every layer, one launch after the loop
+        ws.wg_jobs = [] if (getattr(ws, "defer_wgrad", False) and not use_side and conc) else None
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
                            and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
                            and self.mode != "no-fourier" and not self.layer_norm)
@@ -1200,7 +1220,7 @@ class FFNOEngine:
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
-            g_in, g_out, dh = ws.G[cur], ws.G[1 - cur], ws.DH[l & 1]
+            g_in, g_out, dh = ws.G[cur], ws.G[(cur + 1) % nG], ws.DH[l & 1]
             # words: gradient entering this layer, its feed-forward input, the data gradient, the gradient it hands on
             rg, rs_, rd, rgo = rw(ws, "g", l), rw(ws, "s", l), rw(ws, "d", l), (rw(ws, "g", l - 1) if l > 0 else rw(ws, "g", L))
             if self.use_fork:
@@ -1243,13 +1263,17 @@ class FFNOEngine:
                         self._spectral("spectral_fused(adj)", ws, v, ws.DS, g_out, None, keep,
                                        self._planes_for(si, w, 1, x3[w]), False, int(w > 0), fused[w], st, x3=x3[w],
                                        rin=rd, rout=rgo)
-                cur = 1 - cur
+                cur = (cur + 1) % nG
                 continue
             if layer_calls:
                 # the whole layer backward in one call: FF data gradient (g_in (+)= G1), weight-gradient slices, adjoint pair
                 si = self._fw_sets.index(self.fw_names[l]) if full else 0
                 a, b = pair
                 part = ws.ffparts[len(ws.red_jobs)]
+                if ws.wg_jobs is not None:
+                    ws.wg_jobs.append((ws.S[l].data_ptr(), g_in.data_ptr(), l0.fx[0].data_ptr(),
+                                       self.params[fp + "layers.0.0.bias"].data_ptr(), l0.fx[2].data_ptr(), part.data_ptr(),
+                                       rs_.value, rg.value))
                 d = _capi.LayerBwdDesc(
                     self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
                                  self._planes_for(si, a, 1, x3pair), 0, x3pair, False, rd, rgo),
@@ -1257,13 +1281,13 @@ class FFNOEngine:
                                  self._planes_for(si, b, 1, x3pair), 0, x3pair, False, rd, rgo),
                     int(x3pair), int(self.x3_interleave), _p(g_in), _p(ws.G1) if have_g1 else None, _p(g_in), _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
-                    _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, rg, rs_, rd)
+                    None if ws.wg_jobs is not None else _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, rg, rs_, rd)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
                 ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
                                     gv(fp + "layers.1.0.bias").data_ptr()))
                 ff_seen.add(fp)
                 have_g1 = True
-                cur = 1 - cur
+                cur = (cur + 1) % nG
                 continue
             g_ff = g_in       # gradient w.r.t. the feed-forward output
             if self.layer_norm:
@@ -1307,7 +1331,7 @@ class FFNOEngine:
                 else:
                     torch.add(g_in, ws.DS, out=g_out)
                 self._fold(g_out, rgo, st)
-                cur = 1 - cur
+                cur = (cur + 1) % nG
                 continue
             si = self._fw_sets.index(self.fw_names[l]) if full else 0
             resid = None if last else _p(g_in)      # G_{l-1} = G_l (residual path) + adjoint terms; last layer: none
@@ -1325,7 +1349,7 @@ class FFNOEngine:
                            self._planes_for(si, a, 1, x3pair), self._planes_for(si, b, 1, x3pair), False, st,
                            acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rd, rout=rgo)
             have_g1 = conc
-            cur = 1 - cur
+            cur = (cur + 1) % nG
         if conc and have_g1:      # lift_bwd takes one input
             if self._bf16():
                 ws.G[cur].add_(ws.G1)       # (a torch kernel on the same stream; rounds the sum to bf16 like every stored tensor)
@@ -1333,6 +1357,16 @@ class FFNOEngine:
                 self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(ws.G1), 1.0, P * C, st)
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
+        nsl = ws.nsplit_ff
+        if ws.wg_jobs:
+            nsl = ws.nsplit_ffm
+            sig = tuple(ws.wg_jobs)
+            if sig != ws.wg_sig:
+                arr = (_capi.FfWgDesc * len(sig))(*[_capi.FfWgDesc(*j) for j in sig])
+                ws.wg_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+                ws.wg_sig = sig
+            self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial_multi, _p(ws.wg_table), len(sig), P, C, H, nsl,
+                    self._st(), st)
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:
             sig = tuple(ws.red_jobs)
             if sig != ws.red_sig:       # pointers only change when parameters are re-bound or the workspace is rebuilt
@@ -1340,7 +1374,7 @@ class FFNOEngine:
                 ws.red_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
                 ws.red_sig = sig
             self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce_batched, _p(ws.red_table), len(sig), C, H,
-                    ws.nsplit_ff, st)     # main stream: it has already waited for the side stream's partial kernels
+                    nsl, st)     # main stream: it has already waited for the side stream's partial kernels
         g_fin = ws.G[cur]
         lin_in = self.linears["in_proj."]
         if self._training and self.in_dropout > 0.0:      # backward of x = self.drop(in_proj(x)): the same mask, regenerated

@@ -73,7 +73,7 @@ const char* ffno_build_target(void);
  * library under newer host code would have read shifted arguments).  ffno_abi_version() returns the value the LIBRARY was built
  * with; a caller compares it with the FFNO_ABI_VERSION it was compiled against before the first compute call (the Python host
  * does: fourierflow_amd/_lib.py refuses a mismatch). */
-#define FFNO_ABI_VERSION 4
+#define FFNO_ABI_VERSION 5
 int ffno_abi_version(void);
 
 /* word[0] = max(word[0], bits(max |x[i]|)): folds a tensor into a range word (see "Range words" above) */
@@ -263,7 +263,8 @@ int ffno_spectral_x3_staged_pair(const ffno_fused_branch* a, const ffno_fused_br
  *         out = resid + FF(a.out + b.out);  s_sum (optional, may alias a.out) keeps the FF input for the backward pass,
  *         mask (optional) the ReLU sign bits.
  *   bwd:  ds = FF^T(g [+ g2])  (the sum is stored to g_sum when g2 is given);  partial <- feed-forward weight-gradient slices
- *         (ffno_ffx_bwd_weights_partial: reduce them with ffno_ffx_bwd_weights_reduce[_batched]);  then the adjoint branches
+ *         (ffno_ffx_bwd_weights_partial: reduce them with ffno_ffx_bwd_weights_reduce[_batched]; partial == NULL: skipped --
+ *         the caller runs ffno_ffh_bwd_weights_partial_multi over all layers after the pass);  then the adjoint branches
  *         a, b (a.in == b.in == ds; a.resid = the residual gradient), which also save the dY spectra for the Fourier-weight
  *         gradient through a.spec_save / b.spec_save.
  * branch_kernel selects the fused branch kernel: FFNO_BRANCH_X3 (planes = packed split-bf16 sets) or FFNO_BRANCH_FUSED
@@ -473,6 +474,25 @@ int ffno_ffh_bwd_data2(const float* db, const float* db2, float* db_sum, const v
 int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk1, const float* b1, const void* pk1b,
                                  float* partial, int P, int C, int H, int nsplit, const uint32_t* s_amax,
                                  const uint32_t* db_amax, int storage /* FFNO_STORE_*: format of s and db */, void* stream);
+/* The weight-gradient slices of n feed-forward blocks (all layers of a backward pass) in ONE launch: nothing downstream of a
+ * layer's weight gradient is on the backward's critical path, so a caller that keeps every layer's s and summed gradient runs
+ * this once after the last layer's data gradient.  Per block: `nsplit` slices (layout of ffno_ffx_bwd_weights_partial) at
+ * descs[i].partial; the grid is n x nsplit workgroups -- 3 x CUs / n slices per block keeps three full rounds of workgroups and
+ * makes each one walk many tiles per slice written (the per-layer launch pays 7 us of fragment loads + slice burst and its
+ * reduce 7 us per layer at the headline shape, MI355X round 4).  Both range words of every block are required; width 64 / 256
+ * and 32 / 128 (the single-accumulator kernel's shapes); `descs_dev` is a DEVICE array. */
+typedef struct ffno_ffwg_desc {
+    const void* s;           /* feed-forward input of the block  [P, C], storage format of the call */
+    const void* g;           /* gradient w.r.t. its output       [P, C] */
+    const void* pk1;         /* forward pack of W1 (ffno_ffh_pack) */
+    const float* b1;
+    const void* pk1b;        /* backward pack (the pk1b argument of ffno_ffh_bwd_weights_partial) */
+    float* partial;          /* nsplit slices */
+    const uint32_t* s_amax;
+    const uint32_t* g_amax;
+} ffno_ffwg_desc;
+int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit, int storage,
+                                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),

@@ -139,6 +139,43 @@ def test_ffh_fwd_bwd(be, P, C, H, sched):
     assert rel_l2(be.get(ds), ref_ds) < 3e-5
 
 
+@pytest.mark.parametrize("P,C,H,nsplit", [(200, 64, 256, 2), (131, 32, 128, 3), (4100, 64, 256, 5)])
+def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit):
+    """ffno_ffh_bwd_weights_partial_multi: the slices of n feed-forward blocks (own inputs, gradients, weights, range words) from
+    ONE launch equal the n per-block launches with the same slice count bit for bit -- the same kernel body, the workgroup only
+    finds its block and slice from the table.  Ragged last tile, a slice count that does not divide the tile count."""
+    from fourierflow_amd._capi import FfWgDesc
+    if be.kind == "emu" and P > 1000:
+        pytest.skip("large case on the GPU only")
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(P + nsplit)
+    n = 3
+    nfl = int(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
+    keep, descs, singles = [], [], []
+    for i in range(n):
+        s = (rs.standard_normal((P, C)) * 10.0 ** (i - 1)).astype(np.float32)
+        g = (rs.standard_normal((P, C)) * 10.0 ** (-3 * i)).astype(np.float32)
+        W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+        W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+        b1 = be.put((rs.standard_normal(H) * 0.1).astype(np.float32))
+        (a1, a2, a1b, a2b), k_ = pack_weights_h(be, W1, W2)
+        ds_, dg = be.put(s), be.put(g)
+        sw, gw = amax_word(be, s), amax_word(be, g)
+        one, multi = be.zeros(nfl), be.zeros(nfl)
+        assert lib.ffno_ffh_bwd_weights_partial(p(ds_), p(dg), p(a1), p(b1), p(a1b), p(one), P, C, H, nsplit, p(sw), p(gw), 0, None) == 0
+        singles.append((one, multi))
+        descs.append(FfWgDesc(p(ds_), p(dg), p(a1), p(b1), p(a1b), p(multi), p(sw), p(gw)))
+        keep += [ds_, dg, b1, a1, a2, a1b, a2b, k_, sw, gw]
+    table = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs)), dtype=np.uint8).copy())
+    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, C, H, nsplit, 0, None) == 0
+    for one, multi in singles:
+        a = be.get(one)
+        assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
+        np.testing.assert_array_equal(be.get(multi), a)
+    assert lib.ffno_ffh_bwd_weights_partial_multi(None, n, P, C, H, nsplit, 0, None) == -1
+    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, 64, 128, nsplit, 0, None) == -2
+
+
 @pytest.mark.parametrize("act,grad", [(1e5, 1e4), (1e6, 1e-12), (3e-9, 7e7), (1.0, 1.0)])
 def test_ffh_any_fp32_magnitude_is_in_range(be, act, grad):
     """activations of 1e5 / 1e6 (>= 65504 used to become inf in the fp16 planes) and gradients of any

@@ -463,8 +463,10 @@ def test_spectral_x3_branch_fp16x2_mix(be, x3_tile, B, M, N, K, axis, direction,
     assert lib.ffno_spectral_x3(ctypes.byref(br), C, fwd_ck, inv_ck, conj, None) == 0
     assert rel_l2(be.get(out), 2 * ref + resid) < TOL
     # unknown plane formats / tile sizes are refused
-    bad = FusedBranch(p(dx), p(out), None, p(spec), p(pk_f), p(tw), B, M, N, K, axis, 0, 2, 0, None, None)
+    bad = FusedBranch(p(dx), p(out), None, p(spec), p(pk_f), p(tw), B, M, N, K, axis, 0, 3, 0, None, None)
     assert lib.ffno_spectral_x3(ctypes.byref(bad), C, 0, 1, 0, None) == -1
+    bad = FusedBranch(p(dx), p(out), None, p(spec), p(pk_f), p(tw), B, M, N, K, axis, 0, 2, 0, None, None)
+    assert lib.ffno_spectral_x3(ctypes.byref(bad), C, 0, 1, 0, None) == -2      # the 16-row mix: many-mode axes with a table only
     bad = FusedBranch(p(dx), p(out), None, p(spec), p(pk_f), p(tw), B, M, N, K, axis, 0, 1, 12, None, None)
     assert lib.ffno_spectral_x3(ctypes.byref(bad), C, 0, 1, 0, None) == -1
 
