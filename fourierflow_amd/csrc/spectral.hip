@@ -739,7 +739,11 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(4) void spectral_fused_pai
 // end).  A wave keeps BOTH parts of dW for its rows (4*CT accumulators), so every loaded spectrum element is split
 // once and used in CT (X) / 2 (dY) products: per 16-row step 8*CT products = 48*CT MFMAs against 16 + 16*CT split
 // fragments-of-8 -- matrix bound, and in fp32-equivalent FLOP/s 2.7x the fp32 MFMA ceiling, i.e. HBM-bound in practice.
-template <int C>
+// AL (R and the slice length multiples of 16): a 16-row step never straddles a layer or a slice end, so the row pointers are
+// carried from step to step and the eight rows of a lane are immediate offsets from them -- no per-row layer / bounds logic
+// (the general path spends more instructions on that than on the splits: a 64-bit division per straddling row, a predicate and
+// a select per element).
+template <int C, bool AL = false>
 __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restrict__ xs, const float* __restrict__ dys,
                                                            float* __restrict__ partial, int R, int K, int chunk,
                                                            int beta, int nlayers, long stride_x, long stride_dy, long zstride_x,
@@ -766,7 +770,31 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
 
     // raw rows of one 16-row step: this lane's 8 rows v0 + e of  Xr/Xi[.][32a + j]  and  dYr/dYi[.][32b + j]
     float rxr[8], rxi[8], rdr[CT][8], rdi[CT][8];
+    // AL: this lane's first row of the step to load next (layer lc, row rowc of it) -- every second step of the slice
+    long lc = 0, rowc = 0;
+    if constexpr (AL) {
+        const long v0 = vbeg + 16 * (long)grp + 8 * half;
+        lc = v0 / R;
+        rowc = v0 - lc * R;
+    }
     auto load = [&](int t) {
+        if constexpr (AL) {
+            const float* xrow = xk + lc * stride_x + rowc * 2 * C + 32 * a + j;
+            const float* yrow = dk + lc * stride_dy + rowc * 2 * C + j;
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) {
+                rxr[e] = xrow[e * 2 * C];
+                rxi[e] = xrow[e * 2 * C + C];
+                FFNO_UNROLL
+                for (int b = 0; b < CT; ++b) {
+                    rdr[b][e] = yrow[e * 2 * C + 32 * b];
+                    rdi[b][e] = yrow[e * 2 * C + C + 32 * b];
+                }
+            }
+            rowc += 32;
+            while (rowc >= R) rowc -= R, ++lc;      // (R = 16: two layers further)
+            return;
+        }
         const long v0 = vbeg + 16 * (long)t + 8 * half;
         const long l0 = v0 / R;
         const long row0 = v0 - l0 * R;
@@ -1121,11 +1149,19 @@ extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, f
     const long vtot = (long)nlayers * R;
     long chunk = (vtot + nsplit - 1) / nsplit;
     chunk += chunk & 1;  // even, so the (2t + half) row pairing never straddles slices
+    const bool al = R % 16 == 0;      // whole 16-row steps inside one layer: slices of whole steps, carried row pointers
+    if (al) chunk = (chunk + 15) & ~15L;
     if (chunk > 0x7fffffffL) return FFNO_EINVAL;
     const dim3 grid(nsplit, K), block(C * 4);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 64)
+    if (C == 64 && al)
+        FFNO_LAUNCH((fw_grad_x3_kernel<64, true>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
+                    nlayers, (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L);
+    else if (C == 64)
         FFNO_LAUNCH((fw_grad_x3_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
+                    nlayers, (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L);
+    else if (al)
+        FFNO_LAUNCH((fw_grad_x3_kernel<32, true>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
                     nlayers, (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L);
     else
         FFNO_LAUNCH((fw_grad_x3_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
@@ -1141,10 +1177,18 @@ extern "C" int ffno_fw_grad_partial_multi(const float* spec_x, const float* spec
     if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
     long chunk = ((long)R + nsplit - 1) / nsplit;
     chunk += chunk & 1;
+    const bool al = R % 16 == 0;
+    if (al) chunk = (chunk + 15) & ~15L;
     const dim3 grid(nsplit, K, n), block(C * 4);
     hipStream_t s = (hipStream_t)stream;
-    if (C == 64)
+    if (C == 64 && al)
+        FFNO_LAUNCH((fw_grad_x3_kernel<64, true>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L,
+                    (long)stride_x, (long)stride_dy, (long)stride_p);
+    else if (C == 64)
         FFNO_LAUNCH((fw_grad_x3_kernel<64>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L,
+                    (long)stride_x, (long)stride_dy, (long)stride_p);
+    else if (al)
+        FFNO_LAUNCH((fw_grad_x3_kernel<32, true>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L,
                     (long)stride_x, (long)stride_dy, (long)stride_p);
     else
         FFNO_LAUNCH((fw_grad_x3_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L,

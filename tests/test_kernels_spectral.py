@@ -98,7 +98,7 @@ def test_mode_mix(be, R, C, K, conj_t):
     assert rel_l2(be.get(ys), np.stack([ref.real, ref.imag], axis=2)) < TOL
 
 
-@pytest.mark.parametrize("R,C,K,nsplit", [(37, 64, 2, 3), (64, 32, 3, 4), (500, 64, 2, 5)])
+@pytest.mark.parametrize("R,C,K,nsplit", [(37, 64, 2, 3), (64, 32, 3, 4), (500, 64, 2, 5), (96, 64, 2, 4), (16, 64, 1, 3)])
 def test_fw_grad(be, R, C, K, nsplit):
     rs = np.random.RandomState(R + C + K)
     xs = rs.standard_normal((K, R, 2, C)).astype(np.float32)
@@ -117,7 +117,7 @@ def test_fw_grad(be, R, C, K, nsplit):
     assert rel_l2(be.get(gw), 3 * ref) < TOL
 
 
-@pytest.mark.parametrize("R,C,K,nl,nsplit", [(37, 64, 2, 3, 4), (16, 32, 2, 5, 3)])
+@pytest.mark.parametrize("R,C,K,nl,nsplit", [(37, 64, 2, 3, 4), (16, 32, 2, 5, 3), (48, 64, 2, 3, 4), (32, 64, 1, 4, 7), (16, 64, 1, 8, 1)])
 def test_fw_grad_over_layers(be, R, C, K, nl, nsplit):
     """One launch contracts over the lines of several layers (shared Fourier weights)."""
     rs = np.random.RandomState(R + nl)
