@@ -749,7 +749,7 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
                                                            int beta, int nlayers, long stride_x, long stride_dy, long zstride_x,
                                                            long zstride_dy, long zstride_p) {
     constexpr int CT = C / 32;
-    __shared__ float comb[CT * 64 * (4 * CT * 16)];
+    __shared__ float comb[CT * 64 * (2 * 16)];      // one column tile (both parts) of the second k-group at a time
     // blockIdx.z: independent problems (the per-layer weights of an unshared model: one launch for all layers)
     xs += (long)blockIdx.z * zstride_x;
     dys += (long)blockIdx.z * zstride_dy;
@@ -840,26 +840,25 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
         }
     }
     // combine the two k-groups (group 1 -> LDS -> group 0); consecutive lanes -> consecutive floats
+    // (one column tile per round: 16 KiB of LDS at width 64 instead of 64 -- the slices' workgroups are short, residency counts)
     const int slot = a * 64 + lane;
-    if (grp == 1) {
-        FFNO_UNROLL
-        for (int b = 0; b < CT; ++b) {
+    FFNO_UNROLL
+    for (int b = 0; b < CT; ++b) {
+        if (b) __syncthreads();
+        if (grp == 1) {
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
-                comb[((b * 2 + 0) * 16 + r) * (CT * 64) + slot] = accr[b][r];
-                comb[((b * 2 + 1) * 16 + r) * (CT * 64) + slot] = acci[b][r];
+                comb[(0 * 16 + r) * (CT * 64) + slot] = accr[b][r];
+                comb[(1 * 16 + r) * (CT * 64) + slot] = acci[b][r];
             }
         }
-    }
-    __syncthreads();
-    if (grp == 0) {
-        FFNO_UNROLL
-        for (int b = 0; b < CT; ++b) {
+        __syncthreads();
+        if (grp == 0) {
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int i = 32 * a + drow(r, half);
-                const float vr = accr[b][r] + comb[((b * 2 + 0) * 16 + r) * (CT * 64) + slot];
-                const float vi = acci[b][r] + comb[((b * 2 + 1) * 16 + r) * (CT * 64) + slot];
+                const float vr = accr[b][r] + comb[(0 * 16 + r) * (CT * 64) + slot];
+                const float vi = acci[b][r] + comb[(1 * 16 + r) * (CT * 64) + slot];
                 float* pr = partial + (((long)split * K + k) * 2 + 0) * C * C + (long)i * C + 32 * b + j;
                 float* pi = pr + (long)C * C;
                 *pr = beta ? (*pr + vr) : vr;

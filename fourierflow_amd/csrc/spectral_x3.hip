@@ -1945,9 +1945,18 @@ __global__ __launch_bounds__(512) void spectral_x3c32_pair_kernel(X3Args a, X3Ar
 // transforms and stores column tile t of its line (the even or the odd channels: half of the operand splits and MFMAs of phases
 // 1 and 3); and the ring of weight fragments holds a WHOLE mode (16 fragments in flight per wave instead of 8, refilled with the
 // wave's next mode as they are consumed), which halves the L2 round trips the mix waits for.  256 registers per wave.
-template <bool MIXH2, bool TAB = false>
-__device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
+// CS ("channel split", FFNO_X3_TILE_LATENCY_SPLIT): TWO workgroups per 4-line tile, workgroup h of a tile owning the OUTPUT
+// channels of parity h.  Both run phase 1 in full (the mix needs every input channel); in phase 2 each streams only the weight
+// fragments of its output column tile (half of the 512 KB a workgroup pulls from L2 per launch -- the floor of the phase at
+// batch 1, where 32 workgroups per axis each read the whole pack), and in phase 3 the two waves of a line split the OUTPUT ROW
+// tiles of that one column tile instead of the column tiles.  Same products per output element in the same order: bit-identical
+// to every other tile choice.  Twice the workgroups (64 per axis at batch 1), each with a shorter dependent chain.
+template <bool MIXH2, bool TAB = false, bool CS = false>
+__device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx_) {
     static_assert(!TAB || MIXH2, "the fragment table holds fp16 planes");
+    static_assert(!CS || MIXH2, "the channel-split schedule is written for the fp16x2 packs");
+    const int bidx = CS ? bidx_ >> 1 : bidx_;
+    const int hc = CS ? (bidx_ & 1) : 0;      // CS: the output channel parity this workgroup owns
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF, NL = 4, NWS = 8;
     __shared__ __attribute__((aligned(16))) float XS[NL * F::LSF];
@@ -2050,7 +2059,8 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
             if (row < 2 * K) {
                 const float v = acc[r] * unx;
                 xs[row * RS] = v * rs;
-                if (A.spec_save && live) A.spec_save[(((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + 2 * j + t] = v;
+                if (A.spec_save && live && (!CS || t == hc))
+                    A.spec_save[(((long)(row >> 1) * R + line0) * 2 + (row & 1)) * C + 2 * j + t] = v;
             }
         }
     }
@@ -2070,16 +2080,67 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
         return w;
     };
     MixFrag ring[RING];
+    // CS: fragment g = 0..7 of a mode <-> pack fragment (g < 4 ? hc : 2 + hc) * 4 + (g & 3): the ring holds TWO modes
+    auto cs_frag = [&](int g) { return ((g >> 2) * 2 + hc) * 4 + (g & 3); };
     if (A.wpk && wave < K) {
-        FFNO_UNROLL
-        for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
+        if constexpr (CS) {
+            static_assert(2 * NWS >= F::KK / 2, "two modes per wave cover the kernel's mode range");
+            const bool two = wave + NWS < K;
+            FFNO_UNROLL
+            for (int g = 0; g < 8; ++g) ring[g] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, cs_frag(g));
+            FFNO_UNROLL
+            for (int g = 0; g < 8; ++g)
+                ring[8 + g] = load_w(A.wpk + (long)(two ? wave + NWS : wave) * F::MODE_FRAGS * 64 * MNP, cs_frag(g));
+        } else {
+            FFNO_UNROLL
+            for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
+        }
     }
     __syncthreads();
 
     // ---------------- phase 2: per-mode channel mix of the four lines (8 live rows of the 32-row tile; rows 8..31 repeat them) ----
     if (A.wpk) {
         const float* arow = XS + ((j & (2 * NL - 1)) >> 1) * LSF + (j & 1) * RS + 8 * half;
-        for (int k = wave; k < K; k += NWS) {
+        if constexpr (CS) {
+            // K <= 16 on 8 waves: a wave has at most two modes (wave, wave + 8), both already in the ring -- no refill.  Per mode
+            // the two products of this workgroup's column tile (real-part and imaginary-part weights).
+            auto mode = [&](const int k, const int base) {
+                Hf2 a[4];
+                FFNO_UNROLL
+                for (int st = 0; st < 4; ++st) {
+                    const float4 v0 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st);
+                    const float4 v1 = *reinterpret_cast<const float4*>(arow + 2 * k * RS + 16 * st + 4);
+                    a[st] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+                }
+                f32x16 p1 = zero16(), p2 = zero16();
+                FFNO_UNROLL
+                for (int pp = 0; pp < 2; ++pp) {
+                    f32x16 pc = zero16();
+                    FFNO_UNROLL
+                    for (int st = 0; st < 4; ++st) mfma_h2(a[st], ring[base + pp * 4 + st], pp ? p2 : p1, pc);
+                    SplitHf2::fold(pp ? p2 : p1, pc);
+                }
+                FFNO_UNROLL
+                for (int q = 0; q < NL / 2; ++q) {
+                    const int line = (q & 1) + 2 * half;
+                    const float p1r = p1[2 * q], p1i = p1[2 * q + 1], p2r = p2[2 * q], p2i = p2[2 * q + 1];
+                    float yr, yi;
+                    if (A.conj_t == 0) {
+                        yr = p1r - p2i;
+                        yi = p2r + p1i;
+                    } else {
+                        yr = p1r + p2i;
+                        yi = p1i - p2r;
+                    }
+                    float* dst = XS + line * LSF + 2 * k * RS + 2 * j + hc;
+                    dst[0] = yr;
+                    dst[RS] = yi;
+                }
+            };
+            if (wave < K) mode(wave, 0);
+            if (wave + NWS < K) mode(wave + NWS, 8);
+        }
+        for (int k = wave; k < (CS ? 0 : K); k += NWS) {
             const u32x4* __restrict__ wk = A.wpk + (long)k * F::MODE_FRAGS * 64 * MNP;
             const bool more = k + NWS < K;
             const u32x4* __restrict__ wn = A.wpk + (long)(more ? k + NWS : k) * F::MODE_FRAGS * 64 * MNP;
@@ -2156,8 +2217,10 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
     if (live) {
         const int RTtot = (L + 31) >> 5;
         const unsigned hoff = (unsigned)(4 * half * es * 4);
+        const int ct = CS ? hc : t;               // the column tile this wave transforms back (CS: the workgroup's, rows split)
+        const unsigned lo = (unsigned)((lm.base(line0) + 2 * j + ct) * 4);
         const unsigned lob = lo + hoff;
-        const float* xs = XS + lw * LSF + 2 * j + t;
+        const float* xs = XS + lw * LSF + 2 * j + ct;
         const char* addsrc = A.resid ? reinterpret_cast<const char*>(A.resid)
                                      : (A.accumulate ? reinterpret_cast<const char*>(A.out) : nullptr);
         // B operands: the line's spectrum, column tile t, split: slot e of k-step st <-> row kk = 16 st + 8 half + e
@@ -2198,7 +2261,7 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
                 y[st] = split3_8(v[st][0], v[st][1], v[st][2], v[st][3], v[st][4], v[st][5], v[st][6], v[st][7]);
         }
         FFNO_NOUNROLL
-        for (int rt = 0; rt < RTtot; ++rt) {
+        for (int rt = CS ? t : 0; rt < RTtot; rt += CS ? 2 : 1) {
             float pre[16];
             if (addsrc) {
                 FFNO_UNROLL
@@ -2254,11 +2317,12 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx) {
     if (A.out_amax) range_fold(omax, rfold, NWS, A.out_amax);
 }
 
-template <bool MIXH2, bool TAB = false>
+template <bool MIXH2, bool TAB = false, bool CS = false>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_kernel(X3Args a) {
-    spectral_x3s_body<MIXH2, TAB>(a, blockIdx.x);
+    spectral_x3s_body<MIXH2, TAB, CS>(a, blockIdx.x);
 }
-template <bool MIXH2, bool TAB = false>
+// (CS: n0 / n1 count WORKGROUPS, two per tile)
+template <bool MIXH2, bool TAB = false, bool CS = false>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_pair_kernel(X3Args a, X3Args b, int n0, int n1) {
     const int w = blockIdx.x, nmin = min(n0, n1);
     bool second;
@@ -2270,7 +2334,7 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void spectral_x3s_pair_
         second = n1 > n0;
         idx = w - nmin;
     }
-    spectral_x3s_body<MIXH2, TAB>(x3_pick_args(a, b, second), idx);
+    spectral_x3s_body<MIXH2, TAB, CS>(x3_pick_args(a, b, second), idx);
 }
 
 // 8-line tiles while the launch still fits one round of workgroups (one per CU of the device): more CUs busy, same weight
@@ -2285,9 +2349,17 @@ static inline bool x3_small_tiles(int Ra, int Rb, int tile_lines) {
 // forward at batch 1 / 2 / 4 / 8: 0.70 / 0.77 / 0.89 / 1.08 ms against 0.76 / 0.82 / 0.93 / 1.11 on 8-line tiles).  fp32 storage.
 static inline bool x3_latency_tiles(int Ra, int Rb, int tile_lines, int storage) {
     if (storage != FFNO_STORE_F32) return false;
-    if (tile_lines == FFNO_X3_TILE_LATENCY) return true;
+    if (tile_lines == FFNO_X3_TILE_LATENCY || tile_lines == FFNO_X3_TILE_LATENCY_SPLIT) return true;
     if (tile_lines != 0) return false;
     return (Ra + 3) / 4 + (Rb + 3) / 4 <= device_cu_count();
+}
+// ... and TWO workgroups per such tile (channel split, spectral_x3s_body<.., CS>) while the doubled launch still fits one
+// round: fp16x2 packs with a mix (the split halves the weight stream of a workgroup; a low-pass launch has none)
+static inline bool x3_latency_split(int Ra, int Rb, int tile_lines, bool h2_mix) {
+    if (!h2_mix) return false;
+    if (tile_lines == FFNO_X3_TILE_LATENCY_SPLIT) return true;
+    if (tile_lines != 0) return false;
+    return 2 * ((Ra + 3) / 4 + (Rb + 3) / 4) <= device_cu_count();
 }
 
 static inline bool x3_many_modes(int K) { return 2 * K > X3Cfg::KK; }
@@ -2360,9 +2432,14 @@ static int x3_args(X3Args& a, const ffno_fused_branch* b, int C, int scale_ck_fw
     // format 2 = the 16-row mix of the many-mode kernel (width 64, 17..64 modes), which also takes its DFT fragments from a table
     if (b->planes && b->planes_format == FFNO_PLANES_FP16X2_M16 && (C != X3Cfg::C || !x3_many_modes(b->K) || !b->dft_frags))
         return FFNO_EUNSUPPORTED;
-    if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16 && b->tile_lines != FFNO_X3_TILE_LATENCY) return FFNO_EINVAL;
+    if (b->tile_lines != 0 && b->tile_lines != 8 && b->tile_lines != 16 && b->tile_lines != FFNO_X3_TILE_LATENCY &&
+        b->tile_lines != FFNO_X3_TILE_LATENCY_SPLIT)
+        return FFNO_EINVAL;
     if (b->storage != FFNO_STORE_F32 && b->storage != FFNO_STORE_BF16) return FFNO_EINVAL;
-    if (b->storage == FFNO_STORE_BF16 && b->tile_lines == FFNO_X3_TILE_LATENCY) return FFNO_EUNSUPPORTED;
+    if (b->storage == FFNO_STORE_BF16 && (b->tile_lines == FFNO_X3_TILE_LATENCY || b->tile_lines == FFNO_X3_TILE_LATENCY_SPLIT))
+        return FFNO_EUNSUPPORTED;
+    if (b->tile_lines == FFNO_X3_TILE_LATENCY_SPLIT && !(b->planes && b->planes_format == FFNO_PLANES_FP16X2))
+        return FFNO_EUNSUPPORTED;      // (the split divides the fp16x2 weight stream: it needs one)
     // bf16 storage twins: every fused split kernel (width 64 with <= 64 modes, width 32), on the split-fp16 path -- i.e. WITH
     // fp16x2 packs (a launch without planes, mode 'low-pass', runs the bf16x3 DFT, which has twins only on the K <= 16 kernel)
     if (b->storage == FFNO_STORE_BF16) {
@@ -2424,8 +2501,13 @@ extern "C" int ffno_spectral_x3(const ffno_fused_branch* br, int C, int scale_ck
         return x3_status();
     }
     if (x3_latency_tiles(a.R, 0, br->tile_lines, br->storage)) {
-        const dim3 grid((a.R + 3) / 4);
-        if (h2 && a.dft)
+        const bool cs = x3_latency_split(a.R, 0, br->tile_lines, h2 && a.wpk);
+        const dim3 grid((cs ? 2 : 1) * ((a.R + 3) / 4));
+        if (cs && a.dft)
+            FFNO_LAUNCH((spectral_x3s_kernel<true, true, true>), grid, dim3(512), smem, st, a);
+        else if (cs)
+            FFNO_LAUNCH((spectral_x3s_kernel<true, false, true>), grid, dim3(512), smem, st, a);
+        else if (h2 && a.dft)
             FFNO_LAUNCH((spectral_x3s_kernel<true, true>), grid, dim3(512), smem, st, a);
         else if (h2)
             FFNO_LAUNCH((spectral_x3s_kernel<true>), grid, dim3(512), smem, st, a);
@@ -2526,8 +2608,13 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
         return (interleave & 1) ? 1 : 0;
     };
     if (x3_latency_tiles(a.R, b.R, ba->tile_lines, ba->storage)) {
-        const int n0 = (a.R + 3) / 4, n1 = (b.R + 3) / 4;
-        if (h2 && a.dft && b.dft)
+        const bool cs = x3_latency_split(a.R, b.R, ba->tile_lines, h2 && a.wpk && b.wpk);
+        const int n0 = (cs ? 2 : 1) * ((a.R + 3) / 4), n1 = (cs ? 2 : 1) * ((b.R + 3) / 4);
+        if (cs && a.dft && b.dft)
+            FFNO_LAUNCH((spectral_x3s_pair_kernel<true, true, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else if (cs)
+            FFNO_LAUNCH((spectral_x3s_pair_kernel<true, false, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
+        else if (h2 && a.dft && b.dft)
             FFNO_LAUNCH((spectral_x3s_pair_kernel<true, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
         else if (h2)
             FFNO_LAUNCH((spectral_x3s_pair_kernel<true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);

@@ -672,7 +672,8 @@ class FFNOEngine:
                 njobs = L * (2 if self.use_fork else 1)
                 ws.ffparts = torch.empty(njobs, ws.ffpart.numel(), **f32)
                 ws.red_sig, ws.red_table = None, None
-            ws.nsplit_fw = [max(1, min(max(1, 512 // v.K), (L * v.R + 63) // 64)) for v in ws.views]
+            fwg = int(os.environ.get("FFNO_FW_GRAD_WGS", "512"))      # workgroups of a Fourier-weight-gradient launch (slices x modes)
+            ws.nsplit_fw = [max(1, min(max(1, fwg // v.K), (L * v.R + 63) // 64)) for v in ws.views]
             if self.spectral == "plus":
                 ws.nsplit_fw = [1]
             ws.fwpart = [[torch.empty(ws.nsplit_fw[w] * 2 * (ws.views[w].K2 if self.spectral == "plus" else ws.views[w].K)

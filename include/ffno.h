@@ -209,6 +209,8 @@ typedef struct ffno_fused_branch {
                                       modes; its 4-line tile has 8 live mix rows) then runs 16-row products -- half the matrix time and a
                                       third of the vector work of its mix.  Needs dft_frags; same bytes as FFNO_PLANES_FP16X2 */
 #define FFNO_X3_TILE_LATENCY 1
+#define FFNO_X3_TILE_LATENCY_SPLIT 2 /* the latency tile with TWO workgroups per tile, one per output-channel parity (fp16x2 packs
+                                      * with a mix only; tile_lines = 0 picks it while the doubled launch fits one round) */
 /* DFT-matrix fragment table of the fused kernels that give a wave ONE line (C = 64, FP16X2 planes: the many-mode kernel, 17..64
  * modes, and the latency kernel FFNO_X3_TILE_LATENCY of the <= 16-mode shapes) for one axis length L, mode
  * count K and direction (scale_ck_fwd / apply_ck_inv as the launch will pass them): every (row tile, 64-sample chunk, k-step)

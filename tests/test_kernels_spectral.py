@@ -718,8 +718,14 @@ def test_spectral_x3_latency_tiles_are_bit_identical(be, B, M, N, K, direction, 
         assert lib.ffno_spectral_x3_dft_frags(p(tw), L, K, fwd_ck, inv_ck, p(tab), None) == 0
         keep.append(tab)
         got = {}
-        for tag in (8, 1, "1t"):
-            tile, dft = (1, p(tab)) if tag == "1t" else (tag, None)
+        # (tiles 2 / "2t": FFNO_X3_TILE_LATENCY_SPLIT -- two workgroups per tile, one per output-channel parity; fp16x2 mix only)
+        split_ok = fmt == 1 and planes is not None
+        tags = (8, 1, "1t") + ((2, "2t") if split_ok else ())
+        if not split_ok:
+            d = FusedBranch(p(dx), p(be.empty(x.shape)), None, None, p(planes), p(tw), B, M, N, K, axis, 0, fmt, 2, p(word_in), None)
+            assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == -2
+        for tag in tags:
+            tile, dft = (int(tag[0]), p(tab)) if isinstance(tag, str) else (tag, None)
             out, spec, word = be.empty(x.shape), be.empty((K, R, 2, C)), be.zeros(1, np.uint32)
             d = FusedBranch(p(dx), p(out), None, p(spec), p(planes), p(tw), B, M, N, K, axis, 0, fmt, tile, p(word_in), p(word), 0, 0, dft)
             assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
@@ -728,19 +734,23 @@ def test_spectral_x3_latency_tiles_are_bit_identical(be, B, M, N, K, direction, 
             assert lib.ffno_spectral_x3(ctypes.byref(d), C, fwd_ck, inv_ck, conj, None) == 0
             got[tag] = (first, be.get(spec).copy(), np.asarray(be.get(word)).copy(), be.get(out).copy())
         assert not np.isnan(got[1][0]).any()
-        for tag in (1, "1t"):
+        for tag in tags[1:]:
             for a, b in zip(got[8], got[tag]):
                 np.testing.assert_array_equal(a, b)
-        br[axis] = (planes, tw, got[1][0], tab)
-    oa, ob = be.empty(x.shape), be.empty(x.shape)
-    for with_tab in (False, True):
-        da = FusedBranch(p(dx), p(oa), None, None, p(br[0][0]), p(br[0][1]), B, M, N, K, 0, 0, fmt, 1, p(word_in), None, 0, 0,
-                         p(br[0][3]) if with_tab else None)
-        db = FusedBranch(p(dx), p(ob), None, None, p(br[1][0]), p(br[1][1]), B, M, N, K, 1, 0, fmt, 1, p(word_in), None, 0, 0,
-                         p(br[1][3]) if with_tab else None)
-        assert lib.ffno_spectral_x3_pair(ctypes.byref(da), ctypes.byref(db), C, fwd_ck, inv_ck, conj, 3, None) == 0
-        np.testing.assert_array_equal(be.get(oa), br[0][2])
-        np.testing.assert_array_equal(be.get(ob), br[1][2])
+        br[axis] = (planes, tw, got[1][0], tab, got[1][1])
+    for tile in (1, 2) if split_ok else (1,):
+        for with_tab in (False, True):
+            oa, ob = be.empty(x.shape), be.empty(x.shape)
+            sa, sb = be.empty(br[0][4].shape), be.empty(br[1][4].shape)
+            da = FusedBranch(p(dx), p(oa), None, p(sa), p(br[0][0]), p(br[0][1]), B, M, N, K, 0, 0, fmt, tile, p(word_in), None, 0, 0,
+                             p(br[0][3]) if with_tab else None)
+            db = FusedBranch(p(dx), p(ob), None, p(sb), p(br[1][0]), p(br[1][1]), B, M, N, K, 1, 0, fmt, tile, p(word_in), None, 0, 0,
+                             p(br[1][3]) if with_tab else None)
+            assert lib.ffno_spectral_x3_pair(ctypes.byref(da), ctypes.byref(db), C, fwd_ck, inv_ck, conj, 3, None) == 0
+            np.testing.assert_array_equal(be.get(oa), br[0][2])
+            np.testing.assert_array_equal(be.get(ob), br[1][2])
+            np.testing.assert_array_equal(be.get(sa), br[0][4])
+            np.testing.assert_array_equal(be.get(sb), br[1][4])
 
 
 @pytest.mark.parametrize("B,M,N,Ka,Kb", [(1, 40, 48, 20, 18), (1, 70, 36, 12, 34), (2, 256, 256, 32, 32), (1, 130, 136, 64, 40)])
