@@ -48,7 +48,9 @@ def _run_hip(kw, seed, B, M, N, split=None, storage="fp32"):
     assert eng.paired_last, "the paired spectral launch did not run"
     assert eng._saved_x3 == ([True, True], True), eng._saved_x3
     want = split or "fp16x2"
-    assert eng._x3_fmt == [int(want == "fp16x2")] * 2 and eng.ff_split == want and eng._ffx()
+    # (plane formats of ffno.h: 0 bf16x3, 1 fp16x2, 2 fp16x2 in the 16-row order of the many-mode kernel, 17..64 modes)
+    fmt = 0 if want != "fp16x2" else (2 if kw["modes"] > 16 else 1)
+    assert eng._x3_fmt == [fmt] * 2 and eng.ff_split == want and eng._ffx()
     return pred.cpu().numpy(), loss, grads, masks, (x_np, t_np), gflat
 
 

@@ -160,7 +160,7 @@ def test_block_with_more_than_16_modes_runs_the_fused_split_kernel(host_device, 
     pred = blk(torch.from_numpy(x_np).to(host_device))["forecast"]
     orc.lp_rel_loss(pred, torch.from_numpy(t_np).to(host_device)).backward()
     eng = blk.engine()
-    assert eng.paired_last and eng._saved_x3 == ([True, True], True) and eng._x3_fmt == [1, 1]
+    assert eng.paired_last and eng._saved_x3 == ([True, True], True) and eng._x3_fmt == [2, 2]      # (fp16x2, 16-row mix)
     seen = []
     orig = eng._k
     eng._k = lambda name, fn, *a, _o=orig: (seen.append(name), _o(name, fn, *a))[1]
