@@ -66,7 +66,8 @@ class FxRedDesc(C.Structure):
 
 class FfWgDesc(C.Structure):
     """Mirror of ``ffno_ffwg_desc`` (include/ffno.h)."""
-    _fields_ = [("s", P), ("g", P), ("pk1", P), ("b1", P), ("pk1b", P), ("partial", P), ("s_amax", P), ("g_amax", P)]
+    _fields_ = [("s", P), ("g", P), ("pk1", P), ("b1", P), ("pk1b", P), ("partial", P), ("s_amax", P), ("g_amax", P),
+                ("s2", P), ("g2", P)]
 
 
 class MarkovExtra(C.Structure):
@@ -153,7 +154,7 @@ SIGNATURES = {
     "ffno_ffh_fwd2": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffh_bwd_data2": (I, [P, P, P, P, P, P, P, I, I, I, P, P]),
     "ffno_ffh_bwd_weights_partial": (I, [P, P, P, P, P, P, I, I, I, I, P, P, I, P]),
-    "ffno_ffh_bwd_weights_partial_multi": (I, [P, I, I, I, I, I, I, P]),
+    "ffno_ffh_bwd_weights_partial_multi": (I, [P, I, I, I, I, I, I, I, P]),
     "ffno_layernorm_fwd": (I, [P, P, P, P, P, P, L, I, F, P]),
     "ffno_layernorm_nsplit": (I, [L]),
     "ffno_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L, I, I, P]),

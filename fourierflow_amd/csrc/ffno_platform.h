@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -141,13 +143,46 @@ static inline int cu_count() {
     return n;
 }
 
+// orders the LDS operations of ONE wave around an exchange through LDS between its own lanes: the hardware executes a wave's
+// LDS operations in order, so this only has to stop the compiler from moving them across (no instruction is emitted)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 }  // namespace plat
 
 // dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel
+// (once per kernel and size: the runtime call costs tens of microseconds of host time, more than the launch it precedes -- a
+//  per-launch call makes a stream of 20-us kernels host-bound.  One process drives one device)
 template <class K>
 static inline int allow_dynamic_lds(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return 0;
-    return (int)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    struct Slot {
+        std::atomic<const void*> fn{nullptr};
+        std::atomic<size_t> bytes{0};
+    };
+    static Slot slots[64];
+    const void* p = (const void*)kernel;
+    Slot* mine = nullptr;
+    for (Slot& s : slots) {
+        const void* f = s.fn.load(std::memory_order_acquire);
+        if (f == p) {
+            if (s.bytes.load(std::memory_order_acquire) >= bytes) return 0;
+            mine = &s;
+            break;
+        }
+        if (!f) {
+            const void* expect = nullptr;
+            if (s.fn.compare_exchange_strong(expect, p) || expect == p) {
+                mine = &s;
+                break;
+            }
+        }
+    }
+    const int rc = (int)hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (rc == 0 && mine) mine->bytes.store(bytes, std::memory_order_release);
+    return rc;
 }
 
 }  // namespace ffno

@@ -385,6 +385,236 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const type
     if (out_amax) range_fold(omax, rfold, NW, out_amax);
 }
 
+// ---- forward / backward-data, ONE WAVE PER PIXEL TILE ("wave tiles", split-fp16) ---------------------------------------------
+// Same operators, packs, sign-bit layout and range handling as ffx_chain_kernel.  What differs is who owns what.  There the
+// eight waves of a workgroup share ONE 32-pixel tile, each holding the weights of a 32-row hidden chunk in registers: per tile a
+// wave runs 12 + 12 MFMAs between an LDS staging pass, a 64 KiB exchange of partial outputs and barriers -- the tile is too
+// small for eight waves, the kernels run at a fifth of the matrix rate and their time follows the synchronisation, not the
+// instruction count (round 2-4 measurements).  Here a wave owns a WHOLE tile: it walks all H / 32 hidden chunks
+// itself (GEMM1 chunk -> epilogue -> GEMM2 accumulation, 24 MFMAs per chunk, 192 per tile at 64 / 256), the weights of BOTH
+// linear maps sit in LDS for the whole launch (128 KiB of fp16x2 fragments, copied once per workgroup, read conflict-free as
+// ds_read_b128).  The MFMA fragments want a pixel per lane; read that way from global memory a load touches 32 rows with 16
+// bytes each (measured: a launch that ONLY moves the tiles like that takes 29-40 us, the whole shared-tile kernel 41-45), so
+// the rows travel in 64-byte segments (four lanes per row of a 16-channel block) and a 2.5 KiB staging area per wave turns a
+// block into the fragment layout and back.  No exchange between waves and no barrier after the weight copy: the eight waves of
+// a CU drift apart and fill each other's memory waits.
+//   GEMM1 (per chunk): main + correction accumulators, folded per chunk -- product for product the h of ffx_chain_kernel and
+//   of the weight-gradient kernel's recomputation (same ReLU decisions).  GEMM2: ONE main + correction pair per output tile
+//   over all 16 k-steps, folded once (ffx_chain_kernel folds per chunk and adds the eight partial tiles: same products, other
+//   rounding of the sum -- results agree to fp32 rounding, not bit for bit; bf16 twin == bf16(this kernel at fp32 storage)).
+template <int C, int H, bool BWD, class ST = StF32>
+__global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(const typename ST::T* __restrict__ in,
+                                                                              const typename ST::T* __restrict__ in2,
+                                                                              typename ST::T* sum_out,
+                                                                              const typename ST::T* resid,
+                                                                              const u32x4* __restrict__ pk1,
+                                                                              const float* __restrict__ bias1,
+                                                                              const u32x4* __restrict__ pk2,
+                                                                              const float* __restrict__ bias2,
+                                                                              typename ST::T* out, uint32_t* mask, int P,
+                                                                              const unsigned* in_amax, unsigned* out_amax) {
+    using S = SplitHf2;
+    constexpr int NCH = H / 32, KS = C / 16, CTO = C / 32, NWV = 8;
+    constexpr int NF1 = NCH * KS, NF2 = NCH * CTO * 2;      // fragments of the two packs: two planes of 64 x 16 B each
+    constexpr int SROW = 20;                                // floats per staged row: 16 channels + 4 of padding (bank spread)
+    FFNO_DYN_SMEM(smem);
+    u32x4* w1 = reinterpret_cast<u32x4*>(smem);
+    u32x4* w2 = w1 + NF1 * 2 * 64;
+    float* b1s = reinterpret_cast<float*>(w2 + NF2 * 2 * 64);
+    float* b2s = b1s + H;
+    float* stg_all = b2s + C;                               // NWV x [32 rows][SROW]: one 16-channel block of a tile per wave
+    __shared__ float rfold[NWV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    const int ntiles = (P + 31) >> 5;
+    const float gscale = in_amax ? range_scale(*in_amax, 1, kFfRangeTarget) : 1.f;
+    const float rgscale = 1.f / gscale;
+    float omax = 0.f;
+
+    for (int i = tid; i < NF1 * 2 * 64; i += NWV * 64) w1[i] = pk1[i];
+    for (int i = tid; i < NF2 * 2 * 64; i += NWV * 64) w2[i] = pk2[i];
+    if (!BWD) {
+        for (int e = tid; e < H; e += NWV * 64) b1s[e] = bias1[e] * gscale;
+        for (int e = tid; e < C; e += NWV * 64) b2s[e] = bias2[e];
+    }
+    __syncthreads();
+
+    // Two lane maps of a 16-channel block of the tile ([32 rows][16 channels], 64 contiguous bytes per row in global memory):
+    //   memory map : lane l <-> row 16 i + (l >> 2), channels 4 (l & 3) + (0..3), i = 0, 1   (four lanes per 64-byte row segment:
+    //                what the global loads / stores use)
+    //   operand map: lane (j, half) <-> row j, channels 8 half + (0..7)                       (the MFMA B / D fragments)
+    // The wave's staging rows in LDS convert one into the other, block by block (LDS operations of a wave execute in order, so
+    // a block may be overwritten as soon as the reads of the previous one are issued; wave_sync is a compiler fence there).
+    float* stg = stg_all + wave * (32 * SROW);
+    const int mrow = lane >> 2, mq = lane & 3;
+    float* stg_m0 = stg + mrow * SROW + 4 * mq;             // memory map, i = 0 (i = 1: + 16 rows)
+    float* stg_o = stg + j * SROW + 8 * half;               // operand map
+    const uint16_t* mrd = reinterpret_cast<const uint16_t*>(mask);
+    uint16_t* mwr = reinterpret_cast<uint16_t*>(mask);
+    FFNO_NOUNROLL
+    for (int tile = (int)blockIdx.x * NWV + wave; tile < ntiles; tile += (int)gridDim.x * NWV) {
+        // rows of this lane in the memory map; rows past the end re-read the last row and are zeroed / not stored
+        long mpx[2];
+        bool mok[2];
+        long moff[2];
+        FFNO_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            mpx[i] = (long)tile * 32 + 16 * i + mrow;
+            mok[i] = mpx[i] < P;
+            moff[i] = (mok[i] ? mpx[i] : (long)P - 1) * C + 4 * mq;
+        }
+        typename ST::Raw4 ra[KS][2], rb[KS][2];
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            FFNO_UNROLL
+            for (int i = 0; i < 2; ++i) ra[st][i] = ST::ldr4(in + moff[i] + 16 * st);
+        }
+        if (in2) {
+            FFNO_UNROLL
+            for (int st = 0; st < KS; ++st) {
+                FFNO_UNROLL
+                for (int i = 0; i < 2; ++i) rb[st][i] = ST::ldr4(in2 + moff[i] + 16 * st);
+            }
+        }
+        // requested now, used after the last chunk (forward: the residual rows, memory map) / chunk by chunk (backward: the
+        // sign words of ALL chunks, two per register): nothing inside the chunk loop waits for global memory
+        typename ST::Raw4 rres[KS][2];
+        uint32_t mw[NCH / 2];
+        if (!BWD) {
+            if (resid) {
+                FFNO_UNROLL
+                for (int st = 0; st < KS; ++st) {
+                    FFNO_UNROLL
+                    for (int i = 0; i < 2; ++i) rres[st][i] = ST::ldr4(resid + moff[i] + 16 * st);
+                }
+            }
+        } else {
+            static_assert(NCH % 2 == 0, "sign words are held in pairs");
+            FFNO_UNROLL
+            for (int q = 0; q < NCH / 2; ++q)
+                mw[q] = (uint32_t)mrd[((long)tile * NCH + 2 * q) * 64 + lane] |
+                        ((uint32_t)mrd[((long)tile * NCH + 2 * q + 1) * 64 + lane] << 16);
+        }
+        // the tile's rows as B operands: k-step st <-> channels 16 st + 8 half + (0..7) of pixel j
+        Hf2 b[KS];
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {
+            FFNO_UNROLL
+            for (int i = 0; i < 2; ++i) {
+                float4 v = ST::w4(ra[st][i]);
+                if (in2) {
+                    const float4 t = ST::w4(rb[st][i]);
+                    v.x += t.x, v.y += t.y, v.z += t.z, v.w += t.w;
+                    v = st_rnd4<ST>(v);
+                    if (sum_out && mok[i]) ST::st4(sum_out + moff[i] + 16 * st, v);
+                }
+                const float sc = mok[i] ? gscale : 0.f;
+                v.x *= sc, v.y *= sc, v.z *= sc, v.w *= sc;
+                *reinterpret_cast<float4*>(stg_m0 + 16 * i * SROW) = v;
+            }
+            plat::wave_sync();
+            const float4 v0 = *reinterpret_cast<const float4*>(stg_o), v1 = *reinterpret_cast<const float4*>(stg_o + 4);
+            plat::wave_sync();
+            b[st] = split2_8(v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w);
+        }
+        f32x16 o[CTO], oc[CTO];
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) o[mt] = zero16(), oc[mt] = zero16();
+        FFNO_NOUNROLL
+        for (int ch = 0; ch < NCH; ++ch) {
+            uint32_t bits = 0;
+            if (BWD) {
+                uint32_t w = mw[0];
+                FFNO_UNROLL
+                for (int q = 1; q < NCH / 2; ++q) w = (ch >> 1) == q ? mw[q] : w;
+                bits = (ch & 1) ? (w >> 16) : (w & 0xffffu);
+            }
+            // GEMM1: the chunk's 32 hidden rows for the tile's 32 pixels
+            f32x16 d = zero16(), dc = zero16();
+            FFNO_UNROLL
+            for (int st = 0; st < KS; ++st) {
+                Hf2 a;
+                a.hi = w1[((ch * KS + st) * 2 + 0) * 64 + lane];
+                a.lo = w1[((ch * KS + st) * 2 + 1) * 64 + lane];
+                mfma_h2(a, b[st], d, dc);
+            }
+            S::fold(d, dc);
+            if (BWD) {
+                FFNO_UNROLL
+                for (int r = 0; r < 16; ++r) d[r] = u2f(f2u(d[r]) & bit_mask(bits, 15 - r));
+            } else {
+                FFNO_UNROLL
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(&b1s[32 * ch + 8 * g + 4 * half]);
+                    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+                    FFNO_UNROLL
+                    for (int i = 0; i < 4; ++i) {
+                        const float v = fmaxf(d[4 * g + i] + bb[i], 0.f);
+                        d[4 * g + i] = v;
+                        bits = push_sign(bits, 0u - f2u(v));   // element r ends up at bit 15 - r (ffx_chain_kernel's sign word)
+                    }
+                }
+                if (mwr) mwr[((long)tile * NCH + ch) * 64 + lane] = (uint16_t)bits;
+            }
+            // GEMM2: the chunk's contribution to the output tile, k order = D-fragment order
+            Hf2 hb[2];
+            hb[0] = split2_8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+            hb[1] = split2_8(d[8], d[9], d[10], d[11], d[12], d[13], d[14], d[15]);
+            FFNO_UNROLL
+            for (int mt = 0; mt < CTO; ++mt) {
+                FFNO_UNROLL
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    Hf2 a;
+                    a.hi = w2[(((ch * CTO + mt) * 2 + s2) * 2 + 0) * 64 + lane];
+                    a.lo = w2[(((ch * CTO + mt) * 2 + s2) * 2 + 1) * 64 + lane];
+                    mfma_h2(a, hb[s2], o[mt], oc[mt]);
+                }
+            }
+        }
+        // output rows: accumulator group g of tile mt = channels 32 mt + 8 g + 4 half + (0..3) of pixel j; block (mt, gp) =
+        // channels 32 mt + 16 gp + (0..15): groups 2 gp and 2 gp + 1 of both halves, back through the staging rows
+        FFNO_UNROLL
+        for (int mt = 0; mt < CTO; ++mt) {
+            S::fold(o[mt], oc[mt]);
+            FFNO_UNROLL
+            for (int gp = 0; gp < 2; ++gp) {
+                const int blk = 2 * mt + gp;      // = the k-step index of the same 16 channels
+                FFNO_UNROLL
+                for (int u = 0; u < 2; ++u) {
+                    const int g = 2 * gp + u;
+                    *reinterpret_cast<float4*>(stg + j * SROW + 8 * u + 4 * half) =
+                        make_float4(o[mt][4 * g], o[mt][4 * g + 1], o[mt][4 * g + 2], o[mt][4 * g + 3]);
+                }
+                plat::wave_sync();
+                float4 acc[2];
+                FFNO_UNROLL
+                for (int i = 0; i < 2; ++i) acc[i] = *reinterpret_cast<const float4*>(stg_m0 + 16 * i * SROW);
+                plat::wave_sync();
+                FFNO_UNROLL
+                for (int i = 0; i < 2; ++i) {
+                    const int c0 = 16 * blk + 4 * mq;
+                    acc[i].x *= rgscale, acc[i].y *= rgscale, acc[i].z *= rgscale, acc[i].w *= rgscale;
+                    if (!BWD) {
+                        float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (resid) rr = ST::w4(rres[blk][i]);
+                        acc[i].x += b2s[c0] + rr.x;
+                        acc[i].y += b2s[c0 + 1] + rr.y;
+                        acc[i].z += b2s[c0 + 2] + rr.z;
+                        acc[i].w += b2s[c0 + 3] + rr.w;
+                    }
+                    if (mok[i]) {
+                        ST::st4(out + moff[i] + 16 * blk, acc[i]);
+                        const float4 t = st_rnd4<ST>(acc[i]);
+                        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(t.x), fabsf(t.y))), fmaxf(fabsf(t.z), fabsf(t.w)));
+                    }
+                }
+            }
+        }
+    }
+    if (out_amax) range_fold(omax, rfold, NWV, out_amax);
+}
+
 // ---- forward / backward-data, role-split schedule ---------------------------------------------------------------------
 // Same arithmetic, operands and results as ffx_chain_kernel (bit-identical: same products, same summation order), other
 // schedule.  In ffx_chain_kernel the two waves that share a SIMD (w and w + NW/2) run the same code in phase: after every
@@ -970,11 +1200,17 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //   * branch-free tile loop (one basic block: the scheduler interleaves staging / epilogue vector work with the MFMAs).
 //   * the body takes its slice index and slice count as arguments (bid of nb): the per-layer launch passes its block index and
 //     grid size, the all-layers launch (ffh_wgrad_m_multi_kernel below) the position inside its layer's slices.
-template <int C, int H, int NWV, class ST = StF32>
+//   * TWO: s and db are each the SUM of two tensors (the two branch outputs of the paired spectral launch; the two gradient
+//     buffers of the paired adjoint launch), added -- and rounded to the storage format, as the chain kernels do -- while the
+//     rows are staged: the chain kernels then need not write the sums back (one image write less per launch: 44.6 -> 39.1 us
+//     forward, 41.4 -> 33.4 us backward-data with the wave-tile kernels, MI355X round 4).
+template <int C, int H, int NWV, class ST = StF32, bool TWO = false>
 __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restrict__ s, const typename ST::T* __restrict__ db,
                                                  const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
                                                  const u32x4* __restrict__ pk2t, float* __restrict__ partial, int P,
-                                                 const unsigned* s_amax, const unsigned* db_amax, const int bid, const int nb) {
+                                                 const unsigned* s_amax, const unsigned* db_amax, const int bid, const int nb,
+                                                 const typename ST::T* __restrict__ s2 = nullptr,
+                                                 const typename ST::T* __restrict__ db2 = nullptr) {
     constexpr int CPW = H / (32 * NWV);            // hidden chunks per wave
     using F = FxCfg<C, H, CPW>;
     constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV;
@@ -1021,13 +1257,15 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
     struct Raw1x4 {
         typename ST::Raw1 v[4];
     };
-    typename ST::Raw4 nSP[NV], nDP[NV];
-    Raw1x4 nST[NV], nDT[NV];
+    typename ST::Raw4 nSP[NV], nDP[NV], mSP[NV], mDP[NV];      // (m*: the second addends, TWO only)
+    Raw1x4 nST[NV], nDT[NV], mST[NV], mDT[NV];
     float bs2 = 0.f;
     auto gload = [&](int tile_) {
         const int tile = min(tile_, ntiles - 1);
         const typename ST::T* st = s + (long)tile * (32 * C);
         const typename ST::T* dt = db + (long)tile * (32 * C);
+        const typename ST::T* st2 = TWO ? s2 + (long)tile * (32 * C) : nullptr;
+        const typename ST::T* dt2 = TWO ? db2 + (long)tile * (32 * C) : nullptr;
         const int rows = min(P - tile * 32, 32);
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
@@ -1035,11 +1273,13 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
             const unsigned offp = (unsigned)(min(f / (C / 4), rows - 1) * C + 4 * (f % (C / 4)));
             nSP[v] = ST::ldr4(st + offp);
             nDP[v] = ST::ldr4(dt + offp);
+            if constexpr (TWO) mSP[v] = ST::ldr4(st2 + offp), mDP[v] = ST::ldr4(dt2 + offp);
             const int r0 = 4 * (tg + v * (F::NT / C));
             FFNO_UNROLL
             for (int i = 0; i < 4; ++i) {
                 const unsigned offt = (unsigned)(min(r0 + i, rows - 1) * C + tc);
                 nST[v].v[i] = ST::ldr1(st + offt), nDT[v].v[i] = ST::ldr1(dt + offt);
+                if constexpr (TWO) mST[v].v[i] = ST::ldr1(st2 + offt), mDT[v].v[i] = ST::ldr1(dt2 + offt);
             }
         }
     };
@@ -1053,6 +1293,12 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
             const float mp = (f / (C / 4)) < rows ? 1.f : 0.f;
             const float fs = fscale * mp, gs = gscale * mp;
             float4 sp = ST::w4(nSP[v]), dp = ST::w4(nDP[v]);
+            if constexpr (TWO) {
+                const float4 s2v = ST::w4(mSP[v]), d2v = ST::w4(mDP[v]);
+                sp.x += s2v.x, sp.y += s2v.y, sp.z += s2v.z, sp.w += s2v.w;
+                dp.x += d2v.x, dp.y += d2v.y, dp.z += d2v.z, dp.w += d2v.w;
+                sp = st_rnd4<ST>(sp), dp = st_rnd4<ST>(dp);
+            }
             sp.x *= fs, sp.y *= fs, sp.z *= fs, sp.w *= fs;
             dp.x *= gs, dp.y *= gs, dp.z *= gs, dp.w *= gs;
             const int r0 = 4 * (tg + v * (F::NT / C));
@@ -1060,6 +1306,11 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
                         m3 = r0 + 3 < rows ? 1.f : 0.f;
             float4 tS = make_float4(ST::w1(nST[v].v[0]), ST::w1(nST[v].v[1]), ST::w1(nST[v].v[2]), ST::w1(nST[v].v[3]));
             float4 tD = make_float4(ST::w1(nDT[v].v[0]), ST::w1(nDT[v].v[1]), ST::w1(nDT[v].v[2]), ST::w1(nDT[v].v[3]));
+            if constexpr (TWO) {
+                tS.x += ST::w1(mST[v].v[0]), tS.y += ST::w1(mST[v].v[1]), tS.z += ST::w1(mST[v].v[2]), tS.w += ST::w1(mST[v].v[3]);
+                tD.x += ST::w1(mDT[v].v[0]), tD.y += ST::w1(mDT[v].v[1]), tD.z += ST::w1(mDT[v].v[2]), tD.w += ST::w1(mDT[v].v[3]);
+                tS = st_rnd4<ST>(tS), tD = st_rnd4<ST>(tD);
+            }
             tS.x *= fscale * m0, tS.y *= fscale * m1, tS.z *= fscale * m2, tS.w *= fscale * m3;
             tD.x *= gscale * m0, tD.y *= gscale * m1, tD.z *= gscale * m2, tD.w *= gscale * m3;
             const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
@@ -1253,14 +1504,17 @@ struct FfWgDesc {
     float* partial;
     const unsigned* s_amax;
     const unsigned* g_amax;
+    const void* s2;      // second addends (TWO launches: every block gives both; a block without a second gradient addend -- the
+    const void* g2;      //  last layer's -- passes a zero-filled tensor)
 };
 
-template <int C, int H, int NWV, class ST = StF32>
+template <int C, int H, int NWV, class ST = StF32, bool TWO = false>
 __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_multi_kernel(const FfWgDesc* __restrict__ descs, int P, int nsplit) {
     const int layer = (int)blockIdx.x / nsplit;
     const FfWgDesc d = descs[layer];
-    ffh_wgrad_m_body<C, H, NWV, ST>((const typename ST::T*)d.s, (const typename ST::T*)d.g, d.pk1, d.b1, d.pk2t, d.partial, P,
-                                    d.s_amax, d.g_amax, (int)blockIdx.x - layer * nsplit, nsplit);
+    typedef const typename ST::T* cp;
+    ffh_wgrad_m_body<C, H, NWV, ST, TWO>((cp)d.s, (cp)d.g, d.pk1, d.b1, d.pk2t, d.partial, P, d.s_amax, d.g_amax,
+                                         (int)blockIdx.x - layer * nsplit, nsplit, (cp)d.s2, (cp)d.g2);
 }
 
 // partial slices -> gradients; the dW1 block of a slice is [c][hid] (transposed)
@@ -1412,6 +1666,32 @@ static int fx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void*
     return ffx_launch_status();
 }
 
+// wave-tile chain kernels (ffw_chain_kernel): split-fp16 at 64 / 256; schedule 0 picks them, FFNO_FF_SCHED_WAVE_TILES demands them
+static inline bool fw_wave_tiles(int np, int C, int H, int schedule, int ntiles) {
+    if (np != 2 || !(C == 64 && H == 256)) return false;
+    if (schedule == FFNO_FF_SCHED_WAVE_TILES) return true;
+    // by default only where every CU gets whole workgroups of tiles (a workgroup copies 128 KiB of weights and walks eight tiles
+    // at a time: a batch-1 rollout step of 128 tiles would run on 16 CUs)
+    return schedule == 0 && ntiles >= 8 * device_cu_count();
+}
+template <int C, int H, bool BWD, class ST>
+static int fw_launch(const void* in, const void* in2, void* sum_out, const void* resid, const void* pk1, const float* b1,
+                     const void* pk2, const float* b2, void* out, void* mask, int P, const unsigned* ia, unsigned* oa,
+                     int max_workgroups, hipStream_t st) {
+    typedef typename ST::T T;
+    constexpr int NCH = H / 32, KS = C / 16, CTO = C / 32;
+    const size_t smem = (size_t)(NCH * KS + NCH * CTO * 2) * 2 * 64 * sizeof(u32x4) + (size_t)(H + C + 8 * 32 * 20) * sizeof(float);
+    const int ntiles = (P + 31) / 32;
+    const int want = (ntiles + 7) / 8;
+    const int cap = max_workgroups > 0 ? max_workgroups : device_cu_count();
+    const dim3 grid(want < cap ? want : cap);
+    const int rc = allow_dynamic_lds(ffw_chain_kernel<C, H, BWD, ST>, smem);
+    if (rc) return rc;
+    FFNO_LAUNCH((ffw_chain_kernel<C, H, BWD, ST>), grid, dim3(512), smem, st, (const T*)in, (const T*)in2, (T*)sum_out,
+                (const T*)resid, (const u32x4*)pk1, b1, (const u32x4*)pk2, b2, (T*)out, (uint32_t*)mask, P, ia, oa);
+    return ffx_launch_status();
+}
+
 template <class S>
 static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* resid, const void* pk1, const float* b1,
                    const void* pk2, const float* b2, float* out, void* mask, int P, int C, int H, const ffno_ff_opts* o,
@@ -1421,8 +1701,18 @@ static int fx_fwd2(const float* s, const float* s2, float* s_sum, const float* r
     const dim3 grid(fx_workgroups(o ? o->max_workgroups : 0, ntiles, H));
     const unsigned* ia = o ? o->in_amax : nullptr;
     unsigned* oa = o ? o->out_amax : nullptr;
-    const bool in_phase = o && (o->schedule & FFNO_FF_SCHED_IN_PHASE);
+    const int sched = o ? o->schedule : 0;
+    if (sched < 0 || sched > FFNO_FF_SCHED_ROLE_SPLIT) return FFNO_EINVAL;
+    const bool in_phase = sched == FFNO_FF_SCHED_IN_PHASE;
     hipStream_t st = (hipStream_t)stream;
+    const bool b16 = o && o->storage == FFNO_STORE_BF16;
+    if (o && o->storage != FFNO_STORE_F32 && !b16) return FFNO_EINVAL;
+    if (fw_wave_tiles(S::NP, C, H, sched, ntiles)) {
+        const int mw = o ? o->max_workgroups : 0;
+        return b16 ? fw_launch<64, 256, false, StBf16>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, ia, oa, mw, st)
+                   : fw_launch<64, 256, false, StF32>(s, s2, s_sum, resid, pk1, b1, pk2, b2, out, mask, P, ia, oa, mw, st);
+    }
+    if (sched == FFNO_FF_SCHED_WAVE_TILES) return FFNO_EUNSUPPORTED;
     if (o && o->storage == FFNO_STORE_BF16) {      // bf16 storage twins: the split-fp16 kernels of widths 64 and 32 (factor 4)
         typedef const uint16_t* cp;
         if (S::NP != 2 || !((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
@@ -1461,6 +1751,17 @@ static int fx_bwd_data2(const float* db, const float* db2, float* db_sum, const 
     const unsigned* ia = o ? o->in_amax : nullptr;
     unsigned* oa = o ? o->out_amax : nullptr;
     hipStream_t st = (hipStream_t)stream;
+    const int sched = o ? o->schedule : 0;
+    if (sched < 0 || sched > FFNO_FF_SCHED_ROLE_SPLIT) return FFNO_EINVAL;
+    if (o && o->storage != FFNO_STORE_F32 && o->storage != FFNO_STORE_BF16) return FFNO_EINVAL;
+    if (fw_wave_tiles(S::NP, C, H, sched, ntiles)) {
+        const int mw = o ? o->max_workgroups : 0;
+        void* m = const_cast<void*>(mask);
+        return (o && o->storage == FFNO_STORE_BF16)
+                   ? fw_launch<64, 256, true, StBf16>(db, db2, db_sum, nullptr, pk1b, nullptr, pk2b, nullptr, ds, m, P, ia, oa, mw, st)
+                   : fw_launch<64, 256, true, StF32>(db, db2, db_sum, nullptr, pk1b, nullptr, pk2b, nullptr, ds, m, P, ia, oa, mw, st);
+    }
+    if (sched == FFNO_FF_SCHED_WAVE_TILES) return FFNO_EUNSUPPORTED;
     if (o && o->storage == FFNO_STORE_BF16) {
         typedef const uint16_t* cp;
         if (S::NP != 2 || !((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
@@ -1574,7 +1875,7 @@ extern "C" int ffno_ffh_bwd_weights_partial(const float* s, const float* db, con
 }
 
 extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit,
-                                                  int storage, void* stream) {
+                                                  int storage, int two_addends, void* stream) {
     static_assert(sizeof(ffno_ffwg_desc) == sizeof(FfWgDesc), "descriptor layout");
     if (!descs_dev || n <= 0 || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     if (storage != FFNO_STORE_F32 && storage != FFNO_STORE_BF16) return FFNO_EINVAL;
@@ -1583,6 +1884,12 @@ extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_de
     const FfWgDesc* d = reinterpret_cast<const FfWgDesc*>(descs_dev);
     const dim3 grid((unsigned)n * (unsigned)nsplit);
     const bool b16 = storage == FFNO_STORE_BF16;
+    if (two_addends) {      // (the wave-tile chain kernels' shape: they are what leaves the sums unwritten)
+        if (C != 64) return FFNO_EUNSUPPORTED;
+        if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16, true>), grid, dim3(512), 0, st, d, P, nsplit);
+        else FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StF32, true>), grid, dim3(512), 0, st, d, P, nsplit);
+        return ffx_launch_status();
+    }
     if (C == 64 && b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16>), grid, dim3(512), 0, st, d, P, nsplit);
     else if (C == 64) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8>), grid, dim3(512), 0, st, d, P, nsplit);
     else if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<32, 128, 4, StBf16>), grid, dim3(256), 0, st, d, P, nsplit);

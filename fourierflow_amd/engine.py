@@ -232,6 +232,10 @@ class FFNOEngine:
         # every layer keeps its own gradient buffer instead of the ping-pong pair; `ff_wgrad_rounds` x resident workgroups / L
         # slices per layer
         self.ff_wgrad_deferred = os.environ.get("FFNO_FF_WGRAD_DEFERRED", "1") != "0"
+        # ... and then the chain kernels leave the sums of their two input tensors unwritten (s_sum / db_sum NULL): every layer keeps
+        # both branch outputs and both gradient buffers, the weight-gradient launch adds them while it stages its rows
+        self.ff_lazy_sums = os.environ.get("FFNO_FF_LAZY_SUMS", "1") != "0"
+        self.ff_schedule = int(os.environ.get("FFNO_FF_SCHED", "0"))      # ffno.h FFNO_FF_SCHED_* (0: the library's choice)
         self.ff_wgrad_rounds = int(os.environ.get("FFNO_FF_WGRAD_ROUNDS", "3"))
         self.x3_mix16 = os.environ.get("FFNO_X3_MIX16", "1") != "0"      # 16-row mix packs for the many-mode kernel (False: 32-row)
         self.x3_min_lines = 1
@@ -299,9 +303,9 @@ class FFNOEngine:
         return [w for w in range(n) if w not in pair], pair
 
     def _pair(self, name, ws, v0, v1, src, dst0, dst1, resid0, save0, save1, planes0, planes1, fwd: bool, st, acc0: int = 0,
-              fused: bool = True, x3: bool = False, rin=None, rout=None):
+              fused: bool = True, x3: bool = False, rin=None, rout=None, resid1=None):
         """Branches of views v0 and v1 side by side -- ONE launch when both are fused, three paired stage launches else:
-        dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = branch1(src).
+        dst0 (+)= [resid0 +] branch0(src)  (``acc0``: accumulate into dst0),  dst1 = [resid1 +] branch1(src).
         rin / rout: range words of src / of the two outputs (both branches fold into ``rout``)."""
         lib = _lib.get_lib()
         ck_f, ck_i, conj = (0, 1, 0) if fwd else (1, 0, 1)
@@ -310,7 +314,7 @@ class FFNOEngine:
             sv1 = save1 if save1 is not None else ws.SD2
             ba = _capi.FusedBranch(_p(src), _p(dst0), resid0, _p(sv0), _p(planes0), _p(self._twiddle(v0.L)),
                                    v0.Bv, v0.Mv, v0.Nv, v0.K, v0.a01, acc0, 0, 0, None, rout if x3 else None)
-            bb = _capi.FusedBranch(_p(src), _p(dst1), None, _p(sv1), _p(planes1), _p(self._twiddle(v1.L)),
+            bb = _capi.FusedBranch(_p(src), _p(dst1), resid1, _p(sv1), _p(planes1), _p(self._twiddle(v1.L)),
                                    v1.Bv, v1.Mv, v1.Nv, v1.K, v1.a01, 0, 0, 0, None, rout if x3 else None)
             fn = lib.ffno_spectral_x3_staged_pair if x3 else lib.ffno_spectral_staged_pair      # x3: planes are the packed sets
             self._k("spectral_staged_pair" + ("" if fwd else "(adj)"), fn, ctypes.byref(ba),
@@ -320,7 +324,7 @@ class FFNOEngine:
                 self._fold(dst1, rout, st)
             return
         ba = self._branch(v0, src, dst0, resid0, save0, planes0, acc0, x3, fwd, rin, rout)
-        bb = self._branch(v1, src, dst1, None, save1, planes1, 0, x3, fwd, rin, rout)
+        bb = self._branch(v1, src, dst1, resid1, save1, planes1, 0, x3, fwd, rin, rout)
         if x3:       # planes0 / planes1 are the packed split-bf16 sets
             self._k(name, lib.ffno_spectral_x3_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj,
                     int(self.x3_interleave), st)
@@ -386,14 +390,14 @@ class FFNOEngine:
     def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_fwd2 if self._h2() else lib.ffno_ffx_fwd2
-        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0, self._st())
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), int(self.ff_schedule), self._st())
         self._k("ff_fwd", fn, _p(s), _p(s2), _p(s_sum), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out), _p(mask),
                 P, self.C, self.H, ctypes.byref(o), st)
 
     def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_bwd_data2 if self._h2() else lib.ffno_ffx_bwd_data2
-        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), 0, self._st())
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), int(self.ff_schedule), self._st())
         self._k("ff_bwd_data", fn, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
                 P, self.C, self.H, ctypes.byref(o), st)
 
@@ -659,6 +663,11 @@ class FFNOEngine:
                                   and not self.use_fork and not self.layer_norm and not self.general_ff
                                   and (C, H) in ((64, 256), (32, 128)) and self.mode != "no-fourier")
             ws.G = [torch.empty(P, C, **act) for _ in range(L + 1 if ws.defer_wgrad else 2)]
+            ws.lazy_sums = bool(ws.defer_wgrad and self.ff_lazy_sums and self._conc() and (C, H) == (64, 256))
+            if ws.lazy_sums:
+                ws.TS = [torch.empty(P, C, **act) for _ in range(L)]         # second branch output of every layer
+                ws.G1L = [torch.empty(P, C, **act) for _ in range(L + 1)]    # second gradient buffer beside every ws.G
+                ws.ZeroPC = torch.zeros(P, C, **act)                         # second gradient addend of the last layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(int(self.ff_wgrad_slices), (P + 127) // 128))
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
@@ -840,8 +849,10 @@ class FFNOEngine:
             assert not accumulate
             part = ws.ffparts[len(ws.red_jobs)]
             if getattr(ws, "wg_jobs", None) is not None:
+                s2, g2 = getattr(self, "_wg_second", None) or (None, None)
                 ws.wg_jobs.append((s.data_ptr(), g.data_ptr(), l0.fx[0].data_ptr(), b0.data_ptr(), l0.fx[2].data_ptr(),
-                                   part.data_ptr(), rs.value, rg.value))
+                                   part.data_ptr(), rs.value, rg.value, s2.data_ptr() if s2 is not None else 0,
+                                   g2.data_ptr() if g2 is not None else 0))
             else:
                 self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st, rs, rg)
             ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gb0.data_ptr(), gb1.data_ptr()))
@@ -1035,6 +1046,9 @@ class FFNOEngine:
                 and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
                            and not self.layer_norm)
+        # both branch outputs of every layer are kept and the feed-forward does not write their sum (the deferred weight-gradient
+        # launch forms it): decided here, the backward pass follows (self._saved_lazy)
+        lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", False) and not self.overlap)
         bf16 = self._bf16()
         if bf16 and not (all(fused) and all(x3) and self._h2() and self._x3_h2() and self._ffx() and self.spectral == "factorized"
                          and (C, H) in ((64, 256), (32, 128)) and full and not self.use_fork and not self.layer_norm
@@ -1084,19 +1098,20 @@ class FFNOEngine:
                 if conc:
                     a, b = pair
                     keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in pair]
+                    t_l = ws.TS[sv] if lazy else ws.T
                     if layer_calls:
                         l0, l1, b0, b1 = self._ff_weights(l)
                         d = _capi.LayerFwdDesc(
                             self._branch(ws.views[a], ws.X, s_l, None, keep[0], self._planes_for(si, a, 0, x3pair), int(nwrit > 0),
                                          x3pair, True, rx, rs_),
-                            self._branch(ws.views[b], ws.X, ws.T, None, keep[1], self._planes_for(si, b, 0, x3pair), 0, x3pair, True,
+                            self._branch(ws.views[b], ws.X, t_l, None, keep[1], self._planes_for(si, b, 0, x3pair), 0, x3pair, True,
                                          rx, rs_),
                             int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
-                            _p(s_l) if save_for_backward else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
+                            _p(s_l) if (save_for_backward and not lazy) else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
                             _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()), rxn)
                         self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
                         continue
-                    self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, ws.T, None, keep[0], keep[1],
+                    self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, t_l, None, keep[0], keep[1],
                                self._planes_for(si, a, 0, x3pair), self._planes_for(si, b, 0, x3pair), True, st,
                                acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rx, rout=rs_)
             l0, l1, b0, b1 = self._ff_weights(l)
@@ -1105,7 +1120,7 @@ class FFNOEngine:
             ff_res = None if (self.layer_norm or last) else ws.X
             ff_rout = None if self.layer_norm else rxn     # (LayerNorm: the next layer's input is the normalised tensor)
             if conc:
-                self._ffs_fwd2(s_l, ws.T, s_l if save_for_backward else None, ff_res, l0, b0, b1, ff_out,
+                self._ffs_fwd2(s_l, ws.TS[sv] if lazy else ws.T, s_l if (save_for_backward and not lazy) else None, ff_res, l0, b0, b1, ff_out,
                                ws.MASK[sv] if save_for_backward else None, P, st, rs_, ff_rout)
             elif self.use_fork and last:          # with fork heads the last layer's backcast only feeds the dead x_L
                 pass
@@ -1144,6 +1159,7 @@ class FFNOEngine:
         self._saved = (x, B, S, fused, conc) if save_for_backward else None
         self._saved_x3 = (x3, x3pair)
         self._saved_sched = (singles, pair)
+        self._saved_lazy = lazy
         self.paired_last = conc      # (bench.py: which algorithmic-work table applies)
         return ws.Y.view(B, *S, self.O).clone()
 
@@ -1157,6 +1173,7 @@ class FFNOEngine:
         x, B, S, fused, conc = self._saved
         x3, x3pair = self._saved_x3
         singles, pair = self._saved_sched
+        lazy = bool(getattr(self, "_saved_lazy", False))
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
@@ -1214,6 +1231,9 @@ class FFNOEngine:
         nG = len(ws.G)
         # deferred weight-gradient launch: (s, summed gradient, packs, words, slices) of every layer, one launch after the loop
         ws.wg_jobs = [] if (getattr(ws, "defer_wgrad", False) and not use_side and conc) else None
+        if lazy and ws.wg_jobs is None:
+            raise RuntimeError("the forward pass left the feed-forward input sums to a deferred weight-gradient launch that this "
+                               "backward pass cannot run (engine.overlap switched on between forward and backward?)")
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
                            and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
                            and self.mode != "no-fourier" and not self.layer_norm)
@@ -1222,6 +1242,7 @@ class FFNOEngine:
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
             g_in, g_out, dh = ws.G[cur], ws.G[(cur + 1) % nG], ws.DH[l & 1]
+            g1_in, g1_out = (ws.G1L[cur], ws.G1L[(cur + 1) % nG]) if lazy else (getattr(ws, "G1", None), getattr(ws, "G1", None))
             # words: gradient entering this layer, its feed-forward input, the data gradient, the gradient it hands on
             rg, rs_, rd, rgo = rw(ws, "g", l), rw(ws, "s", l), rw(ws, "d", l), (rw(ws, "g", l - 1) if l > 0 else rw(ws, "g", L))
             if self.use_fork:
@@ -1274,13 +1295,15 @@ class FFNOEngine:
                 if ws.wg_jobs is not None:
                     ws.wg_jobs.append((ws.S[l].data_ptr(), g_in.data_ptr(), l0.fx[0].data_ptr(),
                                        self.params[fp + "layers.0.0.bias"].data_ptr(), l0.fx[2].data_ptr(), part.data_ptr(),
-                                       rs_.value, rg.value))
+                                       rs_.value, rg.value, ws.TS[l].data_ptr() if lazy else 0,
+                                       ((g1_in if have_g1 else ws.ZeroPC).data_ptr()) if lazy else 0))
                 d = _capi.LayerBwdDesc(
                     self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
                                  self._planes_for(si, a, 1, x3pair), 0, x3pair, False, rd, rgo),
-                    self._branch(ws.views[b], ws.DS, ws.G1, None, ws.SDall[b][l] if full else None,
+                    self._branch(ws.views[b], ws.DS, g1_out, _p(g1_in) if (lazy and have_g1) else None, ws.SDall[b][l] if full else None,
                                  self._planes_for(si, b, 1, x3pair), 0, x3pair, False, rd, rgo),
-                    int(x3pair), int(self.x3_interleave), _p(g_in), _p(ws.G1) if have_g1 else None, _p(g_in), _p(ws.MASK[l]),
+                    int(x3pair), int(self.x3_interleave), _p(g_in), _p(g1_in) if have_g1 else None, None if lazy else _p(g_in),
+                    _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
                     None if ws.wg_jobs is not None else _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, rg, rs_, rd)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
@@ -1304,7 +1327,8 @@ class FFNOEngine:
             if conc:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
                 two = bool(have_g1 and not self.layer_norm)
-                self._ffs_bwd2(g_ff, ws.G1 if two else None, g_ff if two else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
+                self._ffs_bwd2(g_ff, g1_in if two else None, g_ff if (two and not lazy) else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
+                self._wg_second = (ws.TS[l], g1_in if two else ws.ZeroPC) if lazy else None
             elif self.general_ff:
                 self._ffg_bwd(ws, fp, "backcast", l, ws.S[l], g_ff, ws.DS, int(fp in ff_seen), P, st, rd)
             else:
@@ -1345,17 +1369,19 @@ class FFNOEngine:
                 nwrit += 1
             if conc:
                 a, b = pair
-                self._pair("spectral_fused(adj)", ws, ws.views[a], ws.views[b], ws.DS, g_out, ws.G1,
+                self._pair("spectral_fused(adj)", ws, ws.views[a], ws.views[b], ws.DS, g_out, g1_out,
                            resid if nwrit == 0 else None, ws.SDall[a][l] if full else None, ws.SDall[b][l] if full else None,
                            self._planes_for(si, a, 1, x3pair), self._planes_for(si, b, 1, x3pair), False, st,
-                           acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rd, rout=rgo)
+                           acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rd, rout=rgo,
+                           resid1=_p(g1_in) if (lazy and have_g1) else None)
             have_g1 = conc
             cur = (cur + 1) % nG
         if conc and have_g1:      # lift_bwd takes one input
+            g1_fin = ws.G1L[cur] if lazy else ws.G1
             if self._bf16():
-                ws.G[cur].add_(ws.G1)       # (a torch kernel on the same stream; rounds the sum to bf16 like every stored tensor)
+                ws.G[cur].add_(g1_fin)      # (a torch kernel on the same stream; rounds the sum to bf16 like every stored tensor)
             else:
-                self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(ws.G1), 1.0, P * C, st)
+                self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(g1_fin), 1.0, P * C, st)
         if use_side:
             main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
         nsl = ws.nsplit_ff
@@ -1367,7 +1393,7 @@ class FFNOEngine:
                 ws.wg_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
                 ws.wg_sig = sig
             self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial_multi, _p(ws.wg_table), len(sig), P, C, H, nsl,
-                    self._st(), st)
+                    self._st(), int(lazy), st)
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:
             sig = tuple(ws.red_jobs)
             if sig != ws.red_sig:       # pointers only change when parameters are re-bound or the workspace is rebuilt

@@ -402,13 +402,20 @@ typedef struct ffno_ff_opts {
     const uint32_t* in_amax; /* range word of the addends of the input (s / s2, db / db2); used by ffno_ffh_* only */
     uint32_t* out_amax;      /* optional: receives max |out| (forward: out; backward-data: ds) */
     int32_t max_workgroups;  /* persistent workgroups; 0 = one per compute unit of the device */
-    int32_t schedule;        /* 0 = the measured default (forward: role-split halves -- a matrix segment on one wave of a SIMD
-                                beside a vector / LDS segment on the other; backward-data: both halves in phase), or
-                                FFNO_FF_SCHED_IN_PHASE for the forward; results are bit-identical */
+    int32_t schedule;        /* 0 = the measured default: ffno_ffh_* at C = 64, H = 256: FFNO_FF_SCHED_WAVE_TILES (one wave per 32-pixel
+                                tile, both weight maps in LDS, no staging / exchange / barriers); every other shape and the
+                                bf16x3 family: the shared-tile kernels (forward: FFNO_FF_SCHED_ROLE_SPLIT -- a matrix segment on
+                                one wave of a SIMD beside a vector / LDS segment on the other; backward-data: both halves in
+                                phase).  The shared-tile schedules are bit-identical to each other; WAVE_TILES sums the hidden
+                                chunks of an output in one accumulator pair instead of eight partial tiles: equal to fp32
+                                rounding (same products), not bit for bit.  An explicit schedule a shape does not have:
+                                FFNO_EUNSUPPORTED */
     int32_t storage;         /* FFNO_STORE_F32 (0) / FFNO_STORE_BF16: format of every activation pointer of the call (s, s2,
                                 s_sum, resid, out / db, db2, db_sum, ds); bf16: ffno_ffh_* at C = 64, H = 256 */
 } ffno_ff_opts;
 #define FFNO_FF_SCHED_IN_PHASE 1
+#define FFNO_FF_SCHED_WAVE_TILES 2
+#define FFNO_FF_SCHED_ROLE_SPLIT 3
 size_t ffno_ffx_pack_bytes(int C, int H);
 int ffno_ffx_pack(const ffno_fxpack_desc* descs_dev, int n, int C, int H, void* stream);
 int ffno_ffx_fwd(const float* s, const float* resid, const void* pk1, const float* b1, const void* pk2,
@@ -492,9 +499,12 @@ typedef struct ffno_ffwg_desc {
     float* partial;          /* nsplit slices */
     const uint32_t* s_amax;
     const uint32_t* g_amax;
+    const void* s2;          /* two_addends != 0: s = s + s2 and g = g + g2 are formed (and rounded to the storage format) while */
+    const void* g2;          /* the rows are staged -- for callers whose chain launches do not write the sums back (s_sum / db_sum
+                              * NULL); every block must give both (a block with one gradient addend: a zero-filled tensor) */
 } ffno_ffwg_desc;
 int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit, int storage,
-                                       void* stream);
+                                       int two_addends /* C = 64, H = 256 only */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),

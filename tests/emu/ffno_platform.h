@@ -66,6 +66,8 @@ inline void sincos_pi(float x, float& s, float& c) {
 
 static inline int cu_count() { return 256; }      // (the emulator plays an MI355X)
 
+// rendezvous of the 64 fibres of a wave (an exchange through LDS between the lanes of one wave needs every lane's write done)
+__device__ __forceinline__ void wave_sync() { (void)__shfl(0.f, 0); }
 }  // namespace plat
 
 template <class K>

@@ -139,6 +139,68 @@ def test_ffh_fwd_bwd(be, P, C, H, sched):
     assert rel_l2(be.get(ds), ref_ds) < 3e-5
 
 
+FFNO_FF_SCHED_WAVE_TILES, FFNO_FF_SCHED_ROLE_SPLIT = 2, 3
+
+
+@pytest.mark.parametrize("P,two", [(70, True), (200, False), (32 * 21, True), (5000, True)])
+def test_ffh_wave_tiles_against_shared_tiles(be, P, two):
+    """FFNO_FF_SCHED_WAVE_TILES (one wave per 32-pixel tile, both weight maps in LDS; what schedule 0 picks for large launches at
+    64 / 256) against the shared-tile kernels on the same operands: the stored input sum and the ReLU sign words are the same
+    bits (the first product chain is the same, product for product), outputs and data gradients agree to fp32 rounding (same
+    products; the hidden chunks of an output are summed in one accumulator pair instead of eight partial tiles), both against
+    fp64.  Ragged last tile, one and two addends, more tiles than waves of a workgroup, fewer tiles than waves."""
+    if be.kind == "emu" and P > 1000:
+        pytest.skip("large case on the GPU only")
+    C, H = 64, 256
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(P)
+    sa, sb = (rs.standard_normal((P, C)).astype(np.float32) * 30 for _ in range(2))
+    s = sa + sb if two else sa
+    resid = rs.standard_normal((P, C)).astype(np.float32)
+    W1 = (rs.standard_normal((H, C)) / np.sqrt(C)).astype(np.float32)
+    b1 = (rs.standard_normal(H) * 0.1).astype(np.float32)
+    W2 = (rs.standard_normal((C, H)) / np.sqrt(H)).astype(np.float32)
+    b2 = (rs.standard_normal(C) * 0.1).astype(np.float32)
+    (a1, a2, a1b, a2b), _keep = pack_weights_h(be, W1, W2)
+    db1_, db2_ = be.put(b1), be.put(b2)
+    s_word = amax_word(be, sa, sb) if two else amax_word(be, sa)
+    ga, gb = ((rs.standard_normal((P, C)) * 3e-3).astype(np.float32) for _ in range(2))
+    g = ga + gb if two else ga
+    g_word = amax_word(be, ga, gb) if two else amax_word(be, ga)
+    got = {}
+    for sched in (FFNO_FF_SCHED_ROLE_SPLIT, FFNO_FF_SCHED_WAVE_TILES):
+        out, ssum = be.empty((P, C)), be.empty((P, C))
+        mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
+        ow, dw = be.zeros(1, np.uint32), be.zeros(1, np.uint32)
+        o = opts(be, s_word, ow, schedule=sched)
+        assert lib.ffno_ffh_fwd2(p(be.put(sa)), p(be.put(sb)) if two else None, p(ssum) if two else None, p(be.put(resid)), p(a1),
+                                 p(db1_), p(a2), p(db2_), p(out), p(mask), P, C, H, ctypes.byref(o), None) == 0
+        gsum, ds = be.empty((P, C)), be.empty((P, C))
+        o = opts(be, g_word, dw, schedule=sched)
+        assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)) if two else None, p(gsum) if two else None, p(mask), p(a1b),
+                                      p(a2b), p(ds), P, C, H, ctypes.byref(o), None) == 0
+        got[sched] = (be.get(out).copy(), be.get(ssum).copy(), np.asarray(be.get(mask)).copy(), be.get(ds).copy(),
+                      be.get(gsum).copy(), word_value(be, ow), word_value(be, dw))
+    ref_out, ref_h = ff_ref(s, resid, W1, b1, W2, b2)
+    ref_ds = ((g.astype(np.float64) @ W2.astype(np.float64)) * (ref_h > 0)) @ W1.astype(np.float64)
+    old, new = got[FFNO_FF_SCHED_ROLE_SPLIT], got[FFNO_FF_SCHED_WAVE_TILES]
+    assert rel_l2(new[0], ref_out) < TOL and rel_l2(new[3], ref_ds) < TOL
+    assert rel_l2(new[0], old[0]) < 5e-7 and rel_l2(new[3], old[3]) < 5e-7
+    np.testing.assert_array_equal(new[2], old[2])
+    if two:
+        np.testing.assert_array_equal(new[1], old[1])
+        np.testing.assert_array_equal(new[4], old[4])
+        np.testing.assert_array_equal(new[1], s)
+    assert new[5] == float(np.abs(new[0]).max()) and new[6] == float(np.abs(new[3]).max())
+    # a shape without wave tiles, an unknown schedule
+    o = opts(be, s_word, None, schedule=FFNO_FF_SCHED_WAVE_TILES)
+    assert lib.ffno_ffh_fwd2(p(be.put(sa)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(be.empty((P, C))), None, P, 64, 128,
+                             ctypes.byref(o), None) == -2
+    o = opts(be, s_word, None, schedule=7)
+    assert lib.ffno_ffh_fwd2(p(be.put(sa)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(be.empty((P, C))), None, P, C, H,
+                             ctypes.byref(o), None) == -1
+
+
 @pytest.mark.parametrize("P,C,H,nsplit", [(200, 64, 256, 2), (131, 32, 128, 3), (4100, 64, 256, 5)])
 def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit):
     """ffno_ffh_bwd_weights_partial_multi: the slices of n feed-forward blocks (own inputs, gradients, weights, range words) from
@@ -151,7 +213,7 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
     rs = np.random.RandomState(P + nsplit)
     n = 3
     nfl = int(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
-    keep, descs, singles = [], [], []
+    keep, descs, singles, descs2, twos = [], [], [], [], []
     for i in range(n):
         s = (rs.standard_normal((P, C)) * 10.0 ** (i - 1)).astype(np.float32)
         g = (rs.standard_normal((P, C)) * 10.0 ** (-3 * i)).astype(np.float32)
@@ -166,14 +228,34 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
         singles.append((one, multi))
         descs.append(FfWgDesc(p(ds_), p(dg), p(a1), p(b1), p(a1b), p(multi), p(sw), p(gw)))
         keep += [ds_, dg, b1, a1, a2, a1b, a2b, k_, sw, gw]
+        # the same block as the sum of two addends (two_addends launch): s = sa + sb, g = ga + gb formed while staging
+        sa = (s * rs.uniform(0.2, 0.8, s.shape)).astype(np.float32)
+        ga = (g * rs.uniform(0.2, 0.8, g.shape)).astype(np.float32)
+        sb, gb = (s - sa).astype(np.float32), (g - ga).astype(np.float32)
+        if i == n - 1:
+            ga, gb = g, np.zeros_like(g)          # a block with one gradient addend passes zeros
+        pre_s, pre_g = be.put(sa + sb), be.put(ga + gb)
+        one2, multi2 = be.zeros(nfl), be.zeros(nfl)
+        assert lib.ffno_ffh_bwd_weights_partial(p(pre_s), p(pre_g), p(a1), p(b1), p(a1b), p(one2), P, C, H, nsplit, p(sw), p(gw), 0, None) == 0
+        dsa, dsb, dga, dgb = be.put(sa), be.put(sb), be.put(ga), be.put(gb)
+        twos.append((one2, multi2))
+        descs2.append(FfWgDesc(p(dsa), p(dga), p(a1), p(b1), p(a1b), p(multi2), p(sw), p(gw), p(dsb), p(dgb)))
+        keep += [pre_s, pre_g, dsa, dsb, dga, dgb]
     table = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs)), dtype=np.uint8).copy())
-    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, C, H, nsplit, 0, None) == 0
+    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, C, H, nsplit, 0, 0, None) == 0
     for one, multi in singles:
         a = be.get(one)
         assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
         np.testing.assert_array_equal(be.get(multi), a)
-    assert lib.ffno_ffh_bwd_weights_partial_multi(None, n, P, C, H, nsplit, 0, None) == -1
-    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, 64, 128, nsplit, 0, None) == -2
+    table2 = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs2)), dtype=np.uint8).copy())
+    if C == 64:
+        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 1, None) == 0
+        for one2, multi2 in twos:
+            np.testing.assert_array_equal(be.get(multi2), be.get(one2))
+    else:
+        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 1, None) == -2
+    assert lib.ffno_ffh_bwd_weights_partial_multi(None, n, P, C, H, nsplit, 0, 0, None) == -1
+    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, 64, 128, nsplit, 0, 0, None) == -2
 
 
 @pytest.mark.parametrize("act,grad", [(1e5, 1e4), (1e6, 1e-12), (3e-9, 7e7), (1.0, 1.0)])
