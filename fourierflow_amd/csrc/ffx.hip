@@ -402,6 +402,9 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const type
 //   of the weight-gradient kernel's recomputation (same ReLU decisions).  GEMM2: ONE main + correction pair per output tile
 //   over all 16 k-steps, folded once (ffx_chain_kernel folds per chunk and adds the eight partial tiles: same products, other
 //   rounding of the sum -- results agree to fp32 rounding, not bit for bit; bf16 twin == bf16(this kernel at fp32 storage)).
+#ifndef FFW_STAGGER
+#define FFW_STAGGER 48      // x 64 cycles
+#endif
 template <int C, int H, bool BWD, class ST = StF32>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(const typename ST::T* __restrict__ in,
                                                                               const typename ST::T* __restrict__ in2,
@@ -452,6 +455,7 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(c
     float* stg_o = stg + j * SROW + 8 * half;               // operand map
     const uint16_t* mrd = reinterpret_cast<const uint16_t*>(mask);
     uint16_t* mwr = reinterpret_cast<uint16_t*>(mask);
+    bool first = true;
     FFNO_NOUNROLL
     for (int tile = (int)blockIdx.x * NWV + wave; tile < ntiles; tile += (int)gridDim.x * NWV) {
         // rows of this lane in the memory map; rows past the end re-read the last row and are zeroed / not stored
@@ -496,6 +500,10 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(c
                 mw[q] = (uint32_t)mrd[((long)tile * NCH + 2 * q) * 64 + lane] |
                         ((uint32_t)mrd[((long)tile * NCH + 2 * q + 1) * 64 + lane] << 16);
         }
+        // the two waves of a SIMD (w and w + 4) start in phase and would stay so, both waiting for their rows and then both
+        // computing: the second one sleeps through part of its first wait so that one computes while the other loads
+        if (first && wave >= NWV / 2) plat::sleep_cycles_64(FFW_STAGGER);
+        first = false;
         // the tile's rows as B operands: k-step st <-> channels 16 st + 8 half + (0..7) of pixel j
         Hf2 b[KS];
         FFNO_UNROLL
@@ -1204,7 +1212,8 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //     buffers of the paired adjoint launch), added -- and rounded to the storage format, as the chain kernels do -- while the
 //     rows are staged: the chain kernels then need not write the sums back (one image write less per launch: 44.6 -> 39.1 us
 //     forward, 41.4 -> 33.4 us backward-data with the wave-tile kernels, MI355X round 4).
-template <int C, int H, int NWV, class ST = StF32, bool TWO = false>
+//     TWO = 1: only s is a sum (db single), TWO = 2: both.
+template <int C, int H, int NWV, class ST = StF32, int TWO = 0>
 __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restrict__ s, const typename ST::T* __restrict__ db,
                                                  const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
                                                  const u32x4* __restrict__ pk2t, float* __restrict__ partial, int P,
@@ -1265,7 +1274,7 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         const typename ST::T* st = s + (long)tile * (32 * C);
         const typename ST::T* dt = db + (long)tile * (32 * C);
         const typename ST::T* st2 = TWO ? s2 + (long)tile * (32 * C) : nullptr;
-        const typename ST::T* dt2 = TWO ? db2 + (long)tile * (32 * C) : nullptr;
+        const typename ST::T* dt2 = TWO == 2 ? db2 + (long)tile * (32 * C) : nullptr;
         const int rows = min(P - tile * 32, 32);
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
@@ -1273,13 +1282,15 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
             const unsigned offp = (unsigned)(min(f / (C / 4), rows - 1) * C + 4 * (f % (C / 4)));
             nSP[v] = ST::ldr4(st + offp);
             nDP[v] = ST::ldr4(dt + offp);
-            if constexpr (TWO) mSP[v] = ST::ldr4(st2 + offp), mDP[v] = ST::ldr4(dt2 + offp);
+            if constexpr (TWO >= 1) mSP[v] = ST::ldr4(st2 + offp);
+            if constexpr (TWO == 2) mDP[v] = ST::ldr4(dt2 + offp);
             const int r0 = 4 * (tg + v * (F::NT / C));
             FFNO_UNROLL
             for (int i = 0; i < 4; ++i) {
                 const unsigned offt = (unsigned)(min(r0 + i, rows - 1) * C + tc);
                 nST[v].v[i] = ST::ldr1(st + offt), nDT[v].v[i] = ST::ldr1(dt + offt);
-                if constexpr (TWO) mST[v].v[i] = ST::ldr1(st2 + offt), mDT[v].v[i] = ST::ldr1(dt2 + offt);
+                if constexpr (TWO >= 1) mST[v].v[i] = ST::ldr1(st2 + offt);
+                if constexpr (TWO == 2) mDT[v].v[i] = ST::ldr1(dt2 + offt);
             }
         }
     };
@@ -1293,11 +1304,15 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
             const float mp = (f / (C / 4)) < rows ? 1.f : 0.f;
             const float fs = fscale * mp, gs = gscale * mp;
             float4 sp = ST::w4(nSP[v]), dp = ST::w4(nDP[v]);
-            if constexpr (TWO) {
-                const float4 s2v = ST::w4(mSP[v]), d2v = ST::w4(mDP[v]);
+            if constexpr (TWO >= 1) {
+                const float4 s2v = ST::w4(mSP[v]);
                 sp.x += s2v.x, sp.y += s2v.y, sp.z += s2v.z, sp.w += s2v.w;
+                sp = st_rnd4<ST>(sp);
+            }
+            if constexpr (TWO == 2) {
+                const float4 d2v = ST::w4(mDP[v]);
                 dp.x += d2v.x, dp.y += d2v.y, dp.z += d2v.z, dp.w += d2v.w;
-                sp = st_rnd4<ST>(sp), dp = st_rnd4<ST>(dp);
+                dp = st_rnd4<ST>(dp);
             }
             sp.x *= fs, sp.y *= fs, sp.z *= fs, sp.w *= fs;
             dp.x *= gs, dp.y *= gs, dp.z *= gs, dp.w *= gs;
@@ -1306,10 +1321,13 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
                         m3 = r0 + 3 < rows ? 1.f : 0.f;
             float4 tS = make_float4(ST::w1(nST[v].v[0]), ST::w1(nST[v].v[1]), ST::w1(nST[v].v[2]), ST::w1(nST[v].v[3]));
             float4 tD = make_float4(ST::w1(nDT[v].v[0]), ST::w1(nDT[v].v[1]), ST::w1(nDT[v].v[2]), ST::w1(nDT[v].v[3]));
-            if constexpr (TWO) {
+            if constexpr (TWO >= 1) {
                 tS.x += ST::w1(mST[v].v[0]), tS.y += ST::w1(mST[v].v[1]), tS.z += ST::w1(mST[v].v[2]), tS.w += ST::w1(mST[v].v[3]);
+                tS = st_rnd4<ST>(tS);
+            }
+            if constexpr (TWO == 2) {
                 tD.x += ST::w1(mDT[v].v[0]), tD.y += ST::w1(mDT[v].v[1]), tD.z += ST::w1(mDT[v].v[2]), tD.w += ST::w1(mDT[v].v[3]);
-                tS = st_rnd4<ST>(tS), tD = st_rnd4<ST>(tD);
+                tD = st_rnd4<ST>(tD);
             }
             tS.x *= fscale * m0, tS.y *= fscale * m1, tS.z *= fscale * m2, tS.w *= fscale * m3;
             tD.x *= gscale * m0, tD.y *= gscale * m1, tD.z *= gscale * m2, tD.w *= gscale * m3;
@@ -1508,7 +1526,7 @@ struct FfWgDesc {
     const void* g2;      //  last layer's -- passes a zero-filled tensor)
 };
 
-template <int C, int H, int NWV, class ST = StF32, bool TWO = false>
+template <int C, int H, int NWV, class ST = StF32, int TWO = 0>
 __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_multi_kernel(const FfWgDesc* __restrict__ descs, int P, int nsplit) {
     const int layer = (int)blockIdx.x / nsplit;
     const FfWgDesc d = descs[layer];
@@ -1884,10 +1902,13 @@ extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_de
     const FfWgDesc* d = reinterpret_cast<const FfWgDesc*>(descs_dev);
     const dim3 grid((unsigned)n * (unsigned)nsplit);
     const bool b16 = storage == FFNO_STORE_BF16;
+    if (two_addends < 0 || two_addends > 2) return FFNO_EINVAL;
     if (two_addends) {      // (the wave-tile chain kernels' shape: they are what leaves the sums unwritten)
         if (C != 64) return FFNO_EUNSUPPORTED;
-        if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16, true>), grid, dim3(512), 0, st, d, P, nsplit);
-        else FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StF32, true>), grid, dim3(512), 0, st, d, P, nsplit);
+        if (two_addends == 1 && b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16, 1>), grid, dim3(512), 0, st, d, P, nsplit);
+        else if (two_addends == 1) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StF32, 1>), grid, dim3(512), 0, st, d, P, nsplit);
+        else if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16, 2>), grid, dim3(512), 0, st, d, P, nsplit);
+        else FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StF32, 2>), grid, dim3(512), 0, st, d, P, nsplit);
         return ffx_launch_status();
     }
     if (C == 64 && b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16>), grid, dim3(512), 0, st, d, P, nsplit);

@@ -234,7 +234,8 @@ class FFNOEngine:
         self.ff_wgrad_deferred = os.environ.get("FFNO_FF_WGRAD_DEFERRED", "1") != "0"
         # ... and then the chain kernels leave the sums of their two input tensors unwritten (s_sum / db_sum NULL): every layer keeps
         # both branch outputs and both gradient buffers, the weight-gradient launch adds them while it stages its rows
-        self.ff_lazy_sums = os.environ.get("FFNO_FF_LAZY_SUMS", "1") != "0"
+        #   "s": the forward's input sums only (the backward-data launch still writes its summed gradient);  "sg": both;  "0": none
+        self.ff_lazy_sums = os.environ.get("FFNO_FF_LAZY_SUMS", "s")
         self.ff_schedule = int(os.environ.get("FFNO_FF_SCHED", "0"))      # ffno.h FFNO_FF_SCHED_* (0: the library's choice)
         self.ff_wgrad_rounds = int(os.environ.get("FFNO_FF_WGRAD_ROUNDS", "3"))
         self.x3_mix16 = os.environ.get("FFNO_X3_MIX16", "1") != "0"      # 16-row mix packs for the many-mode kernel (False: 32-row)
@@ -663,9 +664,11 @@ class FFNOEngine:
                                   and not self.use_fork and not self.layer_norm and not self.general_ff
                                   and (C, H) in ((64, 256), (32, 128)) and self.mode != "no-fourier")
             ws.G = [torch.empty(P, C, **act) for _ in range(L + 1 if ws.defer_wgrad else 2)]
-            ws.lazy_sums = bool(ws.defer_wgrad and self.ff_lazy_sums and self._conc() and (C, H) == (64, 256))
+            ws.lazy_sums = str(self.ff_lazy_sums) if (ws.defer_wgrad and self.ff_lazy_sums in ("s", "sg") and self._conc()
+                                                      and (C, H) == (64, 256)) else ""
             if ws.lazy_sums:
                 ws.TS = [torch.empty(P, C, **act) for _ in range(L)]         # second branch output of every layer
+            if ws.lazy_sums == "sg":
                 ws.G1L = [torch.empty(P, C, **act) for _ in range(L + 1)]    # second gradient buffer beside every ws.G
                 ws.ZeroPC = torch.zeros(P, C, **act)                         # second gradient addend of the last layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
@@ -1048,7 +1051,7 @@ class FFNOEngine:
                            and not self.layer_norm)
         # both branch outputs of every layer are kept and the feed-forward does not write their sum (the deferred weight-gradient
         # launch forms it): decided here, the backward pass follows (self._saved_lazy)
-        lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", False) and not self.overlap)
+        lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", "") and not self.overlap)
         bf16 = self._bf16()
         if bf16 and not (all(fused) and all(x3) and self._h2() and self._x3_h2() and self._ffx() and self.spectral == "factorized"
                          and (C, H) in ((64, 256), (32, 128)) and full and not self.use_fork and not self.layer_norm
@@ -1173,12 +1176,13 @@ class FFNOEngine:
         x, B, S, fused, conc = self._saved
         x3, x3pair = self._saved_x3
         singles, pair = self._saved_sched
-        lazy = bool(getattr(self, "_saved_lazy", False))
         _lib.require_device_tensor(gy, "gy")
         gy = gy.contiguous()
         lib = _lib.get_lib()
         C, H, L = self.C, self.H, self.L
         ws = self._workspace(B, S, True)
+        lazy_s = bool(getattr(self, "_saved_lazy", False))            # forward input sums left to the weight-gradient launch
+        lazy = bool(lazy_s and getattr(ws, "lazy_sums", "") == "sg")   # ... and the backward's gradient sums
         st = _lib.current_stream(self.device)
         rw = self._rw
         if self._ranged():
@@ -1231,7 +1235,7 @@ class FFNOEngine:
         nG = len(ws.G)
         # deferred weight-gradient launch: (s, summed gradient, packs, words, slices) of every layer, one launch after the loop
         ws.wg_jobs = [] if (getattr(ws, "defer_wgrad", False) and not use_side and conc) else None
-        if lazy and ws.wg_jobs is None:
+        if lazy_s and ws.wg_jobs is None:
             raise RuntimeError("the forward pass left the feed-forward input sums to a deferred weight-gradient launch that this "
                                "backward pass cannot run (engine.overlap switched on between forward and backward?)")
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
@@ -1295,7 +1299,7 @@ class FFNOEngine:
                 if ws.wg_jobs is not None:
                     ws.wg_jobs.append((ws.S[l].data_ptr(), g_in.data_ptr(), l0.fx[0].data_ptr(),
                                        self.params[fp + "layers.0.0.bias"].data_ptr(), l0.fx[2].data_ptr(), part.data_ptr(),
-                                       rs_.value, rg.value, ws.TS[l].data_ptr() if lazy else 0,
+                                       rs_.value, rg.value, ws.TS[l].data_ptr() if lazy_s else 0,
                                        ((g1_in if have_g1 else ws.ZeroPC).data_ptr()) if lazy else 0))
                 d = _capi.LayerBwdDesc(
                     self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
@@ -1328,7 +1332,7 @@ class FFNOEngine:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
                 two = bool(have_g1 and not self.layer_norm)
                 self._ffs_bwd2(g_ff, g1_in if two else None, g_ff if (two and not lazy) else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
-                self._wg_second = (ws.TS[l], g1_in if two else ws.ZeroPC) if lazy else None
+                self._wg_second = (ws.TS[l] if lazy_s else None, (g1_in if two else ws.ZeroPC) if lazy else None)
             elif self.general_ff:
                 self._ffg_bwd(ws, fp, "backcast", l, ws.S[l], g_ff, ws.DS, int(fp in ff_seen), P, st, rd)
             else:
@@ -1393,7 +1397,7 @@ class FFNOEngine:
                 ws.wg_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
                 ws.wg_sig = sig
             self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial_multi, _p(ws.wg_table), len(sig), P, C, H, nsl,
-                    self._st(), int(lazy), st)
+                    self._st(), 2 if lazy else int(lazy_s), st)
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:
             sig = tuple(ws.red_jobs)
             if sig != ws.red_sig:       # pointers only change when parameters are re-bound or the workspace is rebuilt

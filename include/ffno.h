@@ -499,12 +499,13 @@ typedef struct ffno_ffwg_desc {
     float* partial;          /* nsplit slices */
     const uint32_t* s_amax;
     const uint32_t* g_amax;
-    const void* s2;          /* two_addends != 0: s = s + s2 and g = g + g2 are formed (and rounded to the storage format) while */
-    const void* g2;          /* the rows are staged -- for callers whose chain launches do not write the sums back (s_sum / db_sum
-                              * NULL); every block must give both (a block with one gradient addend: a zero-filled tensor) */
+    const void* s2;          /* two_addends 1: s = s + s2, 2: also g = g + g2 -- formed (and rounded to the storage format) while   */
+    const void* g2;          /* the rows are staged, for callers whose chain launches do not write the sums back (s_sum / db_sum
+                              * NULL); every block must give the addends the mode names (a block with one gradient addend in
+                              * mode 2: a zero-filled tensor) */
 } ffno_ffwg_desc;
 int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit, int storage,
-                                       int two_addends /* C = 64, H = 256 only */, void* stream);
+                                       int two_addends /* 0, 1 (s) or 2 (s and g); 1 / 2: C = 64, H = 256 only */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),

@@ -168,16 +168,17 @@ def test_ffh_wave_tiles_against_shared_tiles(be, P, two):
     g = ga + gb if two else ga
     g_word = amax_word(be, ga, gb) if two else amax_word(be, ga)
     got = {}
+    dsa, dsb, dres, dga, dgb = be.put(sa), be.put(sb), be.put(resid), be.put(ga), be.put(gb)      # (kept alive across the launches)
     for sched in (FFNO_FF_SCHED_ROLE_SPLIT, FFNO_FF_SCHED_WAVE_TILES):
         out, ssum = be.empty((P, C)), be.empty((P, C))
         mask = be.zeros(lib.ffno_ff_mask_words(P, H), np.uint32)
         ow, dw = be.zeros(1, np.uint32), be.zeros(1, np.uint32)
         o = opts(be, s_word, ow, schedule=sched)
-        assert lib.ffno_ffh_fwd2(p(be.put(sa)), p(be.put(sb)) if two else None, p(ssum) if two else None, p(be.put(resid)), p(a1),
+        assert lib.ffno_ffh_fwd2(p(dsa), p(dsb) if two else None, p(ssum) if two else None, p(dres), p(a1),
                                  p(db1_), p(a2), p(db2_), p(out), p(mask), P, C, H, ctypes.byref(o), None) == 0
         gsum, ds = be.empty((P, C)), be.empty((P, C))
         o = opts(be, g_word, dw, schedule=sched)
-        assert lib.ffno_ffh_bwd_data2(p(be.put(ga)), p(be.put(gb)) if two else None, p(gsum) if two else None, p(mask), p(a1b),
+        assert lib.ffno_ffh_bwd_data2(p(dga), p(dgb) if two else None, p(gsum) if two else None, p(mask), p(a1b),
                                       p(a2b), p(ds), P, C, H, ctypes.byref(o), None) == 0
         got[sched] = (be.get(out).copy(), be.get(ssum).copy(), np.asarray(be.get(mask)).copy(), be.get(ds).copy(),
                       be.get(gsum).copy(), word_value(be, ow), word_value(be, dw))
@@ -194,10 +195,11 @@ def test_ffh_wave_tiles_against_shared_tiles(be, P, two):
     assert new[5] == float(np.abs(new[0]).max()) and new[6] == float(np.abs(new[3]).max())
     # a shape without wave tiles, an unknown schedule
     o = opts(be, s_word, None, schedule=FFNO_FF_SCHED_WAVE_TILES)
-    assert lib.ffno_ffh_fwd2(p(be.put(sa)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(be.empty((P, C))), None, P, 64, 128,
+    scratch = be.empty((P, C))
+    assert lib.ffno_ffh_fwd2(p(dsa), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(scratch), None, P, 64, 128,
                              ctypes.byref(o), None) == -2
     o = opts(be, s_word, None, schedule=7)
-    assert lib.ffno_ffh_fwd2(p(be.put(sa)), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(be.empty((P, C))), None, P, C, H,
+    assert lib.ffno_ffh_fwd2(p(dsa), None, None, None, p(a1), p(db1_), p(a2), p(db2_), p(scratch), None, P, C, H,
                              ctypes.byref(o), None) == -1
 
 
@@ -213,7 +215,7 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
     rs = np.random.RandomState(P + nsplit)
     n = 3
     nfl = int(lib.ffno_ff_wgrad_partial_floats(C, H, nsplit))
-    keep, descs, singles, descs2, twos = [], [], [], [], []
+    keep, descs, singles, descs2, twos, presum_g = [], [], [], [], [], []
     for i in range(n):
         s = (rs.standard_normal((P, C)) * 10.0 ** (i - 1)).astype(np.float32)
         g = (rs.standard_normal((P, C)) * 10.0 ** (-3 * i)).astype(np.float32)
@@ -241,6 +243,7 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
         twos.append((one2, multi2))
         descs2.append(FfWgDesc(p(dsa), p(dga), p(a1), p(b1), p(a1b), p(multi2), p(sw), p(gw), p(dsb), p(dgb)))
         keep += [pre_s, pre_g, dsa, dsb, dga, dgb]
+        presum_g.append(pre_g)
     table = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs)), dtype=np.uint8).copy())
     assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, C, H, nsplit, 0, 0, None) == 0
     for one, multi in singles:
@@ -249,9 +252,19 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
         np.testing.assert_array_equal(be.get(multi), a)
     table2 = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs2)), dtype=np.uint8).copy())
     if C == 64:
-        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 1, None) == 0
+        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 2, None) == 0
         for one2, multi2 in twos:
             np.testing.assert_array_equal(be.get(multi2), be.get(one2))
+        # mode 1: only s is a sum -- the same blocks with the pre-summed gradient in the first slot
+        for d, pg in zip(descs2, presum_g):
+            d.g = p(pg)
+        table3 = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs2)), dtype=np.uint8).copy())
+        for one2, multi2 in twos:
+            multi2[...] = 0 if be.kind == "emu" else multi2.zero_()
+        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table3), n, P, C, H, nsplit, 0, 1, None) == 0
+        for one2, multi2 in twos:
+            np.testing.assert_array_equal(be.get(multi2), be.get(one2))
+        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table3), n, P, C, H, nsplit, 0, 3, None) == -1
     else:
         assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 1, None) == -2
     assert lib.ffno_ffh_bwd_weights_partial_multi(None, n, P, C, H, nsplit, 0, 0, None) == -1
