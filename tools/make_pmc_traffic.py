@@ -10,7 +10,9 @@ from rocpd_pmc import per_kernel
 
 # first match wins, so the instantiations of the default arithmetic (fp16x2) come before the generic patterns: bench.py also runs
 # the all-bf16x3 variant, whose kernels are in the same trace
-NAMES = [("ffh_wgrad_m_multi_kernel<64, 256", "ff_bwd_weights_partial"), ("ffh_wgrad_m_multi_kernel<32, 128", "ff_bwd_weights_partial"),
+NAMES = [("ffw_chain_kernel<64, 256, false, ffno::StF32", "ff_fwd"), ("ffw_chain_kernel<64, 256, true, ffno::StF32", "ff_bwd_data"),
+         ("ffh_wgrad_m_multi_kernel<64, 256, 8, ffno::StF32", "ff_bwd_weights_partial"),
+         ("ffh_wgrad_m_multi_kernel<64, 256", "ff_bwd_weights_partial"), ("ffh_wgrad_m_multi_kernel<32, 128", "ff_bwd_weights_partial"),
          ("ffh_wgrad_m_kernel<64, 256", "ff_bwd_weights_partial"), ("spectral_x3_pair_kernel<16, true", "spectral_fused"),
          ("spectral_x3k_pair_kernel<64, true", "spectral_fused"), ("spectral_x3k_pair_kernel<128, true", "spectral_fused"),
          ("spectral_x3c32_pair_kernel<true", "spectral_fused_pair"), ("spectral_x3c32_kernel<true", "spectral_fused_single"),
