@@ -710,9 +710,9 @@ def main():
                 bf16_variant = dict(steps_per_s=round(alt, 3), ms_per_step=round(1e3 / alt, 3),
                                     forward_rel_l2_vs_fp32_storage=float("%.3g" % ferr), kernel_us_replay=rep_us,
                                     gain_over_fp32_storage=round(alt / steps_per_s - 1.0, 3),
-                                    verdict="below 10 % on every benchmarked shape (round 4: +5 % here, +9 / +5 % at 256 x 256 with 32 / "
-                                            "64 modes, +2 % at 64^3): the launches are bound by their write-back pattern and their "
-                                            "on-chip exchange, not by activation bytes -- kept as a tested storage option, no longer tuned",
+                                    verdict="below 10 % on every benchmarked shape (round 4: +7 % here, +8 / +7 % at 256 x 256 with 32 / "
+                                            "64 modes, +6 % at 64^3): the launches are bound by how their tiles travel (write passes, "
+                                            "one-round launches), not by activation bytes -- kept as a tested storage option, no longer tuned",
                                     what="activation tensors (layer inputs / outputs, branch outputs, saved feed-forward inputs and "
                                          "their gradients) stored as bf16; weights, spectra, accumulation, optimiser state fp32; "
                                          "each twin == bf16(fp32 kernel) bit for bit (tests/test_storage_bf16.py)")
