@@ -40,6 +40,33 @@ def test_train_steps_match_reference_golden(host_device):
                p.data_ptr() < tr.pflat.data_ptr() + tr.pflat.numel() * 4 for p in blk.parameters())
 
 
+@pytest.mark.parametrize("deferred,lazy,sched,layer_calls", [(False, "0", 0, True), (True, "0", 3, True), (True, "s", 2, True),
+                                                             (True, "sg", 2, True), (True, "sg", 3, False), (True, "s", 0, False)])
+def test_train_steps_match_golden_under_every_backward_schedule(host_device, deferred, lazy, sched, layer_calls):
+    """The variants of the backward pass that round 4 added -- feed-forward weight gradients per layer or of ALL layers in one launch
+    after the loop (engine.ff_wgrad_deferred), the chain launches writing their input sums or leaving the forward's ("s") / both
+    ("sg") to that launch (engine.ff_lazy_sums), shared-tile or wave-tile chain kernels (engine.ff_schedule), one C call per layer
+    or one per kernel -- all reproduce the reference's golden training steps (losses 2e-5, final weights 2e-4)."""
+    g = gu.load_golden("train_c64_2l")
+    kw = gu.golden_kwargs(g)
+    B, M, N, seed, steps = [int(v) for v in g["meta"]]
+    blk, tr = make_trainer(kw, seed, host_device)
+    eng = tr.engine
+    eng.ff_wgrad_deferred, eng.ff_lazy_sums, eng.ff_schedule, eng.use_layer_calls = deferred, lazy, sched, layer_calls
+    for s in range(steps):
+        x_np, t_np = gu.make_block_io(kw, seed + 1 + s, B, M, N)
+        loss = tr.train_step(torch.from_numpy(x_np).to(host_device), torch.from_numpy(t_np).to(host_device))
+        assert abs(loss.item() - float(g["losses"][s])) < 2e-5 * max(1.0, float(g["losses"][s]))
+    ws = eng._ws
+    assert bool(getattr(ws, "defer_wgrad", False)) == deferred and (getattr(ws, "lazy_sums", "") or "0") == (lazy if deferred else "0")
+    assert bool(getattr(eng, "_saved_lazy", False)) == (deferred and lazy != "0")
+    assert (ws.wg_jobs is not None and len(ws.wg_jobs) == kw["n_layers"]) == deferred
+    named = dict(blk.named_parameters())
+    for n in [k for k in gu.packed_names(g) if k.startswith("final.")]:
+        err = gu.compare_packed(g, n, named[n[6:]].detach().cpu().numpy(), 1e-5)
+        assert err < 2e-4, (n, err)
+
+
 def test_load_state_dict_on_a_trainer_bound_module_is_seen(host_device):
     """FFNOTrainer re-points the module's parameters at its flat buffer (``p.data = view``), which keeps every
     Parameter's own version counter -- ``load_state_dict`` / ``p.copy_()`` bump that counter only, and an engine bound to the
