@@ -27,6 +27,8 @@
 #include "ffno_device.h"
 #include "ffno.h"
 
+#include <string.h>
+
 namespace ffno {
 
 // magnitude bound (2^kFfRangeTarget) the split-fp16 kernels bring their staged rows to: 2^12 of head-room up to the half
@@ -1526,10 +1528,19 @@ struct FfWgDesc {
     const void* g2;      //  last layer's -- passes a zero-filled tensor)
 };
 
+// The table travels BY VALUE in the kernel-argument segment (up to FFWG_MAX_BLOCKS blocks per launch): pointers inside a by-value
+// argument are known to be global, pointers loaded from a device-resident table are generic to the compiler -- every access
+// through them becomes a flat_load / flat_store, which also counts on the LDS counter, so each wait for an LDS read waited for the
+// wave's outstanding global prefetch as well (the first version of this launch did that: 115-145 flat accesses per kernel).
+constexpr int FFWG_MAX_BLOCKS = 32;
+struct FfWgTable {
+    FfWgDesc d[FFWG_MAX_BLOCKS];
+};
+
 template <int C, int H, int NWV, class ST = StF32, int TWO = 0>
-__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_multi_kernel(const FfWgDesc* __restrict__ descs, int P, int nsplit) {
+__global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_multi_kernel(const FfWgTable tab, int P, int nsplit) {
     const int layer = (int)blockIdx.x / nsplit;
-    const FfWgDesc d = descs[layer];
+    const FfWgDesc& d = tab.d[layer];
     typedef const typename ST::T* cp;
     ffh_wgrad_m_body<C, H, NWV, ST, TWO>((cp)d.s, (cp)d.g, d.pk1, d.b1, d.pk2t, d.partial, P, d.s_amax, d.g_amax,
                                          (int)blockIdx.x - layer * nsplit, nsplit, (cp)d.s2, (cp)d.g2);
@@ -1892,30 +1903,41 @@ extern "C" int ffno_ffh_bwd_weights_partial(const float* s, const float* db, con
     return fx_bwd_weights_partial<SplitHf2>(s, db, pk1, b1, pk1b, partial, P, C, H, nsplit, s_amax, db_amax, storage, stream);
 }
 
-extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit,
+extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs, int n, int P, int C, int H, int nsplit,
                                                   int storage, int two_addends, void* stream) {
     static_assert(sizeof(ffno_ffwg_desc) == sizeof(FfWgDesc), "descriptor layout");
-    if (!descs_dev || n <= 0 || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
+    if (!descs || n <= 0 || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     if (storage != FFNO_STORE_F32 && storage != FFNO_STORE_BF16) return FFNO_EINVAL;
-    if (!((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
-    const FfWgDesc* d = reinterpret_cast<const FfWgDesc*>(descs_dev);
-    const dim3 grid((unsigned)n * (unsigned)nsplit);
-    const bool b16 = storage == FFNO_STORE_BF16;
     if (two_addends < 0 || two_addends > 2) return FFNO_EINVAL;
-    if (two_addends) {      // (the wave-tile chain kernels' shape: they are what leaves the sums unwritten)
-        if (C != 64) return FFNO_EUNSUPPORTED;
-        if (two_addends == 1 && b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16, 1>), grid, dim3(512), 0, st, d, P, nsplit);
-        else if (two_addends == 1) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StF32, 1>), grid, dim3(512), 0, st, d, P, nsplit);
-        else if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16, 2>), grid, dim3(512), 0, st, d, P, nsplit);
-        else FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StF32, 2>), grid, dim3(512), 0, st, d, P, nsplit);
-        return ffx_launch_status();
+    if (!((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
+    if (two_addends && C != 64) return FFNO_EUNSUPPORTED;      // (the wave-tile chain kernels' shape: they leave the sums unwritten)
+    for (int i = 0; i < n; ++i) {
+        const ffno_ffwg_desc& d = descs[i];
+        if (!d.s || !d.g || !d.pk1 || !d.b1 || !d.pk1b || !d.partial || !d.s_amax || !d.g_amax) return FFNO_EINVAL;
+        if ((two_addends >= 1 && !d.s2) || (two_addends == 2 && !d.g2)) return FFNO_EINVAL;
     }
-    if (C == 64 && b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8, StBf16>), grid, dim3(512), 0, st, d, P, nsplit);
-    else if (C == 64) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<64, 256, 8>), grid, dim3(512), 0, st, d, P, nsplit);
-    else if (b16) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<32, 128, 4, StBf16>), grid, dim3(256), 0, st, d, P, nsplit);
-    else FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<32, 128, 4>), grid, dim3(256), 0, st, d, P, nsplit);
-    return ffx_launch_status();
+    hipStream_t st = (hipStream_t)stream;
+    const bool b16 = storage == FFNO_STORE_BF16;
+    // the table is copied into the kernel arguments (host memory, read at enqueue): FFWG_MAX_BLOCKS blocks per launch
+    for (int i0 = 0; i0 < n; i0 += FFWG_MAX_BLOCKS) {
+        const int nb = n - i0 < FFWG_MAX_BLOCKS ? n - i0 : FFWG_MAX_BLOCKS;
+        FfWgTable tab;
+        memcpy(tab.d, descs + i0, sizeof(FfWgDesc) * nb);
+        for (int i = nb; i < FFWG_MAX_BLOCKS; ++i) tab.d[i] = tab.d[0];
+        const dim3 grid((unsigned)nb * (unsigned)nsplit);
+#define WG_LAUNCH(CC, HH, NW, STT, TW) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<CC, HH, NW, STT, TW>), grid, dim3(NW * 64), 0, st, tab, P, nsplit)
+        if (C == 64) {
+            if (two_addends == 0) { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 0); else WG_LAUNCH(64, 256, 8, StF32, 0); }
+            else if (two_addends == 1) { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 1); else WG_LAUNCH(64, 256, 8, StF32, 1); }
+            else { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 2); else WG_LAUNCH(64, 256, 8, StF32, 2); }
+        } else {
+            if (b16) WG_LAUNCH(32, 128, 4, StBf16, 0); else WG_LAUNCH(32, 128, 4, StF32, 0);
+        }
+#undef WG_LAUNCH
+        const int rc = ffx_launch_status();
+        if (rc) return rc;
+    }
+    return FFNO_OK;
 }
 
 extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,

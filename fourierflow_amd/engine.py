@@ -1392,11 +1392,10 @@ class FFNOEngine:
         if ws.wg_jobs:
             nsl = ws.nsplit_ffm
             sig = tuple(ws.wg_jobs)
-            if sig != ws.wg_sig:
-                arr = (_capi.FfWgDesc * len(sig))(*[_capi.FfWgDesc(*j) for j in sig])
-                ws.wg_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+            if sig != ws.wg_sig:      # (a HOST table: the library copies it into the kernel arguments at enqueue)
+                ws.wg_table = (_capi.FfWgDesc * len(sig))(*[_capi.FfWgDesc(*j) for j in sig])
                 ws.wg_sig = sig
-            self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial_multi, _p(ws.wg_table), len(sig), P, C, H, nsl,
+            self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial_multi, ws.wg_table, len(sig), P, C, H, nsl,
                     self._st(), 2 if lazy else int(lazy_s), st)
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:
             sig = tuple(ws.red_jobs)

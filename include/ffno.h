@@ -489,7 +489,9 @@ int ffno_ffh_bwd_weights_partial(const float* s, const float* db, const void* pk
  * descs[i].partial; the grid is n x nsplit workgroups -- 3 x CUs / n slices per block keeps three full rounds of workgroups and
  * makes each one walk many tiles per slice written (the per-layer launch pays 7 us of fragment loads + slice burst and its
  * reduce 7 us per layer at the headline shape, MI355X round 4).  Both range words of every block are required; width 64 / 256
- * and 32 / 128 (the single-accumulator kernel's shapes); `descs_dev` is a DEVICE array. */
+ * and 32 / 128 (the single-accumulator kernel's shapes).  `descs` is a HOST array: it is copied into the kernel arguments at
+ * enqueue (32 blocks per launch) -- pointers that arrive as arguments are global memory to the compiler, pointers loaded from a
+ * device table are not, and the flat accesses they cause tie a wave's LDS waits to its global prefetch. */
 typedef struct ffno_ffwg_desc {
     const void* s;           /* feed-forward input of the block  [P, C], storage format of the call */
     const void* g;           /* gradient w.r.t. its output       [P, C] */
@@ -504,7 +506,7 @@ typedef struct ffno_ffwg_desc {
                               * NULL); every block must give the addends the mode names (a block with one gradient addend in
                               * mode 2: a zero-filled tensor) */
 } ffno_ffwg_desc;
-int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs_dev, int n, int P, int C, int H, int nsplit, int storage,
+int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs, int n, int P, int C, int H, int nsplit, int storage,
                                        int two_addends /* 0, 1 (s) or 2 (s and g); 1 / 2: C = 64, H = 256 only */, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

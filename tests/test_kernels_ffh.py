@@ -244,31 +244,31 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
         descs2.append(FfWgDesc(p(dsa), p(dga), p(a1), p(b1), p(a1b), p(multi2), p(sw), p(gw), p(dsb), p(dgb)))
         keep += [pre_s, pre_g, dsa, dsb, dga, dgb]
         presum_g.append(pre_g)
-    table = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs)), dtype=np.uint8).copy())
-    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, C, H, nsplit, 0, 0, None) == 0
+    table = (FfWgDesc * n)(*descs)          # (a host array: copied into the kernel arguments at enqueue)
+    assert lib.ffno_ffh_bwd_weights_partial_multi(table, n, P, C, H, nsplit, 0, 0, None) == 0
     for one, multi in singles:
         a = be.get(one)
         assert np.all(np.isfinite(a)) and np.abs(a).max() > 0
         np.testing.assert_array_equal(be.get(multi), a)
-    table2 = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs2)), dtype=np.uint8).copy())
+    table2 = (FfWgDesc * n)(*descs2)
     if C == 64:
-        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 2, None) == 0
+        assert lib.ffno_ffh_bwd_weights_partial_multi(table2, n, P, C, H, nsplit, 0, 2, None) == 0
         for one2, multi2 in twos:
             np.testing.assert_array_equal(be.get(multi2), be.get(one2))
         # mode 1: only s is a sum -- the same blocks with the pre-summed gradient in the first slot
         for d, pg in zip(descs2, presum_g):
             d.g = p(pg)
-        table3 = be.put(np.frombuffer(bytes((FfWgDesc * n)(*descs2)), dtype=np.uint8).copy())
+        table3 = (FfWgDesc * n)(*descs2)
         for one2, multi2 in twos:
             multi2[...] = 0 if be.kind == "emu" else multi2.zero_()
-        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table3), n, P, C, H, nsplit, 0, 1, None) == 0
+        assert lib.ffno_ffh_bwd_weights_partial_multi(table3, n, P, C, H, nsplit, 0, 1, None) == 0
         for one2, multi2 in twos:
             np.testing.assert_array_equal(be.get(multi2), be.get(one2))
-        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table3), n, P, C, H, nsplit, 0, 3, None) == -1
+        assert lib.ffno_ffh_bwd_weights_partial_multi(table3, n, P, C, H, nsplit, 0, 3, None) == -1
     else:
-        assert lib.ffno_ffh_bwd_weights_partial_multi(p(table2), n, P, C, H, nsplit, 0, 1, None) == -2
+        assert lib.ffno_ffh_bwd_weights_partial_multi(table2, n, P, C, H, nsplit, 0, 1, None) == -2
     assert lib.ffno_ffh_bwd_weights_partial_multi(None, n, P, C, H, nsplit, 0, 0, None) == -1
-    assert lib.ffno_ffh_bwd_weights_partial_multi(p(table), n, P, 64, 128, nsplit, 0, 0, None) == -2
+    assert lib.ffno_ffh_bwd_weights_partial_multi(table, n, P, 64, 128, nsplit, 0, 0, None) == -2
 
 
 @pytest.mark.parametrize("act,grad", [(1e5, 1e4), (1e6, 1e-12), (3e-9, 7e7), (1.0, 1.0)])

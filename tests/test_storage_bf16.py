@@ -56,8 +56,10 @@ def test_rounding_helper_is_round_to_nearest_even():
 
 
 # ---- feed-forward kernels ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("P,C,H", [(70, 64, 256), (200, 64, 256), (90, 32, 128)])
-def test_ffh_twins_are_the_rounded_fp32_kernels(be, P, C, H):
+@pytest.mark.parametrize("P,C,H,sched", [(70, 64, 256, 0), (200, 64, 256, 0), (90, 32, 128, 0), (70, 64, 256, 2), (32 * 9, 64, 256, 2)])
+def test_ffh_twins_are_the_rounded_fp32_kernels(be, P, C, H, sched):
+    """(sched 2: the wave-tile chain kernels, FFNO_FF_SCHED_WAVE_TILES -- what a large launch at 64 / 256 runs by default -- and,
+    for the weight gradients, the all-layers launch forming the input sum from its two bf16 addends.)"""
     lib, p = be.lib, be.ptr
     rs = np.random.RandomState(P)
     sa_h, sa = bf16_data(rs, (P, C))
@@ -75,13 +77,13 @@ def test_ffh_twins_are_the_rounded_fp32_kernels(be, P, C, H):
     s_word = amax_word(be, sa, sb)          # the same range word for both runs: the same power-of-two scale
     # fp32 kernel on the widened operands
     out32, mask32, w32 = be.empty((P, C)), be.zeros(nmask, np.uint32), be.zeros(1, np.uint32)
-    o = FfOpts(p(s_word), p(w32), 0, 0, 0)
+    o = FfOpts(p(s_word), p(w32), 0, sched, 0)
     assert lib.ffno_ffh_fwd2(p(be.put(s)), None, None, p(be.put(resid)), p(a1), p(db1_), p(a2), p(db2_), p(out32), p(mask32),
                              P, C, H, ctypes.byref(o), None) == 0
     # the twin: two bf16 addends, bf16 residual, bf16 output and stored sum
     out16, sum16 = put16(be, np.zeros((P, C), np.uint16)), put16(be, np.zeros((P, C), np.uint16))
     mask16, w16 = be.zeros(nmask, np.uint32), be.zeros(1, np.uint32)
-    o = FfOpts(p(s_word), p(w16), 0, 0, FFNO_STORE_BF16)
+    o = FfOpts(p(s_word), p(w16), 0, sched, FFNO_STORE_BF16)
     assert lib.ffno_ffh_fwd2(p(put16(be, sa_h)), p(put16(be, sb_h)), p(sum16), p(put16(be, re_h)), p(a1), p(db1_), p(a2), p(db2_),
                              p(out16), p(mask16), P, C, H, ctypes.byref(o), None) == 0
     np.testing.assert_array_equal(get16(be, sum16), s_h)
@@ -97,10 +99,10 @@ def test_ffh_twins_are_the_rounded_fp32_kernels(be, P, C, H):
     g = from_bf16(g_h)
     g_word = amax_word(be, ga, gb)
     ds32 = be.empty((P, C))
-    o = FfOpts(p(g_word), None, 0, 0, 0)
+    o = FfOpts(p(g_word), None, 0, sched, 0)
     assert lib.ffno_ffh_bwd_data2(p(be.put(g)), None, None, p(mask32), p(a1b), p(a2b), p(ds32), P, C, H, ctypes.byref(o), None) == 0
     ds16, gsum16 = put16(be, np.zeros((P, C), np.uint16)), put16(be, np.zeros((P, C), np.uint16))
-    o = FfOpts(p(g_word), None, 0, 0, FFNO_STORE_BF16)
+    o = FfOpts(p(g_word), None, 0, sched, FFNO_STORE_BF16)
     assert lib.ffno_ffh_bwd_data2(p(put16(be, ga_h)), p(put16(be, gb_h)), p(gsum16), p(mask16), p(a1b), p(a2b), p(ds16), P, C, H,
                                   ctypes.byref(o), None) == 0
     np.testing.assert_array_equal(get16(be, gsum16), g_h)
@@ -115,6 +117,14 @@ def test_ffh_twins_are_the_rounded_fp32_kernels(be, P, C, H):
     assert lib.ffno_ffh_bwd_weights_partial(p(sum16), p(gsum16), p(a1), p(db1_), p(a1b), p(part16), P, C, H, nsplit,
                                             p(s_word), p(g_word), FFNO_STORE_BF16, None) == 0
     np.testing.assert_array_equal(be.get(part16), be.get(part32))
+    if sched == 2:      # ... and from the two bf16 addends of s (two_addends = 1) / of s and g (2) in the all-layers launch
+        from fourierflow_amd._capi import FfWgDesc
+        d_sa, d_sb, d_ga, d_gb = put16(be, sa_h), put16(be, sb_h), put16(be, ga_h), put16(be, gb_h)
+        for mode, gptr, g2ptr in ((1, gsum16, None), (2, d_ga, d_gb)):
+            partm = be.zeros(n)
+            desc = (FfWgDesc * 1)(FfWgDesc(p(d_sa), p(gptr), p(a1), p(db1_), p(a1b), p(partm), p(s_word), p(g_word), p(d_sb), p(g2ptr)))
+            assert lib.ffno_ffh_bwd_weights_partial_multi(desc, 1, P, C, H, nsplit, FFNO_STORE_BF16, mode, None) == 0
+            np.testing.assert_array_equal(be.get(partm), be.get(part32))
 
 
 def test_twins_refuse_what_they_do_not_cover(be):
