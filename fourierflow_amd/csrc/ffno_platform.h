@@ -150,10 +150,6 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-// s_sleep: the wave gives up its issue slots for about n x 64 cycles (n <= 127)
-template <int N>
-__device__ __forceinline__ void sleep_cycles_64_t() { __builtin_amdgcn_s_sleep(N); }
-#define sleep_cycles_64(n) sleep_cycles_64_t<(n)>()
 }  // namespace plat
 
 // dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel

@@ -404,9 +404,6 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_chain_kernel(const type
 //   of the weight-gradient kernel's recomputation (same ReLU decisions).  GEMM2: ONE main + correction pair per output tile
 //   over all 16 k-steps, folded once (ffx_chain_kernel folds per chunk and adds the eight partial tiles: same products, other
 //   rounding of the sum -- results agree to fp32 rounding, not bit for bit; bf16 twin == bf16(this kernel at fp32 storage)).
-#ifndef FFW_STAGGER
-#define FFW_STAGGER 48      // x 64 cycles
-#endif
 template <int C, int H, bool BWD, class ST = StF32>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(const typename ST::T* __restrict__ in,
                                                                               const typename ST::T* __restrict__ in2,
@@ -457,7 +454,6 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(c
     float* stg_o = stg + j * SROW + 8 * half;               // operand map
     const uint16_t* mrd = reinterpret_cast<const uint16_t*>(mask);
     uint16_t* mwr = reinterpret_cast<uint16_t*>(mask);
-    bool first = true;
     FFNO_NOUNROLL
     for (int tile = (int)blockIdx.x * NWV + wave; tile < ntiles; tile += (int)gridDim.x * NWV) {
         // rows of this lane in the memory map; rows past the end re-read the last row and are zeroed / not stored
@@ -502,10 +498,6 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void ffw_chain_kernel(c
                 mw[q] = (uint32_t)mrd[((long)tile * NCH + 2 * q) * 64 + lane] |
                         ((uint32_t)mrd[((long)tile * NCH + 2 * q + 1) * 64 + lane] << 16);
         }
-        // the two waves of a SIMD (w and w + 4) start in phase and would stay so, both waiting for their rows and then both
-        // computing: the second one sleeps through part of its first wait so that one computes while the other loads
-        if (first && wave >= NWV / 2) plat::sleep_cycles_64(FFW_STAGGER);
-        first = false;
         // the tile's rows as B operands: k-step st <-> channels 16 st + 8 half + (0..7) of pixel j
         Hf2 b[KS];
         FFNO_UNROLL

@@ -55,7 +55,11 @@ class Backend:
         import torch
         if a.dtype == np.uint32:
             a = a.view(np.int32)
-        return torch.from_numpy(a.copy()).to(self.device)
+        t = torch.from_numpy(a.copy()).to(self.device)
+        # every device operand lives as long as the backend object (one test): a call like  f(p(be.put(a)), p(be.put(b)))  hands
+        # raw pointers to an asynchronous launch, and a temporary freed between the two puts would give its block to the second
+        self.__dict__.setdefault("_keep", []).append(t)
+        return t
 
     def empty(self, shape, dtype=np.float32):
         a = np.empty(shape, dtype)

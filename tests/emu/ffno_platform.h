@@ -68,9 +68,6 @@ static inline int cu_count() { return 256; }      // (the emulator plays an MI35
 
 // rendezvous of the 64 fibres of a wave (an exchange through LDS between the lanes of one wave needs every lane's write done)
 __device__ __forceinline__ void wave_sync() { (void)__shfl(0.f, 0); }
-template <int N>
-__device__ __forceinline__ void sleep_cycles_64_t() {}
-#define sleep_cycles_64(n) sleep_cycles_64_t<(n)>()
 }  // namespace plat
 
 template <class K>
