@@ -47,6 +47,8 @@ def test_train_steps_match_golden_under_every_backward_schedule(host_device, def
     after the loop (engine.ff_wgrad_deferred), the chain launches writing their input sums or leaving the forward's ("s") / both
     ("sg") to that launch (engine.ff_lazy_sums), shared-tile or wave-tile chain kernels (engine.ff_schedule), one C call per layer
     or one per kernel -- all reproduce the reference's golden training steps (losses 2e-5, final weights 2e-4)."""
+    if host_device == "cpu" and (deferred, lazy, sched, layer_calls) in ((True, "0", 3, True), (True, "sg", 3, False)):
+        pytest.skip("emulator time budget (the GPU run covers all six)")
     g = gu.load_golden("train_c64_2l")
     kw = gu.golden_kwargs(g)
     B, M, N, seed, steps = [int(v) for v in g["meta"]]
