@@ -9,6 +9,12 @@
 // runs the launch in 830-900 us, so the headroom is real; what this version lacks is the registers: the W2 fragments (32) fit
 // in LDS now that the staging area is half as large (45 + 64 KB), and the selector products of channel tile mt + 1 belong under
 // the outer products of tile mt.
+// Second version, measured the same evening (not kept as source: this file + the three changes named here reproduce it): W2
+// fragments in LDS (read per k-step of the dh product chain), the fold of h BEFORE the selector products, both channel tiles of g
+// (then of s) transposed right behind the h (dh) product chain so that they run under its vector epilogue, a scheduling fence
+// after each half transposition: 23-27 registers still spilled (7 scratch accesses per tile), the prefetch sits at 16 % of the
+// loop body instead of 65-80 % -- 1720 us.  Better than the first version, still behind the staged kernel (1413 us): the 16 extra
+// MFMAs + 32 v_cvt_pk per wave and tile and the four extra fragment reads cost more than the second staging pass they replace.
 // ---- weight gradients, channel-major operands from the matrix cores ("t") ----------------------------------------------------
 // Same operator, slices and products as ffh_wgrad_m_body.  That kernel stages every tile TWICE: pixel-major (the operand of the
 // hidden-activation products) and channel-major (the operand of the two outer-product GEMMs) -- a second set of global loads,
