@@ -409,9 +409,7 @@ def main():
                     help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
     ap.add_argument("--staged", action="store_true", help="spectral branches through the three stage kernels (HBM spectra) instead of the fused tile")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
-    ap.add_argument("--x3-interleave", type=int, default=3, help="bit 0: even/odd workgroup->branch map; bit 1: image-local (XCD-aware) map where the shapes allow; bits 8..: start skew / 256 cycles")
-    ap.add_argument("--overlap", action="store_true", help="backward: feed-forward weight-gradient kernels on a side stream next to the "
-                                                          "spectral adjoint / the next layer's data gradient (engine.overlap)")
+    ap.add_argument("--x3-interleave", type=int, default=3, help="bit 0: even/odd workgroup->branch map; bit 1: image-local (XCD-aware) map where the shapes allow")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()
@@ -473,7 +471,6 @@ def main():
     if args.ff_split:
         trainer.engine.ff_split = args.ff_split
     trainer.engine.x3_interleave = args.x3_interleave
-    trainer.engine.overlap = bool(args.overlap)
     trainer.engine.storage = args.storage
     B, G = args.batch, args.grid
     gen = torch.Generator().manual_seed(1000 + rank)  # rank r draws its own shard of the global batch
@@ -771,6 +768,8 @@ def main():
             dist_info = dict(world_size=torch.distributed.get_world_size(), world_size_counted_by_all_reduce=rccl_world,
                              backend=torch.distributed.get_backend(), rccl_version=ver, hip=torch.version.hip,
                              launch="one process per GPU (torch.distributed.run; `python bench.py --gpus N` spawns them itself)")
+            if dist_info["backend"] == "nccl" and not ver:
+                raise SystemExit("backend nccl (= RCCL on ROCm) but torch reports no RCCL version: not an RCCL run, no line printed")
         out = {
             "metric": ("training-steps/sec (whole node), FNOPlus2DBlock %dL %dx%d modes %d" % (args.layers, G, G, K) if args.plus else
                        "training-steps/sec (whole node), F-FNO 24L 64x64 torus (torus_li/markov/24_layers)"

@@ -9,7 +9,7 @@ import ctypes as C
 
 # generation of include/ffno.h these signatures and struct mirrors belong to (FFNO_ABI_VERSION there; _lib.check_abi compares
 # it with what the loaded library reports before anything is called)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 P = C.c_void_p
 I = C.c_int
@@ -48,7 +48,8 @@ class LayerFwdDesc(C.Structure):
     """Mirror of ``ffno_layer_fwd_desc`` (include/ffno.h)."""
     _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
                 ("pk1", P), ("b1", P), ("pk2", P), ("b2", P), ("s_sum", P), ("resid", P), ("out", P), ("mask", P),
-                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("ff_kernel", C.c_int32), ("out_amax", P)]
+                ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32), ("ff_kernel", C.c_int32),
+                ("ff_schedule", C.c_int32), ("ff_max_workgroups", C.c_int32), ("pad0_", C.c_int32), ("pad1_", C.c_int32), ("out_amax", P)]
 
 
 class LayerBwdDesc(C.Structure):
@@ -56,7 +57,7 @@ class LayerBwdDesc(C.Structure):
     _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("branch_kernel", C.c_int32), ("interleave", C.c_int32),
                 ("g", P), ("g2", P), ("g_sum", P), ("mask", P), ("pk1b", P), ("pk2b", P), ("ds", P), ("s", P), ("pk1", P),
                 ("b1", P), ("partial", P), ("nsplit", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
-                ("ff_kernel", C.c_int32), ("pad_", C.c_int32), ("g_amax", P), ("s_amax", P), ("ds_amax", P)]
+                ("ff_kernel", C.c_int32), ("ff_schedule", C.c_int32), ("ff_max_workgroups", C.c_int32), ("pad_", C.c_int32), ("g_amax", P), ("s_amax", P), ("ds_amax", P)]
 
 
 class FxRedDesc(C.Structure):

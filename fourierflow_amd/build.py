@@ -77,15 +77,37 @@ def build(force: bool = False, verbose: bool = True, extra_flags=()) -> str:
             if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
                 return LIB
             tag = f".tmp{os.getpid()}"
-            objs = []
-            for src in source_files():
+            # objects are rebuilt only when their own source, a header or the flags changed (per-object stamps), and the
+            # translation units compile side by side: a kernel edit costs one file's compile time, not eleven
+            from concurrent.futures import ThreadPoolExecutor
+            hdr = hashlib.sha256()
+            for p in sorted([os.path.join(CSRC, x) for x in os.listdir(CSRC) if x.endswith(".h")] + [os.path.join(ROOT, "include", "ffno.h")]):
+                with open(p, "rb") as f:
+                    hdr.update(f.read())
+            hdr.update(repr(tuple(extra_flags)).encode())
+
+            def compile_one(src):
                 obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
+                with open(src, "rb") as f:
+                    want = hashlib.sha256(hdr.digest() + f.read()).hexdigest()
+                try:
+                    if not force and os.path.exists(obj) and open(obj + ".stamp").read() == want:
+                        return obj
+                except OSError:
+                    pass
                 cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src,
                        "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", obj, "-Wno-unused-result", *extra_flags]
                 if verbose:
                     print("[ffno build]", " ".join(cmd), flush=True)
+                if os.path.exists(obj + ".stamp"):
+                    os.remove(obj + ".stamp")
                 subprocess.check_call(cmd)
-                objs.append(obj)
+                with open(obj + ".stamp", "w") as f:
+                    f.write(want)
+                return obj
+
+            with ThreadPoolExecutor(max_workers=max(1, min(len(source_files()), (os.cpu_count() or 4)))) as ex:
+                objs = list(ex.map(compile_one, source_files()))
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB + tag, *objs]
             if verbose:
                 print("[ffno build]", " ".join(cmd), flush=True)

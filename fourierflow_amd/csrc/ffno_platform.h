@@ -152,9 +152,10 @@ __device__ __forceinline__ void wave_sync() {
 }
 }  // namespace plat
 
-// dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel
-// (once per kernel and size: the runtime call costs tens of microseconds of host time, more than the launch it precedes -- a
-//  per-launch call makes a stream of 20-us kernels host-bound.  One process drives one device)
+// dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel AND device
+// (remembered per (device, kernel, size): the runtime call costs tens of microseconds of host time, more than the launch it
+//  precedes -- a per-launch call makes a stream of 20-us kernels host-bound.  A process that drives a second device gets its own
+//  slots there: ADVICE r04.)
 template <class K>
 static inline int allow_dynamic_lds(K kernel, size_t bytes) {
     if (bytes <= 48 * 1024) return 0;
@@ -162,10 +163,14 @@ static inline int allow_dynamic_lds(K kernel, size_t bytes) {
         std::atomic<const void*> fn{nullptr};
         std::atomic<size_t> bytes{0};
     };
-    static Slot slots[64];
+    constexpr int kDevs = 16, kSlots = 64;
+    static Slot slots[kDevs][kSlots];
+    int dev = 0;
     const void* p = (const void*)kernel;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs)      // unknown device: no cache, always ask the runtime
+        return (int)hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     Slot* mine = nullptr;
-    for (Slot& s : slots) {
+    for (Slot& s : slots[dev]) {
         const void* f = s.fn.load(std::memory_order_acquire);
         if (f == p) {
             if (s.bytes.load(std::memory_order_acquire) >= bytes) return 0;

@@ -21,9 +21,10 @@
 
 namespace ffno {
 
-// keep(seed, idx): the dropout mask bit of element idx: fmix32(idx ^ fmix32(seed)) (the 32-bit murmur3 finaliser, a bijection;
-// uniform to ~2^-32).  The seed goes through the finaliser BEFORE it meets the index: with `idx * G + seed` the masks of two
-// sites were one bit sequence shifted by (seed difference) / G mod 2^32 elements -- shifted copies, not independent draws.
+// keep(seed, idx): the dropout mask bit of element idx: fmix32(fmix32(idx + k1) ^ k2) with k1 = fmix32(seed), k2 = fmix32(~seed)
+// (fmix32: the 32-bit murmur3 finaliser, a bijection; uniform to ~2^-32).  The seed enters twice, on either side of a
+// non-linear round: `idx * G + seed` made the masks of two sites shifted copies of one bit sequence, and a single
+// `fmix32(idx ^ fmix32(seed))` made them XOR-permuted copies (mask2[i] = mask1[i ^ d]: ADVICE r04) -- neither is an independent draw.
 __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -33,7 +34,7 @@ __host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 __host__ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint32_t idx, uint32_t thr) {
-    return fmix32(idx ^ fmix32(seed)) >= thr;
+    return fmix32(fmix32(idx + fmix32(seed)) ^ fmix32(~seed)) >= thr;
 }
 
 struct GlinDrop {

@@ -22,7 +22,7 @@ extern "C" int ffno_layer_fwd(const ffno_layer_fwd_desc* d, void* stream) {
     if (rc) return rc;
     // the feed-forward reads the word both branches folded their output maxima into
     // (the storage format of the layer's activation tensors is the one its branches name)
-    const ffno_ff_opts o = {d->a.out_amax, d->out_amax, 0, 0, d->a.storage};
+    const ffno_ff_opts o = {d->a.out_amax, d->out_amax, d->ff_max_workgroups, d->ff_schedule, d->a.storage};
     if (d->ff_kernel == FFNO_FF_FP16X2)
         return ffno_ffh_fwd2(d->a.out, d->b.out, d->s_sum, d->resid, d->pk1, d->b1, d->pk2, d->b2, d->out, d->mask, d->P,
                              d->C, d->H, &o, stream);
@@ -36,7 +36,7 @@ extern "C" int ffno_layer_bwd(const ffno_layer_bwd_desc* d, void* stream) {
     if (d->ff_kernel != FFNO_FF_BF16X3 && d->ff_kernel != FFNO_FF_FP16X2) return FFNO_EINVAL;
     const bool h2 = d->ff_kernel == FFNO_FF_FP16X2;
     float* gsum = d->g2 ? d->g_sum : nullptr;
-    const ffno_ff_opts o = {d->g_amax, d->ds_amax, 0, 0, d->a.storage};
+    const ffno_ff_opts o = {d->g_amax, d->ds_amax, d->ff_max_workgroups, d->ff_schedule, d->a.storage};
     if (d->a.storage != FFNO_STORE_F32 && !h2) return FFNO_EUNSUPPORTED;
     int rc = h2 ? ffno_ffh_bwd_data2(d->g, d->g2, gsum, d->mask, d->pk1b, d->pk2b, d->ds, d->P, d->C, d->H, &o, stream)
                 : ffno_ffx_bwd_data2(d->g, d->g2, gsum, d->mask, d->pk1b, d->pk2b, d->ds, d->P, d->C, d->H, &o, stream);

@@ -252,9 +252,6 @@ class FFNOEngine:
         # three; per-kernel timing (a timer attached) needs the individual calls
         self.use_layer_calls = True
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
-        # backward: FF weight-gradient kernels on a side stream next to the spectral adjoint.  Measured on MI355X
-        # (profiles/r01_overlap_trace.md): co-running slows both kernels 2-4x (net -5 %), so it is OFF by default.
-        self.overlap = False
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
         # fp16x2 packs: max |W| of what goes into them is folded at every n-th rebuild of the derived operands (0 = never) and
         # looked at one rebuild later -- with 1 (the default since round 4: three 3-us launches per step) an overflowing weight
@@ -578,8 +575,15 @@ class FFNOEngine:
                 _View(B * X, Y, Z, 1, self.Ks[1], C),       # y: lines (b, x, z), stride Z*C
                 _View(B, X * Y, Z, 0, self.Ks[2], C)]       # z: contiguous lines (b, x, y)
 
+    def _sched_sig(self):
+        """Everything a workspace's buffers and schedule decisions (deferred weight-gradient launch, lazy input sums, slice counts)
+        are derived from besides the geometry: part of the workspace key, so an attribute switched on a live engine gets a
+        workspace laid out for it instead of decisions frozen for the old value."""
+        return (self._h2(), self._ranged(), bool(self.ff_wgrad_deferred), str(self.ff_lazy_sums), int(self.ff_wgrad_slices),
+                int(self.ff_wgrad_rounds), bool(self.use_x3), bool(self.use_fused))
+
     def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
-        key = (B, tuple(S), bool(save), self._ffx(), self._conc(), self.general_ff, self._bf16())
+        key = (B, tuple(S), bool(save), self._ffx(), self._conc(), self.general_ff, self._bf16(), self._sched_sig())
         if self._ws_key == key:
             return self._ws
         cache = self.__dict__.setdefault("_ws_cache", {})   # a few recent geometries (train batch / validation batch /
@@ -656,7 +660,7 @@ class FFNOEngine:
         if save:
             ws.Hbuf = torch.empty(ns, P, H, **f32) if fp32_ff else [None] * ns
             ws.MASK = torch.zeros(ns, ws.mask_words, dtype=torch.int32, device=dev)
-            ws.DH = [torch.empty(P, H, **f32) if fp32_ff else None for _ in range(2)]   # ping-pong (side-stream option)
+            ws.DH = [torch.empty(P, H, **f32) if fp32_ff else None for _ in range(2)]   # ping-pong pair (fp32 feed-forward: stored dh)
             ws.DS = torch.empty(P, C, **act)
             # running gradient: a ping-pong pair -- or one buffer per layer when the weight-gradient launches are deferred to
             # the end of the pass (they read every layer's summed gradient then)
@@ -664,13 +668,11 @@ class FFNOEngine:
                                   and not self.use_fork and not self.layer_norm and not self.general_ff
                                   and (C, H) in ((64, 256), (32, 128)) and self.mode != "no-fourier")
             ws.G = [torch.empty(P, C, **act) for _ in range(L + 1 if ws.defer_wgrad else 2)]
-            ws.lazy_sums = str(self.ff_lazy_sums) if (ws.defer_wgrad and self.ff_lazy_sums in ("s", "sg") and self._conc()
-                                                      and (C, H) == (64, 256)) else ""
+            if self.ff_lazy_sums not in ("s", "0", ""):
+                raise ValueError("ff_lazy_sums must be 's' or '0', got %r" % (self.ff_lazy_sums,))
+            ws.lazy_sums = "s" if (ws.defer_wgrad and self.ff_lazy_sums == "s" and self._conc() and (C, H) == (64, 256)) else ""
             if ws.lazy_sums:
                 ws.TS = [torch.empty(P, C, **act) for _ in range(L)]         # second branch output of every layer
-            if ws.lazy_sums == "sg":
-                ws.G1L = [torch.empty(P, C, **act) for _ in range(L + 1)]    # second gradient buffer beside every ws.G
-                ws.ZeroPC = torch.zeros(P, C, **act)                         # second gradient addend of the last layer
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(int(self.ff_wgrad_slices), (P + 127) // 128))
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
@@ -852,10 +854,9 @@ class FFNOEngine:
             assert not accumulate
             part = ws.ffparts[len(ws.red_jobs)]
             if getattr(ws, "wg_jobs", None) is not None:
-                s2, g2 = getattr(self, "_wg_second", None) or (None, None)
+                s2 = getattr(self, "_wg_second", None)      # second addend of s (lazy input sums)
                 ws.wg_jobs.append((s.data_ptr(), g.data_ptr(), l0.fx[0].data_ptr(), b0.data_ptr(), l0.fx[2].data_ptr(),
-                                   part.data_ptr(), rs.value, rg.value, s2.data_ptr() if s2 is not None else 0,
-                                   g2.data_ptr() if g2 is not None else 0))
+                                   part.data_ptr(), rs.value, rg.value, s2.data_ptr() if s2 is not None else 0, 0))
             else:
                 self._ffs_wgrad(s, g, l0, b0, part, P, ws.nsplit_ff, st, rs, rg)
             ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gb0.data_ptr(), gb1.data_ptr()))
@@ -1051,7 +1052,7 @@ class FFNOEngine:
                            and not self.layer_norm)
         # both branch outputs of every layer are kept and the feed-forward does not write their sum (the deferred weight-gradient
         # launch forms it): decided here, the backward pass follows (self._saved_lazy)
-        lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", "") and not self.overlap)
+        lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", ""))
         bf16 = self._bf16()
         if bf16 and not (all(fused) and all(x3) and self._h2() and self._x3_h2() and self._ffx() and self.spectral == "factorized"
                          and (C, H) in ((64, 256), (32, 128)) and full and not self.use_fork and not self.layer_norm
@@ -1111,7 +1112,8 @@ class FFNOEngine:
                                          rx, rs_),
                             int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
                             _p(s_l) if (save_for_backward and not lazy) else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
-                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()), rxn)
+                            _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()),
+                            int(self.ff_schedule), int(self.ff_max_workgroups), 0, 0, rxn)
                         self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
                         continue
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, t_l, None, keep[0], keep[1],
@@ -1182,7 +1184,6 @@ class FFNOEngine:
         C, H, L = self.C, self.H, self.L
         ws = self._workspace(B, S, True)
         lazy_s = bool(getattr(self, "_saved_lazy", False))            # forward input sums left to the weight-gradient launch
-        lazy = bool(lazy_s and getattr(ws, "lazy_sums", "") == "sg")   # ... and the backward's gradient sums
         st = _lib.current_stream(self.device)
         rw = self._rw
         if self._ranged():
@@ -1197,20 +1198,7 @@ class FFNOEngine:
         pm = ctypes.byref(ws.padmap) if ws.padmap is not None else None
         o0, o1 = self.linears["out.0."], self.linears["out.1."]
         gv = self.grad_view
-        # Optional two-stream schedule (self.overlap): the FF weight-gradient GEMMs of layer l only need
-        # (G_l, dh_l, s_l, h_l), so they can run on a side stream next to the adjoint of layer l.  G and dh are
-        # ping-pong buffers; events order the reuse.
-        use_side = self.overlap and self.device.type == "cuda" and self.mode != "no-fourier" and not self.use_fork
-        side = ev_a = ev_b = main_obj = None
-        st_side = st
-        if use_side:
-            if getattr(self, "_side", None) is None:
-                self._side = torch.cuda.Stream(self.device)
-                self._ev = [torch.cuda.Event() for _ in range(3)]
-            side, main_obj = self._side, torch.cuda.current_stream(self.device)
-            ev_a, ev_b = self._ev[0], self._ev[1:]
-            st_side = ctypes.c_void_p(side.cuda_stream)
-        have_g1 = False      # G1 holds the side-stream part of the running gradient (to be added to g_in)
+        have_g1 = False      # G1 holds the second adjoint branch's part of the running gradient (to be added to g_in)
         cur = 0
         if pm is not None:
             (ws.GF if self.use_fork else ws.G[cur]).zero_()    # adjoint of the crop (mesh_3d.py:173)
@@ -1234,19 +1222,19 @@ class FFNOEngine:
         ws.red_jobs = []
         nG = len(ws.G)
         # deferred weight-gradient launch: (s, summed gradient, packs, words, slices) of every layer, one launch after the loop
-        ws.wg_jobs = [] if (getattr(ws, "defer_wgrad", False) and not use_side and conc) else None
+        ws.wg_jobs = [] if (getattr(ws, "defer_wgrad", False) and conc) else None
         if lazy_s and ws.wg_jobs is None:
             raise RuntimeError("the forward pass left the feed-forward input sums to a deferred weight-gradient launch that this "
-                               "backward pass cannot run (engine.overlap switched on between forward and backward?)")
+                               "backward pass cannot run")
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and pair is not None and fused[pair[0]]
-                           and not singles and not self.use_fork and not use_side and getattr(ws, "defer_reduce", False)
+                           and not singles and not self.use_fork and getattr(ws, "defer_reduce", False)
                            and self.mode != "no-fourier" and not self.layer_norm)
         for l in reversed(range(L)):
             last = l == L - 1
             l0, l1, _, _ = self._ff_weights(l)
             fp = self.ff_prefix[l]
             g_in, g_out, dh = ws.G[cur], ws.G[(cur + 1) % nG], ws.DH[l & 1]
-            g1_in, g1_out = (ws.G1L[cur], ws.G1L[(cur + 1) % nG]) if lazy else (getattr(ws, "G1", None), getattr(ws, "G1", None))
+            g1_in = g1_out = getattr(ws, "G1", None)
             # words: gradient entering this layer, its feed-forward input, the data gradient, the gradient it hands on
             rg, rs_, rd, rgo = rw(ws, "g", l), rw(ws, "s", l), rw(ws, "d", l), (rw(ws, "g", l - 1) if l > 0 else rw(ws, "g", L))
             if self.use_fork:
@@ -1299,17 +1287,17 @@ class FFNOEngine:
                 if ws.wg_jobs is not None:
                     ws.wg_jobs.append((ws.S[l].data_ptr(), g_in.data_ptr(), l0.fx[0].data_ptr(),
                                        self.params[fp + "layers.0.0.bias"].data_ptr(), l0.fx[2].data_ptr(), part.data_ptr(),
-                                       rs_.value, rg.value, ws.TS[l].data_ptr() if lazy_s else 0,
-                                       ((g1_in if have_g1 else ws.ZeroPC).data_ptr()) if lazy else 0))
+                                       rs_.value, rg.value, ws.TS[l].data_ptr() if lazy_s else 0, 0))
                 d = _capi.LayerBwdDesc(
                     self._branch(ws.views[a], ws.DS, g_out, None if last else _p(g_in), ws.SDall[a][l] if full else None,
                                  self._planes_for(si, a, 1, x3pair), 0, x3pair, False, rd, rgo),
-                    self._branch(ws.views[b], ws.DS, g1_out, _p(g1_in) if (lazy and have_g1) else None, ws.SDall[b][l] if full else None,
+                    self._branch(ws.views[b], ws.DS, g1_out, None, ws.SDall[b][l] if full else None,
                                  self._planes_for(si, b, 1, x3pair), 0, x3pair, False, rd, rgo),
-                    int(x3pair), int(self.x3_interleave), _p(g_in), _p(g1_in) if have_g1 else None, None if lazy else _p(g_in),
+                    int(x3pair), int(self.x3_interleave), _p(g_in), _p(g1_in) if have_g1 else None, _p(g_in),
                     _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
-                    None if ws.wg_jobs is not None else _p(part), ws.nsplit_ff, P, C, H, int(self._h2()), 0, rg, rs_, rd)
+                    None if ws.wg_jobs is not None else _p(part), ws.nsplit_ff, P, C, H, int(self._h2()),
+                    int(self.ff_schedule), int(self.ff_max_workgroups), 0, rg, rs_, rd)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
                 ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
                                     gv(fp + "layers.1.0.bias").data_ptr()))
@@ -1331,29 +1319,19 @@ class FFNOEngine:
             if conc:
                 # g_in (+)= G1 while it is staged; the sum is stored back for the weight gradient and the residual path
                 two = bool(have_g1 and not self.layer_norm)
-                self._ffs_bwd2(g_ff, g1_in if two else None, g_ff if (two and not lazy) else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
-                self._wg_second = (ws.TS[l] if lazy_s else None, (g1_in if two else ws.ZeroPC) if lazy else None)
+                self._ffs_bwd2(g_ff, g1_in if two else None, g_ff if two else None, ws.MASK[l], l0, ws.DS, P, st, rg, rd)
+                self._wg_second = ws.TS[l] if lazy_s else None
             elif self.general_ff:
                 self._ffg_bwd(ws, fp, "backcast", l, ws.S[l], g_ff, ws.DS, int(fp in ff_seen), P, st, rd)
             else:
                 self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st, rg, rd)
-            if use_side:
-                ev_a.record(main_obj)
-                side.wait_event(ev_a)
-                self._issue_stream = side
             if not self.general_ff:
                 self._ff_bwd_weights(ws, ws.S[l], g_ff, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
-                                     gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st_side, rs_, rg)
+                                     gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st, rs_, rg)
             ff_seen.add(fp)
             if self.use_fork:
                 self._k("axpy", lib.ffno_axpy, _p(ws.DS), _p(ws.DSF), 1.0, P * C, st)     # ds = ds(backcast) + ds(forecast)
                 self._fold(ws.DS, rd, st)     # (the word already holds both addends' maxima; the sum may exceed either)
-            if use_side:
-                self._issue_stream = None
-                ev_b[l & 1].record(side)
-                if not last:
-                    # layer l+1's weight-gradient kernels read g_out's buffer (their G) and DH[(l+1)&1]: wait for them
-                    main_obj.wait_event(ev_b[(l + 1) & 1])
             if self.mode == "no-fourier":
                 if last:
                     g_out.copy_(ws.DS)
@@ -1377,17 +1355,15 @@ class FFNOEngine:
                            resid if nwrit == 0 else None, ws.SDall[a][l] if full else None, ws.SDall[b][l] if full else None,
                            self._planes_for(si, a, 1, x3pair), self._planes_for(si, b, 1, x3pair), False, st,
                            acc0=int(nwrit > 0), fused=fused[a], x3=x3pair, rin=rd, rout=rgo,
-                           resid1=_p(g1_in) if (lazy and have_g1) else None)
+                           resid1=None)
             have_g1 = conc
             cur = (cur + 1) % nG
         if conc and have_g1:      # lift_bwd takes one input
-            g1_fin = ws.G1L[cur] if lazy else ws.G1
+            g1_fin = ws.G1
             if self._bf16():
                 ws.G[cur].add_(g1_fin)      # (a torch kernel on the same stream; rounds the sum to bf16 like every stored tensor)
             else:
                 self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(g1_fin), 1.0, P * C, st)
-        if use_side:
-            main_obj.wait_event(ev_b[0])      # every FF gradient is in place before weight-norm backward / the optimiser
         nsl = ws.nsplit_ff
         if ws.wg_jobs:
             nsl = ws.nsplit_ffm
@@ -1396,7 +1372,7 @@ class FFNOEngine:
                 ws.wg_table = (_capi.FfWgDesc * len(sig))(*[_capi.FfWgDesc(*j) for j in sig])
                 ws.wg_sig = sig
             self._k("ff_bwd_weights_partial", lib.ffno_ffh_bwd_weights_partial_multi, ws.wg_table, len(sig), P, C, H, nsl,
-                    self._st(), 2 if lazy else int(lazy_s), st)
+                    self._st(), int(lazy_s), st)
         if getattr(ws, "defer_reduce", False) and ws.red_jobs:
             sig = tuple(ws.red_jobs)
             if sig != ws.red_sig:       # pointers only change when parameters are re-bound or the workspace is rebuilt
@@ -1404,7 +1380,7 @@ class FFNOEngine:
                 ws.red_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
                 ws.red_sig = sig
             self._k("ff_bwd_weights_reduce", lib.ffno_ffx_bwd_weights_reduce_batched, _p(ws.red_table), len(sig), C, H,
-                    nsl, st)     # main stream: it has already waited for the side stream's partial kernels
+                    nsl, st)
         g_fin = ws.G[cur]
         lin_in = self.linears["in_proj."]
         if self._training and self.in_dropout > 0.0:      # backward of x = self.drop(in_proj(x)): the same mask, regenerated

@@ -73,7 +73,7 @@ const char* ffno_build_target(void);
  * library under newer host code would have read shifted arguments).  ffno_abi_version() returns the value the LIBRARY was built
  * with; a caller compares it with the FFNO_ABI_VERSION it was compiled against before the first compute call (the Python host
  * does: fourierflow_amd/_lib.py refuses a mismatch). */
-#define FFNO_ABI_VERSION 5
+#define FFNO_ABI_VERSION 6
 int ffno_abi_version(void);
 
 /* word[0] = max(word[0], bits(max |x[i]|)): folds a tensor into a range word (see "Range words" above) */
@@ -292,6 +292,7 @@ typedef struct ffno_layer_fwd_desc {
     void* mask;
     int32_t P, C, H;
     int32_t ff_kernel; /* FFNO_FF_BF16X3 (packs of ffno_ffx_pack) or FFNO_FF_FP16X2 (packs of ffno_ffh_pack) */
+    int32_t ff_schedule, ff_max_workgroups, pad0_, pad1_; /* ffno_ff_opts.schedule / .max_workgroups of the feed-forward launch (0: the library's choice) */
     /* range words: a.in_amax = b.in_amax = word of x; a.out_amax = b.out_amax = word of the branch outputs, which the
      * feed-forward then reads as its in_amax; out_amax receives max |out| (the next layer's x word).  All optional. */
     uint32_t* out_amax;
@@ -311,7 +312,7 @@ typedef struct ffno_layer_bwd_desc {
     const float* b1;
     float* partial;
     int32_t nsplit, P, C, H;
-    int32_t ff_kernel, pad_;
+    int32_t ff_kernel, ff_schedule, ff_max_workgroups, pad_; /* ff_schedule / ff_max_workgroups: as in ffno_layer_fwd_desc */
     /* range words (all optional): g_amax = word of g / g2 (both folded into it by their producers) -- read by the data- and
      * the weight-gradient kernel; s_amax = word of the addends of s (the forward's a.out_amax); ds_amax receives max |ds| and
      * is what the caller also passes as a.in_amax / b.in_amax of the adjoint branches; a.out_amax / b.out_amax receive the

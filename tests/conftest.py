@@ -21,13 +21,21 @@ def pytest_configure(config):
 # GPU tests carry `gpu_extra` instead of `gpu`, so that the driver's `-m gpu` run spends its minutes on the section-8 rows
 # (VERDICT r03 #9).  `-m gpu_extra` runs them on a GPU box; their emulator halves stay in `-m "not gpu"`.
 OUT_OF_SCOPE_FILES = {"test_geofno.py", "test_cno.py", "test_kernels_dct.py"}
+# ... and the kernel-level tests of the bf16 STORAGE twins that compare a twin with the rounded fp32 kernel (self-comparisons, not
+# oracle comparisons): the variant is frozen, so on a GPU box they run under `-m gpu_extra` too; the three oracle
+# band tests of tests/test_storage_bf16.py and the bands of tests/test_bench_geometry.py stay in `-m gpu`.
+FROZEN_TWIN_TESTS = {"test_ffh_twins_are_the_rounded_fp32_kernels", "test_spectral_x3_twin_is_the_rounded_fp32_kernel",
+                     "test_lift_and_head_twins", "test_twins_refuse_what_they_do_not_cover",
+                     "test_switching_the_storage_of_one_engine_back_and_forth",
+                     "test_training_steps_on_bf16_storage_follow_the_fp32_run"}
 
 
 def pytest_collection_modifyitems(config, items):
     for item in items:
-        if os.path.basename(str(item.fspath)) not in OUT_OF_SCOPE_FILES:
+        if (os.path.basename(str(item.fspath)) not in OUT_OF_SCOPE_FILES
+                and getattr(item, "originalname", item.name) not in FROZEN_TWIN_TESTS):
             continue
-        if any(m.name == "gpu" for m in item.own_markers):
+        if any(m.name == "gpu" for m in item.iter_markers()):
             item.own_markers = [m for m in item.own_markers if m.name != "gpu"]
             item.add_marker(pytest.mark.gpu_extra)
             # (without a GPU these must still be skipped like every other device test)

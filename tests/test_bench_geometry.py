@@ -76,6 +76,11 @@ def test_markov24_bench_geometry_forward_backward_vs_oracle(B, split):
     # vanishing fraction of the 24 x P x 256 hidden units (the ones within an ulp of zero)
     plain_out, _, _ = ou.oracle_block_run(kw, seed, B, M, N, io=io)
     assert rel_l2(ref_out["forecast"].detach().numpy(), plain_out["forecast"].detach().numpy()) < 1e-6
+    # ... and counted: the oracle's own decisions differ from the HIP path's on < 1e-5 of the hidden units
+    flips = ou.relu_flips(kw, seed, B, M, N, masks, io=io)
+    total = kw["n_layers"] * B * M * N * kw["width"] * kw["factor"]
+    print(f"[bench-geometry B={B}] ReLU decisions that differ from the oracle's own: {flips} of {total} ({flips / total:.1e})")
+    assert flips <= 1e-5 * total, (flips, total)
 
 
 @pytest.mark.gpu
