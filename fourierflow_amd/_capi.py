@@ -105,6 +105,7 @@ SIGNATURES = {
     "ffno_build_target": (C.c_char_p, []),
     "ffno_abi_version": (I, []),
     "ffno_amax": (I, [P, SZ, P, P]),
+    "ffno_lds_tr16_probe": (I, [P, I, P, P, P]),
     "ffno_twiddle_fill_host": (I, [P, I]),
     "ffno_dft_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "ffno_fw_pack": (I, [P, P, P, I, I, P]),

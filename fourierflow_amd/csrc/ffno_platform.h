@@ -118,6 +118,16 @@ __device__ __forceinline__ void swap_halves(unsigned& a, unsigned& b) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = r[0], b = r[1];
 }
+// ds_read_b64_tr_b16, the LDS transpose read of gfx950.  Every lane gives the address of 8 bytes (4 halves, 8-byte aligned); a
+// 16-lane group's 16 x 4 halves are taken as a [4 rows][16 columns] block -- row r = the 8-byte pieces of lanes 4 r .. 4 r + 3 of
+// the group -- and lane i of the group receives COLUMN i: halves (row 0, i), (row 1, i), (row 2, i), (row 3, i), i.e. from the
+// piece of lane 4 r + (i >> 2) its element i & 3.  (tests/test_kernels_ffh.py checks the hardware against this map.)
+__device__ __forceinline__ uint2 lds_read_tr16_b64(const void* p) {
+    typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 f16x4;
+    typedef __attribute__((address_space(3))) f16x4* lds_f16x4_p;
+    const f16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4_p)(p));
+    return __builtin_bit_cast(uint2, v);
+}
 // (acc << 1) | msb(x): v_alignbit_b32
 __device__ __forceinline__ uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return __builtin_amdgcn_alignbit(acc, x, 31); }
 // all-ones if bit b of x is set, else 0: v_bfe_i32

@@ -1207,24 +1207,46 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //     rows are staged: the chain kernels then need not write the sums back (one image write less per launch: 44.6 -> 39.1 us
 //     forward, 41.4 -> 33.4 us backward-data with the wave-tile kernels, MI355X round 4).
 //     TWO = 1: only s is a sum (db single), TWO = 2: both.
+// Round 5: the CHANNEL-MAJOR operands come from the pixel-major tile through the LDS transpose read.  Until round 4 every tile was
+// staged twice -- pixel-major (float4 rows) and channel-major (four scalar loads per thread and tensor, a second split, a second
+// set of LDS planes); a timing-only build without the second copy ran 35 % faster.  gfx950's ds_read_b64_tr_b16 hands a 16-lane
+// group the TRANSPOSE of a [4 rows][16 halves] block: lane i of the group receives element i of each of the four rows, and the
+// rows are wherever lanes 4 r .. 4 r + 3 of the group point (8 bytes each).  Four pixel rows x 16 channels of a pixel-major fp16
+// plane are therefore one read away from the A operand of the pixel-contraction GEMMs (rows = channels, k = pixels), in exactly
+// the k order of the D-fragment operand on the other side (slot e <-> pixel 16 s2 + (e & 3) + 8 (e >> 2) + 4 half).  Same fp16
+// planes, same products in the same order: the slices are bit-identical to the twice-staged kernel.
+//   LDS image of one plane: row R (pixel) at  R * PROW + 16 ((R >> 2) & 3) + WRAP (R >> 4),  PROW = 192 (C = 64) / 64 (C = 32):
+//   * a transpose read touches rows 4 a .. 4 a + 3 over 64 bytes each: R * PROW mod 256 are four different multiples of 64;
+//   * a pixel-major ds_read_b128 touches 16 rows with different R mod 16 at one column: their 16-byte slots mod 256 are
+//     4 ((-R) & 3) + ((R >> 2) & 3), all different  -- both conflict-free (tools/lds_bank_check.py enumerates the lane groups).
+template <int C>
+struct WgT {
+    static constexpr int PROW = C == 64 ? 192 : 64;
+    static constexpr int WRAP = C == 64 ? 0 : 64;
+    static constexpr int PLANE = 32 * PROW + 48 + WRAP + 16;      // (+16: keeps the next plane 64-byte aligned)
+    static_assert(PLANE % 64 == 0, "plane alignment");
+    static __device__ __forceinline__ int row(int R) { return R * PROW + 16 * ((R >> 2) & 3) + WRAP * (R >> 4); }
+};
+
 template <int C, int H, int NWV, class ST = StF32, int TWO = 0>
 __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restrict__ s, const typename ST::T* __restrict__ db,
                                                  const u32x4* __restrict__ pk1, const float* __restrict__ bias1,
                                                  const u32x4* __restrict__ pk2t, float* __restrict__ partial, int P,
                                                  const unsigned* s_amax, const unsigned* db_amax, const int bid, const int nb,
-                                                 const typename ST::T* __restrict__ s2 = nullptr,
-                                                 const typename ST::T* __restrict__ db2 = nullptr) {
+                                                 const typename ST::T* __restrict__ s2 = nullptr) {
     constexpr int CPW = H / (32 * NWV);            // hidden chunks per wave
     using F = FxCfg<C, H, CPW>;
+    using T = WgT<C>;
     constexpr int KS = F::KS, CTO = F::CTO, NV = F::NV;
     constexpr int GS = KS;                         // operand fragments per staged tile and orientation (C / 16)
     static_assert(F::NW == NWV && F::NT == NWV * 64 && CPW >= 1 && F::NT % C == 0, "wave / chunk map");
+    static_assert(TWO == 0 || TWO == 1, "TWO = 1: s is the sum of two tensors");
     const float fscale = range_scale(*s_amax, 1, kFfRangeTarget);       // (the host side only takes this kernel WITH range words:
     const float gscale = range_scale(*db_amax, 1, kFfRangeTarget);      //  the 2^11 hi plane needs the 2^4 bound)
-    constexpr int BUF = 4 * F::PPLANE + 4 * F::TPLANE;   // [sP x2][dbP x2][sT x2][dbT x2]
-    constexpr int OFF_SP = 0, OFF_DP = 2 * F::PPLANE, OFF_ST = 4 * F::PPLANE, OFF_DT = 4 * F::PPLANE + 2 * F::TPLANE;
-    __shared__ __attribute__((aligned(16))) char lds[2][BUF];
-    __shared__ float red[F::NT];
+    constexpr int BUF = 4 * T::PLANE;              // [s hi][s lo][db hi][db lo], pixel-major
+    constexpr int OFF_SP = 0, OFF_DP = 2 * T::PLANE;
+    __shared__ __attribute__((aligned(64))) char lds[2][BUF];
+    __shared__ float4 red[F::NT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -1251,24 +1273,17 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         acc = plat::mfma_f16_32x32x16(hs, b.hi, acc);
     };
 
-    // staging maps as in ffx_wgrad_kernel (pixel-major float4 f; channel-major: channel tc, pixel group tg + v * NT / C).
-    // Branch-free: tiles past the end re-read the last tile (their staged copy is never used); rows past the end of a ragged
-    // last tile re-read its last valid row and are zeroed -- by stage(), an iteration later: a select placed next to the load
-    // would make the wave wait for every load where it is issued.
-    const int tc = tid % C, tg = tid / C;
+    // Staging: thread f owns 4 consecutive channels of pixel row f / (C / 4).  Branch-free: tiles past the end re-read the last
+    // tile (their staged copy is never used); rows past the end of a ragged last tile re-read its last valid row and are zeroed
+    // -- by stage(), an iteration later: a select placed next to the load would make the wave wait for every load where it is issued.
     // (raw words of the next tile: widened in stage(), an iteration after the request)
-    struct Raw1x4 {
-        typename ST::Raw1 v[4];
-    };
-    typename ST::Raw4 nSP[NV], nDP[NV], mSP[NV], mDP[NV];      // (m*: the second addends, TWO only)
-    Raw1x4 nST[NV], nDT[NV], mST[NV], mDT[NV];
-    float bs2 = 0.f;
+    typename ST::Raw4 nSP[NV], nDP[NV], mSP[NV];      // (m*: the second addend of s, TWO only)
+    float4 bs2 = make_float4(0.f, 0.f, 0.f, 0.f);      // this thread's part of db2: its 4 channels, its pixel row of every tile
     auto gload = [&](int tile_) {
         const int tile = min(tile_, ntiles - 1);
         const typename ST::T* st = s + (long)tile * (32 * C);
         const typename ST::T* dt = db + (long)tile * (32 * C);
         const typename ST::T* st2 = TWO ? s2 + (long)tile * (32 * C) : nullptr;
-        const typename ST::T* dt2 = TWO == 2 ? db2 + (long)tile * (32 * C) : nullptr;
         const int rows = min(P - tile * 32, 32);
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
@@ -1277,15 +1292,6 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
             nSP[v] = ST::ldr4(st + offp);
             nDP[v] = ST::ldr4(dt + offp);
             if constexpr (TWO >= 1) mSP[v] = ST::ldr4(st2 + offp);
-            if constexpr (TWO == 2) mDP[v] = ST::ldr4(dt2 + offp);
-            const int r0 = 4 * (tg + v * (F::NT / C));
-            FFNO_UNROLL
-            for (int i = 0; i < 4; ++i) {
-                const unsigned offt = (unsigned)(min(r0 + i, rows - 1) * C + tc);
-                nST[v].v[i] = ST::ldr1(st + offt), nDT[v].v[i] = ST::ldr1(dt + offt);
-                if constexpr (TWO >= 1) mST[v].v[i] = ST::ldr1(st2 + offt);
-                if constexpr (TWO == 2) mDT[v].v[i] = ST::ldr1(dt2 + offt);
-            }
         }
     };
     // tile_ = the tile whose rows are in the staging registers (may lie past the end: its copy is staged but never used and
@@ -1295,7 +1301,8 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         FFNO_UNROLL
         for (int v = 0; v < NV; ++v) {
             const int f = tid + v * F::NT;
-            const float mp = (f / (C / 4)) < rows ? 1.f : 0.f;
+            const int R = f / (C / 4);
+            const float mp = R < rows ? 1.f : 0.f;
             const float fs = fscale * mp, gs = gscale * mp;
             float4 sp = ST::w4(nSP[v]), dp = ST::w4(nDP[v]);
             if constexpr (TWO >= 1) {
@@ -1303,38 +1310,12 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
                 sp.x += s2v.x, sp.y += s2v.y, sp.z += s2v.z, sp.w += s2v.w;
                 sp = st_rnd4<ST>(sp);
             }
-            if constexpr (TWO == 2) {
-                const float4 d2v = ST::w4(mDP[v]);
-                dp.x += d2v.x, dp.y += d2v.y, dp.z += d2v.z, dp.w += d2v.w;
-                dp = st_rnd4<ST>(dp);
-            }
             sp.x *= fs, sp.y *= fs, sp.z *= fs, sp.w *= fs;
             dp.x *= gs, dp.y *= gs, dp.z *= gs, dp.w *= gs;
-            const int r0 = 4 * (tg + v * (F::NT / C));
-            const float m0 = r0 < rows ? 1.f : 0.f, m1 = r0 + 1 < rows ? 1.f : 0.f, m2 = r0 + 2 < rows ? 1.f : 0.f,
-                        m3 = r0 + 3 < rows ? 1.f : 0.f;
-            float4 tS = make_float4(ST::w1(nST[v].v[0]), ST::w1(nST[v].v[1]), ST::w1(nST[v].v[2]), ST::w1(nST[v].v[3]));
-            float4 tD = make_float4(ST::w1(nDT[v].v[0]), ST::w1(nDT[v].v[1]), ST::w1(nDT[v].v[2]), ST::w1(nDT[v].v[3]));
-            if constexpr (TWO >= 1) {
-                tS.x += ST::w1(mST[v].v[0]), tS.y += ST::w1(mST[v].v[1]), tS.z += ST::w1(mST[v].v[2]), tS.w += ST::w1(mST[v].v[3]);
-                tS = st_rnd4<ST>(tS);
-            }
-            if constexpr (TWO == 2) {
-                tD.x += ST::w1(mDT[v].v[0]), tD.y += ST::w1(mDT[v].v[1]), tD.z += ST::w1(mDT[v].v[2]), tD.w += ST::w1(mDT[v].v[3]);
-                tD = st_rnd4<ST>(tD);
-            }
-            tS.x *= fscale * m0, tS.y *= fscale * m1, tS.z *= fscale * m2, tS.w *= fscale * m3;
-            tD.x *= gscale * m0, tD.y *= gscale * m1, tD.z *= gscale * m2, tD.w *= gscale * m3;
-            const int offp = (f / (C / 4)) * F::PROW + (f % (C / 4)) * 8;
-            stage4_s<SplitHf2>(lds[buf] + OFF_SP, F::PPLANE, offp, sp.x, sp.y, sp.z, sp.w);
-            stage4_s<SplitHf2>(lds[buf] + OFF_DP, F::PPLANE, offp, dp.x, dp.y, dp.z, dp.w);
-            // pixel group grp = (s2 << 2) | (q << 1) | half  <->  local pixels 16 s2 + 8 q + 4 half + i  <->  k slot 4 q + i
-            const int grp = tg + v * (F::NT / C);
-            const int pos = 16 * (grp & 1) + 8 * (grp >> 2) + 4 * ((grp >> 1) & 1);
-            const int offt = tc * F::TROW + 2 * pos;
-            stage4_s<SplitHf2>(lds[buf] + OFF_ST, F::TPLANE, offt, tS.x, tS.y, tS.z, tS.w);
-            stage4_s<SplitHf2>(lds[buf] + OFF_DT, F::TPLANE, offt, tD.x, tD.y, tD.z, tD.w);
-            bs2 += (tD.x + tD.y) + (tD.z + tD.w);
+            const int offp = T::row(R) + (f % (C / 4)) * 8;
+            stage4_s<SplitHf2>(lds[buf] + OFF_SP, T::PLANE, offp, sp.x, sp.y, sp.z, sp.w);
+            stage4_s<SplitHf2>(lds[buf] + OFF_DP, T::PLANE, offp, dp.x, dp.y, dp.z, dp.w);
+            bs2.x += dp.x, bs2.y += dp.y, bs2.z += dp.z, bs2.w += dp.w;
         }
     };
 
@@ -1346,6 +1327,10 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) acc1[ch][mt] = zero16(), acc2[ch][mt] = zero16();
     }
+    // per-lane parts of the two LDS address patterns (the rest are compile-time offsets)
+    const int prow = T::row(j) + 16 * half;                                             // pixel-major: row j, +32 q
+    const int trow = (4 * half + ((lane & 15) >> 2)) * T::PROW + 16 * half              // transposed: row 4 half + jj of its group,
+                     + 32 * ((lane >> 4) & 1) + 8 * (lane & 3);                         //  channels 16 g + 4 q'
 
     gload(bid);
     stage(0, bid);
@@ -1355,16 +1340,31 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
     for (int tile = bid; tile < ntiles; tile += nb, buf ^= 1) {
         const int nt = tile + nb;
         const char* L = lds[buf];
+        // channel-major fragment (mt, s2) of a tensor: rows = channels 32 mt + (lane & 31), k slots = pixels of k-step s2 in the
+        // D-fragment order; two transpose reads per plane (k slots 0..3 / 4..7 = pixel rows +0 / +8)
+        auto tfrag = [&](int off_tensor, int mt, int s2_) {
+            Hf2 f;
+            FFNO_UNROLL
+            for (int p = 0; p < 2; ++p) {
+                const char* base = L + off_tensor + p * T::PLANE + trow + s2_ * (16 * T::PROW + T::WRAP) + 64 * mt;
+                const uint2 lo4 = plat::lds_read_tr16_b64(base);
+                const uint2 hi4 = plat::lds_read_tr16_b64(base + 8 * T::PROW + 32);
+                u32x4 w;
+                w[0] = lo4.x, w[1] = lo4.y, w[2] = hi4.x, w[3] = hi4.y;
+                SplitHf2::set_plane(f, p, w);
+            }
+            return f;
+        };
         // The 16 operand fragments of a tile, in the order the products consume them (s, db^T, db, s^T), come through a ring of
         // two: fragment i + 2 is requested when fragment i has been handed to its MFMAs, and the request is pinned there (a
         // scheduling barrier that only LDS reads may not cross) -- left alone the scheduler puts every read right in front of
         // its use and the wave waits out each LDS round trip.
         auto frag = [&](int i) {
             const int g = i / GS, q = i % GS;
-            if (g == 0) return lds_frag_s<SplitHf2>(L + OFF_SP, F::PPLANE, j * F::PROW + 32 * q + 16 * half);
-            if (g == 1) return lds_frag_s<SplitHf2>(L + OFF_DT, F::TPLANE, (32 * (q >> 1) + j) * F::TROW + 32 * half + 16 * (q & 1));
-            if (g == 2) return lds_frag_s<SplitHf2>(L + OFF_DP, F::PPLANE, j * F::PROW + 32 * q + 16 * half);
-            return lds_frag_s<SplitHf2>(L + OFF_ST, F::TPLANE, (32 * (q >> 1) + j) * F::TROW + 32 * half + 16 * (q & 1));
+            if (g == 0) return lds_frag_s<SplitHf2>(L + OFF_SP, T::PLANE, prow + 32 * q);
+            if (g == 1) return tfrag(OFF_DP, q >> 1, q & 1);
+            if (g == 2) return lds_frag_s<SplitHf2>(L + OFF_DP, T::PLANE, prow + 32 * q);
+            return tfrag(OFF_SP, q >> 1, q & 1);
         };
         Hf2 ring[2];
         ring[0] = frag(0), ring[1] = frag(1);
@@ -1372,8 +1372,8 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         // the next tile's rows arrived during the previous iteration: convert + write them now -- vector / LDS work the scheduler
         // places between the MFMAs of the h GEMM below
         stage(buf ^ 1, nt);
-        if constexpr (NWV == 8) {     // two waves per SIMD hide each other's round trips; the registers are too few to hold the
-            gload(nt + nb);    // rows of the next tile across the whole iteration (the scheduler sinks the requests)
+        if constexpr (NWV == 8) {     // two waves per SIMD hide each other's round trips
+            gload(nt + nb);
             FFNO_SCHED_PIN_VMEM();
         }
         // h^T[px][hid] = relu(s W1^T + b1), pixels on the D rows: main + correction tile, as in the forward kernel
@@ -1414,13 +1414,13 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
             FFNO_UNROLL
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int q = 2 * mt + s2;
+            for (int s2_ = 0; s2_ < 2; ++s2_) {
+                const int q = 2 * mt + s2_;
                 const Hf2 a = ring[q & 1];
                 ring[q & 1] = frag(1 * GS + q + 2);
                 FFNO_SCHED_PIN_DSREAD();
                 FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2], acc2[ch][mt]);
+                for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2_], acc2[ch][mt]);
             }
         }
         // dh^T[px][hid] = (db W2) * [h > 0]   (d = 2^11 x the product)
@@ -1447,15 +1447,15 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         FFNO_UNROLL
         for (int mt = 0; mt < CTO; ++mt) {
             FFNO_UNROLL
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int q = 2 * mt + s2;
+            for (int s2_ = 0; s2_ < 2; ++s2_) {
+                const int q = 2 * mt + s2_;
                 const Hf2 a = ring[q & 1];
                 if (q + 2 < GS) {
                     ring[q & 1] = frag(3 * GS + q + 2);
                     FFNO_SCHED_PIN_DSREAD();
                 }
                 FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2], acc1[ch][mt]);
+                for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2_], acc1[ch][mt]);
             }
         }
         __syncthreads();
@@ -1483,11 +1483,15 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         const float v1 = bs1[ch] + __shfl_xor(bs1[ch], 32);
         if (half == 0) pb1[hid] = v1 * rg;
     }
+    // db2[c] = sum over the slice's pixels: thread f holds channels 4 (f % (C/4)) .. +3 of pixel row f / (C/4); rows in order
     red[tid] = bs2;
     __syncthreads();
     if (tid < C) {
         float v = 0.f;
-        for (int k = tid; k < F::NT; k += C) v += red[k];
+        for (int r = 0; r < F::NT / (C / 4); ++r) {
+            const float4 t = red[r * (C / 4) + (tid >> 2)];
+            v += (tid & 3) == 0 ? t.x : (tid & 3) == 1 ? t.y : (tid & 3) == 2 ? t.z : t.w;
+        }
         pb2[tid] = v * rg;
     }
 }
@@ -1516,8 +1520,8 @@ struct FfWgDesc {
     float* partial;
     const unsigned* s_amax;
     const unsigned* g_amax;
-    const void* s2;      // second addends (TWO launches: every block gives both; a block without a second gradient addend -- the
-    const void* g2;      //  last layer's -- passes a zero-filled tensor)
+    const void* s2;      // second addend of s (TWO launches)
+    const void* g2;      // (reserved: round 4's second gradient addend, measured slower and removed)
 };
 
 // The table travels BY VALUE in the kernel-argument segment (up to FFWG_MAX_BLOCKS blocks per launch): pointers inside a by-value
@@ -1535,7 +1539,7 @@ __global__ __launch_bounds__(NWV * 64) void ffh_wgrad_m_multi_kernel(const FfWgT
     const FfWgDesc& d = tab.d[layer];
     typedef const typename ST::T* cp;
     ffh_wgrad_m_body<C, H, NWV, ST, TWO>((cp)d.s, (cp)d.g, d.pk1, d.b1, d.pk2t, d.partial, P, d.s_amax, d.g_amax,
-                                         (int)blockIdx.x - layer * nsplit, nsplit, (cp)d.s2, (cp)d.g2);
+                                         (int)blockIdx.x - layer * nsplit, nsplit, (cp)d.s2);
 }
 
 // partial slices -> gradients; the dW1 block of a slice is [c][hid] (transposed)
@@ -1900,13 +1904,13 @@ extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs, i
     static_assert(sizeof(ffno_ffwg_desc) == sizeof(FfWgDesc), "descriptor layout");
     if (!descs || n <= 0 || P <= 0 || nsplit <= 0) return FFNO_EINVAL;
     if (storage != FFNO_STORE_F32 && storage != FFNO_STORE_BF16) return FFNO_EINVAL;
-    if (two_addends < 0 || two_addends > 2) return FFNO_EINVAL;
+    if (two_addends < 0 || two_addends > 1) return FFNO_EINVAL;
     if (!((C == 64 && H == 256) || (C == 32 && H == 128))) return FFNO_EUNSUPPORTED;
     if (two_addends && C != 64) return FFNO_EUNSUPPORTED;      // (the wave-tile chain kernels' shape: they leave the sums unwritten)
     for (int i = 0; i < n; ++i) {
         const ffno_ffwg_desc& d = descs[i];
         if (!d.s || !d.g || !d.pk1 || !d.b1 || !d.pk1b || !d.partial || !d.s_amax || !d.g_amax) return FFNO_EINVAL;
-        if ((two_addends >= 1 && !d.s2) || (two_addends == 2 && !d.g2)) return FFNO_EINVAL;
+        if (two_addends == 1 && !d.s2) return FFNO_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
     const bool b16 = storage == FFNO_STORE_BF16;
@@ -1920,8 +1924,7 @@ extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs, i
 #define WG_LAUNCH(CC, HH, NW, STT, TW) FFNO_LAUNCH((ffh_wgrad_m_multi_kernel<CC, HH, NW, STT, TW>), grid, dim3(NW * 64), 0, st, tab, P, nsplit)
         if (C == 64) {
             if (two_addends == 0) { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 0); else WG_LAUNCH(64, 256, 8, StF32, 0); }
-            else if (two_addends == 1) { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 1); else WG_LAUNCH(64, 256, 8, StF32, 1); }
-            else { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 2); else WG_LAUNCH(64, 256, 8, StF32, 2); }
+            else { if (b16) WG_LAUNCH(64, 256, 8, StBf16, 1); else WG_LAUNCH(64, 256, 8, StF32, 1); }
         } else {
             if (b16) WG_LAUNCH(32, 128, 4, StBf16, 0); else WG_LAUNCH(32, 128, 4, StF32, 0);
         }
@@ -1930,6 +1933,23 @@ extern "C" int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs, i
         if (rc) return rc;
     }
     return FFNO_OK;
+}
+
+// Hardware self-check of the LDS transpose read the weight-gradient kernel is built on: one wave copies `image` (n16 halves) into
+// LDS, every lane reads 8 bytes through ds_read_b64_tr_b16 at ITS byte offset, and writes the four halves it received.
+__global__ __launch_bounds__(64) void lds_tr16_probe_kernel(const uint16_t* __restrict__ image, int n16,
+                                                            const int32_t* __restrict__ byte_off, uint16_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(64))) uint16_t img[8192];
+    for (int i = threadIdx.x; i < n16; i += 64) img[i] = image[i];
+    __syncthreads();
+    const uint2 v = plat::lds_read_tr16_b64(reinterpret_cast<const char*>(img) + byte_off[threadIdx.x]);
+    out[4 * threadIdx.x + 0] = (uint16_t)(v.x & 0xffffu), out[4 * threadIdx.x + 1] = (uint16_t)(v.x >> 16);
+    out[4 * threadIdx.x + 2] = (uint16_t)(v.y & 0xffffu), out[4 * threadIdx.x + 3] = (uint16_t)(v.y >> 16);
+}
+extern "C" int ffno_lds_tr16_probe(const uint16_t* image, int n16, const int32_t* byte_off, uint16_t* out, void* stream) {
+    if (!image || !byte_off || !out || n16 <= 0 || n16 > 8192) return FFNO_EINVAL;
+    FFNO_LAUNCH(lds_tr16_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, image, n16, byte_off, out);
+    return ffx_launch_status();
 }
 
 extern "C" int ffno_ffx_bwd_weights_reduce(const float* partial, float* dW1, float* dW2, float* db1, float* db2, int C,

@@ -502,13 +502,18 @@ typedef struct ffno_ffwg_desc {
     float* partial;          /* nsplit slices */
     const uint32_t* s_amax;
     const uint32_t* g_amax;
-    const void* s2;          /* two_addends 1: s = s + s2, 2: also g = g + g2 -- formed (and rounded to the storage format) while   */
-    const void* g2;          /* the rows are staged, for callers whose chain launches do not write the sums back (s_sum / db_sum
-                              * NULL); every block must give the addends the mode names (a block with one gradient addend in
-                              * mode 2: a zero-filled tensor) */
+    const void* s2;          /* two_addends 1: s = s + s2 -- formed (and rounded to the storage format) while the rows are staged,
+                              * for callers whose forward chain launch does not write the sum back (s_sum NULL) */
+    const void* g2;          /* reserved (NULL): round 4's second gradient addend was measured slower and removed */
 } ffno_ffwg_desc;
 int ffno_ffh_bwd_weights_partial_multi(const ffno_ffwg_desc* descs, int n, int P, int C, int H, int nsplit, int storage,
-                                       int two_addends /* 0, 1 (s) or 2 (s and g); 1 / 2: C = 64, H = 256 only */, void* stream);
+                                       int two_addends /* 0 or 1 (s = s + s2; C = 64, H = 256 only) */, void* stream);
+
+/* Hardware self-check of the LDS transpose read (ds_read_b64_tr_b16) the weight-gradient kernel takes its channel-major operands
+ * through: one wave copies image[n16] (halves, n16 <= 8192) into LDS, lane l reads 8 bytes at byte_off[l] (8-byte aligned) with the
+ * transpose read and writes the four halves it received to out[4 l .. 4 l + 3].  Expected (csrc/ffno_platform.h): within each
+ * 16-lane group, lane i receives element i & 3 of the pieces addressed by lanes 4 r + (i >> 2), r = 0..3. */
+int ffno_lds_tr16_probe(const uint16_t* image, int n16, const int32_t* byte_off, uint16_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the channel axis, the last stage of FeedForward(layer_norm=True) (feedforward.py:18-19: nn.LayerNorm(dim),

@@ -56,6 +56,7 @@ inline void swap_halves(unsigned& a, unsigned& b) {
     const float na = hi ? tb : fa, nb = hi ? fb : ta;
     memcpy(&a, &na, 4), memcpy(&b, &nb, 4);
 }
+inline uint2 lds_read_tr16_b64(const void* p) { return emu::lds_read_tr16_b64(p); }
 inline uint32_t shift_in_msb(uint32_t acc, uint32_t x) { return (acc << 1) | (x >> 31); }
 inline uint32_t bit_to_mask(uint32_t x, int b) { return 0u - ((x >> b) & 1u); }
 inline void sleep_cycles(int) {}

@@ -84,6 +84,7 @@ struct Fiber {
 struct WaveX {  // per-wave exchange state (double-buffered by parity)
     float a[2][64], b[2][64];
     unsigned xa[2][64][4], xb[2][64][4];   // 8 x bf16 per lane operands of the 32x32x16 forms
+    const void* ptr[2][64];                // per-lane addresses of a cross-lane memory operation (ds_read_b64_tr_b16)
     int arrived;
     unsigned gen;
     int parity;
@@ -320,6 +321,26 @@ inline f32x4 mfma_16x16x4(float a, float b, f32x4 c) {
     }
     wave_exchange_done(p);
     return d;
+}
+
+// ds_read_b64_tr_b16 (gfx950): every lane addresses 8 bytes (4 halves; the hardware ignores address bits 0..2 -- here a
+// misaligned address aborts); within each 16-lane group lane i receives element (i & 3) of the pieces addressed by lanes
+// 4 r + (i >> 2), r = 0..3: column i of the [4][16] block whose row r the lanes 4 r .. 4 r + 3 address.
+inline uint2 lds_read_tr16_b64(const void* addr) {
+    if (((uintptr_t)addr & 7u) != 0) {
+        fprintf(stderr, "emu: ds_read_b64_tr_b16 at an address that is not 8-byte aligned\n");
+        abort();
+    }
+    WaveX& w = my_wave();
+    int lane = S().cur->linear & 63;
+    int p = w.parity;
+    w.ptr[p][lane] = addr;
+    wave_barrier(w);
+    const int grp = lane & ~15, i = lane & 15;
+    unsigned short v[4];
+    for (int r = 0; r < 4; ++r) memcpy(&v[r], (const char*)w.ptr[p][grp + 4 * r + (i >> 2)] + 2 * (i & 3), 2);
+    wave_exchange_done(p);
+    return make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
 }
 
 inline float shfl(float v, int src_lane) {

@@ -252,18 +252,14 @@ def test_ffh_weight_gradient_of_several_blocks_in_one_launch(be, P, C, H, nsplit
         np.testing.assert_array_equal(be.get(multi), a)
     table2 = (FfWgDesc * n)(*descs2)
     if C == 64:
-        assert lib.ffno_ffh_bwd_weights_partial_multi(table2, n, P, C, H, nsplit, 0, 2, None) == 0
-        for one2, multi2 in twos:
-            np.testing.assert_array_equal(be.get(multi2), be.get(one2))
-        # mode 1: only s is a sum -- the same blocks with the pre-summed gradient in the first slot
+        # two_addends = 1: s is a sum formed while staging -- the same blocks with the pre-summed gradient in the first slot
         for d, pg in zip(descs2, presum_g):
             d.g = p(pg)
         table3 = (FfWgDesc * n)(*descs2)
-        for one2, multi2 in twos:
-            multi2[...] = 0 if be.kind == "emu" else multi2.zero_()
         assert lib.ffno_ffh_bwd_weights_partial_multi(table3, n, P, C, H, nsplit, 0, 1, None) == 0
         for one2, multi2 in twos:
             np.testing.assert_array_equal(be.get(multi2), be.get(one2))
+        assert lib.ffno_ffh_bwd_weights_partial_multi(table3, n, P, C, H, nsplit, 0, 2, None) == -1      # (round 4's second gradient addend: removed)
         assert lib.ffno_ffh_bwd_weights_partial_multi(table3, n, P, C, H, nsplit, 0, 3, None) == -1
     else:
         assert lib.ffno_ffh_bwd_weights_partial_multi(table2, n, P, C, H, nsplit, 0, 1, None) == -2
@@ -340,3 +336,48 @@ def test_ffh_rejects_bad_arguments(be):
     p = be.ptr
     assert be.lib.ffno_ffh_fwd2(p(z), None, None, None, p(z), p(z), p(z), p(z), p(z), None, 1, 48, 192, None, None) == -2
     assert be.lib.ffno_ffh_bwd_data2(None, None, None, p(z), p(z), p(z), p(z), 1, 64, 256, None, None) == -1
+
+
+def _tr16_model(image, byte_off):
+    """ds_read_b64_tr_b16 as csrc/ffno_platform.h documents it: within each 16-lane group, lane i receives element i & 3 of the
+    8-byte pieces addressed by lanes 4 r + (i >> 2), r = 0..3."""
+    out = np.zeros((64, 4), np.uint16)
+    for lane in range(64):
+        grp, i = lane & ~15, lane & 15
+        for r in range(4):
+            out[lane, r] = image[byte_off[grp + 4 * r + (i >> 2)] // 2 + (i & 3)]
+    return out
+
+
+@pytest.mark.parametrize("pattern", ["linear", "wgrad64", "wgrad32", "random"])
+def test_lds_transpose_read_map(be, pattern):
+    """The LDS transpose read the weight-gradient kernel takes its channel-major operands through (ffx.hip `tfrag`), lane by lane:
+    the hardware (-m gpu) and the emulator (-m "not gpu") against the documented map -- for lane-linear addresses (the canonical
+    [4][16] block), for the kernel's own address pattern at both widths (the channels of four pixel rows of the skewed pixel-major
+    plane -> MFMA A-operand slots) and for random 8-byte-aligned addresses."""
+    lib, p = be.lib, be.ptr
+    n16 = 8192
+    image = np.arange(n16, dtype=np.uint16) * 7 + 3
+    rs = np.random.RandomState(5)
+    lane = np.arange(64)
+    if pattern == "linear":
+        off = 8 * lane
+    elif pattern == "random":
+        off = 8 * rs.randint(0, n16 * 2 // 8, 64)
+    else:
+        prow = 192 if pattern == "wgrad64" else 64
+        half, g, i = lane >> 5, (lane >> 4) & 1, lane & 15
+        off = (4 * half + (i >> 2)) * prow + 16 * half + 32 * g + 8 * (i & 3) + (8 * prow + 32)      # (second read of a fragment)
+    off = off.astype(np.int32)
+    out = be.zeros((64, 4), np.uint16)
+    assert lib.ffno_lds_tr16_probe(p(be.put(image)), n16, p(be.put(off)), p(out), None) == 0
+    got = be.get(out).reshape(64, 4)
+    np.testing.assert_array_equal(got, _tr16_model(image, off))
+    if pattern.startswith("wgrad"):
+        # what the kernel relies on: lane l holds channel 16 g + i of pixel rows 8 + 4 half + {0, 1, 2, 3} of the skewed image
+        prow = 192 if pattern == "wgrad64" else 64
+        for l in range(64):
+            half, ch = l >> 5, l & 31
+            for r in range(4):
+                R = 8 + 4 * half + r
+                assert got[l, r] == image[(R * prow + 16 * ((R >> 2) & 3)) // 2 + ch]
