@@ -93,7 +93,7 @@ __device__ __forceinline__ unsigned pk_mul_f16(unsigned w, float k) {
 // words.  Written over two-element vectors so that the pair stays on the packed instructions wherever it is inlined
 // (v_cvt_pk_f16_f32, v_pk_add_f32, v_pk_mul_f32: six instructions per pair; written element by element the same code came out as
 // twelve scalar ones inside the feed-forward epilogues -- and those kernels issue ten vector instructions per MFMA).
-__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+__device__ __forceinline__ void split2_pair_pk(float x0, float x1, unsigned& h, unsigned& l) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2 x = {x0, x1};
@@ -101,6 +101,29 @@ __device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, uns
     const f32x2 r = (x - __builtin_convertvector(hv, f32x2)) * 2048.f;
     h = __builtin_bit_cast(unsigned, hv);
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+// The same split in FIVE instructions: v_cvt_pk_f16_f32, two v_mul_f32 (2^11 x) and the mixed-precision fma that reads h's halves
+// as fp16 operands and writes its fp32 result ROUNDED TO fp16 into one half of the destination (v_fma_mixlo / mixhi_f16):
+//     l = fp16(fma(h, -2^11, 2^11 x))  ==  fp16((x - h) 2^11)      (both arguments of the rounding are exact: bit-identical)
+// The compiler does not select these by itself (its SLP pass packs the pair into v_pk_fma_f32 first), so they are inline
+// assembly -- which the scheduler places as a block: a kernel takes this form only where that was measured to pay (the
+// weight-gradient tile loop with both epilogues merged: ffx.hip; MI355X round 5: -3 %; the same loop in its round-4 order: +6 %).
+__device__ __forceinline__ void split2_pair_mix(float x0, float x1, unsigned& h, unsigned& l) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 hv = {(_Float16)x0, (_Float16)x1};
+    h = __builtin_bit_cast(unsigned, hv);
+    const float y0 = x0 * 2048.f, y1 = x1 * 2048.f;
+    unsigned lo;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(h), "s"(-2048.f), "v"(y0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h), "s"(-2048.f), "v"(y1));
+    l = lo;
+}
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
+#if FFNO_X_MIX_ALL
+    split2_pair_mix(x0, x1, h, l);
+#else
+    split2_pair_pk(x0, x1, h, l);
+#endif
 }
 // two floats -> one word of bf16, round to nearest even (x0 in the low half): v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float x0, float x1) {

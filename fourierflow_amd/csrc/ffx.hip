@@ -1243,7 +1243,10 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
     static_assert(TWO == 0 || TWO == 1, "TWO = 1: s is the sum of two tensors");
     const float fscale = range_scale(*s_amax, 1, kFfRangeTarget);       // (the host side only takes this kernel WITH range words:
     const float gscale = range_scale(*db_amax, 1, kFfRangeTarget);      //  the 2^11 hi plane needs the 2^4 bound)
-    constexpr int BUF = 4 * T::PLANE;              // [s hi][s lo][db hi][db lo], pixel-major
+    // [s hi][s lo][db hi][db lo], pixel-major.  (The third plane of the single-accumulator product, hs = 2^11 hi, is made from hi
+    // after the LDS read: staged as a plane of its own it saves 44 of 280 vector instructions per wave and tile and costs 20 more
+    // LDS reads -- measured equal or slower, MI355X round 5: the launch is power-limited, see DESIGN.md.)
+    constexpr int BUF = 4 * T::PLANE;
     constexpr int OFF_SP = 0, OFF_DP = 2 * T::PLANE;
     __shared__ __attribute__((aligned(64))) char lds[2][BUF];
     __shared__ float4 red[F::NT];
@@ -1264,14 +1267,7 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         b1v[ch] = bias1[32 * (wave * CPW + ch) + j] * fscale;
     }
     // one product block of a staged (bounded) operand a with b on ONE accumulator: 2^11 x the fp32-grade product
-    auto mma3 = [&](const Hf2& a, const Hf2& b, f32x16& acc) {
-        u32x4 hs;
-        FFNO_UNROLL
-        for (int q = 0; q < 4; ++q) hs[q] = plat::pk_mul_f16(a.hi[q], kHf2Scale);
-        acc = plat::mfma_f16_32x32x16(a.lo, b.hi, acc);
-        acc = plat::mfma_f16_32x32x16(a.hi, b.lo, acc);
-        acc = plat::mfma_f16_32x32x16(hs, b.hi, acc);
-    };
+    auto mma3 = [&](const Hf3& a, const Hf2& b, f32x16& acc) { acc = mfma_h2s(a, b, acc); };
 
     // Staging: thread f owns 4 consecutive channels of pixel row f / (C / 4).  Branch-free: tiles past the end re-read the last
     // tile (their staged copy is never used); rows past the end of a ragged last tile re-read its last valid row and are zeroed
@@ -1313,8 +1309,15 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
             sp.x *= fs, sp.y *= fs, sp.z *= fs, sp.w *= fs;
             dp.x *= gs, dp.y *= gs, dp.z *= gs, dp.w *= gs;
             const int offp = T::row(R) + (f % (C / 4)) * 8;
-            stage4_s<SplitHf2>(lds[buf] + OFF_SP, T::PLANE, offp, sp.x, sp.y, sp.z, sp.w);
-            stage4_s<SplitHf2>(lds[buf] + OFF_DP, T::PLANE, offp, dp.x, dp.y, dp.z, dp.w);
+            uint2 ph, pl;
+            plat::split2_pair_mix(sp.x, sp.y, ph.x, pl.x);
+            plat::split2_pair_mix(sp.z, sp.w, ph.y, pl.y);
+            *reinterpret_cast<uint2*>(lds[buf] + OFF_SP + offp) = ph;
+            *reinterpret_cast<uint2*>(lds[buf] + OFF_SP + T::PLANE + offp) = pl;
+            plat::split2_pair_mix(dp.x, dp.y, ph.x, pl.x);
+            plat::split2_pair_mix(dp.z, dp.w, ph.y, pl.y);
+            *reinterpret_cast<uint2*>(lds[buf] + OFF_DP + offp) = ph;
+            *reinterpret_cast<uint2*>(lds[buf] + OFF_DP + T::PLANE + offp) = pl;
             bs2.x += dp.x, bs2.y += dp.y, bs2.z += dp.z, bs2.w += dp.w;
         }
     };
@@ -1343,7 +1346,7 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
         // channel-major fragment (mt, s2) of a tensor: rows = channels 32 mt + (lane & 31), k slots = pixels of k-step s2 in the
         // D-fragment order; two transpose reads per plane (k slots 0..3 / 4..7 = pixel rows +0 / +8)
         auto tfrag = [&](int off_tensor, int mt, int s2_) {
-            Hf2 f;
+            Hf3 f;
             FFNO_UNROLL
             for (int p = 0; p < 2; ++p) {
                 const char* base = L + off_tensor + p * T::PLANE + trow + s2_ * (16 * T::PROW + T::WRAP) + 64 * mt;
@@ -1351,53 +1354,73 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
                 const uint2 hi4 = plat::lds_read_tr16_b64(base + 8 * T::PROW + 32);
                 u32x4 w;
                 w[0] = lo4.x, w[1] = lo4.y, w[2] = hi4.x, w[3] = hi4.y;
-                SplitHf2::set_plane(f, p, w);
+                if (p == 0) f.hi = w;
+                if (p == 1) f.lo = w;
             }
+            FFNO_UNROLL
+            for (int q = 0; q < 4; ++q) f.hs[q] = plat::pk_mul_f16(f.hi[q], kHf2Scale);
+            return f;
+        };
+        // pixel-major fragment q of a tensor (rows = the tile's pixels, k = channels 16 q ..): hi / lo for the h GEMM, + hs for dh
+        auto pfrag = [&](int off_tensor, int q, bool with_hs) {
+            Hf3 f;
+            const char* base = L + off_tensor + prow + 32 * q;
+            f.hi = *reinterpret_cast<const u32x4*>(base);
+            f.lo = *reinterpret_cast<const u32x4*>(base + T::PLANE);
+            if (with_hs) {
+                FFNO_UNROLL
+                for (int q2 = 0; q2 < 4; ++q2) f.hs[q2] = plat::pk_mul_f16(f.hi[q2], kHf2Scale);
+            } else f.hs = f.hi;      // (never used: mfma_h2 takes hi / lo)
             return f;
         };
         // The 16 operand fragments of a tile, in the order the products consume them (s, db^T, db, s^T), come through a ring of
         // two: fragment i + 2 is requested when fragment i has been handed to its MFMAs, and the request is pinned there (a
         // scheduling barrier that only LDS reads may not cross) -- left alone the scheduler puts every read right in front of
         // its use and the wave waits out each LDS round trip.
+        // Order of a tile: both recompute GEMMs first (h from s, dh from db: pixel-major operands), then BOTH epilogues, then both
+        // pixel-contraction GEMMs (channel-major operands through the transpose read).  The MFMAs of the dh product have no
+        // dependence on the h epilogue, those of dW2 none on the dh epilogue, those of dW1 none on the next tile's staging: the
+        // scheduler has independent matrix work to put between the vector instructions of every phase.
         auto frag = [&](int i) {
             const int g = i / GS, q = i % GS;
-            if (g == 0) return lds_frag_s<SplitHf2>(L + OFF_SP, T::PLANE, prow + 32 * q);
-            if (g == 1) return tfrag(OFF_DP, q >> 1, q & 1);
-            if (g == 2) return lds_frag_s<SplitHf2>(L + OFF_DP, T::PLANE, prow + 32 * q);
+            if (g == 0) return pfrag(OFF_SP, q, false);
+            if (g == 1) return pfrag(OFF_DP, q, true);
+            if (g == 2) return tfrag(OFF_DP, q >> 1, q & 1);
             return tfrag(OFF_SP, q >> 1, q & 1);
         };
-        Hf2 ring[2];
+        Hf3 ring[2];
         ring[0] = frag(0), ring[1] = frag(1);
         FFNO_SCHED_PIN_DSREAD();
-        // the next tile's rows arrived during the previous iteration: convert + write them now -- vector / LDS work the scheduler
-        // places between the MFMAs of the h GEMM below
         stage(buf ^ 1, nt);
-        if constexpr (NWV == 8) {     // two waves per SIMD hide each other's round trips
+        if constexpr (NWV == 8) {
             gload(nt + nb);
             FFNO_SCHED_PIN_VMEM();
         }
-        // h^T[px][hid] = relu(s W1^T + b1), pixels on the D rows: main + correction tile, as in the forward kernel
-        f32x16 d[CPW], dc[CPW];
-        uint32_t bits = 0;
+        f32x16 d[CPW], dc[CPW], e[CPW];
         FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16(), dc[ch] = zero16();
+        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16(), dc[ch] = zero16(), e[ch] = zero16();
         static_assert(2 * CTO == KS, "fragment ring: C / 16 fragments per operand, pixel-major and channel-major alike");
         FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Hf2 a = ring[st & 1];
+        for (int st = 0; st < KS; ++st) {      // h^T[px][hid] = s W1^T: main + correction tile, as in the forward kernel
+            const Hf2 a = {ring[st & 1].hi, ring[st & 1].lo};
             ring[st & 1] = frag(0 * GS + st + 2);
             FFNO_SCHED_PIN_DSREAD();
             FFNO_UNROLL
             for (int ch = 0; ch < CPW; ++ch) mfma_h2(a, W1f[ch][st], d[ch], dc[ch]);
         }
-        // ... then request the tile after it, three quarters of an iteration + the staging phase of the next before its rows are
-        // used.  The fence keeps the requests HERE: left alone the scheduler sinks them to the end of the iteration, next to
-        // their use at the top of the next one, and the wave waits out every HBM round trip.
         if constexpr (NWV != 8) {
             gload(nt + nb);
             FFNO_SCHED_FENCE();
         }
-        Hf2 hb[CPW][2];
+        FFNO_UNROLL
+        for (int st = 0; st < KS; ++st) {      // 2^11 db W2 (unmasked dh)
+            const Hf3 a = ring[st & 1];
+            ring[st & 1] = frag(1 * GS + st + 2);
+            FFNO_SCHED_PIN_DSREAD();
+            FFNO_UNROLL
+            for (int ch = 0; ch < CPW; ++ch) mma3(a, W2f[ch][st], e[ch]);
+        }
+        Hf2 hb[CPW][2], gb[CPW][2];
         FFNO_UNROLL
         for (int ch = 0; ch < CPW; ++ch) {
             SplitHf2::fold(d[ch], dc[ch]);
@@ -1406,56 +1429,45 @@ __device__ __forceinline__ void ffh_wgrad_m_body(const typename ST::T* __restric
                 const float v = d[ch][r] + b1v[ch];
                 const bool pos = v > 0.f;
                 d[ch][r] = pos ? v : 0.f;
-                bits |= (pos ? 1u : 0u) << (16 * ch + r);
+                e[ch][r] = pos ? e[ch][r] * kHf2Unscale : 0.f;
+                bs1[ch] += e[ch][r];
             }
-            hb[ch][0] = split2_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
-            hb[ch][1] = split2_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
+            FFNO_UNROLL
+            for (int k2 = 0; k2 < 2; ++k2) {
+                FFNO_UNROLL
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    unsigned hh, ll;
+                    plat::split2_pair_mix(d[ch][8 * k2 + 2 * w2], d[ch][8 * k2 + 2 * w2 + 1], hh, ll);
+                    hb[ch][k2].hi[w2] = hh, hb[ch][k2].lo[w2] = ll;
+                    plat::split2_pair_mix(e[ch][8 * k2 + 2 * w2], e[ch][8 * k2 + 2 * w2 + 1], hh, ll);
+                    gb[ch][k2].hi[w2] = hh, gb[ch][k2].lo[w2] = ll;
+                }
+            }
         }
         FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) {
+        for (int mt = 0; mt < CTO; ++mt) {     // dW2[c][hid] += db^T h
             FFNO_UNROLL
             for (int s2_ = 0; s2_ < 2; ++s2_) {
                 const int q = 2 * mt + s2_;
-                const Hf2 a = ring[q & 1];
-                ring[q & 1] = frag(1 * GS + q + 2);
+                const Hf3 a = ring[q & 1];
+                ring[q & 1] = frag(2 * GS + q + 2);
                 FFNO_SCHED_PIN_DSREAD();
                 FFNO_UNROLL
                 for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2_], acc2[ch][mt]);
             }
         }
-        // dh^T[px][hid] = (db W2) * [h > 0]   (d = 2^11 x the product)
         FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) d[ch] = zero16();
-        FFNO_UNROLL
-        for (int st = 0; st < KS; ++st) {
-            const Hf2 a = ring[st & 1];
-            ring[st & 1] = frag(2 * GS + st + 2);
-            FFNO_SCHED_PIN_DSREAD();
-            FFNO_UNROLL
-            for (int ch = 0; ch < CPW; ++ch) mma3(a, W2f[ch][st], d[ch]);
-        }
-        FFNO_UNROLL
-        for (int ch = 0; ch < CPW; ++ch) {
-            FFNO_UNROLL
-            for (int r = 0; r < 16; ++r) {
-                d[ch][r] = ((bits >> (16 * ch + r)) & 1u) ? d[ch][r] * kHf2Unscale : 0.f;
-                bs1[ch] += d[ch][r];
-            }
-            hb[ch][0] = split2_8(d[ch][0], d[ch][1], d[ch][2], d[ch][3], d[ch][4], d[ch][5], d[ch][6], d[ch][7]);
-            hb[ch][1] = split2_8(d[ch][8], d[ch][9], d[ch][10], d[ch][11], d[ch][12], d[ch][13], d[ch][14], d[ch][15]);
-        }
-        FFNO_UNROLL
-        for (int mt = 0; mt < CTO; ++mt) {
+        for (int mt = 0; mt < CTO; ++mt) {     // dW1^T[c][hid] += s^T dh
             FFNO_UNROLL
             for (int s2_ = 0; s2_ < 2; ++s2_) {
                 const int q = 2 * mt + s2_;
-                const Hf2 a = ring[q & 1];
+                const Hf3 a = ring[q & 1];
                 if (q + 2 < GS) {
                     ring[q & 1] = frag(3 * GS + q + 2);
                     FFNO_SCHED_PIN_DSREAD();
                 }
                 FFNO_UNROLL
-                for (int ch = 0; ch < CPW; ++ch) mma3(a, hb[ch][s2_], acc1[ch][mt]);
+                for (int ch = 0; ch < CPW; ++ch) mma3(a, gb[ch][s2_], acc1[ch][mt]);
             }
         }
         __syncthreads();

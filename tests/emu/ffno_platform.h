@@ -39,6 +39,7 @@ inline void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
     h = pack_f16(x0, x1);
     l = pack_f16((x0 - f16_lo(h)) * 2048.f, (x1 - f16_hi(h)) * 2048.f);
 }
+inline void split2_pair_mix(float x0, float x1, unsigned& h, unsigned& l) { split2_pair(x0, x1, h, l); }
 inline unsigned pack_hi16(unsigned u0, unsigned u1) { return (u0 >> 16) | (u1 & 0xffff0000u); }
 inline unsigned pack_lo16(unsigned u0, unsigned u1) { return (u0 & 0xffffu) | (u1 << 16); }
 inline unsigned bf16_rne(float x) {      // IEEE round-to-nearest-even to bf16 (NaN stays NaN)
