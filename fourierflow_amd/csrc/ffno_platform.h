@@ -118,13 +118,8 @@ __device__ __forceinline__ void split2_pair_mix(float x0, float x1, unsigned& h,
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(h), "s"(-2048.f), "v"(y1));
     l = lo;
 }
-__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) {
-#if FFNO_X_MIX_ALL
-    split2_pair_mix(x0, x1, h, l);
-#else
-    split2_pair_pk(x0, x1, h, l);
-#endif
-}
+// (what every kernel but that loop uses: the whole step ran 183.6 / 184.1 steps/s with this form everywhere, 183.9 with the other)
+__device__ __forceinline__ void split2_pair(float x0, float x1, unsigned& h, unsigned& l) { split2_pair_pk(x0, x1, h, l); }
 // two floats -> one word of bf16, round to nearest even (x0 in the low half): v_cvt_pk_bf16_f32
 __device__ __forceinline__ unsigned pack_bf16(float x0, float x1) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
