@@ -409,7 +409,6 @@ def main():
                     help="operand split of the feed-forward kernels (default: the engine's, fp16x2)")
     ap.add_argument("--staged", action="store_true", help="spectral branches through the three stage kernels (HBM spectra) instead of the fused tile")
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
-    ap.add_argument("--x3-interleave", type=int, default=3, help="bit 0: even/odd workgroup->branch map; bit 1: image-local (XCD-aware) map where the shapes allow")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
     args = ap.parse_args()
@@ -470,7 +469,6 @@ def main():
         trainer.engine.use_fused = False
     if args.ff_split:
         trainer.engine.ff_split = args.ff_split
-    trainer.engine.x3_interleave = args.x3_interleave
     trainer.engine.storage = args.storage
     B, G = args.batch, args.grid
     gen = torch.Generator().manual_seed(1000 + rank)  # rank r draws its own shard of the global batch

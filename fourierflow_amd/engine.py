@@ -31,6 +31,12 @@ from . import _capi, _lib
 MODES = {"full": 0, "low-pass": 1, "no-fourier": 2}
 HEAD_DIM = 128  # grid_2d.py:150-152 / mesh_3d.py:155-157: WNLinear(width, 128) -> WNLinear(128, out)
 _SUPPORTED_CH = {(64, 256), (64, 128), (32, 128), (32, 64)}
+# paired spectral launch, workgroup -> (branch, tile) map (ffno_spectral_x3_pair `interleave`): bit 1 = image-local where the shapes
+# allow it (the workgroups that read one image share an XCD, so the image crosses HBM once: PMC traffic 178.9 -> 150.7 MB per launch,
+# round 2), else bit 0 = even workgroups branch a, odd ones branch b
+X3_INTERLEAVE = 3
+# all-layers feed-forward weight-gradient launch: rounds of resident workgroups (FF_WGRAD_ROUNDS x CUs / L slices per layer)
+FF_WGRAD_ROUNDS = 3
 
 
 def _fmix32(h: int) -> int:
@@ -204,18 +210,10 @@ class FFNOEngine:
         self._saved = None
         self._training = False
         self.use_fused = True   # fused A->B->C branch kernel when (C, K, L) fits its LDS tile; else 3 stage kernels
-        # feed-forward on the bf16 matrix cores at fp32 accuracy (ffx.hip: split-bf16, no stored hidden activations)
-        # when the library has the (C, H) instance; False = the fp32-MFMA kernels of ff.hip
-        self.use_ffx = True
         # operand split of those kernels: "fp16x2" (ffno_ffh_*: two fp16 planes, three MFMAs per product block -- half the matrix
         # work; gradients are range-scaled by a device-resident power of two taken from the loss gradient) or "bf16x3"
         # (ffno_ffx_*: three bf16 planes, six MFMAs, any fp32 range).  Both are fp32-grade (tests/test_kernels_ffh.py).
         self.ff_split = os.environ.get("FFNO_FF_SPLIT", "fp16x2")
-        # The first two spectral branches of a layer (and of its adjoint) run in ONE launch whose workgroups are co-resident
-        # (ffno_spectral_fused_pair), each into its own buffer; the feed-forward kernels that consume them add the two
-        # while staging (ffno_ffx_fwd2 / _bwd_data2).  Needs the split-bf16 feed-forward, no fork heads, and both axes on
-        # the fused kernel with the same [B, M, N] view (the 2-D operators).
-        self.concurrent_branches = True
         # fused branches on the bf16 matrix cores at fp32 accuracy (spectral_x3.hip: 16 or 8 lines per workgroup -- the library
         # picks 8 while the launch still fits one round of workgroups -- packed pre-split weights) for the axes the library
         # takes (C = 64, K <= 16); 17..32 modes go through the split-bf16 stage kernels
@@ -224,12 +222,9 @@ class FFNOEngine:
         # the size; gradient passes hold the spectrum tile range-scaled like the feed-forward) or "bf16x3"
         self.x3_mix_split = os.environ.get("FFNO_X3_MIX_SPLIT", "fp16x2")
         self._x3_fmt = None
-        # 17..64 modes: the fused kernel loads its DFT-matrix fragments from a table built once per (L, K, direction) instead of
-        # rebuilding them from the twiddle table for every line (bit-identical results; False = rebuild: tests)
-        self.x3_dft_tables = True
         self._dft_tabs = {}
         # feed-forward weight gradients of ALL layers as one launch after the backward loop (ffno_ffh_bwd_weights_partial_multi):
-        # every layer keeps its own gradient buffer instead of the ping-pong pair; `ff_wgrad_rounds` x resident workgroups / L
+        # every layer keeps its own gradient buffer instead of the ping-pong pair; FF_WGRAD_ROUNDS x resident workgroups / L
         # slices per layer
         self.ff_wgrad_deferred = os.environ.get("FFNO_FF_WGRAD_DEFERRED", "1") != "0"
         # ... and then the chain kernels leave the sums of their two input tensors unwritten (s_sum / db_sum NULL): every layer keeps
@@ -237,17 +232,10 @@ class FFNOEngine:
         #   "s": the forward's input sums only (the backward-data launch still writes its summed gradient);  "sg": both;  "0": none
         self.ff_lazy_sums = os.environ.get("FFNO_FF_LAZY_SUMS", "s")
         self.ff_schedule = int(os.environ.get("FFNO_FF_SCHED", "0"))      # ffno.h FFNO_FF_SCHED_* (0: the library's choice)
-        self.ff_wgrad_rounds = int(os.environ.get("FFNO_FF_WGRAD_ROUNDS", "3"))
-        self.x3_mix16 = os.environ.get("FFNO_X3_MIX16", "1") != "0"      # 16-row mix packs for the many-mode kernel (False: 32-row)
         self.x3_min_lines = 1
-        self.x3_tile_lines = 0      # lines per workgroup of the fused x3 kernel: 0 = the library chooses, 8 / 16 = forced (tests)
-        self.ff_max_workgroups = int(os.environ.get("FFNO_FF_MAX_WG", "0"))  # persistent workgroups of the feed-forward chain kernels: 0 = one per CU
         # workgroups (= partial slices) of the weight-gradient kernel: one per CU at width 64 (eight waves each), two per CU at
         # width 32 (four waves each: measured 157 -> 165 steps/s at 72^3 x 32 together with three chain workgroups per CU)
         self.ff_wgrad_slices = int(os.environ.get("FFNO_FF_WGRAD_SLICES", "512" if width == 32 else "256"))
-        # paired launch, workgroup -> (branch, tile) map: bit 1 = image-local where the shapes allow it (the workgroups that read
-        # one image share an XCD: the image crosses HBM once), else bit 0 = even workgroups branch a, odd ones branch b
-        self.x3_interleave = 3
         # one C call per layer and direction (ffno_layer_fwd / ffno_layer_bwd: paired branches + feed-forward) instead of two /
         # three; per-kernel timing (a timer attached) needs the individual calls
         self.use_layer_calls = True
@@ -273,7 +261,7 @@ class FFNOEngine:
         return 1 if self._bf16() else 0      # FFNO_STORE_F32 / FFNO_STORE_BF16
 
     def _conc(self) -> bool:
-        return bool(self.concurrent_branches and self._ffx() and not self.use_fork
+        return bool(self._ffx() and not self.use_fork
                     and self.mode != "no-fourier" and self.spectral == "factorized")
 
     @staticmethod
@@ -325,16 +313,16 @@ class FFNOEngine:
         bb = self._branch(v1, src, dst1, resid1, save1, planes1, 0, x3, fwd, rin, rout)
         if x3:       # planes0 / planes1 are the packed split-bf16 sets
             self._k(name, lib.ffno_spectral_x3_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj,
-                    int(self.x3_interleave), st)
+                    X3_INTERLEAVE, st)
             return
         self._k(name, lib.ffno_spectral_fused_pair, ctypes.byref(ba), ctypes.byref(bb), self.C, ck_f, ck_i, conj, st)
 
     def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True, rin=None, rout=None):
         """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
         fmt = int(getattr(v, "x3fmt", 1)) if (x3 and planes is not None and self._x3_h2()) else 0      # ffno.h FFNO_PLANES_*
-        dft = self._dft_frags(v.L, v.K, fwd) if (fmt and self.x3_dft_tables) else None
+        dft = self._dft_frags(v.L, v.K, fwd) if fmt else None
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout, self._st(), 0, _p(dft))
+                                 v.a01, acc, fmt, 0, rin if fmt else None, rout, self._st(), 0, _p(dft))
 
     def _dft_frags(self, L: int, K: int, fwd: bool):
         """DFT-matrix fragment table of the many-mode fused kernel for (axis length, modes, direction): built once per engine and
@@ -377,7 +365,7 @@ class FFNOEngine:
         return self.x3_mix_split == "fp16x2"
 
     def _ffx(self) -> bool:
-        return bool(self.use_ffx and not self.general_ff and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
+        return bool(not self.general_ff and _lib.get_lib().ffno_ffx_supported(self.C, self.H))
 
     def _h2(self) -> bool:
         if self.ff_split not in ("fp16x2", "bf16x3"):
@@ -388,14 +376,14 @@ class FFNOEngine:
     def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_fwd2 if self._h2() else lib.ffno_ffx_fwd2
-        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), int(self.ff_schedule), self._st())
+        o = _capi.FfOpts(rin, rout, 0, int(self.ff_schedule), self._st())
         self._k("ff_fwd", fn, _p(s), _p(s2), _p(s_sum), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out), _p(mask),
                 P, self.C, self.H, ctypes.byref(o), st)
 
     def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_bwd_data2 if self._h2() else lib.ffno_ffx_bwd_data2
-        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), int(self.ff_schedule), self._st())
+        o = _capi.FfOpts(rin, rout, 0, int(self.ff_schedule), self._st())
         self._k("ff_bwd_data", fn, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
                 P, self.C, self.H, ctypes.byref(o), st)
 
@@ -580,7 +568,7 @@ class FFNOEngine:
         are derived from besides the geometry: part of the workspace key, so an attribute switched on a live engine gets a
         workspace laid out for it instead of decisions frozen for the old value."""
         return (self._h2(), self._ranged(), bool(self.ff_wgrad_deferred), str(self.ff_lazy_sums), int(self.ff_wgrad_slices),
-                int(self.ff_wgrad_rounds), bool(self.use_x3), bool(self.use_fused))
+                bool(self.use_x3), bool(self.use_fused))
 
     def _workspace(self, B: int, S: Tuple[int, ...], save: bool):
         key = (B, tuple(S), bool(save), self._ffx(), self._conc(), self.general_ff, self._bf16(), self._sched_sig())
@@ -667,6 +655,12 @@ class FFNOEngine:
             ws.defer_wgrad = bool(self.ff_wgrad_deferred and self._ffx() and self._h2() and self._ranged() and not self.share_fork
                                   and not self.use_fork and not self.layer_norm and not self.general_ff
                                   and (C, H) in ((64, 256), (32, 128)) and self.mode != "no-fourier")
+            # (what the deferred launch costs in memory: L - 1 more gradient buffers, and with lazy sums L more branch images --
+            #  2 L P C words together, 1.7 GB at the headline shape.  Beyond FFNO_FF_DEFER_MAX_BYTES (default 16 GiB of the 288)
+            #  the engine keeps the ping-pong pair and per-layer launches: ADVICE r04.)
+            extra = 2 * L * P * C * (2 if self._bf16() else 4)
+            if extra > int(os.environ.get("FFNO_FF_DEFER_MAX_BYTES", str(16 << 30))):
+                ws.defer_wgrad = False
             ws.G = [torch.empty(P, C, **act) for _ in range(L + 1 if ws.defer_wgrad else 2)]
             if self.ff_lazy_sums not in ("s", "0", ""):
                 raise ValueError("ff_lazy_sums must be 's' or '0', got %r" % (self.ff_lazy_sums,))
@@ -676,7 +670,7 @@ class FFNOEngine:
             ws.SDall = [torch.empty(L, v.spec, **f32) for v in ws.views] if self.mode == "full" else None
             ws.nsplit_ff = max(1, min(int(self.ff_wgrad_slices), (P + 127) // 128))
             cus = torch.cuda.get_device_properties(dev).multi_processor_count if dev.type == "cuda" else 256
-            ws.nsplit_ffm = max(1, min(ws.nsplit_ff, (int(self.ff_wgrad_rounds) * (3 if H <= 128 else 1) * cus) // L))
+            ws.nsplit_ffm = max(1, min(ws.nsplit_ff, (FF_WGRAD_ROUNDS * (3 if H <= 128 else 1) * cus) // L))
             ws.wg_sig, ws.wg_table = None, None
             ws.ffpart = torch.empty(int(lib.ffno_ff_wgrad_partial_floats(C, H, ws.nsplit_ff)), **f32)
             # split-bf16 path with per-layer feed-forwards: every layer keeps its own slices and ONE batched launch
@@ -719,7 +713,7 @@ class FFNOEngine:
         # on the same weights) prepares them once -- five launches less per forward
         try:
             sig = (tuple((t.data_ptr(), t._version) for t in self.params.values()), self.ff_split, self.x3_mix_split,
-                   tuple(self._x3_fmt or ()), self.use_x3, self.use_ffx, getattr(st, "value", st))
+                   tuple(self._x3_fmt or ()), self.use_x3, getattr(st, "value", st))
         except RuntimeError:      # inference tensors (created under torch.inference_mode()) have no version counter:
             sig = None            # nothing to compare -- the operands are rebuilt by every forward, as before round 3
         if sig is not None and sig == getattr(self, "_prep_sig", None):
@@ -1028,7 +1022,7 @@ class FFNOEngine:
         # rows) when their DFT-fragment tables are in use and ALL axes are such and share a tile height (a paired launch carries one
         # format and one tile height)
         many = [v.K > 16 for v in ws.views]
-        m16 = bool(self.x3_mix16 and self.x3_dft_tables and C == 64 and all(many) and len({v.K <= 32 for v in ws.views}) == 1)
+        m16 = bool(C == 64 and all(many) and len({v.K <= 32 for v in ws.views}) == 1)
         self._x3_fmt = [(2 if (m16 and many[w]) else 1) if (self._x3_h2() and fused[w] and x3[w]) else 0 for w in range(len(ws.views))]
         for w, v in enumerate(ws.views):
             v.x3fmt = self._x3_fmt[w]
@@ -1110,10 +1104,10 @@ class FFNOEngine:
                                          x3pair, True, rx, rs_),
                             self._branch(ws.views[b], ws.X, t_l, None, keep[1], self._planes_for(si, b, 0, x3pair), 0, x3pair, True,
                                          rx, rs_),
-                            int(x3pair), int(self.x3_interleave), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
+                            int(x3pair), X3_INTERLEAVE, _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
                             _p(s_l) if (save_for_backward and not lazy) else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
                             _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()),
-                            int(self.ff_schedule), int(self.ff_max_workgroups), 0, 0, rxn)
+                            int(self.ff_schedule), 0, 0, 0, rxn)
                         self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
                         continue
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, t_l, None, keep[0], keep[1],
@@ -1293,11 +1287,11 @@ class FFNOEngine:
                                  self._planes_for(si, a, 1, x3pair), 0, x3pair, False, rd, rgo),
                     self._branch(ws.views[b], ws.DS, g1_out, None, ws.SDall[b][l] if full else None,
                                  self._planes_for(si, b, 1, x3pair), 0, x3pair, False, rd, rgo),
-                    int(x3pair), int(self.x3_interleave), _p(g_in), _p(g1_in) if have_g1 else None, _p(g_in),
+                    int(x3pair), X3_INTERLEAVE, _p(g_in), _p(g1_in) if have_g1 else None, _p(g_in),
                     _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
                     None if ws.wg_jobs is not None else _p(part), ws.nsplit_ff, P, C, H, int(self._h2()),
-                    int(self.ff_schedule), int(self.ff_max_workgroups), 0, rg, rs_, rd)
+                    int(self.ff_schedule), 0, 0, rg, rs_, rd)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
                 ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
                                     gv(fp + "layers.1.0.bias").data_ptr()))

@@ -1,5 +1,4 @@
-"""Forward latency of markov/24 at small batches, per tile choice of the fused split spectral kernel (8-line tiles, the
-4-line latency tiles, the library's own choice): the rollout's metric.  usage: python tools/bench_latency.py"""
+"""Forward latency of markov/24 at small batches (the rollout's metric).  usage: python tools/bench_latency.py"""
 import os
 import sys
 import time
@@ -17,8 +16,7 @@ tr = FFNOTrainer(blk)      # (binds the flat parameter buffer; predict() = engin
 eng = tr.engine
 for B in (1, 2, 4, 8):
     x = torch.randn(B, 64, 64, 3, device="cuda")
-    for tile in (8, 1, 0):
-        eng.x3_tile_lines = tile
+    for tile in ("library's choice",):
         for _ in range(5):
             tr.predict(x)
         torch.cuda.synchronize()
@@ -27,10 +25,9 @@ for B in (1, 2, 4, 8):
             tr.predict(x)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 100
-        print(f"batch {B} tile_lines {tile}: {1e3 * dt:.3f} ms / forward", flush=True)
+        print(f"batch {B} ({tile}): {1e3 * dt:.3f} ms / forward", flush=True)
 
 # the reference API path: nn.Module.__call__ under no_grad (host overhead of the module wrapper included)
-eng.x3_tile_lines = 0
 with torch.no_grad():
     for B in (1, 8):
         x = torch.randn(B, 64, 64, 3, device="cuda")
