@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 GPU sessions (stages by name; logs under gpurun_out/, merged back by gpurun).
+# Round-5 GPU sessions (stages by name; logs under gpurun_out/, merged back by gpurun).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -7,24 +7,24 @@ for st in "$@"; do
   case $st in
     ubench)
       timeout 120 tools/ubench/bin/stream_patterns > gpurun_out/ubench_stream.log 2>&1
-      echo "[r4] ubench rc=$?"; cat gpurun_out/ubench_stream.log ;;
+      echo "[r5] ubench rc=$?"; cat gpurun_out/ubench_stream.log ;;
     newtests)
       timeout 1500 python -m pytest tests/test_bench_geometry.py tests/test_trainer.py tests/test_rollout.py tests/test_capi_exports.py -m gpu -q -s --tb=short -p no:cacheprovider > gpurun_out/pytest_new.log 2>&1
-      echo "[r4] new tests rc=$?"; grep -E "^\[|passed|failed|Error|error" gpurun_out/pytest_new.log | tail -40 ;;
+      echo "[r5] new tests rc=$?"; grep -E "^\[|passed|failed|Error|error" gpurun_out/pytest_new.log | tail -40 ;;
     spectests)
       timeout 900 python -m pytest tests/test_kernels_spectral.py tests/test_storage_bf16.py -m gpu -q -x --tb=short -p no:cacheprovider > gpurun_out/pytest_spec.log 2>&1
-      echo "[r4] spectral tests rc=$?"; tail -n 4 gpurun_out/pytest_spec.log
+      echo "[r5] spectral tests rc=$?"; tail -n 4 gpurun_out/pytest_spec.log
       timeout 900 python -m pytest tests/test_bench_geometry.py -m gpu -q -s --tb=short -p no:cacheprovider -k "B32 or 12L or mesh3d or bf16" > gpurun_out/pytest_geo.log 2>&1
-      echo "[r4] geometry tests rc=$?"; grep -E "^\[|passed|failed" gpurun_out/pytest_geo.log | tail -12 ;;
+      echo "[r5] geometry tests rc=$?"; grep -E "^\[|passed|failed" gpurun_out/pytest_geo.log | tail -12 ;;
     sq256)
       # SQ counters of the 256 x 256 / 64-mode step (its own PMC pass: kernel-trace + pmc only)
       rm -rf gpurun_out/pmc_SQ256
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d "$OLDPWD/gpurun_out/pmc_SQ256" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2 > "$OLDPWD/gpurun_out/pmc_SQ256.log" 2>&1)
-      echo "[r4] pmc SQ256 rc=$?"
+      echo "[r5] pmc SQ256 rc=$?"
       db=$(find gpurun_out/pmc_SQ256 -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_SQ256.md 2>&1; head -n 14 gpurun_out/pmc_SQ256.md | cut -c1-260
       rm -rf gpurun_out/pmc_SQ2
       (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d "$OLDPWD/gpurun_out/pmc_SQ2" -o ffno -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2 > "$OLDPWD/gpurun_out/pmc_SQ2.log" 2>&1)
-      echo "[r4] pmc SQ2 rc=$?"; tail -n 3 gpurun_out/pmc_SQ2.log | cut -c1-200
+      echo "[r5] pmc SQ2 rc=$?"; tail -n 3 gpurun_out/pmc_SQ2.log | cut -c1-200
       db=$(find gpurun_out/pmc_SQ2 -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_SQ2.md 2>&1; head -n 14 gpurun_out/pmc_SQ2.md | cut -c1-260
       find gpurun_out/pmc_SQ256 gpurun_out/pmc_SQ2 -name "*.db" -size +20M -delete ;;
     profall)
@@ -33,10 +33,10 @@ for st in "$@"; do
         tag=$1; shift; n=$1; shift
         rm -rf gpurun_out/prof_$tag
         (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_$tag" -o p -- "$@" > "$OLDPWD/gpurun_out/prof_$tag.log" 2>&1)
-        echo "[r4] rocprof $tag rc=$?"
-        db=$(find gpurun_out/prof_$tag -name "*.db" | head -1); python tools/rocpd_stats.py "$db" $n > gpurun_out/r04_${tag}_kernel_stats.md 2>&1
-        head -n 12 gpurun_out/r04_${tag}_kernel_stats.md | cut -c1-150
-        [ "$tag" = markov24 ] && python tools/rocpd_idle.py "$db" > gpurun_out/r04_markov24_step_idle.md 2>&1
+        echo "[r5] rocprof $tag rc=$?"
+        db=$(find gpurun_out/prof_$tag -name "*.db" | head -1); python tools/rocpd_stats.py "$db" $n > gpurun_out/r05_${tag}_kernel_stats.md 2>&1
+        head -n 12 gpurun_out/r05_${tag}_kernel_stats.md | cut -c1-150
+        [ "$tag" = markov24 ] && python tools/rocpd_idle.py "$db" > gpurun_out/r05_markov24_step_idle.md 2>&1
         find gpurun_out/prof_$tag -type f -size +1M -delete
       }
       R=$PWD
@@ -52,7 +52,7 @@ for st in "$@"; do
         for c in FETCH_SIZE WRITE_SIZE; do
           rm -rf gpurun_out/pmc_${tag}_$c
           (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $c -d "$OLDPWD/gpurun_out/pmc_${tag}_$c" -o p -- "$@" > "$OLDPWD/gpurun_out/pmc_${tag}_$c.log" 2>&1)
-          echo "[r4] pmc $tag $c rc=$?"
+          echo "[r5] pmc $tag $c rc=$?"
         done
         f=$(find gpurun_out/pmc_${tag}_FETCH_SIZE -name "*.db" | head -1); w=$(find gpurun_out/pmc_${tag}_WRITE_SIZE -name "*.db" | head -1)
         (cd tools && python make_pmc_traffic.py "../$f" "../$w" "${FFNO_GIT_HEAD:-unknown}" "$label") > gpurun_out/pmc_traffic_$tag.json
@@ -67,14 +67,14 @@ for st in "$@"; do
       ;;
     final)
       timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
-      echo "[r4] smoke rc=$?"; tail -n 2 gpurun_out/smoke.log
+      echo "[r5] smoke rc=$?"; tail -n 2 gpurun_out/smoke.log
       timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err
-      echo "[r4] bench rc=$?"; tail -n 4 gpurun_out/bench.err
+      echo "[r5] bench rc=$?"; tail -n 4 gpurun_out/bench.err
       timeout 1700 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
-      echo "[r4] pytest -m gpu rc=$?"; tail -n 6 gpurun_out/pytest_gpu.log ;;
+      echo "[r5] pytest -m gpu rc=$?"; tail -n 6 gpurun_out/pytest_gpu.log ;;
     benchfast)
       timeout 600 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/bench_fast.log 2> gpurun_out/bench_fast.err
-      echo "[r4] benchfast rc=$?"; tail -n 12 gpurun_out/bench_fast.err; python - <<'PY'
+      echo "[r5] benchfast rc=$?"; tail -n 12 gpurun_out/bench_fast.err; python - <<'PY'
 import json
 try:
     d = json.loads(open("gpurun_out/bench_fast.log").read().strip().splitlines()[-1])
