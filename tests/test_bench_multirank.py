@@ -14,8 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gpus,extra,scaling,gbatch", [(2, [], "weak", 16), (2, ["--global-batch", "16"], "strong", 16),
-                                                       (8, ["--global-batch", "256"], "strong", 256)])
+@pytest.mark.parametrize("gpus,extra,scaling,gbatch", [(2, [], "weak", 16), (8, ["--global-batch", "256"], "strong", 256)])
 def test_bench_multi_rank_dry_run(gpus, extra, scaling, gbatch):
     """2 ranks (weak / strong) and the shape of BASELINE config 2 itself: 8 ranks, global batch 256 -- so the first
     run on an 8-GPU node only changes the backend."""
