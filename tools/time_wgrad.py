@@ -25,6 +25,11 @@ b1 = (torch.randn(H, generator=g) * 0.1).to(dev)
 sa = [torch.randn(P, C, generator=g).to(dev) * 0.5 for _ in range(2)]
 sb = [torch.randn(P, C, generator=g).to(dev) * 0.5 for _ in range(2)]
 gg = [torch.randn(P, C, generator=g).to(dev) * 1e-3 for _ in range(2)]
+if os.environ.get("WG_ZERO") == "1":      # all-zero activations and gradients: the same instruction stream on operands that toggle nothing
+    for t in sa + sb + gg:
+        t.zero_()
+    sa[0][0, 0] = 1.0
+    gg[0][0, 0] = 1.0      # (non-zero range words)
 ref = None
 for path in libs:
     lib = ctypes.CDLL(path)
