@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //     buffers of the paired adjoint launch), added -- and rounded to the storage format, as the chain kernels do -- while the
 //     rows are staged: the chain kernels then need not write the sums back (one image write less per launch: 44.6 -> 39.1 us
 //     forward, 41.4 -> 33.4 us backward-data with the wave-tile kernels, MI355X round 4).
-//     TWO = 1: only s is a sum (db single), TWO = 2: both.
+//     TWO = 1: s is such a sum (db is single: a second gradient addend, round 4's TWO = 2, was measured slower and removed).
 // Round 5: the CHANNEL-MAJOR operands come from the pixel-major tile through the LDS transpose read.  Until round 4 every tile was
 // staged twice -- pixel-major (float4 rows) and channel-major (four scalar loads per thread and tensor, a second split, a second
 // set of LDS planes); a timing-only build without the second copy ran 35 % faster.  gfx950's ds_read_b64_tr_b16 hands a 16-lane

@@ -229,7 +229,8 @@ class FFNOEngine:
         self.ff_wgrad_deferred = os.environ.get("FFNO_FF_WGRAD_DEFERRED", "1") != "0"
         # ... and then the chain kernels leave the sums of their two input tensors unwritten (s_sum / db_sum NULL): every layer keeps
         # both branch outputs and both gradient buffers, the weight-gradient launch adds them while it stages its rows
-        #   "s": the forward's input sums only (the backward-data launch still writes its summed gradient);  "sg": both;  "0": none
+        #   "s": the forward's input sums (the backward-data launch still writes its summed gradient: leaving that one out too was
+        #   measured slower, round 4);  "0": none
         self.ff_lazy_sums = os.environ.get("FFNO_FF_LAZY_SUMS", "s")
         self.ff_schedule = int(os.environ.get("FFNO_FF_SCHED", "0"))      # ffno.h FFNO_FF_SCHED_* (0: the library's choice)
         self.x3_min_lines = 1
