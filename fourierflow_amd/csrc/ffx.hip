@@ -1202,19 +1202,19 @@ __global__ __launch_bounds__((FxCfg<C, H>::NT)) void ffx_wgrad_kernel(const floa
 //   * branch-free tile loop (one basic block: the scheduler interleaves staging / epilogue vector work with the MFMAs).
 //   * the body takes its slice index and slice count as arguments (bid of nb): the per-layer launch passes its block index and
 //     grid size, the all-layers launch (ffh_wgrad_m_multi_kernel below) the position inside its layer's slices.
-//   * TWO: s and db are each the SUM of two tensors (the two branch outputs of the paired spectral launch; the two gradient
-//     buffers of the paired adjoint launch), added -- and rounded to the storage format, as the chain kernels do -- while the
-//     rows are staged: the chain kernels then need not write the sums back (one image write less per launch: 44.6 -> 39.1 us
-//     forward, 41.4 -> 33.4 us backward-data with the wave-tile kernels, MI355X round 4).
-//     TWO = 1: s is such a sum (db is single: a second gradient addend, round 4's TWO = 2, was measured slower and removed).
+//   * TWO = 1: s is the SUM of two tensors (the two branch outputs of the paired spectral launch), added -- and rounded to the
+//     storage format, as the chain kernel does -- while the rows are staged: the forward chain kernel then need not write the sum
+//     back (one image write less per launch: 46.1 -> 38.2 us with the wave-tile kernels, +2.5 % on the step, MI355X round 5);
+//     s is such a sum (db is single: a second gradient addend, round 4's TWO = 2, was measured slower and removed).
 // Round 5: the CHANNEL-MAJOR operands come from the pixel-major tile through the LDS transpose read.  Until round 4 every tile was
 // staged twice -- pixel-major (float4 rows) and channel-major (four scalar loads per thread and tensor, a second split, a second
-// set of LDS planes); a timing-only build without the second copy ran 35 % faster.  gfx950's ds_read_b64_tr_b16 hands a 16-lane
+// set of LDS planes).  gfx950's ds_read_b64_tr_b16 hands a 16-lane
 // group the TRANSPOSE of a [4 rows][16 halves] block: lane i of the group receives element i of each of the four rows, and the
 // rows are wherever lanes 4 r .. 4 r + 3 of the group point (8 bytes each).  Four pixel rows x 16 channels of a pixel-major fp16
 // plane are therefore one read away from the A operand of the pixel-contraction GEMMs (rows = channels, k = pixels), in exactly
 // the k order of the D-fragment operand on the other side (slot e <-> pixel 16 s2 + (e & 3) + 8 (e >> 2) + 4 half).  Same fp16
-// planes, same products in the same order: the slices are bit-identical to the twice-staged kernel.
+// planes, same products in the same order: the W1 / W2 / b1 slices are bit-identical to the twice-staged kernel (b2 is summed in
+// another order).  1387 -> 1186 us per all-layers launch under rocprofv3; the launch is power-limited.
 //   LDS image of one plane: row R (pixel) at  R * PROW + 16 ((R >> 2) & 3) + WRAP (R >> 4),  PROW = 192 (C = 64) / 64 (C = 32):
 //   * a transpose read touches rows 4 a .. 4 a + 3 over 64 bytes each: R * PROW mod 256 are four different multiples of 64;
 //   * a pixel-major ds_read_b128 touches 16 rows with different R mod 16 at one column: their 16-byte slots mod 256 are
