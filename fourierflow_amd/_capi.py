@@ -60,6 +60,11 @@ class LayerBwdDesc(C.Structure):
                 ("ff_kernel", C.c_int32), ("ff_schedule", C.c_int32), ("ff_max_workgroups", C.c_int32), ("pad_", C.c_int32), ("g_amax", P), ("s_amax", P), ("ds_amax", P)]
 
 
+class AmaxDesc(C.Structure):
+    """Mirror of ``ffno_amax_desc`` (include/ffno.h)."""
+    _fields_ = [("x", P), ("n", C.c_size_t)]
+
+
 class FxRedDesc(C.Structure):
     """Mirror of ``ffno_fxred_desc`` (include/ffno.h)."""
     _fields_ = [("partial", P), ("dW1", P), ("dW2", P), ("db1", P), ("db2", P)]
@@ -105,6 +110,7 @@ SIGNATURES = {
     "ffno_build_target": (C.c_char_p, []),
     "ffno_abi_version": (I, []),
     "ffno_amax": (I, [P, SZ, P, P]),
+    "ffno_amax_batched": (I, [P, I, SZ, P, P]),
     "ffno_lds_tr16_probe": (I, [P, I, P, P, P]),
     "ffno_twiddle_fill_host": (I, [P, I]),
     "ffno_dft_fwd": (I, [P, P, P, I, I, I, I, I, I, I, P]),

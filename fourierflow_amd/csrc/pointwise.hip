@@ -584,6 +584,28 @@ extern "C" int ffno_amax(const float* x, size_t n, uint32_t* word, void* stream)
     return e == hipSuccess ? FFNO_OK : (int)e;
 }
 
+// the same for n tensors in ONE launch (descs is a DEVICE array): blockIdx.y = tensor, all folded into one word
+struct AmaxDesc {
+    const float* x;
+    size_t n;
+};
+__global__ __launch_bounds__(256) void amax_batched_kernel(const AmaxDesc* __restrict__ descs, unsigned* word) {
+    __shared__ float red[4];
+    const AmaxDesc d = descs[blockIdx.y];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(d.x[i]));
+    range_fold(m, red, 4, word);
+}
+extern "C" int ffno_amax_batched(const ffno_amax_desc* descs_dev, int n, size_t max_n, uint32_t* word, void* stream) {
+    static_assert(sizeof(ffno_amax_desc) == sizeof(AmaxDesc), "descriptor layout");
+    if (!descs_dev || !word || n <= 0 || max_n == 0) return FFNO_EINVAL;
+    const int blocks = (int)std::min<size_t>(64, (max_n + 1023) / 1024);
+    FFNO_LAUNCH(amax_batched_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream,
+                reinterpret_cast<const AmaxDesc*>(descs_dev), word);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? FFNO_OK : (int)e;
+}
+
 extern "C" const char* ffno_build_target(void) {
     return FFNO_BUILD_TARGET;
 }

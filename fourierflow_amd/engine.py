@@ -802,8 +802,14 @@ class FFNOEngine:
                 srcs += [self.params[p + "weight"] for p in self.linears if "_ff." in p and p + "weight" in self.params]
         if fp16_mix:
             srcs += [self.params[n] for names in self._fw_sets for n in names]
-        for t in srcs:
-            self._k("amax", lib.ffno_amax, _p(t), t.numel(), _p(self._wr_word), st)
+        # ONE launch for all of them (per-layer Fourier weights are 2-3 tensors per layer: the airfoil model issued 49 of these
+        # 4-us launches per step until round 5); the descriptor table is rebuilt when a tensor moved
+        sig = tuple((t.data_ptr(), t.numel()) for t in srcs)
+        if sig != self.__dict__.get("_wr_sig"):
+            arr = (_capi.AmaxDesc * len(sig))(*[_capi.AmaxDesc(ptr, n) for ptr, n in sig])
+            self._wr_table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(self.device)
+            self._wr_sig = sig
+        self._k("amax", lib.ffno_amax_batched, _p(self._wr_table), len(sig), max(n for _, n in sig), _p(self._wr_word), st)
         ev = None
         if self.device.type == "cuda":
             self._wr_host.copy_(self._wr_word, non_blocking=True)
@@ -1217,7 +1223,9 @@ class FFNOEngine:
         ws.red_jobs = []
         nG = len(ws.G)
         # deferred weight-gradient launch: (s, summed gradient, packs, words, slices) of every layer, one launch after the loop
-        ws.wg_jobs = [] if (getattr(ws, "defer_wgrad", False) and conc) else None
+        # (paired launches or not: the airfoil mesh -- a 32-mode axis beside a 16-mode one, two launches per layer -- ran 24 per-layer
+        #  weight-gradient launches of 56 us until round 5)
+        ws.wg_jobs = [] if getattr(ws, "defer_wgrad", False) else None
         if lazy_s and ws.wg_jobs is None:
             raise RuntimeError("the forward pass left the feed-forward input sums to a deferred weight-gradient launch that this "
                                "backward pass cannot run")
@@ -1320,6 +1328,7 @@ class FFNOEngine:
                 self._ffg_bwd(ws, fp, "backcast", l, ws.S[l], g_ff, ws.DS, int(fp in ff_seen), P, st, rd)
             else:
                 self._ff_bwd_data(g_ff, ws.MASK[l], l0, l1, dh, ws.DS, P, st, rg, rd)
+                self._wg_second = None
             if not self.general_ff:
                 self._ff_bwd_weights(ws, ws.S[l], g_ff, ws.Hbuf[l], dh, l0, l1, self.params[fp + "layers.0.0.bias"],
                                      gv(fp + "layers.0.0.bias"), gv(fp + "layers.1.0.bias"), int(fp in ff_seen), P, st, rs_, rg)

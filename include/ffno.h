@@ -78,6 +78,12 @@ int ffno_abi_version(void);
 
 /* word[0] = max(word[0], bits(max |x[i]|)): folds a tensor into a range word (see "Range words" above) */
 int ffno_amax(const float* x, size_t n, uint32_t* word, void* stream);
+/* the same for n tensors in one launch (descs is a DEVICE array; max_n = the largest descs[i].n): every tensor is folded into word[0] */
+typedef struct ffno_amax_desc {
+    const float* x;
+    size_t n;
+} ffno_amax_desc;
+int ffno_amax_batched(const ffno_amax_desc* descs_dev, int n, size_t max_n, uint32_t* word, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Twiddle table for a transform of length L (host helper, double precision -> fp32):

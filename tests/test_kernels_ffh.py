@@ -82,6 +82,22 @@ def test_amax_folds_and_accumulates(be):
     assert lib.ffno_amax(None, 4, p(w), None) == -1 and lib.ffno_amax(p(w), 0, p(w), None) == -1
 
 
+def test_amax_batched_folds_every_tensor(be):
+    """ffno_amax_batched: n tensors (any lengths) folded into one word by one launch -- what the engine's weight-range check issues."""
+    from fourierflow_amd._capi import AmaxDesc
+    lib, p = be.lib, be.ptr
+    rs = np.random.RandomState(7)
+    xs = [rs.standard_normal(n).astype(np.float32) * sc for n, sc in ((5, 1.0), (4099, 3.0), (70000, 0.5), (1, 2.0))]
+    xs[1][77] = -41.5
+    devs = [be.put(x) for x in xs]
+    descs = (AmaxDesc * len(xs))(*[AmaxDesc(p(d), x.size) for d, x in zip(devs, xs)])
+    table = be.put(np.frombuffer(bytes(descs), dtype=np.uint8))
+    w = be.zeros(1, np.uint32)
+    assert lib.ffno_amax_batched(p(table), len(xs), max(x.size for x in xs), p(w), None) == 0
+    assert np.asarray(be.get(w)).view(np.float32)[0] == 41.5
+    assert lib.ffno_amax_batched(None, 1, 4, p(w), None) == -1 and lib.ffno_amax_batched(p(table), 0, 4, p(w), None) == -1
+
+
 @pytest.mark.parametrize("sched", [0, FFNO_FF_SCHED_IN_PHASE])
 @pytest.mark.parametrize("P,C,H", [(70, 64, 256), (33, 32, 128), (64, 64, 128), (40, 32, 64), (5000, 64, 256), (200, 64, 256)])
 def test_ffh_fwd_bwd(be, P, C, H, sched):
