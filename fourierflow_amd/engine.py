@@ -1401,7 +1401,11 @@ class FFNOEngine:
             real = int(self.spectral == "dct")
             for w in range(len(ws.views)):
                 v = ws.views[w]
-                pstride = ws.nsplit_fw[w] * 2 * v.K * C * C
+                # slices per (layer, mode): the grid is slices x modes x LAYERS here, so the per-axis count of the shared-weight
+                # launch (512 / K) would make 12 288 workgroups of 37 lines each at the airfoil shape and 384 MB of partial
+                # slices for the reduce launch to read back; ~512 workgroups in all are enough
+                nsf = max(1, min(ws.nsplit_fw[w], -(-512 // (v.K * L))))
+                pstride = nsf * 2 * v.K * C * C
                 if getattr(ws, "fwpart_multi", None) is None:
                     ws.fwpart_multi, ws.fwgrad_tab, ws.fwgrad_sig = {}, {}, {}
                 if w not in ws.fwpart_multi:
@@ -1411,9 +1415,9 @@ class FFNOEngine:
                     ws.fwgrad_tab[w] = torch.tensor(ptrs, dtype=torch.int64).to(self.device)
                     ws.fwgrad_sig[w] = ptrs
                 self._k("fw_grad_partial", lib.ffno_fw_grad_partial_multi, _p(ws.SXall[w]), _p(ws.SDall[w]),
-                        _p(ws.fwpart_multi[w]), v.R, C, v.K, ws.nsplit_fw[w], L, v.spec, v.spec, pstride, st)
+                        _p(ws.fwpart_multi[w]), v.R, C, v.K, nsf, L, v.spec, v.spec, pstride, st)
                 self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce_multi, _p(ws.fwpart_multi[w]), _p(ws.fwgrad_tab[w]), L, C, v.K,
-                        ws.nsplit_fw[w], pstride, 0, real, st)
+                        nsf, pstride, 0, real, st)
         for si, names in enumerate(self._fw_sets if not multi else []):
             layers = [l for l in range(L) if self.fw_names[l] == names]
             l0_, nl = layers[0], len(layers)
