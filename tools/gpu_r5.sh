@@ -70,7 +70,7 @@ for st in "$@"; do
       echo "[r5] smoke rc=$?"; tail -n 2 gpurun_out/smoke.log
       timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err
       echo "[r5] bench rc=$?"; tail -n 4 gpurun_out/bench.err
-      timeout 1700 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider -s > gpurun_out/pytest_gpu.log 2>&1
+      timeout 1700 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider -s --durations=25 > gpurun_out/pytest_gpu.log 2>&1
       echo "[r5] pytest -m gpu rc=$?"; tail -n 6 gpurun_out/pytest_gpu.log ;;
     benchfast)
       timeout 600 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/bench_fast.log 2> gpurun_out/bench_fast.err
