@@ -52,7 +52,7 @@ def oracle_block_run(kw, seed, B, M, N, dtype=torch.float32, relu_masks=None, io
     return out, loss, grads
 
 
-def relu_flips(kw, seed, B, M, N, masks, io=None, sd_np=None):
+def relu_flips(kw, seed, B, M, N, masks, io=None, sd_np=None, return_out=False):
     """Number of hidden units on which the oracle's OWN fp32 ReLU decisions differ from the HIP path's active sets
     (``masks`` = engine_relu_masks(engine)), over every backcast feed-forward of the block, evaluated along the oracle's
     unmodified forward.  Zero flips = the two implementations sit on the same linear piece of the network, so their
@@ -64,8 +64,8 @@ def relu_flips(kw, seed, B, M, N, masks, io=None, sd_np=None):
             sd_np = gu.make_block_state_dict(kw, seed) if sd_np is None else sd_np
             x_np, _ = io if io is not None else gu.make_block_io(kw, seed, B, M, N)
             sd, _ = torch_state_dict(sd_np, torch.float32, requires_grad=False)
-            orc.ffno2d_block(sd, torch.tensor(x_np), modes=kwf["modes"], n_layers=kwf["n_layers"], use_fork=kwf["use_fork"],
-                             mode=kwf["mode"], n_ff_layers=kwf["n_ff_layers"], layer_norm=kwf["layer_norm"])
+            plain = orc.ffno2d_block(sd, torch.tensor(x_np), modes=kwf["modes"], n_layers=kwf["n_layers"], use_fork=kwf["use_fork"],
+                                     mode=kwf["mode"], n_ff_layers=kwf["n_ff_layers"], layer_norm=kwf["layer_norm"])
     finally:
         orc.RELU_TRACE = None
     flips, layer = 0, {"backcast": 0, "forecast": 0}
@@ -79,6 +79,8 @@ def relu_flips(kw, seed, B, M, N, masks, io=None, sd_np=None):
             continue        # with fork heads the last backcast only feeds the dead x_L: the HIP path does not evaluate it
         if key in masks:
             flips += int((active.reshape(-1) != masks[key][0].reshape(-1)).sum())
+    if return_out:      # (the oracle's own, unmasked forward: callers that also want it do not run the oracle a third time)
+        return flips, plain
     return flips
 
 
