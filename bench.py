@@ -595,6 +595,34 @@ def main():
                               frac_hbm_floor_8d=round(w["floor"] / us * 1e-3 / HBM_PEAK_GBS, 3),
                               intensity_flop_per_byte=round(inten, 1), ridge_flop_per_byte=round(ridge, 1),
                               bound="hbm" if inten < ridge else "mfma")
+        # The all-layers weight-gradient launch is POWER-limited (profiles/r05_wgrad_sq_counters.md): the same
+        # launch -- same instruction stream, same addresses -- on all-zero activations and gradients runs at a higher shader clock.
+        # Measured live here so that the line carries the effect: the workspace tensors it reads are zeroed (the next training step
+        # of the variant legs below rewrites every one of them) and the captured launch is replayed.
+        try:
+            wcalls = probe.calls.get("ff_bwd_weights_partial") or []
+            ws_ = getattr(trainer.engine, "_ws", None)
+            if headline and len(wcalls) == 1 and ws_ is not None and getattr(ws_, "wg_jobs", None):
+                for t in [ws_.S] + list(getattr(ws_, "TS", [])) + list(ws_.G):
+                    t.zero_()
+                fn_, a_ = wcalls[0]
+                for _ in range(3):
+                    fn_(*a_)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(50):
+                    fn_(*a_)
+                e1.record()
+                torch.cuda.synchronize()
+                zus = 1e3 * e0.elapsed_time(e1) / 50
+                kernels["ff_bwd_weights_partial"].update(
+                    zero_operand_us=round(zus, 2),
+                    power_note="the same captured launch replayed on all-zero activations / gradients: fewer toggling bits -> a higher "
+                               "shader clock; avg_us / zero_operand_us = what the power limit costs this launch on real data")
+                log(f"weight-gradient launch on zeroed operands: {zus:.1f} us (real data: {kernels['ff_bwd_weights_partial']['avg_us']} us)")
+        except Exception as e:  # noqa: BLE001 - optional evidence
+            log(f"zero-operand replay skipped: {e!r}")
         # dominant kernel = the entry point with the largest share of the step (forward and adjoint launches of one kernel
         # symbol are one entry)
         share = {}
