@@ -595,32 +595,36 @@ def main():
                               frac_hbm_floor_8d=round(w["floor"] / us * 1e-3 / HBM_PEAK_GBS, 3),
                               intensity_flop_per_byte=round(inten, 1), ridge_flop_per_byte=round(ridge, 1),
                               bound="hbm" if inten < ridge else "mfma")
-        # The all-layers weight-gradient launch is POWER-limited (profiles/r05_wgrad_sq_counters.md): the same
-        # launch -- same instruction stream, same addresses -- on all-zero activations and gradients runs at a higher shader clock.
-        # Measured live here so that the line carries the effect: the workspace tensors it reads are zeroed (the next training step
-        # of the variant legs below rewrites every one of them) and the captured launch is replayed.
+        # Power: the same captured launches replayed on ALL-ZERO activations, spectra and gradients (same instruction streams, same
+        # addresses, real weights; fewer toggling bits -> the chip grants a higher shader clock).  For the all-layers weight-gradient
+        # launch the busy cycles and instruction counters are identical either way and only the clock differs (1.68 vs 2.11 GHz:
+        # profiles/r05_wgrad_sq_counters.md); measured live here for every hot launch so that the line carries
+        # what the power limit costs on real data.  The workspace tensors are zeroed in place: the next training step of the
+        # variant legs below rewrites every one of them.
+        power_note = None
         try:
-            wcalls = probe.calls.get("ff_bwd_weights_partial") or []
             ws_ = getattr(trainer.engine, "_ws", None)
-            if headline and len(wcalls) == 1 and ws_ is not None and getattr(ws_, "wg_jobs", None):
-                for t in [ws_.S] + list(getattr(ws_, "TS", [])) + list(ws_.G):
-                    t.zero_()
-                fn_, a_ = wcalls[0]
-                for _ in range(3):
-                    fn_(*a_)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
-                for _ in range(50):
-                    fn_(*a_)
-                e1.record()
-                torch.cuda.synchronize()
-                zus = 1e3 * e0.elapsed_time(e1) / 50
-                kernels["ff_bwd_weights_partial"].update(
-                    zero_operand_us=round(zus, 2),
-                    power_note="the same captured launch replayed on all-zero activations / gradients: fewer toggling bits -> a higher "
-                               "shader clock; avg_us / zero_operand_us = what the power limit costs this launch on real data")
-                log(f"weight-gradient launch on zeroed operands: {zus:.1f} us (real data: {kernels['ff_bwd_weights_partial']['avg_us']} us)")
+            if headline and ws_ is not None:
+                def _zero(v):
+                    if torch.is_tensor(v):
+                        if v.is_floating_point():
+                            v.zero_()
+                    elif isinstance(v, (list, tuple)):
+                        for u in v:
+                            _zero(u)
+                    elif isinstance(v, dict):
+                        for u in v.values():
+                            _zero(u)
+                for v in list(vars(ws_).values()):
+                    _zero(v)
+                rep0 = probe.replay(50)
+                for n, us0 in rep0.items():
+                    if n in kernels:
+                        kernels[n]["zero_operand_us"] = round(us0, 2)
+                power_note = ("kernels.*.zero_operand_us: the same captured launch replayed 50 x on all-zero activations / spectra / "
+                              "gradients (real weights): avg_us / zero_operand_us = what the power limit costs the launch on real data "
+                              "(identical busy cycles, higher shader clock: profiles/r05_wgrad_sq_counters.md)")
+                log("zero-operand replays: " + ", ".join(f"{n} {us0:.1f} (real {kernels[n]['avg_us']})" for n, us0 in rep0.items() if n in kernels))
         except Exception as e:  # noqa: BLE001 - optional evidence
             log(f"zero-operand replay skipped: {e!r}")
         # dominant kernel = the entry point with the largest share of the step (forward and adjoint launches of one kernel
@@ -832,7 +836,7 @@ def main():
             "samples_per_s": round(opt_steps_per_s * B * world, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5), "git_head": git_head(), "lib_source_stamp": lib_source_stamp(),
-            "roofline": roofline, "kernels": kernels, "arithmetic_variants_steps_per_s": variants,
+            "roofline": roofline, "kernels": kernels, "power_note": power_note, "arithmetic_variants_steps_per_s": variants,
             "bf16_storage_variant": bf16_variant, "cpu_baseline": cpu,
             "secondary": secondary, "distributed": dist_info,
         }
