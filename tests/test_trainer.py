@@ -108,6 +108,23 @@ def test_arithmetic_switched_on_a_live_trainer_equals_a_fresh_engine(host_device
     assert bool(fresh.engine._ws.defer_wgrad) and len(tr.engine._ws_cache) >= 2      # (one workspace per arithmetic)
 
 
+def test_deferred_launch_falls_back_beyond_its_memory_limit(host_device, monkeypatch):
+    """the all-layers weight-gradient launch keeps one gradient buffer per layer (and, with lazy sums, both branch
+    outputs of every layer).  Beyond FFNO_FF_DEFER_MAX_BYTES the engine keeps the ping-pong pair and per-layer launches -- same
+    golden losses."""
+    monkeypatch.setenv("FFNO_FF_DEFER_MAX_BYTES", "1")
+    g = gu.load_golden("train_c64_2l")
+    kw = gu.golden_kwargs(g)
+    B, M, N, seed, steps = [int(v) for v in g["meta"]]
+    blk, tr = make_trainer(kw, seed, host_device)
+    for s in range(steps):
+        x_np, t_np = gu.make_block_io(kw, seed + 1 + s, B, M, N)
+        loss = tr.train_step(torch.from_numpy(x_np).to(host_device), torch.from_numpy(t_np).to(host_device))
+        assert abs(loss.item() - float(g["losses"][s])) < 2e-5 * max(1.0, float(g["losses"][s]))
+    ws = tr.engine._ws
+    assert not ws.defer_wgrad and len(ws.G) == 2 and ws.wg_jobs is None and not getattr(ws, "lazy_sums", "")
+
+
 def test_load_state_dict_on_a_trainer_bound_module_is_seen(host_device):
     """FFNOTrainer re-points the module's parameters at its flat buffer (``p.data = view``), which keeps every
     Parameter's own version counter -- ``load_state_dict`` / ``p.copy_()`` bump that counter only, and an engine bound to the
