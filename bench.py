@@ -411,6 +411,9 @@ def main():
     ap.add_argument("--no-x3", action="store_true", help="spectral branches on the fp32-MFMA kernel instead of the split-bf16 one")
     ap.add_argument("--plus", action="store_true", help="FNOPlus2DBlock (non-factorized ablation) instead of the F-FNO block; "
                                                        "no roofline / CPU baseline for this secondary workload")
+    ap.add_argument("--n1-steps-per-s", type=float, default=0.0,
+                    help="the `value` of the same command at --gpus 1 (same per-GPU batch for weak scaling, same global batch for "
+                         "strong scaling): the line then carries `efficiency_vs_n1` = value / (gpus x n1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -505,6 +508,7 @@ def main():
         marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     per_step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -513,15 +517,35 @@ def main():
     if rank == 0:
         log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
     loss_val = float(loss.item())
+    # N > 1: what every rank saw of the timed region -- device time of its own steps (min / median / max) and its wall time -- so
+    # that a first multi-GPU record decomposes itself (a slow rank, a slow step, or the collective)
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([per_step_ms[0], per_step_ms[len(per_step_ms) // 2], per_step_ms[-1], 1e3 * elapsed_local],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        per_rank = [dict(rank=r, step_ms_min=round(float(t[0]), 3), step_ms_median=round(float(t[1]), 3),
+                         step_ms_max=round(float(t[2]), 3), region_wall_ms=round(float(t[3]), 3)) for r, t in enumerate(allr)]
     # the instrumented pass: the same steps again (every rank runs them: the step holds a collective), brackets on rank 0
     trainer.engine.timer = probe
     if probe:
         probe.sample = True
+    comm_ev = [] if (world > 1 and rank == 0) else None
+    trainer.comm_events = comm_ev
     for i in range(args.steps):
         trainer.train_step(x, y)
     sync()
+    trainer.comm_events = None
     if probe:
         probe.sample = False
+    allreduce_us = None
+    if comm_ev:
+        us = sorted(1e3 * a.elapsed_time(b) for a, b in comm_ev)
+        allreduce_us = dict(min=round(us[0], 1), median=round(us[len(us) // 2], 1), max=round(us[-1], 1), samples=len(us),
+                            bytes=int(trainer.pflat.numel() * 4),
+                            note="HIP events on rank 0's launch stream around the step's one all_reduce (instrumented pass after the "
+                                 "timed region): includes the wait for the slowest rank's backward pass")
 
     # forward-only latency (the reference's `infer` path), same batch
     trainer.engine.timer = None
@@ -625,6 +649,13 @@ def main():
                               "gradients (real weights): avg_us / zero_operand_us = what the power limit costs the launch on real data "
                               "(identical busy cycles, higher shader clock: profiles/r05_wgrad_sq_counters.md)")
                 log("zero-operand replays: " + ", ".join(f"{n} {us0:.1f} (real {kernels[n]['avg_us']})" for n, us0 in rep0.items() if n in kernels))
+                # the cached workspace now holds zeros beside stale non-zero range words: one untimed training step rewrites every
+                # tensor of it before anything else (a later replay, a forward-only timing) can read them
+                tm_, trainer.engine.timer = trainer.engine.timer, None
+                w_, trainer.world = trainer.world, 1
+                trainer.train_step(x, y)
+                trainer.world, trainer.engine.timer = w_, tm_
+                torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001 - optional evidence
             log(f"zero-operand replay skipped: {e!r}")
         # dominant kernel = the entry point with the largest share of the step (forward and adjoint launches of one kernel
@@ -803,6 +834,9 @@ def main():
                 ver = None
             dist_info = dict(world_size=torch.distributed.get_world_size(), world_size_counted_by_all_reduce=rccl_world,
                              backend=torch.distributed.get_backend(), rccl_version=ver, hip=torch.version.hip,
+                             per_rank=per_rank, allreduce_us=allreduce_us,
+                             efficiency_vs_n1=(round(steps_per_s / (world * args.n1_steps_per_s), 4) if args.n1_steps_per_s > 0 else None),
+                             n1_steps_per_s=(args.n1_steps_per_s or None),
                              launch="one process per GPU (torch.distributed.run; `python bench.py --gpus N` spawns them itself)")
             if dist_info["backend"] == "nccl" and not ver:
                 raise SystemExit("backend nccl (= RCCL on ROCm) but torch reports no RCCL version: not an RCCL run, no line printed")

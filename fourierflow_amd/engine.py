@@ -233,6 +233,9 @@ class FFNOEngine:
         #   measured slower, round 4);  "0": none
         self.ff_lazy_sums = os.environ.get("FFNO_FF_LAZY_SUMS", "s")
         self.ff_schedule = int(os.environ.get("FFNO_FF_SCHED", "0"))      # ffno.h FFNO_FF_SCHED_* (0: the library's choice)
+        # cap on the persistent workgroups of a feed-forward chain launch (ffno_ff_opts.max_workgroups and the field of the layer
+        # descriptors; 0 = one per CU, the library's choice): for callers that share the device with another stream
+        self.ff_max_workgroups = 0
         self.x3_min_lines = 1
         # workgroups (= partial slices) of the weight-gradient kernel: one per CU at width 64 (eight waves each), two per CU at
         # width 32 (four waves each: measured 157 -> 165 steps/s at 72^3 x 32 together with three chain workgroups per CU)
@@ -377,14 +380,14 @@ class FFNOEngine:
     def _ffs_fwd2(self, s, s2, s_sum, resid, l0, b0, b1, out, mask, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_fwd2 if self._h2() else lib.ffno_ffx_fwd2
-        o = _capi.FfOpts(rin, rout, 0, int(self.ff_schedule), self._st())
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), int(self.ff_schedule), self._st())
         self._k("ff_fwd", fn, _p(s), _p(s2), _p(s_sum), _p(resid), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1), _p(out), _p(mask),
                 P, self.C, self.H, ctypes.byref(o), st)
 
     def _ffs_bwd2(self, g, g2, g_sum, mask, l0, ds, P, st, rin=None, rout=None):
         lib = _lib.get_lib()
         fn = lib.ffno_ffh_bwd_data2 if self._h2() else lib.ffno_ffx_bwd_data2
-        o = _capi.FfOpts(rin, rout, 0, int(self.ff_schedule), self._st())
+        o = _capi.FfOpts(rin, rout, int(self.ff_max_workgroups), int(self.ff_schedule), self._st())
         self._k("ff_bwd_data", fn, _p(g), _p(g2), _p(g_sum), _p(mask), _p(l0.fx[2]), _p(l0.fx[3]), _p(ds),
                 P, self.C, self.H, ctypes.byref(o), st)
 
@@ -697,6 +700,21 @@ class FFNOEngine:
         cache[key] = ws
         while len(cache) > 4:
             cache.pop(next(iter(cache)))
+        return ws
+
+    def _forward_workspace(self, B: int, S: Tuple[int, ...]):
+        """The workspace the last ``forward(save_for_backward=True)`` filled.  A schedule / arithmetic attribute switched since then
+        (``ff_split``, ``x3_mix_split``, ``ff_wgrad_deferred``, ``ff_lazy_sums``, ``use_x3``, ``use_fused``, ``storage``, slice
+        counts) would select ANOTHER workspace -- whose saved tensors were never written: refuse instead of differentiating
+        uninitialised memory."""
+        ws = getattr(self, "_saved_ws", None)
+        if ws is None:
+            raise RuntimeError("backward() needs a preceding forward(save_for_backward=True)")
+        key = (B, tuple(S), True, self._ffx(), self._conc(), self.general_ff, self._bf16(), self._sched_sig())
+        if key != self._saved_ws_key:
+            raise RuntimeError("an engine attribute that shapes the workspace (ff_split / x3_mix_split / ff_wgrad_deferred / "
+                               "ff_lazy_sums / ff_wgrad_slices / use_x3 / use_fused / storage) changed between forward() and "
+                               "backward(): run the forward pass again")
         return ws
 
     def weights_changed(self):
@@ -1114,7 +1132,7 @@ class FFNOEngine:
                             int(x3pair), X3_INTERLEAVE, _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
                             _p(s_l) if (save_for_backward and not lazy) else None, None if last else _p(ws.X), _p(ws.Blast if last else ws.X),
                             _p(ws.MASK[sv]) if save_for_backward else None, P, C, H, int(self._h2()),
-                            int(self.ff_schedule), 0, 0, 0, rxn)
+                            int(self.ff_schedule), int(self.ff_max_workgroups), 0, 0, rxn)
                         self._k("layer_fwd", lib.ffno_layer_fwd, ctypes.byref(d), st)
                         continue
                     self._pair("spectral_fused", ws, ws.views[a], ws.views[b], ws.X, s_l, t_l, None, keep[0], keep[1],
@@ -1163,6 +1181,11 @@ class FFNOEngine:
             self._k("head_fwd", lib.ffno_head_fwd_bf16 if bf16 else lib.ffno_head_fwd, _p(ws.Blast), _p(self.fold), _p(ws.Y),
                     ws.P_in, C, self.O, 0, pm, st)
         self._saved = (x, B, S, fused, conc) if save_for_backward else None
+        # the workspace this pass filled (saved tensors, sign bits, range words): the backward pass and the diagnostic readers use
+        # THIS object -- an attribute switched between forward() and backward() changes the workspace key, and a freshly
+        # allocated workspace would hand them uninitialised memory
+        self._saved_ws = ws if save_for_backward else None
+        self._saved_ws_key = self._ws_key if save_for_backward else None
         self._saved_x3 = (x3, x3pair)
         self._saved_sched = (singles, pair)
         self._saved_lazy = lazy
@@ -1183,7 +1206,7 @@ class FFNOEngine:
         gy = gy.contiguous()
         lib = _lib.get_lib()
         C, H, L = self.C, self.H, self.L
-        ws = self._workspace(B, S, True)
+        ws = self._forward_workspace(B, S)
         lazy_s = bool(getattr(self, "_saved_lazy", False))            # forward input sums left to the weight-gradient launch
         st = _lib.current_stream(self.device)
         rw = self._rw
@@ -1300,7 +1323,7 @@ class FFNOEngine:
                     _p(ws.MASK[l]),
                     _p(l0.fx[2]), _p(l0.fx[3]), _p(ws.DS), _p(ws.S[l]), _p(l0.fx[0]), _p(self.params[fp + "layers.0.0.bias"]),
                     None if ws.wg_jobs is not None else _p(part), ws.nsplit_ff, P, C, H, int(self._h2()),
-                    int(self.ff_schedule), 0, 0, rg, rs_, rd)
+                    int(self.ff_schedule), int(self.ff_max_workgroups), 0, rg, rs_, rd)
                 self._k("layer_bwd", lib.ffno_layer_bwd, ctypes.byref(d), st)
                 ws.red_jobs.append((part.data_ptr(), l0.gweff.data_ptr(), l1.gweff.data_ptr(), gv(fp + "layers.0.0.bias").data_ptr(),
                                     gv(fp + "layers.1.0.bias").data_ptr()))
@@ -1404,11 +1427,12 @@ class FFNOEngine:
                 # slices per (layer, mode): the grid is slices x modes x LAYERS here, so the per-axis count of the shared-weight
                 # launch (512 / K) would make 12 288 workgroups of 37 lines each at the airfoil shape and 384 MB of partial
                 # slices for the reduce launch to read back; ~512 workgroups in all are enough
-                nsf = max(1, min(ws.nsplit_fw[w], -(-512 // (v.K * L))))
+                fwg = int(os.environ.get("FFNO_FW_GRAD_WGS", "512"))      # the knob that sizes ws.nsplit_fw, here per (layer, mode)
+                nsf = max(1, min(-(-fwg // (v.K * L)), (v.R + 63) // 64))
                 pstride = nsf * 2 * v.K * C * C
                 if getattr(ws, "fwpart_multi", None) is None:
                     ws.fwpart_multi, ws.fwgrad_tab, ws.fwgrad_sig = {}, {}, {}
-                if w not in ws.fwpart_multi:
+                if w not in ws.fwpart_multi or ws.fwpart_multi[w].numel() != L * pstride:
                     ws.fwpart_multi[w] = torch.empty(L * pstride, dtype=torch.float32, device=self.device)
                 ptrs = tuple(gv(self._fw_sets[l][w]).data_ptr() for l in range(L))
                 if ws.fwgrad_sig.get(w) != ptrs:
@@ -1447,14 +1471,14 @@ class FFNOEngine:
         ``threshold_backward`` of feedforward.py:17 would see.  Split-bf16 feed-forward only."""
         if self._saved is not None and self.general_ff:
             _, B, S, _, _ = self._saved
-            ws = self._workspace(B, S, True)
+            ws = self._forward_workspace(B, S)
             # a LIST per block: one active set per hidden activation; with dropout a dropped unit counts as inactive
             return {(kind, l): [(h > 0).to(torch.uint8) for h in ws.HG[kind][l]] for kind in ws.HG for l in range(self.L)
                     if not (kind == "backcast" and self.use_fork and l == self.L - 1)}
         if self._saved is None or not self._ffx():
             raise RuntimeError("relu_active_sets() needs a preceding forward(save_for_backward=True) on the ffx path")
         _, B, S, _, _ = self._saved
-        ws = self._workspace(B, S, True)
+        ws = self._forward_workspace(B, S)
         lib = _lib.get_lib()
         st = _lib.current_stream(self.device)
         out = {}
@@ -1475,7 +1499,7 @@ class FFNOEngine:
         if self._saved is None:
             raise RuntimeError("dropout_keep_sets() needs a preceding forward(save_for_backward=True)")
         _, B, S, _, _ = self._saved
-        ws = self._workspace(B, S, True)
+        ws = self._forward_workspace(B, S)
         lib = _lib.get_lib()
         st = _lib.current_stream(self.device)
         out = {}

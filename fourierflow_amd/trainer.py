@@ -113,7 +113,14 @@ class FFNOTrainer:
             # or overlapped on purpose: the buffer is complete only after the last backward kernel (weight-norm backward
             # reads the reduced feed-forward gradients), 4.3 MB over xGMI is ~0.1-0.2 ms of an ~7 ms step, and a second
             # collective would add its own launch latency.
+            ev = getattr(self, "comm_events", None)      # optional: a list that receives (start, stop) device events (bench.py)
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             torch.distributed.all_reduce(gflat, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            if ev is not None:
+                e1.record()       # (the launch stream waits for the collective's stream: the pair brackets it)
+                ev.append((e0, e1))
         lr_t = self.current_lr()
         self.step_count += 1
         self.opt_step += 1

@@ -21,12 +21,18 @@ def test_bench_multi_rank_dry_run(gpus, extra, scaling, gbatch):
     env = dict(os.environ, FFNO_BENCH_ONE_DEVICE="1")
     env.pop("RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--batch", "8",
-           "--cpu-steps", "0", "--no-secondary"] + extra
+           "--cpu-steps", "0", "--no-secondary", "--n1-steps-per-s", "100"] + extra
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
+    # the N > 1 line decomposes itself -- every rank's step times, the collective's own time, efficiency vs N = 1
+    dd = d["distributed"]
+    assert len(dd["per_rank"]) == gpus and [p["rank"] for p in dd["per_rank"]] == list(range(gpus))
+    assert all(0 < p["step_ms_min"] <= p["step_ms_median"] <= p["step_ms_max"] and p["region_wall_ms"] > 0 for p in dd["per_rank"])
+    assert dd["allreduce_us"]["samples"] == 2 and 0 < dd["allreduce_us"]["min"] <= dd["allreduce_us"]["max"]
+    assert abs(dd["efficiency_vs_n1"] - d["value"] / (gpus * 100.0)) < 1e-3
     assert d["n_gpus"] == gpus and d["scaling"] == scaling and d["steps"] == 2
     assert d["distributed"]["world_size"] == gpus and d["distributed"]["world_size_counted_by_all_reduce"] == gpus
     assert d["distributed"]["backend"] == "gloo"      # (the dry run; under RCCL the line must carry rccl_version: bench.py refuses else)

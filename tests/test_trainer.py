@@ -108,6 +108,41 @@ def test_arithmetic_switched_on_a_live_trainer_equals_a_fresh_engine(host_device
     assert bool(fresh.engine._ws.defer_wgrad) and len(tr.engine._ws_cache) >= 2      # (one workspace per arithmetic)
 
 
+def test_backward_uses_the_workspace_its_forward_filled(host_device):
+    """the workspace key carries the schedule attributes, and backward() used to re-derive its workspace from
+    the CURRENT attributes -- a switch between forward(save_for_backward=True) and backward() handed it a freshly allocated
+    workspace (uninitialised saved tensors, sign bits, range words: garbage gradients, no error).  The pass now keeps the
+    workspace object it filled: an unchanged engine gets exactly that object (even after another geometry went through the
+    cache in between), a changed one is refused."""
+    g = gu.load_golden("train_c64_2l")
+    kw = gu.golden_kwargs(g)
+    B, M, N, seed, _ = [int(v) for v in g["meta"]]
+    blk, tr = make_trainer(kw, seed, host_device)
+    eng = tr.engine
+    x_np, t_np = gu.make_block_io(kw, seed + 1, B, M, N)
+    x = torch.from_numpy(x_np).to(host_device)
+    out = eng.forward(x, True)
+    ws = eng._saved_ws
+    assert ws is eng._ws
+    gy = torch.ones_like(out)
+    ref = eng.backward(gy).clone()
+    # a validation-sized forward in between moves the engine's current workspace; the saved one is still the forward's
+    out = eng.forward(x, True)
+    ws = eng._saved_ws
+    eng._workspace(1, (M, N), False)
+    assert eng._ws is not ws
+    again = eng.backward(gy)
+    assert eng._saved_ws is ws
+    np.testing.assert_array_equal(again.cpu().numpy(), ref.cpu().numpy())
+    # an arithmetic switch between the two passes: refused (it used to differentiate uninitialised memory)
+    eng.forward(x, True)
+    eng.ff_split = "bf16x3"
+    with pytest.raises(RuntimeError, match="changed between forward"):
+        eng.backward(gy)
+    eng.ff_split = "fp16x2"
+    np.testing.assert_array_equal(eng.backward(gy).cpu().numpy(), ref.cpu().numpy())
+
+
 def test_deferred_launch_falls_back_beyond_its_memory_limit(host_device, monkeypatch):
     """the all-layers weight-gradient launch keeps one gradient buffer per layer (and, with lazy sums, both branch
     outputs of every layer).  Beyond FFNO_FF_DEFER_MAX_BYTES the engine keeps the ping-pong pair and per-layer launches -- same

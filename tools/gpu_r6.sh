@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-6 GPU sessions (stages by name; logs under gpurun_out/, merged back by gpurun).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for st in "$@"; do
+  case $st in
+    powerprobe)
+      # which power / clock sources can an ordinary user read on this box?
+      {
+        echo "== sysfs hwmon"; for d in /sys/class/drm/card*/device/hwmon/hwmon*; do echo "$d"; ls "$d" 2>/dev/null | tr '\n' ' '; echo; for f in power1_average power1_input power1_cap freq1_input freq2_input temp1_input; do [ -r "$d/$f" ] && echo "$f=$(cat $d/$f 2>&1)"; done; done
+        echo "== pp_dpm"; for c in /sys/class/drm/card*/device; do for f in pp_dpm_sclk pp_dpm_mclk gpu_busy_percent; do [ -r "$c/$f" ] && { echo "$c/$f"; cat "$c/$f" 2>&1 | head -12; }; done; done
+        echo "== gpu_metrics"; ls -la /sys/class/drm/card*/device/gpu_metrics 2>&1
+        echo "== amd-smi"; which amd-smi; timeout 60 amd-smi metric -p -c --json 2>&1 | head -60
+        echo "== rocm-smi"; which rocm-smi; timeout 60 rocm-smi --showpower --showclocks --json 2>&1 | head -40
+      } > gpurun_out/powerprobe.log 2>&1
+      echo "[r6] powerprobe rc=$?"; head -c 6000 gpurun_out/powerprobe.log ;;
+    benchfast)
+      timeout 900 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > gpurun_out/bench_fast.log 2> gpurun_out/bench_fast.err
+      echo "[r6] benchfast rc=$?"; tail -n 12 gpurun_out/bench_fast.err; python - <<'PY'
+import json
+try:
+    d = json.loads(open("gpurun_out/bench_fast.log").read().strip().splitlines()[-1])
+    print({k: d.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "ms_per_step_min", "ms_per_forward", "ms_per_forward_batch1", "git_head", "lib_source_stamp")})
+    print("roofline", {k: d["roofline"].get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us", "traffic")})
+    print("roofline_forward", d.get("roofline_forward"))
+    print({n: k["avg_us"] for n, k in d["kernels"].items()})
+    for s in d["secondary"] or []:
+        print(s.get("workload", "?")[:50], s.get("value"), s.get("spectral") or s.get("roofline"), s.get("kernel_us_replay"))
+except Exception as e:
+    print("parse error", e)
+PY
+      ;;
+    *) echo "[r6] unknown stage $st" ;;
+  esac
+done
