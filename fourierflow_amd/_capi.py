@@ -9,7 +9,7 @@ import ctypes as C
 
 # generation of include/ffno.h these signatures and struct mirrors belong to (FFNO_ABI_VERSION there; _lib.check_abi compares
 # it with what the loaded library reports before anything is called)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 P = C.c_void_p
 I = C.c_int
@@ -58,6 +58,13 @@ class LayerBwdDesc(C.Structure):
                 ("g", P), ("g2", P), ("g_sum", P), ("mask", P), ("pk1b", P), ("pk2b", P), ("ds", P), ("s", P), ("pk1", P),
                 ("b1", P), ("partial", P), ("nsplit", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
                 ("ff_kernel", C.c_int32), ("ff_schedule", C.c_int32), ("ff_max_workgroups", C.c_int32), ("pad_", C.c_int32), ("g_amax", P), ("s_amax", P), ("ds_amax", P)]
+
+
+class LayerInferDesc(C.Structure):
+    """Mirror of ``ffno_layer_infer_desc`` (include/ffno.h)."""
+    _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("interleave", C.c_int32), ("pad_", C.c_int32),
+                ("pk1", P), ("b1", P), ("pk2", P), ("b2", P), ("resid", P), ("out", P), ("C", C.c_int32), ("H", C.c_int32),
+                ("out_amax", P)]
 
 
 class AmaxDesc(C.Structure):
@@ -134,6 +141,11 @@ SIGNATURES = {
     "ffno_spectral_x3_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_layer_fwd": (I, [P, P]),
     "ffno_layer_bwd": (I, [P, P]),
+    "ffno_infer_mix_bytes": (SZ, [I, I, I]),
+    "ffno_layer_infer_supported": (I, [I, I, I, I, I, I, I]),
+    "ffno_spectral_x3_mix_pair": (I, [P, P, I, I, P]),
+    "ffno_infer_ff": (I, [P, P, P, P, P, P, P, P, I, I, P, P]),
+    "ffno_layer_infer": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P]),

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libffno_hip.so")
-SOURCES = ["spectral.hip", "spectral_x3.hip", "ff.hip", "ffx.hip", "pointwise.hip", "velocity.hip", "spectral2d.hip", "plin.hip", "layer.hip", "layernorm.hip", "glin.hip"]
+SOURCES = ["spectral.hip", "spectral_x3.hip", "ff.hip", "ffx.hip", "pointwise.hip", "velocity.hip", "spectral2d.hip", "plin.hip", "layer.hip", "layernorm.hip", "glin.hip", "infer.hip"]
 ARCH = "gfx950"
 
 

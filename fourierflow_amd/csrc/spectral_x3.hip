@@ -27,6 +27,7 @@
 
 #include "ffno_device.h"
 #include "ffno_lines.h"
+#include "ffno_x3_dft.h"
 #include "ffno.h"
 
 namespace ffno {
@@ -57,6 +58,11 @@ struct X3Args {
     unsigned* out_amax;
     // many-mode kernel only: precomputed DFT-matrix fragments (x3k_dft_frags_kernel), NULL = built from the twiddle table
     const u32x4* dft;
+    // MIXOUT instances (the inference layer's first kernel, infer.hip): the MIXED spectrum of every line leaves the launch instead
+    // of its inverse transform -- as the split-fp16 operand fragments the second kernel multiplies (mix_out: 8 fragments of 64 lanes
+    // x 16 B per line) beside the factor that turns its accumulators into samples (mix_scale: one float per line)
+    u32x4* mix_out;
+    float* mix_scale;
 };
 
 // ---- weight packing --------------------------------------------------------------------------------------------------
@@ -129,18 +135,6 @@ __device__ __forceinline__ Bf3 x3_load_frag(const u32x4* __restrict__ pk, int fr
 //   forward  part: fragment ((rt * nchunks + chunk) * 4 + u)      rt < RT = KKT / 32, chunk < nchunks, u < 4
 //   inverse  part: fragment (nfwd + tile * NST + st)               tile < ceil(L / 32), st < NST = KKT / 16
 // Values = exactly the expressions of spectral_x3k_body's on-the-fly path (bit-identical results with and without a table).
-struct X3kDft {
-    int KKT, RT, NST, nchunks, ntiles, nfwd;
-};
-static inline X3kDft x3k_dft_layout(int L, int K) {
-    X3kDft d;
-    d.KKT = K <= 16 ? 32 : (K <= 32 ? 64 : 128);      // (<= 16 modes: the latency kernel's tile height)
-    d.RT = d.KKT / 32, d.NST = d.KKT / 16;
-    d.nchunks = (L + 63) >> 6, d.ntiles = (L + 31) >> 5;
-    d.nfwd = d.RT * d.nchunks * 4;
-    return d;
-}
-
 __global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restrict__ tw, int L, int K, int fwd_ck, int inv_ck,
                                                            X3kDft d, u32x4* __restrict__ out) {
     const int frag = blockIdx.x, lane = threadIdx.x, j = lane & 31, half = lane >> 5;
@@ -171,16 +165,6 @@ __global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restri
     out[(frag * 2 + 0) * 64 + lane] = h.hi;
     out[(frag * 2 + 1) * 64 + lane] = h.lo;
 }
-// fragment `frag` of the table as the bounded operand of mfma_h2s
-__device__ __forceinline__ Hf3 x3k_load_dft(const u32x4* __restrict__ tab, int frag, int lane) {
-    Hf3 f;
-    f.hi = tab[(frag * 2 + 0) * 64 + lane];
-    f.lo = tab[(frag * 2 + 1) * 64 + lane];
-    FFNO_UNROLL
-    for (int w = 0; w < 4; ++w) f.hs[w] = plat::pk_mul_f16(f.hi[w], kHf2Scale);
-    return f;
-}
-
 // ---- the branch --------------------------------------------------------------------------------------------------------
 // NL = lines per workgroup: 16 (two per wave; the per-mode mix fills its 32-row tile) or 8 (one per wave: launches with few
 // lines -- batch-1 rollout: 64 lines per axis -- spread over twice as many CUs; the mix then uses rows 0..15 of the tile,
@@ -192,7 +176,9 @@ __device__ __forceinline__ Hf3 x3k_load_dft(const u32x4* __restrict__ tab, int f
 // six of the bf16 split, 6 instead of 11 vector instructions per split pair), the samples are multiplied by the power of two
 // that brings max |in| (range word) to 2^10 while they are split, and each line's mixed spectrum by one derived from ITS OWN
 // maximum (the wave reads the whole line from LDS anyway) -- both exact, both undone where the result is scaled anyway.
-template <int NL, bool MIXH2, class ST = StF32>
+// MIXOUT: phases 1 and 2 only -- each line's mixed spectrum is written out as MFMA operand fragments (X3Args::mix_out) for the
+// kernel that runs both inverse transforms and the feed-forward of an inference layer (infer.hip); nothing else is stored.
+template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false>
 __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
@@ -453,6 +439,48 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         __syncthreads();
     }
 
+    if constexpr (MIXOUT) {
+        // ---------------- phase 3': the lines' mixed spectra leave as operand fragments ----------------
+        // fragment (st, ct) of a line: lane (j, half), slot e <-> Y[kk = 16 st + 8 half + e][c = 2 j + ct] -- the B operand of this
+        // kernel's own phase 3 and, read as rows, the A operand Y^T[c][kk] of the second kernel's transposed inverse transform.
+        // ONE power of two per line brings its maximum to 2^10 (the line went through the weights: nothing bounds it a priori).
+        static_assert(MIXH2, "the fragments are split-fp16");
+        FFNO_UNROLL
+        for (int ln = 0; ln < NLW; ++ln) {
+            if (!(ln ? live1 : live0)) continue;
+            const float* xs = XS + (lw + ln) * LSF + 2 * j;
+            float2 v[2][8];
+            float ym = 0.f;
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                FFNO_UNROLL
+                for (int e = 0; e < 8; ++e) {
+                    const int kk = 16 * st + 8 * half + e;
+                    v[st][e] = make_float2(0.f, 0.f);
+                    if (kk < 2 * K) v[st][e] = *reinterpret_cast<const float2*>(xs + kk * RS);
+                    ym = fmaxf(ym, fmaxf(fabsf(v[st][e].x), fabsf(v[st][e].y)));
+                }
+            }
+            FFNO_UNROLL
+            for (int sh = 32; sh >= 1; sh >>= 1) ym = fmaxf(ym, __shfl_xor(ym, sh));
+            const float sy = range_scale(f2u(ym), 0, 10);
+            u32x4* dst = A.mix_out + (long)(line0 + ln) * (8 * 64) + lane;
+            FFNO_UNROLL
+            for (int st = 0; st < 2; ++st) {
+                const Hf2 y0 = split2_8(v[st][0].x * sy, v[st][1].x * sy, v[st][2].x * sy, v[st][3].x * sy, v[st][4].x * sy,
+                                        v[st][5].x * sy, v[st][6].x * sy, v[st][7].x * sy);
+                const Hf2 y1 = split2_8(v[st][0].y * sy, v[st][1].y * sy, v[st][2].y * sy, v[st][3].y * sy, v[st][4].y * sy,
+                                        v[st][5].y * sy, v[st][6].y * sy, v[st][7].y * sy);
+                dst[((st * 2 + 0) * 2 + 0) * 64] = y0.hi;
+                dst[((st * 2 + 0) * 2 + 1) * 64] = y0.lo;
+                dst[((st * 2 + 1) * 2 + 0) * 64] = y1.hi;
+                dst[((st * 2 + 1) * 2 + 1) * 64] = y1.lo;
+            }
+            // accumulator of the second kernel (2^11 sy rs Y) -> samples
+            if (lane == 0) A.mix_scale[line0 + ln] = rrs * kHf2Unscale / sy;
+        }
+        return;
+    }
     // ---------------- phase 3: zero-padded inverse DFT of the wave's two lines ----------------
     {
         const int RTtot = (L + 31) >> 5;
@@ -969,7 +997,7 @@ __global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
 // Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
 // workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
 // weights of ONE branch only; otherwise [0, n0) run a and the rest b.
-template <int NL, bool MIXH2, class ST = StF32>
+template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false>
 __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
     bool second;
@@ -1009,7 +1037,9 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.in_amax = second ? b.in_amax : a.in_amax;
     s.out_amax = second ? b.out_amax : a.out_amax;
     s.dft = nullptr;
-    spectral_x3_body<NL, MIXH2, ST>(s, idx, (idx & 1) ? skew : 0);
+    s.mix_out = second ? b.mix_out : a.mix_out;
+    s.mix_scale = second ? b.mix_scale : a.mix_scale;
+    spectral_x3_body<NL, MIXH2, ST, MIXOUT>(s, idx, (idx & 1) ? skew : 0);
 }
 
 // ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
@@ -1894,6 +1924,8 @@ __device__ __forceinline__ X3Args x3_pick_args(const X3Args& a, const X3Args& b,
     s.in_amax = second ? b.in_amax : a.in_amax;
     s.out_amax = second ? b.out_amax : a.out_amax;
     s.dft = second ? b.dft : a.dft;
+    s.mix_out = second ? b.mix_out : a.mix_out;
+    s.mix_scale = second ? b.mix_scale : a.mix_scale;
     return s;
 }
 
@@ -2644,6 +2676,52 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
             FFNO_LAUNCH((spectral_x3_pair_kernel<16, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         else
             FFNO_LAUNCH((spectral_x3_pair_kernel<16, false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+    }
+    return x3_status();
+}
+
+// ---- first kernel of the INFERENCE layer (infer.hip): both forward transforms + both channel mixes -> the mixed spectra -------
+// Same branch descriptors as ffno_spectral_x3_pair (forward flags), with `out` = the branch's MIX buffer
+// (ffno_infer_mix_bytes): per line 8 split-fp16 operand fragments (8 KiB) and, behind all lines, one float per line.
+extern "C" size_t ffno_infer_mix_bytes(int C, int K, int lines) {
+    if (C != X3Cfg::C || K < 1 || 2 * K > X3Cfg::KK || lines <= 0) return 0;
+    return (size_t)lines * (8 * 64 * sizeof(u32x4)) + (((size_t)lines * sizeof(float) + 15) & ~(size_t)15);
+}
+
+extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int C, int interleave,
+                                         void* stream) {
+    if (!ba || !bb) return FFNO_EINVAL;
+    if (ba->out == bb->out) return FFNO_EINVAL;
+    X3Args a, b;
+    int rc = x3_args(a, ba, C, 0, 1, 0);
+    if (rc) return rc;
+    rc = x3_args(b, bb, C, 0, 1, 0);
+    if (rc) return rc;
+    // what the fragment form covers: width 64, <= 16 modes, fp16x2 mix packs with range words, fp32 activations, nothing saved
+    if (C != X3Cfg::C || x3_many_modes(a.K) || x3_many_modes(b.K)) return FFNO_EUNSUPPORTED;
+    if (!ba->planes || !bb->planes || ba->planes_format != FFNO_PLANES_FP16X2 || bb->planes_format != FFNO_PLANES_FP16X2)
+        return FFNO_EUNSUPPORTED;
+    if (ba->storage != FFNO_STORE_F32 || bb->storage != FFNO_STORE_F32) return FFNO_EUNSUPPORTED;
+    if (ba->resid || bb->resid || ba->spec_save || bb->spec_save || ba->accumulate || bb->accumulate) return FFNO_EINVAL;
+    if (ba->tile_lines != bb->tile_lines || (ba->tile_lines != 0 && ba->tile_lines != 8 && ba->tile_lines != 16)) return FFNO_EINVAL;
+    a.mix_out = reinterpret_cast<u32x4*>(ba->out), b.mix_out = reinterpret_cast<u32x4*>(bb->out);
+    a.mix_scale = reinterpret_cast<float*>(a.mix_out + (size_t)a.R * 8 * 64);
+    b.mix_scale = reinterpret_cast<float*>(b.mix_out + (size_t)b.R * 8 * 64);
+    a.out = b.out = nullptr, a.out_amax = b.out_amax = nullptr;
+    const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
+    hipStream_t st = (hipStream_t)stream;
+    auto wg_map = [&](int NL, int n0, int n1) {
+        if (n0 != n1) return 0;
+        const bool square = ba->B == bb->B && ba->M == bb->M && ba->N == bb->N && ba->M == ba->N && ba->axis != bb->axis;
+        if ((interleave & 2) && square && ba->B % 8 == 0 && ba->M % NL == 0) return 2 | ((ba->M / NL) << 8);
+        return (interleave & 1) ? 1 : 0;
+    };
+    if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
+        const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
+        FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
+    } else {
+        const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = wg_map(16, n0, n1);
+        FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
     }
     return x3_status();
 }

@@ -243,6 +243,11 @@ class FFNOEngine:
         # one C call per layer and direction (ffno_layer_fwd / ffno_layer_bwd: paired branches + feed-forward) instead of two /
         # three; per-kernel timing (a timer attached) needs the individual calls
         self.use_layer_calls = True
+        # forward passes that save nothing (predict / validation / rollout) through the two-launch INFERENCE layer (csrc/infer.hip:
+        # mixed spectra between the launches, no branch image in memory) where the library takes the shape and the launch is large
+        # enough to fill the chip; small launches (a rollout at batch 1) stay on the latency kernels of the training path
+        self.use_infer_layer = os.environ.get("FFNO_INFER_LAYER", "1") != "0"
+        self.infer_min_lines = None      # lines per axis pair from which the inference layer is used (None: more than 4 per CU)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
         # fp16x2 packs: max |W| of what goes into them is folded at every n-th rebuild of the derived operands (0 = never) and
@@ -962,6 +967,31 @@ class FFNOEngine:
         """Per axis: the split-bf16 fused branch instead of the fp32-MFMA one (same operator, same flags)."""
         return [bool(fused[w] and self._x3_ok(w, v, views)) for w, v in enumerate(views)]
 
+    def _infer_ok(self, ws, B, conc, pair, singles, x3pair, fused) -> bool:
+        """The two-launch inference layer (ffno_layer_infer) serves this forward: both axes of a 2-D layer in one paired launch of
+        the fused split kernels with fp16x2 packs and <= 16 modes, width 64 / hidden 256 on the split-fp16 feed-forward, fp32
+        activations, no fork heads / LayerNorm / dropout -- and enough lines to fill the chip."""
+        if not (self.use_infer_layer and conc and pair is not None and not singles and x3pair and fused[pair[0]]):
+            return False
+        if not (self.nd == 2 and self.mode == "full" and self.spectral == "factorized" and self._ffx() and self._h2() and self._x3_h2()
+                and not self._bf16() and not self.use_fork and not self.layer_norm and not self.general_ff
+                and (self.C, self.H) == (64, 256)):
+            return False
+        va, vb = ws.views[pair[0]], ws.views[pair[1]]
+        if {va.a01, vb.a01} != {0, 1} or (va.Bv, va.Mv, va.Nv) != (vb.Bv, vb.Mv, vb.Nv):
+            return False
+        if any(getattr(v, "x3fmt", 0) != 1 for v in (va, vb)):
+            return False
+        row, col = (va, vb) if va.a01 == 0 else (vb, va)
+        lib = _lib.get_lib()
+        if not lib.ffno_layer_infer_supported(va.Bv, va.Mv, va.Nv, self.C, self.H, row.K, col.K):
+            return False
+        if self._dft_frags(row.L, row.K, True) is None or self._dft_frags(col.L, col.K, True) is None:
+            return False
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        need = self.infer_min_lines if self.infer_min_lines is not None else 4 * cus + 1
+        return va.R + vb.R >= need
+
     def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st,
                   x3: bool = False, rin=None, rout=None):
         """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint);
@@ -1069,6 +1099,11 @@ class FFNOEngine:
                 and 4 * C * max(v.Bv * v.Mv * v.Nv for v in ws.views) < 2 ** 32)
         layer_calls = bool(self.use_layer_calls and self.timer is None and conc and fused[pair[0]] and not self.use_fork
                            and not self.layer_norm)
+        infer = bool(not save_for_backward and self._infer_ok(ws, B, conc, pair, singles, x3pair, fused))
+        if infer and getattr(ws, "MIX", None) is None:
+            ws.MIX = [torch.empty(int(lib.ffno_infer_mix_bytes(C, ws.views[w].K, ws.views[w].R)) // 4, dtype=torch.int32, device=self.device)
+                      for w in pair]
+        self.infer_last = infer      # (tests / bench.py: which layer kernels the last forward ran)
         # both branch outputs of every layer are kept and the feed-forward does not write their sum (the deferred weight-gradient
         # launch forms it): decided here, the backward pass follows (self._saved_lazy)
         lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", ""))
@@ -1118,6 +1153,21 @@ class FFNOEngine:
                                    self._planes_for(si, w, 0, x3[w]), True, int(nwrit > 0), fused[w], st, x3=x3[w],
                                    rin=rx, rout=rs_)
                     nwrit += 1
+                if infer:
+                    a, b = pair
+                    l0, l1, b0, b1 = self._ff_weights(l)
+                    ba = self._branch(ws.views[a], ws.X, ws.MIX[0], None, None, self._planes_for(si, a, 0, True), 0, True, True, rx, None)
+                    bb = self._branch(ws.views[b], ws.X, ws.MIX[1], None, None, self._planes_for(si, b, 0, True), 0, True, True, rx, None)
+                    out_l = ws.Blast if last else ws.X
+                    if self.timer is None:
+                        d = _capi.LayerInferDesc(ba, bb, X3_INTERLEAVE, 0, _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
+                                                 None if last else _p(ws.X), _p(out_l), C, H, rxn)
+                        self._k("layer_infer", lib.ffno_layer_infer, ctypes.byref(d), st)
+                    else:       # (per-kernel timing: the two launches as two calls)
+                        self._k("spectral_mix", lib.ffno_spectral_x3_mix_pair, ctypes.byref(ba), ctypes.byref(bb), C, X3_INTERLEAVE, st)
+                        self._k("infer_ff", lib.ffno_infer_ff, ctypes.byref(ba), ctypes.byref(bb), _p(l0.fx[0]), _p(b0), _p(l0.fx[1]),
+                                _p(b1), None if last else _p(ws.X), _p(out_l), C, H, rxn, st)
+                    continue
                 if conc:
                     a, b = pair
                     keep = [ws.SXall[w][sv] if (full and save_for_backward) else None for w in pair]

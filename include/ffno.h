@@ -73,7 +73,7 @@ const char* ffno_build_target(void);
  * library under newer host code would have read shifted arguments).  ffno_abi_version() returns the value the LIBRARY was built
  * with; a caller compares it with the FFNO_ABI_VERSION it was compiled against before the first compute call (the Python host
  * does: fourierflow_amd/_lib.py refuses a mismatch). */
-#define FFNO_ABI_VERSION 6
+#define FFNO_ABI_VERSION 7
 int ffno_abi_version(void);
 
 /* word[0] = max(word[0], bits(max |x[i]|)): folds a tensor into a range word (see "Range words" above) */
@@ -329,6 +329,45 @@ typedef struct ffno_layer_bwd_desc {
 } ffno_layer_bwd_desc;
 int ffno_layer_fwd(const ffno_layer_fwd_desc* d, void* stream);
 int ffno_layer_bwd(const ffno_layer_bwd_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * INFERENCE layer (round 6): SpectralConv2d.forward + the residual add (grid_2d.py:42-49,51-99,169; feedforward.py:13-19)
+ * with NOTHING saved for a backward pass -- what predict / validation / the autoregressive rollout
+ * (routines/grid_2d_markov.py:130-144,195-326) and the reference's latency metric (commands/train.py:134-148) run -- in two
+ * launches that never write a branch image:
+ *   ffno_spectral_x3_mix_pair  both truncated forward DFTs + both per-mode channel mixes -> the two MIXED spectra (K x C
+ *                              complex per line), stored as the split-fp16 operand fragments the second launch multiplies:
+ *                              `out` of each branch = its mix buffer, ffno_infer_mix_bytes(C, K, lines) bytes (lines = B M for
+ *                              axis 0, B N for axis 1); resid / spec_save / accumulate must be unset; planes = FFNO_PLANES_FP16X2
+ *                              packs; in_amax = the range word of x.
+ *   ffno_infer_ff              both zero-padded inverse DFTs (transposed: channels x pixels, straight into the feed-forward's
+ *                              operand registers), branch sum, Linear + ReLU + Linear, bias, residual -> out; the same branch
+ *                              descriptors (their `out` = the mix buffers just written, their dft_frags = the tables of
+ *                              ffno_spectral_x3_dft_frags(tw, L, K, 0, 1, ...): REQUIRED here), packs of ffno_ffh_pack (pk1: W1
+ *                              type 1, pk2: W2 type 2), resid = x (optional), out_amax (optional) receives max |out|.
+ *   ffno_layer_infer           = the two, one call per layer.
+ * 5 image passes per layer instead of the 7 of ffno_layer_fwd (x -> 2 half-image spectra -> x'); results agree with
+ * ffno_layer_fwd to fp32 rounding (other summation order), not bit for bit.
+ * Supported (ffno_layer_infer_supported): C = 64, H = 256, <= 16 modes per axis, N a multiple of 32 up to 512, fp32 storage.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ffno_layer_infer_desc {
+    ffno_fused_branch a, b;  /* the two axes over the same x (a.in == b.in, a.axis != b.axis, same B / M / N) */
+    int32_t interleave, pad_;
+    const void* pk1;
+    const float* b1;
+    const void* pk2;
+    const float* b2;
+    const float* resid;
+    float* out;
+    int32_t C, H;
+    uint32_t* out_amax;
+} ffno_layer_infer_desc;
+size_t ffno_infer_mix_bytes(int C, int K, int lines);
+int ffno_layer_infer_supported(int B, int M, int N, int C, int H, int K_rows, int K_cols);
+int ffno_spectral_x3_mix_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int interleave, void* stream);
+int ffno_infer_ff(const ffno_fused_branch* a, const ffno_fused_branch* b, const void* pk1, const float* b1, const void* pk2,
+                  const float* b2, const float* resid, float* out, int C, int H, uint32_t* out_amax, void* stream);
+int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
 
 /* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),
  * for the shapes the fused kernel does not take (K > 16 at C = 64: 256 x 256 grids with 32 / 64 modes have only 512 lines

@@ -51,6 +51,11 @@ def _run_hip(kw, seed, B, M, N, split=None, storage="fp32"):
     # (plane formats of ffno.h: 0 bf16x3, 1 fp16x2, 2 fp16x2 in the 16-row order of the many-mode kernel, 17..64 modes)
     fmt = 0 if want != "fp16x2" else (2 if kw["modes"] > 16 else 1)
     assert eng._x3_fmt == [fmt] * 2 and eng.ff_split == want and eng._ffx()
+    # the forward-only path on the same weights and inputs (trainer.predict: what bench.py's `ms_per_forward` times) -- at this size
+    # the two-launch inference layer for the fp16x2 / fp32-storage defaults
+    pred_inf = tr.predict(x).cpu().numpy()
+    assert eng.infer_last == (want == "fp16x2" and storage == "fp32" and B * (M + N) > 4 * 256), (eng.infer_last, want, storage, B)
+    _run_hip.last_predict = pred_inf
     return pred.cpu().numpy(), loss, grads, masks, (x_np, t_np), gflat
 
 
@@ -68,6 +73,9 @@ def test_markov24_bench_geometry_forward_backward_vs_oracle(B, split):
     print(f"[bench-geometry B={B} {split or 'fp16x2 defaults'}] forward rel-L2 {e_fwd:.2e}, |loss diff| {e_loss:.2e}")
     assert e_fwd < 1e-5
     assert e_loss < 1e-5
+    e_inf = rel_l2(_run_hip.last_predict, ref_out["forecast"].detach().numpy())
+    print(f"[bench-geometry B={B} {split or 'fp16x2 defaults'}] trainer.predict (inference layer at this size: {split is None}) rel-L2 {e_inf:.2e}")
+    assert e_inf < 1e-5
     first = {torch.float32: ref_grads}     # the fp32 run above is re-used
     ou.check_grads_at_rounding_level(
         f"bench-geometry B={B}", grads,

@@ -1,0 +1,223 @@
+"""The two-launch INFERENCE layer (include/ffno.h: ffno_spectral_x3_mix_pair + ffno_infer_ff = ffno_layer_infer; csrc/infer.hip)
+against an fp64 restatement of one layer of FNOFactorized2DBlock.forward (reference fourierflow/modules/factorized_fno/
+grid_2d.py:42-49,51-99,169: rfft(ortho) -> [:K] -> complex einsum -> zero-filled irfft along both axes, summed;
+feedforward.py:13-19: Linear -> ReLU -> Linear; + the residual), against the training layer call it replaces (ffno_layer_fwd), and
+through the engine: `forward(save_for_backward=False)` -- predict, validation, rollout -- must take it and agree with the oracle.
+Tolerance: 1e-5 relative L2 (BASELINE north star); observed 1e-7-level."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+import oracle_util as ou
+from backend_util import be, host_device, rel_l2  # noqa: F401
+from test_kernels_ffh import pack_weights_h
+from test_kernels_spectral import _x3_pack
+
+
+def layer_fp64(x, wa, wb, W1, b1, W2, b2, K):
+    """x [B, M, N, C]; wa mixes the LAST axis (lines (b, m)), wb the first (grid_2d.py:58-72 / :76-90)."""
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)                      # b i m n
+    B, I, M, N = xt.shape
+    wA = torch.view_as_complex(torch.tensor(wa, dtype=torch.float64).contiguous())   # [i, o, k]
+    wB = torch.view_as_complex(torch.tensor(wb, dtype=torch.float64).contiguous())
+    fy = torch.fft.rfft(xt, dim=-1, norm="ortho")
+    oy = torch.zeros(B, I, M, N // 2 + 1, dtype=torch.complex128)
+    oy[..., :K] = torch.einsum("bixy,ioy->boxy", fy[..., :K], wA)
+    sy = torch.fft.irfft(oy, n=N, dim=-1, norm="ortho")
+    fx = torch.fft.rfft(xt, dim=-2, norm="ortho")
+    ox = torch.zeros(B, I, M // 2 + 1, N, dtype=torch.complex128)
+    ox[:, :, :K] = torch.einsum("bixy,iox->boxy", fx[:, :, :K], wB)
+    sx = torch.fft.irfft(ox, n=M, dim=-2, norm="ortho")
+    s = (sx + sy).permute(0, 2, 3, 1)
+    h = torch.relu(s @ torch.tensor(W1, dtype=torch.float64).T + torch.tensor(b1, dtype=torch.float64))
+    return (torch.tensor(x, dtype=torch.float64) + h @ torch.tensor(W2, dtype=torch.float64).T + torch.tensor(b2, dtype=torch.float64)).numpy(), s.numpy()
+
+
+def _setup(be, B, M, N, K, seed, scale=1.0):
+    from fourierflow_amd._capi import FusedBranch
+    lib, p = be.lib, be.ptr
+    C, H = 64, 256
+    rs = np.random.RandomState(seed)
+    x = (rs.standard_normal((B, M, N, C)) * scale).astype(np.float32)
+    W1 = (rs.standard_normal((H, C)) / 8).astype(np.float32)
+    W2 = (rs.standard_normal((C, H)) / 16).astype(np.float32)
+    b1, b2 = (rs.standard_normal(H) * 0.1).astype(np.float32), (rs.standard_normal(C) * 0.1 * scale).astype(np.float32)
+    packs, keep = pack_weights_h(be, W1, W2)
+    w = [(rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32) for _ in range(2)]
+    xp = [_x3_pack(be, w[i], K, fmt=1) for i in range(2)]
+    tw = [be.twiddle(N), be.twiddle(M)]
+    L = [N, M]
+    tabs = []
+    for i in range(2):
+        nb = int(lib.ffno_spectral_x3_dft_frags_bytes(L[i], K))
+        assert nb > 0
+        tab = be.zeros(nb // 4, np.uint32)
+        assert lib.ffno_spectral_x3_dft_frags(p(tw[i]), L[i], K, 0, 1, p(tab), None) == 0
+        tabs.append(tab)
+    dx = be.put(x)
+    word = be.zeros(2, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(word), None) == 0
+    lines = [B * M, B * N]
+    mix = []
+    for i in range(2):
+        nb = int(lib.ffno_infer_mix_bytes(C, K, lines[i]))
+        assert nb >= lines[i] * 8192 + lines[i] * 4
+        mix.append(be.zeros(nb // 4, np.uint32))
+
+    def branch(i, out, rout=None):
+        return FusedBranch(p(dx), p(out), None, None, p(xp[i][0]), p(tw[i]), B, M, N, K, i, 0, 1, 0, p(word), rout, 0, 0, p(tabs[i]))
+
+    return dict(x=x, W1=W1, W2=W2, b1=b1, b2=b2, w=w, packs=packs, dx=dx, word=word, mix=mix, branch=branch, db1=be.put(b1),
+                db2=be.put(b2), keep=(keep, xp, tw, tabs))
+
+
+SHAPES = [(1, 8, 32, 4), (2, 16, 64, 8), (8, 64, 64, 16), (1, 32, 128, 16), (3, 20, 32, 11)]
+
+
+@pytest.mark.parametrize("B,M,N,K", SHAPES)
+def test_infer_layer_vs_fp64_and_vs_the_training_layer(be, B, M, N, K):
+    from fourierflow_amd._capi import LayerFwdDesc, LayerInferDesc
+    if be.kind == "emu" and (B, M, N, K) in ((8, 64, 64, 16), (1, 32, 128, 16)):
+        pytest.skip("emulator time budget (the GPU run covers all shapes)")
+    lib, p = be.lib, be.ptr
+    C, H = 64, 256
+    assert lib.ffno_layer_infer_supported(B, M, N, C, H, K, K) == 1
+    S = _setup(be, B, M, N, K, seed=B * 1000 + M + N + K)
+    out = be.empty(S["x"].shape)
+    oword = be.zeros(1, np.uint32)
+    d = LayerInferDesc(S["branch"](0, S["mix"][0]), S["branch"](1, S["mix"][1]), 2, 0, p(S["packs"][0]), p(S["db1"]),
+                       p(S["packs"][1]), p(S["db2"]), p(S["dx"]), p(out), C, H, p(oword))
+    assert lib.ffno_layer_infer(ctypes.byref(d), None) == 0
+    got = np.array(be.get(out)).copy()
+    ref, s_ref = layer_fp64(S["x"], S["w"][0], S["w"][1], S["W1"], S["b1"], S["W2"], S["b2"], K)
+    e = rel_l2(got, ref)
+    # the update alone (out - x): the residual must not hide an error of the layer's own arithmetic
+    e_upd = rel_l2(got.astype(np.float64) - S["x"], ref - S["x"])
+    print(f"[infer layer {B}x{M}x{N} K={K}] out rel-L2 {e:.2e}, update rel-L2 {e_upd:.2e}")
+    assert e < 1e-6 and e_upd < 1e-5
+    # the range word of the output = bits of max |out|
+    assert np.array(be.get(oword)).view(np.float32)[0] == np.abs(got).max()
+    # ... and the training layer call on the same operands (two branch images through memory): equal to fp32 rounding
+    s_img, t_img, out2 = be.empty(S["x"].shape), be.empty(S["x"].shape), be.empty(S["x"].shape)
+    sword = be.zeros(1, np.uint32)
+    P = B * M * N
+    d2 = LayerFwdDesc(S["branch"](0, s_img, p(sword)), S["branch"](1, t_img, p(sword)), 1, 2, p(S["packs"][0]), p(S["db1"]),
+                      p(S["packs"][1]), p(S["db2"]), None, p(S["dx"]), p(out2), None, P, C, H, 1, 0, 0, 0, 0, None)
+    assert lib.ffno_layer_fwd(ctypes.byref(d2), None) == 0
+    assert rel_l2(got, be.get(out2)) < 1e-6
+    assert rel_l2(np.array(be.get(s_img)) + np.array(be.get(t_img)), s_ref) < 1e-5
+
+
+@pytest.mark.parametrize("scale", [1e5, 1e-6])
+def test_infer_layer_any_magnitude(be, scale):
+    """Inputs far outside the half format's range: the line-wise spectrum scales of K1 and the tile-wise input scale of K2 keep
+    every split operand in range (include/ffno.h "Range words")."""
+    from fourierflow_amd._capi import LayerInferDesc
+    lib, p = be.lib, be.ptr
+    B, M, N, K, C, H = 1, 8, 32, 4, 64, 256
+    S = _setup(be, B, M, N, K, seed=77, scale=scale)
+    out = be.empty(S["x"].shape)
+    d = LayerInferDesc(S["branch"](0, S["mix"][0]), S["branch"](1, S["mix"][1]), 2, 0, p(S["packs"][0]), p(S["db1"]),
+                       p(S["packs"][1]), p(S["db2"]), p(S["dx"]), p(out), C, H, None)
+    assert lib.ffno_layer_infer(ctypes.byref(d), None) == 0
+    ref, _ = layer_fp64(S["x"], S["w"][0], S["w"][1], S["W1"], S["b1"], S["W2"], S["b2"], K)
+    got = np.array(be.get(out))
+    assert rel_l2(got.astype(np.float64) - S["x"], ref - S["x"]) < 1e-5
+
+
+def test_infer_layer_argument_checks(be):
+    from fourierflow_amd._capi import LayerInferDesc
+    lib, p = be.lib, be.ptr
+    C, H = 64, 256
+    assert lib.ffno_layer_infer(None, None) == -1
+    assert lib.ffno_layer_infer_supported(2, 16, 48, C, H, 8, 8) == 0        # N not a multiple of 32
+    assert lib.ffno_layer_infer_supported(2, 16, 64, C, H, 17, 8) == 0        # > 16 modes
+    assert lib.ffno_layer_infer_supported(2, 16, 64, 32, 128, 8, 8) == 0      # width 32
+    assert lib.ffno_layer_infer_supported(2, 16, 64, C, H, 8, 10) == 0        # modes > M / 2 + 1
+    assert lib.ffno_infer_mix_bytes(C, 17, 4) == 0
+    S = _setup(be, 1, 8, 32, 4, seed=5)
+    out = be.empty(S["x"].shape)
+    # both branches on the same axis / a missing fragment table: refused
+    a, b = S["branch"](0, S["mix"][0]), S["branch"](0, S["mix"][1])
+    d = LayerInferDesc(a, b, 2, 0, p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]), p(S["dx"]), p(out), C, H, None)
+    assert lib.ffno_infer_ff(ctypes.byref(a), ctypes.byref(b), p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]), None,
+                             p(out), C, H, None, None) == -1
+    b = S["branch"](1, S["mix"][1])
+    b.dft_frags = None
+    assert lib.ffno_infer_ff(ctypes.byref(a), ctypes.byref(b), p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]), None,
+                             p(out), C, H, None, None) == -1
+    # bf16x3 packs / a residual in the first launch: refused
+    a.planes_format = 0
+    assert lib.ffno_spectral_x3_mix_pair(ctypes.byref(a), ctypes.byref(S["branch"](1, S["mix"][1])), C, 2, None) == -2
+
+
+# ---- through the engine: forward(save_for_backward=False) = predict / validation / rollout ------------------------------------------
+def _block(kw, seed, device):
+    from fourierflow_amd.modules import FNOFactorized2DBlock
+    blk = FNOFactorized2DBlock(**kw)
+    blk.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in gu.make_block_state_dict(kw, seed).items()}, strict=True)
+    return blk.to(device)
+
+
+def test_engine_forward_without_saving_takes_the_inference_layer(host_device):
+    """A small block on both backends: the no-save forward runs ffno_layer_infer for every layer (one C call per layer), agrees with the
+    oracle to 1e-5 and with the training-path forward of the same engine to fp32 rounding; a forward that saves for a backward pass
+    keeps the training launches."""
+    kw = dict(modes=4, width=64, input_dim=3, n_layers=3, share_weight=False, factor=4, ff_weight_norm=True, gain=0.5)
+    seed, B, M, N = 9, 2, 8, 32
+    blk = _block(kw, seed, host_device)
+    eng = blk.engine()
+    eng.x3_min_lines = 1
+    eng.infer_min_lines = 1
+    x_np, t_np = gu.make_block_io(kw, seed, B, M, N)
+    x = torch.from_numpy(x_np).to(host_device)
+    seen = []
+    orig = eng._k
+    eng._k = lambda name, fn, *a, _o=orig: (seen.append(name), _o(name, fn, *a))[1]
+    with torch.no_grad():
+        y_inf = blk(x)["forecast"].cpu().numpy()
+    assert eng.infer_last and seen.count("layer_infer") == 3 and "layer_fwd" not in seen and "spectral_fused" not in seen
+    seen.clear()
+    eng.use_infer_layer = False
+    with torch.no_grad():
+        y_trn = blk(x)["forecast"].cpu().numpy()
+    assert not eng.infer_last and "layer_infer" not in seen
+    eng.use_infer_layer = True
+    seen.clear()
+    y_sav = blk(x)["forecast"].detach().cpu().numpy()
+    assert not eng.infer_last and "layer_infer" not in seen      # a pass that saves for backward() keeps its four launches
+    np.testing.assert_array_equal(y_sav, y_trn)
+    ref_out, _, _ = ou.oracle_block_run(kw, seed, B, M, N, io=(x_np, t_np))
+    ref = ref_out["forecast"].detach().numpy()
+    print(f"[engine infer] vs oracle {rel_l2(y_inf, ref):.2e} (training-path forward {rel_l2(y_trn, ref):.2e}), vs training path {rel_l2(y_inf, y_trn):.2e}")
+    assert rel_l2(y_inf, ref) < 1e-5 and rel_l2(y_inf, y_trn) < 2e-6
+    # small launches stay on the latency kernels unless forced (the default threshold: more than 4 lines per CU and axis pair)
+    eng.infer_min_lines = None
+    with torch.no_grad():
+        blk(x)
+    assert not eng.infer_last
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["c64_4l_markov", "c64_24l_markov", "c64_3l_unshared"])
+def test_inference_layer_vs_reference_golden(tag):
+    """The reference's own forward outputs (tests/golden/block_*.npz, generated by the imported reference) through the inference
+    layer: 64 x 64 / 4 layers, 32 x 32 / 24 layers (markov configuration), 16 x 32 / per-layer weights."""
+    g = gu.load_golden("block_" + tag)
+    kw = gu.golden_kwargs(g)
+    B, M, N, seed = [int(v) for v in g["meta"]]
+    blk = _block(kw, seed, "cuda:0")
+    eng = blk.engine()
+    eng.x3_min_lines = 1
+    eng.infer_min_lines = 1
+    x_np, _ = gu.make_block_io(kw, seed, B, M, N)
+    blk.eval()
+    with torch.no_grad():
+        pred = blk(torch.from_numpy(x_np).cuda())["forecast"]
+    assert eng.infer_last
+    e = gu.compare_packed(g, "forecast", pred.cpu().numpy(), 1e-5)
+    print(f"[inference layer vs golden {tag}] {e:.2e}")
+    assert e < 1e-5

@@ -31,6 +31,13 @@ except Exception as e:
     print("parse error", e)
 PY
       ;;
+    infer)
+      timeout 600 python -m pytest tests/test_infer_layer.py -m gpu -q -x -s --tb=short -p no:cacheprovider > gpurun_out/pytest_infer.log 2>&1
+      echo "[r6] infer tests rc=$?"; grep -E "^\[|passed|failed|Error|error" gpurun_out/pytest_infer.log | tail -20
+      timeout 300 python tools/time_infer.py > gpurun_out/time_infer.log 2>&1; echo "[r6] time_infer rc=$?"; tail -n 12 gpurun_out/time_infer.log
+      timeout 300 python tools/time_infer.py 1 64 64 16 > gpurun_out/time_infer_b1.log 2>&1; echo "[r6] time_infer b1 rc=$?"; tail -n 8 gpurun_out/time_infer_b1.log ;;
+    inferring)
+      for d in ${INFER_RINGS:-1 2 3 4 1 2 3 4}; do echo "== FFNO_INFER_RING=$d"; FFNO_INFER_RING=$d timeout 300 python tools/time_infer.py 2>&1 | grep -E "K2|K1 |rel-L2"; done ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
