@@ -64,25 +64,32 @@ def names(g):
     return sorted({k.split("::")[0] for k in g.files if "::" in k})
 
 
-def check(label, tag, out, loss, grads, fwd_tol=1e-5, loss_tol=1e-5, grad_tol=None, grad_med_tol=None, fwd_min=None):
-    """Forward, loss and every parameter gradient against the committed sketch of the fp64 oracle run.  Returns the observed errors
-    (printed: the margins are on record)."""
+def check(label, tag, out, loss, grads, fwd_tol=1e-5, loss_tol=1e-5, grad_tol=None, grad_med_tol=None, fwd_min=None, noise_factor=8.0):
+    """Forward, loss and every parameter gradient against the committed sketch of the fp64 oracle run.  A gradient passes inside
+    max(grad_tol, noise_factor x the oracle's OWN fp32-vs-fp64 difference for that tensor) -- the second term is what
+    tests/oracle_util.py::check_grads_at_rounding_level grants gradients that are sums with heavy cancellation (weight-norm gains, head
+    biases), measured at generation time.  Returns the observed errors (printed: the margins are on record)."""
     g = load(tag)
     e_fwd, s_fwd = sketch_rel_err(g, tag, "out", out)
     e_loss = abs(float(loss) - float(g["loss"]))
-    errs = {}
+    errs, over = {}, {}
     for n in grads:
-        errs[n] = max(sketch_rel_err(g, tag, "grad/" + n, grads[n])[0], 0.0)
+        errs[n] = sketch_rel_err(g, tag, "grad/" + n, grads[n])[0]
+        if grad_tol is not None:
+            band = max(grad_tol, noise_factor * float(g[f"grad/{n}::noise"]))
+            if errs[n] >= band:
+                over[n] = (errs[n], band)
     worst = max(errs, key=errs.get)
     med = float(np.median(list(errs.values())))
+    nlim = sum(1 for n in grads if grad_tol is not None and errs[n] >= grad_tol)
     print(f"[{label}] vs fp64-oracle sketch: forward rel-L2 {e_fwd:.2e} (sampled entries {s_fwd:.2e}), |loss diff| {e_loss:.2e}, "
-          f"gradients: median {med:.2e}, worst {errs[worst]:.2e} ({worst})")
+          f"gradients: median {med:.2e}, worst {errs[worst]:.2e} ({worst}; the oracle's own fp32 noise there "
+          f"{float(g['grad/' + worst + '::noise']):.1e}); {nlim} above {grad_tol} (held to {noise_factor} x their noise)")
     assert e_fwd < fwd_tol and s_fwd < 4 * fwd_tol, (e_fwd, s_fwd)
     if fwd_min is not None:
         assert e_fwd > fwd_min
     assert e_loss < loss_tol, e_loss
-    if grad_tol is not None:
-        assert errs[worst] < grad_tol, (worst, errs[worst])
+    assert not over, over
     if grad_med_tol is not None:
         assert med < grad_med_tol, med
     return e_fwd, med, errs[worst]

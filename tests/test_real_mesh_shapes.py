@@ -6,66 +6,30 @@
   * airfoil     -- experiments/airfoil/ffno/24_layers/config.yaml:16,24-34: FNOFactorizedMesh2D on [10, 221, 51] meshes (229 x 59
     padded), modes (32, 16), width 64, 24 layers.
 
-Forward <= 1e-5 relative L2 and EVERY parameter gradient at rounding level (5e-5) against the oracle evaluated on the HIP path's
-ReLU active sets; the number of hidden units on which the oracle's own ReLU decisions differ is bounded and printed.
+Forward <= 1e-5 relative L2, loss <= 1e-5 and EVERY parameter gradient against the committed sketch of the fp64 oracle run on the same
+seeded inputs (tests/fullsize_util.py: 16 random projections + 256 sampled entries per tensor, generated in the build container).
 Reference: fourierflow/modules/factorized_fno/mesh_3d.py:120,154-177, mesh_2d.py:107-175.
 """
 import numpy as np
 import pytest
 import torch
 
+import fullsize_util as fu
 import golden_util as gu
-import oracle_util as ou
-from backend_util import rel_l2
 from oracle import ffno_oracle as orc
 
-FLIP_BOUND = 1e-5      # fraction of hidden units within an ulp of zero (observed: printed by the tests)
+# gradients against the SKETCH of the fp64 oracle run (the oracle's own ReLU decisions; see tests/test_bench_geometry.py)
+SKETCH_GRAD_TOL = 2e-4
 
 
-def _flip_fraction(masks, run_plain):
-    """Hidden units on which the oracle's OWN ReLU decisions (unmasked fp32 forward) differ from the HIP path's active sets."""
-    orc.RELU_TRACE = trace = []
-    try:
-        with torch.no_grad():
-            run_plain()
-    finally:
-        orc.RELU_TRACE = None
-    flips = total = layer = 0
-    for prefix, i, active in trace:
-        if "backcast_ff" not in prefix or i != 0:
-            continue
-        m = masks[("backcast", layer)][0].reshape(-1)
-        layer += 1
-        flips += int((active.reshape(-1) != m).sum())
-        total += m.numel()
-    assert layer == len(masks)
-    return flips, total
-
-
-def _check(label, blk, out, loss, x_np, t_np, sd_np, oracle_fn, modes, n_layers):
+def _check(label, tag, blk, out, loss):
+    """Forward <= 1e-5, loss <= 1e-5, every parameter gradient inside SKETCH_GRAD_TOL of the committed sketch of the fp64 oracle run
+    on the same seeded inputs (tests/fullsize_util.py, tools/make_fullsize_fixtures.py; VERDICT r05 #7: until round 5 these tests ran
+    the oracle live -- 48 + 58 s of the GPU run -- with the HIP path's ReLU active sets injected; that form stays at markov/24)."""
     eng = blk.engine()
-    masks = ou.engine_relu_masks(eng)
-
-    def oracle(dtype=torch.float32, use_masks=True):
-        sd, uniq = ou.torch_state_dict(sd_np, dtype)
-        o = oracle_fn(sd, torch.tensor(x_np, dtype=dtype), modes=modes, n_layers=n_layers, relu_masks=masks if use_masks else None)
-        l = orc.lp_rel_loss(o, torch.tensor(t_np, dtype=dtype))
-        l.backward()
-        return o, l, {k: (p.grad.detach().numpy() if p.grad is not None else None) for k, p in uniq.items()}
-
-    ref_out, ref_loss, ref_grads = oracle()
-    e_fwd = rel_l2(out.detach().cpu().numpy(), ref_out.detach().numpy())
-    print(f"[{label}] forward rel-L2 {e_fwd:.2e}, |loss diff| {abs(loss.item() - ref_loss.item()):.2e}")
-    assert e_fwd < 1e-5
-    assert abs(loss.item() - ref_loss.item()) < 1e-5
     named = dict(blk.named_parameters())
-    first = {torch.float32: ref_grads}
-    ou.check_grads_at_rounding_level(label, {n: named[n].grad.cpu().numpy() for n in eng.param_names},
-                                     lambda dt: first.get(dt) or oracle(dt)[2])
-    sd0, _ = ou.torch_state_dict(sd_np, torch.float32, requires_grad=False)
-    flips, total = _flip_fraction(masks, lambda: oracle_fn(sd0, torch.from_numpy(x_np), modes=modes, n_layers=n_layers))
-    print(f"[{label}] ReLU decisions that differ from the oracle's own: {flips} of {total} hidden units ({flips / total:.1e})")
-    assert flips <= FLIP_BOUND * total, (flips, total)
+    fu.check(label, tag, out.detach().cpu().numpy(), loss.item(), {n: named[n].grad.cpu().numpy() for n in eng.param_names},
+             grad_tol=SKETCH_GRAD_TOL)
 
 
 @pytest.mark.gpu
@@ -85,7 +49,7 @@ def test_plasticity_real_shape_forward_backward_vs_oracle():
     eng = blk.engine()
     assert [v.L for v in eng._ws.views] == [109, 39, 28] and [v.K for v in eng._ws.views] == [32, 12, 8]
     assert all(eng._saved_x3[0]), eng._saved_x3      # every axis on the fused split kernels (x: the many-mode kernel on a prime length)
-    _check("plasticity 109x39x28 12L", blk, out, loss, x_np, t_np, sd_np, orc.ffno_mesh3d, (32, 12, 8), 12)
+    _check("plasticity 109x39x28 12L", "plasticity", blk, out, loss)
 
 
 @pytest.mark.gpu
@@ -104,4 +68,4 @@ def test_airfoil_real_shape_forward_backward_vs_oracle():
     loss.backward()
     eng = blk.engine()
     assert [v.L for v in eng._ws.views] == [229, 59] and all(eng._saved_x3[0]), eng._saved_x3
-    _check("airfoil 229x59 24L", blk, out, loss, x_np, t_np, sd_np, orc.ffno_mesh2d, (32, 16), 24)
+    _check("airfoil 229x59 24L", "airfoil", blk, out, loss)

@@ -38,6 +38,20 @@ PY
       timeout 300 python tools/time_infer.py 1 64 64 16 > gpurun_out/time_infer_b1.log 2>&1; echo "[r6] time_infer b1 rc=$?"; tail -n 8 gpurun_out/time_infer_b1.log ;;
     inferring)
       for d in ${INFER_RINGS:-1 2 3 4 1 2 3 4}; do echo "== FFNO_INFER_RING=$d"; FFNO_INFER_RING=$d timeout 300 python tools/time_infer.py 2>&1 | grep -E "K2|K1 |rel-L2"; done ;;
+    fullsize)
+      timeout 1500 python -m pytest tests/test_infer_layer.py tests/test_bench_geometry.py tests/test_real_mesh_shapes.py -m gpu -q -s --tb=short -p no:cacheprovider --durations=15 > gpurun_out/pytest_fullsize.log 2>&1
+      echo "[r6] fullsize tests rc=$?"; grep -E "^\[|passed|failed|Error|error|^[0-9.]+s " gpurun_out/pytest_fullsize.log | tail -60 ;;
+    pmcinfer)
+      R=$PWD
+      for pass in "A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "B SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"; do
+        set -- $pass; n=$1; shift
+        rm -rf gpurun_out/pmc_infer_$n
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d "$R/gpurun_out/pmc_infer_$n" -o ffno -- python "$R/tools/time_infer.py" > "$R/gpurun_out/pmc_infer_$n.log" 2>&1)
+        echo "[r6] pmc infer $n rc=$?"
+        db=$(find gpurun_out/pmc_infer_$n -name "*.db" | head -1); python tools/rocpd_pmc_multi.py "$db" ffno > gpurun_out/pmc_infer_$n.md 2>&1
+        find gpurun_out/pmc_infer_$n -type f -size +1M -delete
+        cut -c1-400 gpurun_out/pmc_infer_$n.md
+      done ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done

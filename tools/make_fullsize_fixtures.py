@@ -32,7 +32,7 @@ PLASTICITY = dict(modes_x=32, modes_y=12, modes_z=8, width=64, input_dim=4, outp
                   ff_weight_norm=True, n_ff_layers=2, layer_norm=False)
 AIRFOIL = dict(modes_x=32, modes_y=16, width=64, input_dim=4, n_layers=24, share_weight=False, factor=4, ff_weight_norm=True,
                n_ff_layers=2, layer_norm=False)
-DT = torch.float64
+DT = torch.float64      # (switched to float32 for the second run: the oracle's own rounding noise, see main())
 
 
 def block2d(kw, seed, B, M, N):
@@ -68,20 +68,31 @@ CASES = {
 
 
 def main():
+    global DT
     tags = sys.argv[1:] or list(CASES)
     torch.set_num_threads(os.cpu_count() or 8)
     for tag in tags:
         desc, thunk = CASES[tag]
         t0 = time.time()
+        DT = torch.float64
         out, loss, grads = thunk()
-        d = {"desc": np.array(desc), "loss": np.float64(loss), "dtype": np.array("float64")}
+        # the same run in fp32: |oracle(fp32) - oracle(fp64)| per tensor is the reference op sequence's OWN rounding noise (ReLU
+        # decisions within an ulp of zero included) -- the scale a gradient that is a sum with heavy cancellation is held to
+        # (tests/oracle_util.py::check_grads_at_rounding_level does the same with live runs)
+        DT = torch.float32
+        out32, loss32, grads32 = thunk()
+        d = {"desc": np.array(desc), "loss": np.float64(loss), "dtype": np.array("float64"), "loss_fp32": np.float64(loss32)}
         d.update(fu.make_sketch(tag, "out", out))
+        d["out::noise"] = np.float64(np.linalg.norm(out32.astype(np.float64) - out) / max(np.linalg.norm(out), 1e-30))
         for n, gr in grads.items():
             if gr is not None:
                 d.update(fu.make_sketch(tag, "grad/" + n, gr))
+                d[f"grad/{n}::noise"] = np.float64(np.linalg.norm(grads32[n].astype(np.float64) - gr) / max(np.linalg.norm(gr), 1e-30))
         path = os.path.join(fu.GOLDEN, f"fullsize_{tag}.npz")
         np.savez_compressed(path, **d)
-        print(f"[fullsize] {tag}: {len(grads)} gradients, loss {loss:.6f}, {os.path.getsize(path) / 1024:.0f} KB, {time.time() - t0:.0f} s", flush=True)
+        worst = max((float(d[k]) for k in d if k.endswith("::noise") and k.startswith("grad/")), default=0.0)
+        print(f"[fullsize] {tag}: {len(grads)} gradients, loss {loss:.6f}, forward noise {float(d['out::noise']):.1e}, worst gradient noise "
+              f"{worst:.1e}, {os.path.getsize(path) / 1024:.0f} KB, {time.time() - t0:.0f} s", flush=True)
 
 
 if __name__ == "__main__":
