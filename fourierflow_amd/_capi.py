@@ -150,6 +150,8 @@ SIGNATURES = {
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P]),
     "ffno_spectral2d_ws_floats": (SZ, [I, I, I, I, I]),
+    "ffno_spectral2d_path": (I, [I, I, I, I, I]),
+    "ffno_spectral2d_weights_version": (I, [P, C.c_ulonglong]),
     "ffno_spectral2d_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "ffno_spectral2d_bwd": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "ffno_ff_mask_words": (SZ, [I, I]),

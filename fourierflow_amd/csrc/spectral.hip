@@ -1501,14 +1501,150 @@ extern "C" int ffno_fw_grad_reduce_real(const float* partial, float* gw, int C, 
 }
 
 // ---- operator level -----------------------------------------------------------------------------
+// SpectralConv2d.forward_fourier (grid_2d.py:51-99) and its backward behind ONE call each (SURVEY 8b "signature level 1").
+// Round 6: where the fused split kernels take the shape (ffno_spectral_x3_supported for both axes: width 64 with up to 64 modes,
+// width 32 with up to 16) the call runs THEM -- one launch per axis, spectrum tile in LDS, fp16x2 mix packs, the range word of
+// the input folded by one ffno_amax launch -- instead of the round-1 stage sequence (dft_fwd -> fw_pack -> mode_mix -> dft_inv
+// per axis: eight launches, spectra through HBM).  Everything the fused path needs lives in the caller's workspace behind the
+// stage path's buffers: the packed weight sets (forward + adjoint, both axes), the DFT-fragment tables, the pack descriptors and
+// the range words.  The packs are rebuilt on every call unless the caller declares a weight version
+// (ffno_spectral2d_weights_version): then a call whose (weights, shape, version) equal those the packs in `ws` were made from
+// skips the re-pack -- the library keeps that record per workspace pointer (host side, a small table under a mutex).
 // workspace layout (floats): [spec_a: K*Rmax*2C][spec_b: K*Rmax*2C][wp: 2KCC][wpt: 2KCC][partial: NSPLIT*2KCC]
+//                            [x3: 4 packed sets | 4 fragment tables | 4 pack descriptors | 4 range words]
 static const int kFwSplit = 8;
 
-extern "C" size_t ffno_spectral2d_ws_floats(int B, int M, int N, int C, int K) {
+#include <mutex>
+
+namespace {
+
+struct Sp2dLayout {
+    size_t spec, planes, base;            // floats
+    size_t pack_f, tab_n_f, tab_m_f;      // floats per packed set / per fragment table of the N- / M-axis
+    size_t off_pack, off_tab, off_desc, off_words, total;
+};
+static Sp2dLayout sp2d_layout(int B, int M, int N, int C, int K) {
+    Sp2dLayout l;
     const size_t rmax = (size_t)B * (size_t)max(M, N);
-    const size_t spec = (size_t)K * rmax * 2 * C;
-    const size_t planes = (size_t)2 * K * C * C;
-    return 2 * spec + 2 * planes + (size_t)kFwSplit * planes;
+    l.spec = (size_t)K * rmax * 2 * C;
+    l.planes = (size_t)2 * K * C * C;
+    l.base = 2 * l.spec + 2 * l.planes + (size_t)kFwSplit * l.planes;
+    l.pack_f = (ffno_spectral_x3_pack_bytes(C, K) + 15) / 16 * 4;
+    l.tab_n_f = (ffno_spectral_x3_dft_frags_bytes(N, K) + 15) / 16 * 4;
+    l.tab_m_f = (ffno_spectral_x3_dft_frags_bytes(M, K) + 15) / 16 * 4;
+    l.off_pack = (l.base + 3) / 4 * 4;                     // 16-byte aligned
+    l.off_tab = l.off_pack + 4 * l.pack_f;
+    l.off_desc = l.off_tab + 2 * (l.tab_n_f + l.tab_m_f);
+    l.off_words = l.off_desc + 4 * sizeof(ffno_x3pack_desc) / sizeof(float);
+    l.total = l.off_words + 4;
+    return l;
+}
+static bool sp2d_x3_ok(int B, int M, int N, int C, int K) {
+    if (!ffno_spectral_x3_supported(C, K, N) || !ffno_spectral_x3_supported(C, K, M)) return false;
+    if (K > N / 2 + 1 || K > M / 2 + 1) return false;
+    return (size_t)B * M * N * C * 4 < ((size_t)1 << 32);      // (the fused kernels address with 32-bit byte offsets)
+}
+
+// what the packs / tables inside a workspace were made from
+struct Sp2dRecord {
+    const void* ws;
+    const float *w_y, *w_x;
+    int B, M, N, C, K, mode;
+    unsigned long long declared, packed;      // weight versions: declared by the caller / of the packs in ws (0 = unknown)
+    unsigned long long tick;
+};
+static std::mutex g_sp2d_mu;
+static Sp2dRecord g_sp2d[64];
+static unsigned long long g_sp2d_tick = 0;
+
+static Sp2dRecord* sp2d_record(const void* ws, bool create) {      // (call with the mutex held)
+    Sp2dRecord* lru = &g_sp2d[0];
+    for (Sp2dRecord& r : g_sp2d) {
+        if (r.ws == ws) {
+            r.tick = ++g_sp2d_tick;
+            return &r;
+        }
+        if (r.tick < lru->tick) lru = &r;
+    }
+    if (!create) return nullptr;
+    *lru = Sp2dRecord{ws, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0ull, 0ull, ++g_sp2d_tick};
+    return lru;
+}
+
+// packs + tables for (w_y, w_x, shape) are in ws after this; true = they had to be (re)built
+static int sp2d_prepare(const float* w_y, const float* w_x, float* ws, const float* tw_n, const float* tw_m, int B, int M, int N,
+                        int C, int K, int mode, void* stream, const Sp2dLayout& l) {
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> g(g_sp2d_mu);
+        Sp2dRecord* r = sp2d_record(ws, true);
+        hit = r->declared != 0 && r->packed == r->declared && r->w_y == w_y && r->w_x == w_x && r->B == B && r->M == M && r->N == N &&
+              r->C == C && r->K == K && r->mode == mode;
+        if (!hit) {
+            r->w_y = w_y, r->w_x = w_x, r->B = B, r->M = M, r->N = N, r->C = C, r->K = K, r->mode = mode;
+            r->packed = r->declared;      // (0 while the caller declares nothing: the next call packs again)
+        }
+    }
+    if (hit) return FFNO_OK;
+    int rc;
+    float* wp = ws + 2 * l.spec;
+    float* wpt = wp + l.planes;
+    if (mode == FFNO_MODE_FULL) {
+        ffno_x3pack_desc* descs = reinterpret_cast<ffno_x3pack_desc*>(ws + l.off_desc);
+        for (int axis = 0; axis < 2; ++axis) {
+            if ((rc = ffno_fw_pack(axis == 0 ? w_y : w_x, wp, wpt, C, K, stream))) return rc;
+            const ffno_x3pack_desc h[2] = {{wp, ws + l.off_pack + (2 * axis) * l.pack_f, K, FFNO_PLANES_FP16X2},
+                                           {wpt, ws + l.off_pack + (2 * axis + 1) * l.pack_f, K, FFNO_PLANES_FP16X2}};
+            // (pageable host memory: the copy is staged before the call returns)
+            if (hipMemcpyAsync(descs + 2 * axis, h, sizeof(h), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+                return (int)hipGetLastError();
+            if ((rc = ffno_spectral_x3_pack(descs + 2 * axis, 2, C, K, stream))) return rc;
+        }
+    }
+    // DFT-fragment tables (forward / adjoint flags) of both axes: what the many-mode, latency and width-32 kernels load instead of
+    // rebuilding the fragments for every line
+    float* tab = ws + l.off_tab;
+    if (l.tab_n_f) {
+        if ((rc = ffno_spectral_x3_dft_frags(tw_n, N, K, 0, 1, tab, stream))) return rc;
+        if ((rc = ffno_spectral_x3_dft_frags(tw_n, N, K, 1, 0, tab + l.tab_n_f, stream))) return rc;
+    }
+    if (l.tab_m_f) {
+        if ((rc = ffno_spectral_x3_dft_frags(tw_m, M, K, 0, 1, tab + 2 * l.tab_n_f, stream))) return rc;
+        if ((rc = ffno_spectral_x3_dft_frags(tw_m, M, K, 1, 0, tab + 2 * l.tab_n_f + l.tab_m_f, stream))) return rc;
+    }
+    return FFNO_OK;
+}
+
+// one axis through the fused split kernel: out (+)= branch(in)
+static int sp2d_branch(const float* in, float* out, float* spec_save, const float* ws_c, const Sp2dLayout& l, const float* tw, int B,
+                       int M, int N, int C, int K, int axis, int mode, bool fwd, int accumulate, const uint32_t* word, void* stream) {
+    float* ws = const_cast<float*>(ws_c);
+    ffno_fused_branch br = {};
+    br.in = in, br.out = out, br.spec_save = spec_save, br.tw = tw;
+    br.B = B, br.M = M, br.N = N, br.K = K, br.axis = axis, br.accumulate = accumulate;
+    if (mode == FFNO_MODE_FULL) {
+        br.planes = ws + l.off_pack + (2 * axis + (fwd ? 0 : 1)) * l.pack_f;
+        br.planes_format = FFNO_PLANES_FP16X2;
+        br.in_amax = word;
+        const size_t tf = axis == 0 ? l.tab_n_f : l.tab_m_f;
+        if (tf) br.dft_frags = ws + l.off_tab + (axis == 0 ? 0 : 2 * l.tab_n_f) + (fwd ? 0 : tf);
+    }
+    return fwd ? ffno_spectral_x3(&br, C, 0, 1, 0, stream) : ffno_spectral_x3(&br, C, 1, 0, 1, stream);
+}
+
+}  // namespace
+
+extern "C" size_t ffno_spectral2d_ws_floats(int B, int M, int N, int C, int K) { return sp2d_layout(B, M, N, C, K).total; }
+
+extern "C" int ffno_spectral2d_path(int B, int M, int N, int C, int K) {
+    return sp2d_x3_ok(B, M, N, C, K) ? FFNO_SPECTRAL2D_FUSED_X3 : FFNO_SPECTRAL2D_STAGES;
+}
+
+extern "C" int ffno_spectral2d_weights_version(const float* ws, unsigned long long version) {
+    if (!ws) return FFNO_EINVAL;
+    std::lock_guard<std::mutex> g(g_sp2d_mu);
+    sp2d_record(ws, true)->declared = version;
+    return FFNO_OK;
 }
 
 extern "C" int ffno_spectral2d_fwd(const float* x, const float* w_y, const float* w_x, float* out, float* ws,
@@ -1517,13 +1653,23 @@ extern "C" int ffno_spectral2d_fwd(const float* x, const float* w_y, const float
     if (!x || !out || !ws || !tw_n || !tw_m) return FFNO_EINVAL;
     if (mode != FFNO_MODE_FULL && mode != FFNO_MODE_LOWPASS) return FFNO_EINVAL;
     if (mode == FFNO_MODE_FULL && (!w_y || !w_x)) return FFNO_EINVAL;
-    const size_t rmax = (size_t)B * (size_t)max(M, N);
-    const size_t spec = (size_t)K * rmax * 2 * C, planes = (size_t)2 * K * C * C;
+    const Sp2dLayout l = sp2d_layout(B, M, N, C, K);
+    int rc;
+    if (sp2d_x3_ok(B, M, N, C, K)) {
+        if ((rc = sp2d_prepare(w_y, w_x, ws, tw_n, tw_m, B, M, N, C, K, mode, stream, l))) return rc;
+        uint32_t* word = reinterpret_cast<uint32_t*>(ws + l.off_words);
+        if (mode == FFNO_MODE_FULL) {
+            if (hipMemsetAsync(word, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+            if ((rc = ffno_amax(x, (size_t)B * M * N * C, word, stream))) return rc;
+        }
+        if ((rc = sp2d_branch(x, out, nullptr, ws, l, tw_n, B, M, N, C, K, 0, mode, true, 0, word, stream))) return rc;
+        return sp2d_branch(x, out, nullptr, ws, l, tw_m, B, M, N, C, K, 1, mode, true, 1, word, stream);
+    }
+    const size_t spec = l.spec, planes = l.planes;
     float* sa = ws;
     float* sb = ws + spec;
     float* wp = ws + 2 * spec;
     float* wpt = wp + planes;
-    int rc;
     for (int axis = 0; axis < 2; ++axis) {
         const int R = axis == 0 ? B * M : B * N;
         const float* tw = axis == 0 ? tw_n : tw_m;
@@ -1547,14 +1693,39 @@ extern "C" int ffno_spectral2d_bwd(const float* x, const float* w_y, const float
     if (!gy || !gx || !ws || !tw_n || !tw_m) return FFNO_EINVAL;
     if (mode != FFNO_MODE_FULL && mode != FFNO_MODE_LOWPASS) return FFNO_EINVAL;
     if (mode == FFNO_MODE_FULL && (!w_y || !w_x || !x)) return FFNO_EINVAL;
-    const size_t rmax = (size_t)B * (size_t)max(M, N);
-    const size_t spec = (size_t)K * rmax * 2 * C, planes = (size_t)2 * K * C * C;
+    const Sp2dLayout l = sp2d_layout(B, M, N, C, K);
+    const size_t spec = l.spec, planes = l.planes;
     float* sa = ws;
     float* sb = ws + spec;
     float* wp = ws + 2 * spec;
     float* wpt = wp + planes;
     float* partial = wpt + planes;
     int rc;
+    if (sp2d_x3_ok(B, M, N, C, K)) {
+        // (prepare first: it uses wp / wpt as scratch, the weight-gradient reduction below uses `partial` behind them)
+        if ((rc = sp2d_prepare(w_y, w_x, ws, tw_n, tw_m, B, M, N, C, K, mode, stream, l))) return rc;
+        uint32_t* word = reinterpret_cast<uint32_t*>(ws + l.off_words) + 1;
+        if (mode == FFNO_MODE_FULL) {
+            if (hipMemsetAsync(word, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
+            if ((rc = ffno_amax(gy, (size_t)B * M * N * C, word, stream))) return rc;
+        }
+        for (int axis = 0; axis < 2; ++axis) {
+            const int R = axis == 0 ? B * M : B * N;
+            const float* tw = axis == 0 ? tw_n : tw_m;
+            float* gw = axis == 0 ? gw_y : gw_x;
+            const bool want_gw = mode == FFNO_MODE_FULL && gw;
+            // gx (+)= branch^T(gy); the adjoint launch leaves dY (the adjoint of the zero-padded irfft applied to gy) in `sa`
+            if ((rc = sp2d_branch(gy, gx, want_gw ? sa : nullptr, ws, l, tw, B, M, N, C, K, axis, mode, false,
+                                  (axis == 1) || accumulate_gx, word, stream)))
+                return rc;
+            if (want_gw) {
+                if ((rc = ffno_dft_fwd(x, sb, tw, B, M, N, C, K, axis, 0, stream))) return rc;      // recompute X
+                if ((rc = ffno_fw_grad_partial(sb, sa, partial, R, C, K, kFwSplit, 0, 1, 0, 0, stream))) return rc;
+                if ((rc = ffno_fw_grad_reduce(partial, gw, C, K, kFwSplit, accumulate_gw, stream))) return rc;
+            }
+        }
+        return FFNO_OK;
+    }
     for (int axis = 0; axis < 2; ++axis) {
         const int R = axis == 0 ? B * M : B * N;
         const float* tw = axis == 0 ? tw_n : tw_m;

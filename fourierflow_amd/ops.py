@@ -26,13 +26,40 @@ def _twiddle(L: int, device) -> torch.Tensor:
     return _TW[key]
 
 
+_SP2D_WS = {}
+
+
+def _spectral2d_workspace(x, w_y, w_x, modes):
+    """The operator's workspace for a shape, kept per (shape, device): besides the scratch spectra it holds the packed weight sets
+    of the fused kernels (ffno_spectral2d_path), and the library reuses them across calls when the caller declares the VERSION of
+    the weights (include/ffno.h: ffno_spectral2d_weights_version) -- here (data pointer, torch version counter) of both tensors, so
+    a forward / backward pair and repeated calls on unchanged weights pack once, and an optimizer step re-packs."""
+    lib = _lib.get_lib()
+    B, M, N, C = x.shape
+    key = (B, M, N, C, modes, str(x.device), _lib.is_test_backend())
+    ws = _SP2D_WS.get(key)
+    if ws is None:
+        ws = torch.empty(int(lib.ffno_spectral2d_ws_floats(B, M, N, C, modes)), dtype=torch.float32, device=x.device)
+        _SP2D_WS[key] = ws
+        while len(_SP2D_WS) > 8:
+            _SP2D_WS.pop(next(iter(_SP2D_WS)))
+    version = 0
+    if w_y is not None and w_x is not None:
+        try:
+            version = (hash((w_y.data_ptr(), w_y._version, w_x.data_ptr(), w_x._version)) & 0x7FFFFFFFFFFFFFFF) or 1
+        except RuntimeError:        # inference tensors have no version counter: undeclared, the library packs on every call
+            version = 0
+    _capi.check(lib.ffno_spectral2d_weights_version(_p(ws), version), "spectral2d_weights_version")
+    return ws
+
+
 class _SpectralConv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w_y, w_x, modes, mode_id):
         lib = _lib.get_lib()
         B, M, N, C = x.shape
         st = _lib.current_stream(x.device)
-        ws = torch.empty(int(lib.ffno_spectral2d_ws_floats(B, M, N, C, modes)), dtype=torch.float32, device=x.device)
+        ws = _spectral2d_workspace(x, w_y, w_x, modes)
         out = torch.empty_like(x)
         twn, twm = _twiddle(N, x.device), _twiddle(M, x.device)
         _capi.check(lib.ffno_spectral2d_fwd(_p(x), _p(w_y), _p(w_x), _p(out), _p(ws), _p(twn), _p(twm), B, M, N, C,
@@ -49,7 +76,7 @@ class _SpectralConv2dFn(torch.autograd.Function):
         B, M, N, C = x.shape
         st = _lib.current_stream(x.device)
         gy = gy.contiguous()
-        ws = torch.empty(int(lib.ffno_spectral2d_ws_floats(B, M, N, C, modes)), dtype=torch.float32, device=x.device)
+        ws = _spectral2d_workspace(x, w_y, w_x, modes)
         gx = torch.empty_like(x)
         full = mode_id == MODES["full"]
         gwy = torch.empty_like(w_y) if full else None

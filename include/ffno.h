@@ -385,6 +385,19 @@ int ffno_spectral_staged_pair(const ffno_fused_branch* a, const ffno_fused_branc
  * Backward: gx (+)= d/dx, gw_y/gw_x (+)= d/dW (pass NULL to skip), given gy = dL/dout.
  * --------------------------------------------------------------------------------------------- */
 size_t ffno_spectral2d_ws_floats(int B, int M, int N, int C, int K);
+/* Which kernels the two calls below run for a shape (round 6): FFNO_SPECTRAL2D_FUSED_X3 -- the fused split kernels of
+ * ffno_spectral_x3 (one launch per axis, spectrum tile in LDS, fp16x2 mix packs, the input's range word folded by one ffno_amax
+ * launch; every shape ffno_spectral_x3_supported takes on both axes) -- or FFNO_SPECTRAL2D_STAGES, the stage sequence
+ * dft_fwd -> fw_pack -> mode_mix -> dft_inv per axis (everything else).  The packed weight sets, fragment tables and range words of
+ * the fused path live in `ws` (ffno_spectral2d_ws_floats covers them).
+ * ffno_spectral2d_weights_version (optional): by default every call re-packs the weights (four small launches: the weights may
+ * have changed).  A caller that knows better declares a non-zero VERSION of the weights it is about to pass with `ws`; a call
+ * whose (w_y, w_x, shape, mode, version) equal those the packs inside `ws` were made from skips the re-pack.  The record is kept
+ * per workspace pointer on the host (no device read-back); declare 0 -- or a new number -- after the weights changed. */
+#define FFNO_SPECTRAL2D_STAGES 0
+#define FFNO_SPECTRAL2D_FUSED_X3 1
+int ffno_spectral2d_path(int B, int M, int N, int C, int K);
+int ffno_spectral2d_weights_version(const float* ws, unsigned long long version);
 int ffno_spectral2d_fwd(const float* x, const float* w_y, const float* w_x, float* out, float* ws,
                         const float* tw_n, const float* tw_m, int B, int M, int N, int C, int K,
                         int mode, void* stream);

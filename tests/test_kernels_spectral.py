@@ -149,6 +149,9 @@ def test_spectral2d_operator_vs_reference_golden(be, tag):
     twn, twm = be.twiddle(N), be.twiddle(M)
     dx, dw0, dw1, dgy, y = be.put(x), be.put(w0), be.put(w1), be.put(gy), be.empty(x.shape)
     p = be.ptr
+    # round 6: the level-1 entry point runs the FUSED split kernels (one launch per axis) for every shape they take -- the
+    # reference's own forward_fourier golden meets the kernels that ship
+    assert lib.ffno_spectral2d_path(B, M, N, C, K) == 1
     assert lib.ffno_spectral2d_fwd(p(dx), p(dw0), p(dw1), p(y), p(ws), p(twn), p(twm), B, M, N, C, K, 0, None) == 0
     assert gu.compare_packed(g, "y", be.get(y), TOL) < TOL
     gx, gw0, gw1 = be.empty(x.shape), be.zeros(w0.shape), be.zeros(w1.shape)
@@ -157,6 +160,76 @@ def test_spectral2d_operator_vs_reference_golden(be, tag):
     assert gu.compare_packed(g, "gx", be.get(gx), TOL) < TOL
     assert gu.compare_packed(g, "gw0", be.get(gw0), TOL) < 2e-5
     assert gu.compare_packed(g, "gw1", be.get(gw1), TOL) < 2e-5
+
+
+def _fp64_forward_fourier(x, w0, w1, K):
+    """grid_2d.py:51-99 in fp64 (x [B, M, N, C]; w0 mixes the last axis, w1 the first)."""
+    xt = torch.tensor(x, dtype=torch.float64).permute(0, 3, 1, 2)
+    B, I, M, N = xt.shape
+    wa = torch.view_as_complex(torch.tensor(w0, dtype=torch.float64).contiguous())
+    wb = torch.view_as_complex(torch.tensor(w1, dtype=torch.float64).contiguous())
+    fy = torch.fft.rfft(xt, dim=-1, norm="ortho")
+    oy = torch.zeros(B, I, M, N // 2 + 1, dtype=torch.complex128)
+    oy[..., :K] = torch.einsum("bixy,ioy->boxy", fy[..., :K], wa)
+    fx = torch.fft.rfft(xt, dim=-2, norm="ortho")
+    ox = torch.zeros(B, I, M // 2 + 1, N, dtype=torch.complex128)
+    ox[:, :, :K] = torch.einsum("bixy,iox->boxy", fx[:, :, :K], wb)
+    return (torch.fft.irfft(oy, n=N, dim=-1, norm="ortho") + torch.fft.irfft(ox, n=M, dim=-2, norm="ortho")).permute(0, 2, 3, 1).numpy()
+
+
+def test_spectral2d_pack_cache_follows_the_declared_weight_version(be):
+    """ffno_spectral2d_weights_version (include/ffno.h): by default every call re-packs the weights; with a declared non-zero version
+    a repeated call on the same (ws, weights, shape) skips the re-pack -- shown here by changing the weights IN PLACE behind the
+    library's back: same declared version -> the result still follows the OLD weights (the packs in ws were reused), a new version
+    (or 0) -> the new weights."""
+    lib, p = be.lib, be.ptr
+    B, M, N, C, K = 1, 8, 16, 64, 4
+    rs = np.random.RandomState(7)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    w0, w1 = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32), (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+    assert lib.ffno_spectral2d_path(B, M, N, C, K) == 1
+    ws = be.zeros(lib.ffno_spectral2d_ws_floats(B, M, N, C, K))
+    twn, twm = be.twiddle(N), be.twiddle(M)
+    dx, dw0, dw1, y = be.put(x), be.put(w0), be.put(w1), be.empty(x.shape)
+
+    def run():
+        assert lib.ffno_spectral2d_fwd(p(dx), p(dw0), p(dw1), p(y), p(ws), p(twn), p(twm), B, M, N, C, K, 0, None) == 0
+        return np.array(be.get(y)).copy()
+
+    ref_old = _fp64_forward_fourier(x, w0, w1, K)
+    assert rel_l2(run(), ref_old) < TOL                       # undeclared: packs on every call
+    assert lib.ffno_spectral2d_weights_version(p(ws), 41) == 0
+    assert rel_l2(run(), ref_old) < TOL                       # version 41: packed for it
+    # the weights change in place (same pointers); the caller has NOT declared a new version
+    w0b = (w0 * 1.5).astype(np.float32)
+    if be.kind == "emu":
+        dw0[...] = w0b
+    else:
+        dw0.copy_(torch.from_numpy(w0b))
+    y_stale = run()
+    assert rel_l2(y_stale, ref_old) < TOL                     # the packs of version 41 were reused: no re-pack happened
+    ref_new = _fp64_forward_fourier(x, w0b, w1, K)
+    assert lib.ffno_spectral2d_weights_version(p(ws), 42) == 0
+    assert rel_l2(run(), ref_new) < TOL                       # declared: re-packed
+    assert rel_l2(run(), ref_new) < TOL
+    assert lib.ffno_spectral2d_weights_version(p(ws), 0) == 0     # back to "unknown": every call packs
+    assert rel_l2(run(), ref_new) < TOL
+    assert lib.ffno_spectral2d_weights_version(None, 1) == -1
+
+
+def test_spectral2d_stage_path_still_serves_what_the_fused_kernels_refuse(be):
+    """Width 32 with more than 16 modes: outside ffno_spectral_x3_supported -> the stage sequence, same results."""
+    lib, p = be.lib, be.ptr
+    B, M, N, C, K = 1, 40, 40, 32, 18
+    assert lib.ffno_spectral2d_path(B, M, N, C, K) == 0
+    rs = np.random.RandomState(3)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    w0, w1 = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32), (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+    ws = be.zeros(lib.ffno_spectral2d_ws_floats(B, M, N, C, K))
+    twn, twm = be.twiddle(N), be.twiddle(M)
+    y = be.empty(x.shape)
+    assert lib.ffno_spectral2d_fwd(p(be.put(x)), p(be.put(w0)), p(be.put(w1)), p(y), p(ws), p(twn), p(twm), B, M, N, C, K, 0, None) == 0
+    assert rel_l2(be.get(y), _fp64_forward_fourier(x, w0, w1, K)) < TOL
 
 
 @pytest.mark.gpu

@@ -52,6 +52,12 @@ PY
         find gpurun_out/pmc_infer_$n -type f -size +1M -delete
         cut -c1-400 gpurun_out/pmc_infer_$n.md
       done ;;
+    power)
+      timeout 900 python tools/power_trace.py --seconds ${POWER_SECONDS:-5} > gpurun_out/power_trace.log 2>&1; echo "[r6] power rc=$?"; tail -n 45 gpurun_out/power_trace.log | cut -c1-330 ;;
+    lvl1)
+      timeout 600 python -m pytest tests/test_kernels_spectral.py tests/test_block.py -m gpu -q -x --tb=short -p no:cacheprovider -k "spectral2d or standalone" > gpurun_out/pytest_lvl1.log 2>&1
+      echo "[r6] level-1 tests rc=$?"; tail -n 3 gpurun_out/pytest_lvl1.log
+      timeout 300 python tools/time_spectral2d.py > gpurun_out/time_spectral2d.log 2>&1; echo "[r6] time_spectral2d rc=$?"; tail -n 5 gpurun_out/time_spectral2d.log ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
