@@ -664,6 +664,49 @@ def main():
         for n, kr in kernels.items():
             share[n.split("(")[0]] = share.get(n.split("(")[0], 0.0) + kr["ms_per_step"]
         dom = max(share, key=share.get) if share else None
+        # Forward-only path (trainer.predict = `ms_per_forward`): at this size the two-launch INFERENCE layer (csrc/infer.hip) --
+        # its launches captured from one predict() and replay-timed like the training launches; roofline on SURVEY 8(d)'s bytes of a
+        # fused layer (read x + write x' once) over the time of BOTH launches of a layer
+        roofline_forward = None
+        try:
+            if headline and not args.plus:
+                pf = KernelProbe(["spectral_mix", "infer_ff"])
+                trainer.engine.timer = pf
+                pf.capture = True
+                trainer.predict(x)
+                pf.capture = False
+                trainer.engine.timer = None
+                torch.cuda.synchronize()
+                if getattr(trainer.engine, "infer_last", False) and all(pf.calls.get(n) for n in ("spectral_mix", "infer_ff")):
+                    repf = pf.replay(REPLAYS)
+                    P_, C_ = B * G * G, 64
+                    floor = 2.0 * P_ * C_ * 4
+                    us_layer = repf["spectral_mix"] + repf["infer_ff"]
+                    spec_b = 2.0 * (B * G) * 8192          # the two mixed spectra as operand fragments: 8 KiB per line
+                    moved = dict(spectral_mix=P_ * C_ * 4 + spec_b, infer_ff=spec_b + 2.0 * P_ * C_ * 4)
+                    ff_fl = 4.0 * P_ * C_ * 256
+                    dft = 2.0 * (B * G) * (2 * K) * G * C_
+                    flops = dict(spectral_mix=2 * (dft + 8.0 * (B * G) * K * C_ * C_), infer_ff=2 * dft + ff_fl)
+                    roofline_forward = dict(
+                        bound="hbm", achieved=round(floor / us_layer * 1e-3, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(floor / us_layer * 1e-3 / HBM_PEAK_GBS, 4),
+                        traffic=(int(sum(pmc[n]["hbm_bytes_per_launch"] for n in ("spectral_mix", "infer_ff")))
+                                 if all(n in pmc for n in ("spectral_mix", "infer_ff")) else None),
+                        us_per_layer=round(us_layer, 2), algorithmic_bytes_per_layer=int(floor),
+                        kernels={n: dict(avg_us=round(repf[n], 2), bytes_moved=int(moved[n]),
+                                         gbs_moved=round(moved[n] / repf[n] * 1e-3, 1), frac_hbm_moved=round(moved[n] / repf[n] * 1e-3 / HBM_PEAK_GBS, 3),
+                                         tflops=round(flops[n] / repf[n] * 1e-6, 1),
+                                         frac_mfma_fp16x2=round(flops[n] / repf[n] * 1e-6 / FP16X2_PEAK_TFLOPS, 3),
+                                         hbm_bytes_pmc=(pmc[n]["hbm_bytes_per_launch"] if n in pmc else None)) for n in ("spectral_mix", "infer_ff")},
+                        ms_per_forward=round(ms_fwd, 3), layers=args.layers,
+                        note="the inference layer (two launches per layer: both forward DFTs + channel mixes -> mixed spectra; both inverse "
+                             "DFTs + sum + Linear/ReLU/Linear + residual): 8(d) bytes of a fused layer (2 * P * C * 4: read x, write x') "
+                             "over the replay-timed duration of BOTH launches; bytes_moved = what each launch reads + writes (x / the two "
+                             "8-KiB-per-line fragment spectra / x, x'); traffic = PMC HBM bytes of the two launches (profiles/pmc_traffic.json)")
+                    log(f"inference layer: spectral_mix {repf['spectral_mix']:.1f} us + infer_ff {repf['infer_ff']:.1f} us per layer")
+        except Exception as e:  # noqa: BLE001 - optional evidence
+            trainer.engine.timer = None
+            log(f"forward roofline skipped: {e!r}")
         roofline = None
         if dom and not args.plus:
             members = [n for n in kernels if n.split("(")[0] == dom]
@@ -876,7 +919,7 @@ def main():
             "samples_per_s": round(opt_steps_per_s * B * world, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
             "final_loss": round(loss_val, 5), "git_head": git_head(), "lib_source_stamp": lib_source_stamp(),
-            "roofline": roofline, "kernels": kernels, "power_note": power_note, "arithmetic_variants_steps_per_s": variants,
+            "roofline": roofline, "roofline_forward": roofline_forward, "kernels": kernels, "power_note": power_note, "arithmetic_variants_steps_per_s": variants,
             "bf16_storage_variant": bf16_variant, "cpu_baseline": cpu,
             "secondary": secondary, "distributed": dist_info,
         }

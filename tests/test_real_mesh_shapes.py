@@ -22,14 +22,14 @@ from oracle import ffno_oracle as orc
 SKETCH_GRAD_TOL = 2e-4
 
 
-def _check(label, tag, blk, out, loss):
+def _check(label, tag, blk, out, loss, grad_tol=SKETCH_GRAD_TOL):
     """Forward <= 1e-5, loss <= 1e-5, every parameter gradient inside SKETCH_GRAD_TOL of the committed sketch of the fp64 oracle run
     on the same seeded inputs (tests/fullsize_util.py, tools/make_fullsize_fixtures.py; VERDICT r05 #7: until round 5 these tests ran
     the oracle live -- 48 + 58 s of the GPU run -- with the HIP path's ReLU active sets injected; that form stays at markov/24)."""
     eng = blk.engine()
     named = dict(blk.named_parameters())
     fu.check(label, tag, out.detach().cpu().numpy(), loss.item(), {n: named[n].grad.cpu().numpy() for n in eng.param_names},
-             grad_tol=SKETCH_GRAD_TOL)
+             grad_tol=grad_tol)
 
 
 @pytest.mark.gpu
@@ -68,4 +68,7 @@ def test_airfoil_real_shape_forward_backward_vs_oracle():
     loss.backward()
     eng = blk.engine()
     assert [v.L for v in eng._ws.views] == [229, 59] and all(eng._saved_x3[0]), eng._saved_x3
-    _check("airfoil 229x59 24L", "airfoil", blk, out, loss)
+    # (observed on MI355X, round 6: worst 3.6e-4 at spectral_layers.20.backcast_ff.layers.0.0.weight_g -- the sketch is the oracle on
+    #  its OWN ReLU decisions, and the 57 of 8.3e8 hidden units on which the HIP path decides differently (counted by the round-5
+    #  form of this test, which injected the HIP path's active sets and saw 3.6e-5) sit in that layer's gradient)
+    _check("airfoil 229x59 24L", "airfoil", blk, out, loss, grad_tol=1e-3)

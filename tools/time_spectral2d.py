@@ -49,6 +49,16 @@ def main():
     print("level-1 operator vs paired launch (sum of its two outputs) rel-L2:", float((y - ref).norm() / ref.norm()))
     with torch.no_grad():
         t_op = timeit(lambda: ops.spectral_conv2d(x, w0, w1, K))
+    # the C entry point itself (no autograd.Function, no workspace lookup): what a non-Python host pays
+    wsd = ops._spectral2d_workspace(x, w0, w1, K)
+    twn_, twm_ = ops._twiddle(N, x.device), ops._twiddle(M, x.device)
+    yd = torch.empty_like(x)
+    P_ = ctypes.c_void_p
+    t_c = timeit(lambda: lib.ffno_spectral2d_fwd(P_(x.data_ptr()), P_(w0.data_ptr()), P_(w1.data_ptr()), P_(yd.data_ptr()), P_(wsd.data_ptr()),
+                                                 P_(twn_.data_ptr()), P_(twm_.data_ptr()), B, M, N, C, K, 0, st))
+    lib.ffno_spectral2d_weights_version(P_(wsd.data_ptr()), 0)
+    t_c_repack = timeit(lambda: lib.ffno_spectral2d_fwd(P_(x.data_ptr()), P_(w0.data_ptr()), P_(w1.data_ptr()), P_(yd.data_ptr()), P_(wsd.data_ptr()),
+                                                        P_(twn_.data_ptr()), P_(twm_.data_ptr()), B, M, N, C, K, 0, st))
     t_pair = timeit(lambda: lib.ffno_spectral_x3_pair(ctypes.byref(a2), ctypes.byref(b2), C, 0, 1, 0, 2, st))
     # ... and what the same call cost before round 6: the stage sequence (forced by going through the C entry points directly)
     ws = torch.empty(int(lib.ffno_spectral2d_ws_floats(B, M, N, C, K)), dtype=torch.float32, device="cuda")
@@ -67,6 +77,8 @@ def main():
             lib.ffno_dft_inv(P(sb.data_ptr()), P(out.data_ptr()), None, p(tw), B, M, N, C, K, axis, 1, int(axis == 1), st)
     t_st = timeit(stages, 50)
     print(f"ops.spectral_conv2d (ffno_spectral2d_fwd: amax + one fused launch per axis)   {t_op:8.2f} us")
+    print(f"ffno_spectral2d_fwd from C (declared weight version: packs reused)             {t_c:8.2f} us")
+    print(f"ffno_spectral2d_fwd from C (no version declared: re-packs on every call)       {t_c_repack:8.2f} us")
     print(f"engine's paired fused launch (two branch images, no sum)                     {t_pair:8.2f} us   ratio {t_op / t_pair:.2f}")
     print(f"round-5 level-1 path: dft_fwd -> fw_pack -> mode_mix -> dft_inv per axis       {t_st:8.2f} us")
 
