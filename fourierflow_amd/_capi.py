@@ -145,6 +145,7 @@ SIGNATURES = {
     "ffno_layer_infer_supported": (I, [I, I, I, I, I, I, I]),
     "ffno_spectral_x3_mix_pair": (I, [P, P, I, I, P]),
     "ffno_infer_ff": (I, [P, P, P, P, P, P, P, P, I, I, P, P]),
+    "ffno_infer_sum": (I, [P, P, P, I, P, P]),
     "ffno_layer_infer": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),

@@ -87,7 +87,9 @@ __device__ __forceinline__ LineFrags load_line(const u32x4* __restrict__ mix, lo
 // channel chunks XOR-swizzled by `key`
 __device__ __forceinline__ int swz_key(int mrel, int n) { return (n + mrel) & 15; }
 
-template <int RING = 2>
+// FF = false: the spectral operator alone -- out = branch_rows(x) + branch_cols(x) (SpectralConv2d.forward_fourier, grid_2d.py:51-99):
+// phases A and A', then the tiles leave through the staging rows (ffno_infer_sum; the level-1 entry point ffno_spectral2d_fwd)
+template <int RING = 2, bool FF = true>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_ff_kernel(const InferArgs A) {
     constexpr int C = 64, H = 256, NCH = H / 32, KS = C / 16, CTO = C / 32, NWV = 8;
     constexpr int NF1 = NCH * KS, NF2 = NCH * CTO * 2;
@@ -204,6 +206,36 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_ff_kernel(co
                 s[i][8 * g + 2 * q + 1] = __builtin_fmaf(a1[4 * g + q], osc, s[i][8 * g + 2 * q + 1]);
             }
         }
+    }
+    if constexpr (!FF) {
+        __syncthreads();      // (every wave has read its tiles: the column-branch image may be overwritten by the staging rows)
+        float omax = 0.f;
+        float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SROW);
+        const int mrow = lane >> 2, mq = lane & 3;
+        float* stg_m0 = stg + mrow * SROW + 4 * mq;
+        FFNO_UNROLL
+        for (int i = 0; i < 2; ++i) {
+            if (!tlive[i]) continue;
+            const long px0 = ((long)image * M + m0 + trow[i]) * N + tn0[i];
+            FFNO_UNROLL
+            for (int g = 0; g < 4; ++g) {      // 16 channels at a time: operand map (pixel per lane) -> memory map (64-byte row segments)
+                *reinterpret_cast<float4*>(stg + j * SROW + 8 * half) = make_float4(s[i][8 * g], s[i][8 * g + 1], s[i][8 * g + 2], s[i][8 * g + 3]);
+                *reinterpret_cast<float4*>(stg + j * SROW + 8 * half + 4) =
+                    make_float4(s[i][8 * g + 4], s[i][8 * g + 5], s[i][8 * g + 6], s[i][8 * g + 7]);
+                plat::wave_sync();
+                float4 acc[2];
+                FFNO_UNROLL
+                for (int ii = 0; ii < 2; ++ii) acc[ii] = *reinterpret_cast<const float4*>(stg_m0 + 16 * ii * SROW);
+                plat::wave_sync();
+                FFNO_UNROLL
+                for (int ii = 0; ii < 2; ++ii) {
+                    *reinterpret_cast<float4*>(A.out + (px0 + 16 * ii + mrow) * C + 4 * mq + 16 * g) = acc[ii];
+                    omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc[ii].x), fabsf(acc[ii].y))), fmaxf(fabsf(acc[ii].z), fabsf(acc[ii].w)));
+                }
+            }
+        }
+        if (A.out_amax) range_fold(omax, rfold, NWV, A.out_amax);
+        return;
     }
     // one input scale per WORKGROUP: the maximum of its 512 pixels' feed-forward inputs and of the first linear map's biases (the
     // hidden pre-activations are W1 s + b1: the scale must leave room for both terms) goes to 2^kInferRangeTarget
@@ -394,11 +426,10 @@ extern "C" int ffno_layer_infer_supported(int B, int M, int N, int C, int H, int
     return (long)B * M * N * C * 4 < (1l << 32) ? 1 : 0;
 }
 
-extern "C" int ffno_infer_ff(const ffno_fused_branch* ba, const ffno_fused_branch* bb, const void* pk1, const float* b1,
-                             const void* pk2, const float* b2, const float* resid, float* out, int C, int H, uint32_t* out_amax,
-                             void* stream) {
-    if (!ba || !bb || !pk1 || !b1 || !pk2 || !b2 || !out || !ba->out || !bb->out || !ba->dft_frags || !bb->dft_frags)
-        return FFNO_EINVAL;
+static int infer_launch(const ffno_fused_branch* ba, const ffno_fused_branch* bb, const void* pk1, const float* b1, const void* pk2,
+                        const float* b2, const float* resid, float* out, int C, int H, uint32_t* out_amax, bool ff, void* stream) {
+    if (!ba || !bb || !out || !ba->out || !bb->out || !ba->dft_frags || !bb->dft_frags) return FFNO_EINVAL;
+    if (ff && (!pk1 || !b1 || !pk2 || !b2)) return FFNO_EINVAL;
     if (ba->axis == bb->axis || ba->B != bb->B || ba->M != bb->M || ba->N != bb->N) return FFNO_EINVAL;
     const ffno_fused_branch* row = ba->axis == 0 ? ba : bb;      // lines (b, m), transform along n
     const ffno_fused_branch* col = ba->axis == 0 ? bb : ba;      // lines (b, n), transform along m
@@ -420,12 +451,29 @@ extern "C" int ffno_infer_ff(const ffno_fused_branch* ba, const ffno_fused_branc
     A.out_amax = out_amax;
     const size_t lds_a = (size_t)A.R * N * 256;
     const size_t lds_b = (size_t)(2 * 64 * 1024) + (256 + 64) * sizeof(float) + 8 * 32 * 20 * sizeof(float);
-    const size_t smem = lds_a > lds_b ? lds_a : lds_b;
+    const size_t smem = (!ff || lds_a > lds_b) ? lds_a : lds_b;
     // (ring depth 2: measured 41.6 us per launch at batch 32 against 41.7 / 42.9 / 43.5 for depths 1 / 3 / 4 -- the deeper rings spill)
-    const int rc = allow_dynamic_lds(infer_ff_kernel<2>, smem);
-    if (rc) return rc;
-    FFNO_LAUNCH((infer_ff_kernel<2>), dim3(B * A.T), dim3(512), smem, (hipStream_t)stream, A);
+    if (ff) {
+        const int rc = allow_dynamic_lds(infer_ff_kernel<2, true>, smem);
+        if (rc) return rc;
+        FFNO_LAUNCH((infer_ff_kernel<2, true>), dim3(B * A.T), dim3(512), smem, (hipStream_t)stream, A);
+    } else {
+        const int rc = allow_dynamic_lds(infer_ff_kernel<2, false>, smem);
+        if (rc) return rc;
+        FFNO_LAUNCH((infer_ff_kernel<2, false>), dim3(B * A.T), dim3(512), smem, (hipStream_t)stream, A);
+    }
     return infer_status();
+}
+
+extern "C" int ffno_infer_ff(const ffno_fused_branch* ba, const ffno_fused_branch* bb, const void* pk1, const float* b1,
+                             const void* pk2, const float* b2, const float* resid, float* out, int C, int H, uint32_t* out_amax,
+                             void* stream) {
+    return infer_launch(ba, bb, pk1, b1, pk2, b2, resid, out, C, H, out_amax, true, stream);
+}
+
+extern "C" int ffno_infer_sum(const ffno_fused_branch* ba, const ffno_fused_branch* bb, float* out, int C, uint32_t* out_amax,
+                              void* stream) {
+    return infer_launch(ba, bb, nullptr, nullptr, nullptr, nullptr, nullptr, out, C, 4 * C, out_amax, false, stream);
 }
 
 extern "C" int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream) {

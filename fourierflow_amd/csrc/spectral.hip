@@ -1521,7 +1521,7 @@ namespace {
 struct Sp2dLayout {
     size_t spec, planes, base;            // floats
     size_t pack_f, tab_n_f, tab_m_f;      // floats per packed set / per fragment table of the N- / M-axis
-    size_t off_pack, off_tab, off_desc, off_words, total;
+    size_t off_pack, off_tab, off_desc, off_words, off_mix, mix_y_f, mix_x_f, total;
 };
 static Sp2dLayout sp2d_layout(int B, int M, int N, int C, int K) {
     Sp2dLayout l;
@@ -1536,7 +1536,11 @@ static Sp2dLayout sp2d_layout(int B, int M, int N, int C, int K) {
     l.off_tab = l.off_pack + 4 * l.pack_f;
     l.off_desc = l.off_tab + 2 * (l.tab_n_f + l.tab_m_f);
     l.off_words = l.off_desc + 4 * sizeof(ffno_x3pack_desc) / sizeof(float);
-    l.total = l.off_words + 4;
+    // the mixed spectra between the two launches of the forward operator where the inference kernels take the shape (infer.hip)
+    l.mix_y_f = (ffno_infer_mix_bytes(C, K, B * M) + 15) / 16 * 4;
+    l.mix_x_f = (ffno_infer_mix_bytes(C, K, B * N) + 15) / 16 * 4;
+    l.off_mix = l.off_words + 4;
+    l.total = l.off_mix + l.mix_y_f + l.mix_x_f;
     return l;
 }
 static bool sp2d_x3_ok(int B, int M, int N, int C, int K) {
@@ -1661,6 +1665,22 @@ extern "C" int ffno_spectral2d_fwd(const float* x, const float* w_y, const float
         if (mode == FFNO_MODE_FULL) {
             if (hipMemsetAsync(word, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
             if ((rc = ffno_amax(x, (size_t)B * M * N * C, word, stream))) return rc;
+        }
+        if (mode == FFNO_MODE_FULL && l.mix_y_f && l.mix_x_f && ffno_layer_infer_supported(B, M, N, C, 4 * C, K, K)) {
+            // two launches, no branch image: both forward DFTs + mixes -> the mixed spectra (operand fragments in ws) -> both inverse
+            // DFTs summed in registers (infer.hip: ffno_spectral_x3_mix_pair + ffno_infer_sum)
+            ffno_fused_branch br[2] = {};
+            for (int axis = 0; axis < 2; ++axis) {
+                br[axis].in = x, br[axis].tw = axis == 0 ? tw_n : tw_m;
+                br[axis].out = ws + l.off_mix + (axis == 0 ? 0 : l.mix_y_f);
+                br[axis].B = B, br[axis].M = M, br[axis].N = N, br[axis].K = K, br[axis].axis = axis;
+                br[axis].planes = ws + l.off_pack + (2 * axis) * l.pack_f;
+                br[axis].planes_format = FFNO_PLANES_FP16X2;
+                br[axis].in_amax = word;
+                br[axis].dft_frags = ws + l.off_tab + (axis == 0 ? 0 : 2 * l.tab_n_f);
+            }
+            if ((rc = ffno_spectral_x3_mix_pair(&br[0], &br[1], C, 2, stream))) return rc;
+            return ffno_infer_sum(&br[0], &br[1], out, C, nullptr, stream);
         }
         if ((rc = sp2d_branch(x, out, nullptr, ws, l, tw_n, B, M, N, C, K, 0, mode, true, 0, word, stream))) return rc;
         return sp2d_branch(x, out, nullptr, ws, l, tw_m, B, M, N, C, K, 1, mode, true, 1, word, stream);

@@ -367,6 +367,10 @@ int ffno_layer_infer_supported(int B, int M, int N, int C, int H, int K_rows, in
 int ffno_spectral_x3_mix_pair(const ffno_fused_branch* a, const ffno_fused_branch* b, int C, int interleave, void* stream);
 int ffno_infer_ff(const ffno_fused_branch* a, const ffno_fused_branch* b, const void* pk1, const float* b1, const void* pk2,
                   const float* b2, const float* resid, float* out, int C, int H, uint32_t* out_amax, void* stream);
+/* the second launch WITHOUT the feed-forward: out = the sum of the two branches' zero-padded inverse DFTs = SpectralConv2d.
+ * forward_fourier (grid_2d.py:51-99) of the x that ffno_spectral_x3_mix_pair transformed (ffno_spectral2d_fwd runs this pair for
+ * the shapes ffno_layer_infer_supported takes) */
+int ffno_infer_sum(const ffno_fused_branch* a, const ffno_fused_branch* b, float* out, int C, uint32_t* out_amax, void* stream);
 int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
 
 /* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),

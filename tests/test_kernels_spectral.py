@@ -217,6 +217,42 @@ def test_spectral2d_pack_cache_follows_the_declared_weight_version(be):
     assert lib.ffno_spectral2d_weights_version(None, 1) == -1
 
 
+@pytest.mark.parametrize("B,M,N,K", [(1, 8, 32, 4), (2, 16, 64, 8)])
+def test_spectral2d_forward_through_the_two_launch_pair(be, B, M, N, K):
+    """Where the inference kernels take the shape (width 64, <= 16 modes, N a multiple of 32) the forward operator is two launches --
+    ffno_spectral_x3_mix_pair + ffno_infer_sum: the mixed spectra between them, no branch image, the branch sum in registers --
+    and the backward the fused single-axis launches; both against fp64 torch.fft + autograd."""
+    lib, p = be.lib, be.ptr
+    C = 64
+    assert lib.ffno_spectral2d_path(B, M, N, C, K) == 1 and lib.ffno_layer_infer_supported(B, M, N, C, 4 * C, K, K) == 1
+    rs = np.random.RandomState(B + M + N + K)
+    x = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    gy = rs.standard_normal((B, M, N, C)).astype(np.float32)
+    w0, w1 = (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32), (rs.standard_normal((C, C, K, 2)) / 8).astype(np.float32)
+    ws = be.zeros(lib.ffno_spectral2d_ws_floats(B, M, N, C, K))
+    twn, twm = be.twiddle(N), be.twiddle(M)
+    dx, dw0, dw1, y = be.put(x), be.put(w0), be.put(w1), be.empty(x.shape)
+    assert lib.ffno_spectral2d_fwd(p(dx), p(dw0), p(dw1), p(y), p(ws), p(twn), p(twm), B, M, N, C, K, 0, None) == 0
+    assert rel_l2(be.get(y), _fp64_forward_fourier(x, w0, w1, K)) < TOL
+    # backward on the same workspace (its packs are shared with the forward's)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    t0, t1 = torch.tensor(w0, dtype=torch.float64, requires_grad=True), torch.tensor(w1, dtype=torch.float64, requires_grad=True)
+    xp = xt.permute(0, 3, 1, 2)
+    fy = torch.fft.rfft(xp, dim=-1, norm="ortho")
+    oy = torch.zeros(B, C, M, N // 2 + 1, dtype=torch.complex128)
+    oy[..., :K] = torch.einsum("bixy,ioy->boxy", fy[..., :K], torch.view_as_complex(t0))
+    fx = torch.fft.rfft(xp, dim=-2, norm="ortho")
+    ox = torch.zeros(B, C, M // 2 + 1, N, dtype=torch.complex128)
+    ox[:, :, :K] = torch.einsum("bixy,iox->boxy", fx[:, :, :K], torch.view_as_complex(t1))
+    out = (torch.fft.irfft(oy, n=N, dim=-1, norm="ortho") + torch.fft.irfft(ox, n=M, dim=-2, norm="ortho")).permute(0, 2, 3, 1)
+    out.backward(torch.tensor(gy, dtype=torch.float64))
+    gx, gw0, gw1 = be.empty(x.shape), be.zeros(w0.shape), be.zeros(w1.shape)
+    assert lib.ffno_spectral2d_bwd(p(dx), p(dw0), p(dw1), p(be.put(gy)), p(gx), p(gw0), p(gw1), p(ws), p(twn), p(twm), B, M, N, C, K, 0, 0, 0,
+                                   None) == 0
+    assert rel_l2(be.get(gx), xt.grad.numpy()) < TOL
+    assert rel_l2(be.get(gw0), t0.grad.numpy()) < 2e-5 and rel_l2(be.get(gw1), t1.grad.numpy()) < 2e-5
+
+
 def test_spectral2d_stage_path_still_serves_what_the_fused_kernels_refuse(be):
     """Width 32 with more than 16 modes: outside ffno_spectral_x3_supported -> the stage sequence, same results."""
     lib, p = be.lib, be.ptr
