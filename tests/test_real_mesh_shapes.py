@@ -68,7 +68,5 @@ def test_airfoil_real_shape_forward_backward_vs_oracle():
     loss.backward()
     eng = blk.engine()
     assert [v.L for v in eng._ws.views] == [229, 59] and all(eng._saved_x3[0]), eng._saved_x3
-    # (observed on MI355X, round 6: worst 3.6e-4 at spectral_layers.20.backcast_ff.layers.0.0.weight_g -- the sketch is the oracle on
-    #  its OWN ReLU decisions, and the 57 of 8.3e8 hidden units on which the HIP path decides differently (counted by the round-5
-    #  form of this test, which injected the HIP path's active sets and saw 3.6e-5) sit in that layer's gradient)
-    _check("airfoil 229x59 24L", "airfoil", blk, out, loss, grad_tol=1e-3)
+    # (observed on MI355X, round 6: worst 2.2e-4 at a weight-norm gain whose own fp32-oracle noise is 2.3e-4)
+    _check("airfoil 229x59 24L", "airfoil", blk, out, loss)

@@ -58,6 +58,44 @@ PY
       timeout 600 python -m pytest tests/test_kernels_spectral.py tests/test_block.py -m gpu -q -x --tb=short -p no:cacheprovider -k "spectral2d or standalone" > gpurun_out/pytest_lvl1.log 2>&1
       echo "[r6] level-1 tests rc=$?"; tail -n 3 gpurun_out/pytest_lvl1.log
       timeout 300 python tools/time_spectral2d.py > gpurun_out/time_spectral2d.log 2>&1; echo "[r6] time_spectral2d rc=$?"; tail -n 5 gpurun_out/time_spectral2d.log ;;
+    profall)
+      # rocprofv3 kernel stats, one file per benchmarked configuration
+      prof() {  # tag, steps-in-run, command...
+        tag=$1; shift; n=$1; shift
+        rm -rf gpurun_out/prof_$tag
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof_$tag" -o p -- "$@" > "$OLDPWD/gpurun_out/prof_$tag.log" 2>&1)
+        echo "[r6] rocprof $tag rc=$?"
+        db=$(find gpurun_out/prof_$tag -name "*.db" | head -1); python tools/rocpd_stats.py "$db" $n > gpurun_out/r06_${tag}_kernel_stats.md 2>&1
+        head -n 14 gpurun_out/r06_${tag}_kernel_stats.md | cut -c1-150
+        [ "$tag" = markov24 ] && python tools/rocpd_idle.py "$db" > gpurun_out/r06_markov24_step_idle.md 2>&1
+        find gpurun_out/prof_$tag -type f -size +1M -delete
+      }
+      R=$PWD
+      prof markov24 7 python $R/bench.py --steps 5 --warmup 2 --cpu-steps 0 --no-secondary
+      if [ -z "$PROF_ONLY_HEADLINE" ]; then
+        prof kochkov256_k32 7 python $R/bench.py --steps 5 --warmup 2 --cpu-steps 0 --no-secondary --grid 256 --layers 12 --modes 32 --batch 2
+        prof kochkov256_k64 7 python $R/bench.py --steps 5 --warmup 2 --cpu-steps 0 --no-secondary --grid 256 --layers 24 --modes 64 --batch 2
+        prof cube64 7 python $R/tools/bench_mesh.py --preset cube64 --steps 5 --warmup 2
+      fi ;;
+    pmctraffic)
+      # HBM traffic counters of the headline configuration (training step + forward-only pass), one PMC pass each
+      R=$PWD
+      for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf gpurun_out/pmc_markov24_$c
+        (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d "$R/gpurun_out/pmc_markov24_$c" -o p -- python $R/bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-secondary > "$R/gpurun_out/pmc_markov24_$c.log" 2>&1)
+        echo "[r6] pmc markov24 $c rc=$?"
+      done
+      f=$(find gpurun_out/pmc_markov24_FETCH_SIZE -name "*.db" | head -1); w=$(find gpurun_out/pmc_markov24_WRITE_SIZE -name "*.db" | head -1)
+      (cd tools && python make_pmc_traffic.py "../$f" "../$w" "$(cat ../fourierflow_amd/lib/git_head.stamp 2>/dev/null || echo unknown)" "markov/24 B=32 64x64 fp32 (bench.py defaults: training step + forward-only pass)") > gpurun_out/pmc_traffic_markov24.json
+      head -c 1500 gpurun_out/pmc_traffic_markov24.json; echo
+      find gpurun_out/pmc_markov24_FETCH_SIZE gpurun_out/pmc_markov24_WRITE_SIZE -type f -size +1M -delete ;;
+    final)
+      timeout 600 python __graft_entry__.py --smoke > gpurun_out/smoke.log 2>&1
+      echo "[r6] smoke rc=$?"; tail -n 2 gpurun_out/smoke.log
+      timeout 1200 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err
+      echo "[r6] bench rc=$?"; tail -n 4 gpurun_out/bench.err
+      timeout 1700 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider -s --durations=25 > gpurun_out/pytest_gpu.log 2>&1
+      echo "[r6] pytest -m gpu rc=$?"; tail -n 32 gpurun_out/pytest_gpu.log | cut -c1-200 ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
