@@ -22,7 +22,7 @@
 //     into the feed-forward.
 //   * the COLUMN branch (lines along m) produces s^T[c][m] at fixed n -- pixels of one column, not of one tile.  A workgroup owns
 //     R whole rows of an image (R N = 512 pixels = 16 tiles, two per wave), computes the column branch of those rows for all n
-//     as  Y_n^T[c][kk] G^T[kk][m0 .. m0 + R)  (the image's column spectra come from L2: the R-row workgroups of an image share an
+//     as  Y_n^T[c][kk] G^T[kk][m0 .. m0 + R)  on 16-column products (v_mfma_f32_16x16x32_f16)  (the image's column spectra come from L2: the R-row workgroups of an image share an
 //     XCD) and passes it through LDS (128 KiB fp32, 16-byte chunks swizzled by pixel so that both the column-order writes and the
 //     row-order reads spread over the banks).  Each wave then adds its tiles' row branch in registers.
 //   * the 128 KiB of feed-forward weight fragments take the place of the column-branch image in LDS once every wave holds its
@@ -121,39 +121,53 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_ff_kernel(co
     const int ntiles = (R * N) >> 5;                         // <= 16: tiles 2 wave, 2 wave + 1 belong to this wave
 
     // ---------------- phase A: column branch of the workgroup's R rows, every n, into LDS ----------------
+    // v_mfma_f32_16x16x32_f16: A = Y_n^T tile [16 channels x 32 (mode, part)], B = G^T [32 x 16 rows m] (R <= 16 of the 16 columns live: half the matrix work of a
+    // 32-column product for the same R), D[16 channels x 16 m]: lane (m, g) holds channels 16 t + 4 g + (0..3) -- one 16-byte chunk
     {
-        const int jc0 = m0 & 31, tcol = m0 >> 5;
-        Hf3 G[2];
-        FFNO_UNROLL
-        for (int st = 0; st < 2; ++st) G[st] = x3k_load_dft(A.dft_col, tcol * 2 + st, lane);
-        const bool live = j >= jc0 && j < jc0 + R;
-        const int mrel = j - jc0;
+        const int n0c = m0 & ~15, jc0 = m0 & 15;                  // 16-row tile of the inverse DFT that holds m0 .. m0 + R - 1
+        const int j16 = lane & 15, g16 = lane >> 4;
+        // fragment of the 32x32x16 table (32-sample tile, k-step st): lane (j32, half) <-> G[n = 32 tile + j32][kk = 16 st + 8 half + e];
+        // the 16x16x32 operand wants lane (j16, g) <-> G[n = n0c + j16][kk = 8 g + e]: st = g >> 1, half = g & 1
+        Hf3 G;
+        {
+            const int frag = (n0c >> 5) * 2 + (g16 >> 1), src = ((n0c & 31) + j16) + 32 * (g16 & 1);
+            G.hi = A.dft_col[(frag * 2 + 0) * 64 + src];
+            G.lo = A.dft_col[(frag * 2 + 1) * 64 + src];
+            FFNO_UNROLL
+            for (int w = 0; w < 4; ++w) G.hs[w] = plat::pk_mul_f16(G.hi[w], kHf2Scale);
+        }
+        const bool live = j16 >= jc0 && j16 < jc0 + R;
+        const int mrel = j16 - jc0;
         const long l0 = (long)image * N;
-        LineFrags cur = load_line(A.mix_col, l0 + min(wave, N - 1), lane);
+        // the line's fragments as the first launch wrote them -- (st, ct), lane (j, half): Y[kk = 16 st + 8 half + e][c = 2 j + ct] --
+        // read in the lane order of the 16-column product: lane (i, g) of tile t wants Y[kk = 8 g + e][c = 16 t + i], i.e. the whole
+        // 16-byte slot vector of fragment (st = g >> 1, ct = i & 1), lane (j = 8 t + (i >> 1), half = g & 1)
+        const int src16 = ((((g16 >> 1) * 2 + (j16 & 1)) * 2) * 64) + (j16 >> 1) + 32 * (g16 & 1);
+        auto load16 = [&](long line, Hf2* y) {
+            const u32x4* pp = A.mix_col + line * (8 * 64) + src16;
+            FFNO_UNROLL
+            for (int t4 = 0; t4 < 4; ++t4) y[t4].hi = pp[8 * t4], y[t4].lo = pp[8 * t4 + 64];
+        };
+        Hf2 cur[4];
+        load16(l0 + min(wave, N - 1), cur);
         FFNO_NOUNROLL
         for (int n = wave; n < N; n += NWV) {
             const float osc = A.sc_col[l0 + n];
-            const LineFrags y = cur;
-            if (n + NWV < N) cur = load_line(A.mix_col, l0 + n + NWV, lane);      // the next line travels under this one's products
-            f32x16 a0 = zero16(), a1 = zero16();
+            Hf2 y[4];
             FFNO_UNROLL
-            for (int st = 0; st < 2; ++st) {
-                a0 = mfma_h2s_b(y.y[st][0], G[st], a0);
-                a1 = mfma_h2s_b(y.y[st][1], G[st], a1);
-            }
-            if (live) {
-                char* base = scol + (long)(mrel * N + n) * 256;
-                const int key = swz_key(mrel, n);
-                FFNO_UNROLL
-                for (int g = 0; g < 4; ++g) {
-                    FFNO_UNROLL
-                    for (int i2 = 0; i2 < 2; ++i2) {
-                        // channels 16 g + 8 half + 4 i2 + (0..3): registers 4 g + 2 i2, + 1 of the even / odd column tile
-                        const int r = 4 * g + 2 * i2, chunk = 4 * g + 2 * half + i2;
-                        *reinterpret_cast<float4*>(base + ((chunk ^ key) << 4)) =
-                            make_float4(a0[r] * osc, a1[r] * osc, a0[r + 1] * osc, a1[r + 1] * osc);
-                    }
-                }
+            for (int t4 = 0; t4 < 4; ++t4) y[t4] = cur[t4];
+            if (n + NWV < N) load16(l0 + n + NWV, cur);      // the next line travels under this one's products
+            char* base = scol + (long)(mrel * N + n) * 256;
+            const int key = swz_key(mrel, n);
+            FFNO_UNROLL
+            for (int t4 = 0; t4 < 4; ++t4) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc = plat::mfma_f16_16x16x32(y[t4].hi, G.lo, acc);
+                acc = plat::mfma_f16_16x16x32(y[t4].lo, G.hi, acc);
+                acc = plat::mfma_f16_16x16x32(y[t4].hi, G.hs, acc);
+                if (live)
+                    *reinterpret_cast<float4*>(base + (((4 * t4 + g16) ^ key) << 4)) =
+                        make_float4(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc);
             }
         }
     }
@@ -252,6 +266,16 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_ff_kernel(co
         for (int sh = 32; sh >= 1; sh >>= 1) mx = fmaxf(mx, __shfl_xor(mx, sh));
         if (lane == 0) bfold[wave] = mx;
     }
+    // both weight packs are requested on this side of the barrier (16 x 16 B per thread: the registers the row-branch operands just
+    // left): the copy's round trip runs under the reduction and the wait for the slowest wave's tile reads
+    constexpr int WPT = (NF1 + NF2) * 2 * 64 / (NWV * 64);
+    static_assert(WPT * NWV * 64 == (NF1 + NF2) * 2 * 64 && NF1 == NF2, "weight copy map");
+    u32x4 wreg[WPT];
+    FFNO_UNROLL
+    for (int q = 0; q < WPT; ++q) {
+        const int idx = tid + q * (NWV * 64);
+        wreg[q] = idx < NF1 * 2 * 64 ? A.pk1[idx] : A.pk2[idx - NF1 * 2 * 64];
+    }
     __syncthreads();
     float gmax = bfold[0];
     FFNO_UNROLL
@@ -259,8 +283,8 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_ff_kernel(co
     const float gscale = range_scale(f2u(gmax), 0, kInferRangeTarget), rgscale = 1.f / gscale;
 
     // ---------------- the feed-forward weights take the column branch's place ----------------
-    for (int i = tid; i < NF1 * 2 * 64; i += NWV * 64) w1[i] = A.pk1[i];
-    for (int i = tid; i < NF2 * 2 * 64; i += NWV * 64) w2[i] = A.pk2[i];
+    FFNO_UNROLL
+    for (int q = 0; q < WPT; ++q) w1[tid + q * (NWV * 64)] = wreg[q];      // (w2 follows w1 in LDS)
     for (int e = tid; e < H; e += NWV * 64) b1s[e] = A.bias1[e] * (gscale * kHf2Unscale);      // (as the epilogue adds it: b1 g / 2^11)
     for (int e = tid; e < C; e += NWV * 64) b2s[e] = A.bias2[e];
     __syncthreads();
@@ -404,11 +428,11 @@ static inline int infer_status() {
     return e == hipSuccess ? FFNO_OK : (int)e;
 }
 
-// rows per workgroup: R N <= 512 pixels (the LDS image of the column branch), R a power of two that divides M (and 32: the live
-// columns of a workgroup's column-branch product sit in one 32-column tile); fewer rows while the launch would leave CUs idle
+// rows per workgroup: R N <= 512 pixels (the LDS image of the column branch), R a power of two that divides M (and 16: the live
+// columns of a workgroup's column-branch product sit in one 16-column tile); fewer rows while the launch would leave CUs idle
 static inline int infer_rows(int B, int M, int N) {
     int R = 1;
-    while (2 * R * N <= 512 && 2 * R <= 32 && M % (2 * R) == 0) R *= 2;
+    while (2 * R * N <= 512 && 2 * R <= 16 && M % (2 * R) == 0) R *= 2;
     const int cus = device_cu_count();
     while (R > 1 && (long)B * (M / R) < cus) R >>= 1;
     return R;
