@@ -186,6 +186,7 @@ SIGNATURES = {
     "ffno_transpose_batched": (I, [P, I, I, I, P]),
     "ffno_lift_fwd": (I, [P, P, P, P, I, I, I, P, P, P]),
     "ffno_lift_bwd": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),
+    "ffno_lift_bwd2": (I, [P, P, P, P, P, P, I, I, I, I, I, P, P]),
     "ffno_lift_bwd_data": (I, [P, P, P, I, I, I, P, P]),
     "ffno_lift_fwd_bf16": (I, [P, P, P, P, I, I, I, P, P, P]),
     "ffno_lift_bwd_bf16": (I, [P, P, P, P, P, I, I, I, I, I, P, P]),

@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__
 template <int C, class ST = StF32>
 __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __restrict__ x,
                                                                const typename ST::T* __restrict__ gout,
+                                                               const typename ST::T* __restrict__ gout2,
                                                                float* __restrict__ partial, int P, int Cin,
                                                                int chunk, PadMapDev pm) {
     constexpr int TP = 32;                     // pixels staged per pass
@@ -149,7 +150,17 @@ __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __re
     for (long p0 = pbeg; p0 < pend; p0 += TP) {
         const int np = (int)min((long)TP, pend - p0);
         __syncthreads();
-        for (int e = threadIdx.x; e < TP * C; e += 256) gs[e] = (e / C) < np ? ST::ld1(gout + pm.map(p0 + e / C) * C + (e % C)) : 0.f;
+        // (gout2: the second gradient buffer of a paired adjoint launch, added while the rows are staged -- the sum the engine used to
+        //  form with an axpy pass over both images before this kernel)
+        for (int e = threadIdx.x; e < TP * C; e += 256) {
+            float gvv = 0.f;
+            if ((e / C) < np) {
+                const long off = pm.map(p0 + e / C) * C + (e % C);
+                gvv = ST::ld1(gout + off);
+                if (gout2) gvv = ST::rnd(gvv + ST::ld1(gout2 + off));
+            }
+            gs[e] = gvv;
+        }
         for (int e = threadIdx.x; e < TP * (Cin + 1); e += 256) {
             const int pp = e / (Cin + 1), i = e % (Cin + 1);
             xs[pp * 64 + i] = (pp < np) ? (i < Cin ? x[(p0 + pp) * Cin + i] : 1.f) : 0.f;
@@ -674,17 +685,17 @@ extern "C" int ffno_lift_fwd_bf16(const float* x, const float* W, const float* b
 }
 
 template <class ST>
-static int lift_bwd_impl(const float* x, const typename ST::T* gout, float* partial, float* dW, float* db, int P,
-                         int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
+static int lift_bwd_impl(const float* x, const typename ST::T* gout, const typename ST::T* gout2, float* partial, float* dW, float* db,
+                         int P, int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
     if (!x || !gout || !partial || !dW || !db || P <= 0 || Cin <= 0 || nsplit <= 0) return FFNO_EINVAL;
     if (Cin > 63) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
     const int chunk = (P + nsplit - 1) / nsplit;
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, gout2, partial, P, Cin, chunk, pm);
     else if (C == 32)
-        FFNO_LAUNCH((lift_bwd_partial_kernel<32, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, partial, P, Cin, chunk, pm);
+        FFNO_LAUNCH((lift_bwd_partial_kernel<32, ST>), dim3(nsplit), dim3(256), 0, s, x, gout, gout2, partial, P, Cin, chunk, pm);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();
@@ -696,11 +707,15 @@ static int lift_bwd_impl(const float* x, const typename ST::T* gout, float* part
 }
 extern "C" int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, float* db, int P,
                              int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
-    return lift_bwd_impl<StF32>(x, gout, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
+    return lift_bwd_impl<StF32>(x, gout, nullptr, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
+}
+extern "C" int ffno_lift_bwd2(const float* x, const float* gout, const float* gout2, float* partial, float* dW, float* db, int P,
+                              int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
+    return lift_bwd_impl<StF32>(x, gout, gout2, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
 }
 extern "C" int ffno_lift_bwd_bf16(const float* x, const uint16_t* gout, float* partial, float* dW, float* db, int P,
                                   int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream) {
-    return lift_bwd_impl<StBf16>(x, gout, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
+    return lift_bwd_impl<StBf16>(x, gout, nullptr, partial, dW, db, P, Cin, C, nsplit, accumulate, pad, stream);
 }
 
 extern "C" int ffno_lift_bwd_data(const float* gout, const float* W, float* dx, int P, int Cin, int C,

@@ -1435,12 +1435,15 @@ class FFNOEngine:
                            resid1=None)
             have_g1 = conc
             cur = (cur + 1) % nG
-        if conc and have_g1:      # lift_bwd takes one input
+        g_second = None           # second addend of the gradient that enters the lift (fp32 storage, no input gradient wanted:
+        if conc and have_g1:      # ffno_lift_bwd2 adds it while it stages its rows; else the sum is formed first)
             g1_fin = ws.G1
             if self._bf16():
                 ws.G[cur].add_(g1_fin)      # (a torch kernel on the same stream; rounds the sum to bf16 like every stored tensor)
-            else:
+            elif need_dx or (self._training and self.in_dropout > 0.0):
                 self._k("axpy", lib.ffno_axpy, _p(ws.G[cur]), _p(g1_fin), 1.0, P * C, st)
+            else:
+                g_second = g1_fin
         nsl = ws.nsplit_ff
         if ws.wg_jobs:
             nsl = ws.nsplit_ffm
@@ -1462,8 +1465,12 @@ class FFNOEngine:
         lin_in = self.linears["in_proj."]
         if self._training and self.in_dropout > 0.0:      # backward of x = self.drop(in_proj(x)): the same mask, regenerated
             self._k("in_dropout", lib.ffno_dropout, _p(g_fin), g_fin.numel(), self.in_dropout, self._in_drop_seed, st)
-        self._k("lift_bwd", lib.ffno_lift_bwd_bf16 if self._bf16() else lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart),
-                _p(lin_in.gweff), _p(gv("in_proj.bias")), ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
+        if g_second is not None:
+            self._k("lift_bwd", lib.ffno_lift_bwd2, _p(x), _p(g_fin), _p(g_second), _p(ws.liftpart), _p(lin_in.gweff),
+                    _p(gv("in_proj.bias")), ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
+        else:
+            self._k("lift_bwd", lib.ffno_lift_bwd_bf16 if self._bf16() else lib.ffno_lift_bwd, _p(x), _p(g_fin), _p(ws.liftpart),
+                    _p(lin_in.gweff), _p(gv("in_proj.bias")), ws.P_in, self.Cin, C, ws.nsplit_lift, 0, pm, st)
         self.dx = None
         if need_dx:
             self.dx = torch.empty(B, *S, self.Cin, dtype=torch.float32, device=self.device)

@@ -641,6 +641,10 @@ int ffno_lift_bwd(const float* x, const float* gout, float* partial, float* dW, 
 /* bf16 storage twins ("Storage formats" at the top; C = 64): the lifted features `out` / their gradient `gout` are bf16 */
 int ffno_lift_fwd_bf16(const float* x, const float* W, const float* b, uint16_t* out, int P, int Cin, int C,
                        const ffno_padmap* pad, uint32_t* out_amax, void* stream);
+/* the same with the gradient given as the SUM of two buffers (gout + gout2: the two gradient images a paired adjoint launch
+ * leaves; gout2 may be NULL) -- added while the rows are staged, no separate pass over the images */
+int ffno_lift_bwd2(const float* x, const float* gout, const float* gout2, float* partial, float* dW, float* db, int P,
+                   int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
 int ffno_lift_bwd_bf16(const float* x, const uint16_t* gout, float* partial, float* dW, float* db, int P,
                        int Cin, int C, int nsplit, int accumulate, const ffno_padmap* pad, void* stream);
 /* dx[p][Cin] = gout[q(p)][C] W: the gradient with respect to the block's INPUT (the reference modules are ordinary autograd
