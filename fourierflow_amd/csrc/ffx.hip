@@ -1597,47 +1597,39 @@ struct FxRedDesc {
     float *dW1, *dW2, *db1, *db2;
 };
 
-// (round 6: 16-byte loads -- a lane sums four consecutive elements of every slice; the scalar form read the 101 MB of slices of a
-//  markov/24 step at 1.8 TB/s: 56 us per step.  Same summation order per element: bit-identical results.)
+// (round 6: a 16-byte-load form of this kernel -- a lane summing four consecutive elements of every slice, a quarter of the
+//  workgroups -- was measured and not kept: 20.3 us per launch against 17.3 for this one at the headline shape; 101 MB in 17 us is
+//  5.8 TB/s already)
 __global__ __launch_bounds__(256) void ffx_wgrad_reduce_batched_kernel(const FxRedDesc* __restrict__ descs, int C, int H,
                                                                        int nsplit) {
-    __shared__ float4 red[4][64];
+    __shared__ float red[4][64];
     const FxRedDesc d = descs[blockIdx.y];
-    const int part = 2 * H * C + H + C;      // (a multiple of 4 for every supported (C, H): the regions never split a quad)
-    const int e = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, sg = threadIdx.x >> 6;
-    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int part = 2 * H * C + H + C;
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+    float sum = 0.f;
     if (e < part) {
-        float4 t[8];
+        float t[8];
         int sp = sg;
         for (; sp + 28 < nsplit; sp += 32) {
             FFNO_UNROLL
-            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(d.partial + (long)(sp + 4 * u) * part + e);
+            for (int u = 0; u < 8; ++u) t[u] = d.partial[(long)(sp + 4 * u) * part + e];
             FFNO_UNROLL
-            for (int u = 0; u < 8; ++u) sum.x += t[u].x, sum.y += t[u].y, sum.z += t[u].z, sum.w += t[u].w;
+            for (int u = 0; u < 8; ++u) sum += t[u];
         }
-        for (; sp < nsplit; sp += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(d.partial + (long)sp * part + e);
-            sum.x += v.x, sum.y += v.y, sum.z += v.z, sum.w += v.w;
-        }
+        for (; sp < nsplit; sp += 4) sum += d.partial[(long)sp * part + e];
     }
     red[sg][threadIdx.x & 63] = sum;
     __syncthreads();
     if (sg == 0 && e < part) {
-        const float4 r0 = red[0][threadIdx.x], r1 = red[1][threadIdx.x], r2 = red[2][threadIdx.x], r3 = red[3][threadIdx.x];
-        const float out[4] = {(r0.x + r1.x) + (r2.x + r3.x), (r0.y + r1.y) + (r2.y + r3.y), (r0.z + r1.z) + (r2.z + r3.z),
-                              (r0.w + r1.w) + (r2.w + r3.w)};
-        FFNO_UNROLL
-        for (int q = 0; q < 4; ++q) {
-            const int eq = e + q;
-            if (eq < H * C)
-                d.dW1[(eq % H) * C + eq / H] = out[q];
-            else if (eq < 2 * H * C)
-                d.dW2[eq - H * C] = out[q];
-            else if (eq < 2 * H * C + H)
-                d.db1[eq - 2 * H * C] = out[q];
-            else
-                d.db2[eq - 2 * H * C - H] = out[q];
-        }
+        sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (e < H * C)
+            d.dW1[(e % H) * C + e / H] = sum;
+        else if (e < 2 * H * C)
+            d.dW2[e - H * C] = sum;
+        else if (e < 2 * H * C + H)
+            d.db1[e - 2 * H * C] = sum;
+        else
+            d.db2[e - 2 * H * C - H] = sum;
     }
 }
 
@@ -1989,8 +1981,7 @@ extern "C" int ffno_ffx_bwd_weights_reduce_batched(const ffno_fxred_desc* descs_
     if (!descs_dev || n <= 0 || nsplit <= 0) return FFNO_EINVAL;
     static_assert(sizeof(ffno_fxred_desc) == sizeof(FxRedDesc), "descriptor layout");
     const int part = 2 * H * C + H + C;
-    if (part % 4) return FFNO_EUNSUPPORTED;
-    FFNO_LAUNCH(ffx_wgrad_reduce_batched_kernel, dim3((part / 4 + 63) / 64, n), dim3(256), 0, (hipStream_t)stream,
+    FFNO_LAUNCH(ffx_wgrad_reduce_batched_kernel, dim3((part + 63) / 64, n), dim3(256), 0, (hipStream_t)stream,
                 reinterpret_cast<const FxRedDesc*>(descs_dev), C, H, nsplit);
     return ffx_launch_status();
 }

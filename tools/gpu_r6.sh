@@ -96,6 +96,9 @@ PY
       echo "[r6] bench rc=$?"; tail -n 4 gpurun_out/bench.err
       timeout 1700 python -m pytest tests -m gpu -q --maxfail=25 --tb=short -p no:cacheprovider -s --durations=25 > gpurun_out/pytest_gpu.log 2>&1
       echo "[r6] pytest -m gpu rc=$?"; tail -n 32 gpurun_out/pytest_gpu.log | cut -c1-200 ;;
+    steptests)
+      timeout 900 python -m pytest tests/test_trainer.py tests/test_kernels_ffh.py tests/test_kernels_ffx.py tests/test_block.py -m gpu -q -x --tb=short -p no:cacheprovider > gpurun_out/pytest_step.log 2>&1
+      echo "[r6] step tests rc=$?"; tail -n 3 gpurun_out/pytest_step.log ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
