@@ -128,6 +128,8 @@ SIGNATURES = {
     "ffno_fw_grad_partial": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P]),
     "ffno_fw_grad_partial_multi": (I, [P, P, P, I, I, I, I, I, SZ, SZ, SZ, P]),
     "ffno_fw_grad_reduce_multi": (I, [P, P, I, I, I, I, SZ, I, I, P]),
+    "ffno_fw_grad_partial_h2": (I, [P, P, P, I, I, I, I, I, I, SZ, SZ, P, P, I, P]),
+    "ffno_fw_grad_partial_multi_h2": (I, [P, P, P, I, I, I, I, I, SZ, SZ, SZ, P, P, I, P]),
     "ffno_fw_grad_reduce": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_fused_pair": (I, [P, P, I, I, I, I, P]),
     "ffno_spectral_x3_supported": (I, [I, I, I]),

@@ -743,12 +743,57 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(4) void spectral_fused_pai
 // carried from step to step and the eight rows of a lane are immediate offsets from them -- no per-row layer / bounds logic
 // (the general path spends more instructions on that than on the splits: a 64-bit division per straddling row, a predicate and
 // a select per element).
-template <int C, bool AL = false>
+// H2 (round 6): the same contraction on split-fp16 -- three v_mfma_f32_32x32x16_f16 per product instead of six bf16 ones, 6
+// instead of 11 vector instructions per split pair.  `profiles/r06_power.md`: this launch runs ON the 1400 W socket cap at 1.54 GHz
+// (zero operands: 2.38 GHz, 142 us instead of 178-187): half the matrix energy is what moves it.  Both operands are spectra of
+// tensors that carry range words (the layer inputs x_l and the feed-forward data gradients ds_l): |X| <= 2 sqrt(L) max |x| goes to 2^4
+// (the BOUNDED operand of single-accumulator products, ffno_device.h: Hf3), |dY| to 2^10; one power-of-two pair for the whole launch
+// -- the maximum over the `nwords` layers it contracts over, so that every layer's products land in the same accumulator on the same
+// scale (a layer far below the largest one loses relative accuracy in ITS terms, which the sum does not see) -- or per problem z.
+template <int C, bool AL = false, bool H2 = false>
 __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restrict__ xs, const float* __restrict__ dys,
                                                            float* __restrict__ partial, int R, int K, int chunk,
                                                            int beta, int nlayers, long stride_x, long stride_dy, long zstride_x,
-                                                           long zstride_dy, long zstride_p) {
+                                                           long zstride_dy, long zstride_p, const unsigned* __restrict__ xw = nullptr,
+                                                           const unsigned* __restrict__ dw = nullptr, int nwords = 0,
+                                                           int spec_log2 = 0) {
     constexpr int CT = C / 32;
+    // H2: per-layer operand scales.  Layer l's X goes to 2^4 by its own power of two sx_l (the bounded operand must stay below 32
+    // whatever the other layers do); all products must land in ONE accumulator on ONE scale S, so its dY is multiplied by
+    // t_l = S / sx_l with S = min_l sx_l sd_l (sd_l: what would bring dY_l to 2^10): t_l <= sd_l, no overflow, and the layer with
+    // the largest products keeps both operands at full accuracy -- a layer whose products are smaller loses as much relative
+    // accuracy in dY as its terms are smaller than the sum's (activations growing and gradients shrinking through the layers trade
+    // off inside sx_l sd_l: tests/test_range.py).  All-zero layers do not take part in the minimum.
+    constexpr int kMaxScaleLayers = 64;
+    __shared__ float lsx[kMaxScaleLayers], lst[kMaxScaleLayers];
+    __shared__ unsigned s_inv;      // 4096 - min_l (ex_l + ed_l), through atomicMax (0: no non-zero layer)
+    float unscale = 1.f, unscale2 = 1.f;
+    if constexpr (H2) {
+        const unsigned* xwz = xw + (long)blockIdx.z * nwords;
+        const unsigned* dwz = dw + (long)blockIdx.z * nwords;
+        if (threadIdx.x == 0) s_inv = 0u;
+        __syncthreads();
+        int ex = 0, ed = 0;
+        if ((int)threadIdx.x < nwords) {
+            const unsigned wx = xwz[threadIdx.x], wd = dwz[threadIdx.x];
+            ex = (int)((f2u(range_scale(wx, spec_log2, 4)) >> 23) & 0xffu) - 127;
+            ed = (int)((f2u(range_scale(wd, spec_log2, 10)) >> 23) & 0xffu) - 127;
+            if (wx != 0u && wd != 0u) atomicMax(&s_inv, (unsigned)(4096 - (ex + ed)));
+        }
+        __syncthreads();
+        const int S = s_inv ? 4096 - (int)s_inv : 0;               // (0: every layer is zero, nothing to scale)
+        if ((int)threadIdx.x < nwords) {
+            int et = S - ex;
+            et = et < -126 ? -126 : (et > 126 ? 126 : et);
+            lsx[threadIdx.x] = u2f((unsigned)(ex + 127) << 23);
+            lst[threadIdx.x] = u2f((unsigned)(et + 127) << 23);
+        }
+        __syncthreads();
+        // accumulator = 2^11 2^S (sum): undone in two exact steps (|S| may exceed the exponent range of one float)
+        const int h1 = (-S) / 2, h2 = (-S) - h1;
+        unscale = kHf2Unscale * u2f((unsigned)(max(-126, min(126, h1)) + 127) << 23);
+        unscale2 = u2f((unsigned)(max(-126, min(126, h2)) + 127) << 23);
+    }
     __shared__ float comb[CT * 64 * (2 * 16)];      // one column tile (both parts) of the second k-group at a time
     // blockIdx.z: independent problems (the per-layer weights of an unshared model: one launch for all layers)
     xs += (long)blockIdx.z * zstride_x;
@@ -770,6 +815,10 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
 
     // raw rows of one 16-row step: this lane's 8 rows v0 + e of  Xr/Xi[.][32a + j]  and  dYr/dYi[.][32b + j]
     float rxr[8], rxi[8], rdr[CT][8], rdi[CT][8];
+    // H2: the scale pair(s) of the rows just requested (one per step when a step never straddles a layer, else one per row)
+    float pqx[AL ? 1 : 8], pqd[AL ? 1 : 8];
+    FFNO_UNROLL
+    for (int e = 0; e < (AL ? 1 : 8); ++e) pqx[e] = 1.f, pqd[e] = 1.f;
     // AL: this lane's first row of the step to load next (layer lc, row rowc of it) -- every second step of the slice
     long lc = 0, rowc = 0;
     if constexpr (AL) {
@@ -781,6 +830,9 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
         if constexpr (AL) {
             const float* xrow = xk + lc * stride_x + rowc * 2 * C + 32 * a + j;
             const float* yrow = dk + lc * stride_dy + rowc * 2 * C + j;
+            // (H2: the step's rows belong to ONE layer; its scale pair is remembered and applied where the rows are CONSUMED -- a
+            //  multiplication next to the loads would make the wave wait for them here and undo the prefetch)
+            if constexpr (H2) pqx[0] = lsx[nwords > 1 ? (int)lc : 0], pqd[0] = lst[nwords > 1 ? (int)lc : 0];
             FFNO_UNROLL
             for (int e = 0; e < 8; ++e) {
                 rxr[e] = xrow[e * 2 * C];
@@ -808,6 +860,10 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
             const bool ok = v0 + e < vend;
             const float* xrow = xk + l * stride_x + row * 2 * C;
             const float* yrow = dk + l * stride_dy + row * 2 * C;
+            if constexpr (H2) {
+                const int li = (nwords > 1 && ok) ? (int)l : 0;
+                pqx[AL ? 0 : e] = lsx[li], pqd[AL ? 0 : e] = lst[li];
+            }
             rxr[e] = ok ? xrow[32 * a + j] : 0.f;
             rxi[e] = ok ? xrow[C + 32 * a + j] : 0.f;
             FFNO_UNROLL
@@ -820,6 +876,35 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
     const int nsteps = (int)((max(vend - vbeg, 0L) + 15) >> 4);
     if (grp < nsteps) load(grp);
     for (int t = grp; t < nsteps; t += 2) {
+        if constexpr (H2) {
+            // the scale pair(s) remembered when these rows were requested
+            float qx[8], qd[8];
+            FFNO_UNROLL
+            for (int e = 0; e < 8; ++e) qx[e] = pqx[AL ? 0 : e], qd[e] = pqd[AL ? 0 : e];
+            const Hf3 xr = split2s_8(rxr[0] * qx[0], rxr[1] * qx[1], rxr[2] * qx[2], rxr[3] * qx[3], rxr[4] * qx[4], rxr[5] * qx[5],
+                                     rxr[6] * qx[6], rxr[7] * qx[7]);
+            const Hf3 xi = split2s_8(rxi[0] * qx[0], rxi[1] * qx[1], rxi[2] * qx[2], rxi[3] * qx[3], rxi[4] * qx[4], rxi[5] * qx[5],
+                                     rxi[6] * qx[6], rxi[7] * qx[7]);
+            Hf3 nxi;   // -Xi: flip the sign bit of every half
+            nxi.hi = xi.hi ^ 0x80008000u, nxi.lo = xi.lo ^ 0x80008000u, nxi.hs = xi.hs ^ 0x80008000u;
+            Hf2 dr[CT], di[CT];
+            FFNO_UNROLL
+            for (int b = 0; b < CT; ++b) {
+                dr[b] = split2_8(rdr[b][0] * qd[0], rdr[b][1] * qd[1], rdr[b][2] * qd[2], rdr[b][3] * qd[3], rdr[b][4] * qd[4],
+                                 rdr[b][5] * qd[5], rdr[b][6] * qd[6], rdr[b][7] * qd[7]);
+                di[b] = split2_8(rdi[b][0] * qd[0], rdi[b][1] * qd[1], rdi[b][2] * qd[2], rdi[b][3] * qd[3], rdi[b][4] * qd[4],
+                                 rdi[b][5] * qd[5], rdi[b][6] * qd[6], rdi[b][7] * qd[7]);
+            }
+            if (t + 2 < nsteps) load(t + 2);   // the next step's rows arrive under this step's MFMAs
+            FFNO_UNROLL
+            for (int b = 0; b < CT; ++b) {
+                accr[b] = mfma_h2s(xr, dr[b], accr[b]);
+                acci[b] = mfma_h2s(xr, di[b], acci[b]);
+                accr[b] = mfma_h2s(xi, di[b], accr[b]);
+                acci[b] = mfma_h2s(nxi, dr[b], acci[b]);
+            }
+            continue;
+        }
         const Bf3 xr = split3_8(rxr[0], rxr[1], rxr[2], rxr[3], rxr[4], rxr[5], rxr[6], rxr[7]);
         const Bf3 xi = split3_8(rxi[0], rxi[1], rxi[2], rxi[3], rxi[4], rxi[5], rxi[6], rxi[7]);
         Bf3 nxi;   // -Xi: flip the sign bit of every bf16
@@ -857,8 +942,8 @@ __global__ __launch_bounds__(C * 4) void fw_grad_x3_kernel(const float* __restri
             FFNO_UNROLL
             for (int r = 0; r < 16; ++r) {
                 const int i = 32 * a + drow(r, half);
-                const float vr = accr[b][r] + comb[(0 * 16 + r) * (CT * 64) + slot];
-                const float vi = acci[b][r] + comb[(1 * 16 + r) * (CT * 64) + slot];
+                const float vr = (accr[b][r] + comb[(0 * 16 + r) * (CT * 64) + slot]) * unscale * unscale2;      // (1 on the bf16 split)
+                const float vi = (acci[b][r] + comb[(1 * 16 + r) * (CT * 64) + slot]) * unscale * unscale2;
                 float* pr = partial + (((long)split * K + k) * 2 + 0) * C * C + (long)i * C + 32 * b + j;
                 float* pi = pr + (long)C * C;
                 *pr = beta ? (*pr + vr) : vr;
@@ -1165,6 +1250,59 @@ extern "C" int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, f
     else
         FFNO_LAUNCH((fw_grad_x3_kernel<32>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta,
                     nlayers, (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L);
+    return launch_status();
+}
+
+// the same on split-fp16 operands scaled from range words (fw_grad_x3_kernel<.., H2>): x_words / d_words = the range words of the
+// tensors whose spectra spec_x / spec_dy are (layer inputs / feed-forward data gradients), one per layer of the contraction; L =
+// the axis length (|spectrum| <= 2 sqrt(L) max |tensor|)
+static inline int fw_spec_log2(int L) {      // (the bound the fused kernels use for their spectrum tile: 1 + ceil(log2 L) / 2, rounded up)
+    int l = 0;
+    while ((1 << l) < L) ++l;
+    return 1 + (l + 1) / 2;
+}
+extern "C" int ffno_fw_grad_partial_h2(const float* spec_x, const float* spec_dy, float* partial, int R, int C, int K, int nsplit,
+                                       int beta, int nlayers, size_t layer_stride_x, size_t layer_stride_dy,
+                                       const uint32_t* x_words, const uint32_t* d_words, int L, void* stream) {
+    if (!x_words || !d_words || nlayers > 64)      // (the kernel keeps one scale pair per layer in LDS: 64 of them)
+        return ffno_fw_grad_partial(spec_x, spec_dy, partial, R, C, K, nsplit, beta, nlayers, layer_stride_x, layer_stride_dy, stream);
+    if (!spec_x || !spec_dy || !partial || R <= 0 || K <= 0 || nsplit <= 0 || nlayers <= 0 || L <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    const long vtot = (long)nlayers * R;
+    long chunk = (vtot + nsplit - 1) / nsplit;
+    chunk += chunk & 1;
+    const bool al = R % 16 == 0;
+    if (al) chunk = (chunk + 15) & ~15L;
+    if (chunk > 0x7fffffffL) return FFNO_EINVAL;
+    const dim3 grid(nsplit, K), block(C * 4);
+    hipStream_t s = (hipStream_t)stream;
+    const int sl = fw_spec_log2(L);
+#define FWH2(CC, ALV)                                                                                                          \
+    FFNO_LAUNCH((fw_grad_x3_kernel<CC, ALV, true>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, beta, nlayers, \
+                (long)layer_stride_x, (long)layer_stride_dy, 0L, 0L, 0L, x_words, d_words, nlayers, sl)
+    if (C == 64 && al) FWH2(64, true); else if (C == 64) FWH2(64, false); else if (al) FWH2(32, true); else FWH2(32, false);
+#undef FWH2
+    return launch_status();
+}
+extern "C" int ffno_fw_grad_partial_multi_h2(const float* spec_x, const float* spec_dy, float* partial, int R, int C, int K,
+                                             int nsplit, int n, size_t stride_x, size_t stride_dy, size_t stride_p,
+                                             const uint32_t* x_words, const uint32_t* d_words, int L, void* stream) {
+    if (!x_words || !d_words)
+        return ffno_fw_grad_partial_multi(spec_x, spec_dy, partial, R, C, K, nsplit, n, stride_x, stride_dy, stride_p, stream);
+    if (!spec_x || !spec_dy || !partial || R <= 0 || K <= 0 || nsplit <= 0 || n <= 0 || n > 65535 || L <= 0) return FFNO_EINVAL;
+    if (C != 64 && C != 32) return FFNO_EUNSUPPORTED;
+    long chunk = ((long)R + nsplit - 1) / nsplit;
+    chunk += chunk & 1;
+    const bool al = R % 16 == 0;
+    if (al) chunk = (chunk + 15) & ~15L;
+    const dim3 grid(nsplit, K, n), block(C * 4);
+    hipStream_t s = (hipStream_t)stream;
+    const int sl = fw_spec_log2(L);
+#define FWH2(CC, ALV)                                                                                                        \
+    FFNO_LAUNCH((fw_grad_x3_kernel<CC, ALV, true>), grid, block, 0, s, spec_x, spec_dy, partial, R, K, (int)chunk, 0, 1, 0L, 0L, \
+                (long)stride_x, (long)stride_dy, (long)stride_p, x_words, d_words, 1, sl)
+    if (C == 64 && al) FWH2(64, true); else if (C == 64) FWH2(64, false); else if (al) FWH2(32, true); else FWH2(32, false);
+#undef FWH2
     return launch_status();
 }
 

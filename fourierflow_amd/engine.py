@@ -222,6 +222,9 @@ class FFNOEngine:
         # the size; gradient passes hold the spectrum tile range-scaled like the feed-forward) or "bf16x3"
         self.x3_mix_split = os.environ.get("FFNO_X3_MIX_SPLIT", "fp16x2")
         self._x3_fmt = None
+        # operand split of the Fourier-weight-gradient contraction: None = follow x3_mix_split (fp16x2: three fp16 MFMAs per product,
+        # operands scaled from the range words of the layer inputs / data gradients; the bf16x3 launch runs on the 1400 W power cap)
+        self.fw_grad_split = os.environ.get("FFNO_FW_GRAD_SPLIT") or None
         self._dft_tabs = {}
         # feed-forward weight gradients of ALL layers as one launch after the backward loop (ffno_ffh_bwd_weights_partial_multi):
         # every layer keeps its own gradient buffer instead of the ping-pong pair; FF_WGRAD_ROUNDS x resident workgroups / L
@@ -361,6 +364,20 @@ class FFNOEngine:
         if not self._ranged():
             return None
         return ctypes.c_void_p(ws.RW.data_ptr() + 4 * (ws.rw_kinds[kind] * (self.L + 1) + l))
+
+    def _fw_words(self, ws, l0: int):
+        """Range words of the tensors whose spectra the Fourier-weight-gradient launch contracts, from layer l0 on: the layer inputs
+        (kind x) and the feed-forward data gradients (kind d) -- (x words, d words) as device pointers, or (None, None): then the
+        launch keeps the bf16x3 arithmetic (any range).  fp16x2 (three MFMAs per product instead of six) when the spectral kernels
+        run on fp16x2 packs, i.e. when every producer on the path records its maximum (`fw_grad_split`)."""
+        split = self.fw_grad_split or self.x3_mix_split
+        if split not in ("fp16x2", "bf16x3"):
+            raise ValueError("fw_grad_split must be 'fp16x2', 'bf16x3' or None (follow x3_mix_split), got %r" % (split,))
+        if not (split == "fp16x2" and self._ranged() and self.spectral == "factorized" and self.use_x3 and self._x3_h2()):
+            return None, None
+        base = ws.RW.data_ptr()
+        return (ctypes.c_void_p(base + 4 * (ws.rw_kinds["x"] * (self.L + 1) + l0)),
+                ctypes.c_void_p(base + 4 * (ws.rw_kinds["d"] * (self.L + 1) + l0)))
 
     def _fold(self, t, word, st):
         """Producers that do not record their output maximum themselves: one more pass over the tensor."""
@@ -1495,8 +1512,9 @@ class FFNOEngine:
                 if ws.fwgrad_sig.get(w) != ptrs:
                     ws.fwgrad_tab[w] = torch.tensor(ptrs, dtype=torch.int64).to(self.device)
                     ws.fwgrad_sig[w] = ptrs
-                self._k("fw_grad_partial", lib.ffno_fw_grad_partial_multi, _p(ws.SXall[w]), _p(ws.SDall[w]),
-                        _p(ws.fwpart_multi[w]), v.R, C, v.K, nsf, L, v.spec, v.spec, pstride, st)
+                xw, dw = self._fw_words(ws, 0)
+                self._k("fw_grad_partial", lib.ffno_fw_grad_partial_multi_h2, _p(ws.SXall[w]), _p(ws.SDall[w]),
+                        _p(ws.fwpart_multi[w]), v.R, C, v.K, nsf, L, v.spec, v.spec, pstride, xw, dw, v.L, st)
                 self._k("fw_grad_reduce", lib.ffno_fw_grad_reduce_multi, _p(ws.fwpart_multi[w]), _p(ws.fwgrad_tab[w]), L, C, v.K,
                         nsf, pstride, 0, real, st)
         for si, names in enumerate(self._fw_sets if not multi else []):
@@ -1513,8 +1531,9 @@ class FFNOEngine:
             for w, n in enumerate(names):
                 v = ws.views[w]
                 # dW = sum over the lines of every layer that uses this weight: ONE launch per axis
-                self._k("fw_grad_partial", lib.ffno_fw_grad_partial, _p(ws.SXall[w][l0_]), _p(ws.SDall[w][l0_]),
-                        _p(ws.fwpart[si][w]), v.R, C, v.K, ws.nsplit_fw[w], 0, nl, v.spec, v.spec, st)
+                xw, dw = self._fw_words(ws, l0_) if self.spectral == "factorized" else (None, None)
+                self._k("fw_grad_partial", lib.ffno_fw_grad_partial_h2, _p(ws.SXall[w][l0_]), _p(ws.SDall[w][l0_]),
+                        _p(ws.fwpart[si][w]), v.R, C, v.K, ws.nsplit_fw[w], 0, nl, v.spec, v.spec, xw, dw, v.L, st)
                 reduce = lib.ffno_fw_grad_reduce_real if self.spectral == "dct" else lib.ffno_fw_grad_reduce
                 self._k("fw_grad_reduce", reduce, _p(ws.fwpart[si][w]), _p(gv(n)), C, v.K, ws.nsplit_fw[w], 0, st)
         if self._desc_dev is not None:

@@ -152,6 +152,17 @@ int ffno_fw_grad_partial(const float* spec_x, const float* spec_dy, float* parti
                          size_t layer_stride_dy, void* stream);
 int ffno_fw_grad_reduce(const float* partial, float* gw, int C, int K, int nsplit, int accumulate,
                         void* stream);
+/* The partial step on split-fp16 operands (round 6; three fp16 MFMAs per product instead of six bf16 ones -- the bf16 launch runs on
+ * the 1400 W power cap: profiles/r06_power.md).  x_words / d_words: DEVICE arrays with the range words of the tensors whose spectra
+ * spec_x / spec_dy are -- the layer inputs and the feed-forward data gradients -- one per layer of the contraction (`nlayers` for the
+ * shared launch: ONE power-of-two pair from their maxima scales the whole launch; `n` for the multi launch: one pair per problem);
+ * L = the transform length (|spectrum| <= 2 sqrt(L) max |tensor|).  NULL words: the bf16x3 kernels (any range). */
+int ffno_fw_grad_partial_h2(const float* spec_x, const float* spec_dy, float* partial, int R, int C, int K, int nsplit, int beta,
+                            int nlayers, size_t layer_stride_x, size_t layer_stride_dy, const uint32_t* x_words,
+                            const uint32_t* d_words, int L, void* stream);
+int ffno_fw_grad_partial_multi_h2(const float* spec_x, const float* spec_dy, float* partial, int R, int C, int K, int nsplit, int n,
+                                  size_t stride_x, size_t stride_dy, size_t stride_p, const uint32_t* x_words,
+                                  const uint32_t* d_words, int L, void* stream);
 /* the two steps for n independent weight tensors in one launch each (per-layer Fourier weights of an unshared model):
  * problem z reads spec_x + z*stride_x / spec_dy + z*stride_dy, its slices live at partial + z*stride_p and are reduced into
  * gws[z] (DEVICE array of n pointers); real = 1: real [I][O][K] outputs (DCT operators). */

@@ -136,6 +136,71 @@ def test_fw_grad_over_layers(be, R, C, K, nl, nsplit):
     assert rel_l2(be.get(gw), np.stack([ref.real, ref.imag], axis=-1)) < TOL
 
 
+def _amax_word(a):
+    return np.array([np.abs(a).max()], np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("R,C,K,nl,nsplit,mags", [(37, 64, 2, 1, 3, (1.0,)), (48, 64, 2, 3, 4, (1.0, 1e-3, 30.0)), (64, 32, 3, 2, 4, (1e5, 1e4)),
+                                                 (16, 64, 1, 8, 1, (1e-6,) * 8), (96, 64, 2, 4, 5, (1.0, 1e-9, 1.0, 1e3)),
+                                                 (32, 64, 2, 4, 3, ((1e-6, 1e-3, 1.0, 1e3), (1e4, 10.0, 1e-2, 1e-5)))])
+def test_fw_grad_on_split_fp16_operands(be, R, C, K, nl, nsplit, mags):
+    """ffno_fw_grad_partial_h2 (round 6: three fp16 MFMAs per product, operands scaled from the range words of the tensors the spectra
+    come from) against the fp64 contraction: layers of very different magnitude in one launch (one scale pair for the launch: the
+    SUM is what must be right), any overall magnitude, ragged line counts; and NULL words = the bf16x3 kernel."""
+    L = 64
+    rs = np.random.RandomState(R + C + K + nl)
+    stride = K * R * 2 * C
+    # spectra of tensors with max |.| = mag: |spectrum| <= 2 sqrt(L) mag; here up to ~4 mag
+    # (the last case: activations GROW and gradients SHRINK through the layers, every layer's products equally large -- one scale
+    #  per operand for the whole launch would leave the small end of each operand with a dozen bits: the scales are per layer)
+    xm, dm = mags if isinstance(mags[0], tuple) else (mags, mags)
+    xs = np.stack([rs.standard_normal(stride).astype(np.float32) * m for m in xm])
+    dys = np.stack([rs.standard_normal(stride).astype(np.float32) * m for m in dm])
+    xw = np.concatenate([_amax_word(xs[l]) for l in range(nl)])       # (a valid word: max |tensor| >= max |spectrum| / (2 sqrt(L)))
+    dw = np.concatenate([_amax_word(dys[l]) for l in range(nl)])
+    dxs, ddys = be.put(xs), be.put(dys)
+    partial, gw = be.zeros((nsplit, K, 2, C, C)), be.zeros((C, C, K, 2))
+    p = be.ptr
+    assert be.lib.ffno_fw_grad_partial_h2(p(dxs), p(ddys), p(partial), R, C, K, nsplit, 0, nl, stride, stride, p(be.put(xw)), p(be.put(dw)),
+                                          L, None) == 0
+    assert be.lib.ffno_fw_grad_reduce(p(partial), p(gw), C, K, nsplit, 0, None) == 0
+    x4 = xs.reshape(nl, K, R, 2, C).astype(np.float64)
+    d4 = dys.reshape(nl, K, R, 2, C).astype(np.float64)
+    xc, dc = x4[:, :, :, 0] + 1j * x4[:, :, :, 1], d4[:, :, :, 0] + 1j * d4[:, :, :, 1]
+    ref = np.einsum("lkri,lkro->iok", np.conj(xc), dc)
+    ref = np.stack([ref.real, ref.imag], axis=-1)
+    got = np.array(be.get(gw)).copy()
+    assert rel_l2(got, ref) < TOL
+    # NULL words: the any-range bf16x3 kernel through the same entry point
+    assert be.lib.ffno_fw_grad_partial_h2(p(dxs), p(ddys), p(partial), R, C, K, nsplit, 0, nl, stride, stride, None, None, L, None) == 0
+    assert be.lib.ffno_fw_grad_reduce(p(partial), p(gw), C, K, nsplit, 0, None) == 0
+    assert rel_l2(be.get(gw), ref) < TOL and rel_l2(be.get(gw), got) < 1e-6
+
+
+def test_fw_grad_multi_on_split_fp16_operands(be):
+    """The per-layer launch (unshared Fourier weights): one scale pair per problem -- a layer 1e8 times smaller than its neighbour
+    keeps its own relative accuracy."""
+    R, C, K, n, nsplit, L = 32, 64, 2, 3, 2, 40
+    rs = np.random.RandomState(5)
+    stride = K * R * 2 * C
+    mags = (1.0, 1e-8, 1e4)
+    xs = np.stack([rs.standard_normal(stride).astype(np.float32) * m for m in mags])
+    dys = np.stack([rs.standard_normal(stride).astype(np.float32) * m for m in mags])
+    xw = np.concatenate([_amax_word(xs[l]) for l in range(n)])
+    dw = np.concatenate([_amax_word(dys[l]) for l in range(n)])
+    pstride = nsplit * 2 * K * C * C
+    partial = be.zeros((n, pstride))
+    p = be.ptr
+    assert be.lib.ffno_fw_grad_partial_multi_h2(p(be.put(xs)), p(be.put(dys)), p(partial), R, C, K, nsplit, n, stride, stride, pstride,
+                                                p(be.put(xw)), p(be.put(dw)), L, None) == 0
+    part = np.array(be.get(partial)).reshape(n, nsplit, K, 2, C, C).sum(axis=1)       # [n][k][ri][i][o]
+    for z in range(n):
+        x4 = xs[z].reshape(K, R, 2, C).astype(np.float64)
+        d4 = dys[z].reshape(K, R, 2, C).astype(np.float64)
+        ref = np.einsum("kri,kro->kio", np.conj(x4[:, :, 0] + 1j * x4[:, :, 1]), d4[:, :, 0] + 1j * d4[:, :, 1])
+        assert rel_l2(part[z][:, 0], ref.real) < TOL and rel_l2(part[z][:, 1], ref.imag) < TOL, z
+
+
 @pytest.mark.parametrize("tag", ["c64_rect", "c32_odd", "tiny_lowpass_as_c32"])
 def test_spectral2d_operator_vs_reference_golden(be, tag):
     """ffno_spectral2d_fwd/bwd against golden vectors of the reference's forward_fourier + autograd."""
