@@ -99,6 +99,17 @@ PY
     steptests)
       timeout 900 python -m pytest tests/test_trainer.py tests/test_kernels_ffh.py tests/test_kernels_ffx.py tests/test_block.py -m gpu -q -x --tb=short -p no:cacheprovider > gpurun_out/pytest_step.log 2>&1
       echo "[r6] step tests rc=$?"; tail -n 3 gpurun_out/pytest_step.log ;;
+    fwgrad)
+      timeout 900 python -m pytest tests/test_kernels_spectral.py tests/test_range.py tests/test_trainer.py tests/test_bench_geometry.py -m gpu -q -x --tb=short -p no:cacheprovider -k "fw_grad or growth or golden or B32 or B19 or kochkov or mesh3d" -s > gpurun_out/pytest_fwgrad.log 2>&1
+      echo "[r6] fwgrad tests rc=$?"; grep -oE "(passed|failed).*|\[bench-geometry B=(32|19)[^]]*\] (worst|vs fp64).{0,200}" gpurun_out/pytest_fwgrad.log | tail -8
+      for v in bf16x3 fp16x2 bf16x3 fp16x2; do
+        FFNO_FW_GRAD_SPLIT=$v timeout 300 python bench.py --steps 30 --warmup 5 --cpu-steps 0 --no-secondary > gpurun_out/bench_fwgrad_$v.log 2> gpurun_out/bench_fwgrad_$v.err
+        python - <<PY
+import json
+d = json.loads(open("gpurun_out/bench_fwgrad_$v.log").read().strip().splitlines()[-1])
+print("FFNO_FW_GRAD_SPLIT=$v", d["value"], "steps/s", d["ms_per_step_median"], "ms median; fw_grad_partial", d["kernels"]["fw_grad_partial"]["avg_us"], "us (zero operands", d["kernels"]["fw_grad_partial"].get("zero_operand_us"), ")")
+PY
+      done ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
