@@ -10,6 +10,7 @@ import ctypes as C
 # generation of include/ffno.h these signatures and struct mirrors belong to (FFNO_ABI_VERSION there; _lib.check_abi compares
 # it with what the loaded library reports before anything is called)
 ABI_VERSION = 7
+BRANCH_SELF_RANGE = 1      # ffno_fused_branch.flags: FFNO_BRANCH_SELF_RANGE (ffno_spectral_x3_mix_pair)
 
 P = C.c_void_p
 I = C.c_int
@@ -35,7 +36,7 @@ class FusedBranch(C.Structure):
                 ("B", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
                 ("K", C.c_int32), ("axis", C.c_int32), ("accumulate", C.c_int32),
                 ("planes_format", C.c_int32), ("tile_lines", C.c_int32), ("in_amax", P), ("out_amax", P),
-                ("storage", C.c_int32), ("pad_", C.c_int32), ("dft_frags", P)]
+                ("storage", C.c_int32), ("flags", C.c_int32), ("dft_frags", P)]
 
 
 class FfOpts(C.Structure):

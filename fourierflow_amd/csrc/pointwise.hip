@@ -99,36 +99,54 @@ static inline PadMapDev make_padmap(const ffno_padmap* pm) {
 
 // ---- lift (in_proj) -----------------------------------------------------------------------------------
 // (ST: storage format of the activation tensor -- `out` here; ffno_device.h)
+// One workgroup per CU at most (grid <= 256 x 512 threads): the range word of the lifted features costs one same-address atomic per
+// workgroup, and those serialise at ~10 ns each (tools/ubench/atomic_fold.hip: 2048 workgroups = 21 us of tail behind a 10-us body --
+// the round-5 form of this kernel; 256 = 0.6-2 us).  Two pixels per thread and pass: both pixels' inputs are requested before either
+// is used.
 template <int C, class ST = StF32>
-__global__ __launch_bounds__(256) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(512) void lift_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                        const float* __restrict__ b, typename ST::T* __restrict__ out, int P,
                                                        int Cin, PadMapDev pm, unsigned* out_amax) {
     FFNO_DYN_SMEM(smem);
-    __shared__ float rfold[4];
+    __shared__ float rfold[8];
     float omax = 0.f;
     float* Wt = reinterpret_cast<float*>(smem);  // [Cin + 1][C], last row = bias
     for (int e = threadIdx.x; e < Cin * C; e += blockDim.x) Wt[(e % Cin) * C + (e / Cin)] = W[e];
     for (int e = threadIdx.x; e < C; e += blockDim.x) Wt[Cin * C + e] = b[e];
     __syncthreads();
     constexpr int LPP = C / 4;        // lanes per pixel (one float4 of outputs each)
-    constexpr int PPB = 256 / LPP;    // pixels per block pass
+    const int PPB = (int)blockDim.x / LPP;    // pixels per block pass
     const int c4 = (threadIdx.x % LPP) * 4, pl = threadIdx.x / LPP;
-    for (long p = (long)blockIdx.x * PPB + pl; p < P; p += (long)gridDim.x * PPB) {
-        float4 acc = *reinterpret_cast<const float4*>(Wt + Cin * C + c4);
-        const float* xp = x + p * Cin;
+    const float4 bias = *reinterpret_cast<const float4*>(Wt + Cin * C + c4);
+    const long stride = (long)gridDim.x * PPB;
+    for (long p = (long)blockIdx.x * PPB + pl; p < P; p += 2 * stride) {
+        const long p1 = p + stride;
+        const bool two = p1 < P;
+        float4 acc0 = bias, acc1 = bias;
+        const float* xp0 = x + p * Cin;
+        const float* xp1 = x + (two ? p1 : p) * Cin;
         for (int i = 0; i < Cin; ++i) {
-            const float xv = xp[i];
+            const float xv0 = xp0[i], xv1 = xp1[i];
             const float4 w = *reinterpret_cast<const float4*>(Wt + i * C + c4);
-            acc.x = fmaf(xv, w.x, acc.x);
-            acc.y = fmaf(xv, w.y, acc.y);
-            acc.z = fmaf(xv, w.z, acc.z);
-            acc.w = fmaf(xv, w.w, acc.w);
+            acc0.x = fmaf(xv0, w.x, acc0.x);
+            acc0.y = fmaf(xv0, w.y, acc0.y);
+            acc0.z = fmaf(xv0, w.z, acc0.z);
+            acc0.w = fmaf(xv0, w.w, acc0.w);
+            acc1.x = fmaf(xv1, w.x, acc1.x);
+            acc1.y = fmaf(xv1, w.y, acc1.y);
+            acc1.z = fmaf(xv1, w.z, acc1.z);
+            acc1.w = fmaf(xv1, w.w, acc1.w);
         }
-        ST::st4(out + pm.map(p) * C + c4, acc);
-        acc = st_rnd4<ST>(acc);
-        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+        ST::st4(out + pm.map(p) * C + c4, acc0);
+        acc0 = st_rnd4<ST>(acc0);
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc0.x), fabsf(acc0.y))), fmaxf(fabsf(acc0.z), fabsf(acc0.w)));
+        if (two) {
+            ST::st4(out + pm.map(p1) * C + c4, acc1);
+            acc1 = st_rnd4<ST>(acc1);
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(acc1.x), fabsf(acc1.y))), fmaxf(fabsf(acc1.z), fabsf(acc1.w)));
+        }
     }
-    if (out_amax) range_fold(omax, rfold, 4, out_amax);      // (optional range word of the lifted features)
+    if (out_amax) range_fold(omax, rfold, (int)blockDim.x >> 6, out_amax);      // (optional range word of the lifted features)
 }
 
 // partial[split][i][c] = sum_{p in slice} gout[q(p)][c] * (i < Cin ? x[p][i] : 1)
@@ -354,28 +372,34 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const float* __res
 
 // y = Wb (Wa b + ca) + cb, red[o] = { G_o = sum_p gy[p][o] b[p][:], S_o = sum_p gy[p][o] }:
 //   dWb[o][j] = (Wa G_o)[j] + ca[j] S_o ; dWa[j][c] = sum_o Wb[o][j] G_o[c] ; dca[j] = sum_o Wb[o][j] S_o ; dcb[o] = S_o
-__global__ void head_param_grads_kernel(const float* __restrict__ red, const float* __restrict__ Wa,
-                                        const float* __restrict__ ca, const float* __restrict__ Wb, float* dWa,
-                                        float* dca, float* dWb, float* dcb, int C, int D, int O, int accumulate) {
-    for (int e = threadIdx.x; e < O * D; e += blockDim.x) {
-        const int o = e / D, jd = e % D;
-        float s = ca[jd] * red[o * (C + 1) + C];
-        for (int c = 0; c < C; ++c) s = fmaf(Wa[jd * C + c], red[o * (C + 1) + c], s);
-        dWb[e] = accumulate ? dWb[e] + s : s;
-    }
-    for (int jd = threadIdx.x; jd < D; jd += blockDim.x) {
-        float t = 0.f;
-        for (int o = 0; o < O; ++o) t = fmaf(Wb[o * D + jd], red[o * (C + 1) + C], t);
-        dca[jd] = accumulate ? dca[jd] + t : t;
-    }
-    for (int e = threadIdx.x; e < D * C; e += blockDim.x) {
-        float t = 0.f;
-        for (int o = 0; o < O; ++o) t = fmaf(Wb[o * D + e / C], red[o * (C + 1) + e % C], t);
-        dWa[e] = accumulate ? dWa[e] + t : t;
-    }
-    for (int o = threadIdx.x; o < O; o += blockDim.x) {
-        const float S = red[o * (C + 1) + C];
-        dcb[o] = accumulate ? dcb[o] + S : S;
+// (one flat index space over the four outputs, grid-stride: the single-workgroup form of rounds 1-5 walked its 8k entries of dWa
+//  in 32 dependent rounds -- 13.5 us for 40 kB of results)
+__global__ __launch_bounds__(256) void head_param_grads_kernel(const float* __restrict__ red, const float* __restrict__ Wa,
+                                                               const float* __restrict__ ca, const float* __restrict__ Wb,
+                                                               float* dWa, float* dca, float* dWb, float* dcb, int C, int D,
+                                                               int O, int accumulate) {
+    const int n0 = O * D, n1 = n0 + D, n2 = n1 + D * C, n3 = n2 + O;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n3; idx += gridDim.x * blockDim.x) {
+        if (idx < n0) {
+            const int e = idx, o = e / D, jd = e % D;
+            float s = ca[jd] * red[o * (C + 1) + C];
+            for (int c = 0; c < C; ++c) s = fmaf(Wa[jd * C + c], red[o * (C + 1) + c], s);
+            dWb[e] = accumulate ? dWb[e] + s : s;
+        } else if (idx < n1) {
+            const int jd = idx - n0;
+            float t = 0.f;
+            for (int o = 0; o < O; ++o) t = fmaf(Wb[o * D + jd], red[o * (C + 1) + C], t);
+            dca[jd] = accumulate ? dca[jd] + t : t;
+        } else if (idx < n2) {
+            const int e = idx - n1;
+            float t = 0.f;
+            for (int o = 0; o < O; ++o) t = fmaf(Wb[o * D + e / C], red[o * (C + 1) + e % C], t);
+            dWa[e] = accumulate ? dWa[e] + t : t;
+        } else {
+            const int o = idx - n2;
+            const float S = red[o * (C + 1) + C];
+            dcb[o] = accumulate ? dcb[o] + S : S;
+        }
     }
 }
 
@@ -662,8 +686,8 @@ static int lift_fwd_impl(const float* x, const float* W, const float* b, typenam
     if (Cin > 63) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
     const size_t smem = sizeof(float) * (size_t)(Cin + 1) * C;
-    const int ppb = 256 / (C / 4);
-    const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, 2048L)), block(256);
+    const int ppb = 512 / (C / 4);
+    const dim3 grid((unsigned)min(((long)P + ppb - 1) / ppb, (long)device_cu_count())), block(512);
     hipStream_t s = (hipStream_t)stream;
     if (C == 64)
         FFNO_LAUNCH((lift_fwd_kernel<64, ST>), grid, block, smem, s, x, W, b, out, P, Cin, pm, out_amax);
@@ -804,8 +828,9 @@ extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const fl
                                      float* dWa, float* dca, float* dWb, float* dcb, int C, int D, int O,
                                      int accumulate, void* stream) {
     if (!red || !Wa || !ca || !Wb || !dWa || !dca || !dWb || !dcb || O <= 0) return FFNO_EINVAL;
-    FFNO_LAUNCH(head_param_grads_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, red, Wa, ca, Wb, dWa, dca,
-                       dWb, dcb, C, D, O, accumulate);
+    const int total = O * D + D + D * C + O;
+    FFNO_LAUNCH(head_param_grads_kernel, dim3((unsigned)std::min((total + 255) / 256, 256)), dim3(256), 0, (hipStream_t)stream,
+                red, Wa, ca, Wb, dWa, dca, dWb, dcb, C, D, O, accumulate);
     return pw_status();
 }
 

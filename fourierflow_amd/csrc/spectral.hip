@@ -1800,11 +1800,15 @@ extern "C" int ffno_spectral2d_fwd(const float* x, const float* w_y, const float
     if (sp2d_x3_ok(B, M, N, C, K)) {
         if ((rc = sp2d_prepare(w_y, w_x, ws, tw_n, tw_m, B, M, N, C, K, mode, stream, l))) return rc;
         uint32_t* word = reinterpret_cast<uint32_t*>(ws + l.off_words);
-        if (mode == FFNO_MODE_FULL) {
+        const bool two_launch = mode == FFNO_MODE_FULL && l.mix_y_f && l.mix_x_f && ffno_layer_infer_supported(B, M, N, C, 4 * C, K, K);
+        // axis lengths <= 64 on the two-launch pair: every line is scaled from its own maximum inside the first launch
+        // (FFNO_BRANCH_SELF_RANGE) -- no range word of x, i.e. no memset + ffno_amax pass over x in front of it
+        const bool self_range = two_launch && M <= 64 && N <= 64;
+        if (mode == FFNO_MODE_FULL && !self_range) {
             if (hipMemsetAsync(word, 0, sizeof(uint32_t), (hipStream_t)stream) != hipSuccess) return (int)hipGetLastError();
             if ((rc = ffno_amax(x, (size_t)B * M * N * C, word, stream))) return rc;
         }
-        if (mode == FFNO_MODE_FULL && l.mix_y_f && l.mix_x_f && ffno_layer_infer_supported(B, M, N, C, 4 * C, K, K)) {
+        if (two_launch) {
             // two launches, no branch image: both forward DFTs + mixes -> the mixed spectra (operand fragments in ws) -> both inverse
             // DFTs summed in registers (infer.hip: ffno_spectral_x3_mix_pair + ffno_infer_sum)
             ffno_fused_branch br[2] = {};
@@ -1814,7 +1818,8 @@ extern "C" int ffno_spectral2d_fwd(const float* x, const float* w_y, const float
                 br[axis].B = B, br[axis].M = M, br[axis].N = N, br[axis].K = K, br[axis].axis = axis;
                 br[axis].planes = ws + l.off_pack + (2 * axis) * l.pack_f;
                 br[axis].planes_format = FFNO_PLANES_FP16X2;
-                br[axis].in_amax = word;
+                br[axis].in_amax = self_range ? nullptr : word;
+                br[axis].flags = self_range ? FFNO_BRANCH_SELF_RANGE : 0;
                 br[axis].dft_frags = ws + l.off_tab + (axis == 0 ? 0 : 2 * l.tab_n_f);
             }
             if ((rc = ffno_spectral_x3_mix_pair(&br[0], &br[1], C, 2, stream))) return rc;

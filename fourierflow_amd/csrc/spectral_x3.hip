@@ -63,6 +63,9 @@ struct X3Args {
     // x 16 B per line) beside the factor that turns its accumulators into samples (mix_scale: one float per line)
     u32x4* mix_out;
     float* mix_scale;
+    // MIXOUT instances, lines of <= 64 samples (the wave holds the whole line before its first product): every line is scaled from
+    // ITS OWN maximum instead of the range word of the tensor (FFNO_BRANCH_SELF_RANGE) -- no range word, no atomics, no amax pass
+    int self_range;
 };
 
 // ---- weight packing --------------------------------------------------------------------------------------------------
@@ -196,13 +199,14 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     // range scale of the spectrum tile (fp16x2 mix): applied where phase 1 writes the tile, removed where phase 3 stores; the
     // saved spectrum stays unscaled.  |X[k]| <= 2 sqrt(L) max|x| (orthonormal DFT, c_k <= 2): that bound goes to 2^15, so no
     // finite input can push a split operand of the mix past the half format's 65504.
-    const float rs = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
-    const float rrs = 1.f / rs;
+    const float rs_w = (MIXH2 && A.wpk && A.in_amax) ? range_scale(*A.in_amax, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
+    const float rrs = 1.f / rs_w;
     // fp16x2 DFT: samples x sx (max |in| -> 2^10); the accumulators then hold 2^11 sx X
-    const float sx = (DFTH2 && A.in_amax) ? range_scale(*A.in_amax, 0, 10) : 1.f;
-    const float unx = DFTH2 ? kHf2Unscale / sx : 1.f;      // accumulator -> spectrum
+    const float sx_w = (DFTH2 && A.in_amax) ? range_scale(*A.in_amax, 0, 10) : 1.f;
+    const float unx_w = DFTH2 ? kHf2Unscale / sx_w : 1.f;      // accumulator -> spectrum
     float omax = 0.f;                  // max |out| over what this thread stores
     __shared__ float rfold[F::NW];
+    __shared__ float lrrs[MIXOUT ? NL : 1];      // self-ranged lines: 1 / (tile scale) of every line, phase 1 -> phase 3' (not in registers)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
@@ -276,6 +280,27 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         FFNO_UNROLL
         for (int ln = 0; ln < NLW; ++ln) {
             f32x16 acc0 = zero16(), acc1 = zero16();
+            float sx = sx_w, unx = unx_w, rs = rs_w;      // this line's scales (the tensor's, or the line's own)
+            if constexpr (MIXOUT && !ST::BF16) {
+                if (A.self_range) {
+                    // the whole line (L <= 64: one chunk) sits in `raw`: its maximum over samples and channels takes 63 maxima per lane
+                    // and six butterflies, and replaces the tensor's range word -- scales are per line anyway from here on (rs goes
+                    // into the tile rows of this line, the mix is linear per row, phase 3' folds 1 / rs into the line's mix_scale)
+                    float lmx = 0.f;
+                    FFNO_UNROLL
+                    for (int u = 0; u < 4; ++u) {
+                        FFNO_UNROLL
+                        for (int e = 0; e < 8; ++e) lmx = fmaxf(lmx, fmaxf(fabsf(raw[u][e].x), fabsf(raw[u][e].y)));
+                    }
+                    FFNO_UNROLL
+                    for (int sh = 32; sh >= 1; sh >>= 1) lmx = fmaxf(lmx, __shfl_xor(lmx, sh));
+                    const unsigned lw_ = f2u(lmx);
+                    sx = range_scale(lw_, 0, 10);
+                    unx = kHf2Unscale / sx;
+                    rs = A.wpk ? range_scale(lw_, 1 + (ceil_log2_int(L) + 1) / 2, 15) : 1.f;
+                    if (lane == 0) lrrs[lw + ln] = 1.f / rs;
+                }
+            }
             FFNO_NOUNROLL
             for (int chunk = 0; chunk < nchunks; ++chunk) {
                 if (nchunks > 1 && (ln | chunk)) build_F(chunk);      // one chunk (L <= 64): the fragments serve both lines
@@ -477,7 +502,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                 dst[((st * 2 + 1) * 2 + 1) * 64] = y1.lo;
             }
             // accumulator of the second kernel (2^11 sy rs Y) -> samples
-            if (lane == 0) A.mix_scale[line0 + ln] = rrs * kHf2Unscale / sy;
+            if (lane == 0) A.mix_scale[line0 + ln] = (A.self_range ? lrrs[lw + ln] : rrs) * kHf2Unscale / sy;
         }
         return;
     }
@@ -1039,6 +1064,7 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.dft = nullptr;
     s.mix_out = second ? b.mix_out : a.mix_out;
     s.mix_scale = second ? b.mix_scale : a.mix_scale;
+    s.self_range = a.self_range;      // (common to both branches: ffno_spectral_x3_mix_pair checks it)
     spectral_x3_body<NL, MIXH2, ST, MIXOUT>(s, idx, (idx & 1) ? skew : 0);
 }
 
@@ -1926,6 +1952,7 @@ __device__ __forceinline__ X3Args x3_pick_args(const X3Args& a, const X3Args& b,
     s.dft = second ? b.dft : a.dft;
     s.mix_out = second ? b.mix_out : a.mix_out;
     s.mix_scale = second ? b.mix_scale : a.mix_scale;
+    s.self_range = 0;
     return s;
 }
 
@@ -2708,6 +2735,12 @@ extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno
     a.mix_scale = reinterpret_cast<float*>(a.mix_out + (size_t)a.R * 8 * 64);
     b.mix_scale = reinterpret_cast<float*>(b.mix_out + (size_t)b.R * 8 * 64);
     a.out = b.out = nullptr, a.out_amax = b.out_amax = nullptr;
+    // FFNO_BRANCH_SELF_RANGE: every line scaled from its own maximum (it sits in the wave's registers when L <= 64) -- in_amax unused
+    const int self_range = (ba->flags & FFNO_BRANCH_SELF_RANGE) ? 1 : 0;
+    if (self_range != ((bb->flags & FFNO_BRANCH_SELF_RANGE) ? 1 : 0)) return FFNO_EINVAL;
+    if (self_range && (a.L > 64 || b.L > 64)) return FFNO_EUNSUPPORTED;
+    a.self_range = b.self_range = self_range;
+    if (self_range) a.in_amax = b.in_amax = nullptr;
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
     hipStream_t st = (hipStream_t)stream;
     auto wg_map = [&](int NL, int n0, int n1) {

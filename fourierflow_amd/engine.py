@@ -94,6 +94,8 @@ class FFNOEngine:
                       cropped before the head (mesh_3d.py:165,173); ``output_dim`` outputs.
     """
 
+    can_return_view = True      # forward(..., own_output=False) exists (FFNOTrainer.train_step)
+
     def __init__(self, *, modes, width: int, input_dim: int, n_layers: int, factor: int, share_weight: bool,
                  share_fork: bool = False, ff_weight_norm: bool = False, mode: str = "full", spatial_dims: int = 2,
                  padding: int = 0, output_dim: int = 1, use_fork: bool = False, first_axis_first: bool = False,
@@ -250,6 +252,7 @@ class FFNOEngine:
         # mixed spectra between the launches, no branch image in memory) where the library takes the shape and the launch is large
         # enough to fill the chip; small launches (a rollout at batch 1) stay on the latency kernels of the training path
         self.use_infer_layer = os.environ.get("FFNO_INFER_LAYER", "1") != "0"
+        self.infer_self_range = True      # inference layers of axis length <= 64 scale every line from its own maximum (no range words)
         self.infer_min_lines = None      # lines per axis pair from which the inference layer is used (None: more than 4 per CU)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
@@ -1063,9 +1066,11 @@ class FFNOEngine:
                 accumulate, st)
 
     # ------------------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor, save_for_backward: bool, training: Optional[bool] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, save_for_backward: bool, training: Optional[bool] = None, own_output: bool = True) -> torch.Tensor:
         """x [B, *spatial, input_dim] fp32 on the device -> [B, *spatial, output_dim] (a fresh tensor).
-        ``training`` (default: save_for_backward) switches the dropout masks on (nn.Module.training of the reference)."""
+        ``training`` (default: save_for_backward) switches the dropout masks on (nn.Module.training of the reference).
+        ``own_output=False`` returns a view of the workspace's output buffer instead of a copy -- valid until the next forward of
+        this shape (FFNOTrainer.train_step consumes it at once: one copy launch less per step)."""
         if not self.params:
             raise RuntimeError("bind() parameters first")
         _lib.require_device_tensor(x, "x")
@@ -1121,6 +1126,10 @@ class FFNOEngine:
             ws.MIX = [torch.empty(int(lib.ffno_infer_mix_bytes(C, ws.views[w].K, ws.views[w].R)) // 4, dtype=torch.int32, device=self.device)
                       for w in pair]
         self.infer_last = infer      # (tests / bench.py: which layer kernels the last forward ran)
+        # self-ranged inference layers (axis lengths <= 64: ffno.h FFNO_BRANCH_SELF_RANGE): the first kernel scales every line from its
+        # own maximum, so no launch of this forward has to fold a range word for it (lift, second kernel: no atomics, no fold barrier)
+        infer_sr = bool(infer and self.infer_self_range and all(ws.views[w].L <= 64 for w in pair))
+        self.infer_self_ranged_last = infer_sr
         # both branch outputs of every layer are kept and the feed-forward does not write their sum (the deferred weight-gradient
         # launch forms it): decided here, the backward pass follows (self._saved_lazy)
         lazy = bool(save_for_backward and conc and getattr(ws, "lazy_sums", ""))
@@ -1137,7 +1146,7 @@ class FFNOEngine:
         if pm is not None:
             ws.X.zero_()     # F.pad(..., 0) of the lifted features (mesh_3d.py:165)
         rw = self._rw
-        if self._ranged():
+        if self._ranged() and not infer_sr:
             # the forward's words: layer inputs (x) and branch outputs (s) -- and, in the same launch, the words of the backward
             # pass that will follow this forward
             ws.RW.zero_()
@@ -1145,7 +1154,7 @@ class FFNOEngine:
         in_drop = self._training and self.in_dropout > 0.0
         self._k("lift_fwd", lib.ffno_lift_fwd_bf16 if bf16 else lib.ffno_lift_fwd, _p(x), _p(lin_in.weff),
                 _p(self.params["in_proj.bias"]), _p(ws.X), ws.P_in,
-                self.Cin, C, pm, None if in_drop else rw(ws, "x", 0), st)
+                self.Cin, C, pm, None if (in_drop or infer_sr) else rw(ws, "x", 0), st)
         if in_drop:      # x = self.drop(x) after in_proj (grid_2d.py:158): a regenerated mask over the lifted features
             self._in_drop_seed = _site_seed(self.drop_seed, self._drop_calls, 0xFFFF, 0, 2)
             self._k("in_dropout", lib.ffno_dropout, _p(ws.X), ws.X.numel(), self.in_dropout, self._in_drop_seed, st)
@@ -1175,6 +1184,10 @@ class FFNOEngine:
                     l0, l1, b0, b1 = self._ff_weights(l)
                     ba = self._branch(ws.views[a], ws.X, ws.MIX[0], None, None, self._planes_for(si, a, 0, True), 0, True, True, rx, None)
                     bb = self._branch(ws.views[b], ws.X, ws.MIX[1], None, None, self._planes_for(si, b, 0, True), 0, True, True, rx, None)
+                    if infer_sr:
+                        ba.flags = bb.flags = _capi.BRANCH_SELF_RANGE
+                        ba.in_amax = bb.in_amax = None
+                        rxn = None
                     out_l = ws.Blast if last else ws.X
                     if self.timer is None:
                         d = _capi.LayerInferDesc(ba, bb, X3_INTERLEAVE, 0, _p(l0.fx[0]), _p(b0), _p(l0.fx[1]), _p(b1),
@@ -1257,7 +1270,8 @@ class FFNOEngine:
         self._saved_sched = (singles, pair)
         self._saved_lazy = lazy
         self.paired_last = conc      # (bench.py: which algorithmic-work table applies)
-        return ws.Y.view(B, *S, self.O).clone()
+        y = ws.Y.view(B, *S, self.O)
+        return y.clone() if own_output else y
 
     # ------------------------------------------------------------------------------------------------
     def backward(self, gy: torch.Tensor, need_dx: bool = False) -> torch.Tensor:

@@ -86,26 +86,35 @@ class FFNOTrainer:
             return self.lr * float(self.lr_factor())
         return self.lr * cosine_warmup_factor(self.step_count, *self.sched)
 
-    def loss_and_grad(self, pred: torch.Tensor, target: torch.Tensor, affine: Optional[torch.Tensor] = None):
+    def loss_and_grad(self, pred: torch.Tensor, target: torch.Tensor, affine: Optional[torch.Tensor] = None, fresh_loss: bool = False):
         lib = _lib.get_lib()
         B = pred.shape[0]
         n = pred.numel() // B
         if self._gy is None or self._gy.shape != pred.shape:
             self._gy = torch.empty_like(pred)
             self._tmp = torch.empty(int(lib.ffno_lploss_tmp_floats(B, n)), dtype=torch.float32, device=pred.device)
+        if fresh_loss:
+            # the kernel writes the loss into a NEW 4-byte tensor (a host-side allocation from the caching allocator, no launch):
+            # the caller owns it -- no clone of a persistent buffer afterwards
+            self.loss = torch.empty(1, dtype=torch.float32, device=pred.device)
         _capi.check(lib.ffno_lploss_fwd_bwd(_p(pred), _p(target), _p(self.loss), _p(self._gy), _p(self._tmp), B, n, float(self.loss_scale),
                                             _p(affine), _lib.current_stream(self.device)), "lploss")
-        return self.loss, self._gy     # persistent buffers, overwritten by the next call (train_step returns a copy)
+        return self.loss, self._gy     # gy: a persistent buffer, overwritten by the next call; loss: likewise unless fresh_loss
 
     def train_step(self, x: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         """forward + relative-L2 loss + backward + (all-reduce) + AdamW + schedule; returns the loss (device)."""
         lib = _lib.get_lib()
         target = target.contiguous()
-        pred = self.engine.forward(self.block.prepare_input(x), True)
-        loss, gy = self.loss_and_grad(pred, target)
-        return self.apply_gradients(self.engine.backward(gy), loss)
+        # (the prediction is consumed by the loss kernel at once: a view of the engine's output buffer, not a copy; the loss lands in
+        #  a tensor of its own: two copy launches less per step than forward() + loss.clone())
+        if getattr(self.engine, "can_return_view", False):
+            pred = self.engine.forward(self.block.prepare_input(x), True, own_output=False)
+        else:
+            pred = self.engine.forward(self.block.prepare_input(x), True)
+        loss, gy = self.loss_and_grad(pred, target, fresh_loss=True)
+        return self.apply_gradients(self.engine.backward(gy), loss, loss_is_fresh=True)
 
-    def apply_gradients(self, gflat: torch.Tensor, loss: Optional[torch.Tensor] = None):
+    def apply_gradients(self, gflat: torch.Tensor, loss: Optional[torch.Tensor] = None, loss_is_fresh: bool = False):
         """(all-reduce) + fused AdamW/cosine step on the flat buffers."""
         lib = _lib.get_lib()
         if self.world > 1:
@@ -125,7 +134,7 @@ class FFNOTrainer:
         self.step_count += 1
         self.opt_step += 1
         # a fresh 4-byte tensor per step: the reference returns a new loss tensor each step and callers stack them
-        loss_out = loss.clone() if loss is not None else None
+        loss_out = (loss if loss_is_fresh else loss.clone()) if loss is not None else None
         fn = lib.ffno_adamw_flat if self.decoupled else lib.ffno_adam_flat
         _capi.check(fn(_p(self.pflat), _p(gflat), _p(self.m), _p(self.v), self.pflat.numel(), lr_t, self.betas[0],
                        self.betas[1], self.eps, self.wd, self.opt_step, 1.0 / self.world,

@@ -213,7 +213,7 @@ typedef struct ffno_fused_branch {
     int32_t storage;         /* FFNO_STORE_F32 (0) / FFNO_STORE_BF16: format of in / out / resid ("Storage formats" above;
                                 ffno_spectral_x3[_pair]: every fused split kernel with FP16X2 planes, the K <= 16 kernel also
                                 without planes; spec_save stays fp32) */
-    int32_t pad_;
+    int32_t flags;           /* FFNO_BRANCH_* bits; 0 = none (the field was padding before round 6: zero keeps every earlier behaviour) */
     const void* dft_frags;   /* optional (FP16X2 planes; read by the many-mode kernel, 17..64 modes, by the 4-line latency
                                 kernel of the <= 16-mode shapes and by the width-32 kernel): the DFT-matrix fragments of this
                                 branch's (L, K, flags)
@@ -225,6 +225,11 @@ typedef struct ffno_fused_branch {
 #define FFNO_PLANES_FP16X2_M16 2   /* fp16x2 fragments in the order of v_mfma_f32_16x16x32_f16: the many-mode kernel (C = 64, 17..64
                                       modes; its 4-line tile has 8 live mix rows) then runs 16-row products -- half the matrix time and a
                                       third of the vector work of its mix.  Needs dft_frags; same bytes as FFNO_PLANES_FP16X2 */
+/* ffno_spectral_x3_mix_pair only (both branches alike, axis lengths <= 64): every LINE is brought into the half format's range by
+ * the power of two of its own maximum -- the wave that transforms a line holds all of it before the first product -- instead of
+ * the tensor's range word: in_amax is not read, so nobody has to produce it (no ffno_amax pass over x in front of
+ * ffno_spectral2d_fwd, no out_amax atomics in the launch that wrote x).  At least as tight as the tensor-wide scale. */
+#define FFNO_BRANCH_SELF_RANGE 1
 #define FFNO_X3_TILE_LATENCY 1
 #define FFNO_X3_TILE_LATENCY_SPLIT 2 /* the latency tile with TWO workgroups per tile, one per output-channel parity (fp16x2 packs
                                       * with a mix only; tile_lines = 0 picks it while the doubled launch fits one round) */

@@ -128,6 +128,62 @@ def test_infer_layer_any_magnitude(be, scale):
     assert rel_l2(got.astype(np.float64) - S["x"], ref - S["x"]) < 1e-5
 
 
+@pytest.mark.parametrize("B,M,N,K,spread", [(1, 8, 32, 4, 1.0), (2, 16, 64, 8, 1.0), (2, 16, 64, 8, 1e8), (8, 64, 64, 16, 1e4)])
+def test_infer_layer_self_ranged_lines(be, B, M, N, K, spread):
+    """FFNO_BRANCH_SELF_RANGE (axis lengths <= 64): the first launch scales every LINE from its own maximum -- no range word is read
+    (the descriptor carries none), the second launch records none.  `spread`: the images' magnitudes differ by that factor (one
+    tensor-wide power of two would push the small images' samples towards the half format's subnormals: per-line scales do not
+    care).  Against fp64, per image; and the tensor-ranged launch on the same operands agrees to fp32 rounding when spread = 1."""
+    from fourierflow_amd._capi import BRANCH_SELF_RANGE, LayerInferDesc
+    if be.kind == "emu" and B * M * N > 2048:
+        pytest.skip("emulator time budget (the GPU run covers all shapes)")
+    lib, p = be.lib, be.ptr
+    C, H = 64, 256
+    S = _setup(be, B, M, N, K, seed=4242 + B + M + N + K)
+    x = S["x"]
+    if spread != 1.0:      # image b scaled by spread^(b / (B - 1)) (biases stay: the residual x dominates, so compare the UPDATE per image)
+        f = np.array([spread ** (b / max(1, B - 1)) for b in range(B)], np.float32)
+        x = (x * f[:, None, None, None]).astype(np.float32)
+    dx = be.put(x)
+
+    def branch(i, sr):
+        br = S["branch"](i, S["mix"][i])
+        br.in_ = p(dx)
+        if sr:
+            br.flags, br.in_amax = BRANCH_SELF_RANGE, None
+        else:
+            br.in_amax = p(word)
+        return br
+
+    word = be.zeros(1, np.uint32)
+    assert lib.ffno_amax(p(dx), x.size, p(word), None) == 0
+    outs = []
+    for sr in (True, False):
+        out = be.empty(x.shape)
+        d = LayerInferDesc(branch(0, sr), branch(1, sr), 2, 0, p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]),
+                           p(dx), p(out), C, H, None)
+        assert lib.ffno_layer_infer(ctypes.byref(d), None) == 0
+        outs.append(np.array(be.get(out)).astype(np.float64))
+    ref, _ = layer_fp64(x, S["w"][0], S["w"][1], S["W1"], S["b1"], S["W2"], S["b2"], K)
+    for b in range(B):
+        e = rel_l2(outs[0][b] - x[b], ref[b] - x[b])
+        assert e < 1e-5, (b, e)
+    if spread == 1.0:
+        assert rel_l2(outs[0], outs[1]) < 1e-6
+    # one flagged branch next to an unflagged one: refused; flagged lines longer than 64 samples: unsupported
+    a, b_ = branch(0, True), branch(1, False)
+    assert lib.ffno_spectral_x3_mix_pair(ctypes.byref(a), ctypes.byref(b_), C, 2, None) == -1
+
+
+def test_self_range_refuses_long_lines(be):
+    from fourierflow_amd._capi import BRANCH_SELF_RANGE
+    lib = be.lib
+    S = _setup(be, 1, 32, 128, 16, seed=9)
+    a, b = S["branch"](0, S["mix"][0]), S["branch"](1, S["mix"][1])
+    a.flags = b.flags = BRANCH_SELF_RANGE
+    assert lib.ffno_spectral_x3_mix_pair(ctypes.byref(a), ctypes.byref(b), 64, 2, None) == -2
+
+
 def test_infer_layer_argument_checks(be):
     from fourierflow_amd._capi import LayerInferDesc
     lib, p = be.lib, be.ptr
@@ -180,6 +236,13 @@ def test_engine_forward_without_saving_takes_the_inference_layer(host_device):
     with torch.no_grad():
         y_inf = blk(x)["forecast"].cpu().numpy()
     assert eng.infer_last and seen.count("layer_infer") == 3 and "layer_fwd" not in seen and "spectral_fused" not in seen
+    assert eng.infer_self_ranged_last      # axis lengths 32 / 8: every line scaled from its own maximum, no range words in this pass
+    # ... and with the tensor's range words instead (the round-6 first form; what axis lengths > 64 still run): same result to rounding
+    eng.infer_self_range = False
+    with torch.no_grad():
+        y_rw = blk(x)["forecast"].cpu().numpy()
+    assert eng.infer_last and not eng.infer_self_ranged_last and rel_l2(y_rw, y_inf) < 2e-6
+    eng.infer_self_range = True
     seen.clear()
     eng.use_infer_layer = False
     with torch.no_grad():

@@ -62,6 +62,26 @@ def main():
         "x3_pair (training fwd, nothing saved)": timeit(lambda: lib.ffno_spectral_x3_pair(ctypes.byref(a2), ctypes.byref(b2), C, 0, 1, 0, 2, st)),
         "layer_fwd (pair + chain, nothing saved)": timeit(lambda: lib.ffno_layer_fwd(ctypes.byref(d2), st)),
     }
+    # FFNO_BRANCH_SELF_RANGE (axis lengths <= 64): every line scaled from its own maximum, no range word read or recorded
+    if M <= 64 and N <= 64:
+        from fourierflow_amd._capi import BRANCH_SELF_RANGE
+        a3, b3 = S["branch"](0, S["mix"][0]), S["branch"](1, S["mix"][1])
+        a3.flags = b3.flags = BRANCH_SELF_RANGE
+        a3.in_amax = b3.in_amax = None
+        d3 = LayerInferDesc(a3, b3, 2, 0, p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]), p(S["dx"]), p(out), C, H, None)
+        assert lib.ffno_layer_infer(ctypes.byref(d3), None) == 0
+        torch.cuda.synchronize()
+        g3 = be.get(out)
+        print("self-ranged vs range-word inference layer rel-L2:", float(np.linalg.norm(g3 - g1) / np.linalg.norm(g1)))
+        for rep in range(2):      # (twice, interleaved with the range-word form: same box, same minute)
+            res[f"K1 mix_pair, self-ranged lines [{rep}]"] = timeit(lambda: lib.ffno_spectral_x3_mix_pair(ctypes.byref(a3), ctypes.byref(b3), C, 2, st))
+            res[f"K1 mix_pair, range word [{rep}]"] = timeit(lambda: lib.ffno_spectral_x3_mix_pair(ctypes.byref(a), ctypes.byref(b), C, 2, st))
+            res[f"K2 infer_ff, no out word [{rep}]"] = timeit(lambda: lib.ffno_infer_ff(
+                ctypes.byref(a3), ctypes.byref(b3), p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]), p(S["dx"]), p(out), C, H, None, st))
+            res[f"K2 infer_ff, out word [{rep}]"] = timeit(lambda: lib.ffno_infer_ff(
+                ctypes.byref(a), ctypes.byref(b), p(S["packs"][0]), p(S["db1"]), p(S["packs"][1]), p(S["db2"]), p(S["dx"]), p(out), C, H, p(oword), st))
+            res[f"layer_infer self-ranged [{rep}]"] = timeit(lambda: lib.ffno_layer_infer(ctypes.byref(d3), st))
+            res[f"layer_infer range words [{rep}]"] = timeit(lambda: lib.ffno_layer_infer(ctypes.byref(d), st))
     for k, v in res.items():
         print(f"{k:45s} {v:8.2f} us")
 
