@@ -270,7 +270,7 @@ __device__ __forceinline__ void range_fold(float m, float* red, int nwaves, unsi
     if (threadIdx.x == 0) {
 #endif
         for (int w = 1; w < nwaves; ++w) m = fmaxf(m, red[w]);
-        atomicMax(word, f2u(m));
+        if (f2u(m) != 0u) atomicMax(word, f2u(m));      // (a zero maximum never raises the word: no atomic for it)
     }
 }
 

@@ -95,6 +95,27 @@ def test_amax_batched_folds_every_tensor(be):
     w = be.zeros(1, np.uint32)
     assert lib.ffno_amax_batched(p(table), len(xs), max(x.size for x in xs), p(w), None) == 0
     assert np.asarray(be.get(w)).view(np.float32)[0] == 41.5
+    # the maximum at ANY position is found: last element of a long tensor (its tail past the 16-byte loads), of a short one, and in a
+    # tensor that does not start on a 16-byte boundary (a view one float into a buffer) -- one launch each, fresh word
+    big = be.put(np.zeros(70001, np.float32))
+    for which, pos, off, n in ((2, 69999, 0, 70000), (1, 4098, 0, 4099), (2, 69996, 1, 69999), (0, 4, 0, 5)):
+        ys = [x.copy() for x in xs]
+        ys[which][:] *= 1e-3
+        ys[which] = ys[which][:n]
+        ys[which][pos] = 123.25
+        devs2 = [be.put(y) for y in ys]
+        ptrs = [p(d) for d in devs2]
+        if off:      # unaligned start: the tensor lives one float into a device buffer
+            full = np.zeros(n + off, np.float32)
+            full[off:] = ys[which]
+            devs2[which] = be.put(full)
+            base = p(devs2[which])
+            ptrs[which] = (base.value if hasattr(base, "value") else int(base)) + 4 * off
+        descs2 = (AmaxDesc * len(ys))(*[AmaxDesc(pt, y.size) for pt, y in zip(ptrs, ys)])
+        table2 = be.put(np.frombuffer(bytes(descs2), dtype=np.uint8))
+        w2 = be.zeros(1, np.uint32)
+        assert lib.ffno_amax_batched(p(table2), len(ys), max(y.size for y in ys), p(w2), None) == 0
+        assert np.asarray(be.get(w2)).view(np.float32)[0] == 123.25, (which, pos, off)
     assert lib.ffno_amax_batched(None, 1, 4, p(w), None) == -1 and lib.ffno_amax_batched(p(table), 0, 4, p(w), None) == -1
 
 
