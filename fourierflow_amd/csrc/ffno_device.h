@@ -264,11 +264,7 @@ __device__ __forceinline__ void range_fold(float m, float* red, int nwaves, unsi
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-#ifdef FFNO_EXP_FOLD_SAMPLE      // timing experiment only (tools/variants.py): 1 workgroup in FFNO_EXP_FOLD_SAMPLE folds -- an approximate word
-    if (threadIdx.x == 0 && ((blockIdx.x >> 1) % FFNO_EXP_FOLD_SAMPLE) == 0 && blockIdx.y == 0) {
-#else
     if (threadIdx.x == 0) {
-#endif
         for (int w = 1; w < nwaves; ++w) m = fmaxf(m, red[w]);
         if (f2u(m) != 0u) atomicMax(word, f2u(m));      // (a zero maximum never raises the word: no atomic for it)
     }

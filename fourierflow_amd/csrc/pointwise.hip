@@ -99,7 +99,7 @@ static inline PadMapDev make_padmap(const ffno_padmap* pm) {
 
 // ---- lift (in_proj) -----------------------------------------------------------------------------------
 // (ST: storage format of the activation tensor -- `out` here; ffno_device.h)
-// One workgroup per CU at most (grid <= 256 x 512 threads): the range word of the lifted features costs one same-address atomic per
+// One workgroup per CU at most (grid <= 256 x 512 threads; 1024 threads measured equal: 12.4 vs 12.7 us): the range word of the lifted features costs one same-address atomic per
 // workgroup, and those serialise at ~10 ns each (tools/ubench/atomic_fold.hip: 2048 workgroups = 21 us of tail behind a 10-us body --
 // the round-5 form of this kernel; 256 = 0.6-2 us).  Two pixels per thread and pass: both pixels' inputs are requested before either
 // is used.
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void lift_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ b, typename ST::T* __restrict__ out, int P,
                                                        int Cin, PadMapDev pm, unsigned* out_amax) {
     FFNO_DYN_SMEM(smem);
-    __shared__ float rfold[8];
+    __shared__ float rfold[16];
     float omax = 0.f;
     float* Wt = reinterpret_cast<float*>(smem);  // [Cin + 1][C], last row = bias
     for (int e = threadIdx.x; e < Cin * C; e += blockDim.x) Wt[(e % Cin) * C + (e / Cin)] = W[e];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __re
                                                                int chunk, PadMapDev pm) {
     constexpr int TP = 32;                     // pixels staged per pass
     constexpr int MAXU = (C * 64) / 256;       // pairs per thread for Cin + 1 <= 64
-    __shared__ float gs[TP * C];
+    __shared__ __attribute__((aligned(16))) float gs[TP * C];
     __shared__ float xs[TP * 64];
     const int npairs = C * (Cin + 1);
     float acc[MAXU];
@@ -170,14 +170,19 @@ __global__ __launch_bounds__(256) void lift_bwd_partial_kernel(const float* __re
         __syncthreads();
         // (gout2: the second gradient buffer of a paired adjoint launch, added while the rows are staged -- the sum the engine used to
         //  form with an axpy pass over both images before this kernel)
-        for (int e = threadIdx.x; e < TP * C; e += 256) {
-            float gvv = 0.f;
+        // (four channels per thread and load: 16-byte requests instead of the 4-byte ones of rounds 1-5)
+        for (int e4 = threadIdx.x; e4 < TP * C / 4; e4 += 256) {
+            const int e = 4 * e4;
+            float4 gvv = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((e / C) < np) {
                 const long off = pm.map(p0 + e / C) * C + (e % C);
-                gvv = ST::ld1(gout + off);
-                if (gout2) gvv = ST::rnd(gvv + ST::ld1(gout2 + off));
+                gvv = ST::ld4(gout + off);
+                if (gout2) {
+                    const float4 g2 = ST::ld4(gout2 + off);
+                    gvv = make_float4(ST::rnd(gvv.x + g2.x), ST::rnd(gvv.y + g2.y), ST::rnd(gvv.z + g2.z), ST::rnd(gvv.w + g2.w));
+                }
             }
-            gs[e] = gvv;
+            *reinterpret_cast<float4*>(gs + e) = gvv;
         }
         for (int e = threadIdx.x; e < TP * (Cin + 1); e += 256) {
             const int pp = e / (Cin + 1), i = e % (Cin + 1);
@@ -289,14 +294,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const typename ST::T* __r
 }
 
 // gb[q(p)][:] = sum_o gy[p][o] * weff[o] ;  partial[block][o][0..C) = sum_p gy[p][o] b[q(p)][:],  [o][C] = sum_p gy[p][o]
+// (256 or 1024 threads per workgroup: the slice count -- one same-address atomic each for the range word, ~10 ns apiece -- stays at
+//  <= 256, and a launch over many pixels gets its memory-level parallelism from 16 waves per CU instead of 4: every pass of a wave
+//  is one dependent load -> store round)
 template <int C, class ST = StF32>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const typename ST::T* __restrict__ b, const float* __restrict__ gy,
-                                                       const float* __restrict__ fold, typename ST::T* __restrict__ gb,
-                                                       float* __restrict__ partial, int P, int O, PadMapDev pm,
-                                                       unsigned* gb_amax) {
-    constexpr int LPP = C / 4, PPB = 256 / LPP;
-    __shared__ float red[PPB * (C + 4)];
-    __shared__ float rfold[4];
+__global__ __launch_bounds__(1024) void head_bwd_kernel(const typename ST::T* __restrict__ b, const float* __restrict__ gy,
+                                                        const float* __restrict__ fold, typename ST::T* __restrict__ gb,
+                                                        float* __restrict__ partial, int P, int O, PadMapDev pm,
+                                                        unsigned* gb_amax) {
+    constexpr int LPP = C / 4;
+    const int PPB = (int)blockDim.x / LPP;
+    __shared__ float red[(1024 / LPP) * (C + 4)];
+    __shared__ float rfold[16];
     float omax = 0.f;
     const int l = threadIdx.x % LPP, c4 = l * 4, pl = threadIdx.x / LPP;
     float4 acc[kHeadMaxOut];
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const typename ST::T* __r
         gsum = st_rnd4<ST>(gsum);
         omax = fmaxf(fmaxf(omax, fmaxf(fabsf(gsum.x), fabsf(gsum.y))), fmaxf(fabsf(gsum.z), fabsf(gsum.w)));
     }
-    if (gb && gb_amax) range_fold(omax, rfold, 4, gb_amax);      // (optional range word of the gradient handed to the layers)
+    if (gb && gb_amax) range_fold(omax, rfold, (int)blockDim.x >> 6, gb_amax);      // (optional range word of the gradient handed to the layers)
     for (int o = 0; o < O; ++o) {
         __syncthreads();
         float* r = red + pl * (C + 4);
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const typename ST::T* __r
             }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e <= C; e += 256) {
+        for (int e = threadIdx.x; e <= C; e += blockDim.x) {
             float s = 0.f;
             for (int qq = 0; qq < PPB; ++qq) s += red[qq * (C + 4) + e];
             partial[((long)blockIdx.x * O + o) * (C + 1) + e] = s;
@@ -814,10 +823,12 @@ static int head_bwd_impl(const typename ST::T* b, const float* gy, const float* 
     if (O > kHeadMaxOut) return FFNO_EUNSUPPORTED;
     const PadMapDev pm = make_padmap(pad);
     hipStream_t s = (hipStream_t)stream;
+    // 1024 threads while every workgroup still has several passes of 1024 / (C / 4) pixels
+    const int threads = (long)P >= (long)nsplit * 4 * (1024 / (C / 4)) ? 1024 : 256;
     if (C == 64)
-        FFNO_LAUNCH((head_bwd_kernel<64, ST>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
+        FFNO_LAUNCH((head_bwd_kernel<64, ST>), dim3(nsplit), dim3(threads), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
     else if (C == 32)
-        FFNO_LAUNCH((head_bwd_kernel<32, ST>), dim3(nsplit), dim3(256), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
+        FFNO_LAUNCH((head_bwd_kernel<32, ST>), dim3(nsplit), dim3(threads), 0, s, b, gy, fold, gb, partial, P, O, pm, gb_amax);
     else
         return FFNO_EUNSUPPORTED;
     int rc = pw_status();

@@ -197,7 +197,7 @@ def test_lift_and_head_through_pad_map(be):
     assert rel_l2(be.get(gcb), gy.astype(np.float64).sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("P,C", [(300, 64), (77, 32)])
+@pytest.mark.parametrize("P,C", [(300, 64), (77, 32), (1100, 64), (2100, 32)])      # (the last two: head_bwd on 1024-thread workgroups)
 def test_head(be, P, C):
     lib, p = be.lib, be.ptr
     D = 128
