@@ -857,7 +857,8 @@ extern "C" int ffno_head_param_grads(const float* red, const float* Wa, const fl
     return pw_status();
 }
 
-static inline int lploss_slices(int n) { return max(1, min(64, (n + 8191) / 8192)); }
+// (1024 elements per slice: at 4096 outputs per sample the one-slice form ran 16 dependent load rounds on 32 workgroups)
+static inline int lploss_slices(int n) { return max(1, min(64, (n + 1023) / 1024)); }
 
 extern "C" size_t ffno_lploss_tmp_floats(int B, int n_per_sample) {
     return (size_t)2 * (size_t)B * (size_t)lploss_slices(n_per_sample);

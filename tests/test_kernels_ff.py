@@ -242,7 +242,7 @@ def test_lploss(be, B, n):
     pred = rs.standard_normal((B, n)).astype(np.float32)
     tgt = rs.standard_normal((B, n)).astype(np.float32)
     ntmp = lib.ffno_lploss_tmp_floats(B, n)
-    assert ntmp == 2 * B * max(1, min(64, (n + 8191) // 8192))
+    assert ntmp == 2 * B * max(1, min(64, (n + 1023) // 1024))
     dpred, dtgt, loss, gp, tmp = be.put(pred), be.put(tgt), be.zeros(1), be.zeros((B, n)), be.zeros(ntmp)
     assert lib.ffno_lploss_fwd_bwd(p(dpred), p(dtgt), p(loss), p(gp), p(tmp), B, n, 1.0, None, None) == 0
     pt = torch.tensor(pred, dtype=torch.float64, requires_grad=True)

@@ -110,6 +110,11 @@ d = json.loads(open("gpurun_out/bench_fwgrad_$v.log").read().strip().splitlines(
 print("FFNO_FW_GRAD_SPLIT=$v", d["value"], "steps/s", d["ms_per_step_median"], "ms median; fw_grad_partial", d["kernels"]["fw_grad_partial"]["avg_us"], "us (zero operands", d["kernels"]["fw_grad_partial"].get("zero_operand_us"), ")")
 PY
       done ;;
+    small)
+      # the non-hot launches one by one, the forward A/B of the self-ranged inference layers, the same-address atomic micro-benchmark
+      timeout 300 python tools/time_small.py > gpurun_out/time_small.log 2>&1; echo "[r6] time_small rc=$?"; tail -n 19 gpurun_out/time_small.log
+      timeout 300 python tools/ab_forward.py 5 > gpurun_out/ab_forward.log 2>&1; echo "[r6] ab_forward rc=$?"; tail -n 5 gpurun_out/ab_forward.log
+      [ -x tools/ubench/bin/atomic_fold ] && { timeout 300 tools/ubench/bin/atomic_fold > gpurun_out/atomic_fold.log 2>&1; echo "[r6] atomic_fold rc=$?"; } ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
