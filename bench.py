@@ -704,6 +704,28 @@ def main():
                              "over the replay-timed duration of BOTH launches; bytes_moved = what each launch reads + writes (x / the two "
                              "8-KiB-per-line fragment spectra / x, x'); traffic = PMC HBM bytes of the two launches (profiles/pmc_traffic.json)")
                     log(f"inference layer: spectral_mix {repf['spectral_mix']:.1f} us + infer_ff {repf['infer_ff']:.1f} us per layer")
+                    # ... and what trainer.predict really runs at this geometry since the end of round 6: ALL layers in one persistent
+                    # launch (ffno_infer_stack: the 8 workgroups of an image run both kernels of every layer as phases, group
+                    # barriers between) -- HIP events around that one launch, 10 forward passes; `achieved` / `frac` follow it
+                    ps = KernelProbe(["infer_stack"], every=1)
+                    ps.allow_stack = True
+                    ps.sample = True
+                    trainer.engine.timer = ps
+                    for _ in range(12):
+                        trainer.predict(x)
+                    trainer.engine.timer = None
+                    torch.cuda.synchronize()
+                    st_ = ps.in_step().get("infer_stack")
+                    if getattr(trainer.engine, "infer_stack_last", False) and st_:
+                        us_stack = st_[0] / args.layers
+                        roofline_forward.update(
+                            achieved=round(floor / us_stack * 1e-3, 1), frac=round(floor / us_stack * 1e-3 / HBM_PEAK_GBS, 4),
+                            us_per_layer=round(us_stack, 2), us_per_layer_two_launches=round(us_layer, 2),
+                            persistent=dict(launch_us=round(st_[0], 1), samples=st_[1], layers=args.layers,
+                                            what="ffno_infer_stack: one cooperative launch of 256 workgroups for the whole layer stack; "
+                                                 "bit-identical to the per-layer launches (tests/test_infer_layer.py)"))
+                        log(f"persistent inference stack: {st_[0]:.1f} us for {args.layers} layers = {us_stack:.2f} us per layer "
+                            f"(two launches per layer: {us_layer:.2f})")
         except Exception as e:  # noqa: BLE001 - optional evidence
             trainer.engine.timer = None
             log(f"forward roofline skipped: {e!r}")

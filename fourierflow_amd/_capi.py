@@ -68,6 +68,17 @@ class LayerInferDesc(C.Structure):
                 ("out_amax", P)]
 
 
+class InferStackLayer(C.Structure):
+    """Mirror of ``ffno_infer_stack_layer`` (include/ffno.h)."""
+    _fields_ = [("planes_a", P), ("planes_b", P), ("pk1", P), ("b1", P), ("pk2", P), ("b2", P)]
+
+
+class InferStackDesc(C.Structure):
+    """Mirror of ``ffno_infer_stack_desc`` (include/ffno.h)."""
+    _fields_ = [("a", FusedBranch), ("b", FusedBranch), ("layers", P), ("n_layers", C.c_int32), ("C", C.c_int32), ("H", C.c_int32),
+                ("mode", C.c_int32), ("last_out", P), ("sync", P)]
+
+
 class AmaxDesc(C.Structure):
     """Mirror of ``ffno_amax_desc`` (include/ffno.h)."""
     _fields_ = [("x", P), ("n", C.c_size_t)]
@@ -150,6 +161,9 @@ SIGNATURES = {
     "ffno_infer_ff": (I, [P, P, P, P, P, P, P, P, I, I, P, P]),
     "ffno_infer_sum": (I, [P, P, P, I, P, P]),
     "ffno_layer_infer": (I, [P, P]),
+    "ffno_infer_stack_supported": (I, [I, I, I, I, I, I, I, I]),
+    "ffno_infer_stack_sync_words": (SZ, [I]),
+    "ffno_infer_stack": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),
     "ffno_spectral_fused": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P, P]),

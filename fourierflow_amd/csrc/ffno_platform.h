@@ -178,6 +178,45 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// ---- what the persistent whole-forward kernel (infer_stack_kernel) needs beyond a launch ---------------------------------------
+// the XCD (accelerator complex die, 0..7 on MI355X) this wave runs on: workgroups of one XCD share its L2, which is coherent
+static constexpr bool kPersistentLaunch = true;
+// all workgroups resident at once, or the launch fails (the group barriers of the persistent kernel rely on it)
+static inline int launch_cooperative(const void* fn, dim3 grid, dim3 block, void** args, size_t smem, hipStream_t st) {
+    return (int)hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)smem, st);
+}
+__device__ __forceinline__ int xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 15u);
+}
+// Barrier among the workgroups that share `cnt` -- ALL ON ONE XCD: every thread of every member calls it; the call returns once
+// cnt >= target (each member adds 1 per call, so target = members x number of the call).  Same-XCD visibility by hand instead of
+// agent-scope fences (which write the whole L2 back: 15 us, tools/ubench/group_barrier.hip; this: 2.3 us): a wave's global stores
+// are write-through to the XCD's L2 and complete when vmcnt reaches 0; readers drop what their CU's vector L1 and the scalar
+// cache hold.  Returns false if the members did not arrive within ~0.1 s (a lost member must not hang the device): the caller
+// leaves the kernel; *err counts such exits.
+__device__ __forceinline__ bool group_sync(unsigned* cnt, unsigned target, unsigned* err, int* flag_lds) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 21)) {
+                atomicAdd(err, 1u);
+                ok = 0;
+                break;
+            }
+        }
+        asm volatile("buffer_inv sc0\n\ts_dcache_inv\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        *flag_lds = ok;
+    }
+    __syncthreads();
+    return *flag_lds != 0;
+}
 }  // namespace plat
 
 // dynamic LDS beyond the default 48 KiB window needs an explicit opt-in per kernel AND device

@@ -28,6 +28,7 @@
 #include "ffno_device.h"
 #include "ffno_lines.h"
 #include "ffno_x3_dft.h"
+#include "ffno_infer_body.h"
 #include "ffno.h"
 
 namespace ffno {
@@ -181,17 +182,27 @@ __global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restri
 // maximum (the wave reads the whole line from LDS anyway) -- both exact, both undone where the result is scaled anyway.
 // MIXOUT: phases 1 and 2 only -- each line's mixed spectrum is written out as MFMA operand fragments (X3Args::mix_out) for the
 // kernel that runs both inverse transforms and the feed-forward of an inference layer (infer.hip); nothing else is stored.
-template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false>
-__device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles) {
+// EXTLDS: the spectrum tile and the twiddle table live in caller-provided LDS (`ext_lds`: NL LSF + 2 L floats, 16-byte aligned) instead
+// of this function's own static tile + the launch's dynamic window: the persistent inference kernel (infer_stack_kernel) runs this
+// body and the second inference kernel's by turns in ONE allocation.
+template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false, bool EXTLDS = false>
+__device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles, float* ext_lds = nullptr, int tid_in = 0) {
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
     constexpr int NLW = NL / F::NW;                 // lines per wave
     constexpr bool DFTH2 = MIXH2;
     using DftFrag = typename std::conditional<DFTH2, Hf3, Bf3>::type;      // DFT-matrix fragments
     static_assert(NL == 16 || NL == 8, "16 or 8 lines per workgroup");
-    __shared__ __attribute__((aligned(16))) float XS[NL * F::LSF];
-    FFNO_DYN_SMEM(smem);
-    float* tws = reinterpret_cast<float*>(smem);
+    __shared__ __attribute__((aligned(16))) float XS_own[EXTLDS ? 4 : NL * F::LSF];
+    float* XS = XS_own;
+    float* tws;
+    if constexpr (EXTLDS) {
+        XS = ext_lds;
+        tws = ext_lds + NL * F::LSF;
+    } else {
+        FFNO_DYN_SMEM(smem);
+        tws = reinterpret_cast<float*>(smem);
+    }
 
     const float* __restrict__ in = A.in;
     const int R = A.R, L = A.L, K = A.K;
@@ -208,7 +219,10 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
     __shared__ float rfold[F::NW];
     __shared__ float lrrs[MIXOUT ? NL : 1];      // self-ranged lines: 1 / (tile scale) of every line, phase 1 -> phase 3' (not in registers)
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (EXTLDS: the thread index comes from the caller -- the persistent kernel hands it over through an opaque move per phase, so that
+    //  nothing derived from it is hoisted out of its phase loop and kept in registers across the other kernel's body)
+    const int tidx = EXTLDS ? tid_in : (int)threadIdx.x;
+    const int lane = tidx & 63, wave = tidx >> 6;
     const int j = lane & 31, half = lane >> 5;
     const int lw = NLW * wave;                     // first of this wave's lines inside the tile
     const int line0 = bidx * NL + lw;
@@ -274,7 +288,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         // built from it) while those 16 KiB are on their way
         FFNO_UNROLL
         for (int u = 0; u < 4; ++u) load_rows(0, u, lo0);
-        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+        for (int i = tidx; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
         __syncthreads();
         build_F(0);
         FFNO_UNROLL
@@ -2715,11 +2729,11 @@ extern "C" size_t ffno_infer_mix_bytes(int C, int K, int lines) {
     return (size_t)lines * (8 * 64 * sizeof(u32x4)) + (((size_t)lines * sizeof(float) + 15) & ~(size_t)15);
 }
 
-extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int C, int interleave,
-                                         void* stream) {
+// launch arguments of the first inference kernel from the two branch descriptors (validated): shared by ffno_spectral_x3_mix_pair and
+// ffno_infer_stack
+static int mix_pair_args(X3Args& a, X3Args& b, const ffno_fused_branch* ba, const ffno_fused_branch* bb, int C) {
     if (!ba || !bb) return FFNO_EINVAL;
     if (ba->out == bb->out) return FFNO_EINVAL;
-    X3Args a, b;
     int rc = x3_args(a, ba, C, 0, 1, 0);
     if (rc) return rc;
     rc = x3_args(b, bb, C, 0, 1, 0);
@@ -2741,6 +2755,14 @@ extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno
     if (self_range && (a.L > 64 || b.L > 64)) return FFNO_EUNSUPPORTED;
     a.self_range = b.self_range = self_range;
     if (self_range) a.in_amax = b.in_amax = nullptr;
+    return FFNO_OK;
+}
+
+extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno_fused_branch* bb, int C, int interleave,
+                                         void* stream) {
+    X3Args a, b;
+    const int rca = mix_pair_args(a, b, ba, bb, C);
+    if (rca) return rca;
     const size_t smem = sizeof(float) * 2 * max(a.L, b.L);
     hipStream_t st = (hipStream_t)stream;
     auto wg_map = [&](int NL, int n0, int n1) {
@@ -2757,6 +2779,160 @@ extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno
         FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
     }
     return x3_status();
+}
+
+// ---- the whole layer stack of a forward-only pass as ONE persistent launch (round 6) -----------------------------------------------
+// ffno_layer_infer issues two launches per layer; their 256 workgroups start and stop together, so the chip alternates between
+// "everyone loads", "everyone multiplies", "everyone stores", and every launch pays its ramp and waits for its slowest workgroup.
+// Here the 8 workgroups that own one image (64 x 64: four row tiles + four column tiles of the first kernel = the eight 8-row tiles
+// of the second) run K1 and K2 of ALL layers as phases of one kernel, separated by a barrier among those 8 only
+// (plat::group_sync: 2.3 us); images drift apart, so loads, products and stores of different images overlap on the chip.
+//   * The 8 members of a group must share an XCD (the barrier's visibility argument is the XCD's coherent L2, and the image then
+//     never leaves that L2 between phases).  No placement rule is assumed: a workgroup asks the hardware which XCD it runs on
+//     (plat::xcc_id) and draws a ticket from that XCD's counter; ticket / 8 = its image among the XCD's B / 8, ticket % 8 = its role.
+//     One workgroup per CU (LDS) and B x 8 = the CU count make every XCD receive exactly its share; anything else (a ticket beyond
+//     the share, a barrier that times out) raises the error word and the caller falls back to the two-launch layers.
+//   * LDS: one dynamic window holds the first kernel's spectrum tile + twiddles and, by turns, the second kernel's column image /
+//     weight fragments (spectral_x3_body<.., EXTLDS> / infer_ff_body).
+//   * phases [lo, hi): phase 2 l = K1 of layer l, 2 l + 1 = K2 of layer l.  The emulator build (workgroups run one after the other) and
+//     mode 1 launch one phase at a time -- the same kernel, the end of a launch as the barrier.
+struct InferStackLayer {
+    const u32x4* wpk_a;
+    const u32x4* wpk_b;
+    const u32x4* pk1;
+    const float* b1;
+    const u32x4* pk2;
+    const float* b2;
+};
+constexpr int kStackMaxLayers = 32;
+struct InferStackArgs {
+    X3Args a, b;           // first kernel, branch a / b (wpk per layer)
+    InferArgs f;           // second kernel (packs, biases, resid / out per layer)
+    float* x;              // the activations, updated in place layer by layer
+    float* last_out;       // the LAST layer's feed-forward output (no residual)
+    unsigned* sync;        // [0, 8): tickets per XCD; [8, 8 + B): group counters; [8 + B]: error count
+    int L, T1, phase_lo, phase_hi, use_xcc;
+    InferStackLayer layer[kStackMaxLayers];
+};
+
+template <int RING>
+__global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel(const InferStackArgs S) {
+    FFNO_DYN_SMEM(smem);
+    __shared__ int who[3];
+    const int B = S.f.B;
+    unsigned* err = S.sync + 8 + B;
+    if (threadIdx.x == 0) {
+        int xcc, ticket;
+        if (S.use_xcc) {
+            xcc = plat::xcc_id() & 7;
+            ticket = (int)atomicAdd(S.sync + xcc, 1u);
+        } else {
+            xcc = (int)(blockIdx.x & 7u), ticket = (int)(blockIdx.x >> 3);
+        }
+        const int per_xcd = B >> 3;
+        if (ticket >= 8 * per_xcd) {      // this XCD received more workgroups than its share: no group for this one
+            atomicAdd(err, 1u);
+            who[0] = -1, who[1] = 0;
+        } else {
+            who[0] = xcc * per_xcd + ticket / 8, who[1] = ticket % 8;
+        }
+    }
+    __syncthreads();
+    const int image = who[0], member = who[1];
+    if (image < 0) return;
+    unsigned* cnt = S.sync + 8 + image;
+    unsigned arrivals = 0;
+    for (int ph = S.phase_lo; ph < S.phase_hi; ++ph) {
+        const int l = ph >> 1;
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));      // (opaque: per-lane values of one phase are not kept alive across the other's body)
+        if ((ph & 1) == 0) {
+            const bool second = member >= S.T1;
+            X3Args s = x3_pick_args(S.a, S.b, second);
+            s.mix_out = second ? S.b.mix_out : S.a.mix_out;
+            s.mix_scale = second ? S.b.mix_scale : S.a.mix_scale;
+            s.self_range = S.a.self_range;
+            s.dft = nullptr;
+            s.in = S.x;
+            s.wpk = second ? S.layer[l].wpk_b : S.layer[l].wpk_a;
+            spectral_x3_body<16, true, StF32, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
+                                                           reinterpret_cast<float*>(smem), tid);
+        } else {
+            InferArgs f = S.f;
+            const bool last = l == S.L - 1;
+            f.pk1 = S.layer[l].pk1, f.bias1 = S.layer[l].b1, f.pk2 = S.layer[l].pk2, f.bias2 = S.layer[l].b2;
+            f.resid = last ? nullptr : S.x;
+            f.out = last ? S.last_out : S.x;
+            infer_ff_body<RING, true>(f, image, member, smem, tid);
+        }
+        if (ph + 1 < S.phase_hi) {
+            arrivals += 8;
+            if (!plat::group_sync(cnt, arrivals, err, &who[2])) return;
+        }
+    }
+}
+
+// shapes the persistent form takes: what ffno_layer_infer takes, 64 x 64 images (16-line tiles of both axes and 8-row tiles: 8
+// workgroups per image in either kernel), B x 8 = the CU count (one workgroup per CU, every XCD its share), self-ranged lines
+// returns 2: the persistent launch (B x 8 == the CU count); 1: mode 1 only (one launch per phase); 0: not this shape
+extern "C" int ffno_infer_stack_supported(int B, int M, int N, int C, int H, int K_rows, int K_cols, int n_layers) {
+    if (!ffno_layer_infer_supported(B, M, N, C, H, K_rows, K_cols)) return 0;
+    if (M != 64 || N != 64 || B % 8 != 0 || n_layers < 1 || n_layers > kStackMaxLayers) return 0;
+    return B * 8 == device_cu_count() ? 2 : 1;
+}
+extern "C" size_t ffno_infer_stack_sync_words(int B) { return B > 0 ? (size_t)(8 + B + 1) : 0; }
+
+extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
+    if (!d || !d->layers || !d->last_out || !d->sync || d->a.in != d->b.in || !d->a.in) return FFNO_EINVAL;
+    if (!(d->a.flags & FFNO_BRANCH_SELF_RANGE)) return FFNO_EINVAL;      // (no range words travel between the phases)
+    const ffno_fused_branch* row = d->a.axis == 0 ? &d->a : &d->b;
+    const ffno_fused_branch* col = d->a.axis == 0 ? &d->b : &d->a;
+    const int sup = ffno_infer_stack_supported(d->a.B, d->a.M, d->a.N, d->C, d->H, row->K, col->K, d->n_layers);
+    if (!sup || (d->mode != 0 && d->mode != 1)) return FFNO_EUNSUPPORTED;
+    if (d->mode == 0 && plat::kPersistentLaunch && sup != 2) return FFNO_EUNSUPPORTED;
+    // the descriptors' `planes` are per layer: validate with the first layer's
+    ffno_fused_branch ba = d->a, bb = d->b;
+    ba.planes = reinterpret_cast<const float*>(d->layers[0].planes_a), bb.planes = reinterpret_cast<const float*>(d->layers[0].planes_b);
+    InferStackArgs S;
+    int rc = mix_pair_args(S.a, S.b, &ba, &bb, d->C);
+    if (rc) return rc;
+    rc = infer_build_args(S.f, &ba, &bb, d->layers[0].pk1, d->layers[0].b1, d->layers[0].pk2, d->layers[0].b2, nullptr, d->last_out,
+                          d->C, d->H, nullptr, true);
+    if (rc) return rc;
+    S.f.R = 8, S.f.T = 8;      // (8 members per image in either kernel, whatever infer_rows would pick for a small batch)
+    S.x = const_cast<float*>(d->a.in), S.last_out = d->last_out, S.sync = d->sync;
+    S.L = d->n_layers, S.T1 = d->a.M / 16;
+    for (int l = 0; l < d->n_layers; ++l) {
+        const ffno_infer_stack_layer& y = d->layers[l];
+        if (!y.planes_a || !y.planes_b || !y.pk1 || !y.b1 || !y.pk2 || !y.b2) return FFNO_EINVAL;
+        S.layer[l] = InferStackLayer{reinterpret_cast<const u32x4*>(y.planes_a), reinterpret_cast<const u32x4*>(y.planes_b),
+                                     reinterpret_cast<const u32x4*>(y.pk1), y.b1, reinterpret_cast<const u32x4*>(y.pk2), y.b2};
+    }
+    const int B = S.f.B, grid = B * 8;
+    const size_t lds1 = sizeof(float) * ((size_t)16 * X3Cfg::LSF + 2 * (size_t)max(S.a.L, S.b.L));
+    const size_t smem = max(lds1, infer_lds_bytes(S.f.R, S.f.N, true));
+    hipStream_t st = (hipStream_t)stream;
+    rc = allow_dynamic_lds(infer_stack_kernel<2>, smem);
+    if (rc) return rc;
+    if (hipMemsetAsync(d->sync, 0, sizeof(uint32_t) * ffno_infer_stack_sync_words(B), st) != hipSuccess) return (int)hipGetLastError();
+    if constexpr (plat::kPersistentLaunch) {
+        if (d->mode == 0) {
+            S.phase_lo = 0, S.phase_hi = 2 * S.L, S.use_xcc = 1;
+            (void)hipGetLastError();
+            void* args[] = {&S};
+            // cooperative: the runtime checks that all B x 8 workgroups are resident at once (the group barriers rely on it)
+            const int e = plat::launch_cooperative(reinterpret_cast<const void*>(infer_stack_kernel<2>), dim3(grid), dim3(512), args, smem, st);
+            return e == 0 ? x3_status() : e;
+        }
+    }
+    S.use_xcc = 0;
+    for (int ph = 0; ph < 2 * S.L; ++ph) {
+        S.phase_lo = ph, S.phase_hi = ph + 1;
+        FFNO_LAUNCH((infer_stack_kernel<2>), dim3(grid), dim3(512), smem, st, S);
+        rc = x3_status();
+        if (rc) return rc;
+    }
+    return FFNO_OK;
 }
 
 // The two branches through the three split-bf16 STAGE kernels, as three paired launches (see ffno_spectral_staged_pair).

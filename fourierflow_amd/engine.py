@@ -61,6 +61,10 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class _StackRetry(Exception):
+    """The first persistent inference launch of a workspace reported an error: forward() starts over on the per-layer launches."""
+
+
 class _Linear:
     __slots__ = ("prefix", "rows", "cols", "wnorm", "weff", "gweff", "wt", "fx")
 
@@ -253,6 +257,7 @@ class FFNOEngine:
         # enough to fill the chip; small launches (a rollout at batch 1) stay on the latency kernels of the training path
         self.use_infer_layer = os.environ.get("FFNO_INFER_LAYER", "1") != "0"
         self.infer_self_range = True      # inference layers of axis length <= 64 scale every line from its own maximum (no range words)
+        self.use_infer_stack = os.environ.get("FFNO_INFER_STACK", "1") != "0"      # ... and run as one persistent launch where they can
         self.infer_min_lines = None      # lines per axis pair from which the inference layer is used (None: more than 4 per CU)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
@@ -1012,6 +1017,77 @@ class FFNOEngine:
         need = self.infer_min_lines if self.infer_min_lines is not None else 4 * cus + 1
         return va.R + vb.R >= need
 
+    def _run_infer_stack(self, ws, pair, full, st) -> bool:
+        """Enqueue ffno_infer_stack over ws.X (in place; the last layer's feed-forward output lands in ws.Blast).  False: not this
+        shape / device, or the persistent launch reported a placement or barrier error (then it is switched off for this engine and
+        the caller runs the per-layer launches)."""
+        lib = _lib.get_lib()
+        C, H, L = self.C, self.H, self.L
+        a, b = pair
+        va, vb = ws.views[a], ws.views[b]
+        row, col = (va, vb) if va.a01 == 0 else (vb, va)
+        if int(lib.ffno_infer_stack_supported(va.Bv, va.Mv, va.Nv, C, H, row.K, col.K, L)) != 2:
+            return False
+        pend = getattr(ws, "stack_pending", None)
+        if pend is not None:      # the error word of the PREVIOUS persistent launch on this workspace (copied without synchronising)
+            host, ev = pend
+            if ev is None or ev.query():
+                ws.stack_pending = None
+                if int(host[0]) != 0:
+                    self.use_infer_stack = False
+                    raise RuntimeError("ffno_infer_stack: the previous forward pass reported a workgroup without a group or a barrier "
+                                       "time-out (error word %d): its result was invalid; the persistent launch is now off for this "
+                                       "engine (engine.use_infer_stack)" % int(host[0]))
+        if getattr(ws, "stack_sync", None) is None:
+            n = int(lib.ffno_infer_stack_sync_words(va.Bv))
+            ws.stack_sync = torch.zeros(n, dtype=torch.int32, device=self.device)
+            ws.stack_host = torch.zeros(1, dtype=torch.int32)
+            if self.device.type == "cuda":
+                ws.stack_host = ws.stack_host.pin_memory()
+            ws.stack_checked = False
+        ba = self._branch(va, ws.X, ws.MIX[0], None, None, None, 0, True, True, None, None)
+        bb = self._branch(vb, ws.X, ws.MIX[1], None, None, None, 0, True, True, None, None)
+        for br, v in ((ba, va), (bb, vb)):
+            br.planes_format, br.flags, br.in_amax = 1, _capi.BRANCH_SELF_RANGE, None
+            br.dft_frags = _p(self._dft_frags(v.L, v.K, True))
+        rows = []
+        for l in range(L):
+            si = self._fw_sets.index(self.fw_names[l]) if full else 0
+            l0, l1, b0, b1 = self._ff_weights(l)
+            rows.append(_capi.InferStackLayer(_p(self._planes_for(si, a, 0, True)), _p(self._planes_for(si, b, 0, True)), _p(l0.fx[0]),
+                                              _p(b0), _p(l0.fx[1]), _p(b1)))
+        arr = (_capi.InferStackLayer * L)(*rows)
+        d = _capi.InferStackDesc(ba, bb, ctypes.cast(arr, ctypes.c_void_p), L, C, H, 0, _p(ws.Blast), _p(ws.stack_sync))
+        t = self.timer
+        if t is not None and t.want("infer_stack"):      # (bench.py: HIP events around the one launch)
+            t.start("infer_stack", self._issue_stream)
+            rc = lib.ffno_infer_stack(ctypes.byref(d), st)
+            t.stop("infer_stack", self._issue_stream)
+        else:
+            rc = lib.ffno_infer_stack(ctypes.byref(d), st)
+        if rc != 0:      # (e.g. the cooperative launch was refused: fewer free CUs than workgroups)
+            self.use_infer_stack = False
+            return False
+        err_word = ws.stack_sync[-1:]
+        ws.stack_calls = getattr(ws, "stack_calls", 0) + 1
+        if not ws.stack_checked:
+            # first persistent launch on this workspace: look at its error word before trusting the path
+            ws.stack_checked = True
+            if int(err_word.cpu()[0]) != 0:
+                self.use_infer_stack = False
+                import warnings
+                warnings.warn("ffno_infer_stack reported a placement / barrier error on this device: using the per-layer launches",
+                              RuntimeWarning)
+                raise _StackRetry()
+        elif self.device.type == "cuda" and getattr(ws, "stack_pending", None) is None and ws.stack_calls % 16 == 0:
+            # (every 16th launch: the 4-byte copy is a launch of its own; an error after the first checked launch would be a
+            #  hardware / scheduling anomaly -- it is reported a few passes late, but it is reported)
+            ws.stack_host.copy_(err_word, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            ws.stack_pending = (ws.stack_host, ev)
+        return True
+
     def _spectral(self, name, ws, v: _View, src, dst, resid, save, planes, fwd: bool, accumulate: int, fused: bool, st,
                   x3: bool = False, rin=None, rout=None):
         """One spectral branch  dst (+)= [resid +] iDFT(mix(DFT(src)))  along view v (forward or adjoint);
@@ -1067,6 +1143,12 @@ class FFNOEngine:
 
     # ------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, save_for_backward: bool, training: Optional[bool] = None, own_output: bool = True) -> torch.Tensor:
+        try:
+            return self._forward(x, save_for_backward, training, own_output)
+        except _StackRetry:      # (the persistent inference launch is off now: the same pass on the per-layer launches)
+            return self._forward(x, save_for_backward, training, own_output)
+
+    def _forward(self, x: torch.Tensor, save_for_backward: bool, training: Optional[bool] = None, own_output: bool = True) -> torch.Tensor:
         """x [B, *spatial, input_dim] fp32 on the device -> [B, *spatial, output_dim] (a fresh tensor).
         ``training`` (default: save_for_backward) switches the dropout masks on (nn.Module.training of the reference).
         ``own_output=False`` returns a view of the workspace's output buffer instead of a copy -- valid until the next forward of
@@ -1159,7 +1241,16 @@ class FFNOEngine:
             self._in_drop_seed = _site_seed(self.drop_seed, self._drop_calls, 0xFFFF, 0, 2)
             self._k("in_dropout", lib.ffno_dropout, _p(ws.X), ws.X.numel(), self.in_dropout, self._in_drop_seed, st)
             self._fold(ws.X, rw(ws, "x", 0), st)
-        for l in range(L):
+        # the whole stack of self-ranged inference layers as ONE persistent launch (ffno_infer_stack: 64 x 64 images, batch x 8 = the CU
+        # count; the 8 workgroups of an image run both kernels of every layer as phases): no launch boundary, no chip-wide lock step
+        self.infer_stack_last = False
+        if (infer_sr and self.use_infer_stack and (self.timer is None or getattr(self.timer, "allow_stack", False))
+                and self._run_infer_stack(ws, pair, full, st)):
+            self.infer_stack_last = True
+            n_loop = 0
+        else:
+            n_loop = L
+        for l in range(n_loop):
             sv = l if save_for_backward else 0
             last = l == L - 1
             s_l = ws.S[sv]

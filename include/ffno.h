@@ -389,6 +389,43 @@ int ffno_infer_ff(const ffno_fused_branch* a, const ffno_fused_branch* b, const 
 int ffno_infer_sum(const ffno_fused_branch* a, const ffno_fused_branch* b, float* out, int C, uint32_t* out_amax, void* stream);
 int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The whole layer stack of a forward-only pass in ONE persistent launch (round 6): the loop
+ *     for layer in layers: x = x + FeedForward(SpectralConv2d.forward_fourier(x))        (grid_2d.py:159-177, without the saves)
+ * that a host otherwise issues as n_layers x ffno_layer_infer.  The 8 workgroups that own one 64 x 64 image run the two kernels
+ * of every layer as phases separated by a barrier among those 8 only (they share an XCD: its coherent L2 carries x and the mixed
+ * spectra from phase to phase), so images drift apart and loads, products and stores of different images overlap -- no launch
+ * boundary, no chip-wide lock step.  Results are bit-identical to the ffno_layer_infer loop (same code, same order).
+ *   a, b      as for ffno_layer_infer, with flags = FFNO_BRANCH_SELF_RANGE (required), in = x: the lifted features, UPDATED IN PLACE
+ *             layer by layer; `planes` are ignored (per layer below)
+ *   layers    HOST array of n_layers entries (copied into the kernel arguments): the FP16X2 packs of both axes, the ffno_ffh_pack
+ *             packs and biases of that layer
+ *   last_out  receives the LAST layer's feed-forward output (no residual: what the head reads, grid_2d.py:169-177)
+ *   sync      ffno_infer_stack_sync_words(B) device words, zeroed by the call; word [8 + B] != 0 after the launch = a workgroup found
+ *             no group or a barrier timed out (~0.1 s): the result is INVALID -- run the ffno_layer_infer loop instead
+ *   mode      0: one persistent (cooperative) launch; 1: the same kernel, one launch per phase (2 n_layers launches)
+ * ffno_infer_stack_supported: 0 = not this shape (what ffno_layer_infer takes, 64 x 64 images, B a multiple of 8, n_layers <= 32);
+ * 2 = mode 0 and mode 1 (B x 8 == the device's CU count: B = 32 on MI355X -- one workgroup per CU, every XCD its share); 1 = mode 1 only.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct ffno_infer_stack_layer {
+    const void* planes_a;
+    const void* planes_b;
+    const void* pk1;
+    const float* b1;
+    const void* pk2;
+    const float* b2;
+} ffno_infer_stack_layer;
+typedef struct ffno_infer_stack_desc {
+    ffno_fused_branch a, b;
+    const ffno_infer_stack_layer* layers;
+    int32_t n_layers, C, H, mode;
+    float* last_out;
+    uint32_t* sync;
+} ffno_infer_stack_desc;
+int ffno_infer_stack_supported(int B, int M, int N, int C, int H, int K_rows, int K_cols, int n_layers);
+size_t ffno_infer_stack_sync_words(int B);
+int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream);
+
 /* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),
  * for the shapes the fused kernel does not take (K > 16 at C = 64: 256 x 256 grids with 32 / 64 modes have only 512 lines
  * per axis at batch 2 -- one launch per axis cannot fill the chip).  spec_save must be set in both branches (scratch when

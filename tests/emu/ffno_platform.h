@@ -70,6 +70,15 @@ static inline int cu_count() { return 256; }      // (the emulator plays an MI35
 
 // rendezvous of the 64 fibres of a wave (an exchange through LDS between the lanes of one wave needs every lane's write done)
 __device__ __forceinline__ void wave_sync() { (void)__shfl(0.f, 0); }
+// the persistent whole-forward kernel: the emulator runs workgroups one after the other, so its host side launches ONE phase per
+// launch (kPersistentLaunch false) and the barrier between phases is the end of a launch -- group_sync is never reached
+static constexpr bool kPersistentLaunch = false;
+static inline int launch_cooperative(const void*, dim3, dim3, void**, size_t, hipStream_t) { return -2; }
+inline int xcc_id() { return (int)(blockIdx.x & 7u); }
+inline bool group_sync(unsigned*, unsigned, unsigned* err, int*) {
+    *err += 1;      // (reaching this is a host-side bug: more than one phase in an emulated launch)
+    return false;
+}
 }  // namespace plat
 
 template <class K>

@@ -284,3 +284,122 @@ def test_inference_layer_vs_reference_golden(tag):
     e = gu.compare_packed(g, "forecast", pred.cpu().numpy(), 1e-5)
     print(f"[inference layer vs golden {tag}] {e:.2e}")
     assert e < 1e-5
+
+
+# ---- the whole stack in one persistent launch (ffno_infer_stack) -------------------------------------------------------------------
+def _stack_setup(be, B, K, L, seed):
+    """L layers over one [B, 64, 64, 64] tensor: shared Fourier packs (markov/24 shares them), per-layer feed-forward packs."""
+    S = _setup(be, B, 64, 64, K, seed=seed)
+    rs = np.random.RandomState(seed + 1)
+    C, H = 64, 256
+    layers = []
+    for l in range(L):
+        W1 = (rs.standard_normal((H, C)) / 8).astype(np.float32)
+        W2 = (rs.standard_normal((C, H)) / 16).astype(np.float32)
+        b1, b2 = (rs.standard_normal(H) * 0.1).astype(np.float32), (rs.standard_normal(C) * 0.1).astype(np.float32)
+        packs, keep = pack_weights_h(be, W1, W2)
+        layers.append(dict(W1=W1, W2=W2, b1=b1, b2=b2, packs=packs, keep=keep, db1=be.put(b1), db2=be.put(b2)))
+    return S, layers
+
+
+@pytest.mark.parametrize("B,K,L,mode", [(8, 4, 2, 1), (32, 16, 3, 1), (32, 16, 24, 0)])
+def test_infer_stack_equals_the_layer_loop(be, B, K, L, mode):
+    """ffno_infer_stack (the 8 workgroups of an image run both kernels of every layer as phases of one kernel) == the loop of
+    ffno_layer_infer calls it replaces, BIT FOR BIT (same bodies, same order), and within 1e-5 of fp64 per layer update."""
+    from fourierflow_amd._capi import BRANCH_SELF_RANGE, InferStackDesc, InferStackLayer, LayerInferDesc
+    lib, p = be.lib, be.ptr
+    C, H = 64, 256
+    if be.kind == "emu" and B > 8:
+        pytest.skip("emulator time budget (the GPU run covers the full-size stacks and the persistent launch)")
+    sup = lib.ffno_infer_stack_supported(B, 64, 64, C, H, K, K, L)
+    if be.kind == "gpu" and mode == 0 and sup != 2:
+        pytest.skip("B x 8 != the CU count of this device")
+    assert sup >= 1
+    S, layers = _stack_setup(be, B, K, L, seed=31 + B + K + L)
+    x0 = S["x"]
+
+    def branches(dx):
+        out = []
+        for i in range(2):
+            br = S["branch"](i, S["mix"][i])
+            br.in_ = p(dx)
+            br.flags, br.in_amax = BRANCH_SELF_RANGE, None
+            out.append(br)
+        return out
+
+    # reference: the loop of two-launch layers, in place, the last layer without residual into its own buffer
+    dx = be.put(x0)
+    last_ref = be.empty(x0.shape)
+    a, b = branches(dx)
+    for l, y in enumerate(layers):
+        last = l == L - 1
+        d = LayerInferDesc(a, b, 2, 0, p(y["packs"][0]), p(y["db1"]), p(y["packs"][1]), p(y["db2"]), None if last else p(dx),
+                           p(last_ref) if last else p(dx), C, H, None)
+        assert lib.ffno_layer_infer(ctypes.byref(d), None) == 0
+    ref_last, ref_x = np.array(be.get(last_ref)).copy(), np.array(be.get(dx)).copy()
+    # the stack
+    dx2 = be.put(x0)
+    last_out = be.empty(x0.shape)
+    a2, b2 = branches(dx2)
+    arr = (InferStackLayer * L)(*[InferStackLayer(a2.planes, b2.planes, p(y["packs"][0]), p(y["db1"]), p(y["packs"][1]), p(y["db2"]))
+                                  for y in layers])
+    sync = be.zeros(int(lib.ffno_infer_stack_sync_words(B)), np.uint32)
+    sd = InferStackDesc(a2, b2, ctypes.cast(arr, ctypes.c_void_p), L, C, H, mode, p(last_out), p(sync))
+    assert lib.ffno_infer_stack(ctypes.byref(sd), None) == 0
+    words = np.array(be.get(sync))
+    assert words[8 + B] == 0, f"error word {words[8 + B]} (tickets {words[:8]})"
+    if be.kind == "gpu" and mode == 0:
+        assert list(words[:8]) == [B] * 8      # every XCD drew exactly its share of tickets
+    if B * 8 >= 256:      # the loop's second kernel runs 8-row workgroups too: the same code on the same tiles, bit for bit
+        np.testing.assert_array_equal(np.array(be.get(last_out)), ref_last)
+        np.testing.assert_array_equal(np.array(be.get(dx2)), ref_x)
+    else:                 # (a small batch: the loop picks 2-row workgroups to fill the chip -- other input scales per workgroup, fp32 rounding)
+        assert rel_l2(be.get(last_out), ref_last) < 1e-6 and rel_l2(be.get(dx2), ref_x) < 1e-6
+    # ... and the first layer against fp64 (the loop itself is covered above: test_infer_layer_vs_fp64_and_vs_the_training_layer)
+    if L == 2:
+        y0 = layers[0]
+        r1, _ = layer_fp64(x0, S["w"][0], S["w"][1], y0["W1"], y0["b1"], y0["W2"], y0["b2"], K)
+        assert rel_l2(ref_x.astype(np.float64) - x0, r1 - x0) < 1e-5
+
+
+def test_infer_stack_argument_checks(be):
+    lib = be.lib
+    assert lib.ffno_infer_stack(None, None) == -1
+    assert lib.ffno_infer_stack_supported(8, 64, 32, 64, 256, 4, 4, 2) == 0      # not 64 x 64
+    assert lib.ffno_infer_stack_supported(4, 64, 64, 64, 256, 4, 4, 2) == 0      # batch not a multiple of 8
+    assert lib.ffno_infer_stack_supported(8, 64, 64, 64, 256, 4, 4, 33) == 0     # more than 32 layers
+    assert lib.ffno_infer_stack_sync_words(32) == 41
+
+
+@pytest.mark.gpu
+def test_engine_forward_takes_the_persistent_stack_at_the_bench_geometry():
+    """markov/24 at batch 32 (64 x 64, 16 modes: the BASELINE geometry) through `forward(save_for_backward=False)`: ONE persistent
+    launch for the 24 layers (engine.infer_stack_last), bit-identical to the same pass on the per-layer launches; batch 16 (not one
+    workgroup per CU) stays on the per-layer launches."""
+    import torch
+    from fourierflow_amd import _lib
+    kw = dict(modes=16, width=64, input_dim=3, n_layers=24, share_weight=True, factor=4, ff_weight_norm=True, gain=0.1)
+    blk = _block(kw, 5, "cuda:0")
+    eng = blk.engine()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus != 256:
+        pytest.skip("not a 256-CU device")
+    x = torch.randn(32, 64, 64, 3, device="cuda:0")
+    seen = []
+    orig = eng._k
+    eng._k = lambda name, fn, *a, _o=orig: (seen.append(name), _o(name, fn, *a))[1]
+    with torch.no_grad():
+        y_stack = blk(x)["forecast"].clone()
+        assert eng.infer_last and eng.infer_self_ranged_last and eng.infer_stack_last
+        assert "layer_infer" not in seen and "spectral_mix" not in seen
+        y_again = blk(x)["forecast"].clone()       # (second call: the error word of the first is looked at without synchronising)
+        eng.use_infer_stack = False
+        seen.clear()
+        y_loop = blk(x)["forecast"].clone()
+        assert not eng.infer_stack_last and seen.count("layer_infer") == 24
+        eng.use_infer_stack = True
+        y16 = blk(x[:16].contiguous())["forecast"]
+        assert eng.infer_last and not eng.infer_stack_last
+    assert torch.equal(y_stack, y_loop) and torch.equal(y_again, y_loop)
+    assert int(eng._ws.stack_sync[-1].item()) == 0 if getattr(eng._ws, "stack_sync", None) is not None else True
+    assert torch.isfinite(y16).all()
