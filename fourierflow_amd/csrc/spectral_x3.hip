@@ -2805,13 +2805,15 @@ struct InferStackLayer {
     const float* b2;
 };
 constexpr int kStackMaxLayers = 32;
+constexpr int kStackMaxGroups = 64;      // group counters in the sync words (a 256-CU device runs 32 groups)
 struct InferStackArgs {
     X3Args a, b;           // first kernel, branch a / b (wpk per layer)
     InferArgs f;           // second kernel (packs, biases, resid / out per layer)
     float* x;              // the activations, updated in place layer by layer
     float* last_out;       // the LAST layer's feed-forward output (no residual)
-    unsigned* sync;        // [0, 8): tickets per XCD; [8, 8 + B): group counters; [8 + B]: error count
+    unsigned* sync;        // [0, 8): tickets per XCD; [8, 8 + kStackMaxGroups): group counters; [8 + kStackMaxGroups]: error count
     int L, T1, phase_lo, phase_hi, use_xcc;
+    int groups, groups_per_xcd;      // groups of 8 workgroups in this launch; image i belongs to group i % groups
     InferStackLayer layer[kStackMaxLayers];
 };
 
@@ -2820,67 +2822,75 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel
     FFNO_DYN_SMEM(smem);
     __shared__ int who[3];
     const int B = S.f.B;
-    unsigned* err = S.sync + 8 + B;
+    unsigned* err = S.sync + 8 + kStackMaxGroups;
     if (threadIdx.x == 0) {
-        int xcc, ticket;
         if (S.use_xcc) {
-            xcc = plat::xcc_id() & 7;
-            ticket = (int)atomicAdd(S.sync + xcc, 1u);
+            // the persistent launch: one workgroup per CU, so every XCD holds groups_per_xcd x 8 of them whatever the dispatch order
+            const int xcc = plat::xcc_id() & 7;
+            const int ticket = (int)atomicAdd(S.sync + xcc, 1u);
+            if (ticket >= 8 * S.groups_per_xcd) {      // this XCD received more workgroups than its share: no group for this one
+                atomicAdd(err, 1u);
+                who[0] = -1, who[1] = 0;
+            } else {
+                who[0] = (ticket / 8) * 8 + xcc, who[1] = ticket % 8;      // (groups 0..7 = the first group of every XCD: a small batch spreads over all L2s)
+            }
         } else {
-            xcc = (int)(blockIdx.x & 7u), ticket = (int)(blockIdx.x >> 3);
-        }
-        const int per_xcd = B >> 3;
-        if (ticket >= 8 * per_xcd) {      // this XCD received more workgroups than its share: no group for this one
-            atomicAdd(err, 1u);
-            who[0] = -1, who[1] = 0;
-        } else {
-            who[0] = xcc * per_xcd + ticket / 8, who[1] = ticket % 8;
+            who[0] = (int)(blockIdx.x >> 3), who[1] = (int)(blockIdx.x & 7u);
         }
     }
     __syncthreads();
-    const int image = who[0], member = who[1];
-    if (image < 0) return;
-    unsigned* cnt = S.sync + 8 + image;
+    const int group = who[0], member = who[1];
+    if (group < 0 || group >= B) return;      // (a batch below the group count: the other groups have nothing to do)
+    unsigned* cnt = S.sync + 8 + group;
     unsigned arrivals = 0;
-    for (int ph = S.phase_lo; ph < S.phase_hi; ++ph) {
-        const int l = ph >> 1;
-        int tid = (int)threadIdx.x;
-        asm volatile("" : "+v"(tid));      // (opaque: per-lane values of one phase are not kept alive across the other's body)
-        if ((ph & 1) == 0) {
-            const bool second = member >= S.T1;
-            X3Args s = x3_pick_args(S.a, S.b, second);
-            s.mix_out = second ? S.b.mix_out : S.a.mix_out;
-            s.mix_scale = second ? S.b.mix_scale : S.a.mix_scale;
-            s.self_range = S.a.self_range;
-            s.dft = nullptr;
-            s.in = S.x;
-            s.wpk = second ? S.layer[l].wpk_b : S.layer[l].wpk_a;
-            spectral_x3_body<16, true, StF32, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
-                                                           reinterpret_cast<float*>(smem), tid);
-        } else {
-            InferArgs f = S.f;
-            const bool last = l == S.L - 1;
-            f.pk1 = S.layer[l].pk1, f.bias1 = S.layer[l].b1, f.pk2 = S.layer[l].pk2, f.bias2 = S.layer[l].b2;
-            f.resid = last ? nullptr : S.x;
-            f.out = last ? S.last_out : S.x;
-            infer_ff_body<RING, true>(f, image, member, smem, tid);
-        }
-        if (ph + 1 < S.phase_hi) {
-            arrivals += 8;
-            if (!plat::group_sync(cnt, arrivals, err, &who[2])) return;
+    // a group walks its images one after the other (batch > groups), every image through all its phases: no barrier between two
+    // images (other lines of x, other lines of the mixed spectra), only the workgroup's own LDS changes hands
+    for (int image = group; image < B; image += S.groups) {
+        if (image != group) __syncthreads();
+        for (int ph = S.phase_lo; ph < S.phase_hi; ++ph) {
+            const int l = ph >> 1;
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));      // (opaque: per-lane values of one phase are not kept alive across the other's body)
+            if ((ph & 1) == 0) {
+                const bool second = member >= S.T1;
+                X3Args s = x3_pick_args(S.a, S.b, second);
+                s.mix_out = second ? S.b.mix_out : S.a.mix_out;
+                s.mix_scale = second ? S.b.mix_scale : S.a.mix_scale;
+                s.self_range = S.a.self_range;
+                s.dft = nullptr;
+                s.in = S.x;
+                s.wpk = second ? S.layer[l].wpk_b : S.layer[l].wpk_a;
+                spectral_x3_body<16, true, StF32, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
+                                                               reinterpret_cast<float*>(smem), tid);
+            } else {
+                InferArgs f = S.f;
+                const bool last = l == S.L - 1;
+                f.pk1 = S.layer[l].pk1, f.bias1 = S.layer[l].b1, f.pk2 = S.layer[l].pk2, f.bias2 = S.layer[l].b2;
+                f.resid = last ? nullptr : S.x;
+                f.out = last ? S.last_out : S.x;
+                infer_ff_body<RING, true>(f, image, member, smem, tid);
+            }
+            if (ph + 1 < S.phase_hi) {
+                arrivals += 8;
+                if (!plat::group_sync(cnt, arrivals, err, &who[2])) return;
+            }
         }
     }
 }
 
-// shapes the persistent form takes: what ffno_layer_infer takes, 64 x 64 images (16-line tiles of both axes and 8-row tiles: 8
-// workgroups per image in either kernel), B x 8 = the CU count (one workgroup per CU, every XCD its share), self-ranged lines
-// returns 2: the persistent launch (B x 8 == the CU count); 1: mode 1 only (one launch per phase); 0: not this shape
+// shapes the persistent form takes: what ffno_layer_infer takes on 64 x 64 images (16-line tiles of both axes and 8-row tiles: 8
+// workgroups per image in either kernel), self-ranged lines, any batch.  The persistent launch always fills the device (one
+// workgroup per CU: that is what gives every XCD its share), i.e. CUs / 8 groups; a smaller batch leaves groups idle, a larger one
+// makes groups walk several images.
+// returns 2: the persistent launch (a device whose CUs come in 8 equal XCDs of whole groups); 1: mode 1 only (one launch per
+// phase); 0: not this shape
 extern "C" int ffno_infer_stack_supported(int B, int M, int N, int C, int H, int K_rows, int K_cols, int n_layers) {
-    if (!ffno_layer_infer_supported(B, M, N, C, H, K_rows, K_cols)) return 0;
-    if (M != 64 || N != 64 || B % 8 != 0 || n_layers < 1 || n_layers > kStackMaxLayers) return 0;
-    return B * 8 == device_cu_count() ? 2 : 1;
+    if (B < 1 || !ffno_layer_infer_supported(B, M, N, C, H, K_rows, K_cols)) return 0;
+    if (M != 64 || N != 64 || n_layers < 1 || n_layers > kStackMaxLayers) return 0;
+    const int cus = device_cu_count();
+    return (cus > 0 && cus % 64 == 0 && cus / 8 <= kStackMaxGroups) ? 2 : 1;
 }
-extern "C" size_t ffno_infer_stack_sync_words(int B) { return B > 0 ? (size_t)(8 + B + 1) : 0; }
+extern "C" size_t ffno_infer_stack_sync_words(int B) { return B > 0 ? (size_t)(8 + kStackMaxGroups + 1) : 0; }
 
 extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     if (!d || !d->layers || !d->last_out || !d->sync || d->a.in != d->b.in || !d->a.in) return FFNO_EINVAL;
@@ -2908,7 +2918,7 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
         S.layer[l] = InferStackLayer{reinterpret_cast<const u32x4*>(y.planes_a), reinterpret_cast<const u32x4*>(y.planes_b),
                                      reinterpret_cast<const u32x4*>(y.pk1), y.b1, reinterpret_cast<const u32x4*>(y.pk2), y.b2};
     }
-    const int B = S.f.B, grid = B * 8;
+    const int B = S.f.B;
     const size_t lds1 = sizeof(float) * ((size_t)16 * X3Cfg::LSF + 2 * (size_t)max(S.a.L, S.b.L));
     const size_t smem = max(lds1, infer_lds_bytes(S.f.R, S.f.N, true));
     hipStream_t st = (hipStream_t)stream;
@@ -2917,18 +2927,20 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     if (hipMemsetAsync(d->sync, 0, sizeof(uint32_t) * ffno_infer_stack_sync_words(B), st) != hipSuccess) return (int)hipGetLastError();
     if constexpr (plat::kPersistentLaunch) {
         if (d->mode == 0) {
+            const int cus = device_cu_count();
             S.phase_lo = 0, S.phase_hi = 2 * S.L, S.use_xcc = 1;
+            S.groups = cus / 8, S.groups_per_xcd = cus / 64;
             (void)hipGetLastError();
             void* args[] = {&S};
-            // cooperative: the runtime checks that all B x 8 workgroups are resident at once (the group barriers rely on it)
-            const int e = plat::launch_cooperative(reinterpret_cast<const void*>(infer_stack_kernel<2>), dim3(grid), dim3(512), args, smem, st);
+            // cooperative: the runtime checks that all workgroups (one per CU) are resident at once (the group barriers rely on it)
+            const int e = plat::launch_cooperative(reinterpret_cast<const void*>(infer_stack_kernel<2>), dim3(cus), dim3(512), args, smem, st);
             return e == 0 ? x3_status() : e;
         }
     }
-    S.use_xcc = 0;
+    S.use_xcc = 0, S.groups = B, S.groups_per_xcd = 0;      // one group per image, workgroup w = member w % 8 of group w / 8
     for (int ph = 0; ph < 2 * S.L; ++ph) {
         S.phase_lo = ph, S.phase_hi = ph + 1;
-        FFNO_LAUNCH((infer_stack_kernel<2>), dim3(grid), dim3(512), smem, st, S);
+        FFNO_LAUNCH((infer_stack_kernel<2>), dim3(B * 8), dim3(512), smem, st, S);
         rc = x3_status();
         if (rc) return rc;
     }

@@ -258,6 +258,7 @@ class FFNOEngine:
         self.use_infer_layer = os.environ.get("FFNO_INFER_LAYER", "1") != "0"
         self.infer_self_range = True      # inference layers of axis length <= 64 scale every line from its own maximum (no range words)
         self.use_infer_stack = os.environ.get("FFNO_INFER_STACK", "1") != "0"      # ... and run as one persistent launch where they can
+        self.infer_stack_any_batch = False      # (see _stack_pays)
         self.infer_min_lines = None      # lines per axis pair from which the inference layer is used (None: more than 4 per CU)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
@@ -1017,6 +1018,17 @@ class FFNOEngine:
         need = self.infer_min_lines if self.infer_min_lines is not None else 4 * cus + 1
         return va.R + vb.R >= need
 
+    def _stack_pays(self, B: int) -> bool:
+        """The persistent launch runs CUs / 8 = 32 groups of 8 workgroups, a group per image: a batch below 32 leaves groups idle, a
+        larger one makes groups walk images in rounds of 32.  Measured against the per-layer launches (`tools/ab_stack_batch.py`,
+        `profiles/r06_stack_batch.log`): -17 ... -25 % at 9 / 12 / 19 / 24 images, -2 ... -4 % at 32 / 48 / 64 / 96, but +12 % at 16
+        (where the per-layer launches fill the chip exactly with 4-row tiles) and +5 % at 40 (a last round with a quarter of the
+        groups busy).  `engine.infer_stack_any_batch = True` takes it regardless."""
+        if self.infer_stack_any_batch:
+            return True
+        tail = B % 32
+        return tail == 0 or tail > 16 or B < 16
+
     def _run_infer_stack(self, ws, pair, full, st) -> bool:
         """Enqueue ffno_infer_stack over ws.X (in place; the last layer's feed-forward output lands in ws.Blast).  False: not this
         shape / device, or the persistent launch reported a placement or barrier error (then it is switched off for this engine and
@@ -1027,6 +1039,8 @@ class FFNOEngine:
         va, vb = ws.views[a], ws.views[b]
         row, col = (va, vb) if va.a01 == 0 else (vb, va)
         if int(lib.ffno_infer_stack_supported(va.Bv, va.Mv, va.Nv, C, H, row.K, col.K, L)) != 2:
+            return False
+        if not self._stack_pays(va.Bv):
             return False
         pend = getattr(ws, "stack_pending", None)
         if pend is not None:      # the error word of the PREVIOUS persistent launch on this workspace (copied without synchronising)

@@ -401,11 +401,13 @@ int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
  *   layers    HOST array of n_layers entries (copied into the kernel arguments): the FP16X2 packs of both axes, the ffno_ffh_pack
  *             packs and biases of that layer
  *   last_out  receives the LAST layer's feed-forward output (no residual: what the head reads, grid_2d.py:169-177)
- *   sync      ffno_infer_stack_sync_words(B) device words, zeroed by the call; word [8 + B] != 0 after the launch = a workgroup found
+ *   sync      ffno_infer_stack_sync_words(B) device words, zeroed by the call; the LAST word != 0 after the launch = a workgroup found
  *             no group or a barrier timed out (~0.1 s): the result is INVALID -- run the ffno_layer_infer loop instead
  *   mode      0: one persistent (cooperative) launch; 1: the same kernel, one launch per phase (2 n_layers launches)
- * ffno_infer_stack_supported: 0 = not this shape (what ffno_layer_infer takes, 64 x 64 images, B a multiple of 8, n_layers <= 32);
- * 2 = mode 0 and mode 1 (B x 8 == the device's CU count: B = 32 on MI355X -- one workgroup per CU, every XCD its share); 1 = mode 1 only.
+ * ffno_infer_stack_supported: 0 = not this shape (what ffno_layer_infer takes, 64 x 64 images, any batch, n_layers <= 32);
+ * 2 = mode 0 and mode 1 (a device whose CUs come as 8 XCDs of whole groups: 256 on MI355X.  The persistent launch always runs one
+ * workgroup per CU -- that is what hands every XCD its share --, i.e. CUs / 8 groups: a batch below that leaves groups idle, a
+ * larger one makes a group walk images g, g + CUs / 8, ...); 1 = mode 1 only.
  * --------------------------------------------------------------------------------------------- */
 typedef struct ffno_infer_stack_layer {
     const void* planes_a;
