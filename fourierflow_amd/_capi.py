@@ -163,6 +163,7 @@ SIGNATURES = {
     "ffno_layer_infer": (I, [P, P]),
     "ffno_infer_stack_supported": (I, [I, I, I, I, I, I, I, I]),
     "ffno_infer_stack_sync_words": (SZ, [I]),
+    "ffno_infer_stack_trace_words": (SZ, [I]),
     "ffno_infer_stack": (I, [P, P]),
     "ffno_spectral_staged_pair": (I, [P, P, P, P, I, I, I, I, P]),
     "ffno_spectral_fused_supported": (I, [I, I, I]),

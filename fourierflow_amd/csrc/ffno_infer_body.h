@@ -8,6 +8,11 @@
 
 namespace ffno {
 
+// lines of the column branch a wave keeps in flight (phase A of infer_ff_body)
+#ifndef FFNO_INFER_COL_DEPTH
+#define FFNO_INFER_COL_DEPTH 3
+#endif
+
 // magnitude bound the split-fp16 feed-forward brings its input tile to (ffx.hip: kFfRangeTarget)
 constexpr int kInferRangeTarget = 4;
 
@@ -64,7 +69,8 @@ __device__ __forceinline__ int swz_key(int mrel, int n) { return (n + mrel) & 15
 // phases A and A', then the tiles leave through the staging rows (ffno_infer_sum; the level-1 entry point ffno_spectral2d_fwd)
 // (image, t): the image and the row tile of this workgroup; smem: its LDS window (ffno_infer_lds_bytes), 16-byte aligned
 template <int RING = 2, bool FF = true>
-__device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image, const int t, char* smem, const int tid) {
+__device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image, const int t, char* smem, const int tid,
+                                              unsigned long long* tr = nullptr) {      // tr: diagnostic stamps (infer_stack_kernel<.., TRACE>)
     constexpr int C = 64, H = 256, NCH = H / 32, KS = C / 16, CTO = C / 32, NWV = 8;
     constexpr int NF1 = NCH * KS, NF2 = NCH * CTO * 2;
     constexpr int SROW = 20;
@@ -111,26 +117,60 @@ __device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image
             FFNO_UNROLL
             for (int t4 = 0; t4 < 4; ++t4) y[t4].hi = pp[8 * t4], y[t4].lo = pp[8 * t4 + 64];
         };
-        Hf2 cur[4];
-        load16(l0 + min(wave, N - 1), cur);
-        FFNO_NOUNROLL
-        for (int n = wave; n < N; n += NWV) {
-            const float osc = A.sc_col[l0 + n];
-            Hf2 y[4];
-            FFNO_UNROLL
-            for (int t4 = 0; t4 < 4; ++t4) y[t4] = cur[t4];
-            if (n + NWV < N) load16(l0 + n + NWV, cur);      // the next line travels under this one's products
-            char* base = scol + (long)(mrel * N + n) * 256;
-            const int key = swz_key(mrel, n);
+        // The lines of a wave (n = wave, wave + 8, ...) come from L2, one round trip (~1 us) each, beside 12 short products: DEPTH lines
+        // (and their scale factors) are in flight at any time -- with one, every iteration waited out a whole round trip (trace of the
+        // persistent kernel, tools/trace_stack.py: 8.5 us for the 8 lines of a wave on an otherwise idle chip)
+        constexpr int DEPTH = FFNO_INFER_COL_DEPTH;
+        char* dump = scol + (long)R * N * 256 + 16 * lane;      // (infer_lds_bytes leaves 1 KiB behind the column image)
+        Hf2 buf[DEPTH][4];
+        float oscb[DEPTH];
+        FFNO_UNROLL
+        for (int d = 0; d < DEPTH; ++d) {
+            const int nn = min(wave + d * NWV, N - 1);
+            load16(l0 + nn, buf[d]);
+            oscb[d] = A.sc_col[l0 + nn];
+        }
+        // one line through stage d: products, scaled rows into LDS, then (refill) the stage's next line into the same registers
+        auto stage = [&](int d, int n, bool refill) {
+            // the products of a line past the end run on the (finite) duplicate of line N - 1 and go to a 1-KiB dump behind the image
+            // (as do the lanes without a live row): no branch; the refill is requested AFTER everything that reads the stage's
+            // registers, with a clamped line index -- no copy of a stage, nothing that waits for a load it just issued
+            const float osc = oscb[d];
+            f32x4 acc[4];
             FFNO_UNROLL
             for (int t4 = 0; t4 < 4; ++t4) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc = plat::mfma_f16_16x16x32(y[t4].hi, G.lo, acc);
-                acc = plat::mfma_f16_16x16x32(y[t4].lo, G.hi, acc);
-                acc = plat::mfma_f16_16x16x32(y[t4].hi, G.hs, acc);
-                if (live)
-                    *reinterpret_cast<float4*>(base + (((4 * t4 + g16) ^ key) << 4)) =
-                        make_float4(acc[0] * osc, acc[1] * osc, acc[2] * osc, acc[3] * osc);
+                acc[t4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[t4] = plat::mfma_f16_16x16x32(buf[d][t4].hi, G.lo, acc[t4]);
+                acc[t4] = plat::mfma_f16_16x16x32(buf[d][t4].lo, G.hi, acc[t4]);
+                acc[t4] = plat::mfma_f16_16x16x32(buf[d][t4].hi, G.hs, acc[t4]);
+            }
+            const bool on = live && n < N;
+            char* base = on ? scol + (long)(mrel * N + n) * 256 : dump;
+            const int key = on ? swz_key(mrel, n) : 0;
+            FFNO_UNROLL
+            for (int t4 = 0; t4 < 4; ++t4)
+                *reinterpret_cast<float4*>(base + (on ? (((4 * t4 + g16) ^ key) << 4) : 0)) =
+                    make_float4(acc[t4][0] * osc, acc[t4][1] * osc, acc[t4][2] * osc, acc[t4][3] * osc);
+            if (refill) {
+                const int nn = min(n + DEPTH * NWV, N - 1);      // the line DEPTH rounds ahead travels under the next rounds' products
+                load16(l0 + nn, buf[d]);
+                oscb[d] = A.sc_col[l0 + nn];
+            }
+            // (a full fence per stage: left alone the scheduler starts the products of ALL stages together, i.e. waits for every load in
+            //  flight there -- one stage in flight instead of DEPTH)
+            FFNO_SCHED_FENCE();
+        };
+        constexpr int LPW = 8;      // lines per wave of the unrolled form
+        if (N <= NWV * LPW) {
+            // up to 64 columns (every shape the persistent kernel takes): straight-line code, so the wait before a stage's products
+            // counts exactly the loads issued after its own (in a loop the compiler waits for ALL loads at the loop header)
+            FFNO_UNROLL
+            for (int i = 0; i < LPW; ++i) stage(i % DEPTH, wave + i * NWV, i + DEPTH < LPW);
+        } else {
+            FFNO_NOUNROLL
+            for (int nb = wave; nb < N; nb += DEPTH * NWV) {
+                FFNO_UNROLL
+                for (int d = 0; d < DEPTH; ++d) stage(d, nb + d * NWV, true);
             }
         }
     }
@@ -147,6 +187,7 @@ __device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image
         yrow[i] = load_line(A.mix_row, (long)image * M + m0 + trow[i], lane);
     }
     __syncthreads();
+    if (tr && tid == 0) tr[3] = plat::realtime();
 
     // ---------------- phase A': the tiles of this wave = row branch (registers) + column branch (LDS) ----------------
     float s[2][32];
@@ -240,6 +281,7 @@ __device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image
         wreg[q] = idx < NF1 * 2 * 64 ? A.pk1[idx] : A.pk2[idx - NF1 * 2 * 64];
     }
     __syncthreads();
+    if (tr && tid == 0) tr[4] = plat::realtime();
     float gmax = bfold[0];
     FFNO_UNROLL
     for (int w = 1; w < NWV; ++w) gmax = fmaxf(gmax, bfold[w]);
@@ -251,6 +293,7 @@ __device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image
     for (int e = tid; e < H; e += NWV * 64) b1s[e] = A.bias1[e] * (gscale * kHf2Unscale);      // (as the epilogue adds it: b1 g / 2^11)
     for (int e = tid; e < C; e += NWV * 64) b2s[e] = A.bias2[e];
     __syncthreads();
+    if (tr && tid == 0) tr[5] = plat::realtime();
 
     // ---------------- phase B: Linear + ReLU + Linear + bias + residual of the wave's tiles ----------------
     // Single-accumulator products, software-pipelined over the hidden chunks.  Both GEMMs have an operand that is bounded by
@@ -427,7 +470,7 @@ static inline int infer_build_args(InferArgs& A, const ffno_fused_branch* ba, co
 
 // LDS window of infer_ff_body (ff: with the feed-forward; else the spectral sum alone)
 static inline size_t infer_lds_bytes(int R, int N, bool ff) {
-    const size_t lds_a = (size_t)R * N * 256;
+    const size_t lds_a = (size_t)R * N * 256 + 1024;      // the column-branch image + the dump of its dead lanes
     const size_t lds_b = (size_t)(2 * 64 * 1024) + (256 + 64) * sizeof(float) + 8 * 32 * 20 * sizeof(float);
     return (!ff || lds_a > lds_b) ? lds_a : lds_b;
 }

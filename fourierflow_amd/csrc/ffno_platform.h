@@ -185,6 +185,8 @@ static constexpr bool kPersistentLaunch = true;
 static inline int launch_cooperative(const void* fn, dim3 grid, dim3 block, void** args, size_t smem, hipStream_t st) {
     return (int)hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)smem, st);
 }
+// the device's constant-rate clock (100 MHz on MI355X: s_memrealtime), for the diagnostic trace of the persistent kernel
+__device__ __forceinline__ unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }
 __device__ __forceinline__ int xcc_id() {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));

@@ -185,8 +185,13 @@ __global__ __launch_bounds__(64) void x3k_dft_frags_kernel(const float* __restri
 // EXTLDS: the spectrum tile and the twiddle table live in caller-provided LDS (`ext_lds`: NL LSF + 2 L floats, 16-byte aligned) instead
 // of this function's own static tile + the launch's dynamic window: the persistent inference kernel (infer_stack_kernel) runs this
 // body and the second inference kernel's by turns in ONE allocation.
-template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false, bool EXTLDS = false>
-__device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles, float* ext_lds = nullptr, int tid_in = 0) {
+// DFTTAB (split-fp16 DFT): the DFT-matrix fragments of both transforms come from the precomputed table A.dft (x3k_dft_frags_kernel:
+// the same values, bit for bit) instead of being built from the twiddle table by every wave of every launch -- 32 LDS reads, the
+// index arithmetic and four three-way splits cost a wave 2.2 us per transform (tools/trace_stack.py: the persistent inference
+// kernel), and the twiddle staging with its workgroup barrier goes too.
+template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false, bool EXTLDS = false, bool DFTTAB = false>
+__device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int skew_cycles, float* ext_lds = nullptr, int tid_in = 0,
+                                                 unsigned long long* tr = nullptr) {      // tr: diagnostic stamps (infer_stack_kernel<.., TRACE>)
     using F = X3Cfg;
     constexpr int C = F::C, RS = F::RS, LSF = F::LSF;
     constexpr int NLW = NL / F::NW;                 // lines per wave
@@ -263,7 +268,13 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         // k n mod L advances incrementally: +k per sample, +8 k across the other half-wave's samples.
         DftFrag Ff[4];
         const int k8 = (km * 8) % L;
+        static_assert(!DFTTAB || DFTH2, "the table holds split-fp16 fragments");
         auto build_F = [&](int chunk) {
+            if constexpr (DFTTAB) {
+                FFNO_UNROLL
+                for (int u = 0; u < 4; ++u) Ff[u] = x3k_load_dft(A.dft, chunk * 4 + u, lane);
+                return;
+            }
             int idx = (km * (64 * chunk + 8 * half)) % L;
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
@@ -286,11 +297,16 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         const int nchunks = (L + 63) >> 6;
         // the first line is requested before anything else: the twiddle table is staged (and the DFT-matrix fragments are
         // built from it) while those 16 KiB are on their way
+        if constexpr (DFTTAB) build_F(0);      // (requested first: they are back before the line)
         FFNO_UNROLL
         for (int u = 0; u < 4; ++u) load_rows(0, u, lo0);
-        for (int i = tidx; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
-        __syncthreads();
-        build_F(0);
+        if constexpr (!DFTTAB) {
+            for (int i = tidx; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+            __syncthreads();
+        }
+        if (tr && tidx == 0) tr[3] = plat::realtime();
+        if constexpr (!DFTTAB) build_F(0);
+        if (tr && tidx == 0) tr[6] = plat::realtime();
         FFNO_UNROLL
         for (int ln = 0; ln < NLW; ++ln) {
             f32x16 acc0 = zero16(), acc1 = zero16();
@@ -315,6 +331,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                     if (lane == 0) lrrs[lw + ln] = 1.f / rs;
                 }
             }
+            if (tr && tidx == 0) tr[ln ? 9 : 7] = plat::realtime();
             FFNO_NOUNROLL
             for (int chunk = 0; chunk < nchunks; ++chunk) {
                 if (nchunks > 1 && (ln | chunk)) build_F(chunk);      // one chunk (L <= 64): the fragments serve both lines
@@ -378,6 +395,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
                         *reinterpret_cast<float2*>(A.spec_save + (((long)(row >> 1) * R + line0 + ln) * 2 + (row & 1)) * C + 2 * j) = v;
                 }
             }
+            if (tr && tidx == 0) tr[ln ? 10 : 8] = plat::realtime();
         }
     }
     // weight fragments of phase 2: a ring of RING, requested RING products (6 RING MFMAs ~ 0.6 us at RING = 8) before they are
@@ -403,6 +421,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         for (int f = 0; f < RING; ++f) ring[f] = load_w(A.wpk + (long)wave * F::MODE_FRAGS * 64 * MNP, f);
     }
     __syncthreads();
+    if (tr && tidx == 0) tr[4] = plat::realtime();
 
     // ---------------- phase 2: per-mode channel mix of all 16 lines, in place ----------------
     if (A.wpk) {
@@ -477,6 +496,7 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
         }
         __syncthreads();
     }
+    if (tr && tidx == 0) tr[5] = plat::realtime();
 
     if constexpr (MIXOUT) {
         // ---------------- phase 3': the lines' mixed spectra leave as operand fragments ----------------
@@ -530,6 +550,14 @@ __device__ __forceinline__ void spectral_x3_body(const X3Args A, int bidx, int s
             DftFrag G[2][2];
             FFNO_UNROLL
             for (int q = 0; q < 2; ++q) {
+                if constexpr (DFTTAB) {
+                    // inverse part of the table (ffno_x3_dft.h; <= 16 modes: 4 forward fragments per 64-sample chunk, then 2 per
+                    // 32-row tile); a tile past the end (odd tile count) reads the last one -- its rows are never stored
+                    FFNO_UNROLL
+                    for (int st = 0; st < 2; ++st)
+                        G[q][st] = x3k_load_dft(A.dft, ((L + 63) >> 6) * 4 + min(rt0 + q, RTtot - 1) * 2 + st, lane);
+                    continue;
+                }
                 const int n = 32 * (rt0 + q) + j;
                 FFNO_UNROLL
                 for (int st = 0; st < 2; ++st) {
@@ -1036,7 +1064,8 @@ __global__ __launch_bounds__(512) void spectral_x3_kernel(X3Args a) {
 // Two branches (the two axes of a layer) in ONE launch of n0 + n1 workgroups, one per CU at batch 32.  interleave: even
 // workgroups run branch a, odd ones branch b -- workgroup w lands on XCD w % 8, so every XCD's L2 then holds the packed
 // weights of ONE branch only; otherwise [0, n0) run a and the rest b.
-template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false>
+// DFTTAB (both branches carry a DFT-fragment table): see spectral_x3_body
+template <int NL, bool MIXH2, class ST = StF32, bool MIXOUT = false, bool DFTTAB = false>
 __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args b, int n0, int interleave, int skew) {
     const int w = blockIdx.x;
     bool second;
@@ -1075,11 +1104,11 @@ __global__ __launch_bounds__(512) void spectral_x3_pair_kernel(X3Args a, X3Args 
     s.accumulate = second ? b.accumulate : a.accumulate;
     s.in_amax = second ? b.in_amax : a.in_amax;
     s.out_amax = second ? b.out_amax : a.out_amax;
-    s.dft = nullptr;
+    s.dft = DFTTAB ? (second ? b.dft : a.dft) : nullptr;
     s.mix_out = second ? b.mix_out : a.mix_out;
     s.mix_scale = second ? b.mix_scale : a.mix_scale;
     s.self_range = a.self_range;      // (common to both branches: ffno_spectral_x3_mix_pair checks it)
-    spectral_x3_body<NL, MIXH2, ST, MIXOUT>(s, idx, (idx & 1) ? skew : 0);
+    spectral_x3_body<NL, MIXH2, ST, MIXOUT, false, DFTTAB>(s, idx, (idx & 1) ? skew : 0);
 }
 
 // ---- the three STAGE kernels on the same arithmetic (shapes outside the fused tile: 17..32 modes, e.g. 256 x 256 grids) ----
@@ -2695,25 +2724,38 @@ extern "C" int ffno_spectral_x3_pair(const ffno_fused_branch* ba, const ffno_fus
             FFNO_LAUNCH((spectral_x3s_pair_kernel<false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, n1);
         return x3_status();
     }
+    // <= 16 modes on the split-fp16 DFT with both branches' fragment tables (ffno_spectral_x3_dft_frags for the launch's direction):
+    // no wave rebuilds the DFT matrices from the twiddles (same values: results bit-identical with and without the tables)
+    const bool tab16 = h2 && a.wpk && b.wpk && a.dft && b.dft;
     if (ba->storage == FFNO_STORE_BF16) {
         if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
             const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
-            FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+            if (tab16)
+                FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StBf16, false, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+            else
+                FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         } else {
             const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = wg_map(16, n0, n1);
-            FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+            if (tab16)
+                FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StBf16, false, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+            else
+                FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StBf16>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         }
         return x3_status();
     }
     if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
         const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
-        if (h2)
+        if (tab16)
+            FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StF32, false, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+        else if (h2)
             FFNO_LAUNCH((spectral_x3_pair_kernel<8, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         else
             FFNO_LAUNCH((spectral_x3_pair_kernel<8, false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
     } else {
         const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = wg_map(16, n0, n1);
-        if (h2)
+        if (tab16)
+            FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StF32, false, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
+        else if (h2)
             FFNO_LAUNCH((spectral_x3_pair_kernel<16, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
         else
             FFNO_LAUNCH((spectral_x3_pair_kernel<16, false>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, skew);
@@ -2771,12 +2813,21 @@ extern "C" int ffno_spectral_x3_mix_pair(const ffno_fused_branch* ba, const ffno
         if ((interleave & 2) && square && ba->B % 8 == 0 && ba->M % NL == 0) return 2 | ((ba->M / NL) << 8);
         return (interleave & 1) ? 1 : 0;
     };
+    // both branches with a DFT-fragment table (ffno_spectral_x3_dft_frags; the second inference kernel needs them anyway): the forward
+    // fragments come from it instead of being rebuilt from the twiddles by every wave (same values: results bit-identical)
+    const bool tab = a.dft && b.dft;
     if (x3_small_tiles(a.R, b.R, ba->tile_lines)) {
         const int n0 = (a.R + 7) / 8, n1 = (b.R + 7) / 8, il = wg_map(8, n0, n1);
-        FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
+        if (tab)
+            FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StF32, true, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
+        else
+            FFNO_LAUNCH((spectral_x3_pair_kernel<8, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
     } else {
         const int n0 = (a.R + 15) / 16, n1 = (b.R + 15) / 16, il = wg_map(16, n0, n1);
-        FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
+        if (tab)
+            FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StF32, true, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
+        else
+            FFNO_LAUNCH((spectral_x3_pair_kernel<16, true, StF32, true>), dim3(n0 + n1), dim3(512), smem, st, a, b, n0, il, 0);
     }
     return x3_status();
 }
@@ -2817,12 +2868,16 @@ struct InferStackArgs {
     InferStackLayer layer[kStackMaxLayers];
 };
 
-template <int RING>
+// TRACE (ffno_infer_stack mode | 2, a diagnostic): the 8 members of group 0 leave the device's constant-rate clock (plat::realtime,
+// 100 MHz) behind the sync words for every phase of their first image -- [member][phase][start, body done, barrier passed, three
+// marks inside the body (after its first / second / third workgroup barrier)].
+template <int RING, bool TRACE = false>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel(const InferStackArgs S) {
     FFNO_DYN_SMEM(smem);
     __shared__ int who[3];
     const int B = S.f.B;
     unsigned* err = S.sync + 8 + kStackMaxGroups;
+    unsigned long long* trace = reinterpret_cast<unsigned long long*>(err + 1 + ((8 + kStackMaxGroups + 1) & 1));
     if (threadIdx.x == 0) {
         if (S.use_xcc) {
             // the persistent launch: one workgroup per CU, so every XCD holds groups_per_xcd x 8 of them whatever the dispatch order
@@ -2851,28 +2906,51 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel
             const int l = ph >> 1;
             int tid = (int)threadIdx.x;
             asm volatile("" : "+v"(tid));      // (opaque: per-lane values of one phase are not kept alive across the other's body)
+            unsigned long long* tr = nullptr;
+            if constexpr (TRACE) {
+                if (group == 0 && image == 0) {
+                    tr = trace + ((size_t)member * (2 * S.L) + ph) * 12;
+                    if (threadIdx.x == 0) tr[0] = plat::realtime();
+                }
+            }
             if ((ph & 1) == 0) {
                 const bool second = member >= S.T1;
                 X3Args s = x3_pick_args(S.a, S.b, second);
                 s.mix_out = second ? S.b.mix_out : S.a.mix_out;
                 s.mix_scale = second ? S.b.mix_scale : S.a.mix_scale;
                 s.self_range = S.a.self_range;
-                s.dft = nullptr;
+                s.dft = second ? S.b.dft : S.a.dft;      // (the forward fragment tables: DFTTAB)
                 s.in = S.x;
                 s.wpk = second ? S.layer[l].wpk_b : S.layer[l].wpk_a;
-                spectral_x3_body<16, true, StF32, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
-                                                               reinterpret_cast<float*>(smem), tid);
+                if constexpr (TRACE)
+                    spectral_x3_body<16, true, StF32, true, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
+                                                                         reinterpret_cast<float*>(smem), tid, tr);
+                else
+                    spectral_x3_body<16, true, StF32, true, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
+                                                                         reinterpret_cast<float*>(smem), tid);
             } else {
                 InferArgs f = S.f;
                 const bool last = l == S.L - 1;
                 f.pk1 = S.layer[l].pk1, f.bias1 = S.layer[l].b1, f.pk2 = S.layer[l].pk2, f.bias2 = S.layer[l].b2;
                 f.resid = last ? nullptr : S.x;
                 f.out = last ? S.last_out : S.x;
-                infer_ff_body<RING, true>(f, image, member, smem, tid);
+                if constexpr (TRACE)
+                    infer_ff_body<RING, true>(f, image, member, smem, tid, tr);
+                else
+                    infer_ff_body<RING, true>(f, image, member, smem, tid);
+            }
+            if constexpr (TRACE) {
+                if (tr) {
+                    __syncthreads();
+                    if (threadIdx.x == 0) tr[1] = plat::realtime();
+                }
             }
             if (ph + 1 < S.phase_hi) {
                 arrivals += 8;
                 if (!plat::group_sync(cnt, arrivals, err, &who[2])) return;
+            }
+            if constexpr (TRACE) {
+                if (tr && threadIdx.x == 0) tr[2] = plat::realtime();
             }
         }
     }
@@ -2891,6 +2969,10 @@ extern "C" int ffno_infer_stack_supported(int B, int M, int N, int C, int H, int
     return (cus > 0 && cus % 64 == 0 && cus / 8 <= kStackMaxGroups) ? 2 : 1;
 }
 extern "C" size_t ffno_infer_stack_sync_words(int B) { return B > 0 ? (size_t)(8 + kStackMaxGroups + 1) : 0; }
+// words the trace of mode | 2 needs BEHIND the sync words (one pad word, then 8 members x 2 n_layers phases x 6 stamps of 64 bits)
+extern "C" size_t ffno_infer_stack_trace_words(int n_layers) {
+    return n_layers > 0 ? (size_t)1 + (size_t)8 * 2 * n_layers * 12 * 2 : 0;
+}
 
 extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     if (!d || !d->layers || !d->last_out || !d->sync || d->a.in != d->b.in || !d->a.in) return FFNO_EINVAL;
@@ -2898,8 +2980,9 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     const ffno_fused_branch* row = d->a.axis == 0 ? &d->a : &d->b;
     const ffno_fused_branch* col = d->a.axis == 0 ? &d->b : &d->a;
     const int sup = ffno_infer_stack_supported(d->a.B, d->a.M, d->a.N, d->C, d->H, row->K, col->K, d->n_layers);
-    if (!sup || (d->mode != 0 && d->mode != 1)) return FFNO_EUNSUPPORTED;
-    if (d->mode == 0 && plat::kPersistentLaunch && sup != 2) return FFNO_EUNSUPPORTED;
+    if (!sup || (d->mode & ~3)) return FFNO_EUNSUPPORTED;
+    const bool per_phase = (d->mode & 1) != 0, trace = (d->mode & 2) != 0;
+    if (!per_phase && plat::kPersistentLaunch && sup != 2) return FFNO_EUNSUPPORTED;
     // the descriptors' `planes` are per layer: validate with the first layer's
     ffno_fused_branch ba = d->a, bb = d->b;
     ba.planes = reinterpret_cast<const float*>(d->layers[0].planes_a), bb.planes = reinterpret_cast<const float*>(d->layers[0].planes_b);
@@ -2909,6 +2992,7 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     rc = infer_build_args(S.f, &ba, &bb, d->layers[0].pk1, d->layers[0].b1, d->layers[0].pk2, d->layers[0].b2, nullptr, d->last_out,
                           d->C, d->H, nullptr, true);
     if (rc) return rc;
+    if (!S.a.dft || !S.b.dft) return FFNO_EINVAL;      // (the first kernel's phases read their DFT-matrix fragments from the tables)
     S.f.R = 8, S.f.T = 8;      // (8 members per image in either kernel, whatever infer_rows would pick for a small batch)
     S.x = const_cast<float*>(d->a.in), S.last_out = d->last_out, S.sync = d->sync;
     S.L = d->n_layers, S.T1 = d->a.M / 16;
@@ -2924,16 +3008,23 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     rc = allow_dynamic_lds(infer_stack_kernel<2>, smem);
     if (rc) return rc;
-    if (hipMemsetAsync(d->sync, 0, sizeof(uint32_t) * ffno_infer_stack_sync_words(B), st) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(d->sync, 0, sizeof(uint32_t) * (ffno_infer_stack_sync_words(B) + (trace ? ffno_infer_stack_trace_words(S.L) : 0)), st) !=
+        hipSuccess)
+        return (int)hipGetLastError();
     if constexpr (plat::kPersistentLaunch) {
-        if (d->mode == 0) {
+        if (!per_phase) {
             const int cus = device_cu_count();
             S.phase_lo = 0, S.phase_hi = 2 * S.L, S.use_xcc = 1;
             S.groups = cus / 8, S.groups_per_xcd = cus / 64;
             (void)hipGetLastError();
             void* args[] = {&S};
             // cooperative: the runtime checks that all workgroups (one per CU) are resident at once (the group barriers rely on it)
-            const int e = plat::launch_cooperative(reinterpret_cast<const void*>(infer_stack_kernel<2>), dim3(cus), dim3(512), args, smem, st);
+            if (trace) {
+                rc = allow_dynamic_lds(infer_stack_kernel<2, true>, smem);
+                if (rc) return rc;
+            }
+            const void* fn = trace ? reinterpret_cast<const void*>(infer_stack_kernel<2, true>) : reinterpret_cast<const void*>(infer_stack_kernel<2>);
+            const int e = plat::launch_cooperative(fn, dim3(cus), dim3(512), args, smem, st);
             return e == 0 ? x3_status() : e;
         }
     }

@@ -259,6 +259,9 @@ class FFNOEngine:
         self.infer_self_range = True      # inference layers of axis length <= 64 scale every line from its own maximum (no range words)
         self.use_infer_stack = os.environ.get("FFNO_INFER_STACK", "1") != "0"      # ... and run as one persistent launch where they can
         self.infer_stack_any_batch = False      # (see _stack_pays)
+        # <= 16 modes: the fused split kernels read their DFT-matrix fragments from the precomputed tables too (round 6; the many-mode
+        # and latency kernels always did) -- same values, results bit-identical; 0 = every wave rebuilds them from the twiddles
+        self.x3_dft_tables = os.environ.get("FFNO_X3_DFT_TABLES", "1") != "0"
         self.infer_min_lines = None      # lines per axis pair from which the inference layer is used (None: more than 4 per CU)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
@@ -341,7 +344,7 @@ class FFNOEngine:
     def _branch(self, v, src, dst, resid, save, planes, acc, x3=False, fwd=True, rin=None, rout=None):
         """Branch descriptor; with fp16x2 packs the x3 kernel scales its spectrum tile from the range word of ``src``."""
         fmt = int(getattr(v, "x3fmt", 1)) if (x3 and planes is not None and self._x3_h2()) else 0      # ffno.h FFNO_PLANES_*
-        dft = self._dft_frags(v.L, v.K, fwd) if fmt else None
+        dft = self._dft_frags(v.L, v.K, fwd) if (fmt and (v.K > 16 or self.x3_dft_tables)) else None
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
                                  v.a01, acc, fmt, 0, rin if fmt else None, rout, self._st(), 0, _p(dft))
 

@@ -403,7 +403,10 @@ int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
  *   last_out  receives the LAST layer's feed-forward output (no residual: what the head reads, grid_2d.py:169-177)
  *   sync      ffno_infer_stack_sync_words(B) device words, zeroed by the call; the LAST word != 0 after the launch = a workgroup found
  *             no group or a barrier timed out (~0.1 s): the result is INVALID -- run the ffno_layer_infer loop instead
- *   mode      0: one persistent (cooperative) launch; 1: the same kernel, one launch per phase (2 n_layers launches)
+ *   mode      0: one persistent (cooperative) launch; 1: the same kernel, one launch per phase (2 n_layers launches);
+ *             | 2 (with mode 0, a diagnostic): the 8 workgroups of group 0 leave the device's 100 MHz clock for every phase of their
+ *             first image -- start, body done, barrier passed, three marks inside the body -- as 64-bit stamps [member][phase][6] behind the sync words (+ one pad
+ *             word): `sync` then holds ffno_infer_stack_sync_words(B) + ffno_infer_stack_trace_words(n_layers) words
  * ffno_infer_stack_supported: 0 = not this shape (what ffno_layer_infer takes, 64 x 64 images, any batch, n_layers <= 32);
  * 2 = mode 0 and mode 1 (a device whose CUs come as 8 XCDs of whole groups: 256 on MI355X.  The persistent launch always runs one
  * workgroup per CU -- that is what hands every XCD its share --, i.e. CUs / 8 groups: a batch below that leaves groups idle, a
@@ -426,6 +429,7 @@ typedef struct ffno_infer_stack_desc {
 } ffno_infer_stack_desc;
 int ffno_infer_stack_supported(int B, int M, int N, int C, int H, int K_rows, int K_cols, int n_layers);
 size_t ffno_infer_stack_sync_words(int B);
+size_t ffno_infer_stack_trace_words(int n_layers);
 int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream);
 
 /* The same two branches through the three STAGE kernels, as three paired launches (dft_fwd x2 | mode_mix x2 | dft_inv x2),

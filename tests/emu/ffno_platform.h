@@ -75,6 +75,7 @@ __device__ __forceinline__ void wave_sync() { (void)__shfl(0.f, 0); }
 static constexpr bool kPersistentLaunch = false;
 static inline int launch_cooperative(const void*, dim3, dim3, void**, size_t, hipStream_t) { return -2; }
 inline int xcc_id() { return (int)(blockIdx.x & 7u); }
+inline unsigned long long realtime() { return 0ull; }
 inline bool group_sync(unsigned*, unsigned, unsigned* err, int*) {
     *err += 1;      // (reaching this is a host-side bug: more than one phase in an emulated launch)
     return false;
