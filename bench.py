@@ -570,6 +570,19 @@ def main():
             trainer.predict(x1)
         torch.cuda.synchronize()
         ms_fwd_b1 = 1e3 * (time.perf_counter() - t1) / 20
+    # ... and at the reference's own batch size (experiments/torus_li/markov/24_layers/config.yaml: batch_size 19 -- training,
+    # validation and test batches): 19 of the persistent launch's 32 image groups busy
+    ms_fwd_b19 = None
+    if rank == 0 and headline and B >= 19:
+        x19 = x[:19].contiguous()
+        for _ in range(3):
+            trainer.predict(x19)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            trainer.predict(x19)
+        torch.cuda.synchronize()
+        ms_fwd_b19 = 1e3 * (time.perf_counter() - t1) / 20
 
     if rank == 0:
         log(f"forward-only: {ms_fwd:.3f} ms (batch 1: {ms_fwd_b1:.3f} ms)")
@@ -940,6 +953,7 @@ def main():
                        "ff_split": trainer.engine.ff_split},
             "samples_per_s": round(opt_steps_per_s * B * world, 1), "ms_per_forward": round(ms_fwd, 3),
             "ms_per_forward_batch1": round(ms_fwd_b1, 3),
+            "ms_per_forward_batch19": round(ms_fwd_b19, 3) if ms_fwd_b19 is not None else None,
             "final_loss": round(loss_val, 5), "git_head": git_head(), "lib_source_stamp": lib_source_stamp(),
             "roofline": roofline, "roofline_forward": roofline_forward, "kernels": kernels, "power_note": power_note, "arithmetic_variants_steps_per_s": variants,
             "bf16_storage_variant": bf16_variant, "cpu_baseline": cpu,
