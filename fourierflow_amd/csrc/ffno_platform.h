@@ -181,9 +181,20 @@ __device__ __forceinline__ void wave_sync() {
 // ---- what the persistent whole-forward kernel (infer_stack_kernel) needs beyond a launch ---------------------------------------
 // the XCD (accelerator complex die, 0..7 on MI355X) this wave runs on: workgroups of one XCD share its L2, which is coherent
 static constexpr bool kPersistentLaunch = true;
-// all workgroups resident at once, or the launch fails (the group barriers of the persistent kernel rely on it)
+// The persistent kernel's group barriers need all its workgroups resident at once.  Its grid is one workgroup per CU of a kernel
+// that fits once per CU (LDS), launched behind the stream's previous kernel: an ordinary launch places them all at once.  (The first
+// form went through hipLaunchCooperativeKernel, which checks exactly that -- and makes rocprofv3 of ROCm 7.2 crash at process exit
+// after it has traced such a launch, data intact.  What the check bought is covered anyway: the occupancy query below refuses a
+// kernel that does not fit, and a workgroup that is late or lost -- a device shared with another process -- ends in the barrier
+// time-out, the error word and the caller's fallback to the per-layer launches.)
 static inline int launch_cooperative(const void* fn, dim3 grid, dim3 block, void** args, size_t smem, hipStream_t st) {
-    return (int)hipLaunchCooperativeKernel(fn, grid, block, args, (unsigned)smem, st);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)block.x, smem) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        return -2;
+    }
+    if ((int)grid.x > per_cu * cu_count()) return -2;
+    return (int)hipLaunchKernel(fn, grid, block, args, smem, st);
 }
 // the device's constant-rate clock (100 MHz on MI355X: s_memrealtime), for the diagnostic trace of the persistent kernel
 __device__ __forceinline__ unsigned long long realtime() { return __builtin_amdgcn_s_memrealtime(); }

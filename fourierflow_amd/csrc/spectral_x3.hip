@@ -3018,7 +3018,7 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
             S.groups = cus / 8, S.groups_per_xcd = cus / 64;
             (void)hipGetLastError();
             void* args[] = {&S};
-            // cooperative: the runtime checks that all workgroups (one per CU) are resident at once (the group barriers rely on it)
+            // one workgroup per CU, all resident at once (plat::launch_cooperative: the group barriers rely on it)
             if (trace) {
                 rc = allow_dynamic_lds(infer_stack_kernel<2, true>, smem);
                 if (rc) return rc;

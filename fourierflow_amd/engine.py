@@ -1082,7 +1082,7 @@ class FFNOEngine:
             t.stop("infer_stack", self._issue_stream)
         else:
             rc = lib.ffno_infer_stack(ctypes.byref(d), st)
-        if rc != 0:      # (e.g. the cooperative launch was refused: fewer free CUs than workgroups)
+        if rc != 0:      # (e.g. the persistent launch was refused: the kernel does not fit once per CU on this device)
             self.use_infer_stack = False
             return False
         err_word = ws.stack_sync[-1:]

@@ -403,7 +403,7 @@ int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
  *   last_out  receives the LAST layer's feed-forward output (no residual: what the head reads, grid_2d.py:169-177)
  *   sync      ffno_infer_stack_sync_words(B) device words, zeroed by the call; the LAST word != 0 after the launch = a workgroup found
  *             no group or a barrier timed out (~0.1 s): the result is INVALID -- run the ffno_layer_infer loop instead
- *   mode      0: one persistent (cooperative) launch; 1: the same kernel, one launch per phase (2 n_layers launches);
+ *   mode      0: one persistent launch (one workgroup per CU, all resident); 1: the same kernel, one launch per phase (2 n_layers launches);
  *             | 2 (with mode 0, a diagnostic): the 8 workgroups of group 0 leave the device's 100 MHz clock for every phase of their
  *             first image -- start, body done, barrier passed, three marks inside the body -- as 64-bit stamps [member][phase][6] behind the sync words (+ one pad
  *             word): `sync` then holds ffno_infer_stack_sync_words(B) + ffno_infer_stack_trace_words(n_layers) words
