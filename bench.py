@@ -735,6 +735,8 @@ def main():
                             achieved=round(floor / us_stack * 1e-3, 1), frac=round(floor / us_stack * 1e-3 / HBM_PEAK_GBS, 4),
                             us_per_layer=round(us_stack, 2), us_per_layer_two_launches=round(us_layer, 2),
                             persistent=dict(launch_us=round(st_[0], 1), samples=st_[1], layers=args.layers,
+                                            hbm_bytes_pmc_per_layer=(int(pmc["infer_stack"]["hbm_bytes_per_launch"] / args.layers)
+                                                                     if "infer_stack" in pmc else None),
                                             what="ffno_infer_stack: one persistent launch (one workgroup per CU) for the whole layer stack; "
                                                  "bit-identical to the per-layer launches (tests/test_infer_layer.py)"))
                         log(f"persistent inference stack: {st_[0]:.1f} us for {args.layers} layers = {us_stack:.2f} us per layer "

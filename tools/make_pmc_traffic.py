@@ -10,7 +10,8 @@ from rocpd_pmc import per_kernel
 
 # first match wins, so the instantiations of the default arithmetic (fp16x2) come before the generic patterns: bench.py also runs
 # the all-bf16x3 variant, whose kernels are in the same trace
-NAMES = [("spectral_x3_pair_kernel<16, true, ffno::StF32, true>", "spectral_mix"), ("infer_ff_kernel", "infer_ff"),
+NAMES = [("spectral_x3_pair_kernel<16, true, ffno::StF32, true", "spectral_mix"), ("infer_ff_kernel", "infer_ff"),
+         ("infer_stack_kernel", "infer_stack"),
          ("ffw_chain_kernel<64, 256, false, ffno::StF32", "ff_fwd"), ("ffw_chain_kernel<64, 256, true, ffno::StF32", "ff_bwd_data"),
          ("ffh_wgrad_m_multi_kernel<64, 256, 8, ffno::StF32", "ff_bwd_weights_partial"),
          ("ffh_wgrad_m_multi_kernel<64, 256", "ff_bwd_weights_partial"), ("ffh_wgrad_m_multi_kernel<32, 128", "ff_bwd_weights_partial"),
