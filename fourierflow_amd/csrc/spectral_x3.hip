@@ -775,10 +775,17 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
             }
         };
         const int nchunks = (L + 63) >> 6;
+        // TAB: a 16-sample k-step that lies wholly past the end of the line (the 72-sample lines of the padded 64^3 mesh: three of
+        // the second chunk's four) multiplies zeros of the DFT matrix -- its loads, splits and products are skipped (wave-uniform;
+        // exact: the products it drops are +0) -- and nothing reads the twiddle table, so it is not staged
+        auto kstep = [&](int chunk, int u) { return !TAB || 16 * (4 * chunk + u) < L; };
         FFNO_UNROLL
-        for (int u = 0; u < 4; ++u) load_rows(0, u);
-        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
-        __syncthreads();
+        for (int u = 0; u < 4; ++u)
+            if (kstep(0, u)) load_rows(0, u);
+        if constexpr (!TAB) {
+            for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+            __syncthreads();
+        }
         const int k8 = (km * 8) % L;
         f32x16 acc0 = zero16(), acc1 = zero16();
         FFNO_NOUNROLL
@@ -787,7 +794,8 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
             int idx = (km * (64 * chunk + 8 * half)) % L;
             if constexpr (TAB) {      // the chunk's fragments from the table (the table layout of <= 16 modes: one row tile)
                 FFNO_UNROLL
-                for (int u = 0; u < 4; ++u) Ff[u] = x3k_load_dft(A.dft, chunk * 4 + u, lane);
+                for (int u = 0; u < 4; ++u)
+                    if (kstep(chunk, u)) Ff[u] = x3k_load_dft(A.dft, chunk * 4 + u, lane);
             } else
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
@@ -808,13 +816,14 @@ __device__ __forceinline__ void spectral_x3c32_body(const X3Args A, int bidx) {
             }
             FFNO_UNROLL
             for (int u = 0; u < 4; ++u) {
+                if (!kstep(chunk, u)) continue;      // (then the same k-step of every later chunk is past the end too)
                 if constexpr (DFTH2) {
                     float2 w[8];
                     FFNO_UNROLL
                     for (int e = 0; e < 8; ++e) w[e] = make_float2(raw[u][e].x * sx, raw[u][e].y * sx);
                     const Hf2 b0 = split2_8(w[0].x, w[1].x, w[2].x, w[3].x, w[4].x, w[5].x, w[6].x, w[7].x);
                     const Hf2 b1 = split2_8(w[0].y, w[1].y, w[2].y, w[3].y, w[4].y, w[5].y, w[6].y, w[7].y);
-                    if (chunk + 1 < nchunks) load_rows(chunk + 1, u);
+                    if (chunk + 1 < nchunks && kstep(chunk + 1, u)) load_rows(chunk + 1, u);
                     acc0 = mfma_h2s(Ff[u], b0, acc0);
                     acc1 = mfma_h2s(Ff[u], b1, acc1);
                 } else {
