@@ -1443,8 +1443,10 @@ __device__ __forceinline__ void spectral_x3k_body(const X3Args A, int bidx) {
     const unsigned lo = (unsigned)((lm.base(min(line, R - 1)) + 2 * j) * ST::BYTES);
     const int nchunks = (L + 63) >> 6;
 
-    for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
-    __syncthreads();
+    if constexpr (!TAB) {      // (the table kernels never read the twiddles: no staging pass, no barrier in front of the first line load)
+        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+        __syncthreads();
+    }
 
     // ---------------- phase 1 ----------------
     if constexpr (TAB) {
@@ -2137,8 +2139,10 @@ __device__ __forceinline__ void spectral_x3s_body(const X3Args A, int bidx_) {
         const int nchunks = (L + 63) >> 6;
         FFNO_UNROLL
         for (int u = 0; u < 4; ++u) load_rows(0, u);
-        for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
-        __syncthreads();
+        if constexpr (!TAB) {      // (the table kernels never read the twiddles)
+            for (int i = threadIdx.x; i < 2 * L; i += blockDim.x) tws[i] = A.tw[i];
+            __syncthreads();
+        }
         f32x16 acc = zero16();
         FFNO_NOUNROLL
         for (int chunk = 0; chunk < nchunks; ++chunk) {
