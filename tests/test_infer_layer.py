@@ -362,6 +362,49 @@ def test_infer_stack_equals_the_layer_loop(be, B, K, L, mode):
         assert rel_l2(ref_x.astype(np.float64) - x0, r1 - x0) < 1e-5
 
 
+def test_infer_stack_phase_trace(be):
+    """mode | 2 (a diagnostic, tools/trace_stack.py): the same result as mode 0, and behind the sync words the 8 workgroups of group 0
+    leave ordered device-clock stamps for every phase of their first image (start <= marks <= body done <= barrier passed)."""
+    from fourierflow_amd._capi import BRANCH_SELF_RANGE, InferStackDesc, InferStackLayer
+    if be.kind != "gpu":
+        pytest.skip("device clock")
+    lib, p = be.lib, be.ptr
+    B, K, L, C, H = 16, 8, 3, 64, 256
+    if lib.ffno_infer_stack_supported(B, 64, 64, C, H, K, K, L) != 2:
+        pytest.skip("no persistent launch on this device")
+    S, layers = _stack_setup(be, B, K, L, seed=77)
+    outs = []
+    for mode in (0, 2):
+        dx = be.put(S["x"])
+        last = be.empty(S["x"].shape)
+        brs = []
+        for i in range(2):
+            br = S["branch"](i, S["mix"][i])
+            br.in_ = p(dx)
+            br.flags, br.in_amax = BRANCH_SELF_RANGE, None
+            brs.append(br)
+        arr = (InferStackLayer * L)(*[InferStackLayer(brs[0].planes, brs[1].planes, p(y["packs"][0]), p(y["db1"]), p(y["packs"][1]), p(y["db2"]))
+                                      for y in layers])
+        ns, nt = int(lib.ffno_infer_stack_sync_words(B)), int(lib.ffno_infer_stack_trace_words(L))
+        assert nt == 1 + 8 * 2 * L * 12 * 2
+        sync = be.zeros(ns + nt, np.uint32)
+        sd = InferStackDesc(brs[0], brs[1], ctypes.cast(arr, ctypes.c_void_p), L, C, H, mode, p(last), p(sync))
+        assert lib.ffno_infer_stack(ctypes.byref(sd), None) == 0
+        w = np.array(be.get(sync))
+        assert w[ns - 1] == 0
+        outs.append((np.array(be.get(last)).copy(), np.array(be.get(dx)).copy(), w))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    assert not outs[0][2][ns:].any()      # (mode 0 leaves the trace words alone)
+    t = np.ascontiguousarray(outs[1][2][ns + 1:]).view(np.uint64).reshape(8, 2 * L, 12)
+    assert (t[:, :, 0] > 0).all()
+    for a, b in ((0, 3), (3, 4), (4, 5), (5, 1)):
+        assert (t[:, :, a] <= t[:, :, b]).all(), (a, b)
+    assert (t[:, :-1, 1] <= t[:, :-1, 2]).all()              # the barrier is passed after the body is done ...
+    assert (t[:, :-1, 2] <= t[:, 1:, 0] + 1).all()           # ... and the next phase starts behind it
+    assert (t[:, 2 * L - 1, 1] <= t[:, 2 * L - 1, 2]).all()      # (no barrier after the last phase: the stamp follows the body at once)
+
+
 def test_infer_stack_argument_checks(be):
     lib = be.lib
     assert lib.ffno_infer_stack(None, None) == -1
