@@ -214,9 +214,10 @@ typedef struct ffno_fused_branch {
                                 ffno_spectral_x3[_pair]: every fused split kernel with FP16X2 planes, the K <= 16 kernel also
                                 without planes; spec_save stays fp32) */
     int32_t flags;           /* FFNO_BRANCH_* bits; 0 = none (the field was padding before round 6: zero keeps every earlier behaviour) */
-    const void* dft_frags;   /* optional (FP16X2 planes; read by the many-mode kernel, 17..64 modes, by the 4-line latency
-                                kernel of the <= 16-mode shapes and by the width-32 kernel): the DFT-matrix fragments of this
-                                branch's (L, K, flags)
+    const void* dft_frags;   /* optional (FP16X2 planes; read by every fused split kernel since round 6: the many-mode kernel,
+                                17..64 modes, the 4-line latency kernel and the width-32 kernel as before, and now the 16- / 8-line
+                                kernel of the <= 16-mode shapes too -- in a paired launch when BOTH branches carry one): the
+                                DFT-matrix fragments of this branch's (L, K, direction = scale_ck_fwd / apply_ck_inv of the call)
                                 as ffno_spectral_x3_dft_frags wrote them -- the kernel then loads them instead of rebuilding them
                                 from the twiddle table for every line (bit-identical results); NULL = build on the fly */
 } ffno_fused_branch;
