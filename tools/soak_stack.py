@@ -1,4 +1,7 @@
-"""Soak test of the persistent inference stack (ffno_infer_stack through trainer.predict): 40 s of back-to-back forwards at batch 32 / 19 / 64 / 9\n(every 50th compared bit for bit with the per-layer launches, error word read), then 200 forwards beside a GEMM stream that competes for the CUs.\n    python tools/soak_stack.py"""
+"""Soak test of the persistent inference stack (ffno_infer_stack through trainer.predict): 40 s of back-to-back forwards at batch
+32 / 19 / 64 / 9 (every 50th compared bit for bit with the per-layer launches, error word read), then 200 forwards beside a GEMM
+stream that competes for the CUs.
+    python tools/soak_stack.py"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
