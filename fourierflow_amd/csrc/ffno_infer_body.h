@@ -87,7 +87,7 @@ __device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image
     const int j = lane & 31, half = lane >> 5;
     const int N = A.N, M = A.M, R = A.R;
     const int m0 = t * R;
-    const int ntiles = (R * N) >> 5;                         // <= 16: tiles 2 wave, 2 wave + 1 belong to this wave
+    const int ntiles = (R * N) >> 5;                         // <= 16: tiles wave, wave + 8 belong to this wave
 
     // ---------------- phase A: column branch of the workgroup's R rows, every n, into LDS ----------------
     // v_mfma_f32_16x16x32_f16: A = Y_n^T tile [16 channels x 32 (mode, part)], B = G^T [32 x 16 rows m] (R <= 16 of the 16 columns live: half the matrix work of a
@@ -180,7 +180,9 @@ __device__ __forceinline__ void infer_ff_body(const InferArgs A, const int image
     LineFrags yrow[2];
     FFNO_UNROLL
     for (int i = 0; i < 2; ++i) {
-        const int T_i = 2 * wave + i;
+        // (tiles w and w + 8, not 2 w and 2 w + 1: with 8 tiles -- four rows per workgroup, what a small batch gets -- every wave
+        //  then has ONE tile instead of four waves with two and four with none)
+        const int T_i = wave + NWV * i;
         tlive[i] = T_i < ntiles;
         const int pix0 = 32 * (tlive[i] ? T_i : 0);
         trow[i] = pix0 / N, tn0[i] = pix0 - trow[i] * N;

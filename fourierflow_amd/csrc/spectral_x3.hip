@@ -2884,8 +2884,12 @@ struct InferStackArgs {
 // TRACE (ffno_infer_stack mode | 2, a diagnostic): the 8 members of group 0 leave the device's constant-rate clock (plat::realtime,
 // 100 MHz) behind the sync words for every phase of their first image -- [member][phase][start, body done, barrier passed, three
 // marks inside the body (after its first / second / third workgroup barrier)].
-template <int RING, bool TRACE = false>
+// GM = members of an image's group: 8 (16-line tiles in K1, 8-row tiles in K2) or 16 (8-line / 4-row tiles: half the chain of an image
+// per layer, for batches that fit the 16 groups a 256-CU device then runs)
+template <int RING, bool TRACE = false, int GM = 8>
 __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel(const InferStackArgs S) {
+    static_assert(GM == 8 || GM == 16, "8 or 16 workgroups per image");
+    constexpr int NL1 = GM == 8 ? 16 : 8;      // lines per workgroup in the first kernel's phases
     FFNO_DYN_SMEM(smem);
     __shared__ int who[3];
     const int B = S.f.B;
@@ -2896,14 +2900,14 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel
             // the persistent launch: one workgroup per CU, so every XCD holds groups_per_xcd x 8 of them whatever the dispatch order
             const int xcc = plat::xcc_id() & 7;
             const int ticket = (int)atomicAdd(S.sync + xcc, 1u);
-            if (ticket >= 8 * S.groups_per_xcd) {      // this XCD received more workgroups than its share: no group for this one
+            if (ticket >= GM * S.groups_per_xcd) {      // this XCD received more workgroups than its share: no group for this one
                 atomicAdd(err, 1u);
                 who[0] = -1, who[1] = 0;
             } else {
-                who[0] = (ticket / 8) * 8 + xcc, who[1] = ticket % 8;      // (groups 0..7 = the first group of every XCD: a small batch spreads over all L2s)
+                who[0] = (ticket / GM) * 8 + xcc, who[1] = ticket % GM;      // (groups 0..7 = the first group of every XCD: a small batch spreads over all L2s)
             }
         } else {
-            who[0] = (int)(blockIdx.x >> 3), who[1] = (int)(blockIdx.x & 7u);
+            who[0] = (int)(blockIdx.x / GM), who[1] = (int)(blockIdx.x % GM);
         }
     }
     __syncthreads();
@@ -2921,7 +2925,7 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel
             asm volatile("" : "+v"(tid));      // (opaque: per-lane values of one phase are not kept alive across the other's body)
             unsigned long long* tr = nullptr;
             if constexpr (TRACE) {
-                if (group == 0 && image == 0) {
+                if (group == 0 && image == 0 && member < 8) {      // (the trace words hold 8 members)
                     tr = trace + ((size_t)member * (2 * S.L) + ph) * 12;
                     if (threadIdx.x == 0) tr[0] = plat::realtime();
                 }
@@ -2936,11 +2940,11 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel
                 s.in = S.x;
                 s.wpk = second ? S.layer[l].wpk_b : S.layer[l].wpk_a;
                 if constexpr (TRACE)
-                    spectral_x3_body<16, true, StF32, true, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
-                                                                         reinterpret_cast<float*>(smem), tid, tr);
+                    spectral_x3_body<NL1, true, StF32, true, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
+                                                                          reinterpret_cast<float*>(smem), tid, tr);
                 else
-                    spectral_x3_body<16, true, StF32, true, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
-                                                                         reinterpret_cast<float*>(smem), tid);
+                    spectral_x3_body<NL1, true, StF32, true, true, true>(s, image * S.T1 + (second ? member - S.T1 : member), 0,
+                                                                          reinterpret_cast<float*>(smem), tid);
             } else {
                 InferArgs f = S.f;
                 const bool last = l == S.L - 1;
@@ -2959,7 +2963,7 @@ __global__ __launch_bounds__(512) FFNO_WAVES_PER_SIMD(2) void infer_stack_kernel
                 }
             }
             if (ph + 1 < S.phase_hi) {
-                arrivals += 8;
+                arrivals += GM;
                 if (!plat::group_sync(cnt, arrivals, err, &who[2])) return;
             }
             if constexpr (TRACE) {
@@ -2993,8 +2997,12 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
     const ffno_fused_branch* row = d->a.axis == 0 ? &d->a : &d->b;
     const ffno_fused_branch* col = d->a.axis == 0 ? &d->b : &d->a;
     const int sup = ffno_infer_stack_supported(d->a.B, d->a.M, d->a.N, d->C, d->H, row->K, col->K, d->n_layers);
-    if (!sup || (d->mode & ~3)) return FFNO_EUNSUPPORTED;
+    if (!sup || (d->mode & ~7)) return FFNO_EUNSUPPORTED;
     const bool per_phase = (d->mode & 1) != 0, trace = (d->mode & 2) != 0;
+    // members per image: 16 (8-line / 4-row tiles) while the batch fits the CUs / 16 groups the device then runs -- an image's chain per
+    // layer is then about two thirds of the 8-member form's --, else 8; mode | 4 asks for 8 whatever the batch
+    const int cus_ = device_cu_count();
+    const int GM = (!(d->mode & 4) && d->a.B * 16 <= cus_ && cus_ % 128 == 0) ? 16 : 8;
     if (!per_phase && plat::kPersistentLaunch && sup != 2) return FFNO_EUNSUPPORTED;
     // the descriptors' `planes` are per layer: validate with the first layer's
     ffno_fused_branch ba = d->a, bb = d->b;
@@ -3006,9 +3014,10 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
                           d->C, d->H, nullptr, true);
     if (rc) return rc;
     if (!S.a.dft || !S.b.dft) return FFNO_EINVAL;      // (the first kernel's phases read their DFT-matrix fragments from the tables)
-    S.f.R = 8, S.f.T = 8;      // (8 members per image in either kernel, whatever infer_rows would pick for a small batch)
+    S.f.R = d->a.M / GM, S.f.T = GM;      // (GM members per image in either kernel, whatever infer_rows would pick for a small batch)
     S.x = const_cast<float*>(d->a.in), S.last_out = d->last_out, S.sync = d->sync;
-    S.L = d->n_layers, S.T1 = d->a.M / 16;
+    const int NL1 = GM == 8 ? 16 : 8;
+    S.L = d->n_layers, S.T1 = d->a.M / NL1;
     for (int l = 0; l < d->n_layers; ++l) {
         const ffno_infer_stack_layer& y = d->layers[l];
         if (!y.planes_a || !y.planes_b || !y.pk1 || !y.b1 || !y.pk2 || !y.b2) return FFNO_EINVAL;
@@ -3016,10 +3025,16 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
                                      reinterpret_cast<const u32x4*>(y.pk1), y.b1, reinterpret_cast<const u32x4*>(y.pk2), y.b2};
     }
     const int B = S.f.B;
-    const size_t lds1 = sizeof(float) * ((size_t)16 * X3Cfg::LSF + 2 * (size_t)max(S.a.L, S.b.L));
+    const size_t lds1 = sizeof(float) * ((size_t)NL1 * X3Cfg::LSF + 2 * (size_t)max(S.a.L, S.b.L));
     const size_t smem = max(lds1, infer_lds_bytes(S.f.R, S.f.N, true));
     hipStream_t st = (hipStream_t)stream;
-    rc = allow_dynamic_lds(infer_stack_kernel<2>, smem);
+    // the four instances: (trace, members)
+    const void* fn = GM == 16 ? (trace ? reinterpret_cast<const void*>(infer_stack_kernel<2, true, 16>)
+                                       : reinterpret_cast<const void*>(infer_stack_kernel<2, false, 16>))
+                              : (trace ? reinterpret_cast<const void*>(infer_stack_kernel<2, true, 8>)
+                                       : reinterpret_cast<const void*>(infer_stack_kernel<2, false, 8>));
+    rc = GM == 16 ? (trace ? allow_dynamic_lds(infer_stack_kernel<2, true, 16>, smem) : allow_dynamic_lds(infer_stack_kernel<2, false, 16>, smem))
+                  : (trace ? allow_dynamic_lds(infer_stack_kernel<2, true, 8>, smem) : allow_dynamic_lds(infer_stack_kernel<2, false, 8>, smem));
     if (rc) return rc;
     if (hipMemsetAsync(d->sync, 0, sizeof(uint32_t) * (ffno_infer_stack_sync_words(B) + (trace ? ffno_infer_stack_trace_words(S.L) : 0)), st) !=
         hipSuccess)
@@ -3028,23 +3043,21 @@ extern "C" int ffno_infer_stack(const ffno_infer_stack_desc* d, void* stream) {
         if (!per_phase) {
             const int cus = device_cu_count();
             S.phase_lo = 0, S.phase_hi = 2 * S.L, S.use_xcc = 1;
-            S.groups = cus / 8, S.groups_per_xcd = cus / 64;
+            S.groups = cus / GM, S.groups_per_xcd = cus / 8 / GM;
             (void)hipGetLastError();
             void* args[] = {&S};
             // one workgroup per CU, all resident at once (plat::launch_cooperative: the group barriers rely on it)
-            if (trace) {
-                rc = allow_dynamic_lds(infer_stack_kernel<2, true>, smem);
-                if (rc) return rc;
-            }
-            const void* fn = trace ? reinterpret_cast<const void*>(infer_stack_kernel<2, true>) : reinterpret_cast<const void*>(infer_stack_kernel<2>);
             const int e = plat::launch_cooperative(fn, dim3(cus), dim3(512), args, smem, st);
             return e == 0 ? x3_status() : e;
         }
     }
-    S.use_xcc = 0, S.groups = B, S.groups_per_xcd = 0;      // one group per image, workgroup w = member w % 8 of group w / 8
+    S.use_xcc = 0, S.groups = B, S.groups_per_xcd = 0;      // one group per image, workgroup w = member w % GM of group w / GM
     for (int ph = 0; ph < 2 * S.L; ++ph) {
         S.phase_lo = ph, S.phase_hi = ph + 1;
-        FFNO_LAUNCH((infer_stack_kernel<2>), dim3(B * 8), dim3(512), smem, st, S);
+        if (GM == 16)
+            FFNO_LAUNCH((infer_stack_kernel<2, false, 16>), dim3(B * 16), dim3(512), smem, st, S);
+        else
+            FFNO_LAUNCH((infer_stack_kernel<2, false, 8>), dim3(B * 8), dim3(512), smem, st, S);
         rc = x3_status();
         if (rc) return rc;
     }

@@ -1022,15 +1022,17 @@ class FFNOEngine:
         return va.R + vb.R >= need
 
     def _stack_pays(self, B: int) -> bool:
-        """The persistent launch runs CUs / 8 = 32 groups of 8 workgroups, a group per image: a batch below 32 leaves groups idle, a
-        larger one makes groups walk images in rounds of 32.  Measured against the per-layer launches (`tools/ab_stack_batch.py`,
-        `profiles/r06_stack_batch.log`): -17 ... -25 % at 9 / 12 / 19 / 24 images, -2 ... -4 % at 32 / 48 / 64 / 96, but +12 % at 16
-        (where the per-layer launches fill the chip exactly with 4-row tiles) and +5 % at 40 (a last round with a quarter of the
-        groups busy).  `engine.infer_stack_any_batch = True` takes it regardless."""
+        """The persistent launch runs CUs / 8 = 32 groups of 8 workgroups (16 groups of 16 for a batch <= 16), a group per image: a
+        batch below the group count leaves groups idle, a larger one makes groups walk images in rounds of 32.  Measured against the
+        per-layer launches (`tools/ab_stack_batch.py`, `profiles/r06_stack_batch.log`): -27 % at 9 / 12 images, -10 % at 16, -22 ...
+        -25 % at 19 / 24, -2 ... -6 % at 32 / 48 / 64 / 96, but +5 % at 40 (a last round with a quarter of the groups busy): a last
+        round of 1..16 images keeps the per-layer launches.  `engine.infer_stack_any_batch = True` takes it regardless."""
         if self.infer_stack_any_batch:
             return True
+        if B <= 16:      # (16 members per image: 8-line / 4-row tiles, 0.96-0.98 ms per forward at 9 / 12 / 16 images against 1.09-1.34)
+            return True
         tail = B % 32
-        return tail == 0 or tail > 16 or B < 16
+        return tail == 0 or tail > 16
 
     def _run_infer_stack(self, ws, pair, full, st) -> bool:
         """Enqueue ffno_infer_stack over ws.X (in place; the last layer's feed-forward output lands in ws.Blast).  False: not this

@@ -405,6 +405,8 @@ int ffno_layer_infer(const ffno_layer_infer_desc* d, void* stream);
  *   sync      ffno_infer_stack_sync_words(B) device words, zeroed by the call; the LAST word != 0 after the launch = a workgroup found
  *             no group or a barrier timed out (~0.1 s): the result is INVALID -- run the ffno_layer_infer loop instead
  *   mode      0: one persistent launch (one workgroup per CU, all resident); 1: the same kernel, one launch per phase (2 n_layers launches);
+ *             | 4: 8 workgroups per image whatever the batch (default: 16 -- 8-line / 4-row tiles -- while the batch fits the CUs / 16
+ *             groups the device then runs, 8 -- 16-line / 8-row tiles -- above; the results do not depend on it);
  *             | 2 (with mode 0, a diagnostic): the 8 workgroups of group 0 leave the device's 100 MHz clock for every phase of their
  *             first image -- start, body done, barrier passed, three marks inside the body -- as 64-bit stamps [member][phase][6] behind the sync words (+ one pad
  *             word): `sync` then holds ffno_infer_stack_sync_words(B) + ffno_infer_stack_trace_words(n_layers) words
