@@ -115,6 +115,17 @@ PY
       timeout 300 python tools/time_small.py > gpurun_out/time_small.log 2>&1; echo "[r6] time_small rc=$?"; tail -n 19 gpurun_out/time_small.log
       timeout 300 python tools/ab_forward.py 5 > gpurun_out/ab_forward.log 2>&1; echo "[r6] ab_forward rc=$?"; tail -n 5 gpurun_out/ab_forward.log
       [ -x tools/ubench/bin/atomic_fold ] && { timeout 300 tools/ubench/bin/atomic_fold > gpurun_out/atomic_fold.log 2>&1; echo "[r6] atomic_fold rc=$?"; } ;;
+    stack)
+      # the persistent inference stack: phase trace of one image group, stack vs per-layer launches over batch sizes, soak
+      for b in 8 32; do timeout 200 python tools/trace_stack.py $b 24 2>&1 | grep -v amdgpu.ids; done > gpurun_out/trace_stack.log 2>&1; echo "[r6] trace_stack rc=$?"; grep -v "^phase" gpurun_out/trace_stack.log | tail -n 16
+      timeout 400 python tools/ab_stack_batch.py 3 > gpurun_out/ab_stack_batch.log 2>&1; echo "[r6] ab_stack_batch rc=$?"; grep "^B" gpurun_out/ab_stack_batch.log
+      timeout 300 python tools/soak_stack.py > gpurun_out/soak_stack.log 2>&1; echo "[r6] soak rc=$?"; tail -n 2 gpurun_out/soak_stack.log ;;
+    tables)
+      # same-box A/B of the DFT-fragment tables in the <= 16-mode kernels
+      for r in 1 2; do for t in 1 0; do FFNO_X3_DFT_TABLES=$t timeout 300 python bench.py --steps 20 --warmup 5 --cpu-steps 0 --no-secondary 2> gpurun_out/ab_tab_$t.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); k = d['kernels']
+print('$t', d['value'], d['ms_per_step_median'], d['ms_per_forward'], d['ms_per_forward_batch1'], {n: k[n]['avg_us'] for n in k})"; done; done ;;
     *) echo "[r6] unknown stage $st" ;;
   esac
 done
