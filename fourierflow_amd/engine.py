@@ -262,6 +262,7 @@ class FFNOEngine:
         # <= 16 modes: the fused split kernels read their DFT-matrix fragments from the precomputed tables too (round 6; the many-mode
         # and latency kernels always did) -- same values, results bit-identical; 0 = every wave rebuilds them from the twiddles
         self.x3_dft_tables = os.environ.get("FFNO_X3_DFT_TABLES", "1") != "0"
+        self.x3_tile_lines = int(os.environ.get("FFNO_X3_TILE_LINES", "0"))      # ffno_fused_branch.tile_lines: 0 = the library's choice, 8 / 16
         self.infer_min_lines = None      # lines per axis pair from which the inference layer is used (None: more than 4 per CU)
         self._issue_stream = None   # torch stream object the next launches go to (None = current stream)
         self.timer = None   # optional KernelTimer (bench.py): HIP-event timing of individual launches
@@ -346,7 +347,7 @@ class FFNOEngine:
         fmt = int(getattr(v, "x3fmt", 1)) if (x3 and planes is not None and self._x3_h2()) else 0      # ffno.h FFNO_PLANES_*
         dft = self._dft_frags(v.L, v.K, fwd) if (fmt and (v.K > 16 or self.x3_dft_tables)) else None
         return _capi.FusedBranch(_p(src), _p(dst), resid, _p(save), _p(planes), _p(self._twiddle(v.L)), v.Bv, v.Mv, v.Nv, v.K,
-                                 v.a01, acc, fmt, 0, rin if fmt else None, rout, self._st(), 0, _p(dft))
+                                 v.a01, acc, fmt, int(self.x3_tile_lines), rin if fmt else None, rout, self._st(), 0, _p(dft))
 
     def _dft_frags(self, L: int, K: int, fwd: bool):
         """DFT-matrix fragment table of the many-mode fused kernel for (axis length, modes, direction): built once per engine and
