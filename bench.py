@@ -731,6 +731,9 @@ def main():
                     st_ = ps.in_step().get("infer_stack")
                     if getattr(trainer.engine, "infer_stack_last", False) and st_:
                         us_stack = st_[0] / args.layers
+                        if "infer_stack" in pmc:      # (achieved / frac follow the persistent launch: so does the PMC traffic, per layer)
+                            roofline_forward.update(traffic_two_launches=roofline_forward.get("traffic"),
+                                                    traffic=int(pmc["infer_stack"]["hbm_bytes_per_launch"] / args.layers))
                         roofline_forward.update(
                             achieved=round(floor / us_stack * 1e-3, 1), frac=round(floor / us_stack * 1e-3 / HBM_PEAK_GBS, 4),
                             us_per_layer=round(us_stack, 2), us_per_layer_two_launches=round(us_layer, 2),
