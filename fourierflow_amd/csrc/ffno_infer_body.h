@@ -437,7 +437,7 @@ static inline int infer_rows(int B, int M, int N) {
     int R = 1;
     while (2 * R * N <= 512 && 2 * R <= 16 && M % (2 * R) == 0) R *= 2;
     const int cus = device_cu_count();
-    while (R > 1 && (long)B * (M / R) < cus) R >>= 1;
+    while (R > 1 && (long)B * (M / R) * 2 <= cus) R >>= 1;      // halve only while the halved tiles still fit ONE round of workgroups
     return R;
 }
 

@@ -1025,12 +1025,13 @@ class FFNOEngine:
     def _stack_pays(self, B: int) -> bool:
         """The persistent launch runs CUs / 8 = 32 groups of 8 workgroups (16 groups of 16 for a batch <= 16), a group per image: a
         batch below the group count leaves groups idle, a larger one makes groups walk images in rounds of 32.  Measured against the
-        per-layer launches (`tools/ab_stack_batch.py`, `profiles/r06_stack_batch.log`): -27 % at 9 / 12 images, -10 % at 16, -22 ...
-        -25 % at 19 / 24, -2 ... -6 % at 32 / 48 / 64 / 96, but +5 % at 40 (a last round with a quarter of the groups busy): a last
-        round of 1..16 images keeps the per-layer launches.  `engine.infer_stack_any_batch = True` takes it regardless."""
+        per-layer launches (`tools/ab_stack_batch.py`, `profiles/r06_stack_batch.log`; their own row-tile rule was fixed at the end of the
+        round, which is what these figures are against): -3 ... -6 % at 9 / 12 / 16 / 24 images, -9 % at 19, -2 ... -6 % at 32 / 48 / 64 /
+        96, but +5 % at 40 (a last round with a quarter of the groups busy): a last round of 1..16 images keeps the per-layer launches.
+        `engine.infer_stack_any_batch = True` takes it regardless."""
         if self.infer_stack_any_batch:
             return True
-        if B <= 16:      # (16 members per image: 8-line / 4-row tiles, 0.96-0.98 ms per forward at 9 / 12 / 16 images against 1.09-1.34)
+        if B <= 16:      # (16 members per image: 8-line / 4-row tiles, 0.98-1.00 ms per forward at 9 / 12 / 16 images against 1.01-1.06)
             return True
         tail = B % 32
         return tail == 0 or tail > 16
